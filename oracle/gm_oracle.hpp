@@ -1,0 +1,970 @@
+// gm_oracle.hpp -- CPU restatement of SHRiMP2 gmapper's letter-space hot path.
+//
+// TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may build, link or call this.  The product path (shrimp_amd/csrc,
+// libgmapper_hip.so) never includes or links anything under oracle/.
+//
+// Parity pinning: this restatement is checked byte-for-byte against the reference binary
+// built from /root/reference by oracle/Makefile.ref (tests/golden/*.sam.gz were generated
+// by tools/make_golden.py from that binary) and against known-answer triples produced by the
+// reference's own sw_vector()/sw_full_ls() (oracle/_ref/libref_sw.so).
+//
+// It is plain scalar C++ (no SSE); every function cites the reference file:line it follows.
+// All "file:line" citations are relative to /root/reference.
+#pragma once
+#include <algorithm>
+#include <cassert>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace gmo {
+
+typedef long long llint;
+
+// ---------------------------------------------------------------------------------------------
+// 4-bit alphabet and bitfields (common/fasta.h:26-42, common/util.h:41-42, common/fasta.c:28-57)
+// ---------------------------------------------------------------------------------------------
+static inline int EXTRACT(const uint32_t* g, llint i) { return (g[i / 8] >> (4 * (i % 8))) & 0xf; }
+static inline int BPTO32BW(int x) { return (x + 7) / 8; }
+
+static inline int char_to_code_ls(unsigned char c) {  // fasta_open translate table, common/fasta.c:164-198
+  switch (c) {
+    case 'A': case 'a': return 0;  case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;  case 'T': case 't': return 3;
+    case 'U': case 'u': return 4;  case 'M': case 'm': return 5;
+    case 'R': case 'r': return 6;  case 'W': case 'w': return 7;
+    case 'S': case 's': return 8;  case 'Y': case 'y': return 9;
+    case 'K': case 'k': return 10; case 'V': case 'v': return 11;
+    case 'H': case 'h': return 12; case 'D': case 'd': return 13;
+    case 'B': case 'b': return 14; case 'N': case 'n': case '.': case 'X': case 'x': return 15;
+    default: return -1;
+  }
+}
+static const char LSTRANS[17] = "ACGTUMRWSYKVHDBN";  // base_translate, common/fasta.c:689-690
+
+static inline int complement_base(int b) {  // common/util.h:125-151 (is_rna=false)
+  static const int cmpl[16] = {3, 2, 1, 0, 0, 10, 9, 7, 8, 6, 5, 14, 13, 12, 11, 15};
+  return cmpl[b];
+}
+
+static inline std::vector<uint32_t> pack_codes(const uint8_t* codes, size_t n) {  // fasta_sequence_to_bitfield, fasta.c:609-673
+  std::vector<uint32_t> bf(BPTO32BW((int)std::min<size_t>(n, INT_MAX - 8)) > 0 ? (n + 7) / 8 : 0, 0);
+  for (size_t i = 0; i < n; i++) bf[i / 8] |= (uint32_t)(codes[i] & 0xf) << (4 * (i % 8));
+  return bf;
+}
+
+// reverse_complement_read_ls (common/util.c:540-596): rc[i] = cmpl(read[len-1-i]), unused nibbles 0.
+static inline std::vector<uint32_t> revcomp_ls(const uint32_t* read, size_t len) {
+  std::vector<uint32_t> rc((len + 7) / 8, 0);
+  for (size_t i = 0; i < len; i++) {
+    int b = complement_base(EXTRACT(read, (llint)(len - 1 - i)));
+    rc[i / 8] |= (uint32_t)b << (4 * (i % 8));
+  }
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Parameters = the reference's globals at their letter-space defaults
+// (gmapper/gmapper-defaults.h:21-68, gmapper/gmapper.h:47-127)
+// ---------------------------------------------------------------------------------------------
+struct Seed { uint64_t mask; int span; int weight; };
+
+struct Params {
+  int match_score = 10, mismatch_score = -15;
+  int a_gap_open_score = -33, a_gap_extend_score = -7;
+  int b_gap_open_score = -33, b_gap_extend_score = -3;
+  double window_len = 140.0, window_overlap = 90.0;
+  double window_gen_threshold = 55.0, sw_vect_threshold = 50.0, sw_full_threshold = 50.0;
+  int match_mode = 2, num_outputs = 10, num_tmp_outputs = 30, anchor_width = 8;
+  int region_bits = 11, region_overlap = 50;
+  uint32_t list_cutoff = 4294967295u;
+  bool hash_filter_calls = true;  // -Z turns this off
+  bool Tflag = true, Gflag = true, compute_mapping_qualities = true;
+  bool strata = false;
+  int max_alignments = 0;
+  bool sam_unaligned = false;
+  int longest_read_len = 1000;
+  double score_alpha = 0, score_beta = 0;
+  std::vector<Seed> seeds;
+  int max_seed_span = 0, min_seed_span = 64;
+};
+
+#define GMO_IS_ABSOLUTE(x) ((x) < 0)
+// common/util.h:53 -- keep the macro's expression order (base is an int expression at every call site)
+#define GMO_ABS_OR_PCT(x, base) (GMO_IS_ABSOLUTE(x) ? -(x) : (base) * ((x) / 100.0))
+
+// add_spaced_seed (gmapper/seeds.c:9-43): first char -> highest bit, last char -> bit 0
+static inline void add_spaced_seed(Params& P, const char* s) {
+  Seed sd; sd.mask = 0; sd.span = (int)strlen(s); sd.weight = 0;
+  for (int i = 0; i < sd.span; i++) { sd.mask = (sd.mask << 1) | (s[i] == '1'); sd.weight += (s[i] == '1'); }
+  P.seeds.push_back(sd);
+  P.max_seed_span = std::max(P.max_seed_span, sd.span);
+  P.min_seed_span = std::min(P.min_seed_span, sd.span);
+}
+// load_default_seeds(0) in letter space (gmapper/seeds.c:53-80; gmapper-defaults.h:212-227): 3 seeds of weight 12
+static inline void load_default_seeds(Params& P) {
+  add_spaced_seed(P, "11110111101111");
+  add_spaced_seed(P, "1111011100100001111");
+  add_spaced_seed(P, "1111000011001101111");
+}
+// score -> probability derivation, LS branch (gmapper/gmapper.c:2557-2572)
+static inline void derive_score_probs(Params& P) {
+  double pr_mismatch = .01;
+  P.score_alpha = ((double)P.match_score - (double)P.mismatch_score) / (log((1 - pr_mismatch) / (pr_mismatch / 3.0)) / log(2.0));
+  P.score_beta = (double)P.match_score - 2 * P.score_alpha - P.score_alpha * log(1 - pr_mismatch) / log(2.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Genome + index (gmapper/genome.c:1012-1182; gmapper/gmapper.h:349-368)
+// ---------------------------------------------------------------------------------------------
+struct Genome {
+  std::vector<std::string> names;
+  std::vector<uint32_t> len, offsets;            // genome_len[], contig_offsets[]
+  std::vector<std::vector<uint32_t>> fwd, rc;    // genome_contigs[], genome_contigs_rc[]
+  int num_contigs() const { return (int)len.size(); }
+  void add_contig(const std::string& name, const uint8_t* codes, size_t n) {
+    uint32_t off = offsets.empty() ? 0u : offsets.back() + len.back();
+    names.push_back(name); offsets.push_back(off); len.push_back((uint32_t)n);
+    fwd.push_back(pack_codes(codes, n));
+    rc.push_back(revcomp_ls(fwd.back().data(), n));
+  }
+};
+
+// kmer_to_mapidx_orig (gmapper/gmapper.h:349-368) for the k-mer whose most recent base is seq[end]
+template <class GetBase>
+static inline uint32_t kmer_to_mapidx(const Seed& sd, GetBase base_at, llint end) {
+  uint64_t a = sd.mask; uint32_t mapidx = 0; int i = 0;
+  do {
+    if (a & 1) { mapidx <<= 2; mapidx |= (uint32_t)(base_at(end - i) & 0x3); }
+    a >>= 1; i++;
+  } while (a != 0);
+  return mapidx;
+}
+
+struct Index {                    // genomemap / genomemap_len in CSR form (lists ascending, genome.c:1156-1163)
+  std::vector<std::vector<uint32_t>> start;   // [sn][4^W + 1]  (total entries per seed < 2^32: positions are uint32)
+  std::vector<std::vector<uint32_t>> pos;     // [sn][total]
+  uint32_t list_len(int sn, uint32_t idx) const { return (uint32_t)(start[sn][idx + 1] - start[sn][idx]); }
+  const uint32_t* list(int sn, uint32_t idx) const { return pos[sn].data() + start[sn][idx]; }
+};
+
+static inline void build_index(const Params& P, const Genome& G, Index& I) {
+  int ns = (int)P.seeds.size();
+  I.start.assign(ns, {}); I.pos.assign(ns, {});
+  for (int sn = 0; sn < ns; sn++) {
+    const Seed& sd = P.seeds[sn];
+    size_t cap = (size_t)1 << (2 * sd.weight);
+    std::vector<uint32_t>& st = I.start[sn];
+    st.assign(cap + 1, 0);
+    for (int pass = 0; pass < 2; pass++) {
+      std::vector<uint32_t> fill;
+      if (pass == 1) {
+        uint32_t acc = 0;
+        for (size_t k = 0; k <= cap; k++) { uint32_t c = st[k]; st[k] = acc; acc += c; }
+        I.pos[sn].resize(acc);
+        fill.assign(st.begin(), st.end() - 1);
+      }
+      for (int cn = 0; cn < G.num_contigs(); cn++) {
+        const uint32_t* g = G.fwd[cn].data();
+        int load = 0;  // genome.c:1139-1154: N/X resets the run; k-mers never span contigs
+        for (uint32_t p = 0; p < G.len[cn]; p++) {
+          int base = EXTRACT(g, p);
+          if (base == 15) load = 0; else if (load < P.max_seed_span) load++;
+          if (load < sd.span) continue;
+          uint32_t mi = kmer_to_mapidx(sd, [&](llint q) { return EXTRACT(g, q); }, p);
+          if (pass == 0) st[mi]++;
+          else I.pos[sn][fill[mi]++] = G.offsets[cn] + p - sd.span + 1;
+        }
+      }
+    }
+  }
+}
+
+// automatic list cutoff (gmapper/gmapper.c:2811-2837)
+static inline uint32_t auto_list_cutoff(const Params& P, const Genome& G) {
+  unsigned long long tot = 0; for (auto l : G.len) tot += l;
+  int maxw = 0; for (auto& s : P.seeds) maxw = std::max(maxw, s.weight);
+  uint32_t cutoff = 1000;
+  unsigned long long p4 = 1ull << (2 * maxw);
+  if ((uint32_t)((100ull * tot) / p4) > cutoff) cutoff = (uint32_t)((100ull * tot) / p4);
+  return cutoff;
+}
+
+// get_contig_num (gmapper/gmapper.h:373-405) == upper_bound(offsets, idx) - 1
+static inline int get_contig_num(const Genome& G, uint32_t idx) {
+  int cn = 0;
+  while (cn < G.num_contigs() - 1 && idx >= G.offsets[cn + 1]) cn++;
+  return cn;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Anchors (common/anchors.c, common/anchors.h; struct anchor gmapper-definitions.h:66-74)
+// ---------------------------------------------------------------------------------------------
+struct Anchor { llint x = 0, y = 0; int length = 0, width = 0, weight = 0, cn = 0; };
+
+static inline void anchor_join(const Anchor* a, int n, Anchor* dest) {  // anchors.c:9-52
+  llint nw_min = INT_MAX, sw_min = INT_MAX, ne_max = INT_MIN, se_max = INT_MIN;
+  dest->weight = 0; dest->cn = a[0].cn;
+  for (int i = 0; i < n; i++) {
+    llint nw = a[i].x + a[i].y, sw = a[i].x - a[i].y;
+    llint ne = sw + 2 * (a[i].width - 1), se = nw + 2 * (a[i].length - 1);
+    nw_min = std::min(nw_min, nw); sw_min = std::min(sw_min, sw);
+    ne_max = std::max(ne_max, ne); se_max = std::max(se_max, se);
+    dest->weight += a[i].weight;
+  }
+  if ((nw_min + sw_min) % 2 != 0) nw_min--;
+  dest->x = (nw_min + sw_min) / 2;
+  dest->y = nw_min - dest->x;
+  if ((ne_max - sw_min) % 2 != 0) ne_max++;
+  dest->width = (int)((ne_max - sw_min) / 2 + 1);
+  if ((se_max - nw_min) % 2 != 0) se_max++;
+  dest->length = (int)((se_max - nw_min) / 2 + 1);
+}
+static inline void anchor_widen(Anchor* a, int w) { a->x -= w / 2; a->y += w / 2; a->width += w; }  // anchors.c:55-61
+static inline void anchor_get_x_range(const Anchor* a, int x_len, int y_len, int y, int* x_min, int* x_max) {  // anchors.c:64-95
+  (void)y_len;
+  if (y < a->y) *x_min = 0;
+  else if (y <= a->y + (a->length - 1)) *x_min = (int)(a->x + (y - a->y));
+  else *x_min = (int)(a->x + a->length);
+  if (*x_min < 0) *x_min = 0;
+  if (*x_min >= x_len) *x_min = x_len - 1;
+  if (y < a->y - (a->width - 1)) *x_max = (int)(a->x + (a->width - 1) - 1);
+  else if (y <= a->y - (a->width - 1) + (a->length - 1)) *x_max = (int)(a->x + (a->width - 1) + (y - (a->y - (a->width - 1))));
+  else *x_max = x_len - 1;
+  if (*x_max < 0) *x_max = 0;
+  if (*x_max >= x_len) *x_max = x_len - 1;
+}
+static inline void anchor_uw_join(Anchor* dest, const Anchor* src) {  // anchors.c:98-119
+  if (src->x < dest->x) {
+    llint tmp = dest->x;
+    dest->x = src->x; dest->y = src->y;
+    if (src->x + src->length > tmp + dest->length) dest->length = src->length;
+    else dest->length += (int)(tmp - dest->x);
+  } else {
+    if (src->x + src->length > dest->x + dest->length) dest->length = (int)(src->x - dest->x + src->length);
+  }
+  dest->weight += src->weight;
+}
+static inline bool anchor_uw_colinear(const Anchor* a, const Anchor* b) { return a->x - a->y == b->x - b->y; }  // anchors.h:17-20
+static inline void anchor_reverse(Anchor* a, int x_len, int y_len) {  // anchors.h:30-34
+  a->x = -a->x + (x_len - 1) - (a->length - 1) - (a->width - 1);
+  a->y = -a->y + (y_len - 1) - (a->length - 1) + (a->width - 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Vector SW filter: score-only affine local SW (common/sw-vector.c:228-377,453-515).
+// The SSE2 anti-diagonal sweep with -1/-2 sentinels computes exactly this recurrence over
+// the glen x rlen matrix (see DESIGN.md "sw_vector semantics"); int16 range is guaranteed by
+// sw_vector_setup's match*qrlen < 32768 check (sw-vector.c:393-398).
+//   H(i,j) = max(0, H(i-1,j-1)+s, A(i,j), B(i,j))
+//   A(i,j) = max(A(i,j-1) - a_ext, H(i,j-1) - a_open - a_ext)       gap along the genome
+//   B(i,j) = max(B(i-1,j) - b_ext, H(i-1,j) - b_open - b_ext)       gap along the read
+// Equality is on the raw 4-bit code (N matches N).
+// ---------------------------------------------------------------------------------------------
+static inline int sw_vector(const Params& P, const uint32_t* genome, llint goff, int glen,
+                            const uint32_t* read, int rlen) {
+  const int a_go = -P.a_gap_open_score, a_ge = -P.a_gap_extend_score;
+  const int b_go = -P.b_gap_open_score, b_ge = -P.b_gap_extend_score;
+  std::vector<int> H(glen + 1, 0), B(glen + 1, -b_go);   // nogap[] = 0, b_gap[] = -b_gap_open (sw-vector.c:261-264)
+  std::vector<int8_t> db(glen);
+  for (int j = 0; j < glen; j++) db[j] = (int8_t)EXTRACT(genome, goff + j);
+  int score = 0;
+  for (int i = 0; i < rlen; i++) {
+    int q = EXTRACT(read, i);
+    int hdiag = 0;          // H(i-1, -1)
+    int hleft = 0;          // H(i, -1)
+    int a = -a_go;          // v_a_gap initial = a_gap_ext - a_gap_open_ext (sw-vector.c:312-313)
+    for (int j = 0; j < glen; j++) {
+      a = std::max(a - a_ge, hleft - a_go - a_ge);
+      int b = std::max(B[j + 1] - b_ge, H[j + 1] - b_go - b_ge);
+      int h = hdiag + (db[j] == q ? P.match_score : P.mismatch_score);
+      h = std::max(h, 0); h = std::max(h, a); h = std::max(h, b);
+      hdiag = H[j + 1];
+      H[j + 1] = h; B[j + 1] = b; hleft = h;
+      score = std::max(score, h);
+    }
+  }
+  return score;
+}
+
+// hash_genome_window (common/util.h:224-245) with common/hash.h:70-95
+static inline uint32_t hash_genome_window(const uint32_t* genome, uint32_t goff, uint32_t glen) {
+  uint32_t key = 0;
+  for (uint32_t i = 0; i < (glen + 15) / 16; i++) {
+    uint32_t buffer = 0;
+    for (uint32_t j = 0; j < 16 && i * 16 + j < glen; j++) {
+      buffer <<= 2; buffer |= (uint32_t)(EXTRACT(genome, (llint)goff + i * 16 + j) & 0x3);
+    }
+    key += (buffer >> 16);
+    uint32_t tmp = ((buffer & 0xFFFF) << 11) ^ key;
+    key = (key << 16) ^ tmp;
+    key += key >> 11;
+  }
+  key ^= key << 3; key += key >> 5; key ^= key << 4; key += key >> 17; key ^= key << 25; key += key >> 6;
+  return key;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Full SW, letter space (common/sw-full-ls.c:154-516,637-683; struct common/sw-full-common.h:13-48)
+// ---------------------------------------------------------------------------------------------
+struct SwFullResults {
+  int read_start = 0, rmapped = 0, genome_start = 0, gmapped = 0;
+  int matches = 0, mismatches = 0, insertions = 0, deletions = 0, score = 0;
+  int posterior_score = 0, pct_posterior_score = 0;
+  std::string dbalign, qralign;
+  double posterior = 0;
+  int mqv = 255; double z0 = 0, z1 = 0;
+  std::string ops;   // backtrace ops in alignment order: 'M' match/mismatch, 'I' BACK_INSERTION (gap in read), 'D' BACK_DELETION (gap in genome)
+};
+
+enum { FROM_NORTH_NORTH = 1, FROM_NORTH_NORTHWEST = 2, FROM_WEST_NORTHWEST = 3, FROM_WEST_WEST = 4,
+       FROM_NORTHWEST_NORTH = 5, FROM_NORTHWEST_NORTHWEST = 6, FROM_NORTHWEST_WEST = 7 };
+
+struct SwFullWorkspace {
+  struct Cell { int n, w, nw; int8_t bn, bw, bnw; };
+  std::vector<Cell> m;
+  std::vector<int8_t> db, qr;
+  uint64_t cells = 0;
+};
+
+static inline void sw_full_ls(const Params& P, SwFullWorkspace& W, const uint32_t* genome, llint goff, int glen,
+                              const uint32_t* read, int rlen, int threshscore, int maxscore, SwFullResults* sfr,
+                              bool revcmpl, const Anchor* anchors, int anchors_cnt, int local_alignment) {
+  (void)threshscore; (void)maxscore;
+  assert(!local_alignment && "only the default global mode (Gflag) is restated");
+  const int lena = glen, lenb = rlen;
+  const int a_go = -P.a_gap_open_score, a_ge = -P.a_gap_extend_score;
+  const int b_go = -P.b_gap_open_score, b_ge = -P.b_gap_extend_score;
+  const int match = P.match_score, mismatch = P.mismatch_score;
+  W.db.resize(lena); W.qr.resize(lenb);
+  for (int i = 0; i < lena; i++) W.db[i] = (int8_t)EXTRACT(genome, goff + i);
+  for (int i = 0; i < lenb; i++) W.qr[i] = (int8_t)EXTRACT(read, i);
+  // The reference never clears swmatrix between calls; every cell it reads is written first
+  // (band geometry is monotone), so a fresh poison fill is equivalent and catches mistakes.
+  W.m.assign((size_t)(lena + 1) * (lenb + 1), SwFullWorkspace::Cell{INT_MIN / 4, INT_MIN / 4, INT_MIN / 4, 0, 0, 0});
+  auto init_cell = [&](size_t idx, int local) {  // sw-full-ls.c:66-80
+    auto& c = W.m[idx];
+    if (local) { c.nw = 0; c.n = -b_go; c.w = -a_go; }
+    else { c.nw = -INT_MAX / 2; c.n = -INT_MAX / 2; c.w = -INT_MAX / 2; }
+    c.bnw = c.bn = c.bw = 0;
+  };
+  Anchor rectangle;
+  anchor_join(anchors, anchors_cnt, &rectangle);      // sw-full-ls.c:176-178 (anchors != NULL, anchor_width >= 0)
+  anchor_widen(&rectangle, P.anchor_width);
+  for (int j = 0; j < lena + 1; j++) init_cell(j, 1);  // sw-full-ls.c:194-196
+  int score = 0, max_i = 0, max_j = 0;
+  for (int i = 0; i < lenb; i++) {
+    int x_min, x_max;
+    anchor_get_x_range(&rectangle, lena, lenb, i, &x_min, &x_max);
+    init_cell((size_t)(i + 1) * (lena + 1) + (x_min - 1) + 1, 0);   // :229-231 (global)
+    W.cells += x_max - x_min + 1;
+    for (int j = x_min; j <= x_max; j++) {
+      auto* cnw = &W.m[(size_t)i * (lena + 1) + j];
+      auto* cn = cnw + 1; auto* cw = cnw + (lena + 1); auto* cur = cw + 1;
+      int ms = (W.db[j] == W.qr[i]) ? match : mismatch;
+      int tmp; int8_t tmp2;
+      if (!revcmpl) {                                        // :264-278
+        tmp = cnw->nw + ms; tmp2 = FROM_NORTHWEST_NORTHWEST;
+        if (cnw->n + ms > tmp) { tmp = cnw->n + ms; tmp2 = FROM_NORTHWEST_NORTH; }
+        if (cnw->w + ms > tmp) { tmp = cnw->w + ms; tmp2 = FROM_NORTHWEST_WEST; }
+      } else {                                               // :279-292
+        tmp = cnw->w + ms; tmp2 = FROM_NORTHWEST_WEST;
+        if (cnw->n + ms > tmp) { tmp = cnw->n + ms; tmp2 = FROM_NORTHWEST_NORTH; }
+        if (cnw->nw + ms > tmp) { tmp = cnw->nw + ms; tmp2 = FROM_NORTHWEST_NORTHWEST; }
+      }
+      cur->nw = tmp; cur->bnw = tmp2;
+      if (!revcmpl) {                                        // north :303-320
+        tmp = cn->nw - b_go - b_ge; tmp2 = FROM_NORTH_NORTHWEST;
+        if (cn->n - b_ge > tmp) { tmp = cn->n - b_ge; tmp2 = FROM_NORTH_NORTH; }
+      } else {
+        tmp = cn->n - b_ge; tmp2 = FROM_NORTH_NORTH;
+        if (cn->nw - b_go - b_ge > tmp) { tmp = cn->nw - b_go - b_ge; tmp2 = FROM_NORTH_NORTHWEST; }
+      }
+      cur->n = tmp; cur->bn = tmp2;
+      if (!revcmpl) {                                        // west :330-347
+        tmp = cw->nw - a_go - a_ge; tmp2 = FROM_WEST_NORTHWEST;
+        if (cw->w - a_ge > tmp) { tmp = cw->w - a_ge; tmp2 = FROM_WEST_WEST; }
+      } else {
+        tmp = cw->w - a_ge; tmp2 = FROM_WEST_WEST;
+        if (cw->nw - a_go - a_ge > tmp) { tmp = cw->nw - a_go - a_ge; tmp2 = FROM_WEST_NORTHWEST; }
+      }
+      cur->w = tmp; cur->bw = tmp2;
+      if (i == lenb - 1) {                                   // :359-368 (global: last read row only)
+        int t = std::max(cur->n, cur->nw); t = std::max(t, cur->w);
+        if (t > score) { score = t; max_i = i; max_j = j; }
+      }
+    }
+    if (i + 1 < lenb) {                                      // :378-385
+      int nx_min, nx_max;
+      anchor_get_x_range(&rectangle, lena, lenb, i + 1, &nx_min, &nx_max);
+      for (int j = x_max + 1; j <= nx_max; j++) init_cell((size_t)(i + 1) * (lena + 1) + (j + 1), 0);
+    }
+  }
+  sfr->score = score;
+  sfr->ops.clear();
+  if (score <= 0) {
+    // The reference backtraces from cell (0,0) here, reading whatever a previous call left in its
+    // scratch matrix; the result is discarded by every caller (score 0 fails the threshold).
+    sfr->rmapped = 1; sfr->gmapped = 1; sfr->genome_start = (int)goff;
+    return;
+  }
+  // do_backtrace (sw-full-ls.c:413-516)
+  int i = max_i, j = max_j;
+  auto* cell = &W.m[(size_t)(i + 1) * (lena + 1) + j + 1];
+  int from = cell->bnw; int fromscore = cell->nw;
+  if (cell->w > fromscore) { from = cell->bw; fromscore = cell->w; }
+  if (cell->n > fromscore) from = cell->bn;
+  std::string rev;
+  while (i >= 0 && j >= 0) {
+    switch (from) {
+      case FROM_NORTH_NORTH: case FROM_NORTH_NORTHWEST:
+        rev.push_back('D'); sfr->deletions++; sfr->read_start = i--; break;
+      case FROM_WEST_WEST: case FROM_WEST_NORTHWEST:
+        rev.push_back('I'); sfr->insertions++; sfr->genome_start = j--; break;
+      case FROM_NORTHWEST_NORTH: case FROM_NORTHWEST_NORTHWEST: case FROM_NORTHWEST_WEST:
+        rev.push_back('M');
+        if (W.db[j] == W.qr[i]) sfr->matches++; else sfr->mismatches++;
+        sfr->read_start = i--; sfr->genome_start = j--; break;
+      default: assert(0);
+    }
+    cell = &W.m[(size_t)(i + 1) * (lena + 1) + j + 1];
+    switch (from) {
+      case FROM_NORTH_NORTH: from = cell->bn; break;
+      case FROM_NORTH_NORTHWEST: from = cell->bnw; break;
+      case FROM_WEST_WEST: from = cell->bw; break;
+      case FROM_WEST_NORTHWEST: from = cell->bnw; break;
+      case FROM_NORTHWEST_NORTH: from = cell->bn; break;
+      case FROM_NORTHWEST_NORTHWEST: from = cell->bnw; break;
+      case FROM_NORTHWEST_WEST: from = cell->bw; break;
+    }
+    if (from == 0) break;
+  }
+  sfr->ops.assign(rev.rbegin(), rev.rend());
+  // pretty_print (sw-full-ls.c:524-560)
+  {
+    int pi = sfr->read_start, pj = sfr->genome_start;
+    for (char op : sfr->ops) {
+      if (op == 'D') { sfr->dbalign.push_back('-'); sfr->qralign.push_back(LSTRANS[W.qr[pi++]]); }
+      else if (op == 'I') { sfr->dbalign.push_back(LSTRANS[W.db[pj++]]); sfr->qralign.push_back('-'); }
+      else { sfr->dbalign.push_back(LSTRANS[W.db[pj++]]); sfr->qralign.push_back(LSTRANS[W.qr[pi++]]); }
+    }
+  }
+  sfr->gmapped = max_j - sfr->genome_start + 1;     // sw-full-ls.c:672-675
+  sfr->genome_start += (int)goff;
+  sfr->rmapped = max_i - sfr->read_start + 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-read pipeline (gmapper/mapping.c)
+// ---------------------------------------------------------------------------------------------
+struct Hit {                       // struct read_hit, gmapper-definitions.h:131-160
+  Anchor anchor;
+  llint g_off = 0, g_off_pos_strand = 0;
+  int score_window_gen = 0, score_vector = -1, pct_score_vector = 0, score_full = -1;
+  double pct_score_full = 0;
+  int pass1_key = 0, pass2_key = 0, score_max = 0, matches = 0, cn = 0, w_len = 0, st = 0, gen_st = 0;
+  int saved = 0, sort_idx = 0;
+  bool has_sfr = false;
+  SwFullResults sfr;
+};
+
+struct Read {
+  std::string name, seq;
+  std::vector<uint32_t> bits[2];   // read[0] forward, read[1] reverse complement
+  int read_len = 0, window_len = 0, max_n_kmers = 0, min_kmer_pos = 0, input_strand = 0;
+  std::vector<uint32_t> mapidx[2];
+  std::vector<Anchor> anchors[2];
+  std::vector<Hit> hits[2];
+};
+
+struct Stats { uint64_t vec_calls = 0, vec_cells = 0, vec_bypassed = 0, full_calls = 0, full_cells = 0, reads_matched = 0, dup_pruned = 0; };
+
+struct ThreadState {               // the reference's threadprivate state
+  std::vector<uint16_t> region_map[2];          // region_map[0][st] (number_in_pair 0)
+  int region_map_id = 0;
+  std::vector<uint32_t> f1_tag, f1_score;       // f1_window_cache (common/f1-wrapper.h:27-37)
+  uint32_t f1_hash_tag = 0;
+  SwFullWorkspace sww;
+  Stats stats;
+};
+
+struct Mapper {
+  Params P; const Genome* G = nullptr; const Index* I = nullptr;
+  static const int region_map_id_bits = 13;
+  static const int f1_window_cache_size = 1048576;
+
+  void init_thread(ThreadState& T) const {
+    int n_regions = 1 << (32 - P.region_bits);
+    for (int st = 0; st < 2; st++) T.region_map[st].assign(n_regions, 0);
+    T.region_map_id = 0;
+    T.f1_tag.assign(f1_window_cache_size, 0); T.f1_score.assign(f1_window_cache_size, 0);
+    T.f1_hash_tag = 0;
+  }
+
+  // launch_scan_threads body, LS unpaired part (gmapper/gmapper.c:436-531)
+  void prepare_read(Read& re) const {
+    re.read_len = (int)re.seq.size();
+    re.max_n_kmers = re.read_len - P.min_seed_span + 1;
+    std::vector<uint8_t> codes(re.read_len);
+    for (int i = 0; i < re.read_len; i++) codes[i] = (uint8_t)char_to_code_ls((unsigned char)re.seq[i]);
+    re.bits[0] = pack_codes(codes.data(), codes.size());
+    re.bits[1] = revcomp_ls(re.bits[0].data(), re.read_len);
+    if (re.max_n_kmers < 0) re.max_n_kmers = 0;
+    re.min_kmer_pos = 0; re.input_strand = 0;
+    re.window_len = (uint16_t)GMO_ABS_OR_PCT(P.window_len, re.read_len);  // gmapper.c:530
+  }
+
+  // read_get_mapidxs_per_strand (mapping.c:37-70)
+  void read_get_mapidxs(Read& re) const {
+    int ns = (int)P.seeds.size();
+    for (int st = 0; st < 2; st++) {
+      re.mapidx[st].assign((size_t)ns * re.max_n_kmers, 0);
+      const uint32_t* r = re.bits[st].data();
+      for (int i = 0; i < re.read_len; i++)
+        for (int sn = 0; sn < ns; sn++) {
+          if (i < re.min_kmer_pos + P.seeds[sn].span - 1) continue;
+          int r_idx = i - P.seeds[sn].span + 1;
+          re.mapidx[st][sn * re.max_n_kmers + (r_idx - re.min_kmer_pos)] =
+              kmer_to_mapidx(P.seeds[sn], [&](llint q) { return EXTRACT(r, q); }, i);
+        }
+    }
+  }
+
+  // read_get_region_counts (mapping.c:459-542); bit layout RG_* (mapping.c:25-31)
+  void read_get_region_counts(ThreadState& T, Read& re, int st) const {
+    if (T.region_map_id == 0) {   // mapping.c:471-487: id wrapped -> fresh maps
+      T.region_map_id = 1;
+      for (int s = 0; s < 2; s++) std::fill(T.region_map[s].begin(), T.region_map[s].end(), 0);
+    }
+    uint16_t* rm = T.region_map[st].data();
+    auto mark = [&](int region) {
+      if ((rm[region] >> 3) == T.region_map_id) rm[region] |= 0x1;
+      else rm[region] = (uint16_t)((T.region_map_id << 3) + 0x6);
+    };
+    int ns = (int)P.seeds.size();
+    for (int sn = 0; sn < ns; sn++)
+      for (int i = 0; re.min_kmer_pos + i + P.seeds[sn].span - 1 < re.read_len; i++) {
+        uint32_t mi = re.mapidx[st][sn * re.max_n_kmers + i];
+        uint32_t len = I->list_len(sn, mi);
+        if (len > P.list_cutoff) continue;
+        const uint32_t* l = I->list(sn, mi);
+        for (uint32_t j = 0; j < len; j++) {
+          int region = (int)(l[j] >> P.region_bits);
+          mark(region);
+          if ((l[j] & ((1u << P.region_bits) - 1)) < (uint32_t)P.region_overlap && region > 0) mark(region - 1);
+        }
+      }
+  }
+
+  // heap_uu (common/heap.h:44-139, DEF_HEAP(uint32_t, uint, uu)) -- exact sift rules matter for tie order
+  struct HeapUU {
+    struct E { uint32_t key; uint32_t rest; };
+    std::vector<E> a; uint32_t load = 0;
+    void percolate_up(uint32_t node) {
+      uint32_t parent = node / 2;
+      while (node > 1 && a[node - 1].key < a[parent - 1].key) { std::swap(a[parent - 1], a[node - 1]); node = parent; parent = node / 2; }
+    }
+    void percolate_down(uint32_t node) {
+      for (;;) {
+        uint32_t left = node * 2, right = left + 1, mn = node;
+        if (left <= load && a[left - 1].key < a[node - 1].key) mn = left;
+        if (right <= load && a[right - 1].key < a[mn - 1].key) mn = right;
+        if (mn == node) break;
+        std::swap(a[mn - 1], a[node - 1]); node = mn;
+      }
+    }
+    void insert(E e) { a[load] = e; load++; percolate_up(load); }
+    void replace_min(E e) { a[0] = e; percolate_down(1); }
+    void extract_min() { load--; if (load > 0) { a[0] = a[load]; percolate_down(1); } }
+  };
+
+  // advance_index_in_genomemap (mapping.c:646-805), unpaired branch (use_mp_region_counts == 0)
+  void advance_index(const ThreadState& T, int st, uint32_t* idx, uint32_t max_idx, const uint32_t* map) const {
+    const uint16_t* rm = T.region_map[st].data();
+    while (*idx < max_idx) {
+      int region = (int)(map[*idx] >> P.region_bits);
+      if (rm[region] & 0x1) break;
+      if (region > 0 && (map[*idx] & ((1u << P.region_bits) - 1)) < (uint32_t)P.region_overlap) {
+        region--;
+        if (rm[region] & 0x1) break;
+      }
+      (*idx)++;
+    }
+  }
+
+  // read_get_anchor_list_per_strand (mapping.c:861-1006), collapse = true, use_region_counts = (match_mode == 2)
+  void read_get_anchor_list(const ThreadState& T, Read& re, int st) const {
+    int ns = (int)P.seeds.size();
+    bool use_region_counts = (P.match_mode == 2);
+    re.anchors[st].clear();
+    if (re.mapidx[st].empty()) return;
+    HeapUU h; h.a.resize((size_t)ns * re.max_n_kmers + 1);
+    std::vector<uint32_t> idx((size_t)ns * re.max_n_kmers, 0);
+    std::vector<int> anchor_cache(re.read_len, -1);
+    for (int sn = 0; sn < ns; sn++)
+      for (int i = 0; re.min_kmer_pos + i + P.seeds[sn].span - 1 < re.read_len; i++) {
+        uint32_t off = sn * re.max_n_kmers + i;
+        uint32_t mi = re.mapidx[st][off];
+        uint32_t len = I->list_len(sn, mi); const uint32_t* l = I->list(sn, mi);
+        if (len > P.list_cutoff) idx[off] = len;
+        if (use_region_counts) advance_index(T, st, &idx[off], len, l);
+        if (idx[off] < len) { h.insert({l[idx[off]], off}); idx[off]++; }
+      }
+    std::vector<Anchor>& A = re.anchors[st];
+    while (h.load > 0) {
+      HeapUU::E tmp = h.a[0];
+      uint32_t off = tmp.rest; int sn = off / re.max_n_kmers; int i = off % re.max_n_kmers;
+      Anchor an; an.x = tmp.key; an.y = re.min_kmer_pos + i; an.length = P.seeds[sn].span; an.width = 1; an.weight = 1;
+      an.cn = get_contig_num(*G, (uint32_t)an.x);
+      A.push_back(an);
+      {  // collapse (mapping.c:957-971)
+        int n = (int)A.size();
+        uint32_t diag = (uint32_t)((A[n - 1].x + re.read_len - A[n - 1].y) % re.read_len);
+        int j = anchor_cache[diag];
+        if (j >= 0 && A[j].cn == A[n - 1].cn && anchor_uw_colinear(&A[j], &A[n - 1])) { anchor_uw_join(&A[j], &A[n - 1]); A.pop_back(); }
+        else anchor_cache[diag] = n - 1;
+      }
+      uint32_t mi = re.mapidx[st][off];
+      uint32_t len = I->list_len(sn, mi); const uint32_t* l = I->list(sn, mi);
+      if (use_region_counts) advance_index(T, st, &idx[off], len, l);
+      if (idx[off] < len) { h.replace_min({l[idx[off]], off}); idx[off]++; }
+      else h.extract_min();
+    }
+  }
+
+  // read_get_hit_list_per_strand (mapping.c:1025-1229), gapless = false, match_mode 1 or 2
+  void read_get_hit_list(Read& re, int st) const {
+    std::vector<Anchor>& A = re.anchors[st];
+    std::vector<Hit>& H = re.hits[st];
+    H.clear();
+    int n = (int)A.size();
+    for (int i = 0; i < n; i++) {
+      int cn = A[i].cn;
+      int w_len = re.window_len;
+      if ((uint32_t)w_len > G->len[cn]) w_len = (int)G->len[cn];
+      llint gend = (A[i].x - G->offsets[cn]) + re.read_len - 1 - A[i].y;
+      if (gend > (llint)(uint32_t)(G->len[cn] - 1)) gend = (llint)(uint32_t)(G->len[cn] - 1);
+      llint gstart = (gend >= re.window_len) ? gend - re.window_len : 0;
+      int max_idx = i;
+      int max_score = A[i].length * P.match_score;
+      if (P.match_mode == 2 && A[i].weight == 1) max_score = -1;
+      for (int j = i - 1; j >= 0 && A[j].x >= (llint)G->offsets[cn] + gstart; j--) {
+        if (A[j].y >= A[i].y) continue;
+        int short_len, long_len;
+        if (A[i].x - (llint)G->offsets[cn] - A[i].y > A[j].x - (llint)G->offsets[cn] - A[j].y) {
+          short_len = (int)(A[i].y - A[j].y) + A[i].length; long_len = (int)(A[i].x - A[j].x) + A[i].length;
+        } else {
+          short_len = (int)(A[i].x - A[j].x) + A[i].length; long_len = (int)(A[i].y - A[j].y) + A[i].length;
+        }
+        int tmp_score;
+        if (long_len > short_len) tmp_score = short_len * P.match_score + P.b_gap_open_score + (long_len - short_len) * P.b_gap_extend_score;
+        else tmp_score = short_len * P.match_score;
+        if (tmp_score > max_score) { max_idx = j; max_score = tmp_score; }
+      }
+      if (P.match_mode == 1 ||
+          max_score >= (int)GMO_ABS_OR_PCT(P.window_gen_threshold, (re.read_len < w_len ? re.read_len : w_len) * P.match_score)) {
+        int x_len = (int)(A[i].x - A[max_idx].x) + A[i].length;
+        llint goff;
+        if ((re.window_len - x_len) / 2 < A[max_idx].x - G->offsets[cn]) goff = (A[max_idx].x - G->offsets[cn]) - (re.window_len - x_len) / 2;
+        else goff = 0;
+        if (goff + w_len > (llint)G->len[cn]) goff = (llint)(uint32_t)(G->len[cn] - (uint32_t)w_len);
+        Anchor a[3];
+        if (max_idx < i) {
+          a[0] = A[i]; a[0].x -= (llint)G->offsets[cn] + goff;
+          a[1] = A[max_idx]; a[1].x -= (llint)G->offsets[cn] + goff;
+          anchor_join(a, 2, &a[2]);
+        } else { a[2] = A[i]; a[2].x -= (llint)G->offsets[cn] + goff; }
+        Hit h;
+        h.g_off = goff; h.g_off_pos_strand = goff; h.w_len = w_len; h.cn = cn; h.st = st; h.gen_st = 0;
+        h.anchor = a[2]; h.score_window_gen = max_score;
+        h.matches = (max_idx == i ? A[i].weight : A[i].weight + A[max_idx].weight);
+        h.score_vector = -1; h.score_full = -1;
+        h.score_max = (re.read_len < w_len ? re.read_len : w_len) * P.match_score;
+        H.push_back(h);
+      }
+    }
+    // insertion sort by g_off within contig (mapping.c:1210-1223)
+    for (int i = 1; i < (int)H.size(); i++) {
+      int j = i;
+      while (j >= 1 && H[j - 1].cn == H[i].cn && H[j - 1].g_off > H[i].g_off) j--;
+      if (j < i) { Hit tmp = H[i]; for (int k = i - 1; k >= j; k--) H[k + 1] = H[k]; H[j] = tmp; }
+    }
+  }
+
+  // f1_run (common/f1-wrapper.h:97-134), gapped branch
+  int f1_run(ThreadState& T, const uint32_t* genome, llint goff, int wlen, const uint32_t* read, int rlen, uint32_t tag) const {
+    uint32_t hv = 0;
+    if (P.hash_filter_calls && tag != 0) {
+      hv = hash_genome_window(genome, (uint32_t)goff, (uint32_t)wlen) % f1_window_cache_size;
+      if (T.f1_tag[hv] == tag) { T.stats.vec_bypassed++; return (int)T.f1_score[hv]; }
+    }
+    int score = sw_vector(P, genome, goff, wlen, read, rlen);
+    T.stats.vec_calls++; T.stats.vec_cells += (uint64_t)wlen * rlen;
+    if (P.hash_filter_calls && tag != 0) { T.f1_tag[hv] = tag; T.f1_score[hv] = (uint32_t)score; }
+    return score;
+  }
+
+  // read_pass1_per_strand (mapping.c:1261-1339), letter space, only_paired = false
+  void read_pass1(ThreadState& T, Read& re, int st) const {
+    int last_good_cn = -1; unsigned int last_good_g_off = 0;
+    T.f1_hash_tag++;
+    for (auto& h : re.hits[st]) {
+      if (h.matches < P.match_mode) continue;  // pass1.min_matches = match_mode (gmapper.c:2625)
+      if (h.saved == 1) { last_good_cn = h.cn; last_good_g_off = (unsigned int)h.g_off_pos_strand; continue; }
+      if (last_good_cn >= 0 && h.cn == last_good_cn &&
+          h.g_off_pos_strand + (unsigned int)GMO_ABS_OR_PCT(P.window_overlap, re.window_len) <= (llint)(unsigned int)(last_good_g_off + re.window_len)) {
+        h.score_vector = 0; h.pct_score_vector = 0; continue;
+      }
+      if (h.score_vector <= 0) {
+        h.score_vector = f1_run(T, G->fwd[h.cn].data(), h.g_off, h.w_len, re.bits[st].data(), re.read_len, T.f1_hash_tag);
+        h.pct_score_vector = (1000 * 100 * h.score_vector) / h.score_max;
+        if (h.score_vector >= (int)GMO_ABS_OR_PCT(P.sw_vect_threshold, h.score_max)) { last_good_cn = h.cn; last_good_g_off = (unsigned int)h.g_off_pos_strand; }
+      }
+    }
+  }
+
+  // extheap_unpaired_pass1 (common/heap.h:226-327; CMP mapping.c:1369) over Hit pointers
+  static void xh_up(std::vector<Hit*>& a, int node) {
+    int parent = node / 2;
+    while (node > 1 && a[node - 1]->pass1_key < a[parent - 1]->pass1_key) { std::swap(a[parent - 1], a[node - 1]); node = parent; parent = node / 2; }
+  }
+  static void xh_down(std::vector<Hit*>& a, int load, int node) {
+    for (;;) {
+      int left = node * 2, right = left + 1, mn = node;
+      if (left <= load && a[left - 1]->pass1_key < a[node - 1]->pass1_key) mn = left;
+      if (right <= load && a[right - 1]->pass1_key < a[mn - 1]->pass1_key) mn = right;
+      if (mn == node) break;
+      std::swap(a[mn - 1], a[node - 1]); node = mn;
+    }
+  }
+
+  // read_get_vector_hits (mapping.c:1376-1411)
+  void read_get_vector_hits(Read& re, std::vector<Hit*>& a, int& load) const {
+    a.assign(P.num_tmp_outputs, nullptr); load = 0;
+    bool absthr = GMO_IS_ABSOLUTE(P.sw_vect_threshold);
+    for (int st = 0; st < 2; st++)
+      for (auto& h : re.hits[st]) {
+        if (h.saved == 1) continue;
+        if (h.score_vector >= (int)GMO_ABS_OR_PCT(P.sw_vect_threshold, h.score_max) &&
+            (load < P.num_tmp_outputs || (absthr ? h.score_vector > a[0]->pass1_key : h.pct_score_vector > a[0]->pass1_key))) {
+          h.pass1_key = absthr ? h.score_vector : h.pct_score_vector;
+          if (load < P.num_tmp_outputs) { a[load] = &h; load++; xh_up(a, load); }
+          else { a[0] = &h; xh_down(a, load, 1); }
+        }
+      }
+  }
+
+  // reverse_hit (mapping.c:254-263)
+  void reverse_hit(const Read& re, Hit& h) const {
+    h.g_off = (llint)G->len[h.cn] - h.g_off - h.w_len;
+    anchor_reverse(&h.anchor, h.w_len, re.read_len);
+    h.gen_st = 1 - h.gen_st; h.st = 1 - h.st;
+  }
+
+  // hit_run_full_sw (mapping.c:331-402), letter space
+  void hit_run_full_sw(ThreadState& T, const Read& re, Hit& h, int thresh) const {
+    if (h.st != re.input_strand) reverse_hit(re, h);
+    const uint32_t* gen = (h.gen_st == 0 ? G->fwd[h.cn].data() : G->rc[h.cn].data());
+    h.has_sfr = true; h.sfr = SwFullResults();
+    h.score_vector = sw_vector(P, gen, h.g_off, h.w_len, re.bits[h.st].data(), re.read_len);
+    T.stats.vec_calls++; T.stats.vec_cells += (uint64_t)h.w_len * re.read_len;
+    if (h.score_vector >= thresh) {
+      T.stats.full_calls++;
+      sw_full_ls(P, T.sww, gen, h.g_off, h.w_len, re.bits[h.st].data(), re.read_len, thresh, h.score_vector, &h.sfr,
+                 h.gen_st && P.Tflag, &h.anchor, 1, P.Gflag ? 0 : 1);
+    } else h.sfr.score = 0;
+    h.score_full = h.sfr.score;
+    h.pct_score_full = (1000 * 100 * h.score_full) / h.score_max;
+  }
+
+  // hit_run_post_sw (mapping.c:1609-1625), letter space
+  void hit_run_post_sw(Hit& h) const {
+    SwFullResults& s = h.sfr;
+    s.posterior = pow(2.0, ((double)s.score - (double)s.rmapped * (2.0 * P.score_alpha + P.score_beta)) / P.score_alpha);
+    s.posterior_score = (int)rint(P.score_alpha * log(s.posterior) / log(2.0) + (double)s.rmapped * (2.0 * P.score_alpha + P.score_beta));
+    if (s.posterior_score < 0) s.posterior_score = 0;
+    s.pct_posterior_score = (1000 * 100 * s.posterior_score) / h.score_max;
+    h.score_full = s.posterior_score; h.pct_score_full = s.pct_posterior_score;
+  }
+
+  static int cmp_gen_start(const Hit* a, const Hit* b) {  // mapping.c:1485-1494
+    if (a->cn != b->cn) return a->cn - b->cn;
+    if (a->gen_st != b->gen_st) return a->gen_st - b->gen_st;
+    return a->sfr.genome_start - b->sfr.genome_start;
+  }
+  static int cmp_gen_end(const Hit* a, const Hit* b) {    // mapping.c:1496-1506
+    if (a->cn != b->cn) return a->cn - b->cn;
+    if (a->gen_st != b->gen_st) return a->gen_st - b->gen_st;
+    return (-a->sfr.genome_start - a->sfr.rmapped + a->sfr.deletions - a->sfr.insertions) -
+           (-b->sfr.genome_start - b->sfr.rmapped + b->sfr.deletions - b->sfr.insertions);
+  }
+  // read_remove_duplicate_hits (mapping.c:1520-1606); glibc qsort == stable merge sort on these sizes
+  template <class Cmp>
+  static void dedup_pass(std::vector<Hit*>& v, Cmp cmp, uint64_t& pruned) {
+    std::stable_sort(v.begin(), v.end(), [&](const Hit* a, const Hit* b) { return cmp(a, b) < 0; });
+    size_t i = 0, k = 0, n = v.size();
+    while (i < n) {
+      int mx = v[i]->pass2_key; size_t mx_idx = i, j = i + 1;
+      while (j < n && !cmp(v[i], v[j])) { if (v[j]->pass2_key > mx) { mx = v[j]->pass2_key; mx_idx = j; } j++; }
+      if (mx_idx != k) v[k] = v[mx_idx];
+      k++; i = j;
+    }
+    pruned += n - k; v.resize(k);
+  }
+
+  // read_pass2 (mapping.c:1631-1750)
+  void read_pass2(ThreadState& T, Read& re, std::vector<Hit*>& p1, int n1, std::vector<Hit*>& p2) const {
+    p2.clear();
+    for (int i = 0; i < n1; i++) {
+      Hit* rh = p1[i];
+      if (rh->score_full < 0 || !rh->has_sfr) {
+        hit_run_full_sw(T, re, *rh, (int)GMO_ABS_OR_PCT(P.sw_full_threshold, rh->score_max));
+        if (P.compute_mapping_qualities && rh->score_full > 0) hit_run_post_sw(*rh);
+        rh->pass2_key = GMO_IS_ABSOLUTE(P.sw_full_threshold) ? rh->score_full : (int)rh->pct_score_full;
+      }
+      if (rh->score_full >= GMO_ABS_OR_PCT(P.sw_full_threshold, rh->score_max)) p2.push_back(rh);
+    }
+    dedup_pass(p2, cmp_gen_start, T.stats.dup_pruned);
+    dedup_pass(p2, cmp_gen_end, T.stats.dup_pruned);
+    std::stable_sort(p2.begin(), p2.end(), [](const Hit* a, const Hit* b) { return (b->pass2_key - a->pass2_key) < 0; });  // mapping.c:1479-1482
+    if ((int)p2.size() > P.num_outputs) p2.resize(P.num_outputs);
+    if (P.strata && !p2.empty()) { size_t i = 1; while (i < p2.size() && p2[0]->score_full == p2[i]->score_full) i++; p2.resize(i); }
+    if (!p2.empty()) {
+      if (P.max_alignments == 0 || (int)p2.size() <= P.max_alignments) T.stats.reads_matched++;
+      else p2.clear();
+    }
+    for (auto* h : p2) h->saved = 1;
+  }
+
+  // ---- SAM emission (gmapper/output.c:15-64,164-220,227-774,777-793,955-1008) ----
+  static std::string make_cigar(int read_start, int read_end, int read_length, const std::string& qr, const std::string& db,
+                                std::vector<std::pair<int, char>>* out) {
+    std::vector<std::pair<int, char>>& c = *out; c.clear();
+    if (read_start > 1) c.push_back({read_start - 1, 'S'});
+    int i = 0, n = (int)qr.size();
+    while (i < n) {
+      int length; char op;
+      if (qr[i] == '-') { for (length = 0; i + length < n && qr[i + length] == '-'; length++); op = 'D'; }
+      else if (db[i] == '-') { for (length = 0; i + length < n && db[i + length] == '-'; length++); op = 'I'; }
+      else { for (length = 0; i + length < n && db[i + length] != '-' && qr[i + length] != '-'; length++); op = 'M'; }
+      c.push_back({length, op}); i += length;
+    }
+    if (read_end != read_length) c.push_back({read_length - read_end, 'S'});
+    return std::string();
+  }
+  static char rc_char(char ch) {  // reverse(), output.c:164-220
+    switch (ch) {
+      case 'A': return 'T'; case 'a': return 't'; case 'T': return 'A'; case 't': return 'a';
+      case 'C': return 'G'; case 'c': return 'g'; case 'G': return 'C'; case 'g': return 'c';
+      case '-': return '-'; case 'N': return 'N'; case 'n': return 'n'; case '.': return '.';
+      case 'R': return 'Y'; case 'r': return 'y'; case 'Y': return 'R'; case 'y': return 'r';
+      case 'S': return 'S'; case 's': return 's'; case 'W': return 'W'; case 'w': return 'w';
+      case 'K': return 'M'; case 'k': return 'm'; case 'M': return 'K'; case 'm': return 'k';
+      case 'B': return 'V'; case 'b': return 'v'; case 'V': return 'B'; case 'v': return 'b';
+      case 'D': return 'H'; case 'd': return 'h'; case 'H': return 'D'; case 'h': return 'd';
+      default: return '?';
+    }
+  }
+  static int qv_from_pr_corr(double pr_corr) {  // util.h:267-283
+    double pr_err = 1 - pr_corr;
+    if (pr_err > .99999999) return 0; else if (pr_err < 1E-25) return 250;
+    return (int)(-10.0 * log(pr_err) / log(10.0));
+  }
+  static int double_to_neglog(double x) { return (int)((double)1000 * -log(x)); }  // util.h:297-301
+
+  void hit_output(const Read& re, const Hit* rh, std::string& out) const {
+    char buf[256];
+    std::string seq(re.read_len, 'N');
+    for (int i = 0; i < re.read_len; i++) {   // output.c:320-352
+      char c = re.seq[i];
+      switch (c) {
+        case 'R': case 'Y': case 'S': case 'W': case 'K': case 'M': case 'B': case 'D': case 'H': case 'V': seq[i] = 'N'; break;
+        default: if (c >= 'a') c -= 32; seq[i] = c; break;
+      }
+    }
+    if (rh == nullptr) {                      // unmapped (output.c:411-466), unpaired, letter space, no qualities
+      out += re.name; out += "\t4\t*\t0\t0\t*\t*\t0\t0\t"; out += seq; out += "\t*\n";
+      return;
+    }
+    const SwFullResults& s = rh->sfr;
+    bool reverse_strand = (rh->gen_st == 1);
+    int read_start = s.read_start + 1, read_end = read_start + s.rmapped - 1;
+    int genome_length = (int)G->len[rh->cn];
+    std::vector<std::pair<int, char>> cigar;
+    make_cigar(read_start, read_end, re.read_len, s.qralign, s.dbalign, &cigar);
+    int j = read_start - 1;
+    for (size_t i = 0; i < s.qralign.size(); i++) {   // output.c:485-533
+      char c = s.qralign[i];
+      if (c != '-') {
+        if (c >= 'a') c -= 32;
+        if (c != 'A' && c != 'G' && c != 'C' && c != 'T' && c != 'N') c = 'N';
+        seq[j++] = c;
+      }
+    }
+    seq.resize(j + (re.read_len - read_end));
+    int genome_start;
+    if (!reverse_strand) genome_start = s.genome_start + 1;
+    else {
+      int right = genome_length - s.genome_start;
+      genome_start = right - (read_end - read_start - s.deletions + s.insertions);
+      std::string t(seq.size(), ' ');
+      for (size_t i = 0; i < seq.size(); i++) t[seq.size() - 1 - i] = rc_char(seq[i]);
+      seq = t;
+      std::reverse(cigar.begin(), cigar.end());
+    }
+    int flag = reverse_strand ? 0x10 : 0;
+    out += re.name;
+    snprintf(buf, sizeof buf, "\t%i\t", flag); out += buf;
+    out += G->names[rh->cn];
+    snprintf(buf, sizeof buf, "\t%u\t%i\t", (unsigned)genome_start, s.mqv); out += buf;
+    for (auto& c : cigar) { snprintf(buf, sizeof buf, "%d%c", c.first, c.second); out += buf; }
+    out += "\t*\t0\t0\t"; out += seq; out += "\t*";
+    snprintf(buf, sizeof buf, "\tAS:i:%d", rh->score_full); out += buf;
+    if (P.compute_mapping_qualities) { snprintf(buf, sizeof buf, "\tZ0:i:%d\tZ1:i:%d", double_to_neglog(s.z0), double_to_neglog(s.z1)); out += buf; }
+    snprintf(buf, sizeof buf, "\tNM:i:%d\n", s.mismatches + s.deletions + s.insertions); out += buf;
+  }
+
+  // read_output (output.c:955-1008) + compute_unpaired_mqv (output.c:777-793)
+  void read_output(const Read& re, std::vector<Hit*>& p2, std::string& out) const {
+    if (p2.empty()) return;
+    if (P.compute_mapping_qualities) {
+      double z1 = 0.0;
+      for (auto* h : p2) z1 += h->sfr.posterior;
+      for (auto* h : p2) {
+        h->sfr.z0 = h->sfr.posterior; h->sfr.z1 = z1;
+        h->sfr.mqv = qv_from_pr_corr(h->sfr.posterior / z1);
+        if (h->sfr.mqv < 4) h->sfr.mqv = 0;
+      }
+    }
+    for (auto* h : p2) hit_output(re, h, out);
+  }
+
+  // handle_read (mapping.c:1773-1868) with the single default unpaired option set (gmapper.c:2601-2634)
+  void handle_read(ThreadState& T, Read& re, std::string& out, std::vector<Hit*>* top_out = nullptr) const {
+    read_get_mapidxs(re);
+    bool regions = (P.match_mode == 2);
+    if (regions) {
+      T.region_map_id++; T.region_map_id &= ((1 << region_map_id_bits) - 1);
+      read_get_region_counts(T, re, 0); read_get_region_counts(T, re, 1);
+    }
+    read_get_anchor_list(T, re, 0); read_get_anchor_list(T, re, 1);
+    read_get_hit_list(re, 0); read_get_hit_list(re, 1);
+    for (size_t i = 0; i < re.hits[0].size(); i++) re.hits[0][i].sort_idx = (int)i;
+    for (size_t i = 0; i < re.hits[1].size(); i++) re.hits[1][i].sort_idx = (int)(re.hits[0].size() + i);
+    read_pass1(T, re, 0); read_pass1(T, re, 1);
+    std::vector<Hit*> p1, p2; int n1 = 0;
+    read_get_vector_hits(re, p1, n1);
+    if (top_out) { top_out->assign(p1.begin(), p1.begin() + n1); }
+    read_pass2(T, re, p1, n1, p2);
+    if (!p2.empty()) read_output(re, p2, out);
+    else if (P.sam_unaligned) hit_output(re, nullptr, out);
+  }
+};
+
+}  // namespace gmo

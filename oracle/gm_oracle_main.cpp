@@ -1,0 +1,219 @@
+// gm_oracle_main.cpp -- CLI + C entry points around gm_oracle.hpp.
+// TEST INFRASTRUCTURE ONLY (see gm_oracle.hpp).  Build: make -C oracle
+//
+//   gm_oracle [-N threads] [-Z] [--sam-unaligned] reads.fa genome.fa   > out.sam
+//
+// mirrors `gmapper-ls reads.fa genome.fa` for FASTA input (gmapper/gmapper.c:1720-3109).
+#include "gm_oracle.hpp"
+#include <omp.h>
+#include <chrono>
+#include <fstream>
+#include <iostream>
+
+using namespace gmo;
+
+// fasta_get_next_read_with_range / extract_name (common/fasta.c:242-277,303-545), FASTA only
+static bool read_fasta(const char* path, std::vector<std::string>& names, std::vector<std::string>& seqs) {
+  std::ifstream f(path);
+  if (!f) return false;
+  std::string line;
+  while (std::getline(f, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    if (line.empty() || line[0] == '#') continue;
+    if (line[0] == '>') {
+      std::string nm = line.substr(1);
+      size_t tab = nm.find('\t'); if (tab != std::string::npos) nm = nm.substr(0, tab);
+      size_t b = 0; while (b < nm.size() && isspace((unsigned char)nm[b])) b++;   // strtrim
+      nm = nm.substr(b);
+      size_t e = 0; while (e < nm.size() && nm[e] != ' ' && nm[e] != '\t') e++;
+      names.push_back(nm.substr(0, e)); seqs.emplace_back();
+    } else if (!seqs.empty()) seqs.back() += line;
+  }
+  return true;
+}
+
+struct Session {
+  Mapper M; Genome G; Index I;
+};
+
+static void map_all(const Session& S, std::vector<Read>& reads, int nthreads, std::string& out, Stats* stats_out) {
+  const int chunk = 1000;
+  int nchunks = (int)((reads.size() + chunk - 1) / chunk);
+  std::vector<std::string> outs(nchunks);
+  std::vector<Stats> st(nthreads);
+#pragma omp parallel num_threads(nthreads)
+  {
+    ThreadState T; S.M.init_thread(T);
+#pragma omp for schedule(dynamic, 1)
+    for (int c = 0; c < nchunks; c++) {
+      size_t lo = (size_t)c * chunk, hi = std::min(reads.size(), lo + chunk);
+      for (size_t r = lo; r < hi; r++) {
+        S.M.prepare_read(reads[r]);
+        if (reads[r].read_len > S.M.P.longest_read_len) continue;
+        S.M.handle_read(T, reads[r], outs[c]);
+      }
+    }
+    st[omp_get_thread_num()] = T.stats;
+  }
+  for (auto& o : outs) out += o;
+  if (stats_out) {
+    for (auto& s : st) {
+      stats_out->vec_calls += s.vec_calls; stats_out->vec_cells += s.vec_cells; stats_out->vec_bypassed += s.vec_bypassed;
+      stats_out->full_calls += s.full_calls; stats_out->full_cells += s.full_cells; stats_out->reads_matched += s.reads_matched;
+      stats_out->dup_pruned += s.dup_pruned;
+    }
+    stats_out->full_cells = 0;
+  }
+}
+
+#ifdef GM_ORACLE_MAIN
+int main(int argc, char** argv) {
+  int nthreads = 1; bool noz = false, unal = false;
+  std::vector<const char*> pos;
+  std::string cl;
+  for (int i = 0; i < argc; i++) { if (i) cl += ' '; cl += argv[i]; }
+  for (int i = 1; i < argc; i++) {
+    if (!strcmp(argv[i], "-N") && i + 1 < argc) nthreads = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "-Z")) noz = true;
+    else if (!strcmp(argv[i], "--sam-unaligned")) unal = true;
+    else pos.push_back(argv[i]);
+  }
+  if (pos.size() != 2) { fprintf(stderr, "usage: gm_oracle [-N n] [-Z] [--sam-unaligned] reads.fa genome.fa\n"); return 1; }
+  Session S;
+  load_default_seeds(S.M.P); derive_score_probs(S.M.P);
+  S.M.P.hash_filter_calls = !noz; S.M.P.sam_unaligned = unal;
+  std::vector<std::string> gn, gs;
+  if (!read_fasta(pos[1], gn, gs)) { fprintf(stderr, "cannot read genome\n"); return 1; }
+  for (size_t c = 0; c < gn.size(); c++) {
+    std::vector<uint8_t> codes(gs[c].size());
+    for (size_t i = 0; i < codes.size(); i++) codes[i] = (uint8_t)char_to_code_ls((unsigned char)gs[c][i]);
+    S.G.add_contig(gn[c], codes.data(), codes.size());
+  }
+  auto t0 = std::chrono::steady_clock::now();
+  build_index(S.M.P, S.G, S.I);
+  S.M.P.list_cutoff = auto_list_cutoff(S.M.P, S.G);
+  S.M.G = &S.G; S.M.I = &S.I;
+  auto t1 = std::chrono::steady_clock::now();
+  std::vector<std::string> rn, rs;
+  if (!read_fasta(pos[0], rn, rs)) { fprintf(stderr, "cannot read reads\n"); return 1; }
+  std::vector<Read> reads(rn.size());
+  for (size_t i = 0; i < rn.size(); i++) { reads[i].name = rn[i]; reads[i].seq = rs[i]; }
+  printf("@HD\tVN:1.0\tSO:unsorted\n");
+  for (int c = 0; c < S.G.num_contigs(); c++) printf("@SQ\tSN:%s\tLN:%u\n", S.G.names[c].c_str(), S.G.len[c]);
+  printf("@PG\tID:gmapper\tVN:2.2.3\tCL:%s\n", cl.c_str());
+  std::string out; Stats st;
+  auto t2 = std::chrono::steady_clock::now();
+  map_all(S, reads, nthreads, out, &st);
+  auto t3 = std::chrono::steady_clock::now();
+  fwrite(out.data(), 1, out.size(), stdout);
+  fprintf(stderr, "oracle: index %.2fs, mapping %.3fs (%zu reads, %d threads, %.0f reads/s); vec calls %llu bypassed %llu full calls %llu matched %llu dup %llu cutoff %u\n",
+          std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t3 - t2).count(), reads.size(), nthreads,
+          reads.size() / std::chrono::duration<double>(t3 - t2).count(),
+          (unsigned long long)st.vec_calls, (unsigned long long)st.vec_bypassed, (unsigned long long)st.full_calls,
+          (unsigned long long)st.reads_matched, (unsigned long long)st.dup_pruned, S.M.P.list_cutoff);
+  return 0;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// C entry points for tests/ (ctypes).  Default letter-space parameters throughout.
+// ---------------------------------------------------------------------------------------------
+static Params default_params() { Params P; load_default_seeds(P); derive_score_probs(P); return P; }
+
+extern "C" {
+
+int gmo_sw_vector(const uint32_t* genome, int goff, int glen, const uint32_t* read, int rlen) {
+  static const Params P = default_params();
+  return sw_vector(P, genome, goff, glen, read, rlen);
+}
+
+// out[9] = score read_start rmapped genome_start gmapped matches mismatches insertions deletions
+int gmo_sw_full_ls(const uint32_t* genome, int goff, int glen, const uint32_t* read, int rlen,
+                   long long ax, long long ay, int alen, int awidth, int revcmpl,
+                   int* out, char* dbalign, char* qralign, int cap) {
+  static const Params P = default_params();
+  SwFullWorkspace W; SwFullResults s;
+  Anchor a; a.x = ax; a.y = ay; a.length = alen; a.width = awidth; a.weight = 1;
+  sw_full_ls(P, W, genome, goff, glen, read, rlen, 0, 0, &s, revcmpl != 0, &a, 1, 0);
+  int v[9] = {s.score, s.read_start, s.rmapped, s.genome_start, s.gmapped, s.matches, s.mismatches, s.insertions, s.deletions};
+  memcpy(out, v, sizeof v);
+  if ((int)s.dbalign.size() + 1 > cap) return -1;
+  strcpy(dbalign, s.dbalign.c_str()); strcpy(qralign, s.qralign.c_str());
+  return 0;
+}
+
+void* gmo_session_create(int n_contigs, const uint8_t* const* codes, const uint64_t* lens, const char* const* names) {
+  Session* S = new Session();
+  S->M.P = default_params();
+  for (int c = 0; c < n_contigs; c++) {
+    char nm[64]; snprintf(nm, sizeof nm, "contig%d", c + 1);
+    S->G.add_contig(names && names[c] ? names[c] : nm, codes[c], (size_t)lens[c]);
+  }
+  build_index(S->M.P, S->G, S->I);
+  S->M.P.list_cutoff = auto_list_cutoff(S->M.P, S->G);
+  S->M.G = &S->G; S->M.I = &S->I;
+  return S;
+}
+void gmo_session_destroy(void* s) { delete (Session*)s; }
+unsigned gmo_session_cutoff(void* s) { return ((Session*)s)->M.P.list_cutoff; }
+void gmo_session_set(void* s, int hash_filter_calls, int sam_unaligned) {
+  Session* S = (Session*)s; S->M.P.hash_filter_calls = hash_filter_calls != 0; S->M.P.sam_unaligned = sam_unaligned != 0;
+}
+
+static std::string code_seq(const uint8_t* c, int L) { std::string s(L, 'N'); for (int i = 0; i < L; i++) s[i] = LSTRANS[c[i] & 15]; return s; }
+
+// reads: n x L code matrix (row-major); names: '\n'-separated or NULL (-> r<i>); returns malloc'd SAM body (no header)
+char* gmo_map_sam(void* s, int n, int L, const uint8_t* codes, const char* names, int nthreads, uint64_t* stats7) {
+  Session* S = (Session*)s;
+  std::vector<Read> reads(n);
+  const char* p = names;
+  for (int i = 0; i < n; i++) {
+    if (p) { const char* e = strchr(p, '\n'); if (!e) e = p + strlen(p); reads[i].name.assign(p, e); p = *e ? e + 1 : e; }
+    else { char nm[32]; snprintf(nm, sizeof nm, "r%d", i); reads[i].name = nm; }
+    reads[i].seq = code_seq(codes + (size_t)i * L, L);
+  }
+  std::string out; Stats st;
+  map_all(*S, reads, nthreads > 0 ? nthreads : 1, out, &st);
+  if (stats7) { stats7[0] = st.vec_calls; stats7[1] = st.vec_cells; stats7[2] = st.vec_bypassed; stats7[3] = st.full_calls; stats7[4] = st.reads_matched; stats7[5] = st.dup_pruned; stats7[6] = 0; }
+  char* r = (char*)malloc(out.size() + 1);
+  memcpy(r, out.data(), out.size()); r[out.size()] = 0;
+  return r;
+}
+void gmo_free(void* p) { free(p); }
+
+// Stage dump for one batch, for GPU-vs-oracle stage parity: for every read the pass-1 survivors
+// (top-K heap array order) as rows of 12 ints:
+//   read st cn g_off w_len score_vector pct_score_vector matches anchor.x anchor.y anchor.length anchor.width
+// (hit state *before* pass 2 / reverse_hit).  Returns number of rows written (<= cap).
+long gmo_map_tophits(void* s, int n, int L, const uint8_t* codes, int nthreads, long long* rows, long cap) {
+  Session* S = (Session*)s;
+  std::vector<std::vector<long long>> per(n);
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
+  {
+    ThreadState T; S->M.init_thread(T);
+#pragma omp for schedule(dynamic, 64)
+    for (int i = 0; i < n; i++) {
+      Read re; re.seq = code_seq(codes + (size_t)i * L, L); re.name = "r";
+      S->M.prepare_read(re);
+      S->M.read_get_mapidxs(re);
+      T.region_map_id++; T.region_map_id &= ((1 << Mapper::region_map_id_bits) - 1);
+      S->M.read_get_region_counts(T, re, 0); S->M.read_get_region_counts(T, re, 1);
+      S->M.read_get_anchor_list(T, re, 0); S->M.read_get_anchor_list(T, re, 1);
+      S->M.read_get_hit_list(re, 0); S->M.read_get_hit_list(re, 1);
+      S->M.read_pass1(T, re, 0); S->M.read_pass1(T, re, 1);
+      std::vector<Hit*> p1; int n1 = 0;
+      S->M.read_get_vector_hits(re, p1, n1);
+      for (int k = 0; k < n1; k++) {
+        Hit* h = p1[k];
+        long long r[12] = {i, h->st, h->cn, h->g_off, h->w_len, h->score_vector, h->pct_score_vector, h->matches,
+                           h->anchor.x, h->anchor.y, h->anchor.length, h->anchor.width};
+        per[i].insert(per[i].end(), r, r + 12);
+      }
+    }
+  }
+  long w = 0;
+  for (int i = 0; i < n; i++) for (size_t k = 0; k + 12 <= per[i].size(); k += 12) { if (w >= cap) return w; memcpy(rows + w * 12, &per[i][k], 12 * sizeof(long long)); w++; }
+  return w;
+}
+
+}  // extern "C"

@@ -1,0 +1,152 @@
+"""Deterministic synthetic genomes and reads.
+
+Pure numpy so the very same inputs can be produced in the build container (for the
+reference binary / oracle) and on the GPU box (for bench.py and the parity tests).
+Nothing here is part of the mapping path.
+
+Base codes follow the reference's 4-bit alphabet (common/fasta.h:26-42): A0 C1 G2 T3.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+LETTERS = np.frombuffer(b"ACGT", dtype=np.uint8)
+# complement_base table over all 16 codes (common/util.h:125-151)
+COMPLEMENT = np.array([3, 2, 1, 0, 0, 10, 9, 7, 8, 6, 5, 14, 13, 12, 11, 15], dtype=np.uint8)
+
+# hg18 chr1..22,X,Y lengths (Mbp, rounded) used only as *proportions* for the 24-contig cfg3 genome
+_HG18_MBP = [247, 243, 199, 191, 181, 171, 159, 146, 140, 135, 134, 132, 114, 106, 100, 89, 79, 76,
+             64, 62, 47, 50, 155, 58]
+
+
+def contig_lengths(cfg: str, scale: float = 1.0) -> list[int]:
+    """Contig lengths for the named configuration (`scale` shrinks it for CPU-sized tests)."""
+    if cfg == "cfg1":
+        base = [1_000_000]
+    elif cfg == "cfg2":
+        base = [25_000_000] * 4
+    elif cfg == "cfg3":
+        tot = float(sum(_HG18_MBP))
+        base = [int(3.0e9 * m / tot) for m in _HG18_MBP]
+    else:
+        raise ValueError(cfg)
+    return [max(1000, int(b * scale)) for b in base]
+
+
+def make_genome(lengths: list[int], seed: int) -> list[np.ndarray]:
+    """i.i.d. uniform ACGT contigs as uint8 code arrays (0..3)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return [rng.integers(0, 4, size=n, dtype=np.uint8) for n in lengths]
+
+
+def make_reads(contigs: list[np.ndarray], n_reads: int, read_len: int, seed: int,
+               p_sub: float = 0.02, p_ins: float = 0.002, p_del: float = 0.002,
+               p_rc: float = 0.5):
+    """Sample reads: uniform start over the concatenated genome, `p_rc` reverse-complemented,
+    then per-base substitution / insertion / deletion.  Returns (codes[n_reads, read_len] uint8,
+    truth dict of arrays cn, pos, strand)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 1_000_003))
+    lens = np.array([len(c) for c in contigs], dtype=np.int64)
+    margin = read_len + 16
+    usable = np.maximum(lens - margin, 1)
+    cum = np.concatenate([[0], np.cumsum(usable)])
+    u = rng.integers(0, cum[-1], size=n_reads, dtype=np.int64)
+    cn = np.searchsorted(cum, u, side="right") - 1
+    pos = u - cum[cn]
+    strand = (rng.random(n_reads) < p_rc).astype(np.uint8)
+
+    # source segments of length `margin`, oriented like the read
+    src = np.empty((n_reads, margin), dtype=np.uint8)
+    ar = np.arange(margin, dtype=np.int64)
+    for c in range(len(contigs)):
+        m = np.nonzero(cn == c)[0]
+        if m.size == 0:
+            continue
+        src[m] = contigs[c][pos[m, None] + ar[None, :]]
+    rc = strand == 1
+    src[rc] = COMPLEMENT[src[rc][:, ::-1]]
+
+    out = np.empty((n_reads, read_len), dtype=np.uint8)
+    ptr = np.zeros(n_reads, dtype=np.int64)
+    rows = np.arange(n_reads)
+    for j in range(read_len):
+        r = rng.random(n_reads)
+        ins = r < p_ins
+        dele = (~ins) & (r < p_ins + p_del)
+        ptr = np.minimum(ptr + dele, margin - 1)
+        b = src[rows, ptr]
+        sub = (~ins) & (rng.random(n_reads) < p_sub)
+        b = np.where(sub & (b < 4), (b + rng.integers(1, 4, size=n_reads, dtype=np.uint8)) & 3, b)
+        b = np.where(ins, rng.integers(0, 4, size=n_reads, dtype=np.uint8), b)
+        out[:, j] = b
+        ptr = np.minimum(ptr + (~ins), margin - 1)
+    return out, {"cn": cn.astype(np.int32), "pos": pos, "strand": strand}
+
+
+def pack_nibbles(codes: np.ndarray) -> np.ndarray:
+    """Pack a 1-D code array 8 bases per uint32, base i in nibble i%8 of word i/8
+    (the reference's bitfield layout, common/util.h:41 EXTRACT)."""
+    n = codes.shape[0]
+    nw = (n + 7) // 8
+    pad = np.zeros(nw * 8, dtype=np.uint32)
+    pad[:n] = codes
+    pad = pad.reshape(nw, 8)
+    shifts = (4 * np.arange(8, dtype=np.uint32))[None, :]
+    return np.bitwise_or.reduce(pad << shifts, axis=1).astype(np.uint32)
+
+
+def pack_reads(codes: np.ndarray) -> np.ndarray:
+    """Pack reads[n, L] row-wise to uint32[n, ceil(L/8)]."""
+    n, L = codes.shape
+    nw = (L + 7) // 8
+    pad = np.zeros((n, nw * 8), dtype=np.uint32)
+    pad[:, :L] = codes
+    pad = pad.reshape(n, nw, 8)
+    shifts = (4 * np.arange(8, dtype=np.uint32))[None, None, :]
+    return np.bitwise_or.reduce(pad << shifts, axis=2).astype(np.uint32)
+
+
+def write_fasta_genome(path: str, contigs: list[np.ndarray], width: int = 70) -> None:
+    with open(path, "wb") as f:
+        for i, c in enumerate(contigs):
+            f.write(b">contig%d\n" % (i + 1))
+            s = LETTERS[c]
+            for k in range(0, len(s), width * 10000):
+                blk = s[k:k + width * 10000]
+                full = (len(blk) // width) * width
+                if full:
+                    lines = np.concatenate(
+                        [blk[:full].reshape(-1, width),
+                         np.full((full // width, 1), 10, dtype=np.uint8)], axis=1)
+                    f.write(lines.tobytes())
+                if full < len(blk):
+                    f.write(blk[full:].tobytes() + b"\n")
+
+
+def read_names(n_reads: int) -> list[bytes]:
+    return [b"r%d" % i for i in range(n_reads)]
+
+
+def write_fasta_reads(path: str, reads: np.ndarray) -> None:
+    n, L = reads.shape
+    s = LETTERS[reads]
+    with open(path, "wb") as f:
+        for i in range(n):
+            f.write(b">r%d\n" % i)
+            f.write(s[i].tobytes())
+            f.write(b"\n")
+
+
+CONFIGS = {
+    # name: (genome cfg, genome seed, n_reads, read_len, read seed)
+    "cfg1": ("cfg1", 12345, 10_000, 36, 12345),
+    "cfg2": ("cfg2", 2, 1_000_000, 100, 2),
+    "cfg3": ("cfg3", 3, 10_000_000, 100, 3),
+}
+
+
+def make_config(name: str, scale: float = 1.0, n_reads: int | None = None):
+    g, gseed, nr, L, rseed = CONFIGS[name]
+    contigs = make_genome(contig_lengths(g, scale), gseed)
+    reads, truth = make_reads(contigs, n_reads if n_reads is not None else nr, L, rseed)
+    return contigs, reads, truth

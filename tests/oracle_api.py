@@ -1,0 +1,112 @@
+"""ctypes wrapper over oracle/libgm_oracle.so (the CPU restatement).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package shrimp_amd.
+"""
+import ctypes as C
+import gzip, os, subprocess
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+_LIB = None
+
+
+def build():
+    src = [os.path.join(ROOT, "oracle", f) for f in ("gm_oracle_main.cpp", "gm_oracle.hpp")]
+    so = os.path.join(ROOT, "oracle", "libgm_oracle.so")
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "libgm_oracle.so"], check=True, capture_output=True)
+    return so
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    L = C.CDLL(build())
+    u32p, u8p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+    L.gmo_sw_vector.argtypes = [u32p, C.c_int, C.c_int, u32p, C.c_int]; L.gmo_sw_vector.restype = C.c_int
+    L.gmo_sw_full_ls.argtypes = [u32p, C.c_int, C.c_int, u32p, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(C.c_int), C.c_char_p, C.c_char_p, C.c_int]
+    L.gmo_sw_full_ls.restype = C.c_int
+    L.gmo_session_create.argtypes = [C.c_int, C.POINTER(u8p), C.POINTER(C.c_uint64), C.c_void_p]; L.gmo_session_create.restype = C.c_void_p
+    L.gmo_session_destroy.argtypes = [C.c_void_p]
+    L.gmo_session_cutoff.argtypes = [C.c_void_p]; L.gmo_session_cutoff.restype = C.c_uint
+    L.gmo_session_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.gmo_map_sam.argtypes = [C.c_void_p, C.c_int, C.c_int, u8p, C.c_char_p, C.c_int, C.POINTER(C.c_uint64)]; L.gmo_map_sam.restype = C.c_void_p
+    L.gmo_free.argtypes = [C.c_void_p]
+    L.gmo_map_tophits.argtypes = [C.c_void_p, C.c_int, C.c_int, u8p, C.c_int, C.POINTER(C.c_longlong), C.c_long]; L.gmo_map_tophits.restype = C.c_long
+    _LIB = L
+    return L
+
+
+class Session:
+    def __init__(self, contigs):
+        self.L = load()
+        self.contigs = [np.ascontiguousarray(c, dtype=np.uint8) for c in contigs]
+        n = len(self.contigs)
+        ptrs = (C.POINTER(C.c_uint8) * n)(*[c.ctypes.data_as(C.POINTER(C.c_uint8)) for c in self.contigs])
+        lens = (C.c_uint64 * n)(*[len(c) for c in self.contigs])
+        self.h = self.L.gmo_session_create(n, ptrs, lens, None)
+
+    def set(self, hash_filter_calls=True, sam_unaligned=False):
+        self.L.gmo_session_set(self.h, int(hash_filter_calls), int(sam_unaligned))
+
+    @property
+    def cutoff(self):
+        return self.L.gmo_session_cutoff(self.h)
+
+    def map_sam(self, reads, nthreads=4):
+        reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        n, Lr = reads.shape
+        st = (C.c_uint64 * 7)()
+        p = self.L.gmo_map_sam(self.h, n, Lr, reads.ctypes.data_as(C.POINTER(C.c_uint8)), None, nthreads, st)
+        s = C.string_at(p)
+        self.L.gmo_free(p)
+        self.stats = dict(vec_calls=st[0], vec_cells=st[1], vec_bypassed=st[2], full_calls=st[3], reads_matched=st[4], dup_pruned=st[5])
+        return s
+
+    def tophits(self, reads, nthreads=4):
+        reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        n, Lr = reads.shape
+        cap = n * 30
+        rows = np.zeros((cap, 12), dtype=np.int64)
+        w = self.L.gmo_map_tophits(self.h, n, Lr, reads.ctypes.data_as(C.POINTER(C.c_uint8)), nthreads,
+                                   rows.ctypes.data_as(C.POINTER(C.c_longlong)), cap)
+        return rows[:w]
+
+    def close(self):
+        if self.h:
+            self.L.gmo_session_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
+
+
+def sam_header(contigs):
+    return b"@HD\tVN:1.0\tSO:unsorted\n" + b"".join(b"@SQ\tSN:contig%d\tLN:%d\n" % (i + 1, len(c)) for i, c in enumerate(contigs))
+
+
+def load_golden(name):
+    d = os.path.join(ROOT, "tests", "golden")
+    z = np.load(os.path.join(d, name + ".npz"))
+    contigs = [z["contig%d" % i] for i in range(len(z.files) - 1)]
+    with gzip.open(os.path.join(d, name + ".sam.gz"), "rb") as f:
+        sam = f.read()
+    return contigs, z["reads"], sam
+
+
+def parse_words(s):
+    return np.array([int(x, 16) for x in s.split(",")], dtype=np.uint32)
+
+
+def load_kat():
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "sw_kat.txt.gz"), "rt") as f:
+        for line in f:
+            t = line.split()
+            if t[0] == "V":
+                yield ("V", int(t[1]), int(t[2]), int(t[3]), parse_words(t[4]), parse_words(t[5]), int(t[6]))
+            else:
+                yield ("F", int(t[1]), int(t[2]), int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7]), int(t[8]),
+                       parse_words(t[9]), parse_words(t[10]), [int(x) for x in t[11:20]], t[20], t[21])

@@ -1,0 +1,52 @@
+"""The CPU restatement (oracle/) against the reference's own outputs (tests/golden/*, generated
+by tools/make_golden.py from the reference binary built from /root/reference)."""
+import ctypes as C
+import numpy as np
+import pytest
+from tests import oracle_api as oa
+
+GOLDEN = ["cfg1_36bp_1Mbp", "cfg2s_100bp_2Mbp", "stress_60bp", "stress_100bp_unal"]
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_oracle_sam_matches_reference(name, oracle_lib):
+    contigs, reads, sam = oa.load_golden(name)
+    s = oa.Session(contigs)
+    s.set(hash_filter_calls=True, sam_unaligned=name.endswith("_unal"))
+    got = oa.sam_header(contigs) + s.map_sam(reads, nthreads=4)
+    s.close()
+    assert got == sam, "oracle SAM differs from reference SAM for %s" % name
+
+
+def test_oracle_sw_known_answers(oracle_lib):
+    L = oracle_lib
+    u32p = C.POINTER(C.c_uint32)
+    nv = nf = 0
+    db = C.create_string_buffer(4096); qr = C.create_string_buffer(4096)
+    for rec in oa.load_kat():
+        if rec[0] == "V":
+            _, goff, glen, rlen, g, r, score = rec
+            assert L.gmo_sw_vector(g.ctypes.data_as(u32p), goff, glen, r.ctypes.data_as(u32p), rlen) == score
+            nv += 1
+        else:
+            _, goff, glen, rlen, ax, ay, alen, aw, rv, g, r, exp, edb, eqr = rec
+            out = (C.c_int * 9)()
+            assert L.gmo_sw_full_ls(g.ctypes.data_as(u32p), goff, glen, r.ctypes.data_as(u32p), rlen, ax, ay, alen, aw, rv,
+                                    out, db, qr, 4096) == 0
+            assert list(out) == exp, (goff, glen, rlen, ax, ay, alen, aw, rv)
+            assert db.value.decode() == edb and qr.value.decode() == eqr
+            nf += 1
+    assert nv >= 1000 and nf >= 1000
+
+
+def test_oracle_sharding_invariance(oracle_lib):
+    """reads mapped in two halves and concatenated == mapped at once."""
+    contigs, reads, sam = oa.load_golden("stress_60bp")
+    s = oa.Session(contigs)
+    whole = s.map_sam(reads, nthreads=2)
+    h = len(reads) // 2
+    # names are positional (r<i>), so only compare record payloads after the name column
+    strip = lambda b: [l.split(b"\t", 1)[1] for l in b.split(b"\n") if l]
+    halves = strip(s.map_sam(reads[:h], nthreads=1)) + strip(s.map_sam(reads[h:], nthreads=3))
+    s.close()
+    assert strip(whole) == halves
