@@ -1,0 +1,172 @@
+/*
+ * gmapper_hip.h -- C ABI of libgmapper_hip.so: an MI355X (gfx950) implementation of the
+ * SHRiMP2 gmapper hot path (spaced-seed lookup + Smith-Waterman extension).
+ *
+ * Plain C types only (pointers + sizes); no torch / HIP types cross this boundary.
+ * All "ref:" citations are file:line in compbio-UofT/shrimp (SHRiMP 2.2.3).
+ *
+ * Seams replaced:
+ *   S1  sw_vector_setup / sw_vector / sw_vector_stats      ref: common/sw-vector.h:1-6, common/sw-vector.c:388-515
+ *   S2  sw_full_ls_setup / sw_full_ls                       ref: common/sw-full-ls.h, common/sw-full-ls.c:568-683
+ *   S4  handle_read (per-read pipeline -> SAM text)        ref: gmapper/mapping.h:23, gmapper/mapping.c:1773-1868
+ *   S5  load_genome (index build) + its globals            ref: gmapper/genome.h:23-32, gmapper/genome.c:1012-1182
+ * The reference calls S1/S2/S4 once per window / per read from an OpenMP thread; a GPU needs
+ * batches, so every seam has a batch form; the single-call forms keep the reference's exact
+ * parameter lists (for drop-in linking) and are thin wrappers over a batch of one.
+ *
+ * Errors: integer return codes (0 = ok, <0 = GM_E_*); nothing throws across the ABI.
+ * Threading: one host thread per gm_session; a session owns one HIP stream on one device.
+ */
+#ifndef GMAPPER_HIP_H
+#define GMAPPER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdbool.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GM_OK            0
+#define GM_E_NODEVICE   -1   /* no HIP device / HIP runtime error (message via gm_last_error) */
+#define GM_E_ARG        -2   /* invalid argument */
+#define GM_E_NOTSETUP   -3   /* call before *_setup (the reference abort()s here, sw-vector.c:463) */
+#define GM_E_RANGE      -4   /* match*qrlen >= 32768 (ref: sw-vector.c:393-398, exit(1) there) */
+#define GM_E_OVERFLOW   -5   /* a per-read candidate list exceeded every configured capacity */
+#define GM_E_NOMEM      -6
+
+const char *gm_last_error(void);
+/* number of visible HIP devices (0 when none); never initialises more than the runtime */
+int gm_device_count(void);
+
+/* ---- scoring / pipeline parameters = the reference's globals (ref: gmapper/gmapper.h:47-127) ---- */
+typedef struct gm_params {
+  int match_score, mismatch_score;             /* ref: gmapper-defaults.h:45-46   (10, -15) */
+  int a_gap_open_score, a_gap_extend_score;    /* ref: gmapper-defaults.h:47,49   (-33, -7)  gap along the genome */
+  int b_gap_open_score, b_gap_extend_score;    /* ref: gmapper-defaults.h:48,50   (-33, -3)  gap along the read   */
+  double window_len;                           /* ref: gmapper-defaults.h:31  140.0 (%; negative = absolute) */
+  double window_overlap;                       /* ref: gmapper-defaults.h:32   90.0 */
+  double window_gen_threshold;                 /* ref: gmapper-defaults.h:62   55.0 */
+  double sw_vect_threshold, sw_full_threshold; /* ref: gmapper-defaults.h:67-68; LS: vect := full (gmapper.c:2456-2458) */
+  int match_mode;                              /* ref: gmapper-defaults.h:34    2 */
+  int num_outputs, num_tmp_outputs;            /* ref: gmapper.h:53-55         10, 30 */
+  int anchor_width;                            /* ref: gmapper-defaults.h:36    8 */
+  int region_bits, region_overlap;             /* ref: gmapper-defaults.h:22-23 11, 50 */
+  uint32_t list_cutoff;                        /* 0 = automatic (ref: gmapper.c:2811-2837) */
+  int hash_filter_calls;                       /* ref: gmapper-defaults.h:17 true; 0 == -Z */
+  int tiebreak_rev;                            /* Tflag, ref: gmapper.h:87 true */
+  int sam_unaligned;                           /* ref: gmapper.h:185 false */
+  int longest_read_len;                        /* ref: gmapper-defaults.h:72 1000 */
+} gm_params_t;
+
+void gm_params_default(gm_params_t *p);        /* letter-space defaults of the reference binary */
+
+/* ---------------------------------------------------------------------------------------------
+ * S5: index.  Replaces load_genome() and the globals genomemap / genomemap_len / genome_contigs /
+ * contig_offsets / genome_len (ref: gmapper/genome.c:1012-1182, gmapper/gmapper.h:262-275).
+ * contigs[c] is the reference's own 4-bit bitfield (8 bases per uint32, base i in nibble i%8 of
+ * word i/8; ref: common/util.h:41, common/fasta.c:609-673).  seeds are "0/1" strings
+ * (ref: gmapper/seeds.c:9-43); n_seeds == 0 selects the binary's default 3 seeds of weight 12
+ * (ref: gmapper-defaults.h:212-227).  The index is built on the device (histogram-free radix
+ * sort of (k-mer, position) pairs) and stays resident in HBM.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gm_index gm_index_t;
+int  gm_index_build(gm_index_t **out, int device, int n_contigs, const uint32_t *const *contigs,
+                    const uint32_t *contig_len, const char *const *contig_names,
+                    int n_seeds, const char *const *seeds, const gm_params_t *params);
+void gm_index_free(gm_index_t *ix);
+/* introspection (mirrors the reference's globals) */
+uint32_t gm_index_list_cutoff(const gm_index_t *ix);
+uint64_t gm_index_bytes(const gm_index_t *ix);
+int      gm_index_n_slabs(const gm_index_t *ix);
+/* genomemap_len[sn][mapidx] / genomemap[sn][mapidx][0..len) copied back to the host (tests) */
+int gm_index_get_list(const gm_index_t *ix, int sn, uint32_t mapidx, uint32_t *len, uint32_t *positions, uint32_t cap);
+/* raw device pointers + sizes of the resident arrays, for the single RCCL broadcast at start-up
+ * (SURVEY.md section 8(e)); kind: 0 genome, 1+2*sn directory of seed sn, 2+2*sn positions of seed sn */
+int gm_index_device_array(const gm_index_t *ix, int kind, void **dev_ptr, uint64_t *bytes);
+/* allocate an index with the same shape (from the metadata blob of a built index) so that a
+ * non-root rank can receive the arrays; meta is host memory */
+int gm_index_meta(const gm_index_t *ix, void *meta, uint64_t *meta_bytes);
+int gm_index_alloc_like(gm_index_t **out, int device, const void *meta, uint64_t meta_bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * S1: vector Smith-Waterman filter (score only).  ref: common/sw-vector.c:388-515
+ * Same parameter lists as the reference (penalties passed negative).  State is per calling
+ * thread, as in the reference (threadprivate).  genome_ls/initbp/is_rna are accepted for
+ * signature compatibility; colour space is not implemented (use_colours must be 0).
+ * ------------------------------------------------------------------------------------------- */
+int sw_vector_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
+                    int match, int mismatch, int use_colours, bool reset_stats);
+int sw_vector(uint32_t *genome, int goff, int glen, uint32_t *read, int rlen,
+              uint32_t *genome_ls, int initbp, bool is_rna);
+void sw_vector_stats(uint64_t *invocs, uint64_t *cells, double *secs);
+int sw_vector_cleanup(void);
+/* batch form: n independent windows; genome/read are host bitfields, words are uploaded once.
+ * g_off[i] indexes into `genome` (one shared bitfield), reads[i*read_words .. ) holds read i. */
+int gm_sw_vector_batch(int n, const uint32_t *genome, uint64_t genome_words, const int64_t *g_off, const int *glen,
+                       const uint32_t *reads, int read_words, const int *rlen, int *scores);
+
+/* ---------------------------------------------------------------------------------------------
+ * S2: full Smith-Waterman with traceback, letter space.  ref: common/sw-full-ls.c:568-683
+ * struct layouts follow the reference (ref: common/sw-full-common.h:13-48, gmapper-definitions.h:66-74)
+ * for the fields this path fills; dbalign/qralign are malloc()ed and owned by the caller,
+ * as with the reference's xstrdup (ref: sw-full-ls.c:676-677).
+ * ------------------------------------------------------------------------------------------- */
+struct gm_anchor { long long x, y; int length, width, weight, cn, score; };
+struct gm_sw_full_results {
+  int read_start, rmapped, genome_start, gmapped, matches, mismatches, insertions, deletions, score;
+  char *dbalign, *qralign;
+};
+int sw_full_ls_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
+                     int match, int mismatch, bool reset_stats, int anchor_width);
+void sw_full_ls(uint32_t *genome, int goff, int glen, uint32_t *read, int rlen, int threshscore, int maxscore,
+                struct gm_sw_full_results *sfr, bool revcmpl, struct gm_anchor *anchors, int anchors_cnt,
+                int local_alignment);
+int sw_full_ls_cleanup(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * S4: the per-read pipeline.  Replaces handle_read() for unpaired letter-space reads
+ * (ref: gmapper/mapping.c:1773-1868) and the read loop body around it (ref: gmapper/gmapper.c:436-560).
+ * Input: n reads of one length, as 4-bit bitfields (read_words = (read_len+7)/8 words each), plus
+ * names ('\n' separated) and original sequence text for SAM SEQ.  Output: the SAM records the
+ * reference would append to its thread output buffer, in input order (ref: gmapper/output.c:227-774).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gm_session gm_session_t;
+int  gm_session_create(gm_session_t **out, const gm_index_t *ix, const gm_params_t *params, int max_batch_reads);
+void gm_session_free(gm_session_t *s);
+
+typedef struct gm_map_stats {
+  uint64_t reads, reads_matched, sam_records;
+  uint64_t lookups, list_entries, list_bytes;      /* seed-lookup algorithmic work (SURVEY.md 8(d) B_seed) */
+  uint64_t survivors, anchors, windows;            /* after region filter / collapse / window generation */
+  uint64_t vec_calls, vec_cells, vec_bypassed;     /* pass-1 vector SW (ref: sw-vector.c:509 swcells) */
+  uint64_t full_calls, full_cells;                 /* pass-2 (vector re-score + banded full SW) */
+  uint64_t exact_order_reads;                      /* read-strands that needed heap-order emulation */
+  uint64_t retries;                                /* capacity-overflow re-runs */
+  double   ms_lookup, ms_anchors, ms_pass1, ms_select, ms_pass2, ms_host;   /* device time per stage (events) */
+} gm_map_stats_t;
+
+/* host-buffer form: reads are uploaded, SAM text is returned in a malloc()ed buffer (*sam, *sam_len) */
+int gm_map_reads(gm_session_t *s, int n_reads, int read_len, const uint32_t *reads_packed,
+                 const char *names, char **sam, size_t *sam_len, gm_map_stats_t *stats);
+/* device-resident form for measurement: reads_dev is a device pointer to the same packed layout;
+ * runs the whole device pipeline and the host finalisation (pass-2 selection, MAPQ, SAM text)
+ * unless emit_sam == 0, in which case only the alignment records are produced and counted. */
+int gm_map_reads_device(gm_session_t *s, int n_reads, int read_len, const void *reads_dev,
+                        int emit_sam, char **sam, size_t *sam_len, gm_map_stats_t *stats);
+void gm_free(void *p);
+
+/* per-read top-K candidate rows after pass 1 (heap array order), for stage parity tests:
+ * 12 x int64 per row: read st cn g_off w_len score_vector pct_score_vector matches ax ay alen awidth */
+int gm_debug_tophits(gm_session_t *s, int n_reads, int read_len, const uint32_t *reads_packed,
+                     long long *rows, long cap, long *n_rows);
+
+/* time of the dominant kernel (seed lookup) during the last gm_map_* call, from HIP events on the
+ * session's own stream, and the algorithmic bytes it moved */
+int gm_last_lookup_timing(gm_session_t *s, double *ms, uint64_t *alg_bytes, int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

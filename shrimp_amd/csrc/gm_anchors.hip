@@ -1,0 +1,362 @@
+// gm_anchors.hip -- K2: survivors -> ordered, collapsed anchors -> candidate windows.
+// One wave per read-strand.  Replaces
+//   read_get_anchor_list_per_strand  ref: gmapper/mapping.c:861-1006  (k-way heap merge + colinear collapse)
+//   read_get_hit_list_per_strand     ref: gmapper/mapping.c:1025-1229 (window generation + insertion sort)
+//
+// Ordering.  The reference merges the lists with a binary min-heap keyed by position only
+// (ref: common/heap.h:44-139), so the order of *equal* positions depends on the heap's history.
+// A wave sorts the survivors by (position, read offset y, seed) with a bitonic network in LDS.
+// That order is equivalent to the reference's whenever all survivors sharing a position also share
+// y: such a group is merged by anchor_uw_join into one anchor of length max(span) and weight = group
+// size, whatever the order inside the group (DESIGN.md "tie order").  When a position occurs
+// with two different y, lane 0 replays the reference's heap (same insert order, same strict-<
+// sift rules) over the survivors to obtain the exact pop order.  Both cases are exact.
+#include "gm_common.h"
+#include "gm_internal.h"
+
+#define K2_NONE 0xFFFFu
+
+struct K2Ws {            // per-wave workspace (LDS or global)
+  uint64_t* key;         // [npad]  sort keys; later anchors: x<<32 | len<<16 | weight
+  uint32_t* aux;         // [npad]  y | cn<<16
+  uint16_t* nxt;         // [kmax]  exact path: next survivor of the same list
+  uint16_t* ord;         // [kmax]  exact path: pop order
+  uint16_t* first;       // [NL]    exact path: cursor per list
+  uint32_t* hk;          // [NL]    exact path: heap keys / temp
+  uint16_t* hr;          // [NL]    exact path: heap payload (list id)
+  int16_t*  cache;       // [read_len] anchor_cache (ref: mapping.c:871,909-910)
+};
+
+__device__ __forceinline__ void k2_sync() { __syncthreads(); }
+
+__device__ void k2_bitonic(uint64_t* key, int npad, int lane) {
+  for (int k = 2; k <= npad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = lane; t < (npad >> 1); t += GM_WAVE) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i | j;
+        const bool up = ((i & k) == 0);
+        const uint64_t a = key[i], b = key[l];
+        if ((a > b) == up) { key[i] = b; key[l] = a; }
+      }
+      k2_sync();
+    }
+}
+
+// anchor_join of two anchors (ref: common/anchors.c:9-52) in window-relative coordinates
+struct K2Box { long long x, y; int length, width; };
+__device__ __forceinline__ K2Box k2_join2(long long x0, long long y0, int l0, int w0, long long x1, long long y1, int l1, int w1) {
+  long long nw0 = x0 + y0, sw0 = x0 - y0, ne0 = sw0 + 2 * (w0 - 1), se0 = nw0 + 2 * (l0 - 1);
+  long long nw1 = x1 + y1, sw1 = x1 - y1, ne1 = sw1 + 2 * (w1 - 1), se1 = nw1 + 2 * (l1 - 1);
+  long long nw_min = min(nw0, nw1), sw_min = min(sw0, sw1), ne_max = max(ne0, ne1), se_max = max(se0, se1);
+  K2Box r;
+  if ((nw_min + sw_min) % 2 != 0) nw_min--;
+  r.x = (nw_min + sw_min) / 2;
+  r.y = nw_min - r.x;
+  if ((ne_max - sw_min) % 2 != 0) ne_max++;
+  r.width = (int)((ne_max - sw_min) / 2 + 1);
+  if ((se_max - nw_min) % 2 != 0) se_max++;
+  r.length = (int)((se_max - nw_min) / 2 + 1);
+  return r;
+}
+
+__device__ __forceinline__ int k2_threshold(double frac, int absval, int base) {
+  // (int)abs_or_pct(thr, base), ref: common/util.h:53 -- frac = thr/100.0 computed on the host
+  return frac < 0 ? absval : (int)((double)base * frac);
+}
+
+template <bool GLOBAL_WS>
+__global__ void __launch_bounds__(GM_WAVE)
+k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_len, int max_n_kmers, int NL,
+          const uint64_t* __restrict__ surv, const uint32_t* __restrict__ surv_cnt, int scap, int kmax,
+          uint8_t* __restrict__ ws_global, size_t ws_stride, uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_cnt, int max_big,
+          GmHit* __restrict__ hits, uint16_t* __restrict__ perm, uint32_t* __restrict__ hit_cnt, int hcap,
+          unsigned long long* __restrict__ stats) {
+  extern __shared__ __align__(16) uint8_t smem_raw[];
+  const int lane = threadIdx.x;
+  int rs;
+  if (GLOBAL_WS) {
+    const uint32_t nb = min(*big_cnt, (uint32_t)max_big);
+    if (blockIdx.x >= nb) return;
+    rs = (int)big_list[blockIdx.x];
+  } else {
+    rs = blockIdx.x;
+  }
+  const uint32_t n_all = surv_cnt[rs];
+  const int n = (int)min(n_all, (uint32_t)scap);
+  if (n == 0) { if (lane == 0) hit_cnt[rs] = 0; return; }
+  if (!GLOBAL_WS && n > kmax) {          // deferred to the global-workspace launch
+    if (lane == 0) {
+      uint32_t s = atomicAdd(big_cnt, 1u);
+      if (s < (uint32_t)max_big) big_list[s] = (uint32_t)rs; else atomicAdd(&stats[GS_OVERFLOW_SURV], 1ull);
+      hit_cnt[rs] = 0;
+    }
+    return;
+  }
+  int npad = 64; while (npad < n) npad <<= 1;
+  const int cap = GLOBAL_WS ? scap : kmax;      // array sizes
+
+  // carve the workspace
+  uint8_t* base = GLOBAL_WS ? (ws_global + (size_t)blockIdx.x * ws_stride) : smem_raw;
+  K2Ws ws;
+  ws.key = (uint64_t*)base;                      base += (size_t)cap * 8;
+  ws.aux = (uint32_t*)base;                      base += (size_t)cap * 4;
+  ws.hk = (uint32_t*)base;                       base += (size_t)NL * 4;
+  ws.nxt = (uint16_t*)base;                      base += (size_t)cap * 2;
+  ws.ord = (uint16_t*)base;                      base += (size_t)cap * 2;
+  ws.first = (uint16_t*)base;                    base += (size_t)((NL + 1) & ~1) * 2;
+  ws.hr = (uint16_t*)base;                       base += (size_t)((NL + 1) & ~1) * 2;
+  ws.cache = (int16_t*)base;
+
+  // ---- 1. keys: pos<<32 | y<<16 | sn; bitonic sort ----
+  const uint64_t* sv = surv + (size_t)rs * scap;
+  for (int t = lane; t < npad; t += GM_WAVE) {
+    uint64_t k = ~0ull;
+    if (t < n) {
+      const uint64_t e = sv[t];
+      const uint32_t off = (uint32_t)e;
+      const uint32_t sn = off / (uint32_t)max_n_kmers, y = off - sn * (uint32_t)max_n_kmers;
+      k = (e & 0xFFFFFFFF00000000ull) | ((uint64_t)y << 16) | sn;
+    }
+    ws.key[t] = k;
+  }
+  k2_sync();
+  k2_bitonic(ws.key, npad, lane);
+
+  // ---- 2. does any position carry two different read offsets?  then replay the heap ----
+  bool danger = false;
+  for (int t = lane + 1; t < n; t += GM_WAVE) {
+    const uint64_t a = ws.key[t - 1], b = ws.key[t];
+    danger |= ((a >> 32) == (b >> 32)) && (((a >> 16) & 0xFFFF) != ((b >> 16) & 0xFFFF));
+  }
+  danger = __any(danger);
+  if (danger) {
+    if (lane == 0) {
+      atomicAdd(&stats[GS_EXACT_ORDER], 1ull);
+      for (int o = 0; o < NL; o++) ws.first[o] = K2_NONE;
+      for (int t = n - 1; t >= 0; t--) {
+        const uint64_t k = ws.key[t];
+        const int off = (int)(k & 0xFFFF) * max_n_kmers + (int)((k >> 16) & 0xFFFF);
+        ws.nxt[t] = ws.first[off]; ws.first[off] = (uint16_t)t;
+      }
+      // heap_uu (ref: common/heap.h:44-139): 1-based nodes over hk/hr[0..load)
+      int load = 0;
+      auto pos_of = [&](int t) -> uint32_t { return (uint32_t)(ws.key[t] >> 32); };
+      auto down = [&](int node) {
+        for (;;) {
+          int left = node * 2, right = left + 1, mn = node;
+          if (left <= load && ws.hk[left - 1] < ws.hk[node - 1]) mn = left;
+          if (right <= load && ws.hk[right - 1] < ws.hk[mn - 1]) mn = right;
+          if (mn == node) break;
+          uint32_t tk = ws.hk[mn - 1]; ws.hk[mn - 1] = ws.hk[node - 1]; ws.hk[node - 1] = tk;
+          uint16_t tr = ws.hr[mn - 1]; ws.hr[mn - 1] = ws.hr[node - 1]; ws.hr[node - 1] = tr;
+          node = mn;
+        }
+      };
+      for (int o = 0; o < NL; o++) {          // initial inserts in (seed, read position) order, ref: mapping.c:913-935
+        if (ws.first[o] == K2_NONE) continue;
+        ws.hk[load] = pos_of(ws.first[o]); ws.hr[load] = (uint16_t)o; load++;
+        int node = load, parent = node / 2;
+        while (node > 1 && ws.hk[node - 1] < ws.hk[parent - 1]) {
+          uint32_t tk = ws.hk[parent - 1]; ws.hk[parent - 1] = ws.hk[node - 1]; ws.hk[node - 1] = tk;
+          uint16_t tr = ws.hr[parent - 1]; ws.hr[parent - 1] = ws.hr[node - 1]; ws.hr[node - 1] = tr;
+          node = parent; parent = node / 2;
+        }
+      }
+      int m = 0;
+      while (load > 0) {                      // ref: mapping.c:937-989
+        const int o = ws.hr[0];
+        const int t = ws.first[o];
+        ws.ord[m++] = (uint16_t)t;
+        const uint16_t nx = ws.nxt[t];
+        if (nx != K2_NONE) { ws.first[o] = nx; ws.hk[0] = pos_of(nx); ws.hr[0] = (uint16_t)o; down(1); }
+        else { load--; if (load > 0) { ws.hk[0] = ws.hk[load]; ws.hr[0] = ws.hr[load]; down(1); } }
+      }
+      // apply the pop order: it only permutes entries inside groups of equal position, so only the
+      // low words (y, seed) move; hk is free now and serves as the per-group temporary.
+      int g0 = 0;
+      while (g0 < n) {
+        int g1 = g0 + 1;
+        while (g1 < n && (ws.key[g1] >> 32) == (ws.key[g0] >> 32)) g1++;
+        if (g1 - g0 > 1) {
+          for (int g = g0; g < g1; g++) ws.hk[g - g0] = (uint32_t)ws.key[ws.ord[g]];
+          for (int g = g0; g < g1; g++) ws.key[g] = (ws.key[g] & 0xFFFFFFFF00000000ull) | ws.hk[g - g0];
+        }
+        g0 = g1;
+      }
+    }
+    k2_sync();
+  }
+
+  // ---- 3. contig of every entry (get_contig_num, ref: gmapper.h:373-405), then colinear collapse ----
+  for (int t = lane; t < n; t += GM_WAVE) {
+    const uint64_t k = ws.key[t];
+    const uint32_t x = (uint32_t)(k >> 32);
+    int lo = 0, hi = ix.n_contigs;
+    while (hi - lo > 1) { int m = (lo + hi) >> 1; if (ix.contig_off[m] <= x) lo = m; else hi = m; }
+    ws.aux[t] = (uint32_t)((k >> 16) & 0xFFFF) | ((uint32_t)lo << 16);
+  }
+  for (int d = lane; d < read_len; d += GM_WAVE) ws.cache[d] = -1;
+  k2_sync();
+  __shared__ int sh_na;
+  if (lane == 0) {
+    int na = 0;
+    for (int t = 0; t < n; t++) {       // ref: mapping.c:937-971
+      const uint64_t k = ws.key[t];
+      const uint32_t x = (uint32_t)(k >> 32);
+      const uint32_t au = ws.aux[t];
+      const int y = (int)(au & 0xFFFF), cn = (int)(au >> 16);
+      const int len = ix.seed[(int)(k & 0xFFFF)].span;
+      const int diag = (int)(((long long)x + read_len - y) % read_len);
+      const int j = ws.cache[diag];
+      bool joined = false;
+      if (j >= 0) {
+        const uint64_t aj = ws.key[j];
+        const uint32_t auj = ws.aux[j];
+        const uint32_t xj = (uint32_t)(aj >> 32);
+        if ((int)(auj >> 16) == cn && ((long long)xj - (long long)(auj & 0xFFFF) == (long long)x - y)) {
+          // anchor_uw_join(dest = A[j], src), ref: common/anchors.c:98-119 (src.x >= dest.x here)
+          uint32_t lj = (uint32_t)(aj >> 16) & 0xFFFF, wj = (uint32_t)aj & 0xFFFF;
+          if ((long long)x + len > (long long)xj + lj) lj = (uint32_t)(x - xj + len);
+          wj = min(wj + 1u, 0xFFFFu);
+          ws.key[j] = ((uint64_t)xj << 32) | ((uint64_t)lj << 16) | wj;
+          joined = true;
+        }
+      }
+      if (!joined) {
+        ws.cache[diag] = (int16_t)na;
+        ws.key[na] = ((uint64_t)x << 32) | ((uint64_t)len << 16) | 1u;
+        ws.aux[na] = au;
+        na++;
+      }
+    }
+    sh_na = na;
+  }
+  k2_sync();
+  const int na = sh_na;
+
+  // ---- 4. window generation (ref: mapping.c:1048-1207), one anchor per lane ----
+  GmHit* H = hits + (size_t)rs * hcap;
+  const int match = sc.match;
+  int nh = 0;
+  for (int c0 = 0; c0 < na; c0 += GM_WAVE) {
+    const int i = c0 + lane;
+    bool pass = false; GmHit h;
+    if (i < na) {
+      const uint64_t ai = ws.key[i]; const uint32_t aui = ws.aux[i];
+      const long long xi = (long long)(ai >> 32); const int yi = (int)(aui & 0xFFFF);
+      const int leni = (int)((ai >> 16) & 0xFFFF), wi = (int)(ai & 0xFFFF);
+      const int cn = (int)(aui >> 16);
+      const long long coff = ix.contig_off[cn];
+      const long long clen = (long long)ix.contig_off[cn + 1] - coff;
+      int w_len = window_len;
+      if ((long long)w_len > clen) w_len = (int)clen;
+      long long gend = (xi - coff) + read_len - 1 - yi;
+      if (gend > clen - 1) gend = clen - 1;
+      const long long gstart = (gend >= window_len) ? gend - window_len : 0;
+      int max_idx = i;
+      int max_score = leni * match;
+      if (sc.match_mode == 2 && wi == 1) max_score = -1;
+      for (int j = i - 1; j >= 0; j--) {
+        const uint64_t aj = ws.key[j];
+        const long long xj = (long long)(aj >> 32);
+        if (xj < coff + gstart) break;
+        const int yj = (int)(ws.aux[j] & 0xFFFF);
+        if (yj >= yi) continue;
+        int short_len, long_len;
+        if (xi - yi > xj - yj) { short_len = (yi - yj) + leni; long_len = (int)(xi - xj) + leni; }
+        else { short_len = (int)(xi - xj) + leni; long_len = (yi - yj) + leni; }
+        int tmp;
+        if (long_len > short_len) tmp = short_len * match - sc.b_go - (long_len - short_len) * sc.b_ge;   // ref :1133-1135 (b_ penalties both ways)
+        else tmp = short_len * match;
+        if (tmp > max_score) { max_idx = j; max_score = tmp; }
+      }
+      const int base = (read_len < w_len ? read_len : w_len) * match;
+      if (sc.match_mode == 1 || max_score >= k2_threshold(sc.wgen_thr_frac, sc.wgen_abs, base)) {
+        const uint64_t am = ws.key[max_idx]; const uint32_t aum = ws.aux[max_idx];
+        const long long xm = (long long)(am >> 32);
+        const int x_len = (int)(xi - xm) + leni;
+        long long goff;
+        if ((window_len - x_len) / 2 < xm - coff) goff = (xm - coff) - (window_len - x_len) / 2; else goff = 0;
+        if (goff + w_len > clen) goff = clen - w_len;
+        K2Box b;
+        if (max_idx < i) {
+          b = k2_join2(xi - coff - goff, yi, leni, 1, xm - coff - goff, (int)(aum & 0xFFFF), (int)((am >> 16) & 0xFFFF), 1);
+        } else { b.x = xi - coff - goff; b.y = yi; b.length = leni; b.width = 1; }
+        h.g_off = (uint32_t)goff; h.ax = (int32_t)b.x; h.ay = (int32_t)b.y; h.alen = b.length; h.awidth = b.width;
+        h.score_window_gen = max_score; h.score_vector = -1; h.pct_score_vector = 0;
+        h.cn = (uint16_t)cn; h.w_len = (uint16_t)w_len;
+        const int mt = (max_idx == i) ? wi : wi + (int)(am & 0xFFFF);
+        h.matches = (uint16_t)min(mt, 0xFFFF); h.flags = 0;
+        pass = true;
+      }
+    }
+    const unsigned long long bal = __ballot(pass);
+    if (pass) {
+      const int slot = nh + __popcll(bal & ((1ull << lane) - 1ull));
+      if (slot < hcap) H[slot] = h;
+    }
+    nh += __popcll(bal);
+  }
+  k2_sync();   // anchors are dead from here; ws.key is reused for the window sort
+
+  // ---- 5. stable order by (contig, g_off) == the reference's insertion sort (ref: mapping.c:1210-1223) ----
+  const int nhc = min(nh, hcap);
+  uint16_t* P = perm + (size_t)rs * hcap;
+  if (nhc > 0) {
+    int hp = 64; while (hp < nhc) hp <<= 1;
+    // nhc <= na <= n <= cap, and hp <= npad
+    // the records were written by other lanes of this wave: read them back past the L1 (sc1 loads)
+    for (int t = lane; t < hp; t += GM_WAVE) {
+      uint64_t k = ~0ull;
+      if (t < nhc) {
+        const uint32_t go = __hip_atomic_load(&H[t].g_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t cw = __hip_atomic_load((const uint32_t*)&H[t].cn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        k = ((uint64_t)(cw & 0xFFFF) << 48) | ((uint64_t)go << 16) | (uint64_t)t;
+      }
+      ws.key[t] = k;
+    }
+    k2_sync();
+    k2_bitonic(ws.key, hp, lane);
+    for (int t = lane; t < nhc; t += GM_WAVE) P[t] = (uint16_t)(ws.key[t] & 0xFFFF);
+  }
+  if (lane == 0) {
+    hit_cnt[rs] = (uint32_t)nh;
+    atomicAdd(&stats[GS_ANCHORS], (unsigned long long)na);
+    atomicAdd(&stats[GS_WINDOWS], (unsigned long long)nhc);
+    if (nh > hcap) atomicAdd(&stats[GS_OVERFLOW_HITS], 1ull);
+  }
+}
+
+static size_t k2_ws_bytes(int cap, int NL, int read_len) {
+  size_t b = (size_t)cap * 8 + (size_t)cap * 4 + (size_t)NL * 4 + (size_t)cap * 2 * 2 + (size_t)((NL + 1) & ~1) * 2 * 2 + (size_t)read_len * 2;
+  return (b + 15) & ~(size_t)15;
+}
+
+int gm_anchors_kmax(int expected_survivors) {
+  int k = 512;
+  while (k < 2 * expected_survivors + 256 && k < 4096) k <<= 1;
+  return k;
+}
+size_t gm_anchors_big_ws_bytes(int scap, int NL, int read_len) { return k2_ws_bytes(scap, NL, read_len); }
+
+int gm_launch_anchors(const GmIndexDev& ix, const GmScoreDev& sc, int n_reads, int read_len, int window_len,
+                      const uint64_t* d_surv, const uint32_t* d_surv_cnt, int scap, int kmax,
+                      uint8_t* d_big_ws, uint32_t* d_big_list, uint32_t* d_big_cnt, int max_big,
+                      GmHit* d_hits, uint16_t* d_perm, uint32_t* d_hit_cnt, int hcap, unsigned long long* d_stats, hipStream_t stream) {
+  const int max_n_kmers = std::max(0, read_len - ix.min_seed_span + 1);
+  const int NL = ix.n_seeds * max_n_kmers;
+  if (n_reads == 0) return GM_OK;
+  GM_HIP(hipMemsetAsync(d_big_cnt, 0, 4, stream));
+  const size_t lds = k2_ws_bytes(kmax, NL, read_len);
+  if (lds > 64 * 1024) { gm_set_error("anchor kernel LDS %zu too large", lds); return GM_E_ARG; }
+  hipLaunchKernelGGL(k_anchors<false>, dim3(n_reads * 2), dim3(GM_WAVE), lds, stream, ix, sc, n_reads, read_len, window_len, max_n_kmers, NL,
+                     d_surv, d_surv_cnt, scap, kmax, (uint8_t*)nullptr, (size_t)0, d_big_list, d_big_cnt, max_big,
+                     d_hits, d_perm, d_hit_cnt, hcap, d_stats);
+  const size_t stride = k2_ws_bytes(scap, NL, read_len);
+  hipLaunchKernelGGL(k_anchors<true>, dim3(max_big), dim3(GM_WAVE), 0, stream, ix, sc, n_reads, read_len, window_len, max_n_kmers, NL,
+                     d_surv, d_surv_cnt, scap, kmax, d_big_ws, stride, d_big_list, d_big_cnt, max_big,
+                     d_hits, d_perm, d_hit_cnt, hcap, d_stats);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}

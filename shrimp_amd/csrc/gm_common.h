@@ -1,0 +1,95 @@
+// gm_common.h -- shared device/host definitions for libgmapper_hip.so (gfx950 only).
+// "ref:" citations are file:line in SHRiMP 2.2.3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/gmapper_hip.h"
+
+#define GM_MAX_SEEDS 16
+#define GM_WAVE 64
+
+// ---- error plumbing -------------------------------------------------------------------------
+void gm_set_error(const char* fmt, ...);
+#define GM_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      gm_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return GM_E_NODEVICE;                                                                   \
+    }                                                                                         \
+  } while (0)
+
+// ---- device-side view of the resident index --------------------------------------------------
+// Layout in HBM (DESIGN.md "Index layout"):
+//   genome : 4-bit codes, all contigs concatenated in *global* coordinates (position p is nibble p%8
+//            of word p/8); the reference's per-contig bitfields are re-packed once on the host.
+//   pos[sn]: all k-mer start positions of seed sn, sorted by (mapidx, position): the reference's
+//            genomemap[sn][mapidx][] lists back to back, each ascending (ref: genome.c:1156-1163).
+//   dir[sn]: K*S+1 offsets into pos[sn], K = 4^weight, S = n_slabs: dir[k*S+s] = first entry of
+//            list k whose position is >= s << slab_bits.  List k = [dir[k*S], dir[(k+1)*S]);
+//            its slice inside slab s = [dir[k*S+s], dir[k*S+s+1]).  S = 1 is plain CSR.
+struct GmSeedDev {
+  uint64_t mask;       // ref: seed_type.mask[0], LSB = most recent base (gmapper-definitions.h:59-63)
+  int span, weight;
+  const uint32_t* dir;
+  const uint32_t* pos;
+  uint32_t n_pos;
+};
+
+struct GmIndexDev {
+  const uint32_t* genome;
+  uint64_t total_len;                 // sum of contig lengths (< 2^32)
+  int n_contigs;
+  const uint32_t* contig_off;         // [n_contigs+1] global offsets (ref: contig_offsets[])
+  int n_seeds, min_seed_span, max_seed_span;
+  int slab_bits, n_slabs;
+  int region_bits, region_overlap;
+  uint32_t list_cutoff;
+  GmSeedDev seed[GM_MAX_SEEDS];
+};
+
+// ---- per-batch scoring constants (host computes every double-derived threshold) --------------
+struct GmScoreDev {
+  int match, mismatch;
+  int a_go, a_ge, b_go, b_ge;         // positive penalties (= -score), as sw_vector_setup stores them
+  int anchor_width;
+  int match_mode, min_matches;
+  int num_tmp_outputs;
+  int tiebreak_rev;
+  int hash_filter_calls;
+  double wgen_thr_frac;               // window_gen_threshold/100.0 (or <0: absolute = -value)
+  double vect_thr_frac, full_thr_frac;
+  int wgen_abs, vect_abs, full_abs;   // absolute thresholds when the fractions are negative
+};
+
+// candidate window ("read_hit", ref: gmapper-definitions.h:131-160) as it lives in HBM
+struct GmHit {
+  uint32_t g_off;        // contig-relative window start on the + strand (g_off_pos_strand)
+  int32_t  ax, ay;       // anchor box relative to the window (ref: struct anchor x,y)
+  int32_t  alen, awidth; // anchor length / width
+  int32_t  score_window_gen;
+  int32_t  score_vector; // -1 = not scored
+  int32_t  pct_score_vector;
+  uint16_t cn, w_len;
+  uint16_t matches, flags;
+};
+
+// result of pass 2 for one selected hit (what the host needs to finish A18/A19/A21)
+#define GM_MAX_OPS 2048
+struct GmFullRes {
+  int32_t read_idx;
+  int16_t st, gen_st;            // after reverse_hit (ref: mapping.c:254-263)
+  uint32_t cn; uint32_t g_off;   // g_off on the gen_st strand
+  int32_t w_len;
+  int32_t score_vector;          // re-scored in pass 2 (ref: mapping.c:386-388)
+  int32_t score_max, matches, score_window_gen;
+  int32_t score;                 // sw_full_ls score (0 = below threshold / not run)
+  int32_t read_start, rmapped, genome_start, gmapped;
+  int32_t n_match, n_mismatch, n_ins, n_del;
+  int32_t n_ops; uint32_t ops_off;   // ops bytes ('M','I','D') in the batch's op pool
+  int32_t sort_idx;
+};
+
+static inline int gm_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,760 @@
+// gm_host.hip -- host side of libgmapper_hip.so: handles, batching, and the part of the per-read
+// pipeline the reference keeps on the CPU next to its output code:
+//   hit_run_post_sw (LS)            ref: gmapper/mapping.c:1609-1625
+//   read_pass2 selection + dedup    ref: gmapper/mapping.c:1520-1606,1661-1750
+//   compute_unpaired_mqv            ref: gmapper/output.c:777-793
+//   hit_output (SAM record)         ref: gmapper/output.c:227-774, make_cigar :15-64
+// No CPU fallback exists for the device stages: without a HIP device every entry point fails.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include "gm_common.h"
+#include "gm_internal.h"
+
+// ---- errors -----------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void gm_set_error(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+}
+extern "C" const char* gm_last_error(void) { return g_err; }
+extern "C" int gm_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+extern "C" void gm_free(void* p) { free(p); }
+
+extern "C" void gm_params_default(gm_params_t* p) {
+  memset(p, 0, sizeof *p);
+  p->match_score = 10; p->mismatch_score = -15;
+  p->a_gap_open_score = -33; p->a_gap_extend_score = -7; p->b_gap_open_score = -33; p->b_gap_extend_score = -3;
+  p->window_len = 140.0; p->window_overlap = 90.0; p->window_gen_threshold = 55.0;
+  p->sw_vect_threshold = 50.0; p->sw_full_threshold = 50.0;     // LS: vect := full (ref: gmapper.c:2456-2458)
+  p->match_mode = 2; p->num_outputs = 10; p->num_tmp_outputs = 30; p->anchor_width = 8;
+  p->region_bits = 11; p->region_overlap = 50; p->list_cutoff = 0; p->hash_filter_calls = 1; p->tiebreak_rev = 1;
+  p->sam_unaligned = 0; p->longest_read_len = 1000;
+}
+
+static GmScoreDev make_score(const gm_params_t& P) {
+  GmScoreDev s; memset(&s, 0, sizeof s);
+  s.match = P.match_score; s.mismatch = P.mismatch_score;
+  s.a_go = -P.a_gap_open_score; s.a_ge = -P.a_gap_extend_score; s.b_go = -P.b_gap_open_score; s.b_ge = -P.b_gap_extend_score;
+  s.anchor_width = P.anchor_width; s.match_mode = P.match_mode; s.min_matches = P.match_mode;   // ref: gmapper.c:2625
+  s.num_tmp_outputs = P.num_tmp_outputs; s.tiebreak_rev = P.tiebreak_rev; s.hash_filter_calls = P.hash_filter_calls;
+  auto frac = [](double thr, double* f, int* a) { if (thr < 0) { *f = -1.0; *a = (int)(-thr); } else { *f = thr / 100.0; *a = 0; } };
+  frac(P.window_gen_threshold, &s.wgen_thr_frac, &s.wgen_abs);
+  frac(P.sw_vect_threshold, &s.vect_thr_frac, &s.vect_abs);
+  frac(P.sw_full_threshold, &s.full_thr_frac, &s.full_abs);
+  return s;
+}
+
+// ---- index ------------------------------------------------------------------------------------
+GmIndexDev GmIndexHost::dev_view() const {
+  GmIndexDev d; memset(&d, 0, sizeof d);
+  d.genome = d_genome; d.total_len = total_len; d.n_contigs = n_contigs; d.contig_off = d_contig_off;
+  d.n_seeds = n_seeds; d.min_seed_span = min_seed_span; d.max_seed_span = max_seed_span;
+  d.slab_bits = slab_bits; d.n_slabs = n_slabs; d.region_bits = params.region_bits; d.region_overlap = params.region_overlap;
+  d.list_cutoff = list_cutoff;
+  for (int i = 0; i < n_seeds; i++) {
+    d.seed[i].mask = seeds[i].mask; d.seed[i].span = seeds[i].span; d.seed[i].weight = seeds[i].weight;
+    d.seed[i].dir = seeds[i].d_dir; d.seed[i].pos = seeds[i].d_pos; d.seed[i].n_pos = seeds[i].n_pos;
+  }
+  return d;
+}
+
+static int add_seed(GmIndexHost* ix, const char* s) {   // add_spaced_seed, ref: gmapper/seeds.c:9-43
+  if (ix->n_seeds >= GM_MAX_SEEDS) return GM_E_ARG;
+  GmSeedHost& sd = ix->seeds[ix->n_seeds];
+  sd.mask = 0; sd.span = (int)strlen(s); sd.weight = 0; sd.text = s;
+  if (sd.span < 1 || sd.span > 32) return GM_E_ARG;
+  for (int i = 0; i < sd.span; i++) {
+    if (s[i] != '0' && s[i] != '1') return GM_E_ARG;
+    sd.mask = (sd.mask << 1) | (uint64_t)(s[i] == '1'); sd.weight += (s[i] == '1');
+  }
+  if (sd.weight < 1 || sd.weight > 14) return GM_E_ARG;   // MAX_SEED_WEIGHT, ref: gmapper-definitions.h:52
+  ix->max_seed_span = std::max(ix->max_seed_span, sd.span);
+  ix->min_seed_span = std::min(ix->min_seed_span, sd.span);
+  ix->n_seeds++;
+  return GM_OK;
+}
+
+static void choose_slabs(GmIndexHost* ix) {
+  int bits = 12;
+  while ((1ull << bits) < ix->total_len) bits++;
+  int sb = std::min(bits, 29);
+  if (const char* e = getenv("GM_SLAB_BITS")) sb = std::max(ix->params.region_bits + 2, std::min(31, atoi(e)));
+  ix->slab_bits = sb;
+  ix->n_slabs = (int)((ix->total_len + (1ull << sb) - 1) >> sb);
+  if (ix->n_slabs < 1) ix->n_slabs = 1;
+}
+
+extern "C" int gm_index_build(gm_index_t** out, int device, int n_contigs, const uint32_t* const* contigs,
+                              const uint32_t* contig_len, const char* const* contig_names,
+                              int n_seeds, const char* const* seeds, const gm_params_t* params) {
+  if (!out || n_contigs < 1 || !contigs || !contig_len) { gm_set_error("gm_index_build: bad arguments"); return GM_E_ARG; }
+  if (gm_device_count() <= device) { gm_set_error("no HIP device %d (the seed index lives in HBM; there is no CPU path)", device); return GM_E_NODEVICE; }
+  GM_HIP(hipSetDevice(device));
+  gm_index* ix = new gm_index();
+  ix->device = device;
+  if (params) ix->params = *params; else gm_params_default(&ix->params);
+  int rc = GM_OK;
+  if (n_seeds == 0) {   // load_default_seeds(0), letter space: ref gmapper-defaults.h:212-227
+    rc |= add_seed(ix, "11110111101111"); rc |= add_seed(ix, "1111011100100001111"); rc |= add_seed(ix, "1111000011001101111");
+  } else for (int i = 0; i < n_seeds; i++) rc |= add_seed(ix, seeds[i]);
+  if (rc != GM_OK) { delete ix; gm_set_error("invalid spaced seed"); return GM_E_ARG; }
+  ix->n_contigs = n_contigs;
+  ix->contig_off.resize(n_contigs + 1);
+  uint64_t tot = 0;
+  for (int c = 0; c < n_contigs; c++) {
+    ix->contig_off[c] = (uint32_t)tot; tot += contig_len[c];
+    char nm[64]; snprintf(nm, sizeof nm, "contig%d", c + 1);
+    ix->names.push_back(contig_names && contig_names[c] ? contig_names[c] : nm);
+  }
+  if (tot >= (1ull << 32)) { delete ix; gm_set_error("genome of %llu bp exceeds the reference's 32-bit global coordinates", (unsigned long long)tot); return GM_E_ARG; }
+  ix->contig_off[n_contigs] = (uint32_t)tot;
+  ix->total_len = tot;
+  // automatic list cutoff (ref: gmapper.c:2811-2837): max(1000, 100*total/4^maxW)
+  if (ix->params.list_cutoff == 0) {
+    int maxw = 0; for (int i = 0; i < ix->n_seeds; i++) maxw = std::max(maxw, ix->seeds[i].weight);
+    uint32_t cutoff = 1000; unsigned long long p4 = 1ull << (2 * maxw);
+    if ((uint32_t)((100ull * tot) / p4) > cutoff) cutoff = (uint32_t)((100ull * tot) / p4);
+    ix->list_cutoff = cutoff;
+  } else ix->list_cutoff = ix->params.list_cutoff;
+  choose_slabs(ix);
+  // re-pack the per-contig bitfields into one bitfield in global coordinates
+  ix->genome_words = (tot + 7) / 8 + 64;
+  std::vector<uint32_t> g(ix->genome_words, 0);
+  for (int c = 0; c < n_contigs; c++) {
+    const uint64_t off = ix->contig_off[c]; const uint32_t* src = contigs[c]; const uint64_t len = contig_len[c];
+    const int sh = (int)(off & 7) * 4; uint64_t w0 = off >> 3; const uint64_t nw = (len + 7) / 8;
+    for (uint64_t k = 0; k < nw; k++) {
+      uint32_t w = src[k];
+      if (k == nw - 1 && (len & 7)) w &= (1u << ((len & 7) * 4)) - 1u;
+      g[w0 + k] |= w << sh;
+      if (sh) g[w0 + k + 1] |= w >> (32 - sh);
+    }
+  }
+  hipStream_t stream; GM_HIP(hipStreamCreate(&stream));
+  GM_HIP(hipMalloc(&ix->d_genome, ix->genome_words * 4));
+  GM_HIP(hipMemcpyAsync(ix->d_genome, g.data(), ix->genome_words * 4, hipMemcpyHostToDevice, stream));
+  GM_HIP(hipMalloc(&ix->d_contig_off, (size_t)(n_contigs + 1) * 4));
+  GM_HIP(hipMemcpyAsync(ix->d_contig_off, ix->contig_off.data(), (size_t)(n_contigs + 1) * 4, hipMemcpyHostToDevice, stream));
+  GM_HIP(hipStreamSynchronize(stream));
+  rc = gm_index_build_device(ix, stream);
+  (void)hipStreamDestroy(stream);
+  if (rc != GM_OK) { gm_index_free(ix); return rc; }
+  *out = ix;
+  return GM_OK;
+}
+
+extern "C" void gm_index_free(gm_index_t* ix) {
+  if (!ix) return;
+  (void)hipSetDevice(ix->device);
+  (void)hipFree(ix->d_genome); (void)hipFree(ix->d_contig_off);
+  for (int i = 0; i < ix->n_seeds; i++) { (void)hipFree(ix->seeds[i].d_dir); (void)hipFree(ix->seeds[i].d_pos); }
+  delete ix;
+}
+extern "C" uint32_t gm_index_list_cutoff(const gm_index_t* ix) { return ix->list_cutoff; }
+extern "C" int gm_index_n_slabs(const gm_index_t* ix) { return ix->n_slabs; }
+extern "C" uint64_t gm_index_bytes(const gm_index_t* ix) {
+  uint64_t b = ix->genome_words * 4;
+  for (int i = 0; i < ix->n_seeds; i++) b += (ix->seeds[i].dir_words + (uint64_t)ix->seeds[i].n_pos) * 4;
+  return b;
+}
+extern "C" int gm_index_get_list(const gm_index_t* ix, int sn, uint32_t mapidx, uint32_t* len, uint32_t* positions, uint32_t cap) {
+  if (sn < 0 || sn >= ix->n_seeds || mapidx >= (1u << (2 * ix->seeds[sn].weight))) return GM_E_ARG;
+  GM_HIP(hipSetDevice(ix->device));
+  uint32_t be[2];
+  GM_HIP(hipMemcpy(&be[0], ix->seeds[sn].d_dir + (size_t)mapidx * ix->n_slabs, 4, hipMemcpyDeviceToHost));
+  GM_HIP(hipMemcpy(&be[1], ix->seeds[sn].d_dir + (size_t)(mapidx + 1) * ix->n_slabs, 4, hipMemcpyDeviceToHost));
+  *len = be[1] - be[0];
+  uint32_t n = std::min(*len, cap);
+  if (n && positions) GM_HIP(hipMemcpy(positions, ix->seeds[sn].d_pos + be[0], (size_t)n * 4, hipMemcpyDeviceToHost));
+  return GM_OK;
+}
+extern "C" int gm_index_device_array(const gm_index_t* ix, int kind, void** dev_ptr, uint64_t* bytes) {
+  if (kind == 0) { *dev_ptr = ix->d_genome; *bytes = ix->genome_words * 4; return GM_OK; }
+  int sn = (kind - 1) / 2; if (sn < 0 || sn >= ix->n_seeds) return GM_E_ARG;
+  if ((kind - 1) % 2 == 0) { *dev_ptr = ix->seeds[sn].d_dir; *bytes = (ix->seeds[sn].dir_words + 16) * 4; }
+  else { *dev_ptr = ix->seeds[sn].d_pos; *bytes = ((uint64_t)ix->seeds[sn].n_pos + 64) * 4; }
+  return GM_OK;
+}
+
+// metadata blob: everything but the device arrays (fixed header + contig offsets + names + seed strings)
+struct MetaHdr { uint64_t magic, total_len, genome_words; int32_t n_contigs, n_seeds, slab_bits, n_slabs; uint32_t list_cutoff, pad; gm_params_t params;
+                 uint32_t n_pos[GM_MAX_SEEDS]; uint64_t dir_words[GM_MAX_SEEDS]; };
+extern "C" int gm_index_meta(const gm_index_t* ix, void* meta, uint64_t* meta_bytes) {
+  std::string blob;
+  MetaHdr h; memset(&h, 0, sizeof h);
+  h.magic = 0x474D4958ull; h.total_len = ix->total_len; h.genome_words = ix->genome_words; h.n_contigs = ix->n_contigs; h.n_seeds = ix->n_seeds;
+  h.slab_bits = ix->slab_bits; h.n_slabs = ix->n_slabs; h.list_cutoff = ix->list_cutoff; h.params = ix->params;
+  for (int i = 0; i < ix->n_seeds; i++) { h.n_pos[i] = ix->seeds[i].n_pos; h.dir_words[i] = ix->seeds[i].dir_words; }
+  blob.append((const char*)&h, sizeof h);
+  blob.append((const char*)ix->contig_off.data(), (size_t)(ix->n_contigs + 1) * 4);
+  for (auto& n : ix->names) { blob += n; blob.push_back('\0'); }
+  for (int i = 0; i < ix->n_seeds; i++) { blob += ix->seeds[i].text; blob.push_back('\0'); }
+  if (meta && *meta_bytes >= blob.size()) memcpy(meta, blob.data(), blob.size());
+  *meta_bytes = blob.size();
+  return GM_OK;
+}
+extern "C" int gm_index_alloc_like(gm_index_t** out, int device, const void* meta, uint64_t meta_bytes) {
+  if (meta_bytes < sizeof(MetaHdr)) return GM_E_ARG;
+  MetaHdr h; memcpy(&h, meta, sizeof h);
+  if (h.magic != 0x474D4958ull) return GM_E_ARG;
+  if (gm_device_count() <= device) { gm_set_error("no HIP device %d", device); return GM_E_NODEVICE; }
+  GM_HIP(hipSetDevice(device));
+  gm_index* ix = new gm_index();
+  ix->device = device; ix->params = h.params; ix->total_len = h.total_len; ix->genome_words = h.genome_words; ix->n_contigs = h.n_contigs;
+  ix->slab_bits = h.slab_bits; ix->n_slabs = h.n_slabs; ix->list_cutoff = h.list_cutoff;
+  const char* p = (const char*)meta + sizeof h;
+  ix->contig_off.assign((const uint32_t*)p, (const uint32_t*)p + h.n_contigs + 1); p += (size_t)(h.n_contigs + 1) * 4;
+  for (int c = 0; c < h.n_contigs; c++) { ix->names.push_back(p); p += strlen(p) + 1; }
+  for (int i = 0; i < h.n_seeds; i++) { if (add_seed(ix, p) != GM_OK) { delete ix; return GM_E_ARG; } p += strlen(p) + 1; }
+  GM_HIP(hipMalloc(&ix->d_genome, ix->genome_words * 4));
+  GM_HIP(hipMalloc(&ix->d_contig_off, (size_t)(h.n_contigs + 1) * 4));
+  GM_HIP(hipMemcpy(ix->d_contig_off, ix->contig_off.data(), (size_t)(h.n_contigs + 1) * 4, hipMemcpyHostToDevice));
+  for (int i = 0; i < h.n_seeds; i++) {
+    ix->seeds[i].n_pos = h.n_pos[i]; ix->seeds[i].dir_words = h.dir_words[i];
+    GM_HIP(hipMalloc(&ix->seeds[i].d_dir, (h.dir_words[i] + 16) * 4));
+    GM_HIP(hipMalloc(&ix->seeds[i].d_pos, ((uint64_t)h.n_pos[i] + 64) * 4));
+  }
+  *out = ix;
+  return GM_OK;
+}
+
+// ---- session ----------------------------------------------------------------------------------
+struct gm_session {
+  const gm_index* ix = nullptr;
+  gm_params_t P; GmScoreDev sc;
+  double score_alpha = 0, score_beta = 0;
+  int max_batch = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[12];
+  // capacities (grown on overflow)
+  int cur_len = -1, scap = 0, hcap = 0, kmax = 0, rcap_per_read = 8, max_big = 1024, ops_stride = 0, p2_grid = 2048;
+  // device buffers
+  uint32_t* d_reads = nullptr; uint64_t* d_surv = nullptr; uint32_t* d_surv_cnt = nullptr;
+  GmHit* d_hits = nullptr; uint16_t* d_perm = nullptr; uint32_t* d_hit_cnt = nullptr; unsigned long long* d_slots = nullptr;
+  uint8_t* d_big_ws = nullptr; uint32_t* d_big_list = nullptr; uint32_t* d_big_cnt = nullptr;
+  int32_t* d_sel = nullptr; uint32_t* d_sel_cnt = nullptr; uint32_t* d_sel_off = nullptr; uint32_t* d_work = nullptr; uint32_t* d_n_work = nullptr;
+  GmFullRes* d_res = nullptr; uint8_t* d_ops = nullptr; uint8_t* d_back = nullptr; size_t back_stride = 0;
+  unsigned long long* d_stats = nullptr;
+  // host staging
+  std::vector<GmFullRes> h_res; std::vector<uint8_t> h_ops; std::vector<uint32_t> h_sel_cnt, h_sel_off; std::vector<uint32_t> h_reads;
+  // last lookup timing
+  double last_lookup_ms = 0; uint64_t last_lookup_bytes = 0; int last_lookup_launches = 0;
+};
+
+static void free_buffers(gm_session* s) {
+  void* ptrs[] = {s->d_reads, s->d_surv, s->d_surv_cnt, s->d_hits, s->d_perm, s->d_hit_cnt, s->d_slots, s->d_big_ws, s->d_big_list, s->d_big_cnt,
+                  s->d_sel, s->d_sel_cnt, s->d_sel_off, s->d_work, s->d_n_work, s->d_res, s->d_ops, s->d_back};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  s->d_reads = nullptr; s->d_surv = nullptr; s->d_surv_cnt = nullptr; s->d_hits = nullptr; s->d_perm = nullptr; s->d_hit_cnt = nullptr; s->d_slots = nullptr;
+  s->d_big_ws = nullptr; s->d_big_list = nullptr; s->d_big_cnt = nullptr; s->d_sel = nullptr; s->d_sel_cnt = nullptr; s->d_sel_off = nullptr;
+  s->d_work = nullptr; s->d_n_work = nullptr; s->d_res = nullptr; s->d_ops = nullptr; s->d_back = nullptr;
+}
+
+static int pow2ceil(long long v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+static int window_len_of(const gm_params_t& P, int read_len) {   // ref: gmapper.c:530
+  double w = P.window_len < 0 ? -P.window_len : read_len * (P.window_len / 100.0);
+  return (int)(uint16_t)w;
+}
+
+static int alloc_buffers(gm_session* s, int read_len) {
+  free_buffers(s);
+  const gm_index* ix = s->ix;
+  const int B = s->max_batch, rs = 2 * B;
+  const int read_words = (read_len + 7) / 8;
+  const int W = window_len_of(s->P, read_len);
+  const int max_n_kmers = std::max(0, read_len - ix->min_seed_span + 1);
+  const int NL = ix->n_seeds * max_n_kmers;
+  s->ops_stride = ((read_len + W + 15) / 16) * 16;
+  s->back_stride = (((size_t)read_len * W + 255) / 256) * 256;
+  GM_HIP(hipMalloc(&s->d_reads, (size_t)B * read_words * 4 + 64));
+  GM_HIP(hipMalloc(&s->d_surv, (size_t)rs * s->scap * 8));
+  GM_HIP(hipMalloc(&s->d_surv_cnt, (size_t)rs * 4));
+  GM_HIP(hipMalloc(&s->d_hits, (size_t)rs * s->hcap * sizeof(GmHit)));
+  GM_HIP(hipMalloc(&s->d_perm, (size_t)rs * s->hcap * 2));
+  GM_HIP(hipMalloc(&s->d_hit_cnt, (size_t)rs * 4));
+  GM_HIP(hipMalloc(&s->d_slots, (size_t)rs * s->hcap * 8));
+  GM_HIP(hipMalloc(&s->d_big_ws, (size_t)s->max_big * gm_anchors_big_ws_bytes(s->scap, NL, read_len)));
+  GM_HIP(hipMalloc(&s->d_big_list, (size_t)s->max_big * 4));
+  GM_HIP(hipMalloc(&s->d_big_cnt, 4));
+  GM_HIP(hipMalloc(&s->d_sel, (size_t)B * GM_SEL_MAX * 4));
+  GM_HIP(hipMalloc(&s->d_sel_cnt, (size_t)B * 4));
+  GM_HIP(hipMalloc(&s->d_sel_off, (size_t)B * 4));
+  const size_t rcap = (size_t)B * s->rcap_per_read;
+  GM_HIP(hipMalloc(&s->d_work, (size_t)B * GM_SEL_MAX * 4));
+  GM_HIP(hipMalloc(&s->d_n_work, 4));
+  GM_HIP(hipMalloc(&s->d_res, rcap * sizeof(GmFullRes)));
+  GM_HIP(hipMalloc(&s->d_ops, rcap * s->ops_stride));
+  GM_HIP(hipMalloc(&s->d_back, (size_t)s->p2_grid * s->back_stride));
+  s->cur_len = read_len;
+  return GM_OK;
+}
+
+static void choose_caps(gm_session* s, int read_len) {
+  const gm_index* ix = s->ix;
+  const int max_n_kmers = std::max(0, read_len - ix->min_seed_span + 1);
+  double lists = 0, avg_len = 0;
+  for (int i = 0; i < ix->n_seeds; i++) {
+    lists += std::max(0, read_len - ix->seeds[i].span + 1);
+    avg_len += (double)ix->seeds[i].n_pos / (double)(1ull << (2 * ix->seeds[i].weight)) / ix->n_seeds;
+  }
+  const double entries = lists * avg_len;
+  const double region = (double)(1 << ix->params.region_bits) + ix->params.region_overlap;
+  const double expected = entries * std::min(1.0, entries * region / std::max(1.0, (double)ix->total_len)) + lists;
+  s->scap = std::min(32768, std::max(512, pow2ceil((long long)(3 * expected) + 256)));
+  s->kmax = std::min(s->scap, gm_anchors_kmax((int)expected));
+  s->hcap = 64;
+  if (const char* e = getenv("GM_SCAP")) s->scap = std::min(32768, std::max(64, pow2ceil(atoi(e))));
+  if (const char* e = getenv("GM_HCAP")) s->hcap = std::min(32768, std::max(4, pow2ceil(atoi(e))));
+  if (const char* e = getenv("GM_KMAX")) s->kmax = std::min(s->scap, std::max(64, pow2ceil(atoi(e))));
+  (void)max_n_kmers;
+}
+
+extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const gm_params_t* params, int max_batch_reads) {
+  if (!out || !ix) return GM_E_ARG;
+  GM_HIP(hipSetDevice(ix->device));
+  gm_session* s = new gm_session();
+  s->ix = ix; s->P = params ? *params : ix->params;
+  s->sc = make_score(s->P);
+  // score -> probability derivation, LS branch (ref: gmapper.c:2557-2572)
+  const double pr_mismatch = .01;
+  s->score_alpha = ((double)s->P.match_score - (double)s->P.mismatch_score) / (log((1 - pr_mismatch) / (pr_mismatch / 3.0)) / log(2.0));
+  s->score_beta = (double)s->P.match_score - 2 * s->score_alpha - s->score_alpha * log(1 - pr_mismatch) / log(2.0);
+  s->max_batch = std::max(64, std::min(max_batch_reads > 0 ? max_batch_reads : 131072, 1 << 20));
+  GM_HIP(hipStreamCreate(&s->stream));
+  for (auto& e : s->ev) GM_HIP(hipEventCreate(&e));
+  GM_HIP(hipMalloc(&s->d_stats, GS_N * 8));
+  *out = s;
+  return GM_OK;
+}
+extern "C" void gm_session_free(gm_session_t* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->ix->device);
+  free_buffers(s);
+  (void)hipFree(s->d_stats);
+  for (auto& e : s->ev) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+// ---- host finalisation --------------------------------------------------------------------------
+struct FHit {            // one pass-2 candidate on the host (read_hit + sw_full_results subset)
+  const GmFullRes* r; const uint8_t* ops;
+  int score_full, pass2_key; double pct_score_full; double posterior; int mqv; double z0, z1;
+};
+
+static inline char* put_uint(char* p, unsigned long long v) {
+  char tmp[24]; int n = 0;
+  do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+  while (n) *p++ = tmp[--n];
+  return p;
+}
+static inline char* put_int(char* p, long long v) { if (v < 0) { *p++ = '-'; return put_uint(p, (unsigned long long)(-v)); } return put_uint(p, (unsigned long long)v); }
+static inline char* put_str(char* p, const char* s, size_t n) { memcpy(p, s, n); return p + n; }
+
+static int qv_from_pr_corr(double pr_corr) {   // ref: common/util.h:267-283
+  double pr_err = 1 - pr_corr;
+  if (pr_err > .99999999) return 0; else if (pr_err < 1E-25) return 250;
+  return (int)(-10.0 * log(pr_err) / log(10.0));
+}
+static int double_to_neglog(double x) { return (int)((double)1000 * -log(x)); }   // ref: common/util.h:297-301
+
+static int cmp_gen_start(const FHit* a, const FHit* b) {   // ref: mapping.c:1485-1494
+  if (a->r->cn != b->r->cn) return (int)a->r->cn - (int)b->r->cn;
+  if (a->r->gen_st != b->r->gen_st) return a->r->gen_st - b->r->gen_st;
+  return a->r->genome_start - b->r->genome_start;
+}
+static int cmp_gen_end(const FHit* a, const FHit* b) {     // ref: mapping.c:1496-1506
+  if (a->r->cn != b->r->cn) return (int)a->r->cn - (int)b->r->cn;
+  if (a->r->gen_st != b->r->gen_st) return a->r->gen_st - b->r->gen_st;
+  return (-a->r->genome_start - a->r->rmapped + a->r->n_del - a->r->n_ins) - (-b->r->genome_start - b->r->rmapped + b->r->n_del - b->r->n_ins);
+}
+template <class Cmp>
+static void dedup_pass(std::vector<FHit*>& v, Cmp cmp) {     // ref: mapping.c:1552-1600 (glibc qsort == stable merge sort here)
+  std::stable_sort(v.begin(), v.end(), [&](const FHit* a, const FHit* b) { return cmp(a, b) < 0; });
+  size_t i = 0, k = 0, n = v.size();
+  while (i < n) {
+    int mx = v[i]->pass2_key; size_t mi = i, j = i + 1;
+    while (j < n && !cmp(v[i], v[j])) { if (v[j]->pass2_key > mx) { mx = v[j]->pass2_key; mi = j; } j++; }
+    if (mi != k) v[k] = v[mi];
+    k++; i = j;
+  }
+  v.resize(k);
+}
+
+static const char CODE2SEQ[17] = "ACGTNNNNNNNNNNNN";   // SEQ letter of an aligned read base (ref: output.c:485-533: non-ACGTN -> N)
+static inline char rc_char(char c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'N'; } }
+
+struct Finalizer {
+  const gm_session* s; int read_len, read_words; const uint32_t* reads;   // host copy of the packed reads of this sub-batch
+  const char* const* name_ptr; const int* name_len; long name_base;
+
+  // emits the SAM records of read `rd` (local index) into out; returns number of records
+  int finalize_read(int rd, const GmFullRes* res, const uint8_t* ops, int ops_stride, int n, std::string& out, std::vector<FHit>& fh, std::vector<FHit*>& p2) const {
+    const gm_params_t& P = s->P; const gm_index* ix = s->ix;
+    fh.clear(); p2.clear();
+    fh.resize(n);
+    for (int i = 0; i < n; i++) {
+      FHit& h = fh[i]; h.r = &res[i]; h.ops = ops + (size_t)res[i].ops_off; h.mqv = 255; h.z0 = h.z1 = 0; h.posterior = 0;
+      h.score_full = h.r->score;
+      h.pct_score_full = (1000 * 100 * h.score_full) / h.r->score_max;             // ref: mapping.c:400-401
+      if (h.score_full > 0) {                                                      // hit_run_post_sw, ref: mapping.c:1609-1625
+        const double a = s->score_alpha, b = s->score_beta;
+        h.posterior = pow(2.0, ((double)h.r->score - (double)h.r->rmapped * (2.0 * a + b)) / a);
+        int ps = (int)rint(a * log(h.posterior) / log(2.0) + (double)h.r->rmapped * (2.0 * a + b));
+        if (ps < 0) ps = 0;
+        h.score_full = ps; h.pct_score_full = (1000 * 100 * ps) / h.r->score_max;
+      }
+      h.pass2_key = P.sw_full_threshold < 0 ? h.score_full : (int)h.pct_score_full;
+      const double thr = P.sw_full_threshold < 0 ? -P.sw_full_threshold : h.r->score_max * (P.sw_full_threshold / 100.0);
+      if (h.score_full >= thr) p2.push_back(&h);                                   // ref: mapping.c:1661 (double compare)
+    }
+    dedup_pass(p2, cmp_gen_start);
+    dedup_pass(p2, cmp_gen_end);
+    std::stable_sort(p2.begin(), p2.end(), [](const FHit* a, const FHit* b) { return (b->pass2_key - a->pass2_key) < 0; });   // ref :1479-1482,1678
+    if ((int)p2.size() > P.num_outputs) p2.resize(P.num_outputs);
+    const uint32_t* rw = reads + (size_t)rd * read_words;
+    char nbuf[32]; const char* nm; size_t nl;
+    if (name_ptr) { nm = name_ptr[rd]; nl = (size_t)name_len[rd]; }
+    else { nl = (size_t)snprintf(nbuf, sizeof nbuf, "r%ld", name_base + rd); nm = nbuf; }
+    const size_t need = 64 + nl + 4 * (size_t)read_len + 256;
+    if (p2.empty()) {
+      if (P.sam_unaligned) {                                                       // ref: output.c:411-466
+        size_t o = out.size(); out.resize(o + need); char* p = &out[o];
+        p = put_str(p, nm, nl); p = put_str(p, "\t4\t*\t0\t0\t*\t*\t0\t0\t", 18);
+        for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = (c < 4) ? "ACGT"[c] : 'N'; }
+        p = put_str(p, "\t*\n", 3);
+        out.resize(p - out.data());
+        return 1;
+      }
+      return 0;
+    }
+    double z1 = 0.0;                                                               // compute_unpaired_mqv, ref: output.c:777-793
+    for (auto* h : p2) z1 += h->posterior;
+    for (auto* h : p2) { h->z0 = h->posterior; h->z1 = z1; h->mqv = qv_from_pr_corr(h->posterior / z1); if (h->mqv < 4) h->mqv = 0; }
+    for (auto* h : p2) {
+      const GmFullRes& r = *h->r;
+      size_t o = out.size(); out.resize(o + need + 12 * (size_t)r.n_ops); char* p = &out[o];
+      const bool rev = r.gen_st == 1;
+      const int read_start = r.read_start + 1, read_end = read_start + r.rmapped - 1;
+      const int glen = (int)(ix->contig_off[r.cn + 1] - ix->contig_off[r.cn]);
+      p = put_str(p, nm, nl); *p++ = '\t';
+      p = put_int(p, rev ? 16 : 0); *p++ = '\t';
+      p = put_str(p, ix->names[r.cn].data(), ix->names[r.cn].size()); *p++ = '\t';
+      int genome_start;
+      if (!rev) genome_start = r.genome_start + 1;
+      else genome_start = (glen - r.genome_start) - (read_end - read_start - r.n_del + r.n_ins);   // ref: output.c:626-634
+      p = put_uint(p, (unsigned)genome_start); *p++ = '\t';
+      p = put_int(p, h->mqv); *p++ = '\t';
+      // CIGAR (make_cigar, ref: output.c:15-64): 'I' op = gap in the read -> D; 'D' op = gap in the genome -> I
+      struct Run { int len; char op; }; Run runs[GM_MAX_OPS]; int nr = 0;
+      if (read_start > 1) runs[nr++] = {read_start - 1, 'S'};
+      const int nops = std::min(r.n_ops, ops_stride);
+      for (int i = 0; i < nops;) {
+        const char op = (char)h->ops[i]; int j = i; while (j < nops && h->ops[j] == (uint8_t)op) j++;
+        if (nr < GM_MAX_OPS - 1) runs[nr++] = {j - i, op == 'M' ? 'M' : (op == 'I' ? 'D' : 'I')};
+        i = j;
+      }
+      if (read_end != read_len) runs[nr++] = {read_len - read_end, 'S'};
+      if (!rev) for (int i = 0; i < nr; i++) { p = put_uint(p, (unsigned)runs[i].len); *p++ = runs[i].op; }
+      else for (int i = nr - 1; i >= 0; i--) { p = put_uint(p, (unsigned)runs[i].len); *p++ = runs[i].op; }
+      p = put_str(p, "\t*\t0\t0\t", 7);
+      // SEQ: read bases in input orientation (aligned part from qralign == the read's own letters), revcomp on '-'
+      if (!rev) for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = CODE2SEQ[c]; }
+      else for (int i = read_len - 1; i >= 0; i--) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = rc_char(CODE2SEQ[c]); }
+      p = put_str(p, "\t*\tAS:i:", 8); p = put_int(p, h->score_full);
+      p = put_str(p, "\tZ0:i:", 6); p = put_int(p, double_to_neglog(h->z0));
+      p = put_str(p, "\tZ1:i:", 6); p = put_int(p, double_to_neglog(h->z1));
+      p = put_str(p, "\tNM:i:", 6); p = put_int(p, r.n_mismatch + r.n_del + r.n_ins);
+      *p++ = '\n';
+      out.resize(p - out.data());
+    }
+    return (int)p2.size();
+  }
+};
+
+static int run_device_pipeline(gm_session* s, int n, int read_len, gm_map_stats_t* st, float* lookup_ms) {
+  const gm_index* ix = s->ix;
+  const GmIndexDev dv = ix->dev_view();
+  const int read_words = (read_len + 7) / 8;
+  const int W = window_len_of(s->P, read_len);
+  const int overlap_abs = (int)(unsigned int)(s->P.window_overlap < 0 ? -s->P.window_overlap : W * (s->P.window_overlap / 100.0));   // ref: mapping.c:1289
+  hipStream_t q = s->stream;
+  for (int attempt = 0; attempt < 6; attempt++) {
+    GM_HIP(hipMemsetAsync(s->d_stats, 0, GS_N * 8, q));
+    GM_HIP(hipEventRecord(s->ev[0], q));
+    int rc = gm_launch_lookup(dv, s->d_reads, n, read_len, read_words, s->d_surv, s->d_surv_cnt, s->scap, s->d_stats, q);
+    if (rc) return rc;
+    GM_HIP(hipEventRecord(s->ev[1], q));
+    rc = gm_launch_anchors(dv, s->sc, n, read_len, W, s->d_surv, s->d_surv_cnt, s->scap, s->kmax, s->d_big_ws, s->d_big_list, s->d_big_cnt, s->max_big,
+                           s->d_hits, s->d_perm, s->d_hit_cnt, s->hcap, s->d_stats, q);
+    if (rc) return rc;
+    GM_HIP(hipEventRecord(s->ev[2], q));
+    rc = gm_launch_pass1(dv, s->sc, s->d_reads, n, read_len, read_words, W, overlap_abs, s->d_hits, s->d_perm, s->d_hit_cnt, s->hcap, s->d_slots, s->d_stats, q);
+    if (rc) return rc;
+    GM_HIP(hipEventRecord(s->ev[3], q));
+    rc = gm_launch_select(s->sc, n, read_len, s->d_hits, s->d_perm, s->d_hit_cnt, s->hcap, s->d_sel, s->d_sel_cnt, s->d_sel_off, s->d_work, s->d_n_work, q);
+    if (rc) return rc;
+    GM_HIP(hipEventRecord(s->ev[4], q));
+    unsigned long long hs[GS_N]; uint32_t n_work = 0;
+    GM_HIP(hipMemcpyAsync(&n_work, s->d_n_work, 4, hipMemcpyDeviceToHost, q));
+    GM_HIP(hipMemcpyAsync(hs, s->d_stats, GS_N * 8, hipMemcpyDeviceToHost, q));
+    GM_HIP(hipStreamSynchronize(q));
+    const size_t rcap = (size_t)s->max_batch * s->rcap_per_read;
+    bool retry = false;
+    if (hs[GS_OVERFLOW_SURV]) { if (s->scap >= 32768) { gm_set_error("survivor list overflow at capacity %d", s->scap); return GM_E_OVERFLOW; } s->scap *= 2; if (s->max_big < 8192) s->max_big *= 2; retry = true; }
+    if (hs[GS_OVERFLOW_HITS]) { if (s->hcap >= 32768) { gm_set_error("window list overflow at capacity %d", s->hcap); return GM_E_OVERFLOW; } s->hcap *= 4; retry = true; }
+    if (n_work > rcap) { if (s->rcap_per_read >= 32) { gm_set_error("pass-2 work overflow"); return GM_E_OVERFLOW; } s->rcap_per_read = std::min(32, s->rcap_per_read * 2); retry = true; }
+    if (retry) {
+      if (st) st->retries++;
+      // keep the reads across the re-allocation
+      std::vector<uint32_t> keep((size_t)n * read_words);
+      GM_HIP(hipMemcpy(keep.data(), s->d_reads, keep.size() * 4, hipMemcpyDeviceToHost));
+      rc = alloc_buffers(s, read_len); if (rc) return rc;
+      GM_HIP(hipMemcpy(s->d_reads, keep.data(), keep.size() * 4, hipMemcpyHostToDevice));
+      continue;
+    }
+    rc = gm_launch_pass2(dv, s->sc, s->d_reads, n, read_len, read_words, W, s->d_hits, s->d_perm, s->hcap, s->d_sel, s->d_sel_cnt, s->d_work, s->d_n_work,
+                         s->d_res, s->d_ops, s->ops_stride, s->d_back, s->back_stride, s->p2_grid, s->d_stats, q);
+    if (rc) return rc;
+    GM_HIP(hipEventRecord(s->ev[5], q));
+    s->h_res.resize(n_work); s->h_ops.resize((size_t)n_work * s->ops_stride); s->h_sel_cnt.resize(n); s->h_sel_off.resize(n);
+    if (n_work) {
+      GM_HIP(hipMemcpyAsync(s->h_res.data(), s->d_res, (size_t)n_work * sizeof(GmFullRes), hipMemcpyDeviceToHost, q));
+      GM_HIP(hipMemcpyAsync(s->h_ops.data(), s->d_ops, (size_t)n_work * s->ops_stride, hipMemcpyDeviceToHost, q));
+    }
+    GM_HIP(hipMemcpyAsync(s->h_sel_cnt.data(), s->d_sel_cnt, (size_t)n * 4, hipMemcpyDeviceToHost, q));
+    GM_HIP(hipMemcpyAsync(s->h_sel_off.data(), s->d_sel_off, (size_t)n * 4, hipMemcpyDeviceToHost, q));
+    GM_HIP(hipMemcpyAsync(hs, s->d_stats, GS_N * 8, hipMemcpyDeviceToHost, q));
+    GM_HIP(hipStreamSynchronize(q));
+    float ms[5];
+    for (int i = 0; i < 5; i++) GM_HIP(hipEventElapsedTime(&ms[i], s->ev[i], s->ev[i + 1]));
+    *lookup_ms = ms[0];
+    if (st) {
+      st->lookups += hs[GS_LOOKUPS]; st->list_entries += hs[GS_ENTRIES]; st->list_bytes += 12ull * hs[GS_LOOKUPS] + 4ull * hs[GS_ENTRIES];
+      st->survivors += hs[GS_SURVIVORS]; st->anchors += hs[GS_ANCHORS]; st->windows += hs[GS_WINDOWS];
+      st->vec_calls += hs[GS_VEC_CALLS]; st->vec_cells += hs[GS_VEC_CELLS]; st->vec_bypassed += hs[GS_VEC_BYPASSED];
+      st->full_calls += hs[GS_FULL_CALLS]; st->full_cells += hs[GS_FULL_CELLS]; st->exact_order_reads += hs[GS_EXACT_ORDER];
+      st->ms_lookup += ms[0]; st->ms_anchors += ms[1]; st->ms_pass1 += ms[2]; st->ms_select += ms[3]; st->ms_pass2 += ms[4];
+    }
+    s->last_lookup_bytes += 12ull * hs[GS_LOOKUPS] + 4ull * hs[GS_ENTRIES];
+    return GM_OK;
+  }
+  gm_set_error("capacity retries exhausted"); return GM_E_OVERFLOW;
+}
+
+static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* reads_host, const void* reads_dev,
+                    const char* names, int emit_sam, char** sam, size_t* sam_len, gm_map_stats_t* stats) {
+  if (!s || n_reads < 0 || read_len < 1) { gm_set_error("gm_map_reads: bad arguments"); return GM_E_ARG; }
+  if (read_len > s->P.longest_read_len || read_len >= 32768 / std::max(1, s->P.match_score)) { gm_set_error("read length %d out of range (ref: sw-vector.c:393-398)", read_len); return GM_E_RANGE; }
+  GM_HIP(hipSetDevice(s->ix->device));
+  if (stats) memset(stats, 0, sizeof *stats);
+  if (s->cur_len != read_len) { choose_caps(s, read_len); int rc = alloc_buffers(s, read_len); if (rc) return rc; }
+  const int read_words = (read_len + 7) / 8;
+  s->last_lookup_ms = 0; s->last_lookup_bytes = 0; s->last_lookup_launches = 0;
+  // names
+  std::vector<const char*> nptr; std::vector<int> nlen;
+  if (names) { const char* p = names; for (int i = 0; i < n_reads; i++) { const char* e = strchr(p, '\n'); if (!e) e = p + strlen(p); nptr.push_back(p); nlen.push_back((int)(e - p)); p = *e ? e + 1 : e; } }
+  std::string out;
+  uint64_t matched = 0, records = 0;
+  for (int base = 0; base < n_reads; base += s->max_batch) {
+    const int n = std::min(s->max_batch, n_reads - base);
+    if (reads_host) GM_HIP(hipMemcpyAsync(s->d_reads, reads_host + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyHostToDevice, s->stream));
+    else GM_HIP(hipMemcpyAsync(s->d_reads, (const uint32_t*)reads_dev + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyDeviceToDevice, s->stream));
+    float lk = 0;
+    int rc = run_device_pipeline(s, n, read_len, stats, &lk);
+    if (rc) return rc;
+    s->last_lookup_ms += lk; s->last_lookup_launches++;
+    // host finalisation (multi-threaded over reads, output kept in input order)
+    auto t0 = std::chrono::steady_clock::now();
+    const uint32_t* hreads = reads_host ? reads_host + (size_t)base * read_words : nullptr;
+    if (!hreads) { s->h_reads.resize((size_t)n * read_words); GM_HIP(hipMemcpy(s->h_reads.data(), s->d_reads, (size_t)n * read_words * 4, hipMemcpyDeviceToHost)); hreads = s->h_reads.data(); }
+    int nthreads = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("GM_HOST_THREADS")) nthreads = std::max(1, atoi(e));
+    const int chunk = 4096; const int nchunks = (n + chunk - 1) / chunk;
+    std::vector<std::string> outs(nchunks); std::vector<uint64_t> cm(nchunks, 0), cr(nchunks, 0);
+    std::atomic<int> next(0);
+    Finalizer F{s, read_len, read_words, hreads, names ? nptr.data() + base : nullptr, names ? nlen.data() + base : nullptr, (long)base};
+    auto worker = [&]() {
+      std::vector<FHit> fh; std::vector<FHit*> p2;
+      for (;;) {
+        int c = next.fetch_add(1); if (c >= nchunks) break;
+        std::string& o = outs[c]; if (emit_sam) o.reserve((size_t)chunk * (read_len + 120));
+        for (int rd = c * chunk; rd < std::min(n, (c + 1) * chunk); rd++) {
+          const uint32_t cnt = s->h_sel_cnt[rd], off = s->h_sel_off[rd];
+          int k = F.finalize_read(rd, cnt ? &s->h_res[off] : nullptr, s->h_ops.data(), s->ops_stride, (int)cnt, o, fh, p2);
+          if (!p2.empty()) cm[c]++;
+          cr[c] += k;
+          if (!emit_sam) o.clear();
+        }
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; t++) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+    for (int c = 0; c < nchunks; c++) { if (emit_sam) out += outs[c]; matched += cm[c]; records += cr[c]; }
+    if (stats) stats->ms_host += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  if (stats) { stats->reads = n_reads; stats->reads_matched = matched; stats->sam_records = records; }
+  if (emit_sam && sam) {
+    char* r = (char*)malloc(out.size() + 1); if (!r) return GM_E_NOMEM;
+    memcpy(r, out.data(), out.size()); r[out.size()] = 0; *sam = r; if (sam_len) *sam_len = out.size();
+  } else { if (sam) *sam = nullptr; if (sam_len) *sam_len = 0; }
+  return GM_OK;
+}
+
+extern "C" int gm_map_reads(gm_session_t* s, int n_reads, int read_len, const uint32_t* reads_packed, const char* names,
+                            char** sam, size_t* sam_len, gm_map_stats_t* stats) {
+  return map_impl(s, n_reads, read_len, reads_packed, nullptr, names, 1, sam, sam_len, stats);
+}
+extern "C" int gm_map_reads_device(gm_session_t* s, int n_reads, int read_len, const void* reads_dev, int emit_sam, char** sam, size_t* sam_len, gm_map_stats_t* stats) {
+  return map_impl(s, n_reads, read_len, nullptr, reads_dev, nullptr, emit_sam, sam, sam_len, stats);
+}
+extern "C" int gm_last_lookup_timing(gm_session_t* s, double* ms, uint64_t* alg_bytes, int* launches) {
+  if (!s) return GM_E_ARG;
+  if (ms) *ms = s->last_lookup_ms; if (alg_bytes) *alg_bytes = s->last_lookup_bytes; if (launches) *launches = s->last_lookup_launches;
+  return GM_OK;
+}
+
+// stage dump for parity tests: hits selected by pass 1, in ext-heap array order (before pass 2 / reverse_hit)
+extern "C" int gm_debug_tophits(gm_session_t* s, int n_reads, int read_len, const uint32_t* reads_packed, long long* rows, long cap, long* n_rows) {
+  if (!s || n_reads > s->max_batch) { gm_set_error("gm_debug_tophits: at most max_batch reads"); return GM_E_ARG; }
+  GM_HIP(hipSetDevice(s->ix->device));
+  if (s->cur_len != read_len) { choose_caps(s, read_len); int rc = alloc_buffers(s, read_len); if (rc) return rc; }
+  const int read_words = (read_len + 7) / 8;
+  GM_HIP(hipMemcpyAsync(s->d_reads, reads_packed, (size_t)n_reads * read_words * 4, hipMemcpyHostToDevice, s->stream));
+  float lk; int rc = run_device_pipeline(s, n_reads, read_len, nullptr, &lk); if (rc) return rc;
+  std::vector<int32_t> sel((size_t)n_reads * GM_SEL_MAX); std::vector<GmHit> hits((size_t)n_reads * 2 * s->hcap);
+  GM_HIP(hipMemcpy(sel.data(), s->d_sel, sel.size() * 4, hipMemcpyDeviceToHost));
+  GM_HIP(hipMemcpy(hits.data(), s->d_hits, hits.size() * sizeof(GmHit), hipMemcpyDeviceToHost));
+  long w = 0;
+  for (int rd = 0; rd < n_reads; rd++)
+    for (uint32_t k = 0; k < s->h_sel_cnt[rd]; k++) {
+      if (w >= cap) { *n_rows = w; return GM_OK; }
+      const int id = sel[(size_t)rd * GM_SEL_MAX + k]; const int st = id >> 16, hi = id & 0xFFFF;
+      const GmHit& h = hits[((size_t)rd * 2 + st) * s->hcap + hi];
+      long long r[12] = {rd, st, h.cn, h.g_off, h.w_len, h.score_vector, h.pct_score_vector, h.matches, h.ax, h.ay, h.alen, h.awidth};
+      memcpy(rows + w * 12, r, sizeof r); w++;
+    }
+  *n_rows = w;
+  return GM_OK;
+}
+
+// ---- S1: vector SW on caller bitfields ----------------------------------------------------------
+struct SwVecState { bool init = false; GmScoreDev sc; int dblen = 0, qrlen = 0; uint64_t invocs = 0, cells = 0; double secs = 0; };
+static thread_local SwVecState g_sv;
+
+extern "C" int sw_vector_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
+                               int match, int mismatch, int use_colours, bool reset_stats) {
+  if (match * qrlen >= 32768) { gm_set_error("match * qrlen >= 32768 (ref: sw-vector.c:393-398)"); return GM_E_RANGE; }
+  if (use_colours) { gm_set_error("colour space is not implemented"); return GM_E_ARG; }
+  if (gm_device_count() < 1) { gm_set_error("no HIP device"); return GM_E_NODEVICE; }
+  gm_params_t P; gm_params_default(&P);
+  P.match_score = match; P.mismatch_score = mismatch; P.a_gap_open_score = a_gap_open; P.a_gap_extend_score = a_gap_ext;
+  P.b_gap_open_score = b_gap_open; P.b_gap_extend_score = b_gap_ext;
+  g_sv.sc = make_score(P); g_sv.dblen = dblen; g_sv.qrlen = qrlen; g_sv.init = true;
+  if (reset_stats) { g_sv.invocs = g_sv.cells = 0; g_sv.secs = 0; }
+  return 0;
+}
+extern "C" int sw_vector_cleanup(void) { g_sv.init = false; return 0; }
+extern "C" void sw_vector_stats(uint64_t* invocs, uint64_t* cells, double* secs) {
+  if (invocs) *invocs = g_sv.invocs; if (cells) *cells = g_sv.cells; if (secs) *secs = g_sv.secs;
+}
+
+extern "C" int gm_sw_vector_batch(int n, const uint32_t* genome, uint64_t genome_words, const int64_t* g_off, const int* glen,
+                                  const uint32_t* reads, int read_words, const int* rlen, int* scores) {
+  if (!g_sv.init) { gm_set_error("sw_vector called before sw_vector_setup"); return GM_E_NOTSETUP; }
+  if (n <= 0) return GM_OK;
+  int max_g = 0, max_r = 0;
+  for (int i = 0; i < n; i++) { max_g = std::max(max_g, glen[i]); max_r = std::max(max_r, rlen[i]); if (glen[i] < 1 || rlen[i] < 1) return GM_E_ARG; }
+  if (max_g > g_sv.dblen || max_r > g_sv.qrlen) { gm_set_error("window/read longer than sw_vector_setup sizes"); return GM_E_ARG; }
+  uint32_t *dg = nullptr, *dr = nullptr; long long* dgo = nullptr; int *dgl = nullptr, *drl = nullptr, *ds = nullptr;
+  GM_HIP(hipMalloc(&dg, (genome_words + 8) * 4)); GM_HIP(hipMalloc(&dr, (size_t)n * read_words * 4 + 32));
+  GM_HIP(hipMalloc(&dgo, (size_t)n * 8)); GM_HIP(hipMalloc(&dgl, (size_t)n * 4)); GM_HIP(hipMalloc(&drl, (size_t)n * 4)); GM_HIP(hipMalloc(&ds, (size_t)n * 4));
+  GM_HIP(hipMemset(dg, 0, (genome_words + 8) * 4));
+  GM_HIP(hipMemcpy(dg, genome, genome_words * 4, hipMemcpyHostToDevice));
+  GM_HIP(hipMemcpy(dr, reads, (size_t)n * read_words * 4, hipMemcpyHostToDevice));
+  GM_HIP(hipMemcpy(dgo, g_off, (size_t)n * 8, hipMemcpyHostToDevice));
+  GM_HIP(hipMemcpy(dgl, glen, (size_t)n * 4, hipMemcpyHostToDevice));
+  GM_HIP(hipMemcpy(drl, rlen, (size_t)n * 4, hipMemcpyHostToDevice));
+  int rc = gm_launch_sw_vector_batch(g_sv.sc, n, dg, dgo, dgl, dr, read_words, drl, max_g, max_r, ds, 0);
+  if (rc == GM_OK) { GM_HIP(hipDeviceSynchronize()); GM_HIP(hipMemcpy(scores, ds, (size_t)n * 4, hipMemcpyDeviceToHost)); }
+  (void)hipFree(dg); (void)hipFree(dr); (void)hipFree(dgo); (void)hipFree(dgl); (void)hipFree(drl); (void)hipFree(ds);
+  for (int i = 0; i < n; i++) { g_sv.invocs++; g_sv.cells += (uint64_t)glen[i] * rlen[i]; }
+  return rc;
+}
+
+extern "C" int sw_vector(uint32_t* genome, int goff, int glen, uint32_t* read, int rlen, uint32_t* genome_ls, int initbp, bool is_rna) {
+  (void)genome_ls; (void)initbp; (void)is_rna;
+  if (!g_sv.init) abort();   // ref: sw-vector.c:462-463
+  int64_t go = goff; int score = 0;
+  const uint64_t gw = ((uint64_t)goff + glen + 7) / 8;
+  int rc = gm_sw_vector_batch(1, genome, gw, &go, &glen, read, (rlen + 7) / 8, &rlen, &score);
+  return rc == GM_OK ? score : rc;
+}
+
+// ---- S2: full SW on caller bitfields ------------------------------------------------------------
+struct SwFullState { bool init = false; GmScoreDev sc; int dblen = 0, qrlen = 0; };
+static thread_local SwFullState g_sf;
+static const char LSTRANS[17] = "ACGTUMRWSYKVHDBN";   // base_translate, ref: common/fasta.c:689-690
+
+extern "C" int sw_full_ls_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
+                                int match, int mismatch, bool reset_stats, int anchor_width) {
+  (void)reset_stats;
+  if (gm_device_count() < 1) { gm_set_error("no HIP device"); return GM_E_NODEVICE; }
+  gm_params_t P; gm_params_default(&P);
+  P.match_score = match; P.mismatch_score = mismatch; P.a_gap_open_score = a_gap_open; P.a_gap_extend_score = a_gap_ext;
+  P.b_gap_open_score = b_gap_open; P.b_gap_extend_score = b_gap_ext; P.anchor_width = anchor_width;
+  g_sf.sc = make_score(P); g_sf.dblen = dblen; g_sf.qrlen = qrlen; g_sf.init = true;
+  return 0;
+}
+extern "C" int sw_full_ls_cleanup(void) { g_sf.init = false; return 0; }
+
+extern "C" void sw_full_ls(uint32_t* genome, int goff, int glen, uint32_t* read, int rlen, int threshscore, int maxscore,
+                           struct gm_sw_full_results* sfr, bool revcmpl, struct gm_anchor* anchors, int anchors_cnt, int local_alignment) {
+  (void)threshscore; (void)maxscore;
+  if (!g_sf.init) abort();   // ref: sw-full-ls.c:649-650
+  if (local_alignment || anchors == nullptr || anchors_cnt != 1 || glen > g_sf.dblen || rlen > g_sf.qrlen || glen < 1 || rlen < 1) {
+    gm_set_error("sw_full_ls: only the global mode with one anchor box (gmapper's call, ref: mapping.c:391-394) is implemented");
+    sfr->score = 0; sfr->dbalign = strdup(""); sfr->qralign = strdup(""); return;
+  }
+  const uint64_t gw = ((uint64_t)goff + glen + 7) / 8 + 8; const int rwords = (rlen + 7) / 8 + 1;
+  const int ops_cap = glen + rlen + 8;
+  uint32_t *dg = nullptr, *dr = nullptr; uint8_t *dback = nullptr, *dops = nullptr; int* dout = nullptr;
+  bool ok = hipMalloc(&dg, gw * 4) == hipSuccess && hipMalloc(&dr, (size_t)rwords * 4) == hipSuccess &&
+            hipMalloc(&dback, (size_t)glen * rlen + 256) == hipSuccess && hipMalloc(&dops, ops_cap) == hipSuccess && hipMalloc(&dout, 16 * 4) == hipSuccess;
+  int out[16] = {0}; std::vector<uint8_t> ops(ops_cap);
+  if (ok) {
+    ok = hipMemset(dg, 0, gw * 4) == hipSuccess && hipMemcpy(dg, genome, (gw - 8) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(dr, read, (size_t)(rwords - 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         gm_launch_sw_full_single(g_sf.sc, dg, goff, glen, dr, rlen, anchors[0].x, anchors[0].y, anchors[0].length, anchors[0].width, revcmpl ? 1 : 0,
+                                  dback, dout, dops, ops_cap, 0) == GM_OK &&
+         hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, dout, sizeof out, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(ops.data(), dops, ops_cap, hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  (void)hipFree(dg); (void)hipFree(dr); (void)hipFree(dback); (void)hipFree(dops); (void)hipFree(dout);
+  if (!ok) { gm_set_error("sw_full_ls: HIP failure"); sfr->score = 0; sfr->dbalign = strdup(""); sfr->qralign = strdup(""); return; }
+  sfr->score = out[0];
+  std::string db, qr;
+  if (out[0] > 0) {
+    sfr->read_start = out[1]; sfr->rmapped = out[2]; sfr->genome_start = out[3]; sfr->gmapped = out[4];
+    sfr->matches += out[5]; sfr->mismatches += out[6]; sfr->insertions += out[7]; sfr->deletions += out[8];
+    int pi = out[1], pj = out[3];   // pretty_print, ref: sw-full-ls.c:524-560 (genome_start already includes goff)
+    auto nib = [](const uint32_t* b, long long i) { return (int)((b[i / 8] >> (4 * (i % 8))) & 0xf); };
+    for (int k = 0; k < out[9]; k++) {
+      if (ops[k] == 'D') { db.push_back('-'); qr.push_back(LSTRANS[nib(read, pi++)]); }
+      else if (ops[k] == 'I') { db.push_back(LSTRANS[nib(genome, pj++)]); qr.push_back('-'); }
+      else { db.push_back(LSTRANS[nib(genome, pj++)]); qr.push_back(LSTRANS[nib(read, pi++)]); }
+    }
+  } else {   // the reference backtraces stale scratch here; every caller discards it (score 0 < threshold)
+    sfr->rmapped = 1; sfr->gmapped = 1; sfr->genome_start = goff;
+  }
+  sfr->dbalign = strdup(db.c_str()); sfr->qralign = strdup(qr.c_str());
+}

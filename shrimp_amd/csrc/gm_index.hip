@@ -1,0 +1,108 @@
+// gm_index.hip -- on-device construction of the resident seed index (S5).
+// Replaces load_genome() (ref: gmapper/genome.c:1012-1182): for every genome position and every
+// seed whose span fits since the last N/X or contig start, the k-mer's start position is appended
+// to the list of its map index, so lists are ascending.  Here: emit (mapidx, position) keys for
+// every position, stable LSD radix sort by mapidx (rocPRIM), then cut the sorted array into
+// (k-mer, slab) slices -- see gm_common.h for the layout.
+#include <cstring>
+#include <algorithm>
+#include "gm_common.h"
+#include "gm_internal.h"
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+// kmer_to_mapidx_orig (ref: gmapper/gmapper.h:349-368): walk the mask from the LSB (= most recent
+// base = highest position); every 1-bit appends the base's low 2 bits => most recent base on top.
+__device__ __forceinline__ uint32_t gm_nib(const uint32_t* g, uint64_t p) { return (g[p >> 3] >> ((p & 7) * 4)) & 0xf; }
+
+__global__ void __launch_bounds__(256) k_emit_keys(const uint32_t* __restrict__ genome, uint64_t total_len,
+                                                   const uint32_t* __restrict__ contig_off, int n_contigs,
+                                                   uint64_t mask, int span, int weight, uint32_t* __restrict__ keys) {
+  uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint32_t invalid = 1u << (2 * weight);
+  for (; q < total_len; q += stride) {
+    // contig of q: largest cn with contig_off[cn] <= q
+    int lo = 0, hi = n_contigs;
+    while (hi - lo > 1) { int m = (lo + hi) >> 1; if (contig_off[m] <= q) lo = m; else hi = m; }
+    uint64_t cend = contig_off[lo + 1];
+    uint32_t key = invalid;
+    if (q + span <= cend) {
+      // bases q .. q+span-1; mask bit i <-> base at q+span-1-i
+      uint32_t mapidx = 0; bool has_n = false;
+      uint64_t a = mask; int i = 0;
+      // N/X anywhere inside the span (also under a 0 of the mask) resets the reference's `load`
+      // counter (ref: genome.c:1147-1150), so the whole span must be free of code 15.
+      for (int t = 0; t < span; t++) {
+        uint32_t b = gm_nib(genome, q + span - 1 - t);
+        has_n |= (b == 15u);
+        if ((a >> t) & 1) { mapidx = (mapidx << 2) | (b & 3u); }
+      }
+      (void)i;
+      if (!has_n) key = mapidx;
+    }
+    keys[q] = key;
+  }
+}
+
+// first index e with keys[e] >= invalid  (keys sorted)
+__global__ void k_count_valid(const uint32_t* __restrict__ keys, uint64_t n, uint32_t invalid, uint32_t* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (keys[m] < invalid) lo = m + 1; else hi = m; }
+    *out = (uint32_t)lo;
+  }
+}
+
+// dir[c] = first e with composite(e) >= c, composite = key*S + (pos >> slab_bits), c in [0, K*S]
+__global__ void __launch_bounds__(256) k_build_dir(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ pos, uint32_t n_valid,
+                                                   int S, int slab_bits, uint64_t KS, uint32_t* __restrict__ dir) {
+  uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; e <= n_valid; e += stride) {
+    long long prev = (e == 0) ? -1 : (long long)keys[e - 1] * S + (pos[e - 1] >> slab_bits);
+    long long cur = (e == n_valid) ? (long long)KS : (long long)keys[e] * S + (pos[e] >> slab_bits);
+    for (long long c = prev + 1; c <= cur; c++) dir[c] = (uint32_t)e;
+  }
+}
+
+int gm_index_build_device(GmIndexHost* ix, hipStream_t stream) {
+  const uint64_t n = ix->total_len;
+  uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_b = nullptr, *d_cnt = nullptr;
+  void* tmp = nullptr;
+  GM_HIP(hipMalloc(&keys_a, n * 4));
+  GM_HIP(hipMalloc(&keys_b, n * 4));
+  GM_HIP(hipMalloc(&vals_b, n * 4));
+  GM_HIP(hipMalloc(&d_cnt, 4));
+  size_t tmp_bytes = 0;
+  rocprim::counting_iterator<uint32_t> iota(0);
+  int maxbits = 0;
+  for (int sn = 0; sn < ix->n_seeds; sn++) maxbits = std::max(maxbits, 2 * ix->seeds[sn].weight + 1);
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, iota, vals_b, (size_t)n, 0, maxbits, stream);
+  if (e != hipSuccess) { gm_set_error("radix_sort_pairs size query: %s", hipGetErrorString(e)); return GM_E_NODEVICE; }
+  GM_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+  const int grid = 256 * 16;
+  for (int sn = 0; sn < ix->n_seeds; sn++) {
+    GmSeedHost& sd = ix->seeds[sn];
+    const uint64_t K = 1ull << (2 * sd.weight);
+    const uint64_t KS = K * (uint64_t)ix->n_slabs;
+    hipLaunchKernelGGL(k_emit_keys, dim3(grid), dim3(256), 0, stream, ix->d_genome, n, ix->d_contig_off, ix->n_contigs,
+                       sd.mask, sd.span, sd.weight, keys_a);
+    e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_a, keys_b, iota, vals_b, (size_t)n, 0, 2 * sd.weight + 1, stream);
+    if (e != hipSuccess) { gm_set_error("radix_sort_pairs: %s", hipGetErrorString(e)); return GM_E_NODEVICE; }
+    hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(64), 0, stream, keys_b, n, (uint32_t)K, d_cnt);
+    uint32_t n_valid = 0;
+    GM_HIP(hipMemcpyAsync(&n_valid, d_cnt, 4, hipMemcpyDeviceToHost, stream));
+    GM_HIP(hipStreamSynchronize(stream));
+    sd.n_pos = n_valid;
+    GM_HIP(hipMalloc(&sd.d_pos, (size_t)(n_valid + 64) * 4));
+    GM_HIP(hipMemsetAsync(sd.d_pos, 0xff, (size_t)(n_valid + 64) * 4, stream));   // tail pad: 0xffffffff sentinels
+    GM_HIP(hipMemcpyAsync(sd.d_pos, vals_b, (size_t)n_valid * 4, hipMemcpyDeviceToDevice, stream));
+    GM_HIP(hipMalloc(&sd.d_dir, (size_t)(KS + 1 + 16) * 4));
+    hipLaunchKernelGGL(k_build_dir, dim3(grid), dim3(256), 0, stream, keys_b, vals_b, n_valid, ix->n_slabs, ix->slab_bits, KS, sd.d_dir);
+    GM_HIP(hipStreamSynchronize(stream));
+    sd.dir_words = KS + 1;
+  }
+  (void)hipFree(keys_a); (void)hipFree(keys_b); (void)hipFree(vals_b); (void)hipFree(d_cnt); (void)hipFree(tmp);
+  return GM_OK;
+}

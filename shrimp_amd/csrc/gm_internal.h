@@ -1,0 +1,71 @@
+// gm_internal.h -- host-side objects behind the opaque handles of include/gmapper_hip.h
+#pragma once
+#include "gm_common.h"
+
+struct GmSeedHost {
+  uint64_t mask = 0; int span = 0, weight = 0;
+  uint32_t* d_dir = nullptr; uint32_t* d_pos = nullptr;
+  uint32_t n_pos = 0; uint64_t dir_words = 0;
+  std::string text;
+};
+
+struct GmIndexHost {
+  int device = 0;
+  uint64_t total_len = 0;
+  int n_contigs = 0;
+  std::vector<uint32_t> contig_off;     // n_contigs + 1
+  std::vector<std::string> names;
+  uint32_t* d_genome = nullptr; uint64_t genome_words = 0;
+  uint32_t* d_contig_off = nullptr;
+  int n_seeds = 0, min_seed_span = 64, max_seed_span = 0;
+  GmSeedHost seeds[GM_MAX_SEEDS];
+  int slab_bits = 29, n_slabs = 1;
+  gm_params_t params;
+  uint32_t list_cutoff = 0;
+  GmIndexDev dev_view() const;
+};
+struct gm_index : GmIndexHost {};
+
+// stats slots written by the kernels (uint64 each)
+enum { GS_LOOKUPS = 0, GS_ENTRIES, GS_SURVIVORS, GS_ANCHORS, GS_WINDOWS, GS_VEC_CALLS, GS_VEC_CELLS, GS_VEC_BYPASSED,
+       GS_FULL_CALLS, GS_FULL_CELLS, GS_EXACT_ORDER, GS_OVERFLOW_SURV, GS_OVERFLOW_HITS, GS_N };
+
+// ---- kernel launchers (one per .hip file) -----------------------------------------------------
+int gm_index_build_device(GmIndexHost* ix, hipStream_t stream);
+
+// K1 seed lookup + region filter: one workgroup per read-strand
+int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
+                     uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, unsigned long long* d_stats, hipStream_t stream);
+size_t gm_lookup_lds_bytes(const GmIndexDev& ix, int read_len);
+
+// K2 anchors + candidate windows: one wave per read-strand (LDS workspace), big read-strands in a second launch (global workspace)
+int gm_anchors_kmax(int expected_survivors);
+size_t gm_anchors_big_ws_bytes(int scap, int NL, int read_len);
+int gm_launch_anchors(const GmIndexDev& ix, const GmScoreDev& sc, int n_reads, int read_len, int window_len,
+                      const uint64_t* d_surv, const uint32_t* d_surv_cnt, int scap, int kmax,
+                      uint8_t* d_big_ws, uint32_t* d_big_list, uint32_t* d_big_cnt, int max_big,
+                      GmHit* d_hits, uint16_t* d_perm, uint32_t* d_hit_cnt, int hcap, unsigned long long* d_stats, hipStream_t stream);
+
+// K3 pass 1 (vector SW + overlap rule), one wave per read-strand
+int gm_launch_pass1(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
+                    int window_len, int window_overlap_abs, GmHit* d_hits, const uint16_t* d_perm, const uint32_t* d_hit_cnt, int hcap,
+                    unsigned long long* d_slots, unsigned long long* d_stats, hipStream_t stream);
+
+// K4a top-K selection (ref: read_get_vector_hits), one thread per read; K4b pass 2, one wave per selected hit
+#define GM_SEL_MAX 64
+int gm_launch_select(const GmScoreDev& sc, int n_reads, int read_len, const GmHit* d_hits, const uint16_t* d_perm,
+                     const uint32_t* d_hit_cnt, int hcap, int32_t* d_sel, uint32_t* d_sel_cnt, uint32_t* d_sel_off,
+                     uint32_t* d_work, uint32_t* d_n_work, hipStream_t stream);
+int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
+                    int window_len, const GmHit* d_hits, const uint16_t* d_perm, int hcap, const int32_t* d_sel, const uint32_t* d_sel_cnt,
+                    const uint32_t* d_work, const uint32_t* d_n_work, GmFullRes* d_res, uint8_t* d_ops, int ops_stride,
+                    uint8_t* d_back, size_t back_stride, int grid, unsigned long long* d_stats, hipStream_t stream);
+
+// S1 batch kernel on caller-provided bitfields
+int gm_launch_sw_vector_batch(const GmScoreDev& sc, int n, const uint32_t* d_genome, const long long* d_goff, const int* d_glen,
+                              const uint32_t* d_reads, int read_words, const int* d_rlen, int max_g, int max_r, int* d_scores, hipStream_t stream);
+
+// S2 single alignment on caller-provided bitfields
+int gm_launch_sw_full_single(const GmScoreDev& sc, const uint32_t* d_genome, long long goff, int glen, const uint32_t* d_read, int rlen,
+                             long long ax, long long ay, int alen, int awidth, int revcmpl, uint8_t* d_back, int* d_out, uint8_t* d_ops, int ops_cap,
+                             hipStream_t stream);

@@ -1,0 +1,219 @@
+// gm_lookup.hip -- K1: spaced-seed lookup + exact region filter.  HBM-bound; this is the kernel
+// priced against the HBM roofline (B_seed = sum over lookups of 12 + 4*len bytes).
+//
+// Replaces, for one read-strand per workgroup:
+//   read_get_mapidxs_per_strand   ref: gmapper/mapping.c:37-70     k-mer -> map index
+//   read_get_region_counts        ref: gmapper/mapping.c:459-542   ">= 2 k-mer hits in a 2048(+50) bp region"
+//   advance_index_in_genomemap    ref: gmapper/mapping.c:646-805   per-entry survival test (unpaired branch :731-743)
+// The reference walks every inverted list twice through a 4 MB per-thread region map in DRAM
+// (latency bound).  Here the genome is cut into slabs of 2^slab_bits positions; per slab the
+// region counters (2 bits each) live in LDS, the list slices of that slab are streamed from HBM
+// once (coalesced: consecutive lanes read consecutive entries of the flattened slice set) and
+// re-read from L2 for the survival test.  Output: the surviving (position, list id) pairs.
+//
+// Exactness: a region's count is the number of list entries e with region(e) == r, plus those in
+// the first `region_overlap` bases of region r+1 (ref :521-533); an entry survives iff its region,
+// or region-1 when it lies in that strip, has count >= 2 (ref :733-742).  Counts do not depend on
+// the visiting order, so the slab sweep reproduces them exactly; slab borders are handled by
+// reading the (rare) entries of the neighbouring slices that can mark a border region.
+#include "gm_common.h"
+#include "gm_internal.h"
+
+#define K1_THREADS 256
+
+struct K1Smem {
+  uint32_t n_surv;
+  uint32_t total;
+};
+
+__device__ __forceinline__ void k1_mark(uint32_t* bm, uint32_t rloc) {
+  const uint32_t w = rloc >> 4, sh = (rloc & 15u) * 2u;
+  const uint32_t old = atomicOr(&bm[w], 1u << sh);
+  if (old & (1u << sh)) atomicOr(&bm[w], 2u << sh);
+}
+__device__ __forceinline__ bool k1_has2(const uint32_t* bm, uint32_t rloc) {
+  return (bm[rloc >> 4] >> ((rloc & 15u) * 2u + 1u)) & 1u;
+}
+
+// dynamic LDS layout: codes[read_len pad 4] | kS[NL] | lbeg[NL] | lend[NL] | lo[NL] | hi[NL] | pre[NL+1] | bitmap[bm_words]
+__global__ void __launch_bounds__(K1_THREADS)
+k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
+         int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap,
+         unsigned long long* __restrict__ stats) {
+  extern __shared__ __align__(16) uint32_t smem[];
+  __shared__ K1Smem sh;
+  const int tid = threadIdx.x;
+  const int rs = blockIdx.x;            // read-strand id
+  const int rd = rs >> 1, st = rs & 1;
+  uint8_t* codes = (uint8_t*)smem;
+  const int code_words = (read_len + 3) / 4;
+  uint32_t* kS = smem + code_words;
+  uint32_t* lbeg = kS + NL;
+  uint32_t* lend = lbeg + NL;
+  uint32_t* lo = lend + NL;
+  uint32_t* hi = lo + NL;
+  uint32_t* pre = hi + NL;              // NL + 1
+  uint32_t* bm = pre + NL + 1;
+  const int S = ix.n_slabs, rb = ix.region_bits;
+  const uint32_t rmask = (1u << rb) - 1u, ovl = (uint32_t)ix.region_overlap;
+
+  // ---- 0. read codes of this strand (strand 1 = reverse complement, ref: util.c:540-596) ----
+  const uint32_t* rw = reads + (size_t)rd * read_words;
+  for (int i = tid; i < read_len; i += K1_THREADS) {
+    int src = st ? (read_len - 1 - i) : i;
+    uint32_t c = (rw[src >> 3] >> ((src & 7) * 4)) & 0xf;
+    if (st) {   // complement_base, ref: util.h:125-151
+      const uint64_t cm = 0xFBCDE56879A00123ull;   // nibble i = complement of code i
+      c = (uint32_t)(cm >> (c * 4)) & 0xf;
+    }
+    codes[i] = (uint8_t)c;
+  }
+  if (tid == 0) sh.n_surv = 0;
+  __syncthreads();
+
+  // ---- 1. map indexes + whole-list bounds (ref: mapping.c:53-66, KMER_TO_MAPIDX gmapper.h:349-368) ----
+  unsigned long long my_lookups = 0, my_entries = 0;
+  for (int off = tid; off < NL; off += K1_THREADS) {
+    const int sn = off / max_n_kmers, i = off - sn * max_n_kmers;
+    uint32_t k = 0, b = 0, e = 0;
+    const int span = ix.seed[sn].span;
+    if (i + span <= read_len) {
+      const uint64_t mask = ix.seed[sn].mask;
+      uint32_t mapidx = 0;
+      for (int t = 0; t < span; t++)
+        if ((mask >> t) & 1) mapidx = (mapidx << 2) | (codes[i + span - 1 - t] & 3u);
+      k = mapidx * (uint32_t)S;
+      const uint32_t* dir = ix.seed[sn].dir;
+      b = dir[k]; e = dir[k + S];
+      my_lookups++;
+      if (e - b > ix.list_cutoff) { b = 0; e = 0; }    // ref: mapping.c:497 (skipped, not deleted)
+      my_entries += (e - b);
+    }
+    kS[off] = k; lbeg[off] = b; lend[off] = e;
+  }
+  __syncthreads();
+
+  // ---- 2. slab sweep ----
+  for (int s = 0; s < S; s++) {
+    const uint64_t B = (uint64_t)s << ix.slab_bits;
+    const uint64_t E = B + (1ull << ix.slab_bits);
+    const uint32_t rbase = (uint32_t)(B >> rb);           // local region index = region - rbase + 1
+    for (int w = tid; w < bm_words; w += K1_THREADS) bm[w] = 0;
+    for (int off = tid; off < NL; off += K1_THREADS) {
+      uint32_t l = 0, h = 0, c = 0;
+      if (lend[off] > lbeg[off]) {
+        if (S == 1) { l = lbeg[off]; h = lend[off]; }
+        else { const uint32_t* dir = ix.seed[off / max_n_kmers].dir; l = dir[kS[off] + s]; h = dir[kS[off] + s + 1]; }
+        // one candidate border entry on each side (they decide whether a border scan is needed)
+        c = (h - l) + (l > lbeg[off] ? 1u : 0u) + (h < lend[off] ? 1u : 0u);
+      }
+      lo[off] = l; hi[off] = h; pre[off] = c;
+    }
+    __syncthreads();
+    // exclusive scan of pre[0..NL) by wave 0
+    if (tid < GM_WAVE) {
+      const int per = (NL + GM_WAVE - 1) / GM_WAVE;
+      const int a0 = tid * per, a1 = min(NL, a0 + per);
+      uint32_t sum = 0;
+      for (int a = a0; a < a1; a++) sum += pre[a];
+      uint32_t incl = sum;
+      for (int d = 1; d < GM_WAVE; d <<= 1) { uint32_t o = __shfl_up(incl, d); if (tid >= d) incl += o; }
+      uint32_t run = incl - sum;
+      for (int a = a0; a < a1; a++) { uint32_t c = pre[a]; pre[a] = run; run += c; }
+      if (tid == GM_WAVE - 1) { pre[NL] = incl; sh.total = incl; }
+    }
+    __syncthreads();
+    const uint32_t total = sh.total;
+    if (total == 0) { __syncthreads(); continue; }
+
+    for (int phase = 0; phase < 2; phase++) {
+      for (uint32_t e0 = 0; e0 < total; e0 += K1_THREADS) {
+        const uint32_t e = e0 + tid;
+        if (e < total) {
+          // list of entry e: largest l with pre[l] <= e (pre non-decreasing; empty lists skipped by <=)
+          int a = 0, z = NL;
+          while (z - a > 1) { int m = (a + z) >> 1; if (pre[m] <= e) a = m; else z = m; }
+          const int off = a;
+          const uint32_t l = lo[off], h = hi[off];
+          const uint32_t ext_lo = l - (l > lbeg[off] ? 1u : 0u);
+          const uint32_t idx = ext_lo + (e - pre[off]);
+          const uint32_t* plist = ix.seed[off / max_n_kmers].pos;
+          const uint32_t p = plist[idx];
+          const uint32_t reg = p >> rb;
+          if (idx >= l && idx < h) {
+            const uint32_t rloc = reg - rbase + 1u;
+            const bool strip = ((p & rmask) < ovl) && reg > 0;
+            if (phase == 0) {
+              k1_mark(bm, rloc);
+              if (strip) k1_mark(bm, rloc - 1u);
+            } else {
+              if (k1_has2(bm, rloc) || (strip && k1_has2(bm, rloc - 1u))) {
+                const uint32_t slot = atomicAdd(&sh.n_surv, 1u);
+                if (slot < (uint32_t)scap) surv[(size_t)rs * scap + slot] = ((uint64_t)p << 32) | (uint32_t)off;
+              }
+            }
+          } else if (phase == 0) {
+            if (idx < l) {
+              // entries of the previous slab inside the last region before B count for local region 0
+              if (reg + 1u == rbase) {
+                k1_mark(bm, 0u);
+                for (uint32_t q = idx; q > lbeg[off];) { --q; if ((plist[q] >> rb) + 1u != rbase) break; k1_mark(bm, 0u); }
+              }
+            } else {
+              // entries of the next slab inside the overlap strip count for this slab's last region
+              const uint32_t rend = (uint32_t)(E >> rb);
+              if (reg == rend && (p & rmask) < ovl) {
+                k1_mark(bm, rend - rbase);
+                for (uint32_t q = idx + 1; q < lend[off]; q++) {
+                  const uint32_t pq = plist[q];
+                  if ((pq >> rb) != rend || (pq & rmask) >= ovl) break;
+                  k1_mark(bm, rend - rbase);
+                }
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    surv_cnt[rs] = sh.n_surv;
+    atomicAdd(&stats[GS_SURVIVORS], (unsigned long long)min(sh.n_surv, (uint32_t)scap));
+    if (sh.n_surv > (uint32_t)scap) atomicAdd(&stats[GS_OVERFLOW_SURV], 1ull);
+  }
+  // per-wave reduction of the work counters
+  for (int d = GM_WAVE / 2; d > 0; d >>= 1) { my_lookups += __shfl_down(my_lookups, d); my_entries += __shfl_down(my_entries, d); }
+  if ((tid & (GM_WAVE - 1)) == 0) { atomicAdd(&stats[GS_LOOKUPS], my_lookups); atomicAdd(&stats[GS_ENTRIES], my_entries); }
+}
+
+static void k1_geometry(const GmIndexDev& ix, int read_len, int* max_n_kmers, int* NL, int* bm_words, size_t* lds) {
+  *max_n_kmers = read_len - ix.min_seed_span + 1;
+  if (*max_n_kmers < 0) *max_n_kmers = 0;
+  *NL = ix.n_seeds * (*max_n_kmers);
+  uint64_t slab_len = (ix.n_slabs == 1) ? ix.total_len : (1ull << ix.slab_bits);
+  uint64_t regions = (slab_len >> ix.region_bits) + 3;      // +1 region before, +1 partial, +1 slack
+  *bm_words = (int)((regions + 15) / 16);
+  *lds = (size_t)((read_len + 3) / 4) * 4 + (size_t)(*NL) * 5 * 4 + ((size_t)(*NL) + 1) * 4 + (size_t)(*bm_words) * 4;
+}
+
+size_t gm_lookup_lds_bytes(const GmIndexDev& ix, int read_len) {
+  int a, b, c; size_t l; k1_geometry(ix, read_len, &a, &b, &c, &l); return l;
+}
+
+int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
+                     uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, unsigned long long* d_stats, hipStream_t stream) {
+  int max_n_kmers, NL, bm_words; size_t lds;
+  k1_geometry(ix, read_len, &max_n_kmers, &NL, &bm_words, &lds);
+  if (lds > 160 * 1024) { gm_set_error("lookup kernel needs %zu bytes of LDS (read_len %d, slab_bits %d)", lds, read_len, ix.slab_bits); return GM_E_ARG; }
+  if (NL == 0 || n_reads == 0) { GM_HIP(hipMemsetAsync(d_surv_cnt, 0, (size_t)n_reads * 2 * 4, stream)); return GM_OK; }
+  static size_t configured = 0;
+  if (lds > 48 * 1024 && lds > configured) {
+    GM_HIP(hipFuncSetAttribute((const void*)k_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = lds;
+  }
+  hipLaunchKernelGGL(k_lookup, dim3(n_reads * 2), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+                     max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_stats);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}

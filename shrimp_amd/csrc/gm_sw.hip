@@ -1,0 +1,640 @@
+// gm_sw.hip -- Smith-Waterman kernels: wave-level anti-diagonal DP (no MFMA: max-plus recurrence).
+//
+//   sw_vector_wave   score-only affine local SW, packed int16 (2 read rows per lane)
+//                    ref: common/sw-vector.c:228-377 (vect_sw_same_gap / _diff_gap), :453-515
+//   k_pass1          read_pass1_per_strand + f1_run           ref: gmapper/mapping.c:1261-1339, common/f1-wrapper.h:97-134
+//   k_select         read_get_vector_hits (top-K ext-heap)    ref: gmapper/mapping.c:1376-1411, common/heap.h:226-327
+//   k_pass2          hit_run_full_sw + sw_full_ls             ref: gmapper/mapping.c:331-402, common/sw-full-ls.c:154-516
+//   k_sw_vector_batch  S1 batch entry
+//
+// sw_vector semantics.  The SSE2 code sweeps 8-row stripes along anti-diagonals with -1/-2
+// sentinels around both sequences; the value it returns is exactly
+//   H(i,j) = max(0, H(i-1,j-1)+s(i,j), A(i,j), B(i,j)),   s = match if codes equal else mismatch
+//   A(i,j) = max(A(i,j-1) - a_ext, H(i,j-1) - a_open - a_ext)     (gap along the genome)
+//   B(i,j) = max(B(i-1,j) - b_ext, H(i-1,j) - b_open - b_ext)     (gap along the read)
+// maximised over the glen x rlen matrix, in int16 (no overflow: match*rlen < 32768, sw-vector.c:393).
+// Pad cells (sentinel codes never match) cannot raise the maximum.  A wave holds read rows 2l and
+// 2l+1 in the two halves of lane l's registers and advances one anti-diagonal per step; row r works
+// on column t-r.  What row r needs from row r-1 arrives through one DPP wave shift + v_alignbit.
+#include "gm_common.h"
+#include "gm_internal.h"
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+#define SW_DB_SENT 0xF0u      // genome pad code (never equals a read code)
+#define SW_QR_SENT 0xF1u      // read pad code
+
+__device__ __forceinline__ uint32_t pk(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
+__device__ __forceinline__ s16x2 as_s(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_max(as_s(a), as_s(b))); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u(as_s(a) - as_s(b)); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return as_u(as_s(a) + as_s(b)); }
+
+// value of lane l-1 (lane 0 keeps `lane0`): v_mov_b32_dpp wave_shr:1
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t lane0) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0, (int)v, 0x138, 0xf, 0xf, false);
+}
+// {low: prev-lane high half, high: own low half}
+__device__ __forceinline__ uint32_t up_of(uint32_t own, uint32_t shifted) { return __builtin_amdgcn_alignbit(own, shifted, 16); }
+
+// Score-only SW of db[0..glen) x qr[0..rlen) by one wave.  db/qr are byte arrays of 4-bit codes in
+// LDS; carry is 2*(glen) int16 in LDS, used only when rlen > 128.  Every lane returns the score.
+__device__ int sw_vector_wave(const uint8_t* db, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc,
+                              int16_t* carry, int lane) {
+  const uint32_t v_match = pk(sc.match, sc.match);
+  const uint32_t v_delta = pk(sc.mismatch - sc.match, sc.mismatch - sc.match);
+  const uint32_t v_a_ext = pk(sc.a_ge, sc.a_ge), v_a_oe = pk(sc.a_go + sc.a_ge, sc.a_go + sc.a_ge);
+  const uint32_t v_b_ext = pk(sc.b_ge, sc.b_ge), v_b_oe = pk(sc.b_go + sc.b_ge, sc.b_go + sc.b_ge);
+  const uint32_t v_one = pk(1, 1);
+  uint32_t v_score = 0;
+  const int n_stripes = (rlen + 127) >> 7;
+  int16_t* carryH = carry; int16_t* carryB = carry + glen;
+  for (int s = 0; s < n_stripes; s++) {
+    const int r0 = s * 128 + 2 * lane;
+    const uint32_t q = pk(r0 < rlen ? qr[r0] : SW_QR_SENT, r0 + 1 < rlen ? qr[r0 + 1] : SW_QR_SENT);
+    const int rows = min(128, rlen - s * 128);
+    const int steps = glen + rows - 1;
+    uint32_t Hprev = 0, Aprev = pk(-sc.a_go, -sc.a_go), Bprev = pk(-sc.b_go, -sc.b_go);
+    uint32_t Gprev = pk(SW_DB_SENT, SW_DB_SENT);
+    uint32_t upH_prev = 0;                     // H(r-1, c-1) for the step to come
+    const bool more = (s + 1 < n_stripes);
+    uint32_t dbv = 0, chv = 0, cbv = 0;
+    for (int t = 0; t < steps; t++) {
+      if ((t & 63) == 0) {                     // refill the per-lane staging of the next 64 columns
+        const int c = t + lane;
+        dbv = (c < glen) ? (uint32_t)db[c] : SW_DB_SENT;
+        if (s > 0) { chv = (c < glen) ? (uint32_t)(uint16_t)carryH[c] : 0u; cbv = (c < glen) ? (uint32_t)(uint16_t)carryB[c] : (uint32_t)(uint16_t)(-sc.b_go); }
+      }
+      const int sl = t & 63;
+      // lane 0's neighbour (row 128s - 1) comes from the carry arrays / the initial row
+      const uint32_t in_g = (uint32_t)__builtin_amdgcn_readlane((int)dbv, sl) << 16;
+      const uint32_t in_h = (s > 0) ? ((uint32_t)__builtin_amdgcn_readlane((int)chv, sl) << 16) : 0u;
+      const uint32_t in_b = (s > 0) ? ((uint32_t)__builtin_amdgcn_readlane((int)cbv, sl) << 16) : ((uint32_t)(uint16_t)(-sc.b_go) << 16);
+      const uint32_t G = up_of(Gprev, wave_shr1(Gprev, in_g));
+      const uint32_t upH = up_of(Hprev, wave_shr1(Hprev, in_h));
+      const uint32_t upB = up_of(Bprev, wave_shr1(Bprev, in_b));
+      // a: gap along the genome (from the left), b: gap along the read (from above)
+      const uint32_t a = pk_max(pk_sub(Aprev, v_a_ext), pk_sub(Hprev, v_a_oe));
+      const uint32_t b = pk_max(pk_sub(upB, v_b_ext), pk_sub(upH, v_b_oe));
+      // s = match where codes are equal, else mismatch:  match + delta * min(code_xor, 1)
+      const uint32_t x = G ^ q;
+      const uint32_t ne = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, x), __builtin_bit_cast(u16x2, v_one)));
+      const uint32_t sv = as_u(as_s(ne) * as_s(v_delta) + as_s(v_match));
+      uint32_t h = pk_add(upH_prev, sv);
+      h = pk_max(h, 0u);
+      h = pk_max(h, a);
+      h = pk_max(h, b);
+      v_score = pk_max(v_score, h);
+      if (more && lane == 63) {                // row 128s+127 feeds the next stripe
+        const int c = t - 127;
+        if (c >= 0 && c < glen) { carryH[c] = (int16_t)(h >> 16); carryB[c] = (int16_t)(b >> 16); }
+      }
+      upH_prev = upH; Hprev = h; Aprev = a; Bprev = b; Gprev = G;
+    }
+    if (more) __syncthreads();
+  }
+  int best = max((int)(int16_t)(v_score & 0xFFFF), (int)(int16_t)(v_score >> 16));
+  for (int d = 32; d > 0; d >>= 1) best = max(best, __shfl_xor(best, d));
+  return best;
+}
+
+// unpack `len` codes starting at global position g0 into dst (forward) or reverse-complemented
+__device__ void load_window(const uint32_t* __restrict__ genome, uint64_t g0, int len, bool rc, uint8_t* dst, int lane) {
+  const uint64_t w0 = g0 >> 3; const int sh = (int)(g0 & 7);
+  const int nwords = (sh + len + 7) >> 3;
+  const uint64_t cm = 0xFBCDE56879A00123ull;   // complement_base as nibbles (ref: util.h:125-151)
+  for (int k = lane; k < nwords; k += GM_WAVE) {
+    const uint32_t w = genome[w0 + k];
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+      const int idx = k * 8 + n - sh;
+      if (idx >= 0 && idx < len) {
+        uint32_t c = (w >> (4 * n)) & 0xf;
+        if (rc) { c = (uint32_t)(cm >> (c * 4)) & 0xf; dst[len - 1 - idx] = (uint8_t)c; }
+        else dst[idx] = (uint8_t)c;
+      }
+    }
+  }
+}
+
+__device__ void load_read(const uint32_t* __restrict__ rw, int read_len, bool rc, uint8_t* dst, int lane) {
+  const uint64_t cm = 0xFBCDE56879A00123ull;
+  for (int i = lane; i < read_len; i += GM_WAVE) {
+    const int src = rc ? (read_len - 1 - i) : i;
+    uint32_t c = (rw[src >> 3] >> ((src & 7) * 4)) & 0xf;
+    if (rc) c = (uint32_t)(cm >> (c * 4)) & 0xf;
+    dst[i] = (uint8_t)c;
+  }
+}
+
+// hash_genome_window % f1_window_cache_size (ref: common/util.h:224-245, common/hash.h:70-95, f1-wrapper.h:27)
+__device__ uint32_t window_hash_slot(const uint8_t* db, int glen, int lane) {
+  const int nbuf = (glen + 15) >> 4;
+  uint32_t key = 0;
+  for (int i0 = 0; i0 < nbuf; i0 += GM_WAVE) {
+    const int i = i0 + lane;
+    uint32_t buffer = 0;
+    if (i < nbuf) for (int j = 0; j < 16 && i * 16 + j < glen; j++) buffer = (buffer << 2) | (db[i * 16 + j] & 3u);
+    const int cnt = min(GM_WAVE, nbuf - i0);
+    for (int k = 0; k < cnt; k++) {
+      const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)buffer, k);
+      key += (bk >> 16);
+      const uint32_t tmp = ((bk & 0xFFFFu) << 11) ^ key;
+      key = (key << 16) ^ tmp;
+      key += key >> 11;
+    }
+  }
+  key ^= key << 3; key += key >> 5; key ^= key << 4; key += key >> 17; key ^= key << 25; key += key >> 6;
+  return key & (1048576u - 1u);
+}
+
+__device__ __forceinline__ int thr_of(double frac, int absval, int base) { return frac < 0 ? absval : (int)((double)base * frac); }
+
+// ---------------------------------------------------------------------------------------------
+// K3: pass 1.  One wave per read-strand walks its windows in (contig, g_off) order.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GM_WAVE)
+k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words,
+        int window_len, int overlap_abs, GmHit* __restrict__ hits, const uint16_t* __restrict__ perm,
+        const uint32_t* __restrict__ hit_cnt, int hcap, unsigned long long* __restrict__ slots, unsigned long long* __restrict__ stats) {
+  extern __shared__ __align__(16) uint8_t sm[];
+  const int lane = threadIdx.x;
+  const int rs = blockIdx.x, rd = rs >> 1, st = rs & 1;
+  const int nh = (int)min(hit_cnt[rs], (uint32_t)hcap);
+  if (nh == 0) return;
+  const int max_w = window_len;
+  uint8_t* qr = sm;                                   // read_len
+  uint8_t* db = sm + ((read_len + 15) & ~15);         // max_w
+  int16_t* carry = (int16_t*)(db + ((max_w + 15) & ~15));
+  load_read(reads + (size_t)rd * read_words, read_len, st != 0, qr, lane);
+  __syncthreads();
+  GmHit* H = hits + (size_t)rs * hcap;
+  const uint16_t* P = perm + (size_t)rs * hcap;
+  unsigned long long* SL = slots + (size_t)rs * hcap; // (cache slot, score) of every computed window (hash_filter_calls); sc1 accesses: written by lane 0, read by all
+  int last_good_cn = -1; uint32_t last_good_goff = 0;
+  int n_comp = 0;
+  unsigned long long calls = 0, cells = 0, bypass = 0;
+  for (int t = 0; t < nh; t++) {
+    const int hi = P[t];
+    GmHit* h = &H[hi];
+    const int matches = h->matches; const int cn = h->cn; const uint32_t goff = h->g_off; const int w_len = h->w_len;
+    if (matches < sc.min_matches) continue;                                             // ref: mapping.c:1275
+    if (last_good_cn >= 0 && cn == last_good_cn &&
+        (long long)goff + (long long)(uint32_t)overlap_abs <= (long long)(uint32_t)(last_good_goff + (uint32_t)window_len)) {  // ref :1287-1293
+      if (lane == 0) { h->score_vector = 0; h->pct_score_vector = 0; }
+      continue;
+    }
+    // (score_vector <= 0 always holds here in unpaired mode, ref :1295)
+    const uint64_t g0 = (uint64_t)ix.contig_off[cn] + goff;
+    load_window(ix.genome, g0, w_len, false, db, lane);
+    __syncthreads();
+    int score = -1;
+    uint32_t slot = 0;
+    if (sc.hash_filter_calls) {                                                          // f1_run look-up, ref: f1-wrapper.h:103-114
+      slot = window_hash_slot(db, w_len, lane);
+      // first computed window of this read-strand with the same slot wins (same tag)
+      int found = -1;
+      for (int c0 = 0; c0 < n_comp; c0 += GM_WAVE) {
+        const int c = c0 + lane;
+        const bool hit = (c < n_comp) && ((uint32_t)__hip_atomic_load(&SL[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == slot);
+        const unsigned long long bal = __ballot(hit);
+        if (bal) { found = c0 + __builtin_ctzll(bal); break; }
+      }
+      if (found >= 0) { score = (int)(__hip_atomic_load(&SL[found], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32); bypass++; }
+    }
+    if (score < 0) {
+      score = sw_vector_wave(db, w_len, qr, read_len, sc, carry, lane);
+      calls++; cells += (unsigned long long)w_len * read_len;
+      if (sc.hash_filter_calls) {
+        if (lane == 0) __hip_atomic_store(&SL[n_comp], (unsigned long long)slot | ((unsigned long long)(uint32_t)score << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        n_comp++; __syncthreads();
+      }
+    }
+    const int score_max = (read_len < w_len ? read_len : w_len) * sc.match;
+    if (lane == 0) { h->score_vector = score; h->pct_score_vector = (1000 * 100 * score) / score_max; }
+    if (score >= thr_of(sc.vect_thr_frac, sc.vect_abs, score_max)) { last_good_cn = cn; last_good_goff = goff; }   // ref :1332-1335
+    __syncthreads();
+  }
+  if (lane == 0) {
+    atomicAdd(&stats[GS_VEC_CALLS], calls); atomicAdd(&stats[GS_VEC_CELLS], cells); atomicAdd(&stats[GS_VEC_BYPASSED], bypass);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4a: top-K by pass1 key with the reference's ext-heap (array order matters downstream).
+// One thread per read; sel[rd][k] = (st << 16) | hit index, in heap array order.
+// ---------------------------------------------------------------------------------------------
+#define SEL_MAX 64
+__global__ void __launch_bounds__(64)
+k_select(GmScoreDev sc, int n_reads, int read_len, const GmHit* __restrict__ hits, const uint16_t* __restrict__ perm,
+         const uint32_t* __restrict__ hit_cnt, int hcap, int32_t* __restrict__ sel, uint32_t* __restrict__ sel_cnt) {
+  const int rd = blockIdx.x * blockDim.x + threadIdx.x;
+  if (rd >= n_reads) return;
+  int key[SEL_MAX]; int id[SEL_MAX];
+  int load = 0;
+  const int K = min(sc.num_tmp_outputs, SEL_MAX);
+  const bool absthr = sc.vect_thr_frac < 0;
+  for (int st = 0; st < 2; st++) {
+    const int rs = rd * 2 + st;
+    const int nh = (int)min(hit_cnt[rs], (uint32_t)hcap);
+    const GmHit* H = hits + (size_t)rs * hcap;
+    const uint16_t* P = perm + (size_t)rs * hcap;
+    for (int t = 0; t < nh; t++) {
+      const GmHit& h = H[P[t]];
+      const int score_max = (read_len < (int)h.w_len ? read_len : (int)h.w_len) * sc.match;
+      const int k = absthr ? h.score_vector : h.pct_score_vector;
+      if (h.score_vector >= thr_of(sc.vect_thr_frac, sc.vect_abs, score_max) && (load < K || k > key[0])) {   // ref: mapping.c:1391-1396
+        const int me = (st << 16) | (int)P[t];
+        if (load < K) {                       // extheap insert + percolate_up (strict <)
+          key[load] = k; id[load] = me; load++;
+          int node = load, parent = node / 2;
+          while (node > 1 && key[node - 1] < key[parent - 1]) {
+            int tk = key[parent - 1]; key[parent - 1] = key[node - 1]; key[node - 1] = tk;
+            int ti = id[parent - 1]; id[parent - 1] = id[node - 1]; id[node - 1] = ti;
+            node = parent; parent = node / 2;
+          }
+        } else {                              // replace_min + percolate_down
+          key[0] = k; id[0] = me;
+          int node = 1;
+          for (;;) {
+            int left = node * 2, right = left + 1, mn = node;
+            if (left <= load && key[left - 1] < key[node - 1]) mn = left;
+            if (right <= load && key[right - 1] < key[mn - 1]) mn = right;
+            if (mn == node) break;
+            int tk = key[mn - 1]; key[mn - 1] = key[node - 1]; key[node - 1] = tk;
+            int ti = id[mn - 1]; id[mn - 1] = id[node - 1]; id[node - 1] = ti;
+            node = mn;
+          }
+        }
+      }
+    }
+  }
+  for (int k = 0; k < load; k++) sel[(size_t)rd * SEL_MAX + k] = id[k];
+  sel_cnt[rd] = (uint32_t)load;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4b: pass 2.  One wave per selected hit: reverse_hit when needed, re-score with the vector
+// filter, then the banded 3-state full SW with the reference's tie rules, and the backtrace.
+// Lane l owns read row 64s + l; column t - l at step t.  Cells outside the band are -INF, as the
+// reference's init_cell(.., 0) leaves them (sw-full-ls.c:66-80,229-231,378-385); the virtual row
+// above the matrix is init_cell(.., 1): nw 0, n -b_open, w -a_open, back 0 (:194-196).
+// ---------------------------------------------------------------------------------------------
+#define FS_NEG (-(INT_MAX / 2))
+
+__device__ __forceinline__ void band_range(long long ax, long long ay, int alen, int awidth, int x_len, int y, int* x_min, int* x_max) {
+  // anchor_get_x_range, ref: common/anchors.c:64-95
+  int mn, mx;
+  if (y < ay) mn = 0;
+  else if (y <= ay + (alen - 1)) mn = (int)(ax + (y - ay));
+  else mn = (int)(ax + alen);
+  if (mn < 0) mn = 0;
+  if (mn >= x_len) mn = x_len - 1;
+  if (y < ay - (awidth - 1)) mx = (int)(ax + (awidth - 1) - 1);
+  else if (y <= ay - (awidth - 1) + (alen - 1)) mx = (int)(ax + (awidth - 1) + (y - (ay - (awidth - 1))));
+  else mx = x_len - 1;
+  if (mx < 0) mx = 0;
+  if (mx >= x_len) mx = x_len - 1;
+  *x_min = mn; *x_max = mx;
+}
+
+__device__ __forceinline__ int shr1_i(int v, int lane0) { return __builtin_amdgcn_update_dpp(lane0, v, 0x138, 0xf, 0xf, false); }
+
+struct FullOut { int score, max_i, max_j, e_nw, e_n, e_w; };
+
+// back byte: bits 0-1 nw source (0 NW_NW, 1 NW_N, 2 NW_W), bit 2 n source (0 N_NW, 1 N_N), bit 3 w source (0 W_NW, 1 W_W), bit 7 = cell computed
+__device__ FullOut full_sw_wave(const uint8_t* db, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc, bool revcmpl,
+                                long long rx, long long ry, int rl, int rw, uint8_t* back, int* carry, int lane) {
+  const int a_go = sc.a_go, a_ge = sc.a_ge, b_go = sc.b_go, b_ge = sc.b_ge;
+  FullOut out; out.score = 0; out.max_i = 0; out.max_j = 0; out.e_nw = out.e_n = out.e_w = 0;
+  const int n_stripes = (rlen + 63) >> 6;
+  int* cNW = carry; int* cN = carry + glen; int* cW = carry + 2 * glen;   // last row of the previous stripe, per column
+  for (int s = 0; s < n_stripes; s++) {
+    const int r = s * 64 + lane;
+    const bool row_ok = r < rlen;
+    const int q = row_ok ? qr[r] : 0x7F;
+    int x_min = 0, x_max = -1;
+    if (row_ok) band_range(rx, ry, rl, rw, glen, r, &x_min, &x_max);
+    const int rows = min(64, rlen - s * 64);
+    const int steps = glen + rows - 1;
+    // own previous cell (r, c-1) and the two cells of row r-1 needed next: (r-1, c) arrives by shift
+    int pw_nw = FS_NEG, pw_n = FS_NEG, pw_w = FS_NEG;          // cell_w  = (r, c-1); column -1 is out of band
+    int d_nw = FS_NEG, d_n = FS_NEG, d_w = FS_NEG;             // cell_nw = (r-1, c-1)
+    int cur_nw = FS_NEG, cur_n = FS_NEG, cur_w = FS_NEG;       // this lane's latest cell, shifted to lane+1 next step
+    if (s == 0 && lane == 0) { d_nw = 0; d_n = -b_go; d_w = -a_go; }   // virtual row -1, column -1
+    const bool more = (s + 1 < n_stripes);
+    const bool last_row_lane = row_ok && (r == rlen - 1);
+    for (int t = 0; t < steps; t++) {
+      const int c = t - lane;
+      // lane 0's upper neighbour at column t: virtual row (stripe 0) or carry from the previous stripe
+      int in_nw, in_n, in_w;
+      if (s == 0) { in_nw = 0; in_n = -b_go; in_w = -a_go; }
+      else { const int cc = min(t, glen - 1); in_nw = cNW[cc]; in_n = cN[cc]; in_w = cW[cc]; if (t >= glen) { in_nw = in_n = in_w = FS_NEG; } }
+      const int u_nw = shr1_i(cur_nw, in_nw), u_n = shr1_i(cur_n, in_n), u_w = shr1_i(cur_w, in_w);   // cell_n = (r-1, c)
+      const bool inband = row_ok && c >= x_min && c <= x_max;
+      int n_nw = FS_NEG, n_n = FS_NEG, n_w = FS_NEG;
+      if (inband) {
+        const int ms = (db[c] == q) ? sc.match : sc.mismatch;
+        int tmp, b0, b1, b2;
+        if (!revcmpl) {                                            // ref: sw-full-ls.c:264-278
+          tmp = d_nw + ms; b0 = 0;
+          if (d_n + ms > tmp) { tmp = d_n + ms; b0 = 1; }
+          if (d_w + ms > tmp) { tmp = d_w + ms; b0 = 2; }
+        } else {                                                   // :279-292
+          tmp = d_w + ms; b0 = 2;
+          if (d_n + ms > tmp) { tmp = d_n + ms; b0 = 1; }
+          if (d_nw + ms > tmp) { tmp = d_nw + ms; b0 = 0; }
+        }
+        n_nw = tmp;
+        if (!revcmpl) {                                            // north :303-320
+          tmp = u_nw - b_go - b_ge; b1 = 0;
+          if (u_n - b_ge > tmp) { tmp = u_n - b_ge; b1 = 1; }
+        } else {
+          tmp = u_n - b_ge; b1 = 1;
+          if (u_nw - b_go - b_ge > tmp) { tmp = u_nw - b_go - b_ge; b1 = 0; }
+        }
+        n_n = tmp;
+        if (!revcmpl) {                                            // west :330-347
+          tmp = pw_nw - a_go - a_ge; b2 = 0;
+          if (pw_w - a_ge > tmp) { tmp = pw_w - a_ge; b2 = 1; }
+        } else {
+          tmp = pw_w - a_ge; b2 = 1;
+          if (pw_nw - a_go - a_ge > tmp) { tmp = pw_nw - a_go - a_ge; b2 = 0; }
+        }
+        n_w = tmp;
+        back[(size_t)r * glen + c] = (uint8_t)(0x80 | b0 | (b1 << 2) | (b2 << 3));
+        if (last_row_lane) {                                       // :359-368 leftmost strict maximum on the last read row
+          int m = max(n_n, n_nw); m = max(m, n_w);
+          if (m > out.score) { out.score = m; out.max_i = r; out.max_j = c; out.e_nw = n_nw; out.e_n = n_n; out.e_w = n_w; }
+        }
+      }
+      if (more && lane == 63 && c >= 0 && c < glen) { cNW[c] = n_nw; cN[c] = n_n; cW[c] = n_w; }
+      // advance: the cell just computed becomes cell_w; the shifted-in cell becomes next step's cell_nw
+      d_nw = u_nw; d_n = u_n; d_w = u_w;
+      pw_nw = n_nw; pw_n = n_n; pw_w = n_w;
+      cur_nw = n_nw; cur_n = n_n; cur_w = n_w;
+      (void)pw_n;
+    }
+    if (more) __syncthreads();
+  }
+  // broadcast the last row's result from its lane
+  const int src = (rlen - 1) & 63;
+  out.score = __shfl(out.score, src); out.max_i = __shfl(out.max_i, src); out.max_j = __shfl(out.max_j, src);
+  out.e_nw = __shfl(out.e_nw, src); out.e_n = __shfl(out.e_n, src); out.e_w = __shfl(out.e_w, src);
+  return out;
+}
+
+__global__ void __launch_bounds__(GM_WAVE)
+k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words,
+        const GmHit* __restrict__ hits, const uint16_t* __restrict__ perm, int hcap,
+        const int32_t* __restrict__ sel, const uint32_t* __restrict__ sel_cnt,
+        const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work_p,
+        GmFullRes* __restrict__ res, uint8_t* __restrict__ ops, int ops_stride,
+        uint8_t* __restrict__ back_pool, size_t back_stride, int max_w, unsigned long long* __restrict__ stats) {
+  extern __shared__ __align__(16) uint8_t sm[];
+  const int lane = threadIdx.x;
+  uint8_t* qr = sm;
+  uint8_t* db = sm + ((read_len + 15) & ~15);
+  int* carry = (int*)(db + ((max_w + 15) & ~15));
+  uint8_t* back = back_pool + (size_t)blockIdx.x * back_stride;
+  const uint32_t n_work = *n_work_p;
+  unsigned long long vcalls = 0, vcells = 0, fcalls = 0;
+  int cur_rd = -1;
+  for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+    const uint32_t wk = work[wi];
+    const int rd = (int)(wk >> 6), k = (int)(wk & 63);
+    const int id = sel[(size_t)rd * SEL_MAX + k];
+    int st = id >> 16; const int hi = id & 0xFFFF;
+    const GmHit h = hits[((size_t)rd * 2 + st) * hcap + hi];
+    if (rd != cur_rd) { __syncthreads(); load_read(reads + (size_t)rd * read_words, read_len, false, qr, lane); cur_rd = rd; }
+    const int cn = h.cn, w_len = h.w_len;
+    const long long clen = (long long)ix.contig_off[cn + 1] - ix.contig_off[cn];
+    long long g_off = h.g_off; long long ax = h.ax, ay = h.ay; int gen_st = 0;
+    if (st != 0) {                                              // reverse_hit, ref: mapping.c:254-263; anchor_reverse anchors.h:30-34
+      g_off = clen - g_off - w_len;
+      ax = -ax + (w_len - 1) - (h.alen - 1) - (h.awidth - 1);
+      ay = -ay + (read_len - 1) - (h.alen - 1) + (h.awidth - 1);
+      gen_st = 1; st = 0;
+    }
+    // the window on the gen_st strand == the + strand window of the original hit, reverse-complemented
+    const uint64_t g0 = (uint64_t)ix.contig_off[cn] + h.g_off;
+    __syncthreads();
+    load_window(ix.genome, g0, w_len, gen_st != 0, db, lane);
+    __syncthreads();
+    const int score_max = (read_len < w_len ? read_len : w_len) * sc.match;
+    const int thresh = thr_of(sc.full_thr_frac, sc.full_abs, score_max);
+    const int sv = sw_vector_wave(db, w_len, qr, read_len, sc, (int16_t*)carry, lane);    // ref: mapping.c:386-388
+    vcalls++; vcells += (unsigned long long)w_len * read_len;
+    GmFullRes R;
+    R.read_idx = rd; R.st = 0; R.gen_st = (int16_t)gen_st; R.cn = (uint32_t)cn; R.g_off = (uint32_t)g_off; R.w_len = w_len;
+    R.score_vector = sv; R.score_max = score_max; R.matches = h.matches; R.score_window_gen = h.score_window_gen;
+    R.score = 0; R.read_start = 0; R.rmapped = 0; R.genome_start = 0; R.gmapped = 0;
+    R.n_match = R.n_mismatch = R.n_ins = R.n_del = 0; R.n_ops = 0; R.ops_off = (uint32_t)(wi * (uint32_t)ops_stride);
+    R.sort_idx = (h.cn);   // filled by host
+    if (sv >= thresh) {
+      fcalls++;
+      // rectangle = anchor_join(1 anchor) + anchor_widen(anchor_width), ref: sw-full-ls.c:176-178, anchors.c:9-61
+      long long nw = ax + ay, sw = ax - ay, ne = sw + 2 * (h.awidth - 1), se = nw + 2 * (h.alen - 1);
+      if ((nw + sw) % 2 != 0) nw--;
+      long long rx = (nw + sw) / 2, ry = nw - rx;
+      if ((ne - sw) % 2 != 0) ne++;
+      int rw = (int)((ne - sw) / 2 + 1);
+      if ((se - nw) % 2 != 0) se++;
+      int rl = (int)((se - nw) / 2 + 1);
+      rx -= sc.anchor_width / 2; ry += sc.anchor_width / 2; rw += sc.anchor_width;
+      __syncthreads();
+      const FullOut fo = full_sw_wave(db, w_len, qr, read_len, sc, (gen_st != 0) && sc.tiebreak_rev, rx, ry, rl, rw, back, carry, lane);
+      __syncthreads();
+      R.score = fo.score;
+      if (fo.score > 0) {
+        // do_backtrace, ref: sw-full-ls.c:413-516 -- lane 0 walks; ops are emitted reversed then flipped
+        if (lane == 0) {
+          int i = fo.max_i, j = fo.max_j;
+          // from-state: 0 nw, 1 n, 2 w  (ref :420-427: nw, then w if strictly greater, then n if strictly greater)
+          int state = 0, fs = fo.e_nw;
+          if (fo.e_w > fs) { state = 2; fs = fo.e_w; }
+          if (fo.e_n > fs) state = 1;
+          uint8_t* o = ops + (size_t)R.ops_off;
+          int no = 0, rstart = 0, gstart = 0, nm = 0, nmm = 0, nin = 0, ndel = 0;
+          while (i >= 0 && j >= 0) {
+            const uint8_t bb = __hip_atomic_load(&back[(size_t)i * w_len + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(bb & 0x80)) break;                // out-of-band cell: back == 0 in the reference
+            int nstate;
+            if (state == 1) {                       // FROM_NORTH_*: BACK_DELETION (gap in the genome)
+              if (no < ops_stride) o[no] = 'D'; no++; ndel++; rstart = i; i--;
+              nstate = ((bb >> 2) & 1) ? 1 : 0;
+            } else if (state == 2) {                // FROM_WEST_*: BACK_INSERTION (gap in the read)
+              if (no < ops_stride) o[no] = 'I'; no++; nin++; gstart = j; j--;
+              nstate = ((bb >> 3) & 1) ? 2 : 0;
+            } else {                                // FROM_NORTHWEST_*
+              if (no < ops_stride) o[no] = 'M'; no++;
+              if (db[j] == qr[i]) nm++; else nmm++;
+              rstart = i; gstart = j; i--; j--;
+              nstate = (bb & 3);                    // 0 nw, 1 n, 2 w
+            }
+            state = nstate;
+          }
+          const int nov = min(no, ops_stride);
+          for (int a = 0, b = nov - 1; a < b; a++, b--) { uint8_t tt = o[a]; o[a] = o[b]; o[b] = tt; }
+          R.n_ops = no; R.read_start = rstart; R.genome_start = gstart + (int)g_off;
+          R.gmapped = fo.max_j - gstart + 1; R.rmapped = fo.max_i - rstart + 1;
+          R.n_match = nm; R.n_mismatch = nmm; R.n_ins = nin; R.n_del = ndel;
+        }
+      }
+    }
+    if (lane == 0) res[wi] = R;
+  }
+  if (lane == 0) { atomicAdd(&stats[GS_FULL_CALLS], fcalls); atomicAdd(&stats[GS_VEC_CALLS], vcalls); atomicAdd(&stats[GS_VEC_CELLS], vcells); }
+}
+
+// work list = (read << 6 | k) for every selected hit, built by a scan-free atomic append (order fixed up on the host by key)
+__global__ void __launch_bounds__(256) k_build_work(int n_reads, const uint32_t* __restrict__ sel_cnt, const uint32_t* __restrict__ sel_off,
+                                                     uint32_t* __restrict__ work) {
+  const int rd = blockIdx.x * blockDim.x + threadIdx.x;
+  if (rd >= n_reads) return;
+  const uint32_t n = sel_cnt[rd], o = sel_off[rd];
+  for (uint32_t k = 0; k < n; k++) work[o + k] = ((uint32_t)rd << 6) | k;
+}
+
+// exclusive scan of sel_cnt (single block; n_reads per sub-batch is modest) -> sel_off, total in n_work
+__global__ void __launch_bounds__(1024) k_scan_counts(int n, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off, uint32_t* __restrict__ total) {
+  __shared__ uint32_t part[1024];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int a0 = tid * per, a1 = min(n, a0 + per);
+  uint32_t s = 0;
+  for (int a = a0; a < a1; a++) s += cnt[a];
+  part[tid] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) { uint32_t v = (tid >= d) ? part[tid - d] : 0; __syncthreads(); part[tid] += v; __syncthreads(); }
+  uint32_t run = part[tid] - s;
+  for (int a = a0; a < a1; a++) { off[a] = run; run += cnt[a]; }
+  if (tid == 1023) *total = part[1023];
+}
+
+// ---------------------------------------------------------------------------------------------
+// S1 batch: n independent (window, read) pairs on caller bitfields
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GM_WAVE)
+k_sw_vector_batch(GmScoreDev sc, int n, const uint32_t* __restrict__ genome, const long long* __restrict__ goff, const int* __restrict__ glen,
+                  const uint32_t* __restrict__ reads, int read_words, const int* __restrict__ rlen, int max_g, int max_r, int* __restrict__ scores) {
+  extern __shared__ __align__(16) uint8_t sm[];
+  const int lane = threadIdx.x;
+  uint8_t* qr = sm;
+  uint8_t* db = sm + ((max_r + 15) & ~15);
+  int16_t* carry = (int16_t*)(db + ((max_g + 15) & ~15));
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    __syncthreads();
+    load_read(reads + (size_t)i * read_words, rlen[i], false, qr, lane);
+    load_window(genome, (uint64_t)goff[i], glen[i], false, db, lane);
+    __syncthreads();
+    const int s = sw_vector_wave(db, glen[i], qr, rlen[i], sc, carry, lane);
+    if (lane == 0) scores[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S2 single call: sw_full_ls on caller bitfields (ref: common/sw-full-ls.c:637-683), global mode.
+// out[0..12] = score read_start rmapped genome_start gmapped matches mismatches insertions deletions n_ops max_i max_j 0
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GM_WAVE)
+k_sw_full_single(GmScoreDev sc, const uint32_t* __restrict__ genome, long long goff, int glen, const uint32_t* __restrict__ read, int rlen,
+                 long long ax, long long ay, int alen, int awidth, int revcmpl, uint8_t* __restrict__ back, int* __restrict__ out,
+                 uint8_t* __restrict__ ops, int ops_cap) {
+  extern __shared__ __align__(16) uint8_t sm[];
+  const int lane = threadIdx.x;
+  uint8_t* qr = sm;
+  uint8_t* db = sm + ((rlen + 15) & ~15);
+  int* carry = (int*)(db + ((glen + 15) & ~15));
+  load_read(read, rlen, false, qr, lane);
+  load_window(genome, (uint64_t)goff, glen, false, db, lane);
+  __syncthreads();
+  long long nw = ax + ay, sw = ax - ay, ne = sw + 2 * (awidth - 1), se = nw + 2 * (alen - 1);
+  if ((nw + sw) % 2 != 0) nw--;
+  long long rx = (nw + sw) / 2, ry = nw - rx;
+  if ((ne - sw) % 2 != 0) ne++;
+  int rw = (int)((ne - sw) / 2 + 1);
+  if ((se - nw) % 2 != 0) se++;
+  int rl = (int)((se - nw) / 2 + 1);
+  rx -= sc.anchor_width / 2; ry += sc.anchor_width / 2; rw += sc.anchor_width;
+  const FullOut fo = full_sw_wave(db, glen, qr, rlen, sc, revcmpl != 0, rx, ry, rl, rw, back, carry, lane);
+  __syncthreads();
+  if (lane == 0) {
+    int i = fo.max_i, j = fo.max_j, no = 0, rstart = 0, gstart = 0, nm = 0, nmm = 0, nin = 0, ndel = 0;
+    if (fo.score > 0) {
+      int state = 0, fs = fo.e_nw;
+      if (fo.e_w > fs) { state = 2; fs = fo.e_w; }
+      if (fo.e_n > fs) state = 1;
+      while (i >= 0 && j >= 0) {
+        const uint8_t bb = __hip_atomic_load(&back[(size_t)i * glen + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(bb & 0x80)) break;
+        int nstate;
+        if (state == 1) { if (no < ops_cap) ops[no] = 'D'; no++; ndel++; rstart = i; i--; nstate = ((bb >> 2) & 1) ? 1 : 0; }
+        else if (state == 2) { if (no < ops_cap) ops[no] = 'I'; no++; nin++; gstart = j; j--; nstate = ((bb >> 3) & 1) ? 2 : 0; }
+        else { if (no < ops_cap) ops[no] = 'M'; no++; if (db[j] == qr[i]) nm++; else nmm++; rstart = i; gstart = j; i--; j--; nstate = (bb & 3); }
+        state = nstate;
+      }
+      const int nov = min(no, ops_cap);
+      for (int a = 0, b = nov - 1; a < b; a++, b--) { uint8_t tt = ops[a]; ops[a] = ops[b]; ops[b] = tt; }
+    }
+    out[0] = fo.score; out[1] = rstart; out[2] = fo.max_i - rstart + 1; out[3] = gstart + (int)goff; out[4] = fo.max_j - gstart + 1;
+    out[5] = nm; out[6] = nmm; out[7] = nin; out[8] = ndel; out[9] = no; out[10] = fo.max_i; out[11] = fo.max_j;
+  }
+}
+
+int gm_launch_sw_full_single(const GmScoreDev& sc, const uint32_t* d_genome, long long goff, int glen, const uint32_t* d_read, int rlen,
+                             long long ax, long long ay, int alen, int awidth, int revcmpl, uint8_t* d_back, int* d_out, uint8_t* d_ops, int ops_cap,
+                             hipStream_t stream) {
+  const size_t lds = ((rlen + 15) & ~15) + ((glen + 15) & ~15) + (size_t)glen * 12 + 64;
+  hipLaunchKernelGGL(k_sw_full_single, dim3(1), dim3(GM_WAVE), lds, stream, sc, d_genome, goff, glen, d_read, rlen, ax, ay, alen, awidth, revcmpl,
+                     d_back, d_out, d_ops, ops_cap);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+// ---- launchers ---------------------------------------------------------------------------------
+int gm_launch_pass1(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
+                    int window_len, int window_overlap_abs, GmHit* d_hits, const uint16_t* d_perm, const uint32_t* d_hit_cnt, int hcap,
+                    unsigned long long* d_slots, unsigned long long* d_stats, hipStream_t stream) {
+  if (n_reads == 0) return GM_OK;
+  const size_t lds = ((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 4 + 64;
+  hipLaunchKernelGGL(k_pass1, dim3(n_reads * 2), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
+                     window_len, window_overlap_abs, d_hits, d_perm, d_hit_cnt, hcap, d_slots, d_stats);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+int gm_launch_select(const GmScoreDev& sc, int n_reads, int read_len, const GmHit* d_hits, const uint16_t* d_perm,
+                     const uint32_t* d_hit_cnt, int hcap, int32_t* d_sel, uint32_t* d_sel_cnt, uint32_t* d_sel_off,
+                     uint32_t* d_work, uint32_t* d_n_work, hipStream_t stream) {
+  if (n_reads == 0) return GM_OK;
+  hipLaunchKernelGGL(k_select, dim3((n_reads + 63) / 64), dim3(64), 0, stream, sc, n_reads, read_len, d_hits, d_perm, d_hit_cnt, hcap, d_sel, d_sel_cnt);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, stream, n_reads, d_sel_cnt, d_sel_off, d_n_work);
+  hipLaunchKernelGGL(k_build_work, dim3((n_reads + 255) / 256), dim3(256), 0, stream, n_reads, d_sel_cnt, d_sel_off, d_work);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
+                    int window_len, const GmHit* d_hits, const uint16_t* d_perm, int hcap, const int32_t* d_sel, const uint32_t* d_sel_cnt,
+                    const uint32_t* d_work, const uint32_t* d_n_work, GmFullRes* d_res, uint8_t* d_ops, int ops_stride,
+                    uint8_t* d_back, size_t back_stride, int grid, unsigned long long* d_stats, hipStream_t stream) {
+  if (n_reads == 0) return GM_OK;
+  const size_t lds = ((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 12 + 64;
+  hipLaunchKernelGGL(k_pass2, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
+                     d_hits, d_perm, hcap, d_sel, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+int gm_launch_sw_vector_batch(const GmScoreDev& sc, int n, const uint32_t* d_genome, const long long* d_goff, const int* d_glen,
+                              const uint32_t* d_reads, int read_words, const int* d_rlen, int max_g, int max_r, int* d_scores, hipStream_t stream) {
+  if (n == 0) return GM_OK;
+  const size_t lds = ((max_r + 15) & ~15) + ((max_g + 15) & ~15) + (size_t)max_g * 4 + 64;
+  const int grid = std::min(n, 256 * 16);
+  hipLaunchKernelGGL(k_sw_vector_batch, dim3(grid), dim3(GM_WAVE), lds, stream, sc, n, d_genome, d_goff, d_glen, d_reads, read_words, d_rlen, max_g, max_r, d_scores);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}

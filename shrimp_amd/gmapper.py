@@ -1,0 +1,293 @@
+"""Python host mirror of the gmapper hot path on MI355X (ctypes over libgmapper_hip.so).
+
+Mirrors the reference's call surface for this path (names, argument meaning, error behaviour):
+    load_genome / genomemap globals   -> Index            (ref: gmapper/genome.c:1012-1182)
+    sw_vector_setup / sw_vector       -> sw_vector_*      (ref: common/sw-vector.c:388-515)
+    sw_full_ls_setup / sw_full_ls     -> sw_full_ls       (ref: common/sw-full-ls.c:568-683)
+    handle_read + SAM emission        -> Session.map_reads (ref: gmapper/mapping.c:1773-1868, gmapper/output.c:227-774)
+All compute happens in the HIP library; there is no Python/CPU fallback: importing works without
+a GPU (so that symbol checks can run), every compute call fails loudly without one.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgmapper_hip.so")
+
+
+class GmError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):   # gm_params_t (include/gmapper_hip.h)
+    _fields_ = [("match_score", C.c_int), ("mismatch_score", C.c_int),
+                ("a_gap_open_score", C.c_int), ("a_gap_extend_score", C.c_int),
+                ("b_gap_open_score", C.c_int), ("b_gap_extend_score", C.c_int),
+                ("window_len", C.c_double), ("window_overlap", C.c_double), ("window_gen_threshold", C.c_double),
+                ("sw_vect_threshold", C.c_double), ("sw_full_threshold", C.c_double),
+                ("match_mode", C.c_int), ("num_outputs", C.c_int), ("num_tmp_outputs", C.c_int), ("anchor_width", C.c_int),
+                ("region_bits", C.c_int), ("region_overlap", C.c_int), ("list_cutoff", C.c_uint32),
+                ("hash_filter_calls", C.c_int), ("tiebreak_rev", C.c_int), ("sam_unaligned", C.c_int), ("longest_read_len", C.c_int)]
+
+
+class MapStats(C.Structure):   # gm_map_stats_t
+    _fields_ = [(n, C.c_uint64) for n in ("reads", "reads_matched", "sam_records", "lookups", "list_entries", "list_bytes",
+                                          "survivors", "anchors", "windows", "vec_calls", "vec_cells", "vec_bypassed",
+                                          "full_calls", "full_cells", "exact_order_reads", "retries")] + \
+               [(n, C.c_double) for n in ("ms_lookup", "ms_anchors", "ms_pass1", "ms_select", "ms_pass2", "ms_host")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Anchor(C.Structure):      # struct gm_anchor == the reference's struct anchor (gmapper-definitions.h:66-74)
+    _fields_ = [("x", C.c_longlong), ("y", C.c_longlong), ("length", C.c_int), ("width", C.c_int),
+                ("weight", C.c_int), ("cn", C.c_int), ("score", C.c_int)]
+
+
+class SwFullResults(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("read_start", "rmapped", "genome_start", "gmapped", "matches", "mismatches",
+                                       "insertions", "deletions", "score")] + [("dbalign", C.c_void_p), ("qralign", C.c_void_p)]
+
+
+# every entry point include/gmapper_hip.h declares
+EXPORTS = ["gm_last_error", "gm_device_count", "gm_params_default", "gm_index_build", "gm_index_free", "gm_index_list_cutoff",
+           "gm_index_bytes", "gm_index_n_slabs", "gm_index_get_list", "gm_index_device_array", "gm_index_meta", "gm_index_alloc_like",
+           "sw_vector_setup", "sw_vector", "sw_vector_stats", "sw_vector_cleanup", "gm_sw_vector_batch",
+           "sw_full_ls_setup", "sw_full_ls", "sw_full_ls_cleanup",
+           "gm_session_create", "gm_session_free", "gm_map_reads", "gm_map_reads_device", "gm_free", "gm_debug_tophits",
+           "gm_last_lookup_timing"]
+
+_lib = None
+
+
+def lib():
+    """The HIP library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GmError(f"{LIB_PATH} is missing: build it with `make -C shrimp_amd/csrc` (or __graft_entry__.build())")
+    L = C.CDLL(LIB_PATH)
+    u32p, vp = C.POINTER(C.c_uint32), C.c_void_p
+    L.gm_last_error.restype = C.c_char_p
+    L.gm_device_count.restype = C.c_int
+    L.gm_params_default.argtypes = [C.POINTER(Params)]
+    L.gm_index_build.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(u32p), u32p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_char_p), C.POINTER(Params)]
+    L.gm_index_free.argtypes = [vp]
+    L.gm_index_list_cutoff.argtypes = [vp]; L.gm_index_list_cutoff.restype = C.c_uint32
+    L.gm_index_bytes.argtypes = [vp]; L.gm_index_bytes.restype = C.c_uint64
+    L.gm_index_n_slabs.argtypes = [vp]; L.gm_index_n_slabs.restype = C.c_int
+    L.gm_index_get_list.argtypes = [vp, C.c_int, C.c_uint32, u32p, u32p, C.c_uint32]
+    L.gm_index_device_array.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64)]
+    L.gm_index_meta.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
+    L.gm_index_alloc_like.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_uint64]
+    L.sw_vector_setup.argtypes = [C.c_int] * 9 + [C.c_bool]
+    L.sw_vector.argtypes = [u32p, C.c_int, C.c_int, u32p, C.c_int, u32p, C.c_int, C.c_bool]
+    L.gm_sw_vector_batch.argtypes = [C.c_int, u32p, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int), u32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.sw_full_ls_setup.argtypes = [C.c_int] * 8 + [C.c_bool, C.c_int]
+    L.sw_full_ls.argtypes = [u32p, C.c_int, C.c_int, u32p, C.c_int, C.c_int, C.c_int, C.POINTER(SwFullResults), C.c_bool, C.POINTER(Anchor), C.c_int, C.c_int]
+    L.sw_full_ls.restype = None
+    L.gm_session_create.argtypes = [C.POINTER(vp), vp, C.POINTER(Params), C.c_int]
+    L.gm_session_free.argtypes = [vp]
+    L.gm_map_reads.argtypes = [vp, C.c_int, C.c_int, u32p, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
+    L.gm_map_reads_device.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
+    L.gm_free.argtypes = [vp]
+    L.gm_debug_tophits.argtypes = [vp, C.c_int, C.c_int, u32p, C.POINTER(C.c_longlong), C.c_long, C.POINTER(C.c_long)]
+    L.gm_last_lookup_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise GmError(f"{what} failed ({rc}): {lib().gm_last_error().decode()}")
+
+
+def default_params() -> Params:
+    p = Params()
+    lib().gm_params_default(C.byref(p))
+    return p
+
+
+def pack_codes(codes: np.ndarray) -> np.ndarray:
+    """4-bit codes -> the reference's bitfield (8 bases per uint32; ref: common/util.h:41)."""
+    from .synth import pack_nibbles
+    return pack_nibbles(np.asarray(codes, dtype=np.uint8))
+
+
+class Index:
+    """Device-resident seed index + genome (the reference's genomemap/genome_contigs globals)."""
+
+    def __init__(self, contigs, names=None, seeds=None, params: Params | None = None, device: int = 0):
+        L = lib()
+        self.params = params or default_params()
+        self._packed = [np.ascontiguousarray(pack_codes(c)) for c in contigs]
+        n = len(contigs)
+        self.contig_len = [int(len(c)) for c in contigs]
+        ptrs = (C.POINTER(C.c_uint32) * n)(*[p.ctypes.data_as(C.POINTER(C.c_uint32)) for p in self._packed])
+        lens = (C.c_uint32 * n)(*self.contig_len)
+        cn = None
+        if names is not None:
+            cn = (C.c_char_p * n)(*[s.encode() if isinstance(s, str) else s for s in names])
+        sd = None
+        ns = 0
+        if seeds:
+            ns = len(seeds); sd = (C.c_char_p * ns)(*[s.encode() for s in seeds])
+        self.h = C.c_void_p()
+        _check(L.gm_index_build(C.byref(self.h), device, n, ptrs, lens, cn, ns, sd, C.byref(self.params)), "gm_index_build")
+        self.device = device
+
+    @property
+    def list_cutoff(self): return lib().gm_index_list_cutoff(self.h)
+    @property
+    def nbytes(self): return lib().gm_index_bytes(self.h)
+    @property
+    def n_slabs(self): return lib().gm_index_n_slabs(self.h)
+
+    def get_list(self, sn: int, mapidx: int) -> np.ndarray:
+        L = lib(); n = C.c_uint32()
+        _check(L.gm_index_get_list(self.h, sn, mapidx, C.byref(n), None, 0), "gm_index_get_list")
+        out = np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            _check(L.gm_index_get_list(self.h, sn, mapidx, C.byref(n), out.ctypes.data_as(C.POINTER(C.c_uint32)), n.value), "gm_index_get_list")
+        return out
+
+    def device_arrays(self):
+        """(device pointer, nbytes) of every resident array, for the start-up broadcast."""
+        L = lib(); out = []
+        kind = 0
+        while True:
+            p = C.c_void_p(); b = C.c_uint64()
+            if L.gm_index_device_array(self.h, kind, C.byref(p), C.byref(b)) != 0:
+                break
+            out.append((p.value, b.value)); kind += 1
+        return out
+
+    def meta(self) -> bytes:
+        L = lib(); nb = C.c_uint64(0)
+        L.gm_index_meta(self.h, None, C.byref(nb))
+        buf = C.create_string_buffer(nb.value)
+        L.gm_index_meta(self.h, buf, C.byref(nb))
+        return buf.raw
+
+    @classmethod
+    def alloc_like(cls, meta: bytes, device: int = 0) -> "Index":
+        self = cls.__new__(cls)
+        self.h = C.c_void_p(); self.device = device; self.params = default_params()
+        _check(lib().gm_index_alloc_like(C.byref(self.h), device, meta, len(meta)), "gm_index_alloc_like")
+        return self
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gm_index_free(self.h); self.h = None
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
+
+
+class Session:
+    """One mapping stream on one GPU (the reference's per-thread state)."""
+
+    def __init__(self, index: Index, params: Params | None = None, max_batch_reads: int = 131072):
+        self.index = index
+        self.h = C.c_void_p()
+        self.params = params or index.params
+        _check(lib().gm_session_create(C.byref(self.h), index.h, C.byref(self.params), max_batch_reads), "gm_session_create")
+        self.stats = None
+
+    def map_reads(self, reads_codes: np.ndarray, names=None) -> bytes:
+        """reads_codes: [n, L] uint8 4-bit codes -> SAM records (bytes), input order."""
+        from .synth import pack_reads
+        reads_codes = np.ascontiguousarray(reads_codes, dtype=np.uint8)
+        n, Lr = reads_codes.shape
+        packed = np.ascontiguousarray(pack_reads(reads_codes))
+        return self.map_packed(packed, n, Lr, names)
+
+    def map_packed(self, packed: np.ndarray, n: int, read_len: int, names=None) -> bytes:
+        L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
+        nm = None
+        if names is not None:
+            nm = b"\n".join(x if isinstance(x, bytes) else x.encode() for x in names)
+        _check(L.gm_map_reads(self.h, n, read_len, packed.ctypes.data_as(C.POINTER(C.c_uint32)), nm, C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_reads")
+        out = C.string_at(sam, sl.value) if sam.value else b""
+        L.gm_free(sam)
+        self.stats = st.as_dict()
+        return out
+
+    def map_device(self, dev_ptr: int, n: int, read_len: int, emit_sam: bool = True):
+        L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
+        _check(L.gm_map_reads_device(self.h, n, read_len, C.c_void_p(dev_ptr), int(emit_sam), C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_reads_device")
+        out = C.string_at(sam, sl.value) if sam.value else b""
+        if sam.value: L.gm_free(sam)
+        self.stats = st.as_dict()
+        return out
+
+    def tophits(self, reads_codes: np.ndarray) -> np.ndarray:
+        from .synth import pack_reads
+        reads_codes = np.ascontiguousarray(reads_codes, dtype=np.uint8)
+        n, Lr = reads_codes.shape
+        packed = np.ascontiguousarray(pack_reads(reads_codes))
+        rows = np.zeros((n * 30, 12), dtype=np.int64); nr = C.c_long()
+        _check(lib().gm_debug_tophits(self.h, n, Lr, packed.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                      rows.ctypes.data_as(C.POINTER(C.c_longlong)), n * 30, C.byref(nr)), "gm_debug_tophits")
+        return rows[:nr.value]
+
+    def lookup_timing(self):
+        ms = C.c_double(); b = C.c_uint64(); n = C.c_int()
+        lib().gm_last_lookup_timing(self.h, C.byref(ms), C.byref(b), C.byref(n))
+        return ms.value, b.value, n.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gm_session_free(self.h); self.h = None
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
+
+
+# ---- S1 / S2 seams ---------------------------------------------------------------------------------
+def sw_vector_setup(dblen, qrlen, a_gap_open, a_gap_ext, b_gap_open, b_gap_ext, match, mismatch, use_colours=0, reset_stats=True):
+    _check(lib().sw_vector_setup(dblen, qrlen, a_gap_open, a_gap_ext, b_gap_open, b_gap_ext, match, mismatch, use_colours, reset_stats), "sw_vector_setup")
+
+
+def sw_vector_batch(genome_words: np.ndarray, g_off, glen, reads_words: np.ndarray, rlen) -> np.ndarray:
+    L = lib()
+    genome_words = np.ascontiguousarray(genome_words, dtype=np.uint32)
+    reads_words = np.ascontiguousarray(reads_words, dtype=np.uint32)
+    n = reads_words.shape[0]
+    g_off = np.ascontiguousarray(g_off, dtype=np.int64); glen = np.ascontiguousarray(glen, dtype=np.int32); rlen = np.ascontiguousarray(rlen, dtype=np.int32)
+    out = np.zeros(n, dtype=np.int32)
+    _check(L.gm_sw_vector_batch(n, genome_words.ctypes.data_as(C.POINTER(C.c_uint32)), genome_words.size,
+                                g_off.ctypes.data_as(C.POINTER(C.c_int64)), glen.ctypes.data_as(C.POINTER(C.c_int)),
+                                reads_words.ctypes.data_as(C.POINTER(C.c_uint32)), reads_words.shape[1],
+                                rlen.ctypes.data_as(C.POINTER(C.c_int)), out.ctypes.data_as(C.POINTER(C.c_int))), "gm_sw_vector_batch")
+    return out
+
+
+def sw_vector(genome_words, goff, glen, read_words, rlen) -> int:
+    g = np.ascontiguousarray(genome_words, dtype=np.uint32); r = np.ascontiguousarray(read_words, dtype=np.uint32)
+    return lib().sw_vector(g.ctypes.data_as(C.POINTER(C.c_uint32)), goff, glen, r.ctypes.data_as(C.POINTER(C.c_uint32)), rlen, None, -1, False)
+
+
+def sw_full_ls_setup(dblen, qrlen, a_gap_open, a_gap_ext, b_gap_open, b_gap_ext, match, mismatch, reset_stats=True, anchor_width=8):
+    _check(lib().sw_full_ls_setup(dblen, qrlen, a_gap_open, a_gap_ext, b_gap_open, b_gap_ext, match, mismatch, reset_stats, anchor_width), "sw_full_ls_setup")
+
+
+def sw_full_ls(genome_words, goff, glen, read_words, rlen, anchor, revcmpl=False):
+    """anchor = (x, y, length, width); returns (fields dict, dbalign, qralign)."""
+    L = lib()
+    g = np.ascontiguousarray(genome_words, dtype=np.uint32); r = np.ascontiguousarray(read_words, dtype=np.uint32)
+    a = Anchor(anchor[0], anchor[1], anchor[2], anchor[3], 1, 0, 0)
+    s = SwFullResults()
+    L.sw_full_ls(g.ctypes.data_as(C.POINTER(C.c_uint32)), goff, glen, r.ctypes.data_as(C.POINTER(C.c_uint32)), rlen, 0, 0,
+                 C.byref(s), bool(revcmpl), C.byref(a), 1, 0)
+    db = C.string_at(s.dbalign).decode() if s.dbalign else ""
+    qr = C.string_at(s.qralign).decode() if s.qralign else ""
+    L.gm_free(s.dbalign); L.gm_free(s.qralign)
+    return {n: getattr(s, n) for n, _ in SwFullResults._fields_[:9]}, db, qr

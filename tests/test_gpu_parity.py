@@ -1,0 +1,146 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, through the C ABI, against
+(a) the reference's own golden outputs, (b) the CPU oracle on seeded inputs."""
+import numpy as np
+import pytest
+from tests import oracle_api as oa
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = ["cfg1_36bp_1Mbp", "cfg2s_100bp_2Mbp", "stress_60bp", "stress_100bp_unal"]
+
+
+@pytest.fixture(scope="module")
+def gm():
+    from shrimp_amd import gmapper
+    if gmapper.lib().gm_device_count() < 1:
+        pytest.fail("no HIP device: the product path has no CPU fallback")
+    return gmapper
+
+
+def _first_diff(a: bytes, b: bytes):
+    la, lb = a.split(b"\n"), b.split(b"\n")
+    for i, (x, y) in enumerate(zip(la, lb)):
+        if x != y:
+            return i, x[:300], y[:300]
+    return min(len(la), len(lb)), b"<eof>", b"<eof>"
+
+
+def test_sw_vector_known_answers(gm):
+    """S1: every vector-SW known answer produced by the reference's own sw_vector()."""
+    gm.sw_vector_setup(1400, 1000, -33, -7, -33, -3, 10, -15, 0, True)
+    recs = [r for r in oa.load_kat() if r[0] == "V"]
+    n = 0
+    for _, goff, glen, rlen, g, r, score in recs:
+        got = gm.sw_vector_batch(g, [goff], [glen], r[None, :], [rlen])[0]
+        assert got == score, (goff, glen, rlen, got, score)
+        n += 1
+        if n >= 400: break
+    # and the single-call form with the reference's parameter list
+    _, goff, glen, rlen, g, r, score = recs[0]
+    assert gm.sw_vector(g, goff, glen, r, rlen) == score
+
+
+def test_sw_vector_batch_random_vs_oracle(gm, oracle_lib):
+    """>= 10^4 random + adversarial windows in one batch against the CPU restatement."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    n, L = 4000, 100
+    G = rng.integers(0, 4, size=200_000, dtype=np.uint8)
+    G[rng.integers(0, G.size, 300)] = 15
+    starts = rng.integers(0, G.size - 400, size=n)
+    reads = np.stack([G[s + 20:s + 20 + L].copy() for s in starts])
+    mut = rng.random(reads.shape) < 0.06
+    reads = np.where(mut, rng.integers(0, 4, size=reads.shape), reads).astype(np.uint8)
+    reads[:50] = 0; G[:2000] = 0                      # homopolymer block: all ties
+    from shrimp_amd import synth
+    gw = synth.pack_nibbles(G); rw = synth.pack_reads(reads)
+    glen = np.full(n, 140, dtype=np.int32); glen[::7] = 90   # window shorter than the read
+    gm.sw_vector_setup(1400, 1000, -33, -7, -33, -3, 10, -15, 0, True)
+    got = gm.sw_vector_batch(gw, starts, glen, rw, np.full(n, L, dtype=np.int32))
+    u32p = C.POINTER(C.c_uint32)
+    want = np.array([oracle_lib.gmo_sw_vector(gw.ctypes.data_as(u32p), int(starts[i]), int(glen[i]),
+                                              np.ascontiguousarray(rw[i]).ctypes.data_as(u32p), L) for i in range(n)])
+    assert (got == want).all(), np.nonzero(got != want)[0][:10]
+
+
+def test_sw_vector_long_reads_multi_stripe(gm, oracle_lib):
+    """reads longer than 128 rows exercise the stripe carry"""
+    import ctypes as C
+    from shrimp_amd import synth
+    rng = np.random.default_rng(9)
+    n, L, W = 64, 300, 420
+    G = rng.integers(0, 4, size=50_000, dtype=np.uint8)
+    starts = rng.integers(0, G.size - 600, size=n)
+    reads = np.stack([G[s + 40:s + 40 + L].copy() for s in starts])
+    reads = np.where(rng.random(reads.shape) < 0.04, rng.integers(0, 4, size=reads.shape), reads).astype(np.uint8)
+    gw = synth.pack_nibbles(G); rw = synth.pack_reads(reads)
+    gm.sw_vector_setup(1400, 1000, -33, -7, -33, -3, 10, -15, 0, True)
+    got = gm.sw_vector_batch(gw, starts, np.full(n, W, dtype=np.int32), rw, np.full(n, L, dtype=np.int32))
+    u32p = C.POINTER(C.c_uint32)
+    want = np.array([oracle_lib.gmo_sw_vector(gw.ctypes.data_as(u32p), int(starts[i]), W,
+                                              np.ascontiguousarray(rw[i]).ctypes.data_as(u32p), L) for i in range(n)])
+    assert (got == want).all()
+
+
+def test_sw_full_ls_known_answers(gm):
+    """S2: full SW + traceback against the reference's own sw_full_ls() answers."""
+    gm.sw_full_ls_setup(1400, 1000, -33, -7, -33, -3, 10, -15, True, 8)
+    n = 0
+    for rec in oa.load_kat():
+        if rec[0] != "F": continue
+        _, goff, glen, rlen, ax, ay, alen, aw, rv, g, r, exp, edb, eqr = rec
+        f, db, qr = gm.sw_full_ls(g, goff, glen, r, rlen, (ax, ay, alen, aw), revcmpl=bool(rv))
+        got = [f[k] for k in ("score", "read_start", "rmapped", "genome_start", "gmapped", "matches", "mismatches", "insertions", "deletions")]
+        assert got == exp, (n, goff, glen, rlen, ax, ay, alen, aw, rv, got, exp)
+        assert db == edb and qr == eqr
+        n += 1
+        if n >= 300: break
+    assert n >= 300
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_sam_matches_reference_golden(gm, name):
+    """S4/S5: index build + full pipeline -> SAM, byte-identical to the reference binary's output."""
+    contigs, reads, sam = oa.load_golden(name)
+    p = gm.default_params()
+    p.sam_unaligned = 1 if name.endswith("_unal") else 0
+    ix = gm.Index(contigs, params=p)
+    s = gm.Session(ix, params=p, max_batch_reads=4096)
+    got = oa.sam_header(contigs) + s.map_reads(reads)
+    st = s.stats
+    s.close(); ix.close()
+    assert got == sam, (_first_diff(got, sam), st)
+
+
+def test_tophits_match_oracle_on_stress(gm, oracle_lib):
+    """stage parity: the pass-1 survivors (ext-heap array order, scores, anchor boxes)"""
+    contigs, reads, _ = oa.load_golden("stress_60bp")
+    ix = gm.Index(contigs); s = gm.Session(ix, max_batch_reads=4096)
+    got = s.tophits(reads)
+    o = oa.Session(contigs); want = o.tophits(reads); o.close()
+    s.close(); ix.close()
+    assert got.shape == want.shape and (got == want).all(), (got.shape, want.shape)
+
+
+def test_index_lists_match_oracle_semantics(gm):
+    """S5: lists are ascending, skip N-containing spans and never cross contigs (ref: genome.c:1139-1163)."""
+    rng = np.random.default_rng(3)
+    c1 = rng.integers(0, 4, size=5000, dtype=np.uint8); c1[100:105] = 15
+    c2 = rng.integers(0, 4, size=3000, dtype=np.uint8)
+    ix = gm.Index([c1, c2])
+    mask = "11110111101111"; span = len(mask)
+    allc = np.concatenate([c1, c2])
+    tot = 0
+    for q in list(range(80, 130)) + list(range(4980, 5010)):
+        if q + span > len(allc): continue
+        win = allc[q:q + span]
+        idx = 0
+        for t in range(span):                      # mask bit t <-> base q+span-1-t
+            if mask[span - 1 - t] == "1": idx = (idx << 2) | int(win[span - 1 - t] & 3)
+        lst = ix.get_list(0, idx)
+        valid = (15 not in win) and not (q < 5000 < q + span)
+        assert (q in lst) == valid, (q, valid)
+        assert (np.diff(lst.astype(np.int64)) > 0).all()
+        tot += 1
+    ix.close()
+    assert tot > 50
