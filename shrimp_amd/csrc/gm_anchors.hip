@@ -11,25 +11,37 @@
 // size, whatever the order inside the group (DESIGN.md "tie order").  When a position occurs
 // with two different y, lane 0 replays the reference's heap (same insert order, same strict-<
 // sift rules) over the survivors to obtain the exact pop order.  Both cases are exact.
+#include <cstring>
+#include <algorithm>
 #include "gm_common.h"
 #include "gm_internal.h"
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 
-#define K2_NONE 0xFFFFu
+// Two tiers.  LDS tier (BIG = false): one wave per read-strand, survivors (<= scap) sorted by a
+// bitonic network in LDS.  Heavy tier (BIG = true): the few read-strands with more survivors than
+// that (low-complexity reads, repeats); their keys were re-emitted by K1 into exactly sized global
+// segments and sorted by one segmented radix sort; the same code then runs on global arrays.
+template <bool BIG> struct K2Idx { typedef uint16_t type; static constexpr uint32_t none = 0xFFFFu; };
+template <> struct K2Idx<true> { typedef uint32_t type; static constexpr uint32_t none = 0xFFFFFFFFu; };
 
-struct K2Ws {            // per-wave workspace (LDS or global)
-  uint64_t* key;         // [npad]  sort keys; later anchors: x<<32 | len<<16 | weight
-  uint32_t* aux;         // [npad]  y | cn<<16
-  uint16_t* nxt;         // [kmax]  exact path: next survivor of the same list
-  uint16_t* ord;         // [kmax]  exact path: pop order
-  uint16_t* first;       // [NL]    exact path: cursor per list
-  uint32_t* hk;          // [NL]    exact path: heap keys / temp
-  uint16_t* hr;          // [NL]    exact path: heap payload (list id)
+template <bool BIG>
+struct K2Ws {            // per-wave workspace
+  typedef typename K2Idx<BIG>::type idx_t;
+  uint64_t* key;         // [cap]  sort keys pos<<32 | y<<16 | seed; later anchors: x<<32 | len<<16 | weight
+  uint32_t* aux;         // [cap]  y | cn<<16
+  idx_t* nxt;            // [cap]  exact path: next survivor of the same list
+  idx_t* ord;            // [cap]  exact path: pop order
+  idx_t* first;          // [NL]   exact path: cursor per list
+  uint32_t* hk;          // [NL]   exact path: heap keys / temp
+  uint16_t* hr;          // [NL]   exact path: heap payload (list id)
   int16_t*  cache;       // [read_len] anchor_cache (ref: mapping.c:871,909-910)
 };
 
-__device__ __forceinline__ void k2_sync() { __syncthreads(); }
+// LDS tier: a plain barrier.  Heavy tier: the arrays live in global memory and are written by one
+// lane and read by the others, so the barrier also releases/acquires at agent scope (L1 invalidate).
+template <bool BIG> __device__ __forceinline__ void k2_sync() { if (BIG) __threadfence(); __syncthreads(); }
 
-__device__ void k2_bitonic(uint64_t* key, int npad, int lane) {
+template <bool BIG> __device__ void k2_bitonic(uint64_t* key, int npad, int lane) {
   for (int k = 2; k <= npad; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int t = lane; t < (npad >> 1); t += GM_WAVE) {
@@ -39,7 +51,7 @@ __device__ void k2_bitonic(uint64_t* key, int npad, int lane) {
         const uint64_t a = key[i], b = key[l];
         if ((a > b) == up) { key[i] = b; key[l] = a; }
       }
-      k2_sync();
+      k2_sync<BIG>();
     }
 }
 
@@ -65,63 +77,51 @@ __device__ __forceinline__ int k2_threshold(double frac, int absval, int base) {
   return frac < 0 ? absval : (int)((double)base * frac);
 }
 
-template <bool GLOBAL_WS>
+template <bool BIG>
 __global__ void __launch_bounds__(GM_WAVE)
 k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_len, int max_n_kmers, int NL,
-          const uint64_t* __restrict__ surv, const uint32_t* __restrict__ surv_cnt, int scap, int kmax,
-          uint8_t* __restrict__ ws_global, size_t ws_stride, uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_cnt, int max_big,
+          const uint64_t* __restrict__ surv, const uint32_t* __restrict__ surv_cnt, int scap,
+          // heavy tier only: list of read-strands, their segments in big_keys/big_aux/big_nxt/big_ord
+          int n_heavy, const uint32_t* __restrict__ heavy_list, const uint64_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_n,
+          uint64_t* __restrict__ big_keys, uint32_t* __restrict__ big_aux, uint32_t* __restrict__ big_nxt, uint32_t* __restrict__ big_ord,
           GmHit* __restrict__ hits, uint16_t* __restrict__ perm, uint32_t* __restrict__ hit_cnt, int hcap,
           unsigned long long* __restrict__ stats) {
+  typedef typename K2Idx<BIG>::type idx_t;
+  constexpr uint32_t K2_NONE = K2Idx<BIG>::none;
   extern __shared__ __align__(16) uint8_t smem_raw[];
   const int lane = threadIdx.x;
-  int rs;
-  if (GLOBAL_WS) {
-    const uint32_t nb = min(*big_cnt, (uint32_t)max_big);
-    if (blockIdx.x >= nb) return;
-    rs = (int)big_list[blockIdx.x];
+  int rs, n;
+  K2Ws<BIG> ws;
+  uint8_t* base = smem_raw;
+  if (BIG) {
+    if ((int)blockIdx.x >= n_heavy) return;
+    rs = (int)heavy_list[blockIdx.x];
+    n = (int)seg_n[blockIdx.x];
+    const uint64_t o = seg_off[blockIdx.x];
+    ws.key = big_keys + o; ws.aux = big_aux + o; ws.nxt = (idx_t*)(big_nxt + o); ws.ord = (idx_t*)(big_ord + o);
   } else {
     rs = blockIdx.x;
+    const uint32_t n_all = surv_cnt[rs];
+    if (n_all == 0 || n_all > (uint32_t)scap) { if (lane == 0) hit_cnt[rs] = 0; return; }   // > scap: heavy tier
+    n = (int)n_all;
+    ws.key = (uint64_t*)base;                    base += (size_t)scap * 8;
+    ws.aux = (uint32_t*)base;                    base += (size_t)scap * 4;
+    ws.nxt = (idx_t*)base;                       base += (size_t)scap * sizeof(idx_t);
+    ws.ord = (idx_t*)base;                       base += (size_t)scap * sizeof(idx_t);
   }
-  const uint32_t n_all = surv_cnt[rs];
-  const int n = (int)min(n_all, (uint32_t)scap);
-  if (n == 0) { if (lane == 0) hit_cnt[rs] = 0; return; }
-  if (!GLOBAL_WS && n > kmax) {          // deferred to the global-workspace launch
-    if (lane == 0) {
-      uint32_t s = atomicAdd(big_cnt, 1u);
-      if (s < (uint32_t)max_big) big_list[s] = (uint32_t)rs; else atomicAdd(&stats[GS_OVERFLOW_SURV], 1ull);
-      hit_cnt[rs] = 0;
-    }
-    return;
-  }
-  int npad = 64; while (npad < n) npad <<= 1;
-  const int cap = GLOBAL_WS ? scap : kmax;      // array sizes
-
-  // carve the workspace
-  uint8_t* base = GLOBAL_WS ? (ws_global + (size_t)blockIdx.x * ws_stride) : smem_raw;
-  K2Ws ws;
-  ws.key = (uint64_t*)base;                      base += (size_t)cap * 8;
-  ws.aux = (uint32_t*)base;                      base += (size_t)cap * 4;
   ws.hk = (uint32_t*)base;                       base += (size_t)NL * 4;
-  ws.nxt = (uint16_t*)base;                      base += (size_t)cap * 2;
-  ws.ord = (uint16_t*)base;                      base += (size_t)cap * 2;
-  ws.first = (uint16_t*)base;                    base += (size_t)((NL + 1) & ~1) * 2;
+  ws.first = (idx_t*)base;                       base += (size_t)((NL + 1) & ~1) * sizeof(idx_t);
   ws.hr = (uint16_t*)base;                       base += (size_t)((NL + 1) & ~1) * 2;
   ws.cache = (int16_t*)base;
 
-  // ---- 1. keys: pos<<32 | y<<16 | sn; bitonic sort ----
-  const uint64_t* sv = surv + (size_t)rs * scap;
-  for (int t = lane; t < npad; t += GM_WAVE) {
-    uint64_t k = ~0ull;
-    if (t < n) {
-      const uint64_t e = sv[t];
-      const uint32_t off = (uint32_t)e;
-      const uint32_t sn = off / (uint32_t)max_n_kmers, y = off - sn * (uint32_t)max_n_kmers;
-      k = (e & 0xFFFFFFFF00000000ull) | ((uint64_t)y << 16) | sn;
-    }
-    ws.key[t] = k;
+  // ---- 1. sort by (position, read offset, seed): bitonic in LDS / already done by the segmented radix sort ----
+  if (!BIG) {
+    int npad = 64; while (npad < n) npad <<= 1;
+    const uint64_t* sv = surv + (size_t)rs * scap;
+    for (int t = lane; t < npad; t += GM_WAVE) ws.key[t] = (t < n) ? sv[t] : ~0ull;
+    k2_sync<BIG>();
+    k2_bitonic<BIG>(ws.key, npad, lane);
   }
-  k2_sync();
-  k2_bitonic(ws.key, npad, lane);
 
   // ---- 2. does any position carry two different read offsets?  then replay the heap ----
   bool danger = false;
@@ -133,11 +133,11 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
   if (danger) {
     if (lane == 0) {
       atomicAdd(&stats[GS_EXACT_ORDER], 1ull);
-      for (int o = 0; o < NL; o++) ws.first[o] = K2_NONE;
+      for (int o = 0; o < NL; o++) ws.first[o] = (idx_t)K2_NONE;
       for (int t = n - 1; t >= 0; t--) {
         const uint64_t k = ws.key[t];
         const int off = (int)(k & 0xFFFF) * max_n_kmers + (int)((k >> 16) & 0xFFFF);
-        ws.nxt[t] = ws.first[off]; ws.first[off] = (uint16_t)t;
+        ws.nxt[t] = ws.first[off]; ws.first[off] = (idx_t)t;
       }
       // heap_uu (ref: common/heap.h:44-139): 1-based nodes over hk/hr[0..load)
       int load = 0;
@@ -154,8 +154,8 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
         }
       };
       for (int o = 0; o < NL; o++) {          // initial inserts in (seed, read position) order, ref: mapping.c:913-935
-        if (ws.first[o] == K2_NONE) continue;
-        ws.hk[load] = pos_of(ws.first[o]); ws.hr[load] = (uint16_t)o; load++;
+        if (ws.first[o] == (idx_t)K2_NONE) continue;
+        ws.hk[load] = pos_of((int)ws.first[o]); ws.hr[load] = (uint16_t)o; load++;
         int node = load, parent = node / 2;
         while (node > 1 && ws.hk[node - 1] < ws.hk[parent - 1]) {
           uint32_t tk = ws.hk[parent - 1]; ws.hk[parent - 1] = ws.hk[node - 1]; ws.hk[node - 1] = tk;
@@ -166,10 +166,10 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
       int m = 0;
       while (load > 0) {                      // ref: mapping.c:937-989
         const int o = ws.hr[0];
-        const int t = ws.first[o];
-        ws.ord[m++] = (uint16_t)t;
-        const uint16_t nx = ws.nxt[t];
-        if (nx != K2_NONE) { ws.first[o] = nx; ws.hk[0] = pos_of(nx); ws.hr[0] = (uint16_t)o; down(1); }
+        const int t = (int)ws.first[o];
+        ws.ord[m++] = (idx_t)t;
+        const idx_t nx = ws.nxt[t];
+        if (nx != (idx_t)K2_NONE) { ws.first[o] = nx; ws.hk[0] = pos_of((int)nx); ws.hr[0] = (uint16_t)o; down(1); }
         else { load--; if (load > 0) { ws.hk[0] = ws.hk[load]; ws.hr[0] = ws.hr[load]; down(1); } }
       }
       // apply the pop order: it only permutes entries inside groups of equal position, so only the
@@ -185,7 +185,7 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
         g0 = g1;
       }
     }
-    k2_sync();
+    k2_sync<BIG>();
   }
 
   // ---- 3. contig of every entry (get_contig_num, ref: gmapper.h:373-405), then colinear collapse ----
@@ -197,7 +197,7 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
     ws.aux[t] = (uint32_t)((k >> 16) & 0xFFFF) | ((uint32_t)lo << 16);
   }
   for (int d = lane; d < read_len; d += GM_WAVE) ws.cache[d] = -1;
-  k2_sync();
+  k2_sync<BIG>();
   __shared__ int sh_na;
   if (lane == 0) {
     int na = 0;
@@ -232,7 +232,7 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
     }
     sh_na = na;
   }
-  k2_sync();
+  k2_sync<BIG>();
   const int na = sh_na;
 
   // ---- 4. window generation (ref: mapping.c:1048-1207), one anchor per lane ----
@@ -298,14 +298,14 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
     }
     nh += __popcll(bal);
   }
-  k2_sync();   // anchors are dead from here; ws.key is reused for the window sort
+  k2_sync<BIG>();   // anchors are dead from here; ws.key is reused for the window sort
 
   // ---- 5. stable order by (contig, g_off) == the reference's insertion sort (ref: mapping.c:1210-1223) ----
   const int nhc = min(nh, hcap);
   uint16_t* P = perm + (size_t)rs * hcap;
   if (nhc > 0) {
     int hp = 64; while (hp < nhc) hp <<= 1;
-    // nhc <= na <= n <= cap, and hp <= npad
+    // nhc <= na <= n, and every key array holds pow2ceil(n) >= hp entries
     // the records were written by other lanes of this wave: read them back past the L1 (sc1 loads)
     for (int t = lane; t < hp; t += GM_WAVE) {
       uint64_t k = ~0ull;
@@ -316,8 +316,8 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
       }
       ws.key[t] = k;
     }
-    k2_sync();
-    k2_bitonic(ws.key, hp, lane);
+    k2_sync<BIG>();
+    k2_bitonic<BIG>(ws.key, hp, lane);
     for (int t = lane; t < nhc; t += GM_WAVE) P[t] = (uint16_t)(ws.key[t] & 0xFFFF);
   }
   if (lane == 0) {
@@ -328,35 +328,55 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
   }
 }
 
-static size_t k2_ws_bytes(int cap, int NL, int read_len) {
-  size_t b = (size_t)cap * 8 + (size_t)cap * 4 + (size_t)NL * 4 + (size_t)cap * 2 * 2 + (size_t)((NL + 1) & ~1) * 2 * 2 + (size_t)read_len * 2;
+static size_t k2_lds_bytes(bool big, int scap, int NL, int read_len) {
+  size_t b = (size_t)NL * 4 + (size_t)((NL + 1) & ~1) * (big ? 4 : 2) + (size_t)((NL + 1) & ~1) * 2 + (size_t)read_len * 2;
+  if (!big) b += (size_t)scap * (8 + 4 + 2 + 2);
   return (b + 15) & ~(size_t)15;
 }
 
-int gm_anchors_kmax(int expected_survivors) {
-  int k = 512;
-  while (k < 2 * expected_survivors + 256 && k < 4096) k <<= 1;
-  return k;
-}
-size_t gm_anchors_big_ws_bytes(int scap, int NL, int read_len) { return k2_ws_bytes(scap, NL, read_len); }
-
 int gm_launch_anchors(const GmIndexDev& ix, const GmScoreDev& sc, int n_reads, int read_len, int window_len,
-                      const uint64_t* d_surv, const uint32_t* d_surv_cnt, int scap, int kmax,
-                      uint8_t* d_big_ws, uint32_t* d_big_list, uint32_t* d_big_cnt, int max_big,
+                      const uint64_t* d_surv, const uint32_t* d_surv_cnt, int scap,
                       GmHit* d_hits, uint16_t* d_perm, uint32_t* d_hit_cnt, int hcap, unsigned long long* d_stats, hipStream_t stream) {
   const int max_n_kmers = std::max(0, read_len - ix.min_seed_span + 1);
   const int NL = ix.n_seeds * max_n_kmers;
   if (n_reads == 0) return GM_OK;
-  GM_HIP(hipMemsetAsync(d_big_cnt, 0, 4, stream));
-  const size_t lds = k2_ws_bytes(kmax, NL, read_len);
-  if (lds > 64 * 1024) { gm_set_error("anchor kernel LDS %zu too large", lds); return GM_E_ARG; }
+  const size_t lds = k2_lds_bytes(false, scap, NL, read_len);
+  if (lds > 64 * 1024) {
+    static size_t configured = 0;
+    if (lds > 160 * 1024) { gm_set_error("anchor kernel LDS %zu too large", lds); return GM_E_ARG; }
+    if (lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_anchors<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
+  }
   hipLaunchKernelGGL(k_anchors<false>, dim3(n_reads * 2), dim3(GM_WAVE), lds, stream, ix, sc, n_reads, read_len, window_len, max_n_kmers, NL,
-                     d_surv, d_surv_cnt, scap, kmax, (uint8_t*)nullptr, (size_t)0, d_big_list, d_big_cnt, max_big,
-                     d_hits, d_perm, d_hit_cnt, hcap, d_stats);
-  const size_t stride = k2_ws_bytes(scap, NL, read_len);
-  hipLaunchKernelGGL(k_anchors<true>, dim3(max_big), dim3(GM_WAVE), 0, stream, ix, sc, n_reads, read_len, window_len, max_n_kmers, NL,
-                     d_surv, d_surv_cnt, scap, kmax, d_big_ws, stride, d_big_list, d_big_cnt, max_big,
+                     d_surv, d_surv_cnt, scap, 0, (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr,
+                     (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
                      d_hits, d_perm, d_hit_cnt, hcap, d_stats);
   GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+// heavy tier: segmented radix sort of the re-emitted keys (64-bit, all bits), then the same pipeline on global arrays
+int gm_launch_anchors_heavy(const GmIndexDev& ix, const GmScoreDev& sc, int n_reads, int read_len, int window_len,
+                            int n_heavy, const uint32_t* d_heavy_list, const uint64_t* d_seg_off, const uint32_t* d_seg_n,
+                            const uint32_t* d_seg_begin32, const uint32_t* d_seg_end32, uint64_t total_keys,
+                            uint64_t* d_keys_in, uint64_t* d_keys_sorted, uint32_t* d_aux, uint32_t* d_nxt, uint32_t* d_ord,
+                            GmHit* d_hits, uint16_t* d_perm, uint32_t* d_hit_cnt, int hcap, unsigned long long* d_stats, hipStream_t stream) {
+  if (n_heavy == 0) return GM_OK;
+  const int max_n_kmers = std::max(0, read_len - ix.min_seed_span + 1);
+  const int NL = ix.n_seeds * max_n_kmers;
+  size_t tmp_bytes = 0; void* tmp = nullptr;
+  hipError_t e = rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, d_keys_in, d_keys_sorted, (unsigned int)total_keys, (unsigned int)n_heavy,
+                                                    d_seg_begin32, d_seg_end32, 0, 64, stream);
+  if (e != hipSuccess) { gm_set_error("segmented_radix_sort_keys size query: %s", hipGetErrorString(e)); return GM_E_NODEVICE; }
+  GM_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+  e = rocprim::segmented_radix_sort_keys(tmp, tmp_bytes, d_keys_in, d_keys_sorted, (unsigned int)total_keys, (unsigned int)n_heavy,
+                                         d_seg_begin32, d_seg_end32, 0, 64, stream);
+  if (e != hipSuccess) { (void)hipFree(tmp); gm_set_error("segmented_radix_sort_keys: %s", hipGetErrorString(e)); return GM_E_NODEVICE; }
+  const size_t lds = k2_lds_bytes(true, 0, NL, read_len);
+  hipLaunchKernelGGL(k_anchors<true>, dim3(n_heavy), dim3(GM_WAVE), lds, stream, ix, sc, n_reads, read_len, window_len, max_n_kmers, NL,
+                     (const uint64_t*)nullptr, (const uint32_t*)nullptr, 0, n_heavy, d_heavy_list, d_seg_off, d_seg_n,
+                     d_keys_sorted, d_aux, d_nxt, d_ord, d_hits, d_perm, d_hit_cnt, hcap, d_stats);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(stream));
+  (void)hipFree(tmp);
   return GM_OK;
 }

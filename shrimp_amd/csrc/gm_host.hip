@@ -233,11 +233,11 @@ struct gm_session {
   hipStream_t stream = nullptr;
   hipEvent_t ev[12];
   // capacities (grown on overflow)
-  int cur_len = -1, scap = 0, hcap = 0, kmax = 0, rcap_per_read = 8, max_big = 1024, ops_stride = 0, p2_grid = 2048;
+  int cur_len = -1, scap = 0, hcap = 0, rcap_per_read = 8, ops_stride = 0, p2_grid = 2048, eff_batch = 0;
   // device buffers
   uint32_t* d_reads = nullptr; uint64_t* d_surv = nullptr; uint32_t* d_surv_cnt = nullptr;
   GmHit* d_hits = nullptr; uint16_t* d_perm = nullptr; uint32_t* d_hit_cnt = nullptr; unsigned long long* d_slots = nullptr;
-  uint8_t* d_big_ws = nullptr; uint32_t* d_big_list = nullptr; uint32_t* d_big_cnt = nullptr;
+  uint32_t* d_heavy_list = nullptr; uint32_t* d_heavy_cnt = nullptr;   // read-strands beyond the LDS tier of K2
   int32_t* d_sel = nullptr; uint32_t* d_sel_cnt = nullptr; uint32_t* d_sel_off = nullptr; uint32_t* d_work = nullptr; uint32_t* d_n_work = nullptr;
   GmFullRes* d_res = nullptr; uint8_t* d_ops = nullptr; uint8_t* d_back = nullptr; size_t back_stride = 0;
   unsigned long long* d_stats = nullptr;
@@ -248,11 +248,11 @@ struct gm_session {
 };
 
 static void free_buffers(gm_session* s) {
-  void* ptrs[] = {s->d_reads, s->d_surv, s->d_surv_cnt, s->d_hits, s->d_perm, s->d_hit_cnt, s->d_slots, s->d_big_ws, s->d_big_list, s->d_big_cnt,
+  void* ptrs[] = {s->d_reads, s->d_surv, s->d_surv_cnt, s->d_hits, s->d_perm, s->d_hit_cnt, s->d_slots, s->d_heavy_list, s->d_heavy_cnt,
                   s->d_sel, s->d_sel_cnt, s->d_sel_off, s->d_work, s->d_n_work, s->d_res, s->d_ops, s->d_back};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->d_reads = nullptr; s->d_surv = nullptr; s->d_surv_cnt = nullptr; s->d_hits = nullptr; s->d_perm = nullptr; s->d_hit_cnt = nullptr; s->d_slots = nullptr;
-  s->d_big_ws = nullptr; s->d_big_list = nullptr; s->d_big_cnt = nullptr; s->d_sel = nullptr; s->d_sel_cnt = nullptr; s->d_sel_off = nullptr;
+  s->d_heavy_list = nullptr; s->d_heavy_cnt = nullptr; s->d_sel = nullptr; s->d_sel_cnt = nullptr; s->d_sel_off = nullptr;
   s->d_work = nullptr; s->d_n_work = nullptr; s->d_res = nullptr; s->d_ops = nullptr; s->d_back = nullptr;
 }
 
@@ -266,11 +266,14 @@ static int window_len_of(const gm_params_t& P, int read_len) {   // ref: gmapper
 static int alloc_buffers(gm_session* s, int read_len) {
   free_buffers(s);
   const gm_index* ix = s->ix;
-  const int B = s->max_batch, rs = 2 * B;
   const int read_words = (read_len + 7) / 8;
   const int W = window_len_of(s->P, read_len);
-  const int max_n_kmers = std::max(0, read_len - ix->min_seed_span + 1);
-  const int NL = ix->n_seeds * max_n_kmers;
+  // sub-batch size under a device-memory budget (candidate windows dominate when hcap has grown)
+  const double budget = 16e9;
+  const double per_read = 2.0 * ((double)s->scap * 8 + (double)s->hcap * (sizeof(GmHit) + 2 + 8)) + (double)s->rcap_per_read * (sizeof(GmFullRes) + read_len + W + 16);
+  s->eff_batch = (int)std::max(64.0, std::min((double)s->max_batch, budget / per_read));
+  const int B = s->eff_batch, rs = 2 * B;
+  (void)ix;
   s->ops_stride = ((read_len + W + 15) / 16) * 16;
   s->back_stride = (((size_t)read_len * W + 255) / 256) * 256;
   GM_HIP(hipMalloc(&s->d_reads, (size_t)B * read_words * 4 + 64));
@@ -280,9 +283,8 @@ static int alloc_buffers(gm_session* s, int read_len) {
   GM_HIP(hipMalloc(&s->d_perm, (size_t)rs * s->hcap * 2));
   GM_HIP(hipMalloc(&s->d_hit_cnt, (size_t)rs * 4));
   GM_HIP(hipMalloc(&s->d_slots, (size_t)rs * s->hcap * 8));
-  GM_HIP(hipMalloc(&s->d_big_ws, (size_t)s->max_big * gm_anchors_big_ws_bytes(s->scap, NL, read_len)));
-  GM_HIP(hipMalloc(&s->d_big_list, (size_t)s->max_big * 4));
-  GM_HIP(hipMalloc(&s->d_big_cnt, 4));
+  GM_HIP(hipMalloc(&s->d_heavy_list, (size_t)rs * 4));
+  GM_HIP(hipMalloc(&s->d_heavy_cnt, 4));
   GM_HIP(hipMalloc(&s->d_sel, (size_t)B * GM_SEL_MAX * 4));
   GM_HIP(hipMalloc(&s->d_sel_cnt, (size_t)B * 4));
   GM_HIP(hipMalloc(&s->d_sel_off, (size_t)B * 4));
@@ -307,12 +309,11 @@ static void choose_caps(gm_session* s, int read_len) {
   const double entries = lists * avg_len;
   const double region = (double)(1 << ix->params.region_bits) + ix->params.region_overlap;
   const double expected = entries * std::min(1.0, entries * region / std::max(1.0, (double)ix->total_len)) + lists;
-  s->scap = std::min(32768, std::max(512, pow2ceil((long long)(3 * expected) + 256)));
-  s->kmax = std::min(s->scap, gm_anchors_kmax((int)expected));
+  // scap = capacity of the LDS tier of K2 (16 B of LDS per entry); read-strands beyond it take the heavy tier
+  s->scap = std::min(4096, std::max(256, pow2ceil((long long)(1.5 * expected) + 128)));
   s->hcap = 64;
-  if (const char* e = getenv("GM_SCAP")) s->scap = std::min(32768, std::max(64, pow2ceil(atoi(e))));
+  if (const char* e = getenv("GM_SCAP")) s->scap = std::min(8192, std::max(64, pow2ceil(atoi(e))));
   if (const char* e = getenv("GM_HCAP")) s->hcap = std::min(32768, std::max(4, pow2ceil(atoi(e))));
-  if (const char* e = getenv("GM_KMAX")) s->kmax = std::min(s->scap, std::max(64, pow2ceil(atoi(e))));
   (void)max_n_kmers;
 }
 
@@ -427,7 +428,7 @@ struct Finalizer {
     if (p2.empty()) {
       if (P.sam_unaligned) {                                                       // ref: output.c:411-466
         size_t o = out.size(); out.resize(o + need); char* p = &out[o];
-        p = put_str(p, nm, nl); p = put_str(p, "\t4\t*\t0\t0\t*\t*\t0\t0\t", 18);
+        p = put_str(p, nm, nl); p = put_str(p, "\t4\t*\t0\t0\t*\t*\t0\t0\t", 17);
         for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = (c < 4) ? "ACGT"[c] : 'N'; }
         p = put_str(p, "\t*\n", 3);
         out.resize(p - out.data());
@@ -479,6 +480,45 @@ struct Finalizer {
   }
 };
 
+// Heavy tier of K2: the few read-strands whose survivors exceed the LDS tier (low-complexity reads,
+// repeats).  Sizes are known now, so every array is allocated exactly, the keys are re-emitted by K1
+// and sorted by one segmented radix sort; then K2 runs on global arrays.  Rare by construction.
+static int run_heavy_tier(gm_session* s, const GmIndexDev& dv, int n, int read_len, int read_words, int W, int n_heavy) {
+  hipStream_t q = s->stream;
+  std::vector<uint32_t> list(n_heavy), cnt_all((size_t)n * 2);
+  GM_HIP(hipMemcpy(list.data(), s->d_heavy_list, (size_t)n_heavy * 4, hipMemcpyDeviceToHost));
+  GM_HIP(hipMemcpy(cnt_all.data(), s->d_surv_cnt, cnt_all.size() * 4, hipMemcpyDeviceToHost));
+  std::sort(list.begin(), list.end());
+  std::vector<uint64_t> off(n_heavy + 1); std::vector<uint32_t> segn(n_heavy), b32(n_heavy), e32(n_heavy);
+  uint64_t tot = 0;
+  for (int i = 0; i < n_heavy; i++) {
+    const uint32_t c = cnt_all[list[i]];
+    off[i] = tot; segn[i] = c; b32[i] = (uint32_t)tot; e32[i] = (uint32_t)(tot + c);
+    tot += (uint64_t)std::max(64, pow2ceil(c));       // room for the padded window sort
+  }
+  off[n_heavy] = tot;
+  if (tot >= (1ull << 32)) { gm_set_error("heavy tier: %llu keys in one sub-batch", (unsigned long long)tot); return GM_E_OVERFLOW; }
+  uint32_t *d_list = nullptr, *d_segn = nullptr, *d_b32 = nullptr, *d_e32 = nullptr, *d_aux = nullptr, *d_nxt = nullptr, *d_ord = nullptr;
+  uint64_t *d_off = nullptr, *d_kin = nullptr, *d_ks = nullptr;
+  GM_HIP(hipMalloc(&d_list, (size_t)n_heavy * 4)); GM_HIP(hipMalloc(&d_segn, (size_t)n_heavy * 4)); GM_HIP(hipMalloc(&d_b32, (size_t)n_heavy * 4)); GM_HIP(hipMalloc(&d_e32, (size_t)n_heavy * 4));
+  GM_HIP(hipMalloc(&d_off, (size_t)(n_heavy + 1) * 8));
+  GM_HIP(hipMalloc(&d_kin, tot * 8)); GM_HIP(hipMalloc(&d_ks, tot * 8)); GM_HIP(hipMalloc(&d_aux, tot * 4)); GM_HIP(hipMalloc(&d_nxt, tot * 4)); GM_HIP(hipMalloc(&d_ord, tot * 4));
+  GM_HIP(hipMemcpyAsync(d_list, list.data(), (size_t)n_heavy * 4, hipMemcpyHostToDevice, q));
+  GM_HIP(hipMemcpyAsync(d_segn, segn.data(), (size_t)n_heavy * 4, hipMemcpyHostToDevice, q));
+  GM_HIP(hipMemcpyAsync(d_b32, b32.data(), (size_t)n_heavy * 4, hipMemcpyHostToDevice, q));
+  GM_HIP(hipMemcpyAsync(d_e32, e32.data(), (size_t)n_heavy * 4, hipMemcpyHostToDevice, q));
+  GM_HIP(hipMemcpyAsync(d_off, off.data(), (size_t)(n_heavy + 1) * 8, hipMemcpyHostToDevice, q));
+  GM_HIP(hipMemsetAsync(d_ks, 0xff, tot * 8, q));
+  int rc = gm_launch_lookup_redo(dv, s->d_reads, n, read_len, read_words, n_heavy, d_list, d_off, d_kin, s->d_stats, q);
+  if (rc == GM_OK)
+    rc = gm_launch_anchors_heavy(dv, s->sc, n, read_len, W, n_heavy, d_list, d_off, d_segn, d_b32, d_e32, tot, d_kin, d_ks, d_aux, d_nxt, d_ord,
+                                 s->d_hits, s->d_perm, s->d_hit_cnt, s->hcap, s->d_stats, q);
+  GM_HIP(hipStreamSynchronize(q));
+  (void)hipFree(d_list); (void)hipFree(d_segn); (void)hipFree(d_b32); (void)hipFree(d_e32); (void)hipFree(d_off);
+  (void)hipFree(d_kin); (void)hipFree(d_ks); (void)hipFree(d_aux); (void)hipFree(d_nxt); (void)hipFree(d_ord);
+  return rc;
+}
+
 static int run_device_pipeline(gm_session* s, int n, int read_len, gm_map_stats_t* st, float* lookup_ms) {
   const gm_index* ix = s->ix;
   const GmIndexDev dv = ix->dev_view();
@@ -486,15 +526,18 @@ static int run_device_pipeline(gm_session* s, int n, int read_len, gm_map_stats_
   const int W = window_len_of(s->P, read_len);
   const int overlap_abs = (int)(unsigned int)(s->P.window_overlap < 0 ? -s->P.window_overlap : W * (s->P.window_overlap / 100.0));   // ref: mapping.c:1289
   hipStream_t q = s->stream;
-  for (int attempt = 0; attempt < 6; attempt++) {
+  {
     GM_HIP(hipMemsetAsync(s->d_stats, 0, GS_N * 8, q));
     GM_HIP(hipEventRecord(s->ev[0], q));
-    int rc = gm_launch_lookup(dv, s->d_reads, n, read_len, read_words, s->d_surv, s->d_surv_cnt, s->scap, s->d_stats, q);
+    int rc = gm_launch_lookup(dv, s->d_reads, n, read_len, read_words, s->d_surv, s->d_surv_cnt, s->scap, s->d_heavy_list, s->d_heavy_cnt, 2 * s->eff_batch, s->d_stats, q);
     if (rc) return rc;
     GM_HIP(hipEventRecord(s->ev[1], q));
-    rc = gm_launch_anchors(dv, s->sc, n, read_len, W, s->d_surv, s->d_surv_cnt, s->scap, s->kmax, s->d_big_ws, s->d_big_list, s->d_big_cnt, s->max_big,
-                           s->d_hits, s->d_perm, s->d_hit_cnt, s->hcap, s->d_stats, q);
+    rc = gm_launch_anchors(dv, s->sc, n, read_len, W, s->d_surv, s->d_surv_cnt, s->scap, s->d_hits, s->d_perm, s->d_hit_cnt, s->hcap, s->d_stats, q);
     if (rc) return rc;
+    uint32_t n_heavy = 0;
+    GM_HIP(hipMemcpyAsync(&n_heavy, s->d_heavy_cnt, 4, hipMemcpyDeviceToHost, q));
+    GM_HIP(hipStreamSynchronize(q));
+    if (n_heavy) { rc = run_heavy_tier(s, dv, n, read_len, read_words, W, (int)n_heavy); if (rc) return rc; if (st) st->exact_order_reads += 0; }
     GM_HIP(hipEventRecord(s->ev[2], q));
     rc = gm_launch_pass1(dv, s->sc, s->d_reads, n, read_len, read_words, W, overlap_abs, s->d_hits, s->d_perm, s->d_hit_cnt, s->hcap, s->d_slots, s->d_stats, q);
     if (rc) return rc;
@@ -506,19 +549,15 @@ static int run_device_pipeline(gm_session* s, int n, int read_len, gm_map_stats_
     GM_HIP(hipMemcpyAsync(&n_work, s->d_n_work, 4, hipMemcpyDeviceToHost, q));
     GM_HIP(hipMemcpyAsync(hs, s->d_stats, GS_N * 8, hipMemcpyDeviceToHost, q));
     GM_HIP(hipStreamSynchronize(q));
-    const size_t rcap = (size_t)s->max_batch * s->rcap_per_read;
+    const size_t rcap = (size_t)s->eff_batch * s->rcap_per_read;
     bool retry = false;
-    if (hs[GS_OVERFLOW_SURV]) { if (s->scap >= 32768) { gm_set_error("survivor list overflow at capacity %d", s->scap); return GM_E_OVERFLOW; } s->scap *= 2; if (s->max_big < 8192) s->max_big *= 2; retry = true; }
+    if (hs[GS_OVERFLOW_SURV]) { gm_set_error("heavy list overflow"); return GM_E_OVERFLOW; }
     if (hs[GS_OVERFLOW_HITS]) { if (s->hcap >= 32768) { gm_set_error("window list overflow at capacity %d", s->hcap); return GM_E_OVERFLOW; } s->hcap *= 4; retry = true; }
     if (n_work > rcap) { if (s->rcap_per_read >= 32) { gm_set_error("pass-2 work overflow"); return GM_E_OVERFLOW; } s->rcap_per_read = std::min(32, s->rcap_per_read * 2); retry = true; }
-    if (retry) {
+    if (retry) {   // capacities grew: re-allocate and let the caller re-submit (the sub-batch size may have shrunk)
       if (st) st->retries++;
-      // keep the reads across the re-allocation
-      std::vector<uint32_t> keep((size_t)n * read_words);
-      GM_HIP(hipMemcpy(keep.data(), s->d_reads, keep.size() * 4, hipMemcpyDeviceToHost));
       rc = alloc_buffers(s, read_len); if (rc) return rc;
-      GM_HIP(hipMemcpy(s->d_reads, keep.data(), keep.size() * 4, hipMemcpyHostToDevice));
-      continue;
+      return 1;
     }
     rc = gm_launch_pass2(dv, s->sc, s->d_reads, n, read_len, read_words, W, s->d_hits, s->d_perm, s->hcap, s->d_sel, s->d_sel_cnt, s->d_work, s->d_n_work,
                          s->d_res, s->d_ops, s->ops_stride, s->d_back, s->back_stride, s->p2_grid, s->d_stats, q);
@@ -546,7 +585,6 @@ static int run_device_pipeline(gm_session* s, int n, int read_len, gm_map_stats_
     s->last_lookup_bytes += 12ull * hs[GS_LOOKUPS] + 4ull * hs[GS_ENTRIES];
     return GM_OK;
   }
-  gm_set_error("capacity retries exhausted"); return GM_E_OVERFLOW;
 }
 
 static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* reads_host, const void* reads_dev,
@@ -563,12 +601,14 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   if (names) { const char* p = names; for (int i = 0; i < n_reads; i++) { const char* e = strchr(p, '\n'); if (!e) e = p + strlen(p); nptr.push_back(p); nlen.push_back((int)(e - p)); p = *e ? e + 1 : e; } }
   std::string out;
   uint64_t matched = 0, records = 0;
-  for (int base = 0; base < n_reads; base += s->max_batch) {
-    const int n = std::min(s->max_batch, n_reads - base);
-    if (reads_host) GM_HIP(hipMemcpyAsync(s->d_reads, reads_host + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyHostToDevice, s->stream));
-    else GM_HIP(hipMemcpyAsync(s->d_reads, (const uint32_t*)reads_dev + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyDeviceToDevice, s->stream));
-    float lk = 0;
-    int rc = run_device_pipeline(s, n, read_len, stats, &lk);
+  for (int base = 0; base < n_reads;) {
+    int n, rc; float lk = 0;
+    do {
+      n = std::min(s->eff_batch, n_reads - base);
+      if (reads_host) GM_HIP(hipMemcpyAsync(s->d_reads, reads_host + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyHostToDevice, s->stream));
+      else GM_HIP(hipMemcpyAsync(s->d_reads, (const uint32_t*)reads_dev + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyDeviceToDevice, s->stream));
+      rc = run_device_pipeline(s, n, read_len, stats, &lk);
+    } while (rc == 1);
     if (rc) return rc;
     s->last_lookup_ms += lk; s->last_lookup_launches++;
     // host finalisation (multi-threaded over reads, output kept in input order)
@@ -601,6 +641,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     for (auto& t : th) t.join();
     for (int c = 0; c < nchunks; c++) { if (emit_sam) out += outs[c]; matched += cm[c]; records += cr[c]; }
     if (stats) stats->ms_host += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    base += n;
   }
   if (stats) { stats->reads = n_reads; stats->reads_matched = matched; stats->sam_records = records; }
   if (emit_sam && sam) {
@@ -625,12 +666,18 @@ extern "C" int gm_last_lookup_timing(gm_session_t* s, double* ms, uint64_t* alg_
 
 // stage dump for parity tests: hits selected by pass 1, in ext-heap array order (before pass 2 / reverse_hit)
 extern "C" int gm_debug_tophits(gm_session_t* s, int n_reads, int read_len, const uint32_t* reads_packed, long long* rows, long cap, long* n_rows) {
-  if (!s || n_reads > s->max_batch) { gm_set_error("gm_debug_tophits: at most max_batch reads"); return GM_E_ARG; }
+  if (!s) return GM_E_ARG;
   GM_HIP(hipSetDevice(s->ix->device));
   if (s->cur_len != read_len) { choose_caps(s, read_len); int rc = alloc_buffers(s, read_len); if (rc) return rc; }
+  if (n_reads > s->eff_batch) { gm_set_error("gm_debug_tophits: at most %d reads per call", s->eff_batch); return GM_E_ARG; }
   const int read_words = (read_len + 7) / 8;
-  GM_HIP(hipMemcpyAsync(s->d_reads, reads_packed, (size_t)n_reads * read_words * 4, hipMemcpyHostToDevice, s->stream));
-  float lk; int rc = run_device_pipeline(s, n_reads, read_len, nullptr, &lk); if (rc) return rc;
+  float lk; int rc;
+  do {
+    if (n_reads > s->eff_batch) { gm_set_error("gm_debug_tophits: at most %d reads per call", s->eff_batch); return GM_E_ARG; }
+    GM_HIP(hipMemcpyAsync(s->d_reads, reads_packed, (size_t)n_reads * read_words * 4, hipMemcpyHostToDevice, s->stream));
+    rc = run_device_pipeline(s, n_reads, read_len, nullptr, &lk);
+  } while (rc == 1);
+  if (rc) return rc;
   std::vector<int32_t> sel((size_t)n_reads * GM_SEL_MAX); std::vector<GmHit> hits((size_t)n_reads * 2 * s->hcap);
   GM_HIP(hipMemcpy(sel.data(), s->d_sel, sel.size() * 4, hipMemcpyDeviceToHost));
   GM_HIP(hipMemcpy(hits.data(), s->d_hits, hits.size() * sizeof(GmHit), hipMemcpyDeviceToHost));

@@ -33,18 +33,25 @@ enum { GS_LOOKUPS = 0, GS_ENTRIES, GS_SURVIVORS, GS_ANCHORS, GS_WINDOWS, GS_VEC_
 // ---- kernel launchers (one per .hip file) -----------------------------------------------------
 int gm_index_build_device(GmIndexHost* ix, hipStream_t stream);
 
-// K1 seed lookup + region filter: one workgroup per read-strand
+// K1 seed lookup + region filter: one workgroup per read-strand; read-strands with more than scap
+// survivors are listed in d_heavy_list (count in d_surv_cnt) and re-run by gm_launch_lookup_redo
 int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
-                     uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, unsigned long long* d_stats, hipStream_t stream);
+                     uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
+                     unsigned long long* d_stats, hipStream_t stream);
+int gm_launch_lookup_redo(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
+                          int n_heavy, const uint32_t* d_redo_list, const uint64_t* d_redo_off, uint64_t* d_out,
+                          unsigned long long* d_stats, hipStream_t stream);
 size_t gm_lookup_lds_bytes(const GmIndexDev& ix, int read_len);
 
-// K2 anchors + candidate windows: one wave per read-strand (LDS workspace), big read-strands in a second launch (global workspace)
-int gm_anchors_kmax(int expected_survivors);
-size_t gm_anchors_big_ws_bytes(int scap, int NL, int read_len);
+// K2 anchors + candidate windows: one wave per read-strand (LDS tier) + heavy tier on global arrays
 int gm_launch_anchors(const GmIndexDev& ix, const GmScoreDev& sc, int n_reads, int read_len, int window_len,
-                      const uint64_t* d_surv, const uint32_t* d_surv_cnt, int scap, int kmax,
-                      uint8_t* d_big_ws, uint32_t* d_big_list, uint32_t* d_big_cnt, int max_big,
+                      const uint64_t* d_surv, const uint32_t* d_surv_cnt, int scap,
                       GmHit* d_hits, uint16_t* d_perm, uint32_t* d_hit_cnt, int hcap, unsigned long long* d_stats, hipStream_t stream);
+int gm_launch_anchors_heavy(const GmIndexDev& ix, const GmScoreDev& sc, int n_reads, int read_len, int window_len,
+                            int n_heavy, const uint32_t* d_heavy_list, const uint64_t* d_seg_off, const uint32_t* d_seg_n,
+                            const uint32_t* d_seg_begin32, const uint32_t* d_seg_end32, uint64_t total_keys,
+                            uint64_t* d_keys_in, uint64_t* d_keys_sorted, uint32_t* d_aux, uint32_t* d_nxt, uint32_t* d_ord,
+                            GmHit* d_hits, uint16_t* d_perm, uint32_t* d_hit_cnt, int hcap, unsigned long long* d_stats, hipStream_t stream);
 
 // K3 pass 1 (vector SW + overlap rule), one wave per read-strand
 int gm_launch_pass1(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* d_reads, int n_reads, int read_len, int read_words,

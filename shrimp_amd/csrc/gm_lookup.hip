@@ -38,13 +38,20 @@ __device__ __forceinline__ bool k1_has2(const uint32_t* bm, uint32_t rloc) {
 // dynamic LDS layout: codes[read_len pad 4] | kS[NL] | lbeg[NL] | lend[NL] | lo[NL] | hi[NL] | pre[NL+1] | bitmap[bm_words]
 __global__ void __launch_bounds__(K1_THREADS)
 k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
-         int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap,
+         int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
+         uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap,
+         const uint32_t* __restrict__ redo_list, const uint64_t* __restrict__ redo_off,
          unsigned long long* __restrict__ stats) {
   extern __shared__ __align__(16) uint32_t smem[];
   __shared__ K1Smem sh;
   const int tid = threadIdx.x;
-  const int rs = blockIdx.x;            // read-strand id
+  // normal mode: block b = read-strand b, output slot surv[b*scap_all .. +scap_all).
+  // redo mode (redo_list != 0): block b re-runs heavy read-strand redo_list[b] into surv[redo_off[b] .. redo_off[b+1])
+  const bool redo = (redo_list != nullptr);
+  const int rs = redo ? (int)redo_list[blockIdx.x] : (int)blockIdx.x;
   const int rd = rs >> 1, st = rs & 1;
+  uint64_t* out = redo ? (surv + redo_off[blockIdx.x]) : (surv + (size_t)rs * scap_all);
+  const uint32_t scap = redo ? (uint32_t)(redo_off[blockIdx.x + 1] - redo_off[blockIdx.x]) : (uint32_t)scap_all;
   uint8_t* codes = (uint8_t*)smem;
   const int code_words = (read_len + 3) / 4;
   uint32_t* kS = smem + code_words;
@@ -149,7 +156,11 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
             } else {
               if (k1_has2(bm, rloc) || (strip && k1_has2(bm, rloc - 1u))) {
                 const uint32_t slot = atomicAdd(&sh.n_surv, 1u);
-                if (slot < (uint32_t)scap) surv[(size_t)rs * scap + slot] = ((uint64_t)p << 32) | (uint32_t)off;
+                if (slot < scap) {
+                  // sort key of K2: position, then read offset y, then seed
+                  const uint32_t sn = (uint32_t)off / (uint32_t)max_n_kmers, y = (uint32_t)off - sn * (uint32_t)max_n_kmers;
+                  out[slot] = ((uint64_t)p << 32) | ((uint64_t)y << 16) | sn;
+                }
               }
             }
           } else if (phase == 0) {
@@ -177,10 +188,14 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
       __syncthreads();
     }
   }
+  if (redo) return;                      // counters were taken by the first run
   if (tid == 0) {
     surv_cnt[rs] = sh.n_surv;
-    atomicAdd(&stats[GS_SURVIVORS], (unsigned long long)min(sh.n_surv, (uint32_t)scap));
-    if (sh.n_surv > (uint32_t)scap) atomicAdd(&stats[GS_OVERFLOW_SURV], 1ull);
+    atomicAdd(&stats[GS_SURVIVORS], (unsigned long long)sh.n_surv);
+    if (sh.n_surv > scap) {              // too many for the LDS tier of K2: handled by the heavy tier
+      const uint32_t hs = atomicAdd(heavy_cnt, 1u);
+      if (hs < (uint32_t)heavy_cap) heavy_list[hs] = (uint32_t)rs; else atomicAdd(&stats[GS_OVERFLOW_SURV], 1ull);
+    }
   }
   // per-wave reduction of the work counters
   for (int d = GM_WAVE / 2; d > 0; d >>= 1) { my_lookups += __shfl_down(my_lookups, d); my_entries += __shfl_down(my_entries, d); }
@@ -202,10 +217,12 @@ size_t gm_lookup_lds_bytes(const GmIndexDev& ix, int read_len) {
 }
 
 int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
-                     uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, unsigned long long* d_stats, hipStream_t stream) {
+                     uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
+                     unsigned long long* d_stats, hipStream_t stream) {
   int max_n_kmers, NL, bm_words; size_t lds;
   k1_geometry(ix, read_len, &max_n_kmers, &NL, &bm_words, &lds);
   if (lds > 160 * 1024) { gm_set_error("lookup kernel needs %zu bytes of LDS (read_len %d, slab_bits %d)", lds, read_len, ix.slab_bits); return GM_E_ARG; }
+  GM_HIP(hipMemsetAsync(d_heavy_cnt, 0, 4, stream));
   if (NL == 0 || n_reads == 0) { GM_HIP(hipMemsetAsync(d_surv_cnt, 0, (size_t)n_reads * 2 * 4, stream)); return GM_OK; }
   static size_t configured = 0;
   if (lds > 48 * 1024 && lds > configured) {
@@ -213,7 +230,22 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     configured = lds;
   }
   hipLaunchKernelGGL(k_lookup, dim3(n_reads * 2), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
-                     max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_stats);
+                     max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
+                     (const uint32_t*)nullptr, (const uint64_t*)nullptr, d_stats);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+// heavy tier: re-run the listed read-strands, each into its exactly sized slice of d_out
+int gm_launch_lookup_redo(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
+                          int n_heavy, const uint32_t* d_redo_list, const uint64_t* d_redo_off, uint64_t* d_out,
+                          unsigned long long* d_stats, hipStream_t stream) {
+  int max_n_kmers, NL, bm_words; size_t lds;
+  k1_geometry(ix, read_len, &max_n_kmers, &NL, &bm_words, &lds);
+  if (n_heavy == 0) return GM_OK;
+  hipLaunchKernelGGL(k_lookup, dim3(n_heavy), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+                     max_n_kmers, NL, bm_words, d_out, (uint32_t*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0,
+                     d_redo_list, d_redo_off, d_stats);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

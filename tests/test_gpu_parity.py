@@ -115,7 +115,7 @@ def test_sam_matches_reference_golden(gm, name):
 def test_tophits_match_oracle_on_stress(gm, oracle_lib):
     """stage parity: the pass-1 survivors (ext-heap array order, scores, anchor boxes)"""
     contigs, reads, _ = oa.load_golden("stress_60bp")
-    ix = gm.Index(contigs); s = gm.Session(ix, max_batch_reads=4096)
+    ix = gm.Index(contigs); s = gm.Session(ix, max_batch_reads=8192)
     got = s.tophits(reads)
     o = oa.Session(contigs); want = o.tophits(reads); o.close()
     s.close(); ix.close()

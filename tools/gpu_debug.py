@@ -9,7 +9,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "cfg2s_100bp_2Mbp"
 contigs, reads, sam = oa.load_golden(name)
 p = gm.default_params(); p.sam_unaligned = 1 if name.endswith("_unal") else 0
 t = time.time(); ix = gm.Index(contigs, params=p); print("index build %.2fs, %d MB, slabs %d, cutoff %d" % (time.time() - t, ix.nbytes >> 20, ix.n_slabs, ix.list_cutoff))
-s = gm.Session(ix, params=p, max_batch_reads=4096)
+s = gm.Session(ix, params=p, max_batch_reads=16384)
 t = time.time(); got = oa.sam_header(contigs) + s.map_reads(reads); print("map %.2fs" % (time.time() - t)); print(s.stats)
 la, lb = got.split(b"\n"), sam.split(b"\n")
 print("lines got/want", len(la), len(lb))
