@@ -154,14 +154,26 @@ struct Index {                    // genomemap / genomemap_len in CSR form (list
   const uint32_t* list(int sn, uint32_t idx) const { return pos[sn].data() + start[sn][idx]; }
 };
 
+// map index of the k-mer ending at the newest base of a rolling 2-bit window `w` (newest base in
+// bits 63:62, older bases below): identical to kmer_to_mapidx_orig because walking the mask from
+// its LSB appends the newest base first (=> top of the index) -- see kmer_to_mapidx above.
+static inline uint32_t mapidx_from_window(uint64_t w, const int* sel, int weight) {
+  uint32_t m = 0;
+  for (int k = 0; k < weight; k++) m = (m << 2) | (uint32_t)((w >> (62 - 2 * sel[k])) & 3u);
+  return m;
+}
+
 static inline void build_index(const Params& P, const Genome& G, Index& I) {
   int ns = (int)P.seeds.size();
   I.start.assign(ns, {}); I.pos.assign(ns, {});
+#pragma omp parallel for schedule(dynamic, 1)
   for (int sn = 0; sn < ns; sn++) {
     const Seed& sd = P.seeds[sn];
     size_t cap = (size_t)1 << (2 * sd.weight);
     std::vector<uint32_t>& st = I.start[sn];
     st.assign(cap + 1, 0);
+    int sel[64], nsel = 0;                       // ages (0 = newest base) of the mask's 1-bits, LSB first
+    for (int t = 0; t < sd.span; t++) if ((sd.mask >> t) & 1) sel[nsel++] = t;
     for (int pass = 0; pass < 2; pass++) {
       std::vector<uint32_t> fill;
       if (pass == 1) {
@@ -173,11 +185,13 @@ static inline void build_index(const Params& P, const Genome& G, Index& I) {
       for (int cn = 0; cn < G.num_contigs(); cn++) {
         const uint32_t* g = G.fwd[cn].data();
         int load = 0;  // genome.c:1139-1154: N/X resets the run; k-mers never span contigs
+        uint64_t w = 0;
         for (uint32_t p = 0; p < G.len[cn]; p++) {
           int base = EXTRACT(g, p);
+          w = (w >> 2) | ((uint64_t)(base & 3) << 62);
           if (base == 15) load = 0; else if (load < P.max_seed_span) load++;
           if (load < sd.span) continue;
-          uint32_t mi = kmer_to_mapidx(sd, [&](llint q) { return EXTRACT(g, q); }, p);
+          uint32_t mi = mapidx_from_window(w, sel, nsel);
           if (pass == 0) st[mi]++;
           else I.pos[sn][fill[mi]++] = G.offsets[cn] + p - sd.span + 1;
         }

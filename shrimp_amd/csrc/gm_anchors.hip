@@ -132,7 +132,7 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
   danger = __any(danger);
   if (danger) {
     if (lane == 0) {
-      atomicAdd(&stats[GS_EXACT_ORDER], 1ull);
+      GS_ADD(stats, GS_EXACT_ORDER, 1ull);
       for (int o = 0; o < NL; o++) ws.first[o] = (idx_t)K2_NONE;
       for (int t = n - 1; t >= 0; t--) {
         const uint64_t k = ws.key[t];
@@ -322,9 +322,9 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
   }
   if (lane == 0) {
     hit_cnt[rs] = (uint32_t)nh;
-    atomicAdd(&stats[GS_ANCHORS], (unsigned long long)na);
-    atomicAdd(&stats[GS_WINDOWS], (unsigned long long)nhc);
-    if (nh > hcap) atomicAdd(&stats[GS_OVERFLOW_HITS], 1ull);
+    GS_ADD(stats, GS_ANCHORS, (unsigned long long)na);
+    GS_ADD(stats, GS_WINDOWS, (unsigned long long)nhc);
+    if (nh > hcap) GS_ADD(stats, GS_OVERFLOW_HITS, 1ull);
   }
 }
 

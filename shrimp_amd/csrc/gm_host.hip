@@ -330,7 +330,7 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   s->max_batch = std::max(64, std::min(max_batch_reads > 0 ? max_batch_reads : 131072, 1 << 20));
   GM_HIP(hipStreamCreate(&s->stream));
   for (auto& e : s->ev) GM_HIP(hipEventCreate(&e));
-  GM_HIP(hipMalloc(&s->d_stats, GS_N * 8));
+  GM_HIP(hipMalloc(&s->d_stats, (size_t)GS_STRIPES * GS_STRIDE * 8));
   *out = s;
   return GM_OK;
 }
@@ -527,7 +527,7 @@ static int run_device_pipeline(gm_session* s, int n, int read_len, gm_map_stats_
   const int overlap_abs = (int)(unsigned int)(s->P.window_overlap < 0 ? -s->P.window_overlap : W * (s->P.window_overlap / 100.0));   // ref: mapping.c:1289
   hipStream_t q = s->stream;
   {
-    GM_HIP(hipMemsetAsync(s->d_stats, 0, GS_N * 8, q));
+    GM_HIP(hipMemsetAsync(s->d_stats, 0, (size_t)GS_STRIPES * GS_STRIDE * 8, q));
     GM_HIP(hipEventRecord(s->ev[0], q));
     int rc = gm_launch_lookup(dv, s->d_reads, n, read_len, read_words, s->d_surv, s->d_surv_cnt, s->scap, s->d_heavy_list, s->d_heavy_cnt, 2 * s->eff_batch, s->d_stats, q);
     if (rc) return rc;
@@ -546,9 +546,12 @@ static int run_device_pipeline(gm_session* s, int n, int read_len, gm_map_stats_
     if (rc) return rc;
     GM_HIP(hipEventRecord(s->ev[4], q));
     unsigned long long hs[GS_N]; uint32_t n_work = 0;
+    std::vector<unsigned long long> hraw((size_t)GS_STRIPES * GS_STRIDE);
+    auto fold = [&]() { for (int k = 0; k < GS_N; k++) { hs[k] = 0; for (int t = 0; t < GS_STRIPES; t++) hs[k] += hraw[(size_t)t * GS_STRIDE + k]; } };
     GM_HIP(hipMemcpyAsync(&n_work, s->d_n_work, 4, hipMemcpyDeviceToHost, q));
-    GM_HIP(hipMemcpyAsync(hs, s->d_stats, GS_N * 8, hipMemcpyDeviceToHost, q));
+    GM_HIP(hipMemcpyAsync(hraw.data(), s->d_stats, hraw.size() * 8, hipMemcpyDeviceToHost, q));
     GM_HIP(hipStreamSynchronize(q));
+    fold();
     const size_t rcap = (size_t)s->eff_batch * s->rcap_per_read;
     bool retry = false;
     if (hs[GS_OVERFLOW_SURV]) { gm_set_error("heavy list overflow"); return GM_E_OVERFLOW; }
@@ -570,8 +573,9 @@ static int run_device_pipeline(gm_session* s, int n, int read_len, gm_map_stats_
     }
     GM_HIP(hipMemcpyAsync(s->h_sel_cnt.data(), s->d_sel_cnt, (size_t)n * 4, hipMemcpyDeviceToHost, q));
     GM_HIP(hipMemcpyAsync(s->h_sel_off.data(), s->d_sel_off, (size_t)n * 4, hipMemcpyDeviceToHost, q));
-    GM_HIP(hipMemcpyAsync(hs, s->d_stats, GS_N * 8, hipMemcpyDeviceToHost, q));
+    GM_HIP(hipMemcpyAsync(hraw.data(), s->d_stats, hraw.size() * 8, hipMemcpyDeviceToHost, q));
     GM_HIP(hipStreamSynchronize(q));
+    fold();
     float ms[5];
     for (int i = 0; i < 5; i++) GM_HIP(hipEventElapsedTime(&ms[i], s->ev[i], s->ev[i + 1]));
     *lookup_ms = ms[0];

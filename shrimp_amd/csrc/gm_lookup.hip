@@ -191,15 +191,15 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
   if (redo) return;                      // counters were taken by the first run
   if (tid == 0) {
     surv_cnt[rs] = sh.n_surv;
-    atomicAdd(&stats[GS_SURVIVORS], (unsigned long long)sh.n_surv);
+    GS_ADD(stats, GS_SURVIVORS, (unsigned long long)sh.n_surv);
     if (sh.n_surv > scap) {              // too many for the LDS tier of K2: handled by the heavy tier
       const uint32_t hs = atomicAdd(heavy_cnt, 1u);
-      if (hs < (uint32_t)heavy_cap) heavy_list[hs] = (uint32_t)rs; else atomicAdd(&stats[GS_OVERFLOW_SURV], 1ull);
+      if (hs < (uint32_t)heavy_cap) heavy_list[hs] = (uint32_t)rs; else GS_ADD(stats, GS_OVERFLOW_SURV, 1ull);
     }
   }
   // per-wave reduction of the work counters
   for (int d = GM_WAVE / 2; d > 0; d >>= 1) { my_lookups += __shfl_down(my_lookups, d); my_entries += __shfl_down(my_entries, d); }
-  if ((tid & (GM_WAVE - 1)) == 0) { atomicAdd(&stats[GS_LOOKUPS], my_lookups); atomicAdd(&stats[GS_ENTRIES], my_entries); }
+  if ((tid & (GM_WAVE - 1)) == 0) { GS_ADD(stats, GS_LOOKUPS, my_lookups); GS_ADD(stats, GS_ENTRIES, my_entries); }
 }
 
 static void k1_geometry(const GmIndexDev& ix, int read_len, int* max_n_kmers, int* NL, int* bm_words, size_t* lds) {

@@ -218,7 +218,7 @@ k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
     __syncthreads();
   }
   if (lane == 0) {
-    atomicAdd(&stats[GS_VEC_CALLS], calls); atomicAdd(&stats[GS_VEC_CELLS], cells); atomicAdd(&stats[GS_VEC_BYPASSED], bypass);
+    GS_ADD(stats, GS_VEC_CALLS, calls); GS_ADD(stats, GS_VEC_CELLS, cells); GS_ADD(stats, GS_VEC_BYPASSED, bypass);
   }
 }
 
@@ -486,7 +486,7 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
     }
     if (lane == 0) res[wi] = R;
   }
-  if (lane == 0) { atomicAdd(&stats[GS_FULL_CALLS], fcalls); atomicAdd(&stats[GS_VEC_CALLS], vcalls); atomicAdd(&stats[GS_VEC_CELLS], vcells); }
+  if (lane == 0) { GS_ADD(stats, GS_FULL_CALLS, fcalls); GS_ADD(stats, GS_VEC_CALLS, vcalls); GS_ADD(stats, GS_VEC_CELLS, vcells); }
 }
 
 // work list = (read << 6 | k) for every selected hit, built by a scan-free atomic append (order fixed up on the host by key)

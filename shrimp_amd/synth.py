@@ -85,25 +85,28 @@ def make_reads(contigs: list[np.ndarray], n_reads: int, read_len: int, seed: int
 
 def pack_nibbles(codes: np.ndarray) -> np.ndarray:
     """Pack a 1-D code array 8 bases per uint32, base i in nibble i%8 of word i/8
-    (the reference's bitfield layout, common/util.h:41 EXTRACT)."""
+    (the reference's bitfield layout, common/util.h:41 EXTRACT).  Little-endian bytes: byte k of
+    the stream holds bases 2k (low nibble) and 2k+1 (high nibble)."""
+    codes = np.asarray(codes, dtype=np.uint8)
     n = codes.shape[0]
     nw = (n + 7) // 8
-    pad = np.zeros(nw * 8, dtype=np.uint32)
-    pad[:n] = codes
-    pad = pad.reshape(nw, 8)
-    shifts = (4 * np.arange(8, dtype=np.uint32))[None, :]
-    return np.bitwise_or.reduce(pad << shifts, axis=1).astype(np.uint32)
+    b = np.zeros(nw * 4, dtype=np.uint8)
+    ne = (n + 1) // 2
+    b[:ne] = codes[0::2] & 0xF
+    b[:n // 2] |= (codes[1::2] & 0xF) << 4
+    return b.view("<u4")
 
 
 def pack_reads(codes: np.ndarray) -> np.ndarray:
     """Pack reads[n, L] row-wise to uint32[n, ceil(L/8)]."""
+    codes = np.asarray(codes, dtype=np.uint8)
     n, L = codes.shape
     nw = (L + 7) // 8
-    pad = np.zeros((n, nw * 8), dtype=np.uint32)
-    pad[:, :L] = codes
-    pad = pad.reshape(n, nw, 8)
-    shifts = (4 * np.arange(8, dtype=np.uint32))[None, None, :]
-    return np.bitwise_or.reduce(pad << shifts, axis=2).astype(np.uint32)
+    b = np.zeros((n, nw * 4), dtype=np.uint8)
+    ne = (L + 1) // 2
+    b[:, :ne] = codes[:, 0::2] & 0xF
+    b[:, :L // 2] |= (codes[:, 1::2] & 0xF) << 4
+    return np.ascontiguousarray(b).view("<u4")
 
 
 def write_fasta_genome(path: str, contigs: list[np.ndarray], width: int = 70) -> None:
