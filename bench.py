@@ -18,12 +18,6 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
-class _DevArray:
-    """__cuda_array_interface__ shim so torch can view a raw device pointer (for the RCCL broadcast)."""
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,24 +61,14 @@ def main():
 
     # ---- index: built on rank 0's GPU, broadcast once ----
     t0 = time.time()
-    if rank == 0:
-        ix = gm.Index(contigs, device=local)
-        meta = [ix.meta()]
-    else:
-        ix = None; meta = [None]
+    ix = gm.Index(contigs, device=local) if rank == 0 else None
     t_index = time.time() - t0
     t_bcast = 0.0
     if world > 1:
-        dist.broadcast_object_list(meta, src=0)
-        if rank != 0:
-            ix = gm.Index.alloc_like(meta[0], device=local)
+        from shrimp_amd import parallel
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.time()
-        for ptr, nb in ix.device_arrays():
-            t = torch.as_tensor(_DevArray(ptr, nb), device=dev)
-            # chunks of <= 1 GiB keep the RCCL staging modest
-            for o in range(0, nb, 1 << 30):
-                dist.broadcast(t[o:o + (1 << 30)], src=0)
+        ix = parallel.broadcast_index(ix, rank, dev, src=0)      # the single collective of the whole job
         torch.cuda.synchronize(); dist.barrier()
         t_bcast = time.time() - t0
     sess = gm.Session(ix, max_batch_reads=int(os.environ.get("GM_SUBBATCH", "131072")))

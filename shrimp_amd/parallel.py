@@ -1,0 +1,56 @@
+"""Multi-GPU layer: reads are independent units, so the node-level scheme is
+  * one process per GPU (torch.distributed; backend "nccl" == RCCL on ROCm),
+  * ONE broadcast of the resident index arrays from the building rank at start-up,
+  * contiguous blocks of whole read chunks per rank, no per-step collective,
+  * output re-serialised in input order (rank order == chunk order), as the reference's
+    chunk-ordered output heap does (ref: gmapper/gmapper.c:588-607).
+Nothing here computes alignments.
+"""
+from __future__ import annotations
+
+
+def shard_bounds(n_reads: int, world: int, chunk: int = 1000, paired: bool = False) -> list[tuple[int, int]]:
+    """Contiguous [lo, hi) block of reads per rank, in whole chunks (ref chunk_size = 1000,
+    gmapper-defaults.h:13; made even in paired mode, gmapper.c:2319-2322) so that mates never split."""
+    if paired and chunk % 2:
+        chunk += 1
+    n_chunks = (n_reads + chunk - 1) // chunk
+    out = []
+    for r in range(world):
+        c0 = (n_chunks * r) // world
+        c1 = (n_chunks * (r + 1)) // world
+        out.append((min(n_reads, c0 * chunk), min(n_reads, c1 * chunk)))
+    return out
+
+
+class _DevArray:
+    """__cuda_array_interface__ shim: lets torch view a raw device pointer without copying."""
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def broadcast_index(index, rank: int, device, src: int = 0, chunk_bytes: int = 1 << 30):
+    """Replicate the index built on `src` to every rank: metadata by object broadcast, then each
+    resident array (packed genome, per-seed directory, per-seed positions) by dist.broadcast straight
+    from/into HBM.  xGMI is point-to-point, so one ring broadcast of the 39 GB hg-sized index is per-link
+    bound (~0.3 s); it happens once.  Returns the local Index."""
+    import torch
+    import torch.distributed as dist
+    from . import gmapper as gm
+    meta = [index.meta() if rank == src else None]
+    dist.broadcast_object_list(meta, src=src)
+    if rank != src:
+        index = gm.Index.alloc_like(meta[0], device=device.index if hasattr(device, "index") else int(device))
+    for ptr, nb in index.device_arrays():
+        t = torch.as_tensor(_DevArray(ptr, nb), device=device)
+        for o in range(0, nb, chunk_bytes):
+            dist.broadcast(t[o:o + chunk_bytes], src=src)
+    return index
+
+
+def gather_ordered(local: bytes, rank: int, world: int, dst: int = 0):
+    """Concatenate per-rank SAM text in rank (= input) order on `dst`; other ranks get None."""
+    import torch.distributed as dist
+    parts = [None] * world if rank == dst else None
+    dist.gather_object(local, parts, dst=dst)
+    return b"".join(parts) if rank == dst else None

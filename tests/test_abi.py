@@ -1,0 +1,66 @@
+"""CPU-side checks of the drop-in boundary: the shared library builds, loads, exports every symbol
+include/gmapper_hip.h declares, and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os, re, subprocess
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def gm():
+    from shrimp_amd import gmapper
+    if not os.path.exists(gmapper.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "shrimp_amd", "csrc"), "-j8"], check=True, capture_output=True)
+    return gmapper
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "gmapper_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set()
+    for m in re.finditer(r"\b([a-z_][a-z0-9_]*)\s*\(", src):
+        n = m.group(1)
+        if n.startswith(("gm_", "sw_")) and not n.endswith("_t"):
+            names.add(n)
+    return sorted(names)
+
+
+def test_every_declared_symbol_is_exported(gm):
+    L = gm.lib()
+    decl = declared_functions()
+    assert len(decl) >= 25
+    missing = [n for n in decl if not hasattr(L, n)]
+    assert not missing, missing
+    assert sorted(gm.EXPORTS) == decl, set(gm.EXPORTS) ^ set(decl)
+
+
+def test_symbols_have_c_linkage(gm):
+    out = subprocess.run(["nm", "-D", "--defined-only", gm.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    syms = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    for n in declared_functions():
+        assert n in syms, n          # unmangled: the reference's own names (sw_vector, sw_full_ls, ...) link as C
+
+
+def test_params_default_match_reference_defaults(gm):
+    p = gm.default_params()
+    assert (p.match_score, p.mismatch_score, p.a_gap_open_score, p.a_gap_extend_score, p.b_gap_open_score, p.b_gap_extend_score) == (10, -15, -33, -7, -33, -3)
+    assert (p.window_len, p.window_overlap, p.window_gen_threshold, p.sw_vect_threshold, p.sw_full_threshold) == (140.0, 90.0, 55.0, 50.0, 50.0)
+    assert (p.match_mode, p.num_outputs, p.num_tmp_outputs, p.anchor_width, p.region_bits, p.region_overlap) == (2, 10, 30, 8, 11, 50)
+
+
+def test_no_cpu_fallback_without_gpu(gm):
+    L = gm.lib()
+    if L.gm_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(gm.GmError, match="no HIP device"):
+        gm.Index([np.zeros(1000, dtype=np.uint8)])
+    with pytest.raises(gm.GmError):
+        gm.sw_vector_setup(140, 100, -33, -7, -33, -3, 10, -15)
+
+
+def test_sw_vector_setup_range_check(gm):
+    """match * qrlen >= 32768 is rejected (the reference exit(1)s, sw-vector.c:393-398) before any device use."""
+    rc = gm.lib().sw_vector_setup(1400, 4000, -33, -7, -33, -3, 10, -15, 0, True)
+    assert rc == -4
