@@ -3,24 +3,28 @@
 //   read_get_anchor_list_per_strand  ref: gmapper/mapping.c:861-1006  (k-way heap merge + colinear collapse)
 //   read_get_hit_list_per_strand     ref: gmapper/mapping.c:1025-1229 (window generation + insertion sort)
 //
-// Ordering.  The reference merges the lists with a binary min-heap keyed by position only
-// (ref: common/heap.h:44-139), so the order of *equal* positions depends on the heap's history.
-// A wave sorts the survivors by (position, read offset y, seed) with a bitonic network in LDS.
-// That order is equivalent to the reference's whenever all survivors sharing a position also share
-// y: such a group is merged by anchor_uw_join into one anchor of length max(span) and weight = group
-// size, whatever the order inside the group (DESIGN.md "tie order").  When a position occurs
-// with two different y, lane 0 replays the reference's heap (same insert order, same strict-<
-// sift rules) over the survivors to obtain the exact pop order.  Both cases are exact.
+// Order.  The reference merges the lists with a binary min-heap keyed by position only
+// (ref: common/heap.h:44-139): equal positions pop in a history-dependent order.  What that order can
+// influence is narrow (DESIGN.md "tie order"):
+//   * the collapse is order-free: survivors are collapsed per diagonal class (x + L - y) % L, and two
+//     survivors of one class at one position have the same y, hence merge whatever their order;
+//   * anchors are created in pop order, so only the relative order of anchors with EQUAL x is open;
+//     it matters only if (a) the best partner of an anchor in the look-back scan is, or ties in score
+//     with, an equal-x sibling, or (b) two windows with equal (contig, g_off) come from equal-x anchors.
+// Fast path: canonical order (x, y, seed), data-parallel collapse, and detection of (a)/(b).
+// Exact path (taken when detected, and always in the heavy tier): lane 0 replays the reference's heap
+// (same insert order, same strict-< sift rules) and the sequential collapse.  Both paths are exact.
+//
+// Two tiers.  LDS tier (BIG = false): survivors (<= scap) sorted by a bitonic network in LDS.
+// Heavy tier (BIG = true): the few read-strands with more survivors (low-complexity reads, repeats);
+// their keys were re-emitted by K1 into exactly sized global segments and sorted by one segmented
+// radix sort; the exact path then runs on global arrays with agent-scope fences.
 #include <cstring>
 #include <algorithm>
 #include "gm_common.h"
 #include "gm_internal.h"
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 
-// Two tiers.  LDS tier (BIG = false): one wave per read-strand, survivors (<= scap) sorted by a
-// bitonic network in LDS.  Heavy tier (BIG = true): the few read-strands with more survivors than
-// that (low-complexity reads, repeats); their keys were re-emitted by K1 into exactly sized global
-// segments and sorted by one segmented radix sort; the same code then runs on global arrays.
 template <bool BIG> struct K2Idx { typedef uint16_t type; static constexpr uint32_t none = 0xFFFFu; };
 template <> struct K2Idx<true> { typedef uint32_t type; static constexpr uint32_t none = 0xFFFFFFFFu; };
 
@@ -28,9 +32,9 @@ template <bool BIG>
 struct K2Ws {            // per-wave workspace
   typedef typename K2Idx<BIG>::type idx_t;
   uint64_t* key;         // [cap]  sort keys pos<<32 | y<<16 | seed; later anchors: x<<32 | len<<16 | weight
-  uint32_t* aux;         // [cap]  y | cn<<16
-  idx_t* nxt;            // [cap]  exact path: next survivor of the same list
-  idx_t* ord;            // [cap]  exact path: pop order
+  uint32_t* aux;         // [cap]  y | cn<<16   (bit 15 = dead marker during the parallel collapse)
+  idx_t* nxt;            // [cap]  exact path: next survivor of the same list   } LDS tier: the two u16 arrays are
+  idx_t* ord;            // [cap]  exact path: pop order                        } contiguous = one u32[cap] scratch
   idx_t* first;          // [NL]   exact path: cursor per list
   uint32_t* hk;          // [NL]   exact path: heap keys / temp
   uint16_t* hr;          // [NL]   exact path: heap payload (list id)
@@ -41,14 +45,14 @@ struct K2Ws {            // per-wave workspace
 // lane and read by the others, so the barrier also releases/acquires at agent scope (L1 invalidate).
 template <bool BIG> __device__ __forceinline__ void k2_sync() { if (BIG) __threadfence(); __syncthreads(); }
 
-template <bool BIG> __device__ void k2_bitonic(uint64_t* key, int npad, int lane) {
+template <bool BIG, typename T> __device__ void k2_bitonic(T* key, int npad, int lane) {
   for (int k = 2; k <= npad; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int t = lane; t < (npad >> 1); t += GM_WAVE) {
         const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
         const int l = i | j;
         const bool up = ((i & k) == 0);
-        const uint64_t a = key[i], b = key[l];
+        const T a = key[i], b = key[l];
         if ((a > b) == up) { key[i] = b; key[l] = a; }
       }
       k2_sync<BIG>();
@@ -77,6 +81,234 @@ __device__ __forceinline__ int k2_threshold(double frac, int absval, int base) {
   return frac < 0 ? absval : (int)((double)base * frac);
 }
 
+// ---- exact pop order: replay of heap_uu over the survivors (lane 0) -----------------------------
+template <bool BIG>
+__device__ void k2_exact_order(K2Ws<BIG>& ws, int n, int NL, int max_n_kmers) {
+  typedef typename K2Idx<BIG>::type idx_t;
+  const idx_t NONE = (idx_t)K2Idx<BIG>::none;
+  for (int o = 0; o < NL; o++) ws.first[o] = NONE;
+  for (int t = n - 1; t >= 0; t--) {
+    const uint64_t k = ws.key[t];
+    const int off = (int)(k & 0xFFFF) * max_n_kmers + (int)((k >> 16) & 0xFFFF);
+    ws.nxt[t] = ws.first[off]; ws.first[off] = (idx_t)t;
+  }
+  // heap_uu (ref: common/heap.h:44-139): 1-based nodes over hk/hr[0..load)
+  int load = 0;
+  auto pos_of = [&](int t) -> uint32_t { return (uint32_t)(ws.key[t] >> 32); };
+  auto down = [&](int node) {
+    for (;;) {
+      int left = node * 2, right = left + 1, mn = node;
+      if (left <= load && ws.hk[left - 1] < ws.hk[node - 1]) mn = left;
+      if (right <= load && ws.hk[right - 1] < ws.hk[mn - 1]) mn = right;
+      if (mn == node) break;
+      uint32_t tk = ws.hk[mn - 1]; ws.hk[mn - 1] = ws.hk[node - 1]; ws.hk[node - 1] = tk;
+      uint16_t tr = ws.hr[mn - 1]; ws.hr[mn - 1] = ws.hr[node - 1]; ws.hr[node - 1] = tr;
+      node = mn;
+    }
+  };
+  for (int o = 0; o < NL; o++) {          // initial inserts in (seed, read position) order, ref: mapping.c:913-935
+    if (ws.first[o] == NONE) continue;
+    ws.hk[load] = pos_of((int)ws.first[o]); ws.hr[load] = (uint16_t)o; load++;
+    int node = load, parent = node / 2;
+    while (node > 1 && ws.hk[node - 1] < ws.hk[parent - 1]) {
+      uint32_t tk = ws.hk[parent - 1]; ws.hk[parent - 1] = ws.hk[node - 1]; ws.hk[node - 1] = tk;
+      uint16_t tr = ws.hr[parent - 1]; ws.hr[parent - 1] = ws.hr[node - 1]; ws.hr[node - 1] = tr;
+      node = parent; parent = node / 2;
+    }
+  }
+  int m = 0;
+  while (load > 0) {                      // ref: mapping.c:937-989
+    const int o = ws.hr[0];
+    const int t = (int)ws.first[o];
+    ws.ord[m++] = (idx_t)t;
+    const idx_t nx = ws.nxt[t];
+    if (nx != NONE) { ws.first[o] = nx; ws.hk[0] = pos_of((int)nx); ws.hr[0] = (uint16_t)o; down(1); }
+    else { load--; if (load > 0) { ws.hk[0] = ws.hk[load]; ws.hr[0] = ws.hr[load]; down(1); } }
+  }
+  // apply the pop order: it only permutes entries inside groups of equal position, so only the
+  // low words (y, seed) move; hk is free now and serves as the per-group temporary.
+  int g0 = 0;
+  while (g0 < n) {
+    int g1 = g0 + 1;
+    while (g1 < n && (ws.key[g1] >> 32) == (ws.key[g0] >> 32)) g1++;
+    if (g1 - g0 > 1) {
+      for (int g = g0; g < g1; g++) ws.hk[g - g0] = (uint32_t)ws.key[ws.ord[g]];
+      for (int g = g0; g < g1; g++) ws.key[g] = (ws.key[g] & 0xFFFFFFFF00000000ull) | ws.hk[g - g0];
+    }
+    g0 = g1;
+  }
+}
+
+// ---- sequential collapse in pop order (lane 0), ref: mapping.c:937-971 ---------------------------
+template <bool BIG>
+__device__ int k2_collapse_seq(const GmIndexDev& ix, K2Ws<BIG>& ws, int n, int read_len) {
+  int na = 0;
+  for (int t = 0; t < n; t++) {
+    const uint64_t k = ws.key[t];
+    const uint32_t x = (uint32_t)(k >> 32);
+    const uint32_t au = ws.aux[t];
+    const int y = (int)((k >> 16) & 0xFFFF), cn = (int)(au >> 16);     // y from the key: the pop order permuted the keys
+    const int len = ix.seed[(int)(k & 0xFFFF)].span;
+    const int diag = (int)(((long long)x + read_len - y) % read_len);
+    const int j = ws.cache[diag];
+    bool joined = false;
+    if (j >= 0) {
+      const uint64_t aj = ws.key[j];
+      const uint32_t auj = ws.aux[j];
+      const uint32_t xj = (uint32_t)(aj >> 32);
+      if ((int)(auj >> 16) == cn && ((long long)xj - (long long)(auj & 0x7FFF) == (long long)x - y)) {
+        // anchor_uw_join(dest = A[j], src), ref: common/anchors.c:98-119 (src.x >= dest.x here)
+        uint32_t lj = (uint32_t)(aj >> 16) & 0xFFFF, wj = (uint32_t)aj & 0xFFFF;
+        if ((long long)x + len > (long long)xj + lj) lj = (uint32_t)(x - xj + len);
+        wj = min(wj + 1u, 0xFFFFu);
+        ws.key[j] = ((uint64_t)xj << 32) | ((uint64_t)lj << 16) | wj;
+        joined = true;
+      }
+    }
+    if (!joined) {
+      ws.cache[diag] = (int16_t)na;
+      ws.key[na] = ((uint64_t)x << 32) | ((uint64_t)len << 16) | 1u;
+      ws.aux[na] = (uint32_t)y | ((uint32_t)cn << 16);
+      na++;
+    }
+  }
+  return na;
+}
+
+// ---- data-parallel collapse (LDS tier).  Entries in canonical order; ck = u32 scratch [npad]. ------
+// Within a diagonal class the survivors are visited in position order; an entry opens a new anchor iff
+// its (true diagonal, contig) differs from its class predecessor's (all members of a run are colinear
+// with the run's first entry, so comparing with the predecessor == comparing with the cached anchor).
+__device__ int k2_collapse_par(const GmIndexDev& ix, K2Ws<false>& ws, uint32_t* ck, int n, int npad, int read_len, int lane) {
+  for (int t = lane; t < npad; t += GM_WAVE) {
+    uint32_t c = 0xFFFFFFFFu;
+    if (t < n) {
+      const uint32_t x = (uint32_t)(ws.key[t] >> 32); const uint32_t y = ws.aux[t] & 0x7FFFu;
+      const uint32_t cls = ((x % (uint32_t)read_len) + (uint32_t)read_len - y) % (uint32_t)read_len;
+      c = (cls << 16) | (uint32_t)t;
+    }
+    ck[t] = c;
+  }
+  k2_sync<false>();
+  k2_bitonic<false, uint32_t>(ck, npad, lane);
+  for (int r = lane; r < n; r += GM_WAVE) {
+    const uint32_t c = ck[r]; const int t = (int)(c & 0xFFFF);
+    const uint64_t k = ws.key[t]; const uint32_t au = ws.aux[t];
+    const long long x = (long long)(k >> 32); const int y = (int)(au & 0x7FFF); const int cn = (int)(au >> 16);
+    bool head = true;
+    if (r > 0) {
+      const uint32_t cp = ck[r - 1];
+      if ((cp >> 16) == (c >> 16)) {
+        const int tp = (int)(cp & 0xFFFF);
+        const long long xp = (long long)(ws.key[tp] >> 32); const uint32_t aup = ws.aux[tp];
+        head = !((int)(aup >> 16) == cn && (xp - (long long)(aup & 0x7FFF)) == (x - y));
+      }
+    }
+    if (!head) { atomicOr(&ws.aux[t], 0x8000u); continue; }
+    long long end = x + ix.seed[(int)(k & 0xFFFF)].span; uint32_t w = 1;
+    for (int r2 = r + 1; r2 < n; r2++) {
+      const uint32_t c2 = ck[r2];
+      if ((c2 >> 16) != (c >> 16)) break;
+      const int t2 = (int)(c2 & 0xFFFF);
+      const uint64_t k2 = ws.key[t2]; const uint32_t au2 = ws.aux[t2];
+      const long long x2 = (long long)(k2 >> 32);
+      if (!((int)(au2 >> 16) == cn && (x2 - (long long)(au2 & 0x7FFF)) == (x - y))) break;
+      end = max(end, x2 + ix.seed[(int)(k2 & 0xFFFF)].span); w++;
+    }
+    // members keep their sort key (x, y, seed: read above by other lanes); the head's own low word is only read by itself
+    ws.key[t] = ((uint64_t)x << 32) | ((uint64_t)(uint32_t)(end - x) << 16) | min(w, 0xFFFFu);
+  }
+  k2_sync<false>();
+  // stable compaction of the heads, in canonical (= creation) order
+  int na = 0;
+  for (int c0 = 0; c0 < n; c0 += GM_WAVE) {
+    const int t = c0 + lane;
+    uint64_t k = 0; uint32_t au = 0x8000u;
+    if (t < n) { k = ws.key[t]; au = ws.aux[t]; }
+    const bool alive = !(au & 0x8000u);
+    const unsigned long long bal = __ballot(alive);
+    k2_sync<false>();
+    if (alive) { const int d = na + __popcll(bal & ((1ull << lane) - 1ull)); ws.key[d] = k; ws.aux[d] = au; }
+    na += __popcll(bal);
+    k2_sync<false>();
+  }
+  return na;
+}
+
+// ---- window generation (ref: mapping.c:1048-1207), one anchor per lane.  Returns the number of windows;
+// DETECT additionally reports whether the open order of equal-x anchors could matter. ----------------
+template <bool BIG, bool DETECT>
+__device__ int k2_windows(const GmIndexDev& ix, const GmScoreDev& sc, K2Ws<BIG>& ws, int na, int read_len, int window_len,
+                          GmHit* H, uint32_t* hitx, int hcap, int lane, bool* sensitive) {
+  const int match = sc.match;
+  int nh = 0; bool sens = false;
+  for (int c0 = 0; c0 < na; c0 += GM_WAVE) {
+    const int i = c0 + lane;
+    bool pass = false; GmHit h; uint32_t myx = 0;
+    if (i < na) {
+      const uint64_t ai = ws.key[i]; const uint32_t aui = ws.aux[i];
+      const long long xi = (long long)(ai >> 32); const int yi = (int)(aui & 0x7FFF);
+      const int leni = (int)((ai >> 16) & 0xFFFF), wi = (int)(ai & 0xFFFF);
+      const int cn = (int)(aui >> 16);
+      myx = (uint32_t)xi;
+      const long long coff = ix.contig_off[cn];
+      const long long clen = (long long)ix.contig_off[cn + 1] - coff;
+      int w_len = window_len;
+      if ((long long)w_len > clen) w_len = (int)clen;
+      long long gend = (xi - coff) + read_len - 1 - yi;
+      if (gend > clen - 1) gend = clen - 1;
+      const long long gstart = (gend >= window_len) ? gend - window_len : 0;
+      int max_idx = i;
+      int max_score = leni * match;
+      if (sc.match_mode == 2 && wi == 1) max_score = -1;
+      bool tie_sibling = false;        // another candidate with the argmax's x reached the same score
+      for (int j = i - 1; j >= 0; j--) {
+        const uint64_t aj = ws.key[j];
+        const long long xj = (long long)(aj >> 32);
+        if (xj < coff + gstart) break;
+        const int yj = (int)(ws.aux[j] & 0x7FFF);
+        if (yj >= yi) continue;
+        int short_len, long_len;
+        if (xi - yi > xj - yj) { short_len = (yi - yj) + leni; long_len = (int)(xi - xj) + leni; }
+        else { short_len = (int)(xi - xj) + leni; long_len = (yi - yj) + leni; }
+        int tmp;
+        if (long_len > short_len) tmp = short_len * match - sc.b_go - (long_len - short_len) * sc.b_ge;   // ref :1133-1135 (b_ penalties both ways)
+        else tmp = short_len * match;
+        if (tmp > max_score) { max_idx = j; max_score = tmp; tie_sibling = false; }
+        else if (DETECT && tmp == max_score && max_idx != i && xj == (long long)(ws.key[max_idx] >> 32)) tie_sibling = true;
+      }
+      const int base = (read_len < w_len ? read_len : w_len) * match;
+      if (sc.match_mode == 1 || max_score >= k2_threshold(sc.wgen_thr_frac, sc.wgen_abs, base)) {
+        const uint64_t am = ws.key[max_idx]; const uint32_t aum = ws.aux[max_idx];
+        const long long xm = (long long)(am >> 32);
+        if (DETECT && max_idx != i && (tie_sibling || xm == xi)) sens = true;          // case (a)
+        const int x_len = (int)(xi - xm) + leni;
+        long long goff;
+        if ((window_len - x_len) / 2 < xm - coff) goff = (xm - coff) - (window_len - x_len) / 2; else goff = 0;
+        if (goff + w_len > clen) goff = clen - w_len;
+        K2Box b;
+        if (max_idx < i) {
+          b = k2_join2(xi - coff - goff, yi, leni, 1, xm - coff - goff, (int)(aum & 0x7FFF), (int)((am >> 16) & 0xFFFF), 1);
+        } else { b.x = xi - coff - goff; b.y = yi; b.length = leni; b.width = 1; }
+        h.g_off = (uint32_t)goff; h.ax = (int32_t)b.x; h.ay = (int32_t)b.y; h.alen = b.length; h.awidth = b.width;
+        h.score_window_gen = max_score; h.score_vector = -1; h.pct_score_vector = 0;
+        h.cn = (uint16_t)cn; h.w_len = (uint16_t)w_len;
+        const int mt = (max_idx == i) ? wi : wi + (int)(am & 0xFFFF);
+        h.matches = (uint16_t)min(mt, 0xFFFF); h.flags = 0;
+        pass = true;
+      }
+    }
+    const unsigned long long bal = __ballot(pass);
+    if (pass) {
+      const int slot = nh + __popcll(bal & ((1ull << lane) - 1ull));
+      if (slot < hcap) { H[slot] = h; if (DETECT) hitx[slot] = myx; }
+    }
+    nh += __popcll(bal);
+  }
+  if (DETECT) *sensitive = __any(sens);
+  return nh;
+}
+
 template <bool BIG>
 __global__ void __launch_bounds__(GM_WAVE)
 k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_len, int max_n_kmers, int NL,
@@ -87,8 +319,8 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
           GmHit* __restrict__ hits, uint16_t* __restrict__ perm, uint32_t* __restrict__ hit_cnt, int hcap,
           unsigned long long* __restrict__ stats) {
   typedef typename K2Idx<BIG>::type idx_t;
-  constexpr uint32_t K2_NONE = K2Idx<BIG>::none;
   extern __shared__ __align__(16) uint8_t smem_raw[];
+  __shared__ int sh_na;
   const int lane = threadIdx.x;
   int rs, n;
   K2Ws<BIG> ws;
@@ -113,217 +345,96 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
   ws.first = (idx_t*)base;                       base += (size_t)((NL + 1) & ~1) * sizeof(idx_t);
   ws.hr = (uint16_t*)base;                       base += (size_t)((NL + 1) & ~1) * 2;
   ws.cache = (int16_t*)base;
+  uint32_t* scratch32 = (uint32_t*)ws.nxt;       // LDS tier: nxt+ord = u32[scap]; heavy tier: nxt = u32[cap]
+  GmHit* H = hits + (size_t)rs * hcap;
+  int npad = 64; while (npad < n) npad <<= 1;
 
-  // ---- 1. sort by (position, read offset, seed): bitonic in LDS / already done by the segmented radix sort ----
-  if (!BIG) {
-    int npad = 64; while (npad < n) npad <<= 1;
-    const uint64_t* sv = surv + (size_t)rs * scap;
-    for (int t = lane; t < npad; t += GM_WAVE) ws.key[t] = (t < n) ? sv[t] : ~0ull;
-    k2_sync<BIG>();
-    k2_bitonic<BIG>(ws.key, npad, lane);
-  }
-
-  // ---- 2. does any position carry two different read offsets?  then replay the heap ----
-  bool danger = false;
-  for (int t = lane + 1; t < n; t += GM_WAVE) {
-    const uint64_t a = ws.key[t - 1], b = ws.key[t];
-    danger |= ((a >> 32) == (b >> 32)) && (((a >> 16) & 0xFFFF) != ((b >> 16) & 0xFFFF));
-  }
-  danger = __any(danger);
-  if (danger) {
-    if (lane == 0) {
-      GS_ADD(stats, GS_EXACT_ORDER, 1ull);
-      for (int o = 0; o < NL; o++) ws.first[o] = (idx_t)K2_NONE;
-      for (int t = n - 1; t >= 0; t--) {
-        const uint64_t k = ws.key[t];
-        const int off = (int)(k & 0xFFFF) * max_n_kmers + (int)((k >> 16) & 0xFFFF);
-        ws.nxt[t] = ws.first[off]; ws.first[off] = (idx_t)t;
-      }
-      // heap_uu (ref: common/heap.h:44-139): 1-based nodes over hk/hr[0..load)
-      int load = 0;
-      auto pos_of = [&](int t) -> uint32_t { return (uint32_t)(ws.key[t] >> 32); };
-      auto down = [&](int node) {
-        for (;;) {
-          int left = node * 2, right = left + 1, mn = node;
-          if (left <= load && ws.hk[left - 1] < ws.hk[node - 1]) mn = left;
-          if (right <= load && ws.hk[right - 1] < ws.hk[mn - 1]) mn = right;
-          if (mn == node) break;
-          uint32_t tk = ws.hk[mn - 1]; ws.hk[mn - 1] = ws.hk[node - 1]; ws.hk[node - 1] = tk;
-          uint16_t tr = ws.hr[mn - 1]; ws.hr[mn - 1] = ws.hr[node - 1]; ws.hr[node - 1] = tr;
-          node = mn;
-        }
-      };
-      for (int o = 0; o < NL; o++) {          // initial inserts in (seed, read position) order, ref: mapping.c:913-935
-        if (ws.first[o] == (idx_t)K2_NONE) continue;
-        ws.hk[load] = pos_of((int)ws.first[o]); ws.hr[load] = (uint16_t)o; load++;
-        int node = load, parent = node / 2;
-        while (node > 1 && ws.hk[node - 1] < ws.hk[parent - 1]) {
-          uint32_t tk = ws.hk[parent - 1]; ws.hk[parent - 1] = ws.hk[node - 1]; ws.hk[node - 1] = tk;
-          uint16_t tr = ws.hr[parent - 1]; ws.hr[parent - 1] = ws.hr[node - 1]; ws.hr[node - 1] = tr;
-          node = parent; parent = node / 2;
-        }
-      }
-      int m = 0;
-      while (load > 0) {                      // ref: mapping.c:937-989
-        const int o = ws.hr[0];
-        const int t = (int)ws.first[o];
-        ws.ord[m++] = (idx_t)t;
-        const idx_t nx = ws.nxt[t];
-        if (nx != (idx_t)K2_NONE) { ws.first[o] = nx; ws.hk[0] = pos_of((int)nx); ws.hr[0] = (uint16_t)o; down(1); }
-        else { load--; if (load > 0) { ws.hk[0] = ws.hk[load]; ws.hr[0] = ws.hr[load]; down(1); } }
-      }
-      // apply the pop order: it only permutes entries inside groups of equal position, so only the
-      // low words (y, seed) move; hk is free now and serves as the per-group temporary.
-      int g0 = 0;
-      while (g0 < n) {
-        int g1 = g0 + 1;
-        while (g1 < n && (ws.key[g1] >> 32) == (ws.key[g0] >> 32)) g1++;
-        if (g1 - g0 > 1) {
-          for (int g = g0; g < g1; g++) ws.hk[g - g0] = (uint32_t)ws.key[ws.ord[g]];
-          for (int g = g0; g < g1; g++) ws.key[g] = (ws.key[g] & 0xFFFFFFFF00000000ull) | ws.hk[g - g0];
-        }
-        g0 = g1;
-      }
+  // loads the survivors in canonical order and fills aux = y | contig<<16 (get_contig_num, ref: gmapper.h:373-405)
+  auto load_sorted = [&]() {
+    if (!BIG) {
+      const uint64_t* sv = surv + (size_t)rs * scap;
+      for (int t = lane; t < npad; t += GM_WAVE) ws.key[t] = (t < n) ? sv[t] : ~0ull;
+      k2_sync<BIG>();
+      k2_bitonic<BIG, uint64_t>(ws.key, npad, lane);
     }
-    k2_sync<BIG>();
-  }
-
-  // ---- 3. contig of every entry (get_contig_num, ref: gmapper.h:373-405), then colinear collapse ----
-  for (int t = lane; t < n; t += GM_WAVE) {
-    const uint64_t k = ws.key[t];
-    const uint32_t x = (uint32_t)(k >> 32);
-    int lo = 0, hi = ix.n_contigs;
-    while (hi - lo > 1) { int m = (lo + hi) >> 1; if (ix.contig_off[m] <= x) lo = m; else hi = m; }
-    ws.aux[t] = (uint32_t)((k >> 16) & 0xFFFF) | ((uint32_t)lo << 16);
-  }
-  for (int d = lane; d < read_len; d += GM_WAVE) ws.cache[d] = -1;
-  k2_sync<BIG>();
-  __shared__ int sh_na;
-  if (lane == 0) {
-    int na = 0;
-    for (int t = 0; t < n; t++) {       // ref: mapping.c:937-971
+    for (int t = lane; t < n; t += GM_WAVE) {
       const uint64_t k = ws.key[t];
       const uint32_t x = (uint32_t)(k >> 32);
-      const uint32_t au = ws.aux[t];
-      const int y = (int)(au & 0xFFFF), cn = (int)(au >> 16);
-      const int len = ix.seed[(int)(k & 0xFFFF)].span;
-      const int diag = (int)(((long long)x + read_len - y) % read_len);
-      const int j = ws.cache[diag];
-      bool joined = false;
-      if (j >= 0) {
-        const uint64_t aj = ws.key[j];
-        const uint32_t auj = ws.aux[j];
-        const uint32_t xj = (uint32_t)(aj >> 32);
-        if ((int)(auj >> 16) == cn && ((long long)xj - (long long)(auj & 0xFFFF) == (long long)x - y)) {
-          // anchor_uw_join(dest = A[j], src), ref: common/anchors.c:98-119 (src.x >= dest.x here)
-          uint32_t lj = (uint32_t)(aj >> 16) & 0xFFFF, wj = (uint32_t)aj & 0xFFFF;
-          if ((long long)x + len > (long long)xj + lj) lj = (uint32_t)(x - xj + len);
-          wj = min(wj + 1u, 0xFFFFu);
-          ws.key[j] = ((uint64_t)xj << 32) | ((uint64_t)lj << 16) | wj;
-          joined = true;
-        }
-      }
-      if (!joined) {
-        ws.cache[diag] = (int16_t)na;
-        ws.key[na] = ((uint64_t)x << 32) | ((uint64_t)len << 16) | 1u;
-        ws.aux[na] = au;
-        na++;
-      }
-    }
-    sh_na = na;
-  }
-  k2_sync<BIG>();
-  const int na = sh_na;
-
-  // ---- 4. window generation (ref: mapping.c:1048-1207), one anchor per lane ----
-  GmHit* H = hits + (size_t)rs * hcap;
-  const int match = sc.match;
-  int nh = 0;
-  for (int c0 = 0; c0 < na; c0 += GM_WAVE) {
-    const int i = c0 + lane;
-    bool pass = false; GmHit h;
-    if (i < na) {
-      const uint64_t ai = ws.key[i]; const uint32_t aui = ws.aux[i];
-      const long long xi = (long long)(ai >> 32); const int yi = (int)(aui & 0xFFFF);
-      const int leni = (int)((ai >> 16) & 0xFFFF), wi = (int)(ai & 0xFFFF);
-      const int cn = (int)(aui >> 16);
-      const long long coff = ix.contig_off[cn];
-      const long long clen = (long long)ix.contig_off[cn + 1] - coff;
-      int w_len = window_len;
-      if ((long long)w_len > clen) w_len = (int)clen;
-      long long gend = (xi - coff) + read_len - 1 - yi;
-      if (gend > clen - 1) gend = clen - 1;
-      const long long gstart = (gend >= window_len) ? gend - window_len : 0;
-      int max_idx = i;
-      int max_score = leni * match;
-      if (sc.match_mode == 2 && wi == 1) max_score = -1;
-      for (int j = i - 1; j >= 0; j--) {
-        const uint64_t aj = ws.key[j];
-        const long long xj = (long long)(aj >> 32);
-        if (xj < coff + gstart) break;
-        const int yj = (int)(ws.aux[j] & 0xFFFF);
-        if (yj >= yi) continue;
-        int short_len, long_len;
-        if (xi - yi > xj - yj) { short_len = (yi - yj) + leni; long_len = (int)(xi - xj) + leni; }
-        else { short_len = (int)(xi - xj) + leni; long_len = (yi - yj) + leni; }
-        int tmp;
-        if (long_len > short_len) tmp = short_len * match - sc.b_go - (long_len - short_len) * sc.b_ge;   // ref :1133-1135 (b_ penalties both ways)
-        else tmp = short_len * match;
-        if (tmp > max_score) { max_idx = j; max_score = tmp; }
-      }
-      const int base = (read_len < w_len ? read_len : w_len) * match;
-      if (sc.match_mode == 1 || max_score >= k2_threshold(sc.wgen_thr_frac, sc.wgen_abs, base)) {
-        const uint64_t am = ws.key[max_idx]; const uint32_t aum = ws.aux[max_idx];
-        const long long xm = (long long)(am >> 32);
-        const int x_len = (int)(xi - xm) + leni;
-        long long goff;
-        if ((window_len - x_len) / 2 < xm - coff) goff = (xm - coff) - (window_len - x_len) / 2; else goff = 0;
-        if (goff + w_len > clen) goff = clen - w_len;
-        K2Box b;
-        if (max_idx < i) {
-          b = k2_join2(xi - coff - goff, yi, leni, 1, xm - coff - goff, (int)(aum & 0xFFFF), (int)((am >> 16) & 0xFFFF), 1);
-        } else { b.x = xi - coff - goff; b.y = yi; b.length = leni; b.width = 1; }
-        h.g_off = (uint32_t)goff; h.ax = (int32_t)b.x; h.ay = (int32_t)b.y; h.alen = b.length; h.awidth = b.width;
-        h.score_window_gen = max_score; h.score_vector = -1; h.pct_score_vector = 0;
-        h.cn = (uint16_t)cn; h.w_len = (uint16_t)w_len;
-        const int mt = (max_idx == i) ? wi : wi + (int)(am & 0xFFFF);
-        h.matches = (uint16_t)min(mt, 0xFFFF); h.flags = 0;
-        pass = true;
-      }
-    }
-    const unsigned long long bal = __ballot(pass);
-    if (pass) {
-      const int slot = nh + __popcll(bal & ((1ull << lane) - 1ull));
-      if (slot < hcap) H[slot] = h;
-    }
-    nh += __popcll(bal);
-  }
-  k2_sync<BIG>();   // anchors are dead from here; ws.key is reused for the window sort
-
-  // ---- 5. stable order by (contig, g_off) == the reference's insertion sort (ref: mapping.c:1210-1223) ----
-  const int nhc = min(nh, hcap);
-  uint16_t* P = perm + (size_t)rs * hcap;
-  if (nhc > 0) {
-    int hp = 64; while (hp < nhc) hp <<= 1;
-    // nhc <= na <= n, and every key array holds pow2ceil(n) >= hp entries
-    // the records were written by other lanes of this wave: read them back past the L1 (sc1 loads)
-    for (int t = lane; t < hp; t += GM_WAVE) {
-      uint64_t k = ~0ull;
-      if (t < nhc) {
-        const uint32_t go = __hip_atomic_load(&H[t].g_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t cw = __hip_atomic_load((const uint32_t*)&H[t].cn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        k = ((uint64_t)(cw & 0xFFFF) << 48) | ((uint64_t)go << 16) | (uint64_t)t;
-      }
-      ws.key[t] = k;
+      int lo = 0, hi = ix.n_contigs;
+      while (hi - lo > 1) { int m = (lo + hi) >> 1; if (ix.contig_off[m] <= x) lo = m; else hi = m; }
+      ws.aux[t] = (uint32_t)((k >> 16) & 0x7FFF) | ((uint32_t)lo << 16);
     }
     k2_sync<BIG>();
-    k2_bitonic<BIG>(ws.key, hp, lane);
-    for (int t = lane; t < nhc; t += GM_WAVE) P[t] = (uint16_t)(ws.key[t] & 0xFFFF);
+  };
+
+  // orders the windows by (contig, g_off), stable == the reference's insertion sort (ref: mapping.c:1210-1223);
+  // detect: case (b), equal (contig, g_off) windows made from equal-x anchors (hitx = scratch32)
+  auto sort_windows = [&](int nhc, bool detect) -> bool {
+    bool sens = false;
+    uint16_t* P = perm + (size_t)rs * hcap;
+    if (nhc > 0) {
+      int hp = 64; while (hp < nhc) hp <<= 1;
+      // nhc <= na <= n, and every key array holds pow2ceil(n) >= hp entries.
+      // The records were written by other lanes of this wave: read them back past the L1 (sc1 loads).
+      for (int t = lane; t < hp; t += GM_WAVE) {
+        uint64_t k = ~0ull;
+        if (t < nhc) {
+          const uint32_t go = __hip_atomic_load(&H[t].g_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t cw = __hip_atomic_load((const uint32_t*)&H[t].cn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          k = ((uint64_t)(cw & 0xFFFF) << 48) | ((uint64_t)go << 16) | (uint64_t)t;
+        }
+        ws.key[t] = k;
+      }
+      k2_sync<BIG>();
+      k2_bitonic<BIG, uint64_t>(ws.key, hp, lane);
+      for (int t = lane; t < nhc; t += GM_WAVE) {
+        P[t] = (uint16_t)(ws.key[t] & 0xFFFF);
+        if (detect && t > 0 && (ws.key[t] >> 16) == (ws.key[t - 1] >> 16) &&
+            scratch32[ws.key[t] & 0xFFFF] == scratch32[ws.key[t - 1] & 0xFFFF]) sens = true;
+      }
+    }
+    return __any(sens);
+  };
+
+  int na = 0, nh = 0;
+  bool need_exact = BIG;
+  load_sorted();
+  if (!BIG) {
+    // ---- fast path: order-free collapse + windows in canonical order, with sensitivity detection ----
+    na = k2_collapse_par(ix, *(K2Ws<false>*)&ws, scratch32, n, npad, read_len, lane);
+    bool sens = false;
+    nh = k2_windows<BIG, true>(ix, sc, ws, na, read_len, window_len, H, scratch32, hcap, lane, &sens);
+    k2_sync<BIG>();
+    need_exact = sens;
+    if (!need_exact) need_exact = sort_windows(min(nh, hcap), true);
+  }
+  if (need_exact) {
+    // ---- exact path: reference pop order (heap replay when a position carries two read offsets) ----
+    if (!BIG) { k2_sync<BIG>(); load_sorted(); }
+    bool danger = false;
+    for (int t = lane + 1; t < n; t += GM_WAVE) {
+      const uint64_t a = ws.key[t - 1], b = ws.key[t];
+      danger |= ((a >> 32) == (b >> 32)) && (((a >> 16) & 0xFFFF) != ((b >> 16) & 0xFFFF));
+    }
+    danger = __any(danger);
+    for (int d = lane; d < read_len; d += GM_WAVE) ws.cache[d] = -1;
+    k2_sync<BIG>();
+    if (lane == 0) {
+      GS_ADD(stats, GS_EXACT_ORDER, 1ull);
+      if (danger) k2_exact_order<BIG>(ws, n, NL, max_n_kmers);
+      sh_na = k2_collapse_seq<BIG>(ix, ws, n, read_len);
+    }
+    k2_sync<BIG>();
+    na = sh_na;
+    bool dummy;
+    nh = k2_windows<BIG, false>(ix, sc, ws, na, read_len, window_len, H, scratch32, hcap, lane, &dummy);
+    k2_sync<BIG>();
+    sort_windows(min(nh, hcap), false);
   }
   if (lane == 0) {
     hit_cnt[rs] = (uint32_t)nh;
-    GS_ADD(stats, GS_ANCHORS, (unsigned long long)na);
-    GS_ADD(stats, GS_WINDOWS, (unsigned long long)nhc);
+    GS_ADD(stats, GS_ANCHORS, na);
+    GS_ADD(stats, GS_WINDOWS, min(nh, hcap));
     if (nh > hcap) GS_ADD(stats, GS_OVERFLOW_HITS, 1ull);
   }
 }
@@ -354,7 +465,7 @@ int gm_launch_anchors(const GmIndexDev& ix, const GmScoreDev& sc, int n_reads, i
   return GM_OK;
 }
 
-// heavy tier: segmented radix sort of the re-emitted keys (64-bit, all bits), then the same pipeline on global arrays
+// heavy tier: segmented radix sort of the re-emitted keys (64-bit, all bits), then the exact path on global arrays
 int gm_launch_anchors_heavy(const GmIndexDev& ix, const GmScoreDev& sc, int n_reads, int read_len, int window_len,
                             int n_heavy, const uint32_t* d_heavy_list, const uint64_t* d_seg_off, const uint32_t* d_seg_n,
                             const uint32_t* d_seg_begin32, const uint32_t* d_seg_end32, uint64_t total_keys,
