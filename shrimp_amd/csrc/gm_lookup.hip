@@ -20,6 +20,8 @@
 #include "gm_internal.h"
 
 #define K1_THREADS 256
+#define K1_SHORT 64u      // slices up to this many entries are streamed by their own lane
+#define K1_UNROLL 8       // loads in flight per lane
 
 struct K1Smem {
   uint32_t n_surv;
@@ -31,6 +33,13 @@ __device__ __forceinline__ void k1_mark(uint32_t* bm, uint32_t rloc) {
   const uint32_t old = atomicOr(&bm[w], 1u << sh);
   if (old & (1u << sh)) atomicOr(&bm[w], 2u << sh);
 }
+// 8 consecutive positions with 4-byte alignment: two global_load_dwordx4 (gfx950 runs in unaligned-access mode)
+typedef uint32_t k1_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void k1_load8(const uint32_t* __restrict__ src, uint32_t* p) {
+  const k1_u32x4 a = *(const k1_u32x4*)src;
+  const k1_u32x4 b = *(const k1_u32x4*)(src + 4);
+  p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w; p[4] = b.x; p[5] = b.y; p[6] = b.z; p[7] = b.w;
+}
 __device__ __forceinline__ bool k1_has2(const uint32_t* bm, uint32_t rloc) {
   return (bm[rloc >> 4] >> ((rloc & 15u) * 2u + 1u)) & 1u;
 }
@@ -41,7 +50,7 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
          int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
          uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap,
          const uint32_t* __restrict__ redo_list, const uint64_t* __restrict__ redo_off,
-         unsigned long long* __restrict__ stats) {
+         unsigned long long* __restrict__ stats, int ablate) {
   extern __shared__ __align__(16) uint32_t smem[];
   __shared__ K1Smem sh;
   const int tid = threadIdx.x;
@@ -60,7 +69,7 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
   uint32_t* lo = lend + NL;
   uint32_t* hi = lo + NL;
   uint32_t* pre = hi + NL;              // NL + 1
-  uint32_t* bm = pre + NL + 1;
+  uint32_t* bm = smem + ((code_words + 6 * NL + 1 + 3) & ~3);     // 16-byte aligned for the b128 clears
   const int S = ix.n_slabs, rb = ix.region_bits;
   const uint32_t rmask = (1u << rb) - 1u, ovl = (uint32_t)ix.region_overlap;
 
@@ -101,39 +110,107 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
   __syncthreads();
 
   // ---- 2. slab sweep ----
+  // Short slices (<= K1_SHORT entries; all of them on uniform genomes) are streamed by the lane that
+  // owns the list: its bounds stay in registers and K1_UNROLL loads are in flight per lane.  Long
+  // slices (repeats) are flattened over the whole workgroup so that one lane never walks a long list.
+  auto emit = [&](uint32_t p, int off) {
+    const uint32_t slot = atomicAdd(&sh.n_surv, 1u);
+    if (slot < scap) {   // sort key of K2: position, then read offset y, then seed
+      const uint32_t sn = (uint32_t)off / (uint32_t)max_n_kmers, y = (uint32_t)off - sn * (uint32_t)max_n_kmers;
+      out[slot] = ((uint64_t)p << 32) | ((uint64_t)y << 16) | sn;
+    }
+  };
   for (int s = 0; s < S; s++) {
     const uint64_t B = (uint64_t)s << ix.slab_bits;
     const uint64_t E = B + (1ull << ix.slab_bits);
     const uint32_t rbase = (uint32_t)(B >> rb);           // local region index = region - rbase + 1
-    for (int w = tid; w < bm_words; w += K1_THREADS) bm[w] = 0;
+    const uint32_t rend = (uint32_t)(E >> rb);
+    {   // clear the region counters (16-byte stores)
+      uint4* bm4 = (uint4*)bm; const int n4 = (ablate & 8) ? 0 : (bm_words >> 2);
+      for (int w = tid; w < n4; w += K1_THREADS) bm4[w] = make_uint4(0, 0, 0, 0);
+      for (int w = (n4 << 2) + tid; w < bm_words; w += K1_THREADS) bm[w] = 0;
+    }
+    if (tid == 0) sh.total = 0;
+    __syncthreads();
+    // -- phase 0: mark --
+    bool any_long = false;
     for (int off = tid; off < NL; off += K1_THREADS) {
       uint32_t l = 0, h = 0, c = 0;
-      if (lend[off] > lbeg[off]) {
-        if (S == 1) { l = lbeg[off]; h = lend[off]; }
+      const uint32_t lb = lbeg[off], le = lend[off];
+      if (le > lb) {
+        const uint32_t* plist = ix.seed[off / max_n_kmers].pos;
+        if (S == 1) { l = lb; h = le; }
         else { const uint32_t* dir = ix.seed[off / max_n_kmers].dir; l = dir[kS[off] + s]; h = dir[kS[off] + s + 1]; }
-        // one candidate border entry on each side (they decide whether a border scan is needed)
-        c = (h - l) + (l > lbeg[off] ? 1u : 0u) + (h < lend[off] ? 1u : 0u);
+        if (h - l > K1_SHORT) {
+          c = (h - l) + (l > lb ? 1u : 0u) + (h < le ? 1u : 0u);     // + one candidate border entry on each side
+          any_long = true;
+        } else {
+          for (uint32_t e = l; e < h; e += K1_UNROLL) {
+            // unconditional wide loads (two dwordx4 per lane, both in flight); lanes past the slice end read the
+            // next list / the 0xffffffff tail pad and are masked below -- predicated loads would serialise
+            uint32_t p[K1_UNROLL];
+            k1_load8(plist + e, p);
+#pragma unroll
+            for (int u = 0; u < K1_UNROLL; u++)
+              if (e + u < h) {
+                const uint32_t reg = p[u] >> rb, rloc = reg - rbase + 1u;
+                if (ablate & 4) { if (p[u] == 0x12345u) bm[0] = 1; continue; }
+                k1_mark(bm, rloc);
+                if (((p[u] & rmask) < ovl) && reg > 0) k1_mark(bm, rloc - 1u);
+              }
+          }
+          if (S > 1 && !(ablate & 2)) {
+            // entries of the previous slab inside the last region before B count for local region 0
+            for (uint32_t q = l; q > lb;) { --q; if ((plist[q] >> rb) + 1u != rbase) break; k1_mark(bm, 0u); }
+            // entries of the next slab inside the overlap strip count for this slab's last region
+            for (uint32_t q = h; q < le; q++) { const uint32_t pq = plist[q]; if ((pq >> rb) != rend || (pq & rmask) >= ovl) break; k1_mark(bm, rend - rbase); }
+          }
+        }
       }
       lo[off] = l; hi[off] = h; pre[off] = c;
     }
+    if (any_long) sh.total = 1;            // benign race: every writer stores 1
     __syncthreads();
-    // exclusive scan of pre[0..NL) by wave 0
-    if (tid < GM_WAVE) {
-      const int per = (NL + GM_WAVE - 1) / GM_WAVE;
-      const int a0 = tid * per, a1 = min(NL, a0 + per);
-      uint32_t sum = 0;
-      for (int a = a0; a < a1; a++) sum += pre[a];
-      uint32_t incl = sum;
-      for (int d = 1; d < GM_WAVE; d <<= 1) { uint32_t o = __shfl_up(incl, d); if (tid >= d) incl += o; }
-      uint32_t run = incl - sum;
-      for (int a = a0; a < a1; a++) { uint32_t c = pre[a]; pre[a] = run; run += c; }
-      if (tid == GM_WAVE - 1) { pre[NL] = incl; sh.total = incl; }
+    const bool have_long = sh.total != 0;
+    uint32_t total = 0;
+    if (have_long) {
+      __syncthreads();
+      // exclusive scan of pre[0..NL) by wave 0
+      if (tid < GM_WAVE) {
+        const int per = (NL + GM_WAVE - 1) / GM_WAVE;
+        const int a0 = tid * per, a1 = min(NL, a0 + per);
+        uint32_t sum = 0;
+        for (int a = a0; a < a1; a++) sum += pre[a];
+        uint32_t incl = sum;
+        for (int d = 1; d < GM_WAVE; d <<= 1) { uint32_t o = __shfl_up(incl, d); if (tid >= d) incl += o; }
+        uint32_t run = incl - sum;
+        for (int a = a0; a < a1; a++) { uint32_t c = pre[a]; pre[a] = run; run += c; }
+        if (tid == GM_WAVE - 1) { pre[NL] = incl; sh.total = incl; }
+      }
+      __syncthreads();
+      total = sh.total;
     }
-    __syncthreads();
-    const uint32_t total = sh.total;
-    if (total == 0) { __syncthreads(); continue; }
-
     for (int phase = 0; phase < 2; phase++) {
+      if (phase == 1 && !(ablate & 1)) {
+        // -- phase 1 (short slices): survival test, re-reading the slice from L1/L2 --
+        for (int off = tid; off < NL; off += K1_THREADS) {
+          const uint32_t l = lo[off], h = hi[off];
+          if (h <= l || h - l > K1_SHORT) continue;
+          const uint32_t* plist = ix.seed[off / max_n_kmers].pos;
+          for (uint32_t e = l; e < h; e += K1_UNROLL) {
+            uint32_t p[K1_UNROLL];
+            k1_load8(plist + e, p);
+#pragma unroll
+            for (int u = 0; u < K1_UNROLL; u++)
+              if (e + u < h) {
+                const uint32_t reg = p[u] >> rb, rloc = reg - rbase + 1u;
+                const bool strip = ((p[u] & rmask) < ovl) && reg > 0;
+                if (k1_has2(bm, rloc) || (strip && k1_has2(bm, rloc - 1u))) emit(p[u], off);
+              }
+          }
+        }
+      }
+      // -- long slices, flattened over the workgroup (both phases) --
       for (uint32_t e0 = 0; e0 < total; e0 += K1_THREADS) {
         const uint32_t e = e0 + tid;
         if (e < total) {
@@ -153,26 +230,14 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
             if (phase == 0) {
               k1_mark(bm, rloc);
               if (strip) k1_mark(bm, rloc - 1u);
-            } else {
-              if (k1_has2(bm, rloc) || (strip && k1_has2(bm, rloc - 1u))) {
-                const uint32_t slot = atomicAdd(&sh.n_surv, 1u);
-                if (slot < scap) {
-                  // sort key of K2: position, then read offset y, then seed
-                  const uint32_t sn = (uint32_t)off / (uint32_t)max_n_kmers, y = (uint32_t)off - sn * (uint32_t)max_n_kmers;
-                  out[slot] = ((uint64_t)p << 32) | ((uint64_t)y << 16) | sn;
-                }
-              }
-            }
+            } else if (k1_has2(bm, rloc) || (strip && k1_has2(bm, rloc - 1u))) emit(p, off);
           } else if (phase == 0) {
             if (idx < l) {
-              // entries of the previous slab inside the last region before B count for local region 0
               if (reg + 1u == rbase) {
                 k1_mark(bm, 0u);
                 for (uint32_t q = idx; q > lbeg[off];) { --q; if ((plist[q] >> rb) + 1u != rbase) break; k1_mark(bm, 0u); }
               }
             } else {
-              // entries of the next slab inside the overlap strip count for this slab's last region
-              const uint32_t rend = (uint32_t)(E >> rb);
               if (reg == rend && (p & rmask) < ovl) {
                 k1_mark(bm, rend - rbase);
                 for (uint32_t q = idx + 1; q < lend[off]; q++) {
@@ -209,7 +274,8 @@ static void k1_geometry(const GmIndexDev& ix, int read_len, int* max_n_kmers, in
   uint64_t slab_len = (ix.n_slabs == 1) ? ix.total_len : (1ull << ix.slab_bits);
   uint64_t regions = (slab_len >> ix.region_bits) + 3;      // +1 region before, +1 partial, +1 slack
   *bm_words = (int)((regions + 15) / 16);
-  *lds = (size_t)((read_len + 3) / 4) * 4 + (size_t)(*NL) * 5 * 4 + ((size_t)(*NL) + 1) * 4 + (size_t)(*bm_words) * 4;
+  *bm_words = (*bm_words + 3) & ~3;
+  *lds = (size_t)((((read_len + 3) / 4) + 6 * (*NL) + 1 + 3) & ~3) * 4 + (size_t)(*bm_words) * 4;
 }
 
 size_t gm_lookup_lds_bytes(const GmIndexDev& ix, int read_len) {
@@ -231,7 +297,7 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
   }
   hipLaunchKernelGGL(k_lookup, dim3(n_reads * 2), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
                      max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
-                     (const uint32_t*)nullptr, (const uint64_t*)nullptr, d_stats);
+                     (const uint32_t*)nullptr, (const uint64_t*)nullptr, d_stats, getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }
@@ -245,7 +311,7 @@ int gm_launch_lookup_redo(const GmIndexDev& ix, const uint32_t* d_reads, int n_r
   if (n_heavy == 0) return GM_OK;
   hipLaunchKernelGGL(k_lookup, dim3(n_heavy), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
                      max_n_kmers, NL, bm_words, d_out, (uint32_t*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0,
-                     d_redo_list, d_redo_off, d_stats);
+                     d_redo_list, d_redo_off, d_stats, 0);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }
