@@ -75,7 +75,7 @@ def main():
 
     def step(i):
         p = pools[i % n_pool]
-        sess.map_device(p.data_ptr(), R, L, emit_sam=not args.no_sam)
+        sess.map_device(p.data_ptr(), R, L, emit_sam=not args.no_sam, return_bytes=False)
         return sess.stats
 
     for i in range(args.warmup):

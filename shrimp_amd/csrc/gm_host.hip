@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include "gm_common.h"
 #include "gm_internal.h"
@@ -233,7 +234,7 @@ struct gm_session {
   hipStream_t stream = nullptr;
   hipEvent_t ev[12];
   // capacities (grown on overflow)
-  int cur_len = -1, scap = 0, hcap = 0, rcap_per_read = 8, ops_stride = 0, p2_grid = 2048, eff_batch = 0;
+  int cur_len = -1, scap = 0, hcap = 0, rcap_per_read = 8, ops_stride = 0, p2_grid = 2560, eff_batch = 0;
   // device buffers
   uint32_t* d_reads = nullptr; uint64_t* d_surv = nullptr; uint32_t* d_surv_cnt = nullptr;
   GmHit* d_hits = nullptr; uint16_t* d_perm = nullptr; uint32_t* d_hit_cnt = nullptr; unsigned long long* d_slots = nullptr;
@@ -603,38 +604,34 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   // names
   std::vector<const char*> nptr; std::vector<int> nlen;
   if (names) { const char* p = names; for (int i = 0; i < n_reads; i++) { const char* e = strchr(p, '\n'); if (!e) e = p + strlen(p); nptr.push_back(p); nlen.push_back((int)(e - p)); p = *e ? e + 1 : e; } }
-  std::string out;
-  uint64_t matched = 0, records = 0;
-  for (int base = 0; base < n_reads;) {
-    int n, rc; float lk = 0;
-    do {
-      n = std::min(s->eff_batch, n_reads - base);
-      if (reads_host) GM_HIP(hipMemcpyAsync(s->d_reads, reads_host + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyHostToDevice, s->stream));
-      else GM_HIP(hipMemcpyAsync(s->d_reads, (const uint32_t*)reads_dev + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyDeviceToDevice, s->stream));
-      rc = run_device_pipeline(s, n, read_len, stats, &lk);
-    } while (rc == 1);
-    if (rc) return rc;
-    s->last_lookup_ms += lk; s->last_lookup_launches++;
-    // host finalisation (multi-threaded over reads, output kept in input order)
+  // Sub-batches are pipelined: while the GPU works on sub-batch i+1, host threads finish sub-batch i
+  // (pass-2 selection, MAPQ, SAM text).  Output stays in input order.
+  struct Job {
+    std::vector<GmFullRes> res; std::vector<uint8_t> ops; std::vector<uint32_t> sel_cnt, sel_off, reads;
+    const uint32_t* hreads = nullptr; int base = 0, n = 0;
+    std::vector<std::string> outs; std::vector<uint64_t> cm, cr; double ms = 0;
+    std::thread th;
+  };
+  std::vector<std::unique_ptr<Job>> jobs;
+  int nthreads = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* e = getenv("GM_HOST_THREADS")) nthreads = std::max(1, atoi(e));
+  const int ops_stride = s->ops_stride;
+  auto run_job = [&, nthreads, ops_stride](Job* J) {
     auto t0 = std::chrono::steady_clock::now();
-    const uint32_t* hreads = reads_host ? reads_host + (size_t)base * read_words : nullptr;
-    if (!hreads) { s->h_reads.resize((size_t)n * read_words); GM_HIP(hipMemcpy(s->h_reads.data(), s->d_reads, (size_t)n * read_words * 4, hipMemcpyDeviceToHost)); hreads = s->h_reads.data(); }
-    int nthreads = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char* e = getenv("GM_HOST_THREADS")) nthreads = std::max(1, atoi(e));
-    const int chunk = 4096; const int nchunks = (n + chunk - 1) / chunk;
-    std::vector<std::string> outs(nchunks); std::vector<uint64_t> cm(nchunks, 0), cr(nchunks, 0);
+    const int n = J->n; const int chunk = 4096; const int nchunks = (n + chunk - 1) / chunk;
+    J->outs.assign(nchunks, std::string()); J->cm.assign(nchunks, 0); J->cr.assign(nchunks, 0);
     std::atomic<int> next(0);
-    Finalizer F{s, read_len, read_words, hreads, names ? nptr.data() + base : nullptr, names ? nlen.data() + base : nullptr, (long)base};
+    Finalizer F{s, read_len, read_words, J->hreads, names ? nptr.data() + J->base : nullptr, names ? nlen.data() + J->base : nullptr, (long)J->base};
     auto worker = [&]() {
       std::vector<FHit> fh; std::vector<FHit*> p2;
       for (;;) {
         int c = next.fetch_add(1); if (c >= nchunks) break;
-        std::string& o = outs[c]; if (emit_sam) o.reserve((size_t)chunk * (read_len + 120));
+        std::string& o = J->outs[c]; if (emit_sam) o.reserve((size_t)chunk * (read_len + 120));
         for (int rd = c * chunk; rd < std::min(n, (c + 1) * chunk); rd++) {
-          const uint32_t cnt = s->h_sel_cnt[rd], off = s->h_sel_off[rd];
-          int k = F.finalize_read(rd, cnt ? &s->h_res[off] : nullptr, s->h_ops.data(), s->ops_stride, (int)cnt, o, fh, p2);
-          if (!p2.empty()) cm[c]++;
-          cr[c] += k;
+          const uint32_t cnt = J->sel_cnt[rd], off = J->sel_off[rd];
+          int k = F.finalize_read(rd, cnt ? &J->res[off] : nullptr, J->ops.data(), ops_stride, (int)cnt, o, fh, p2);
+          if (!p2.empty()) J->cm[c]++;
+          J->cr[c] += k;
           if (!emit_sam) o.clear();
         }
       }
@@ -643,14 +640,51 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     for (int t = 1; t < nthreads; t++) th.emplace_back(worker);
     worker();
     for (auto& t : th) t.join();
-    for (int c = 0; c < nchunks; c++) { if (emit_sam) out += outs[c]; matched += cm[c]; records += cr[c]; }
-    if (stats) stats->ms_host += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    J->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  };
+  size_t joined = 0;
+  for (int base = 0; base < n_reads;) {
+    int n, rc; float lk = 0;
+    do {
+      n = std::min(s->eff_batch, n_reads - base);
+      if (reads_host) GM_HIP(hipMemcpyAsync(s->d_reads, reads_host + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyHostToDevice, s->stream));
+      else GM_HIP(hipMemcpyAsync(s->d_reads, (const uint32_t*)reads_dev + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyDeviceToDevice, s->stream));
+      rc = run_device_pipeline(s, n, read_len, stats, &lk);
+    } while (rc == 1);
+    if (rc) { for (auto& j : jobs) if (j->th.joinable()) j->th.join(); return rc; }
+    s->last_lookup_ms += lk; s->last_lookup_launches++;
+    std::unique_ptr<Job> J(new Job());
+    J->base = base; J->n = n;
+    J->res.swap(s->h_res); J->ops.swap(s->h_ops); J->sel_cnt.swap(s->h_sel_cnt); J->sel_off.swap(s->h_sel_off);
+    if (reads_host) J->hreads = reads_host + (size_t)base * read_words;
+    else { J->reads.resize((size_t)n * read_words); GM_HIP(hipMemcpy(J->reads.data(), s->d_reads, (size_t)n * read_words * 4, hipMemcpyDeviceToHost)); J->hreads = J->reads.data(); }
+    // at most two host jobs outstanding
+    while (jobs.size() - joined >= 2) { jobs[joined]->th.join(); joined++; }
+    Job* jp = J.get();
+    J->th = std::thread(run_job, jp);
+    jobs.push_back(std::move(J));
     base += n;
+  }
+  for (auto& j : jobs) if (j->th.joinable()) j->th.join();
+  uint64_t matched = 0, records = 0; size_t total = 0;
+  std::vector<std::pair<const std::string*, size_t>> pieces;     // (chunk text, offset in the final buffer)
+  for (auto& j : jobs) {
+    for (size_t c = 0; c < j->outs.size(); c++) {
+      if (emit_sam) { pieces.push_back({&j->outs[c], total}); total += j->outs[c].size(); }
+      matched += j->cm[c]; records += j->cr[c];
+    }
+    if (stats) stats->ms_host += j->ms;
   }
   if (stats) { stats->reads = n_reads; stats->reads_matched = matched; stats->sam_records = records; }
   if (emit_sam && sam) {
-    char* r = (char*)malloc(out.size() + 1); if (!r) return GM_E_NOMEM;
-    memcpy(r, out.data(), out.size()); r[out.size()] = 0; *sam = r; if (sam_len) *sam_len = out.size();
+    char* r = (char*)malloc(total + 1); if (!r) return GM_E_NOMEM;
+    std::atomic<size_t> nextp(0);
+    auto copier = [&]() { for (;;) { size_t i = nextp.fetch_add(1); if (i >= pieces.size()) break; memcpy(r + pieces[i].second, pieces[i].first->data(), pieces[i].first->size()); } };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; t++) th.emplace_back(copier);
+    copier();
+    for (auto& t : th) t.join();
+    r[total] = 0; *sam = r; if (sam_len) *sam_len = total;
   } else { if (sam) *sam = nullptr; if (sam_len) *sam_len = 0; }
   return GM_OK;
 }

@@ -21,7 +21,9 @@
 
 #define K1_THREADS 256
 #define K1_SHORT 64u      // slices up to this many entries are streamed by their own lane
-#define K1_UNROLL 8       // loads in flight per lane
+#ifndef K1_UNROLL
+#define K1_UNROLL 8       // positions in flight per lane (two dwordx4 per 8)
+#endif
 
 struct K1Smem {
   uint32_t n_surv;
@@ -36,9 +38,11 @@ __device__ __forceinline__ void k1_mark(uint32_t* bm, uint32_t rloc) {
 // 8 consecutive positions with 4-byte alignment: two global_load_dwordx4 (gfx950 runs in unaligned-access mode)
 typedef uint32_t k1_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ void k1_load8(const uint32_t* __restrict__ src, uint32_t* p) {
-  const k1_u32x4 a = *(const k1_u32x4*)src;
-  const k1_u32x4 b = *(const k1_u32x4*)(src + 4);
-  p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w; p[4] = b.x; p[5] = b.y; p[6] = b.z; p[7] = b.w;
+  k1_u32x4 v[K1_UNROLL / 4];
+#pragma unroll
+  for (int q = 0; q < K1_UNROLL / 4; q++) v[q] = *(const k1_u32x4*)(src + 4 * q);
+#pragma unroll
+  for (int q = 0; q < K1_UNROLL / 4; q++) { p[4 * q] = v[q].x; p[4 * q + 1] = v[q].y; p[4 * q + 2] = v[q].z; p[4 * q + 3] = v[q].w; }
 }
 __device__ __forceinline__ bool k1_has2(const uint32_t* bm, uint32_t rloc) {
   return (bm[rloc >> 4] >> ((rloc & 15u) * 2u + 1u)) & 1u;

@@ -386,6 +386,7 @@ __device__ FullOut full_sw_wave(const uint8_t* db, int glen, const uint8_t* qr, 
   return out;
 }
 
+template <bool BACK_LDS>
 __global__ void __launch_bounds__(GM_WAVE)
 k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words,
         const GmHit* __restrict__ hits, const uint16_t* __restrict__ perm, int hcap,
@@ -398,7 +399,8 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
   uint8_t* qr = sm;
   uint8_t* db = sm + ((read_len + 15) & ~15);
   int* carry = (int*)(db + ((max_w + 15) & ~15));
-  uint8_t* back = back_pool + (size_t)blockIdx.x * back_stride;
+  // back pointers: one byte per cell; in LDS when read_len x window fits (short reads), else in a per-wave global scratch
+  uint8_t* back = BACK_LDS ? (uint8_t*)(carry + 3 * max_w) : (back_pool + (size_t)blockIdx.x * back_stride);
   const uint32_t n_work = *n_work_p;
   unsigned long long vcalls = 0, vcells = 0, fcalls = 0;
   int cur_rd = -1;
@@ -459,7 +461,8 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
           uint8_t* o = ops + (size_t)R.ops_off;
           int no = 0, rstart = 0, gstart = 0, nm = 0, nmm = 0, nin = 0, ndel = 0;
           while (i >= 0 && j >= 0) {
-            const uint8_t bb = __hip_atomic_load(&back[(size_t)i * w_len + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint8_t bb = BACK_LDS ? back[(size_t)i * w_len + j]
+                                        : __hip_atomic_load(&back[(size_t)i * w_len + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!(bb & 0x80)) break;                // out-of-band cell: back == 0 in the reference
             int nstate;
             if (state == 1) {                       // FROM_NORTH_*: BACK_DELETION (gap in the genome)
@@ -622,9 +625,16 @@ int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
                     const uint32_t* d_work, const uint32_t* d_n_work, GmFullRes* d_res, uint8_t* d_ops, int ops_stride,
                     uint8_t* d_back, size_t back_stride, int grid, unsigned long long* d_stats, hipStream_t stream) {
   if (n_reads == 0) return GM_OK;
-  const size_t lds = ((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 12 + 64;
-  hipLaunchKernelGGL(k_pass2, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
-                     d_hits, d_perm, hcap, d_sel, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats);
+  size_t lds = ((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 12 + 64;
+  const size_t back_bytes = (size_t)read_len * window_len;
+  if (back_bytes <= 40 * 1024) {
+    lds += back_bytes + 16;
+    hipLaunchKernelGGL(k_pass2<true>, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
+                       d_hits, d_perm, hcap, d_sel, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats);
+  } else {
+    hipLaunchKernelGGL(k_pass2<false>, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
+                       d_hits, d_perm, hcap, d_sel, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats);
+  }
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

@@ -219,10 +219,14 @@ class Session:
         self.stats = st.as_dict()
         return out
 
-    def map_device(self, dev_ptr: int, n: int, read_len: int, emit_sam: bool = True):
+    def map_device(self, dev_ptr: int, n: int, read_len: int, emit_sam: bool = True, return_bytes: bool = True):
+        """Reads already resident in HBM (packed layout).  With return_bytes=False the SAM text is produced
+        in the library's buffer and released without a Python-side copy (returns its length)."""
         L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
         _check(L.gm_map_reads_device(self.h, n, read_len, C.c_void_p(dev_ptr), int(emit_sam), C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_reads_device")
-        out = C.string_at(sam, sl.value) if sam.value else b""
+        out = sl.value
+        if return_bytes:
+            out = C.string_at(sam, sl.value) if sam.value else b""
         if sam.value: L.gm_free(sam)
         self.stats = st.as_dict()
         return out
