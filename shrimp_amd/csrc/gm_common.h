@@ -35,6 +35,7 @@ struct GmSeedDev {
   int span, weight;
   const uint32_t* dir;
   const uint32_t* pos;
+  const uint32_t* bkt;   // optional [K][16]: list length + first 15 positions (small genomes; see gm_index.hip)
   uint32_t n_pos;
 };
 

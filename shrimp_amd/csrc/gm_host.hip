@@ -60,7 +60,7 @@ GmIndexDev GmIndexHost::dev_view() const {
   d.list_cutoff = list_cutoff;
   for (int i = 0; i < n_seeds; i++) {
     d.seed[i].mask = seeds[i].mask; d.seed[i].span = seeds[i].span; d.seed[i].weight = seeds[i].weight;
-    d.seed[i].dir = seeds[i].d_dir; d.seed[i].pos = seeds[i].d_pos; d.seed[i].n_pos = seeds[i].n_pos;
+    d.seed[i].dir = seeds[i].d_dir; d.seed[i].pos = seeds[i].d_pos; d.seed[i].bkt = seeds[i].d_bkt; d.seed[i].n_pos = seeds[i].n_pos;
   }
   return d;
 }
@@ -154,14 +154,14 @@ extern "C" void gm_index_free(gm_index_t* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
   (void)hipFree(ix->d_genome); (void)hipFree(ix->d_contig_off);
-  for (int i = 0; i < ix->n_seeds; i++) { (void)hipFree(ix->seeds[i].d_dir); (void)hipFree(ix->seeds[i].d_pos); }
+  for (int i = 0; i < ix->n_seeds; i++) { (void)hipFree(ix->seeds[i].d_dir); (void)hipFree(ix->seeds[i].d_pos); (void)hipFree(ix->seeds[i].d_bkt); }
   delete ix;
 }
 extern "C" uint32_t gm_index_list_cutoff(const gm_index_t* ix) { return ix->list_cutoff; }
 extern "C" int gm_index_n_slabs(const gm_index_t* ix) { return ix->n_slabs; }
 extern "C" uint64_t gm_index_bytes(const gm_index_t* ix) {
   uint64_t b = ix->genome_words * 4;
-  for (int i = 0; i < ix->n_seeds; i++) b += (ix->seeds[i].dir_words + (uint64_t)ix->seeds[i].n_pos) * 4;
+  for (int i = 0; i < ix->n_seeds; i++) b += (ix->seeds[i].dir_words + (uint64_t)ix->seeds[i].n_pos + (ix->seeds[i].d_bkt ? (16ull << (2 * ix->seeds[i].weight)) : 0ull)) * 4;
   return b;
 }
 extern "C" int gm_index_get_list(const gm_index_t* ix, int sn, uint32_t mapidx, uint32_t* len, uint32_t* positions, uint32_t cap) {
@@ -177,21 +177,22 @@ extern "C" int gm_index_get_list(const gm_index_t* ix, int sn, uint32_t mapidx, 
 }
 extern "C" int gm_index_device_array(const gm_index_t* ix, int kind, void** dev_ptr, uint64_t* bytes) {
   if (kind == 0) { *dev_ptr = ix->d_genome; *bytes = ix->genome_words * 4; return GM_OK; }
-  int sn = (kind - 1) / 2; if (sn < 0 || sn >= ix->n_seeds) return GM_E_ARG;
-  if ((kind - 1) % 2 == 0) { *dev_ptr = ix->seeds[sn].d_dir; *bytes = (ix->seeds[sn].dir_words + 16) * 4; }
-  else { *dev_ptr = ix->seeds[sn].d_pos; *bytes = ((uint64_t)ix->seeds[sn].n_pos + 64) * 4; }
+  const int sn = (kind - 1) / 3, what = (kind - 1) % 3; if (sn < 0 || sn >= ix->n_seeds) return GM_E_ARG;
+  if (what == 0) { *dev_ptr = ix->seeds[sn].d_dir; *bytes = (ix->seeds[sn].dir_words + 16) * 4; }
+  else if (what == 1) { *dev_ptr = ix->seeds[sn].d_pos; *bytes = ((uint64_t)ix->seeds[sn].n_pos + 64) * 4; }
+  else { *dev_ptr = ix->seeds[sn].d_bkt; *bytes = ix->seeds[sn].d_bkt ? (16ull << (2 * ix->seeds[sn].weight)) * 4 : 0; }
   return GM_OK;
 }
 
 // metadata blob: everything but the device arrays (fixed header + contig offsets + names + seed strings)
 struct MetaHdr { uint64_t magic, total_len, genome_words; int32_t n_contigs, n_seeds, slab_bits, n_slabs; uint32_t list_cutoff, pad; gm_params_t params;
-                 uint32_t n_pos[GM_MAX_SEEDS]; uint64_t dir_words[GM_MAX_SEEDS]; };
+                 uint32_t n_pos[GM_MAX_SEEDS]; uint64_t dir_words[GM_MAX_SEEDS]; uint32_t has_bkt[GM_MAX_SEEDS]; };
 extern "C" int gm_index_meta(const gm_index_t* ix, void* meta, uint64_t* meta_bytes) {
   std::string blob;
   MetaHdr h; memset(&h, 0, sizeof h);
   h.magic = 0x474D4958ull; h.total_len = ix->total_len; h.genome_words = ix->genome_words; h.n_contigs = ix->n_contigs; h.n_seeds = ix->n_seeds;
   h.slab_bits = ix->slab_bits; h.n_slabs = ix->n_slabs; h.list_cutoff = ix->list_cutoff; h.params = ix->params;
-  for (int i = 0; i < ix->n_seeds; i++) { h.n_pos[i] = ix->seeds[i].n_pos; h.dir_words[i] = ix->seeds[i].dir_words; }
+  for (int i = 0; i < ix->n_seeds; i++) { h.n_pos[i] = ix->seeds[i].n_pos; h.dir_words[i] = ix->seeds[i].dir_words; h.has_bkt[i] = ix->seeds[i].d_bkt != nullptr; }
   blob.append((const char*)&h, sizeof h);
   blob.append((const char*)ix->contig_off.data(), (size_t)(ix->n_contigs + 1) * 4);
   for (auto& n : ix->names) { blob += n; blob.push_back('\0'); }
@@ -220,6 +221,7 @@ extern "C" int gm_index_alloc_like(gm_index_t** out, int device, const void* met
     ix->seeds[i].n_pos = h.n_pos[i]; ix->seeds[i].dir_words = h.dir_words[i];
     GM_HIP(hipMalloc(&ix->seeds[i].d_dir, (h.dir_words[i] + 16) * 4));
     GM_HIP(hipMalloc(&ix->seeds[i].d_pos, ((uint64_t)h.n_pos[i] + 64) * 4));
+    if (h.has_bkt[i]) GM_HIP(hipMalloc(&ix->seeds[i].d_bkt, (16ull << (2 * ix->seeds[i].weight)) * 4));
   }
   *out = ix;
   return GM_OK;

@@ -66,6 +66,17 @@ __global__ void __launch_bounds__(256) k_build_dir(const uint32_t* __restrict__ 
   }
 }
 
+// bucket k = { list length, first min(len, 15) positions }: one 64-byte line per k-mer (S == 1 only)
+__global__ void __launch_bounds__(256) k_build_buckets(const uint32_t* __restrict__ dir, const uint32_t* __restrict__ pos, uint64_t K, uint32_t* __restrict__ bkt) {
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; t < K * 16; t += stride) {
+    const uint64_t k = t >> 4; const uint32_t w = (uint32_t)(t & 15);
+    const uint32_t b = dir[k], e = dir[k + 1];
+    bkt[t] = (w == 0) ? (e - b) : ((w - 1 < e - b) ? pos[b + w - 1] : 0xFFFFFFFFu);
+  }
+}
+
 int gm_index_build_device(GmIndexHost* ix, hipStream_t stream) {
   const uint64_t n = ix->total_len;
   uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_b = nullptr, *d_cnt = nullptr;
@@ -100,6 +111,11 @@ int gm_index_build_device(GmIndexHost* ix, hipStream_t stream) {
     GM_HIP(hipMemcpyAsync(sd.d_pos, vals_b, (size_t)n_valid * 4, hipMemcpyDeviceToDevice, stream));
     GM_HIP(hipMalloc(&sd.d_dir, (size_t)(KS + 1 + 16) * 4));
     hipLaunchKernelGGL(k_build_dir, dim3(grid), dim3(256), 0, stream, keys_b, vals_b, n_valid, ix->n_slabs, ix->slab_bits, KS, sd.d_dir);
+    // small genomes (one slab, short lists): add the 64-byte buckets so that a lookup is a single HBM sector
+    if (ix->n_slabs == 1 && (double)n_valid / (double)K <= 12.0 && !getenv("GM_NO_BUCKETS")) {
+      GM_HIP(hipMalloc(&sd.d_bkt, (size_t)K * 16 * 4));
+      hipLaunchKernelGGL(k_build_buckets, dim3(grid), dim3(256), 0, stream, sd.d_dir, sd.d_pos, K, sd.d_bkt);
+    }
     GM_HIP(hipStreamSynchronize(stream));
     sd.dir_words = KS + 1;
   }

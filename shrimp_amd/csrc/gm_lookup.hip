@@ -49,7 +49,8 @@ __device__ __forceinline__ bool k1_has2(const uint32_t* bm, uint32_t rloc) {
 }
 
 // dynamic LDS layout: codes[read_len pad 4] | kS[NL] | lbeg[NL] | lend[NL] | lo[NL] | hi[NL] | pre[NL+1] | bitmap[bm_words]
-__global__ void __launch_bounds__(K1_THREADS)
+template <bool BKT>
+__global__ void __launch_bounds__(256)
 k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
          int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
          uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap,
@@ -58,6 +59,7 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
   extern __shared__ __align__(16) uint32_t smem[];
   __shared__ K1Smem sh;
   const int tid = threadIdx.x;
+  const int nthr = blockDim.x;       // 256, or NL rounded up to a wave in bucket mode (one list per thread)
   // normal mode: block b = read-strand b, output slot surv[b*scap_all .. +scap_all).
   // redo mode (redo_list != 0): block b re-runs heavy read-strand redo_list[b] into surv[redo_off[b] .. redo_off[b+1])
   const bool redo = (redo_list != nullptr);
@@ -79,7 +81,7 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
 
   // ---- 0. read codes of this strand (strand 1 = reverse complement, ref: util.c:540-596) ----
   const uint32_t* rw = reads + (size_t)rd * read_words;
-  for (int i = tid; i < read_len; i += K1_THREADS) {
+  for (int i = tid; i < read_len; i += nthr) {
     int src = st ? (read_len - 1 - i) : i;
     uint32_t c = (rw[src >> 3] >> ((src & 7) * 4)) & 0xf;
     if (st) {   // complement_base, ref: util.h:125-151
@@ -92,8 +94,14 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
   __syncthreads();
 
   // ---- 1. map indexes + whole-list bounds (ref: mapping.c:53-66, KMER_TO_MAPIDX gmapper.h:349-368) ----
+  // BKT (small genomes, one slab, one list per thread): the probe is ONE 64-byte bucket per k-mer holding the
+  // list length and its first 15 positions, so a lookup costs one HBM sector instead of directory + list.
   unsigned long long my_lookups = 0, my_entries = 0;
-  for (int off = tid; off < NL; off += K1_THREADS) {
+  uint32_t bp[16];                        // BKT: bp[0] = list length, bp[1..15] = first positions (registers)
+  uint32_t blen = 0;                      // BKT: entries held in registers (0 when the list is long or skipped)
+#pragma unroll
+  for (int q = 0; q < 16; q++) bp[q] = 0;
+  for (int off = tid; off < NL; off += (BKT ? NL : nthr)) {     // bucket mode: exactly one list per thread
     const int sn = off / max_n_kmers, i = off - sn * max_n_kmers;
     uint32_t k = 0, b = 0, e = 0;
     const int span = ix.seed[sn].span;
@@ -103,11 +111,24 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
       for (int t = 0; t < span; t++)
         if ((mask >> t) & 1) mapidx = (mapidx << 2) | (codes[i + span - 1 - t] & 3u);
       k = mapidx * (uint32_t)S;
-      const uint32_t* dir = ix.seed[sn].dir;
-      b = dir[k]; e = dir[k + S];
       my_lookups++;
-      if (e - b > ix.list_cutoff) { b = 0; e = 0; }    // ref: mapping.c:497 (skipped, not deleted)
-      my_entries += (e - b);
+      if (BKT) {
+        const uint4* bk = (const uint4*)(ix.seed[sn].bkt + (size_t)mapidx * 16);
+        const uint4 q0 = bk[0], q1 = bk[1], q2 = bk[2], q3 = bk[3];
+        bp[0] = q0.x; bp[1] = q0.y; bp[2] = q0.z; bp[3] = q0.w; bp[4] = q1.x; bp[5] = q1.y; bp[6] = q1.z; bp[7] = q1.w;
+        bp[8] = q2.x; bp[9] = q2.y; bp[10] = q2.z; bp[11] = q2.w; bp[12] = q3.x; bp[13] = q3.y; bp[14] = q3.z; bp[15] = q3.w;
+        const uint32_t len = bp[0];
+        if (len <= ix.list_cutoff) {        // ref: mapping.c:497 (longer lists are skipped, not deleted)
+          my_entries += len;
+          if (len <= 15u) blen = len;
+          else { const uint32_t* dir = ix.seed[sn].dir; b = dir[k]; e = dir[k + 1]; }   // rare: stream the list itself
+        }
+      } else {
+        const uint32_t* dir = ix.seed[sn].dir;
+        b = dir[k]; e = dir[k + S];
+        if (e - b > ix.list_cutoff) { b = 0; e = 0; }    // ref: mapping.c:497 (skipped, not deleted)
+        my_entries += (e - b);
+      }
     }
     kS[off] = k; lbeg[off] = b; lend[off] = e;
   }
@@ -131,14 +152,23 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
     const uint32_t rend = (uint32_t)(E >> rb);
     {   // clear the region counters (16-byte stores)
       uint4* bm4 = (uint4*)bm; const int n4 = (ablate & 8) ? 0 : (bm_words >> 2);
-      for (int w = tid; w < n4; w += K1_THREADS) bm4[w] = make_uint4(0, 0, 0, 0);
-      for (int w = (n4 << 2) + tid; w < bm_words; w += K1_THREADS) bm[w] = 0;
+      for (int w = tid; w < n4; w += nthr) bm4[w] = make_uint4(0, 0, 0, 0);
+      for (int w = (n4 << 2) + tid; w < bm_words; w += nthr) bm[w] = 0;
     }
     if (tid == 0) sh.total = 0;
     __syncthreads();
     // -- phase 0: mark --
     bool any_long = false;
-    for (int off = tid; off < NL; off += K1_THREADS) {
+    if (BKT) {
+#pragma unroll
+      for (int u = 0; u < 15; u++)
+        if ((uint32_t)u < blen) {
+          const uint32_t pv = bp[u + 1]; const uint32_t reg = pv >> rb, rloc = reg - rbase + 1u;
+          k1_mark(bm, rloc);
+          if (((pv & rmask) < ovl) && reg > 0) k1_mark(bm, rloc - 1u);
+        }
+    }
+    for (int off = tid; off < NL; off += nthr) {
       uint32_t l = 0, h = 0, c = 0;
       const uint32_t lb = lbeg[off], le = lend[off];
       if (le > lb) {
@@ -195,9 +225,27 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
       total = sh.total;
     }
     for (int phase = 0; phase < 2; phase++) {
+      if (BKT && phase == 1) {
+        uint32_t alive = 0;                 // bit u: register entry u survives
+#pragma unroll
+        for (int u = 0; u < 15; u++)
+          if ((uint32_t)u < blen) {
+            const uint32_t pv = bp[u + 1]; const uint32_t reg = pv >> rb, rloc = reg - rbase + 1u;
+            const bool strip = ((pv & rmask) < ovl) && reg > 0;
+            if (k1_has2(bm, rloc) || (strip && k1_has2(bm, rloc - 1u))) alive |= 1u << u;
+          }
+        if (alive) {
+          const uint32_t cnt = __popc(alive);
+          uint32_t slot = atomicAdd(&sh.n_surv, cnt);
+          const uint32_t sn = (uint32_t)tid / (uint32_t)max_n_kmers, y = (uint32_t)tid - sn * (uint32_t)max_n_kmers;
+#pragma unroll
+          for (int u = 0; u < 15; u++)
+            if (alive & (1u << u)) { if (slot < scap) out[slot] = ((uint64_t)bp[u + 1] << 32) | ((uint64_t)y << 16) | sn; slot++; }
+        }
+      }
       if (phase == 1 && !(ablate & 1)) {
         // -- phase 1 (short slices): survival test, re-reading the slice from L1/L2 --
-        for (int off = tid; off < NL; off += K1_THREADS) {
+        for (int off = tid; off < NL; off += nthr) {
           const uint32_t l = lo[off], h = hi[off];
           if (h <= l || h - l > K1_SHORT) continue;
           const uint32_t* plist = ix.seed[off / max_n_kmers].pos;
@@ -215,7 +263,7 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
         }
       }
       // -- long slices, flattened over the workgroup (both phases) --
-      for (uint32_t e0 = 0; e0 < total; e0 += K1_THREADS) {
+      for (uint32_t e0 = 0; e0 < total; e0 += nthr) {
         const uint32_t e = e0 + tid;
         if (e < total) {
           // list of entry e: largest l with pre[l] <= e (pre non-decreasing; empty lists skipped by <=)
@@ -271,6 +319,119 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
   if ((tid & (GM_WAVE - 1)) == 0) { GS_ADD(stats, GS_LOOKUPS, my_lookups); GS_ADD(stats, GS_ENTRIES, my_entries); }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Bucket mode (small genomes: one slab, mean list length <= 12): one thread per k-mer of the read-strand.
+// The probe is ONE 64-byte bucket per k-mer = {list length, first 15 positions}, so a lookup costs one HBM
+// sector instead of directory + list, and both sweeps run out of registers.  Lists longer than 15 entries
+// (and <= the cutoff) are streamed from pos[] by their wave, 64 entries at a time.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512)
+k_lookup_bkt(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
+             int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
+             uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap,
+             unsigned long long* __restrict__ stats) {
+  extern __shared__ __align__(16) uint32_t smem[];
+  __shared__ uint32_t n_surv;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int rs = blockIdx.x, rd = rs >> 1, st = rs & 1;
+  uint8_t* codes = (uint8_t*)smem;
+  uint32_t* bm = smem + ((((read_len + 3) / 4) + 3) & ~3);
+  const int rb = ix.region_bits;
+  const uint32_t rmask = (1u << rb) - 1u, ovl = (uint32_t)ix.region_overlap;
+  uint64_t* out = surv + (size_t)rs * scap_all;
+  const uint32_t scap = (uint32_t)scap_all;
+  const uint32_t* rw = reads + (size_t)rd * read_words;
+  for (int i = tid; i < read_len; i += blockDim.x) {
+    int src = st ? (read_len - 1 - i) : i;
+    uint32_t c = (rw[src >> 3] >> ((src & 7) * 4)) & 0xf;
+    if (st) { const uint64_t cm = 0xFBCDE56879A00123ull; c = (uint32_t)(cm >> (c * 4)) & 0xf; }
+    codes[i] = (uint8_t)c;
+  }
+  { uint4* bm4 = (uint4*)bm; for (int w = tid; w < (bm_words >> 2); w += blockDim.x) bm4[w] = make_uint4(0, 0, 0, 0); }
+  if (tid == 0) n_surv = 0;
+  __syncthreads();
+  // my k-mer
+  const int sn = tid / max_n_kmers, i = tid - sn * max_n_kmers;
+  uint32_t len = 0, lb = 0; bool longl = false; uint32_t lookups = 0, y = (uint32_t)i;
+  uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+  const uint32_t* plist = nullptr;
+  if (tid < NL && i + ix.seed[sn].span <= read_len) {
+    const int span = ix.seed[sn].span; const uint64_t mask = ix.seed[sn].mask;
+    uint32_t mapidx = 0;
+    for (int t = 0; t < span; t++) if ((mask >> t) & 1) mapidx = (mapidx << 2) | (codes[i + span - 1 - t] & 3u);
+    const uint4* bk = (const uint4*)(ix.seed[sn].bkt + (size_t)mapidx * 16);
+    q0 = bk[0]; q1 = bk[1]; q2 = bk[2]; q3 = bk[3];
+    lookups = 1;
+    len = q0.x;
+    if (len > ix.list_cutoff) len = 0;                 // ref: mapping.c:497 (skipped, not deleted)
+    if (len > 15u) { longl = true; lb = ix.seed[sn].dir[mapidx]; plist = ix.seed[sn].pos; }
+  }
+  const uint32_t p[15] = {q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+  const uint32_t nreg = longl ? 0u : len;
+  // -- mark --
+#pragma unroll
+  for (int u = 0; u < 15; u++)
+    if ((uint32_t)u < nreg) {
+      const uint32_t reg = p[u] >> rb;
+      k1_mark(bm, reg + 1u);
+      if (((p[u] & rmask) < ovl) && reg > 0) k1_mark(bm, reg);
+    }
+  unsigned long long lm = __ballot(longl);
+  while (lm) {                                         // long lists of this wave, one at a time, 64 entries per step
+    const int l = __builtin_ctzll(lm); lm &= lm - 1;
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)lb, l), n = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
+    const uint32_t* pl = ix.seed[__builtin_amdgcn_readlane(sn, l)].pos;
+    for (uint32_t q = lane; q < n; q += 64) {
+      const uint32_t pv = pl[b + q]; const uint32_t reg = pv >> rb;
+      k1_mark(bm, reg + 1u);
+      if (((pv & rmask) < ovl) && reg > 0) k1_mark(bm, reg);
+    }
+  }
+  __syncthreads();
+  // -- test + emit --
+  uint32_t alive = 0;
+#pragma unroll
+  for (int u = 0; u < 15; u++)
+    if ((uint32_t)u < nreg) {
+      const uint32_t reg = p[u] >> rb;
+      const bool strip = ((p[u] & rmask) < ovl) && reg > 0;
+      if (k1_has2(bm, reg + 1u) || (strip && k1_has2(bm, reg))) alive |= 1u << u;
+    }
+  if (alive) {
+    uint32_t slot = atomicAdd(&n_surv, (uint32_t)__popc(alive));
+#pragma unroll
+    for (int u = 0; u < 15; u++)
+      if (alive & (1u << u)) { if (slot < scap) out[slot] = ((uint64_t)p[u] << 32) | ((uint64_t)y << 16) | (uint32_t)sn; slot++; }
+  }
+  lm = __ballot(longl);
+  while (lm) {
+    const int l = __builtin_ctzll(lm); lm &= lm - 1;
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)lb, l), n = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
+    const int lsn = __builtin_amdgcn_readlane(sn, l); const uint32_t ly = (uint32_t)__builtin_amdgcn_readlane((int)y, l);
+    const uint32_t* pl = ix.seed[lsn].pos;
+    for (uint32_t q = lane; q < n; q += 64) {
+      const uint32_t pv = pl[b + q]; const uint32_t reg = pv >> rb;
+      const bool strip = ((pv & rmask) < ovl) && reg > 0;
+      if (k1_has2(bm, reg + 1u) || (strip && k1_has2(bm, reg))) {
+        const uint32_t slot = atomicAdd(&n_surv, 1u);
+        if (slot < scap) out[slot] = ((uint64_t)pv << 32) | ((uint64_t)ly << 16) | (uint32_t)lsn;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    surv_cnt[rs] = n_surv;
+    GS_ADD(stats, GS_SURVIVORS, n_surv);
+    if (n_surv > scap) {
+      const uint32_t hs = atomicAdd(heavy_cnt, 1u);
+      if (hs < (uint32_t)heavy_cap) heavy_list[hs] = (uint32_t)rs; else GS_ADD(stats, GS_OVERFLOW_SURV, 1ull);
+    }
+  }
+  unsigned long long lk = lookups, en = len;
+  for (int d = GM_WAVE / 2; d > 0; d >>= 1) { lk += __shfl_down(lk, d); en += __shfl_down(en, d); }
+  if (lane == 0) { GS_ADD(stats, GS_LOOKUPS, lk); GS_ADD(stats, GS_ENTRIES, en); }
+}
+
 static void k1_geometry(const GmIndexDev& ix, int read_len, int* max_n_kmers, int* NL, int* bm_words, size_t* lds) {
   *max_n_kmers = read_len - ix.min_seed_span + 1;
   if (*max_n_kmers < 0) *max_n_kmers = 0;
@@ -296,10 +457,16 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
   if (NL == 0 || n_reads == 0) { GM_HIP(hipMemsetAsync(d_surv_cnt, 0, (size_t)n_reads * 2 * 4, stream)); return GM_OK; }
   static size_t configured = 0;
   if (lds > 48 * 1024 && lds > configured) {
-    GM_HIP(hipFuncSetAttribute((const void*)k_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GM_HIP(hipFuncSetAttribute((const void*)k_lookup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = lds;
   }
-  hipLaunchKernelGGL(k_lookup, dim3(n_reads * 2), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+  const bool bkt = ix.seed[0].bkt != nullptr && ix.n_slabs == 1 && NL <= 512 && !getenv("GM_NO_BUCKETS");
+  if (bkt) {
+    const size_t lds_b = (size_t)((((read_len + 3) / 4) + 3) & ~3) * 4 + (size_t)bm_words * 4;
+    hipLaunchKernelGGL(k_lookup_bkt, dim3(n_reads * 2), dim3((NL + 63) & ~63), lds_b, stream, ix, d_reads, n_reads, read_len, read_words,
+                       max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats);
+  } else
+  hipLaunchKernelGGL(k_lookup<false>, dim3(n_reads * 2), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
                      max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
                      (const uint32_t*)nullptr, (const uint64_t*)nullptr, d_stats, getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0);
   GM_HIP(hipGetLastError());
@@ -313,7 +480,7 @@ int gm_launch_lookup_redo(const GmIndexDev& ix, const uint32_t* d_reads, int n_r
   int max_n_kmers, NL, bm_words; size_t lds;
   k1_geometry(ix, read_len, &max_n_kmers, &NL, &bm_words, &lds);
   if (n_heavy == 0) return GM_OK;
-  hipLaunchKernelGGL(k_lookup, dim3(n_heavy), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+  hipLaunchKernelGGL(k_lookup<false>, dim3(n_heavy), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
                      max_n_kmers, NL, bm_words, d_out, (uint32_t*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0,
                      d_redo_list, d_redo_off, d_stats, 0);
   GM_HIP(hipGetLastError());

@@ -42,6 +42,8 @@ def broadcast_index(index, rank: int, device, src: int = 0, chunk_bytes: int = 1
     if rank != src:
         index = gm.Index.alloc_like(meta[0], device=device.index if hasattr(device, "index") else int(device))
     for ptr, nb in index.device_arrays():
+        if not nb or not ptr:
+            continue
         t = torch.as_tensor(_DevArray(ptr, nb), device=device)
         for o in range(0, nb, chunk_bytes):
             dist.broadcast(t[o:o + chunk_bytes], src=src)
