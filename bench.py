@@ -118,8 +118,19 @@ def main():
     if rank == 0:
         # dominant kernel = seed lookup (k_lookup): algorithmic bytes / its own HIP-event time
         ach = (lk_bytes / 1e9) / (lk_ms / 1e3) if lk_ms > 0 else 0.0
+        kname = "k_lookup_bkt" if ix.has_buckets else "k_lookup"
+        # HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, profiles/traffic.json),
+        # valid only for the workload / sub-batch they were measured on
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            t = tj.get("%s/%s/%d" % (args.workload, kname, min(R, int(os.environ.get("GM_SUBBATCH", "131072")))))
+            if t and args.scale == 1.0:
+                traffic = t["bytes_per_launch"]
+        except Exception:
+            pass
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                           "traffic": None, "kernel": "k_lookup", "launches": lk_launch,
+                           "traffic": traffic, "kernel": kname, "launches": lk_launch,
                            "avg_launch_ms": lk_ms / max(1, lk_launch), "alg_bytes_per_launch": lk_bytes / max(1, lk_launch)}
         out["stages_ms_per_step"] = {k: agg[k] / args.steps for k in agg if k.startswith("ms_")}
         out["per_read"] = {"lookups": agg["lookups"] / (R * args.steps), "list_entries": agg["list_entries"] / (R * args.steps),

@@ -80,6 +80,7 @@ void gm_index_free(gm_index_t *ix);
 uint32_t gm_index_list_cutoff(const gm_index_t *ix);
 uint64_t gm_index_bytes(const gm_index_t *ix);
 int      gm_index_n_slabs(const gm_index_t *ix);
+int      gm_index_has_buckets(const gm_index_t *ix);   /* 1 when the 64-byte bucket layout is resident (small genomes) */
 /* genomemap_len[sn][mapidx] / genomemap[sn][mapidx][0..len) copied back to the host (tests) */
 int gm_index_get_list(const gm_index_t *ix, int sn, uint32_t mapidx, uint32_t *len, uint32_t *positions, uint32_t cap);
 /* raw device pointers + sizes of the resident arrays, for the single RCCL broadcast at start-up

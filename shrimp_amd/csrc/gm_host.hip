@@ -159,6 +159,7 @@ extern "C" void gm_index_free(gm_index_t* ix) {
 }
 extern "C" uint32_t gm_index_list_cutoff(const gm_index_t* ix) { return ix->list_cutoff; }
 extern "C" int gm_index_n_slabs(const gm_index_t* ix) { return ix->n_slabs; }
+extern "C" int gm_index_has_buckets(const gm_index_t* ix) { return ix->seeds[0].d_bkt != nullptr; }
 extern "C" uint64_t gm_index_bytes(const gm_index_t* ix) {
   uint64_t b = ix->genome_words * 4;
   for (int i = 0; i < ix->n_seeds; i++) b += (ix->seeds[i].dir_words + (uint64_t)ix->seeds[i].n_pos + (ix->seeds[i].d_bkt ? (16ull << (2 * ix->seeds[i].weight)) : 0ull)) * 4;

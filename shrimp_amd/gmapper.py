@@ -55,7 +55,7 @@ class SwFullResults(C.Structure):
 
 # every entry point include/gmapper_hip.h declares
 EXPORTS = ["gm_last_error", "gm_device_count", "gm_params_default", "gm_index_build", "gm_index_free", "gm_index_list_cutoff",
-           "gm_index_bytes", "gm_index_n_slabs", "gm_index_get_list", "gm_index_device_array", "gm_index_meta", "gm_index_alloc_like",
+           "gm_index_bytes", "gm_index_n_slabs", "gm_index_has_buckets", "gm_index_get_list", "gm_index_device_array", "gm_index_meta", "gm_index_alloc_like",
            "sw_vector_setup", "sw_vector", "sw_vector_stats", "sw_vector_cleanup", "gm_sw_vector_batch",
            "sw_full_ls_setup", "sw_full_ls", "sw_full_ls_cleanup",
            "gm_session_create", "gm_session_free", "gm_map_reads", "gm_map_reads_device", "gm_free", "gm_debug_tophits",
@@ -81,6 +81,7 @@ def lib():
     L.gm_index_list_cutoff.argtypes = [vp]; L.gm_index_list_cutoff.restype = C.c_uint32
     L.gm_index_bytes.argtypes = [vp]; L.gm_index_bytes.restype = C.c_uint64
     L.gm_index_n_slabs.argtypes = [vp]; L.gm_index_n_slabs.restype = C.c_int
+    L.gm_index_has_buckets.argtypes = [vp]; L.gm_index_has_buckets.restype = C.c_int
     L.gm_index_get_list.argtypes = [vp, C.c_int, C.c_uint32, u32p, u32p, C.c_uint32]
     L.gm_index_device_array.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.gm_index_meta.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
@@ -147,6 +148,8 @@ class Index:
     def nbytes(self): return lib().gm_index_bytes(self.h)
     @property
     def n_slabs(self): return lib().gm_index_n_slabs(self.h)
+    @property
+    def has_buckets(self): return bool(lib().gm_index_has_buckets(self.h))
 
     def get_list(self, sn: int, mapidx: int) -> np.ndarray:
         L = lib(); n = C.c_uint32()
