@@ -93,6 +93,11 @@ struct Params {
   double score_alpha = 0, score_beta = 0;
   std::vector<Seed> seeds;
   int max_seed_span = 0, min_seed_span = 64;
+  // pairing (gmapper/gmapper.h:138-151, gmapper-defaults.h:25-29)
+  int pair_mode = 0;               // 0 none, 1 opp-in, 2 opp-out, 3 col-fw, 4 col-bw
+  int min_insert_size = 0, max_insert_size = 1000;
+  double insert_size_mean = 200, insert_size_stddev = 100;
+  bool half_paired = true;
 };
 
 #define GMO_IS_ABSOLUTE(x) ((x) < 0)
@@ -333,7 +338,7 @@ struct SwFullResults {
   int posterior_score = 0, pct_posterior_score = 0;
   std::string dbalign, qralign;
   double posterior = 0;
-  int mqv = 255; double z0 = 0, z1 = 0;
+  int mqv = 255; double z0 = 0, z1 = 0, z2 = 0, z3 = 0, pr_top_random_at_location = 0, pr_missed_mp = 0, insert_size_denom = 0;
   std::string ops;   // backtrace ops in alignment order: 'M' match/mismatch, 'I' BACK_INSERTION (gap in read), 'D' BACK_DELETION (gap in genome)
 };
 
@@ -484,6 +489,8 @@ struct Hit {                       // struct read_hit, gmapper-definitions.h:131
   double pct_score_full = 0;
   int pass1_key = 0, pass2_key = 0, score_max = 0, matches = 0, cn = 0, w_len = 0, st = 0, gen_st = 0;
   int saved = 0, sort_idx = 0;
+  int pair_min = -1, pair_max = -1;
+  std::vector<int> paired_hit_idx;
   bool has_sfr = false;
   SwFullResults sfr;
 };
@@ -495,12 +502,15 @@ struct Read {
   std::vector<uint32_t> mapidx[2];
   std::vector<Anchor> anchors[2];
   std::vector<Hit> hits[2];
+  bool paired = false, first_in_pair = false; Read* mate_pair = nullptr;
+  int delta_g_off_min[2] = {0, 0}, delta_g_off_max[2] = {0, 0};
+  std::vector<Hit> final_unpaired_hits; bool mapped = false;
 };
 
 struct Stats { uint64_t vec_calls = 0, vec_cells = 0, vec_bypassed = 0, full_calls = 0, full_cells = 0, reads_matched = 0, dup_pruned = 0; };
 
 struct ThreadState {               // the reference's threadprivate state
-  std::vector<uint16_t> region_map[2];          // region_map[0][st] (number_in_pair 0)
+  std::vector<uint16_t> region_map[2][2];       // region_map[number_in_pair][st]
   int region_map_id = 0;
   std::vector<uint32_t> f1_tag, f1_score;       // f1_window_cache (common/f1-wrapper.h:27-37)
   uint32_t f1_hash_tag = 0;
@@ -515,7 +525,7 @@ struct Mapper {
 
   void init_thread(ThreadState& T) const {
     int n_regions = 1 << (32 - P.region_bits);
-    for (int st = 0; st < 2; st++) T.region_map[st].assign(n_regions, 0);
+    for (int nip = 0; nip < 2; nip++) for (int st = 0; st < 2; st++) T.region_map[nip][st].assign(n_regions, 0);
     T.region_map_id = 0;
     T.f1_tag.assign(f1_window_cache_size, 0); T.f1_score.assign(f1_window_cache_size, 0);
     T.f1_hash_tag = 0;
@@ -554,9 +564,9 @@ struct Mapper {
   void read_get_region_counts(ThreadState& T, Read& re, int st) const {
     if (T.region_map_id == 0) {   // mapping.c:471-487: id wrapped -> fresh maps
       T.region_map_id = 1;
-      for (int s = 0; s < 2; s++) std::fill(T.region_map[s].begin(), T.region_map[s].end(), 0);
+      for (int nip = 0; nip < 2; nip++) for (int s = 0; s < 2; s++) std::fill(T.region_map[nip][s].begin(), T.region_map[nip][s].end(), 0);
     }
-    uint16_t* rm = T.region_map[st].data();
+    uint16_t* rm = T.region_map[re.first_in_pair || !re.paired ? 0 : 1][st].data();
     auto mark = [&](int region) {
       if ((rm[region] >> 3) == T.region_map_id) rm[region] |= 0x1;
       else rm[region] = (uint16_t)((T.region_map_id << 3) + 0x6);
@@ -599,8 +609,8 @@ struct Mapper {
   };
 
   // advance_index_in_genomemap (mapping.c:646-805), unpaired branch (use_mp_region_counts == 0)
-  void advance_index(const ThreadState& T, int st, uint32_t* idx, uint32_t max_idx, const uint32_t* map) const {
-    const uint16_t* rm = T.region_map[st].data();
+  void advance_index(const ThreadState& T, int nip, int st, uint32_t* idx, uint32_t max_idx, const uint32_t* map) const {
+    const uint16_t* rm = T.region_map[nip][st].data();
     while (*idx < max_idx) {
       int region = (int)(map[*idx] >> P.region_bits);
       if (rm[region] & 0x1) break;
@@ -615,7 +625,9 @@ struct Mapper {
   // read_get_anchor_list_per_strand (mapping.c:861-1006), collapse = true, use_region_counts = (match_mode == 2)
   void read_get_anchor_list(const ThreadState& T, Read& re, int st) const {
     int ns = (int)P.seeds.size();
-    bool use_region_counts = (P.match_mode == 2);
+    // unpaired: use_region_counts = (match_mode == 2) (gmapper.c:2615); paired default (mode 4, half-paired): true, no mp counts (:2652-2660)
+    bool use_region_counts = re.paired ? true : (P.match_mode == 2);
+    const int nip = (re.first_in_pair || !re.paired) ? 0 : 1;
     re.anchors[st].clear();
     if (re.mapidx[st].empty()) return;
     HeapUU h; h.a.resize((size_t)ns * re.max_n_kmers + 1);
@@ -627,7 +639,7 @@ struct Mapper {
         uint32_t mi = re.mapidx[st][off];
         uint32_t len = I->list_len(sn, mi); const uint32_t* l = I->list(sn, mi);
         if (len > P.list_cutoff) idx[off] = len;
-        if (use_region_counts) advance_index(T, st, &idx[off], len, l);
+        if (use_region_counts) advance_index(T, nip, st, &idx[off], len, l);
         if (idx[off] < len) { h.insert({l[idx[off]], off}); idx[off]++; }
       }
     std::vector<Anchor>& A = re.anchors[st];
@@ -646,7 +658,7 @@ struct Mapper {
       }
       uint32_t mi = re.mapidx[st][off];
       uint32_t len = I->list_len(sn, mi); const uint32_t* l = I->list(sn, mi);
-      if (use_region_counts) advance_index(T, st, &idx[off], len, l);
+      if (use_region_counts) advance_index(T, nip, st, &idx[off], len, l);
       if (idx[off] < len) { h.replace_min({l[idx[off]], off}); idx[off]++; }
       else h.extract_min();
     }
@@ -725,10 +737,11 @@ struct Mapper {
   }
 
   // read_pass1_per_strand (mapping.c:1261-1339), letter space, only_paired = false
-  void read_pass1(ThreadState& T, Read& re, int st) const {
+  void read_pass1(ThreadState& T, Read& re, int st, bool only_paired = false) const {
     int last_good_cn = -1; unsigned int last_good_g_off = 0;
     T.f1_hash_tag++;
     for (auto& h : re.hits[st]) {
+      if (only_paired && h.pair_min < 0) continue;                 // mapping.c:1271-1273
       if (h.matches < P.match_mode) continue;  // pass1.min_matches = match_mode (gmapper.c:2625)
       if (h.saved == 1) { last_good_cn = h.cn; last_good_g_off = (unsigned int)h.g_off_pos_strand; continue; }
       if (last_good_cn >= 0 && h.cn == last_good_cn &&
@@ -957,6 +970,444 @@ struct Mapper {
       }
     }
     for (auto* h : p2) hit_output(re, h, out);
+  }
+
+  // =============================================================================================
+  // Paired mode (default option sets: match_mode 4, half-paired, mapping qualities on;
+  // gmapper.c:2636-2720).  All of it follows gmapper/mapping.c:266-325,405-456,1871-2636 and
+  // gmapper/output.c:795-942,1070-1291.
+  // =============================================================================================
+  struct HitPair {                  // struct read_hit_pair, gmapper-definitions.h:162-173
+    Hit* rh[2] = {nullptr, nullptr}; int rh_idx[2] = {-1, -1};
+    int score_max = 0, score = 0, pct_score = 0, key = 0, insert_size = 0; bool improper_mapping = false;
+  };
+  struct PairEntry {                // pair_entry, gmapper-definitions.h:186-193
+    Read* re[2]; std::vector<Hit> pool[2]; std::vector<HitPair> final_paired_hits; bool mapped = false;
+  };
+
+  // readpair_compute_mp_ranges (mapping.c:2317-2442); only the delta_g_off part is used without mp region counts
+  void readpair_compute_mp_ranges(Read& re1, Read& re2) const {
+    const int mn = P.min_insert_size, mx = P.max_insert_size;
+    int a = mn - re2.window_len, b = mx + (re1.window_len - re1.read_len) - re2.read_len;
+    int c = -mx + re1.read_len + (re2.read_len - re2.window_len), d = -mn + re1.window_len;
+    switch (P.pair_mode) {
+      case 1: break;
+      case 2: a += re1.read_len + re2.read_len; b += re1.read_len + re2.read_len; c -= re1.read_len + re2.read_len; d -= re1.read_len + re2.read_len; break;
+      case 3: a += re2.read_len; b += re2.read_len; c -= re2.read_len; d -= re2.read_len; break;
+      case 4: a += re1.read_len; b += re1.read_len; c -= re1.read_len; d -= re1.read_len; break;
+      default: assert(0);
+    }
+    re1.delta_g_off_min[0] = a; re1.delta_g_off_max[0] = b; re1.delta_g_off_min[1] = c; re1.delta_g_off_max[1] = d;
+    if (P.pair_mode == 1 || P.pair_mode == 2) {
+      re2.delta_g_off_min[0] = -d; re2.delta_g_off_max[0] = -c; re2.delta_g_off_min[1] = -b; re2.delta_g_off_max[1] = -a;
+    } else {
+      re2.delta_g_off_min[0] = -b; re2.delta_g_off_max[0] = -a; re2.delta_g_off_min[1] = -d; re2.delta_g_off_max[1] = -c;
+    }
+  }
+
+  // readpair_pair_up_hits (mapping.c:266-325)
+  void readpair_pair_up_hits(Read& re1, Read& re2) const {
+    for (int st1 = 0; st1 < 2; st1++) {
+      int st2 = 1 - st1;
+      int j = 0;
+      auto& H1 = re1.hits[st1]; auto& H2 = re2.hits[st2];
+      for (int i = 0; i < (int)H1.size(); i++) {
+        while (j < (int)H2.size() && (H2[j].cn < H1[i].cn ||
+               (H2[j].cn == H1[i].cn && (int64_t)H2[j].g_off < (int64_t)H1[i].g_off + (int64_t)re1.delta_g_off_min[st1]))) j++;
+        int k = j;
+        while (k < (int)H2.size() && H2[k].cn == H1[i].cn && (int64_t)H2[k].g_off <= (int64_t)H1[i].g_off + (int64_t)re1.delta_g_off_max[st1]) k++;
+        if (j == k) continue;
+        H1[i].pair_min = j; H1[i].pair_max = k - 1;
+        for (int l = j; l < k; l++) { if (H2[l].pair_min < 0) H2[l].pair_min = i; H2[l].pair_max = i; }
+      }
+    }
+  }
+
+  static void xhp_up(std::vector<HitPair>& a, int node) {
+    int parent = node / 2;
+    while (node > 1 && a[node - 1].key < a[parent - 1].key) { std::swap(a[parent - 1], a[node - 1]); node = parent; parent = node / 2; }
+  }
+  static void xhp_down(std::vector<HitPair>& a, int load, int node) {
+    for (;;) {
+      int left = node * 2, right = left + 1, mn = node;
+      if (left <= load && a[left - 1].key < a[node - 1].key) mn = left;
+      if (right <= load && a[right - 1].key < a[mn - 1].key) mn = right;
+      if (mn == node) break;
+      std::swap(a[mn - 1], a[node - 1]); node = mn;
+    }
+  }
+
+  // readpair_get_vector_hits (mapping.c:1877-1932)
+  void readpair_get_vector_hits(Read& re1, Read& re2, std::vector<HitPair>& a, int& load) const {
+    a.assign(P.num_tmp_outputs, HitPair()); load = 0;
+    const bool absthr = GMO_IS_ABSOLUTE(P.sw_vect_threshold);
+    for (int st1 = 0; st1 < 2; st1++) {
+      int st2 = 1 - st1;
+      for (auto& h1 : re1.hits[st1]) {
+        if (h1.saved == 1) continue;
+        if (h1.pair_min < 0) continue;
+        for (int j = h1.pair_min; j <= h1.pair_max; j++) {
+          Hit& h2 = re2.hits[st2][j];
+          if (h2.saved == 1) continue;
+          HitPair tmp;
+          tmp.score = h1.score_vector + h2.score_vector;
+          tmp.score_max = h1.score_max + h2.score_max;
+          tmp.pct_score = (1000 * 100 * tmp.score) / tmp.score_max;
+          tmp.key = absthr ? tmp.score : tmp.pct_score;
+          if (tmp.score >= (int)GMO_ABS_OR_PCT(P.sw_vect_threshold, tmp.score_max) && (load < P.num_tmp_outputs || tmp.key > a[0].key)) {
+            tmp.rh[0] = &h1; tmp.rh[1] = &h2;
+            tmp.insert_size = (int)(st1 == 0 ? h2.g_off - (h1.g_off + h1.w_len) : h1.g_off - (h2.g_off + h2.w_len));
+            if (load < P.num_tmp_outputs) { a[load] = tmp; load++; xhp_up(a, load); }
+            else { a[0] = tmp; xhp_down(a, load, 1); }
+          }
+        }
+      }
+    }
+  }
+
+  // get_insert_size (mapping.c:405-456)
+  int get_insert_size(const Hit* rh, const Hit* rh_mp) const {
+    if (rh_mp == nullptr || rh == nullptr || rh->cn != rh_mp->cn) return 0;
+    auto ends = [&](const Hit* h, int* gstart, int* gend) {
+      int read_start = h->sfr.read_start + 1, read_end = read_start + h->sfr.rmapped - 1;
+      int glen = (int)G->len[h->cn];
+      if (h->gen_st != 1) *gstart = h->sfr.genome_start + 1;
+      else *gstart = (glen - h->sfr.genome_start) - (read_end - read_start - h->sfr.deletions + h->sfr.insertions);
+      *gend = *gstart + h->sfr.gmapped - 1;
+    };
+    int gs_mp, ge_mp, gs, ge; ends(rh_mp, &gs_mp, &ge_mp); ends(rh, &gs, &ge);
+    int fivep = (rh->gen_st == 1) ? ge : gs - 1;
+    int fivep_mp = (rh_mp->gen_st == 1) ? ge_mp : gs_mp - 1;
+    return fivep_mp - fivep;
+  }
+
+  // readpair_compute_paired_hit (mapping.c:2053-2080)
+  void readpair_compute_paired_hit(Hit* rh1, Hit* rh2, bool absthr, HitPair* dest) const {
+    dest->rh[0] = rh1; dest->rh[1] = rh2;
+    dest->score_max = rh1->score_max + rh2->score_max;
+    dest->score = rh1->score_full + rh2->score_full;
+    dest->pct_score = (1000 * 100 * dest->score) / dest->score_max;
+    dest->key = absthr ? dest->score : dest->pct_score;
+    int ins_sz = get_insert_size(rh1, rh2);
+    int sign;
+    if (P.pair_mode == 1 || P.pair_mode == 3) sign = (rh1->gen_st == 0) ? +1 : -1;
+    else sign = (rh1->gen_st == 1) ? +1 : -1;
+    dest->insert_size = sign * ins_sz;
+    dest->improper_mapping = false;
+  }
+
+  // readpair_push_dominant_single_hits (mapping.c:2083-2110)
+  template <class Cmp>
+  void push_dominant(std::vector<HitPair>& v, bool absthr, int nip, Cmp cmp) const {
+    std::stable_sort(v.begin(), v.end(), [&](const HitPair& a, const HitPair& b) { return cmp(a, b) < 0; });
+    size_t i = 0, n = v.size();
+    while (i < n) {
+      int mx = v[i].rh[nip]->score_full; size_t mi = i, j = i + 1;
+      while (j < n && !cmp(v[i], v[j])) { if (v[j].rh[nip]->score_full > mx) { mx = v[j].rh[nip]->score_full; mi = j; } j++; }
+      for (size_t k = i; k < j; k++)
+        if (k != mi) { v[k].rh[nip] = v[mi].rh[nip]; readpair_compute_paired_hit(v[k].rh[0], v[k].rh[1], absthr, &v[k]); }
+      i = j;
+    }
+  }
+  static int pair_pointer_cmp(const HitPair& a, const HitPair& b) {   // pass2_readpair_pointer_cmp (mapping.c:2004-2050), non-NULL case
+    if (a.rh[0]->sort_idx != b.rh[0]->sort_idx) return a.rh[0]->sort_idx - b.rh[0]->sort_idx;
+    return a.rh[1]->sort_idx - b.rh[1]->sort_idx;
+  }
+
+  // readpair_pass2 (mapping.c:2181-2314)
+  void readpair_pass2(ThreadState& T, Read& re1, Read& re2, std::vector<HitPair>& p1, int n1, std::vector<HitPair>& p2) const {
+    p2.clear();
+    const bool absthr = GMO_IS_ABSOLUTE(P.sw_full_threshold);
+    const double mate_thres = P.sw_full_threshold * 0.5;                     // gmapper.c:2677
+    for (int i = 0; i < n1; i++) {
+      for (int j = 0; j < 2; j++) {
+        Hit* rh = p1[i].rh[j]; Read& re = (j == 0 ? re1 : re2);
+        if (rh->score_full < 0 || !rh->has_sfr) {
+          hit_run_full_sw(T, re, *rh, (int)GMO_ABS_OR_PCT(mate_thres, rh->score_max));
+          if (P.compute_mapping_qualities && rh->score_full > 0) hit_run_post_sw(*rh);
+        }
+      }
+      if (p1[i].rh[0]->score_full == 0 || p1[i].rh[1]->score_full == 0) continue;
+      if (p1[i].rh[0]->score_full + p1[i].rh[1]->score_full >= (int)GMO_ABS_OR_PCT(P.sw_full_threshold, p1[i].score_max)) {
+        HitPair hp; readpair_compute_paired_hit(p1[i].rh[0], p1[i].rh[1], absthr, &hp); p2.push_back(hp);
+      }
+    }
+    // readpair_remove_duplicate_hits (mapping.c:2113-2175)
+    push_dominant(p2, absthr, 0, [](const HitPair& a, const HitPair& b) { return cmp_gen_start(a.rh[0], b.rh[0]); });
+    push_dominant(p2, absthr, 0, [](const HitPair& a, const HitPair& b) { return cmp_gen_end(a.rh[0], b.rh[0]); });
+    push_dominant(p2, absthr, 1, [](const HitPair& a, const HitPair& b) { return cmp_gen_start(a.rh[1], b.rh[1]); });
+    push_dominant(p2, absthr, 1, [](const HitPair& a, const HitPair& b) { return cmp_gen_end(a.rh[1], b.rh[1]); });
+    std::stable_sort(p2.begin(), p2.end(), [](const HitPair& a, const HitPair& b) { return pair_pointer_cmp(a, b) < 0; });
+    { size_t m = 0, i = 0, n = p2.size();                                  // removedups (common/util.c:1240-1255)
+      while (i < n) { size_t j = i + 1; while (j < n && !pair_pointer_cmp(p2[i], p2[j])) j++; if (m < i) p2[m] = p2[i]; m++; i = j; }
+      p2.resize(m); }
+    std::stable_sort(p2.begin(), p2.end(), [](const HitPair& a, const HitPair& b) { return (b.key - a.key) < 0; });
+    if ((int)p2.size() > P.num_outputs) p2.resize(P.num_outputs);
+    if (P.strata && !p2.empty()) { size_t i = 1; while (i < p2.size() && p2[0].score == p2[i].score) i++; p2.resize(i); }
+    if (!p2.empty() && !(P.max_alignments == 0 || (int)p2.size() <= P.max_alignments)) p2.clear();
+    for (auto& hp : p2) { hp.rh[0]->saved = 1; hp.rh[1]->saved = 1; }
+  }
+
+  // readpair_save_final_hits (mapping.c:2446-2499): pool order = first appearance; paired_hit_idx in increasing pair index
+  void readpair_save_final_hits(PairEntry& pe, std::vector<HitPair>& p2) const {
+    size_t base = pe.final_paired_hits.size();
+    pe.final_paired_hits.insert(pe.final_paired_hits.end(), p2.begin(), p2.end());
+    for (size_t i = 0; i < p2.size(); i++)
+      for (int nip = 0; nip < 2; nip++) {
+        if (pe.final_paired_hits[base + i].rh[nip] != nullptr) {
+          pe.pool[nip].push_back(*pe.final_paired_hits[base + i].rh[nip]);
+          int pidx = (int)pe.pool[nip].size() - 1;
+          for (size_t j = i; j < p2.size(); j++) {
+            HitPair& hp = pe.final_paired_hits[base + j];
+            if (hp.rh[nip] == p2[i].rh[nip]) { hp.rh[nip] = nullptr; hp.rh_idx[nip] = pidx; pe.pool[nip][pidx].paired_hit_idx.push_back((int)(base + j)); }
+          }
+        }
+      }
+  }
+
+  // handle_read as the half-paired fall-back (unpaired_mapping_options[nip][0], gmapper.c:2700-2714):
+  // regions / anchors / windows are reused, pass 1 re-runs over all windows, results are saved, not printed
+  void handle_read_half(ThreadState& T, Read& re) const {
+    read_pass1(T, re, 0, false); read_pass1(T, re, 1, false);
+    std::vector<Hit*> p1, p2; int n1 = 0;
+    read_get_vector_hits(re, p1, n1);
+    read_pass2(T, re, p1, n1, p2);
+    if (!p2.empty()) { for (auto* h : p2) re.final_unpaired_hits.push_back(*h); re.mapped = true; }   // read_save_final_hits (mapping.c:1753-1770)
+  }
+
+  static double normal_cdf(double x, double mean, double stddev) {            // common/util.h:311-326
+    double y = (x - mean) / stddev; if (y < 0) y = -y;
+    double b0 = 0.2316419, b1 = 0.319381530, b2 = -0.356563782, b3 = 1.781477937, b4 = -1.821255978, b5 = 1.330274429, pi = 3.141592653589;
+    double t = 1.0 / (1.0 + b0 * y);
+    double res = (exp(-y * y / 2) / sqrt(2.0 * pi)) * ((((b5 * t + b4) * t + b3) * t + b2) * t + b1) * t;
+    if (x > mean) res = 1 - res;
+    return res;
+  }
+  double get_pr_insert_size(double ins) const {                                // output.c:795-808
+    double res = normal_cdf(ins + 10, P.insert_size_mean, P.insert_size_stddev) - normal_cdf(ins - 10, P.insert_size_mean, P.insert_size_stddev);
+    if (res < 1e-200) res = 1e-200;
+    return res;
+  }
+  static double get_pr_missed(const Read& re) { return re.read_len < 40 ? 1e-10 : (re.read_len < 60 ? 1e-14 : 1e-16); }   // mapping.h:28-37
+  double pr_random_mapping_given_score(const Read& re, int score) const {      // mapping.h:39-61 (letter space)
+    int read_len = re.read_len;
+    if (score > read_len * P.match_score) return 1e-200;
+    unsigned a = (unsigned)(read_len * P.match_score - score), b = (unsigned)abs(P.mismatch_score - P.match_score);
+    int n_mismatches = (a == 0) ? 0 : (int)((a - 1) / b + 1);                   // ceil_div (util.h:213-219)
+    double lnck = 0.0; for (int i = 0; i < n_mismatches; i++) lnck += log(read_len - i) - log(i + 1);   // log_nchoosek (util.c:1306-1313)
+    double tmp = -lnck - n_mismatches * log(3) + read_len * log(4);
+    return exp(-tmp);
+  }
+
+  // compute_paired_mqv (output.c:811-942)
+  void compute_paired_mqv(PairEntry& pe) const {
+    double z1[2], z3, pr_top_random[3] = {1.0, 1.0, 1.0}, pr_missed_mp[2], class_select_denom;
+    long long total_genome_size = 0; for (auto l : G->len) total_genome_size += l;
+    for (int nip = 0; nip < 2; nip++) {
+      z1[nip] = 0;
+      for (auto& h : pe.re[nip]->final_unpaired_hits) z1[nip] += h.sfr.posterior;
+      for (auto& h : pe.re[nip]->final_unpaired_hits) { h.sfr.z0 = h.sfr.posterior; h.sfr.z1 = z1[nip]; }
+    }
+    double insert_size_denom = 0.0;
+    for (auto& hp : pe.final_paired_hits) insert_size_denom += get_pr_insert_size(hp.insert_size);
+    for (int nip = 0; nip < 2; nip++) for (auto& h : pe.pool[nip]) h.sfr.insert_size_denom = insert_size_denom;
+    z3 = 0.0;
+    for (int nip = 0; nip < 2; nip++)
+      for (auto& rh : pe.pool[nip]) {
+        double tmp = 0.0;
+        for (int idx : rh.paired_hit_idx) {
+          HitPair& hp = pe.final_paired_hits[idx];
+          Hit& mp = pe.pool[1 - nip][hp.rh_idx[1 - nip]];
+          tmp += get_pr_insert_size(hp.insert_size) * mp.sfr.posterior;
+        }
+        tmp *= rh.sfr.posterior;
+        if (tmp < 1e-200) tmp = 1e-200;
+        rh.sfr.z2 = tmp;
+        if (nip == 0) z3 += tmp;
+      }
+    for (int nip = 0; nip < 2; nip++) for (auto& h : pe.pool[nip]) h.sfr.z3 = z3;
+    for (int nip = 0; nip < 2; nip++) {
+      auto& U = pe.re[nip]->final_unpaired_hits;
+      if (U.empty()) continue;
+      size_t mx = 0;
+      for (size_t i = 1; i < U.size(); i++) if (U[i].sfr.z0 > U[mx].sfr.z0) mx = i;
+      pr_top_random[nip] = pr_random_mapping_given_score(*pe.re[nip], U[mx].sfr.posterior_score);
+      for (auto& h : U) h.sfr.pr_top_random_at_location = pr_top_random[nip];
+      pr_top_random[nip] *= (double)total_genome_size;
+      if (pr_top_random[nip] > 1) pr_top_random[nip] = 1.0;
+    }
+    for (auto& hp : pe.final_paired_hits) {
+      double tmp = pr_random_mapping_given_score(*pe.re[0], pe.pool[0][hp.rh_idx[0]].sfr.posterior_score);
+      tmp *= pr_random_mapping_given_score(*pe.re[1], pe.pool[1][hp.rh_idx[1]].sfr.posterior_score);
+      tmp *= 1000;
+      if (tmp < pr_top_random[2]) pr_top_random[2] = tmp;
+    }
+    for (auto& hp : pe.final_paired_hits) {
+      pe.pool[0][hp.rh_idx[0]].sfr.pr_top_random_at_location = pr_top_random[2];
+      pe.pool[1][hp.rh_idx[1]].sfr.pr_top_random_at_location = pr_top_random[2];
+    }
+    pr_top_random[2] *= (double)total_genome_size;
+    if (pr_top_random[2] > 1) pr_top_random[2] = 1.0;
+    for (int nip = 0; nip < 2; nip++) {
+      pr_missed_mp[nip] = get_pr_missed(*pe.re[1 - nip]);
+      for (auto& h : pe.re[nip]->final_unpaired_hits) h.sfr.pr_missed_mp = pr_missed_mp[nip];
+    }
+    class_select_denom = 0.0;
+    if (!pe.re[0]->final_unpaired_hits.empty()) class_select_denom += pr_top_random[1] * pr_top_random[2] * pr_missed_mp[0];
+    if (!pe.re[1]->final_unpaired_hits.empty()) class_select_denom += pr_top_random[0] * pr_top_random[2] * pr_missed_mp[1];
+    if (!pe.final_paired_hits.empty()) class_select_denom += pr_top_random[0] * pr_top_random[1];
+    for (int nip = 0; nip < 2; nip++)
+      for (auto& rh : pe.re[nip]->final_unpaired_hits) {
+        double p_corr = (pr_top_random[1 - nip] * pr_top_random[2] * pr_missed_mp[nip] / class_select_denom) * (rh.sfr.z0 / rh.sfr.z1);
+        rh.sfr.mqv = qv_from_pr_corr(p_corr); if (rh.sfr.mqv < 4) rh.sfr.mqv = 0;
+      }
+    for (auto& hp : pe.final_paired_hits)
+      for (int nip = 0; nip < 2; nip++) {
+        Hit& rh = pe.pool[nip][hp.rh_idx[nip]];
+        double p_corr = (pr_top_random[0] * pr_top_random[1] / class_select_denom) * (rh.sfr.z2 / rh.sfr.z3);
+        rh.sfr.mqv = qv_from_pr_corr(p_corr); if (rh.sfr.mqv < 4) rh.sfr.mqv = 0;
+      }
+  }
+
+  // hit_output in paired mode (output.c:227-774): rh may be null (unmapped mate line), rh_mp may be null
+  void hit_output_paired(const Read& re, const Hit* rh, const Hit* rh_mp, bool first_in_pair, bool improper, std::string& out) const {
+    char buf[256];
+    const Read& re_mp = *re.mate_pair;
+    std::string qname = re.name;                                             // common prefix of the two names (output.c:365-378)
+    { size_t n = std::min(re.name.size(), re_mp.name.size()), i = 0;
+      while (i < n && re.name[i] == re_mp.name[i]) i++;
+      if (i > 0 && (re.name[i - 1] == ':' || re.name[i - 1] == '/')) i--;
+      qname = re.name.substr(0, i); }
+    std::string seq(re.read_len, 'N');
+    for (int i = 0; i < re.read_len; i++) {
+      char c = re.seq[i];
+      switch (c) { case 'R': case 'Y': case 'S': case 'W': case 'K': case 'M': case 'B': case 'D': case 'H': case 'V': seq[i] = 'N'; break;
+                   default: if (c >= 'a') c -= 32; seq[i] = c; break; }
+    }
+    const bool paired_alignment = (rh != nullptr && rh_mp != nullptr && !improper);
+    const bool query_unmapped = (rh == nullptr), mate_unmapped = (rh_mp == nullptr);
+    bool reverse_strand = false, reverse_strand_mp = false;
+    int genome_start_mp = 0, genome_end_mp = 0, mpos = 0; const char* mrnm = "*";
+    if (!mate_unmapped) {
+      int rs = rh_mp->sfr.read_start + 1, rend = rs + rh_mp->sfr.rmapped - 1, glen = (int)G->len[rh_mp->cn];
+      reverse_strand_mp = (rh_mp->gen_st == 1);
+      if (!reverse_strand_mp) genome_start_mp = rh_mp->sfr.genome_start + 1;
+      else genome_start_mp = (glen - rh_mp->sfr.genome_start) - (rend - rs - rh_mp->sfr.deletions + rh_mp->sfr.insertions);
+      genome_end_mp = genome_start_mp + rh_mp->sfr.gmapped - 1;
+      mpos = genome_start_mp; mrnm = G->names[rh_mp->cn].c_str();
+    }
+    const bool second_in_pair = !first_in_pair;
+    auto flags = [&]() {
+      return 0x1 | (paired_alignment ? 0x2 : 0) | (query_unmapped ? 0x4 : 0) | (mate_unmapped ? 0x8 : 0) | (reverse_strand ? 0x10 : 0) |
+             (reverse_strand_mp ? 0x20 : 0) | (first_in_pair ? 0x40 : 0) | (second_in_pair ? 0x80 : 0);
+    };
+    if (query_unmapped) {                                                     // output.c:411-466 (half_paired => only this case)
+      out += qname; snprintf(buf, sizeof buf, "\t%i\t*\t0\t0\t*\t%s\t%u\t0\t", flags(), mrnm, (unsigned)mpos); out += buf;
+      out += seq; out += "\t*\n";
+      return;
+    }
+    const SwFullResults& s = rh->sfr;
+    reverse_strand = (rh->gen_st == 1);
+    int read_start = s.read_start + 1, read_end = read_start + s.rmapped - 1, genome_length = (int)G->len[rh->cn];
+    std::vector<std::pair<int, char>> cigar;
+    make_cigar(read_start, read_end, re.read_len, s.qralign, s.dbalign, &cigar);
+    int j = read_start - 1;
+    for (size_t i = 0; i < s.qralign.size(); i++) {
+      char c = s.qralign[i];
+      if (c != '-') { if (c >= 'a') c -= 32; if (c != 'A' && c != 'G' && c != 'C' && c != 'T' && c != 'N') c = 'N'; seq[j++] = c; }
+    }
+    seq.resize(j + (re.read_len - read_end));
+    int genome_start;
+    if (!reverse_strand) genome_start = s.genome_start + 1;
+    else {
+      genome_start = (genome_length - s.genome_start) - (read_end - read_start - s.deletions + s.insertions);
+      std::string t(seq.size(), ' ');
+      for (size_t i = 0; i < seq.size(); i++) t[seq.size() - 1 - i] = rc_char(seq[i]);
+      seq = t; std::reverse(cigar.begin(), cigar.end());
+    }
+    int genome_end = genome_start + s.gmapped - 1;
+    int isize = 0;
+    if (!mate_unmapped) {
+      if (G->names[rh->cn] == mrnm) {
+        mrnm = "=";
+        int fivep = reverse_strand ? genome_end : genome_start - 1;
+        int fivep_mp = reverse_strand_mp ? genome_end_mp : genome_start_mp - 1;
+        isize = fivep_mp - fivep;
+      } else isize = 0;
+    }
+    out += qname;
+    snprintf(buf, sizeof buf, "\t%i\t", flags()); out += buf;
+    out += G->names[rh->cn];
+    snprintf(buf, sizeof buf, "\t%u\t%i\t", (unsigned)genome_start, s.mqv); out += buf;
+    for (auto& c : cigar) { snprintf(buf, sizeof buf, "%d%c", c.first, c.second); out += buf; }
+    snprintf(buf, sizeof buf, "\t%s\t%u\t%i\t", mrnm, (unsigned)mpos, isize); out += buf;
+    out += seq; out += "\t*";
+    snprintf(buf, sizeof buf, "\tAS:i:%d", rh->score_full); out += buf;
+    if (P.compute_mapping_qualities) {
+      if (rh != nullptr && rh_mp != nullptr && !improper)
+        snprintf(buf, sizeof buf, "\tZ2:i:%d\tZ3:i:%d\tZ4:i:%d\tZ6:i:%d", double_to_neglog(s.z2), double_to_neglog(s.z3),
+                 double_to_neglog(s.pr_top_random_at_location), double_to_neglog(s.insert_size_denom));
+      else
+        snprintf(buf, sizeof buf, "\tZ0:i:%d\tZ1:i:%d\tZ4:i:%d\tZ5:i:%d", double_to_neglog(s.z0), double_to_neglog(s.z1),
+                 double_to_neglog(s.pr_top_random_at_location), double_to_neglog(s.pr_missed_mp));
+      out += buf;
+    }
+    snprintf(buf, sizeof buf, "\tNM:i:%d\n", s.mismatches + s.deletions + s.insertions); out += buf;
+  }
+
+  // readpair_output (output.c:1070-1291), default flags (no single-best-mapping)
+  void readpair_output(PairEntry& pe, std::string& out) const {
+    if (P.compute_mapping_qualities) compute_paired_mqv(pe);
+    for (auto& hp : pe.final_paired_hits) {
+      Hit* rh1 = &pe.pool[0][hp.rh_idx[0]]; Hit* rh2 = &pe.pool[1][hp.rh_idx[1]];
+      hit_output_paired(*pe.re[0], rh1, rh2, true, hp.improper_mapping, out);
+      hit_output_paired(*pe.re[1], rh2, rh1, false, hp.improper_mapping, out);
+    }
+    for (int nip = 0; nip < 2; nip++)
+      for (auto& rh : pe.re[nip]->final_unpaired_hits) {
+        Read& rep = *pe.re[nip];
+        if (rep.first_in_pair) { hit_output_paired(rep, &rh, nullptr, true, false, out); hit_output_paired(*rep.mate_pair, nullptr, &rh, false, false, out); }
+        else { hit_output_paired(*rep.mate_pair, nullptr, &rh, true, false, out); hit_output_paired(rep, &rh, nullptr, false, false, out); }
+      }
+  }
+
+  // read_reverse (gmapper.c:174-185)
+  static void read_reverse(Read& re) { std::swap(re.bits[0], re.bits[1]); re.input_strand = 1 - re.input_strand; }
+
+  // handle_readpair (mapping.c:2502-2636) + the pair set-up of the read loop (gmapper.c:561-577)
+  void handle_readpair(ThreadState& T, Read& re1, Read& re2, std::string& out) const {
+    static const bool pair_reverse[5][2] = {{0, 0}, {0, 0}, {1, 1}, {0, 1}, {1, 0}};   // gmapper-defaults.h:184-191
+    if (pair_reverse[P.pair_mode][0]) read_reverse(re1);
+    if (pair_reverse[P.pair_mode][1]) read_reverse(re2);
+    re1.paired = true; re1.first_in_pair = true; re1.mate_pair = &re2;
+    re2.paired = true; re2.first_in_pair = false; re2.mate_pair = &re1;
+    PairEntry pe; pe.re[0] = &re1; pe.re[1] = &re2;
+    read_get_mapidxs(re1); read_get_mapidxs(re2);
+    readpair_compute_mp_ranges(re1, re2);
+    T.region_map_id++; T.region_map_id &= ((1 << region_map_id_bits) - 1);
+    read_get_region_counts(T, re1, 0); read_get_region_counts(T, re1, 1);
+    read_get_region_counts(T, re2, 0); read_get_region_counts(T, re2, 1);
+    read_get_anchor_list(T, re1, 0); read_get_anchor_list(T, re1, 1);
+    read_get_anchor_list(T, re2, 0); read_get_anchor_list(T, re2, 1);
+    for (Read* re : {&re1, &re2}) {
+      read_get_hit_list(*re, 0); read_get_hit_list(*re, 1);
+      for (size_t i = 0; i < re->hits[0].size(); i++) re->hits[0][i].sort_idx = (int)i;
+      for (size_t i = 0; i < re->hits[1].size(); i++) re->hits[1][i].sort_idx = (int)(re->hits[0].size() + i);
+    }
+    readpair_pair_up_hits(re1, re2);
+    read_pass1(T, re1, 0, true); read_pass1(T, re1, 1, true);
+    read_pass1(T, re2, 0, true); read_pass1(T, re2, 1, true);
+    std::vector<HitPair> p1, p2; int n1 = 0;
+    readpair_get_vector_hits(re1, re2, p1, n1);
+    readpair_pass2(T, re1, re2, p1, n1, p2);
+    if (!p2.empty()) { readpair_save_final_hits(pe, p2); pe.mapped = true; }
+    // hits of pass 1 that were not saved lose their alignment (free_sfrp, mapping.c:2590-2595) and are re-aligned if selected again
+    for (int i = 0; i < n1; i++) for (int j = 0; j < 2; j++) if (p1[i].rh[j]->has_sfr && p1[i].rh[j]->saved != 1) { p1[i].rh[j]->has_sfr = false; }
+    if (P.half_paired) { handle_read_half(T, re1); handle_read_half(T, re2); }   // stop_threshold 101 % is never met (gmapper.c:2686-2687)
+    readpair_output(pe, out);
+    if (P.sam_unaligned && !(pe.mapped || re1.mapped || re2.mapped)) {
+      hit_output_paired(re1, nullptr, nullptr, true, false, out); hit_output_paired(re2, nullptr, nullptr, false, false, out);
+    }
   }
 
   // handle_read (mapping.c:1773-1868) with the single default unpaired option set (gmapper.c:2601-2634)

@@ -47,6 +47,13 @@ static void map_all(const Session& S, std::vector<Read>& reads, int nthreads, st
 #pragma omp for schedule(dynamic, 1)
     for (int c = 0; c < nchunks; c++) {
       size_t lo = (size_t)c * chunk, hi = std::min(reads.size(), lo + chunk);
+      if (S.M.P.pair_mode != 0) {           // mates are adjacent; chunk is even (gmapper.c:2319-2322)
+        for (size_t r = lo; r + 1 < hi; r += 2) {
+          S.M.prepare_read(reads[r]); S.M.prepare_read(reads[r + 1]);
+          if (reads[r].read_len > S.M.P.longest_read_len || reads[r + 1].read_len > S.M.P.longest_read_len) continue;
+          S.M.handle_readpair(T, reads[r], reads[r + 1], outs[c]);
+        }
+      } else
       for (size_t r = lo; r < hi; r++) {
         S.M.prepare_read(reads[r]);
         if (reads[r].read_len > S.M.P.longest_read_len) continue;
@@ -68,7 +75,7 @@ static void map_all(const Session& S, std::vector<Read>& reads, int nthreads, st
 
 #ifdef GM_ORACLE_MAIN
 int main(int argc, char** argv) {
-  int nthreads = 1; bool noz = false, unal = false;
+  int nthreads = 1; bool noz = false, unal = false; int pair_mode = 0, ins_min = 0, ins_max = 1000;
   std::vector<const char*> pos;
   std::string cl;
   for (int i = 0; i < argc; i++) { if (i) cl += ' '; cl += argv[i]; }
@@ -76,12 +83,15 @@ int main(int argc, char** argv) {
     if (!strcmp(argv[i], "-N") && i + 1 < argc) nthreads = atoi(argv[++i]);
     else if (!strcmp(argv[i], "-Z")) noz = true;
     else if (!strcmp(argv[i], "--sam-unaligned")) unal = true;
+    else if (!strcmp(argv[i], "-p") && i + 1 < argc) { const char* m = argv[++i]; pair_mode = !strcmp(m, "opp-in") ? 1 : !strcmp(m, "opp-out") ? 2 : !strcmp(m, "col-fw") ? 3 : !strcmp(m, "col-bw") ? 4 : 0; }
+    else if (!strcmp(argv[i], "-I") && i + 1 < argc) { sscanf(argv[++i], "%d,%d", &ins_min, &ins_max); }
     else pos.push_back(argv[i]);
   }
   if (pos.size() != 2) { fprintf(stderr, "usage: gm_oracle [-N n] [-Z] [--sam-unaligned] reads.fa genome.fa\n"); return 1; }
   Session S;
   load_default_seeds(S.M.P); derive_score_probs(S.M.P);
   S.M.P.hash_filter_calls = !noz; S.M.P.sam_unaligned = unal;
+  S.M.P.pair_mode = pair_mode; S.M.P.min_insert_size = ins_min; S.M.P.max_insert_size = ins_max;
   std::vector<std::string> gn, gs;
   if (!read_fasta(pos[1], gn, gs)) { fprintf(stderr, "cannot read genome\n"); return 1; }
   for (size_t c = 0; c < gn.size(); c++) {
@@ -156,6 +166,9 @@ void* gmo_session_create(int n_contigs, const uint8_t* const* codes, const uint6
 }
 void gmo_session_destroy(void* s) { delete (Session*)s; }
 unsigned gmo_session_cutoff(void* s) { return ((Session*)s)->M.P.list_cutoff; }
+void gmo_session_set_pairing(void* s, int pair_mode, int min_insert, int max_insert) {
+  Session* S = (Session*)s; S->M.P.pair_mode = pair_mode; S->M.P.min_insert_size = min_insert; S->M.P.max_insert_size = max_insert;
+}
 void gmo_session_set(void* s, int hash_filter_calls, int sam_unaligned) {
   Session* S = (Session*)s; S->M.P.hash_filter_calls = hash_filter_calls != 0; S->M.P.sam_unaligned = sam_unaligned != 0;
 }
@@ -175,6 +188,26 @@ char* gmo_map_sam(void* s, int n, int L, const uint8_t* codes, const char* names
   std::string out; Stats st;
   map_all(*S, reads, nthreads > 0 ? nthreads : 1, out, &st);
   if (stats7) { stats7[0] = st.vec_calls; stats7[1] = st.vec_cells; stats7[2] = st.vec_bypassed; stats7[3] = st.full_calls; stats7[4] = st.reads_matched; stats7[5] = st.dup_pruned; stats7[6] = 0; }
+  char* r = (char*)malloc(out.size() + 1);
+  memcpy(r, out.data(), out.size()); r[out.size()] = 0;
+  return r;
+}
+// pairs: mates 1 are n x L1 codes, mates 2 are n x L2 codes; names '\n'-separated (or NULL -> p<i>/1, p<i>/2)
+char* gmo_map_pairs_sam(void* s, int n, int L1, const uint8_t* codes1, int L2, const uint8_t* codes2,
+                        const char* names1, const char* names2, int nthreads) {
+  Session* S = (Session*)s;
+  std::vector<Read> reads((size_t)2 * n);
+  const char* p1 = names1; const char* p2 = names2;
+  auto next_name = [](const char*& p, std::string& dst) { const char* e = strchr(p, '\n'); if (!e) e = p + strlen(p); dst.assign(p, e); p = *e ? e + 1 : e; };
+  for (int i = 0; i < n; i++) {
+    char nm[40];
+    if (p1) next_name(p1, reads[2 * i].name); else { snprintf(nm, sizeof nm, "p%d/1", i); reads[2 * i].name = nm; }
+    if (p2) next_name(p2, reads[2 * i + 1].name); else { snprintf(nm, sizeof nm, "p%d/2", i); reads[2 * i + 1].name = nm; }
+    reads[2 * i].seq = code_seq(codes1 + (size_t)i * L1, L1);
+    reads[2 * i + 1].seq = code_seq(codes2 + (size_t)i * L2, L2);
+  }
+  std::string out;
+  map_all(*S, reads, nthreads > 0 ? nthreads : 1, out, nullptr);
   char* r = (char*)malloc(out.size() + 1);
   memcpy(r, out.data(), out.size()); r[out.size()] = 0;
   return r;

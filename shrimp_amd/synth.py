@@ -83,6 +83,39 @@ def make_reads(contigs: list[np.ndarray], n_reads: int, read_len: int, seed: int
     return out, {"cn": cn.astype(np.int32), "pos": pos, "strand": strand}
 
 
+def make_pairs(contigs: list[np.ndarray], n_pairs: int, read_len: int, seed: int, ins_mean: float = 300.0, ins_sd: float = 30.0,
+               ins_min: int = 160, p_sub: float = 0.01):
+    """opp-in pairs: a fragment of length ~N(ins_mean, ins_sd) (clipped to >= ins_min and >= read_len),
+    mate 1 = its first read_len bases, mate 2 = reverse complement of its last read_len bases; the fragment is taken from either
+    strand with equal probability.  Returns codes[2*n_pairs, read_len] with mates adjacent."""
+    rng = np.random.Generator(np.random.PCG64(seed + 2_000_003))
+    lens = np.array([len(c) for c in contigs], dtype=np.int64)
+    ins = np.maximum(np.maximum(np.rint(rng.normal(ins_mean, ins_sd, n_pairs)).astype(np.int64), ins_min), read_len)
+    maxins = int(ins.max())
+    usable = np.maximum(lens - maxins - 1, 1)
+    cum = np.concatenate([[0], np.cumsum(usable)])
+    u = rng.integers(0, cum[-1], size=n_pairs, dtype=np.int64)
+    cn = np.searchsorted(cum, u, side="right") - 1
+    pos = u - cum[cn]
+    strand = (rng.random(n_pairs) < 0.5)
+    out = np.empty((2 * n_pairs, read_len), dtype=np.uint8)
+    ar = np.arange(read_len, dtype=np.int64)
+    for c in range(len(contigs)):
+        m = np.nonzero(cn == c)[0]
+        if m.size == 0:
+            continue
+        left = contigs[c][pos[m, None] + ar[None, :]]                                  # fragment start, + strand
+        right = contigs[c][(pos[m] + ins[m] - read_len)[:, None] + ar[None, :]]         # fragment end, + strand
+        fwd = ~strand[m]
+        m1 = np.where(fwd[:, None], left, COMPLEMENT[right[:, ::-1]])
+        m2 = np.where(fwd[:, None], COMPLEMENT[right[:, ::-1]], left)
+        out[2 * m] = m1
+        out[2 * m + 1] = m2
+    sub = (rng.random(out.shape) < p_sub) & (out < 4)
+    out = np.where(sub, (out + rng.integers(1, 4, size=out.shape, dtype=np.uint8)) & 3, out).astype(np.uint8)
+    return out, {"cn": cn.astype(np.int32), "pos": pos, "ins": ins, "strand": strand}
+
+
 def pack_nibbles(codes: np.ndarray) -> np.ndarray:
     """Pack a 1-D code array 8 bases per uint32, base i in nibble i%8 of word i/8
     (the reference's bitfield layout, common/util.h:41 EXTRACT).  Little-endian bytes: byte k of

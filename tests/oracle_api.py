@@ -34,20 +34,40 @@ def load():
     L.gmo_session_cutoff.argtypes = [C.c_void_p]; L.gmo_session_cutoff.restype = C.c_uint
     L.gmo_session_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.gmo_map_sam.argtypes = [C.c_void_p, C.c_int, C.c_int, u8p, C.c_char_p, C.c_int, C.POINTER(C.c_uint64)]; L.gmo_map_sam.restype = C.c_void_p
+    L.gmo_session_set_pairing.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.gmo_map_pairs_sam.argtypes = [C.c_void_p, C.c_int, C.c_int, u8p, C.c_int, u8p, C.c_char_p, C.c_char_p, C.c_int]; L.gmo_map_pairs_sam.restype = C.c_void_p
     L.gmo_free.argtypes = [C.c_void_p]
     L.gmo_map_tophits.argtypes = [C.c_void_p, C.c_int, C.c_int, u8p, C.c_int, C.POINTER(C.c_longlong), C.c_long]; L.gmo_map_tophits.restype = C.c_long
     _LIB = L
     return L
 
 
+PAIR_MODES = {"none": 0, "opp-in": 1, "opp-out": 2, "col-fw": 3, "col-bw": 4}
+
+
 class Session:
-    def __init__(self, contigs):
+    def __init__(self, contigs, contig_names=None):
         self.L = load()
         self.contigs = [np.ascontiguousarray(c, dtype=np.uint8) for c in contigs]
         n = len(self.contigs)
         ptrs = (C.POINTER(C.c_uint8) * n)(*[c.ctypes.data_as(C.POINTER(C.c_uint8)) for c in self.contigs])
         lens = (C.c_uint64 * n)(*[len(c) for c in self.contigs])
-        self.h = self.L.gmo_session_create(n, ptrs, lens, None)
+        names = None
+        if contig_names is not None:
+            self._names = (C.c_char_p * n)(*[bytes(x) for x in contig_names]); names = C.cast(self._names, C.c_void_p)
+        self.h = self.L.gmo_session_create(n, ptrs, lens, names)
+
+    def set_pairing(self, mode, min_insert, max_insert):
+        self.L.gmo_session_set_pairing(self.h, PAIR_MODES[mode] if isinstance(mode, str) else int(mode), int(min_insert), int(max_insert))
+
+    def map_pairs_sam(self, m1, m2, names1=None, names2=None, nthreads=4):
+        m1 = np.ascontiguousarray(m1, dtype=np.uint8); m2 = np.ascontiguousarray(m2, dtype=np.uint8)
+        n1 = b"\n".join(bytes(x) for x in names1) if names1 is not None else None
+        n2 = b"\n".join(bytes(x) for x in names2) if names2 is not None else None
+        p = self.L.gmo_map_pairs_sam(self.h, m1.shape[0], m1.shape[1], m1.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                     m2.shape[1], m2.ctypes.data_as(C.POINTER(C.c_uint8)), n1, n2, nthreads)
+        s = C.string_at(p); self.L.gmo_free(p)
+        return s
 
     def set(self, hash_filter_calls=True, sam_unaligned=False):
         self.L.gmo_session_set(self.h, int(hash_filter_calls), int(sam_unaligned))
@@ -84,8 +104,20 @@ class Session:
         except Exception: pass
 
 
-def sam_header(contigs):
-    return b"@HD\tVN:1.0\tSO:unsorted\n" + b"".join(b"@SQ\tSN:contig%d\tLN:%d\n" % (i + 1, len(c)) for i, c in enumerate(contigs))
+def sam_header(contigs, names=None):
+    names = names if names is not None else [b"contig%d" % (i + 1) for i in range(len(contigs))]
+    return b"@HD\tVN:1.0\tSO:unsorted\n" + b"".join(b"@SQ\tSN:%s\tLN:%d\n" % (bytes(nm), len(c)) for nm, c in zip(names, contigs))
+
+
+def load_golden_pairs(name):
+    d = os.path.join(ROOT, "tests", "golden")
+    z = np.load(os.path.join(d, name + ".npz"))
+    contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
+    with gzip.open(os.path.join(d, name + ".sam.gz"), "rb") as f:
+        sam = f.read()
+    return dict(contigs=contigs, contig_names=[bytes(x) for x in z["contig_names"]], m1=z["mates1"], m2=z["mates2"],
+                names1=[bytes(x) for x in z["names1"]], names2=[bytes(x) for x in z["names2"]],
+                mode=str(z["mode"]), ins=tuple(int(x) for x in z["ins"]), sam=sam)
 
 
 def load_golden(name):

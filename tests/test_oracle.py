@@ -50,3 +50,17 @@ def test_oracle_sharding_invariance(oracle_lib):
     halves = strip(s.map_sam(reads[:h], nthreads=1)) + strip(s.map_sam(reads[h:], nthreads=3))
     s.close()
     assert strip(whole) == halves
+
+
+PAIRED = ["pairfix_opp-in", "pairfix_opp-out", "pairfix_col-fw", "pairfix_col-bw", "cfg5s_2x150_1Mbp", "stress_pairs_2x100"]
+
+
+@pytest.mark.parametrize("name", PAIRED)
+def test_oracle_paired_sam_matches_reference(name, oracle_lib):
+    """paired mode (handle_readpair, half-paired rescue, paired MAPQ) incl. the reference's own pairing fixture"""
+    g = oa.load_golden_pairs(name)
+    s = oa.Session(g["contigs"], g["contig_names"])
+    s.set_pairing(g["mode"], *g["ins"])
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_sam(g["m1"], g["m2"], g["names1"], g["names2"], nthreads=4)
+    s.close()
+    assert got == g["sam"], "oracle paired SAM differs from the reference for %s" % name

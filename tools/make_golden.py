@@ -76,8 +76,71 @@ def run_case(name, contigs, reads, extra=()):
     print(f"{name}: {len(reads)} reads -> {n_map} SAM records")
 
 
+def read_fa(path):
+    names, seqs = [], []
+    for line in open(path, "rb"):
+        line = line.strip()
+        if not line: continue
+        if line.startswith(b">"): names.append(line[1:].split()[0]); seqs.append(b"")
+        else: seqs[-1] += line
+    return names, seqs
+
+
+CODE = {c: i for i, c in enumerate(b"ACGTUMRWSYKVHDBN")}
+
+
+def to_codes(seq):
+    return np.array([CODE[c] for c in seq.upper()], dtype=np.uint8)
+
+
+def run_pair_case(name, contigs, contig_names, m1, m2, names1, names2, mode, ins):
+    """mates adjacent in one file, as gmapper expects in paired mode (ref: gmapper.c:2319-2322)"""
+    with tempfile.TemporaryDirectory() as d:
+        g = os.path.join(d, "g.fa"); r = os.path.join(d, "r.fa")
+        write_fa_codes(g, contig_names, contigs)
+        names = [n for pair in zip(names1, names2) for n in pair]
+        seqs = [q for pair in zip(list(m1), list(m2)) for q in pair]
+        write_fa_codes(r, names, seqs)
+        p = subprocess.run([REF, "-N", "4", "-p", mode, "-I", "%d,%d" % ins, r, g], capture_output=True, check=True)
+        body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **{"contig%d" % i: c for i, c in enumerate(contigs)},
+                        mates1=np.asarray(m1), mates2=np.asarray(m2),
+                        names1=np.array(names1), names2=np.array(names2), contig_names=np.array(contig_names),
+                        mode=np.array(mode), ins=np.array(ins))
+    with gzip.open(os.path.join(OUT, name + ".sam.gz"), "wb", compresslevel=9) as f:
+        f.write(body)
+    n_rec = sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@"))
+    print("%s: %d pairs -> %d SAM records" % (name, len(m1), n_rec))
+
+
+def paired_cases():
+    # (1) the reference's own pairing fixture (not_in_dist/test_pairing): 24 pairs, mates of 30 and 50 bp, under all four pair modes
+    fx = "/root/reference/not_in_dist/test_pairing"
+    gn, gs = read_fa(os.path.join(fx, "reference-pairing.fa"))
+    rn, rs = read_fa(os.path.join(fx, "reads-pairing.fa"))
+    contigs = [to_codes(q) for q in gs]
+    m1 = np.stack([to_codes(q) for q in rs[0::2]]); m2 = np.stack([to_codes(q) for q in rs[1::2]])
+    for mode in ("opp-in", "opp-out", "col-fw", "col-bw"):
+        run_pair_case("pairfix_" + mode, contigs, gn, m1, m2, rn[0::2], rn[1::2], mode, (0, 500))
+    # (2) cfg5-like: 2 x 150 bp opp-in pairs, insert ~ N(300, 30), 1 % substitutions, uniform genome
+    contigs = synth.make_genome([600_000, 400_000], 55)
+    reads, _ = synth.make_pairs(contigs, 1500, 150, 5)
+    n = len(reads) // 2
+    run_pair_case("cfg5s_2x150_1Mbp", contigs, [b"contig1", b"contig2"], reads[0::2], reads[1::2],
+                  [b"p%d/1" % i for i in range(n)], [b"p%d/2" % i for i in range(n)], "opp-in", (100, 600))
+    # (3) pairs on the repeat-rich stress genome (half-paired rescue, duplicate pruning, unpaired mates)
+    sg = stress_genome()
+    r2, _ = synth.make_pairs([c for c in sg if len(c) > 2000], 1200, 100, 6, ins_mean=250, ins_sd=40, ins_min=120, p_sub=0.02)
+    r2 = np.where(r2 > 3, 15, r2).astype(np.uint8)
+    n = len(r2) // 2
+    run_pair_case("stress_pairs_2x100", sg, [b"contig%d" % (i + 1) for i in range(len(sg))], r2[0::2], r2[1::2],
+                  [b"q%d:1" % i for i in range(n)], [b"q%d:2" % i for i in range(n)], "opp-in", (100, 600))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--paired-only" in sys.argv:
+        paired_cases(); return
     contigs, reads, _ = synth.make_config("cfg1")
     run_case("cfg1_36bp_1Mbp", contigs, reads)
     contigs, reads, _ = synth.make_config("cfg2", scale=0.02, n_reads=5000)
@@ -89,6 +152,7 @@ def main():
     with gzip.open(os.path.join(OUT, "sw_kat.txt.gz"), "wb", compresslevel=9) as f:
         f.write(kat)
     print("sw_kat:", kat.count(b"\nV ") + 1, "vector,", kat.count(b"\nF "), "full")
+    paired_cases()
 
 
 if __name__ == "__main__":
