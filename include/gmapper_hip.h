@@ -84,7 +84,8 @@ int      gm_index_has_buckets(const gm_index_t *ix);   /* 1 when the 64-byte buc
 /* genomemap_len[sn][mapidx] / genomemap[sn][mapidx][0..len) copied back to the host (tests) */
 int gm_index_get_list(const gm_index_t *ix, int sn, uint32_t mapidx, uint32_t *len, uint32_t *positions, uint32_t cap);
 /* raw device pointers + sizes of the resident arrays, for the single RCCL broadcast at start-up
- * (SURVEY.md section 8(e)); kind: 0 genome, 1+2*sn directory of seed sn, 2+2*sn positions of seed sn */
+ * (SURVEY.md section 8(e)); kind: 0 genome, 1+3*sn directory of seed sn, 2+3*sn positions of seed sn,
+ * 3+3*sn the 64-byte buckets of seed sn (bytes == 0 when that layout is not resident) */
 int gm_index_device_array(const gm_index_t *ix, int kind, void **dev_ptr, uint64_t *bytes);
 /* allocate an index with the same shape (from the metadata blob of a built index) so that a
  * non-root rank can receive the arrays; meta is host memory */
@@ -157,6 +158,28 @@ int gm_map_reads(gm_session_t *s, int n_reads, int read_len, const uint32_t *rea
 int gm_map_reads_device(gm_session_t *s, int n_reads, int read_len, const void *reads_dev,
                         int emit_sam, char **sam, size_t *sam_len, gm_map_stats_t *stats);
 void gm_free(void *p);
+
+/* ---------------------------------------------------------------------------------------------
+ * Paired mode.  Replaces handle_readpair() (ref: gmapper/mapping.c:2502-2636) with the binary's
+ * default paired option sets (ref: gmapper/gmapper.c:2636-2720: two matches per mate, half-paired
+ * fall-back, mapping qualities) and readpair_output() (ref: gmapper/output.c:1070-1291).
+ * pair_mode / insert sizes are the reference's -p and -I options (ref: gmapper.c:1583-1623,
+ * gmapper-defaults.h:28-31,184-191); mean/stddev feed the insert-size term of the paired MAPQ
+ * (ref: output.c:795-808).  mates1[i] and mates2[i] are the two reads of pair i; each side has
+ * ONE length per call.  Output: for every pair the paired records, then the half-paired records
+ * of mate 1, then of mate 2 -- the text the reference appends to its output buffer.
+ * ------------------------------------------------------------------------------------------- */
+enum { GM_PAIR_OPP_IN = 1, GM_PAIR_OPP_OUT = 2, GM_PAIR_COL_FW = 3, GM_PAIR_COL_BW = 4 };   /* ref: gmapper-definitions.h:42-46 */
+typedef struct gm_pair_opts {
+  int pair_mode;                               /* ref: gmapper.h:140 */
+  int min_insert_size, max_insert_size;        /* ref: gmapper-defaults.h:28-29  0 / 1000 */
+  double insert_size_mean, insert_size_stddev; /* ref: gmapper-defaults.h:30-31  200 / 100 */
+  int half_paired;                             /* ref: gmapper.h:181 true */
+} gm_pair_opts_t;
+void gm_pair_opts_default(gm_pair_opts_t *o);
+int gm_map_pairs(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_packed, int len2, const uint32_t *mates2_packed,
+                 const char *names1, const char *names2, const gm_pair_opts_t *opts,
+                 char **sam, size_t *sam_len, gm_map_stats_t *stats);
 
 /* per-read top-K candidate rows after pass 1 (heap array order), for stage parity tests:
  * 12 x int64 per row: read st cn g_off w_len score_vector pct_score_vector matches ax ay alen awidth */

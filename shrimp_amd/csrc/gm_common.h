@@ -90,7 +90,8 @@ struct GmFullRes {
   int32_t read_start, rmapped, genome_start, gmapped;
   int32_t n_match, n_mismatch, n_ins, n_del;
   int32_t n_ops; uint32_t ops_off;   // ops bytes ('M','I','D') in the batch's op pool
-  int32_t sort_idx;
+  int32_t sort_idx;              // paired mode: position in the read's (strand 0, strand 1) window list (ref: mapping.c:2545-2552)
+  uint32_t hit_slot;             // index of the window in the batch's GmHit array
 };
 
 static inline int gm_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <memory>
 #include <thread>
+#include <functional>
 #include "gm_common.h"
 #include "gm_internal.h"
 
@@ -229,35 +230,46 @@ extern "C" int gm_index_alloc_like(gm_index_t** out, int device, const void* met
 }
 
 // ---- session ----------------------------------------------------------------------------------
+// One read set of a sub-batch: every device array K1..K4 need for reads of ONE length.  Unpaired
+// mapping uses set[0]; paired mapping uses set[0] for the first mates and set[1] for the second.
+struct DevSet {
+  // capacities (grown on overflow)
+  int cur_len = -1, scap = 0, hcap = 0, rcap_per_read = 8, ops_stride = 0, eff_batch = 0;
+  uint32_t* d_reads = nullptr; uint64_t* d_surv = nullptr; uint32_t* d_surv_cnt = nullptr;
+  GmHit* d_hits = nullptr; uint16_t* d_perm = nullptr; uint32_t* d_hit_cnt = nullptr; unsigned long long* d_slots = nullptr;
+  uint32_t* d_heavy_list = nullptr; uint32_t* d_heavy_cnt = nullptr;   // read-strands beyond the LDS tier of K2
+  int32_t* d_sel = nullptr; int32_t* d_sel_sidx = nullptr; uint32_t* d_sel_cnt = nullptr; uint32_t* d_sel_off = nullptr; uint32_t* d_work = nullptr; uint32_t* d_n_work = nullptr;
+  GmFullRes* d_res = nullptr; uint8_t* d_ops = nullptr; uint8_t* d_back = nullptr; size_t back_stride = 0;
+  // paired mode only: mate range of every window (by sorted position) and the "saved" mark (by hit slot)
+  int32_t* d_pmin = nullptr; int32_t* d_pmax = nullptr; uint8_t* d_saved = nullptr; uint32_t* d_saved_list = nullptr;
+  // host staging
+  std::vector<GmFullRes> h_res; std::vector<uint8_t> h_ops; std::vector<uint32_t> h_sel_cnt, h_sel_off; std::vector<uint32_t> h_reads;
+};
+
 struct gm_session {
   const gm_index* ix = nullptr;
   gm_params_t P; GmScoreDev sc;
   double score_alpha = 0, score_beta = 0;
-  int max_batch = 0;
+  int max_batch = 0, p2_grid = 2560;
   hipStream_t stream = nullptr;
   hipEvent_t ev[12];
-  // capacities (grown on overflow)
-  int cur_len = -1, scap = 0, hcap = 0, rcap_per_read = 8, ops_stride = 0, p2_grid = 2560, eff_batch = 0;
-  // device buffers
-  uint32_t* d_reads = nullptr; uint64_t* d_surv = nullptr; uint32_t* d_surv_cnt = nullptr;
-  GmHit* d_hits = nullptr; uint16_t* d_perm = nullptr; uint32_t* d_hit_cnt = nullptr; unsigned long long* d_slots = nullptr;
-  uint32_t* d_heavy_list = nullptr; uint32_t* d_heavy_cnt = nullptr;   // read-strands beyond the LDS tier of K2
-  int32_t* d_sel = nullptr; uint32_t* d_sel_cnt = nullptr; uint32_t* d_sel_off = nullptr; uint32_t* d_work = nullptr; uint32_t* d_n_work = nullptr;
-  GmFullRes* d_res = nullptr; uint8_t* d_ops = nullptr; uint8_t* d_back = nullptr; size_t back_stride = 0;
+  DevSet set[2];
+  uint32_t* d_pairs = nullptr; uint32_t* d_pair_cnt = nullptr; int pairs_cap = 0;   // paired mode: selected (mate 1, mate 2) window pairs
   unsigned long long* d_stats = nullptr;
-  // host staging
-  std::vector<GmFullRes> h_res; std::vector<uint8_t> h_ops; std::vector<uint32_t> h_sel_cnt, h_sel_off; std::vector<uint32_t> h_reads;
   // last lookup timing
   double last_lookup_ms = 0; uint64_t last_lookup_bytes = 0; int last_lookup_launches = 0;
 };
 
-static void free_buffers(gm_session* s) {
-  void* ptrs[] = {s->d_reads, s->d_surv, s->d_surv_cnt, s->d_hits, s->d_perm, s->d_hit_cnt, s->d_slots, s->d_heavy_list, s->d_heavy_cnt,
-                  s->d_sel, s->d_sel_cnt, s->d_sel_off, s->d_work, s->d_n_work, s->d_res, s->d_ops, s->d_back};
+static void free_buffers(DevSet& D) {
+  void* ptrs[] = {D.d_reads, D.d_surv, D.d_surv_cnt, D.d_hits, D.d_perm, D.d_hit_cnt, D.d_slots, D.d_heavy_list, D.d_heavy_cnt,
+                  D.d_sel, D.d_sel_sidx, D.d_sel_cnt, D.d_sel_off, D.d_work, D.d_n_work, D.d_res, D.d_ops, D.d_back,
+                  D.d_pmin, D.d_pmax, D.d_saved, D.d_saved_list};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  s->d_reads = nullptr; s->d_surv = nullptr; s->d_surv_cnt = nullptr; s->d_hits = nullptr; s->d_perm = nullptr; s->d_hit_cnt = nullptr; s->d_slots = nullptr;
-  s->d_heavy_list = nullptr; s->d_heavy_cnt = nullptr; s->d_sel = nullptr; s->d_sel_cnt = nullptr; s->d_sel_off = nullptr;
-  s->d_work = nullptr; s->d_n_work = nullptr; s->d_res = nullptr; s->d_ops = nullptr; s->d_back = nullptr;
+  D.d_reads = nullptr; D.d_surv = nullptr; D.d_surv_cnt = nullptr; D.d_hits = nullptr; D.d_perm = nullptr; D.d_hit_cnt = nullptr; D.d_slots = nullptr;
+  D.d_heavy_list = nullptr; D.d_heavy_cnt = nullptr; D.d_sel = nullptr; D.d_sel_sidx = nullptr; D.d_sel_cnt = nullptr; D.d_sel_off = nullptr;
+  D.d_work = nullptr; D.d_n_work = nullptr; D.d_res = nullptr; D.d_ops = nullptr; D.d_back = nullptr;
+  D.d_pmin = nullptr; D.d_pmax = nullptr; D.d_saved = nullptr; D.d_saved_list = nullptr;
+  D.cur_len = -1;
 }
 
 static int pow2ceil(long long v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -267,42 +279,47 @@ static int window_len_of(const gm_params_t& P, int read_len) {   // ref: gmapper
   return (int)(uint16_t)w;
 }
 
-static int alloc_buffers(gm_session* s, int read_len) {
-  free_buffers(s);
+static int alloc_buffers(gm_session* s, DevSet& D, int read_len, bool paired = false) {
+  free_buffers(D);
   const gm_index* ix = s->ix;
   const int read_words = (read_len + 7) / 8;
   const int W = window_len_of(s->P, read_len);
   // sub-batch size under a device-memory budget (candidate windows dominate when hcap has grown)
   const double budget = 16e9;
-  const double per_read = 2.0 * ((double)s->scap * 8 + (double)s->hcap * (sizeof(GmHit) + 2 + 8)) + (double)s->rcap_per_read * (sizeof(GmFullRes) + read_len + W + 16);
-  s->eff_batch = (int)std::max(64.0, std::min((double)s->max_batch, budget / per_read));
-  const int B = s->eff_batch, rs = 2 * B;
+  const double per_read = 2.0 * ((double)D.scap * 8 + (double)D.hcap * (sizeof(GmHit) + 2 + 8)) + (double)D.rcap_per_read * (sizeof(GmFullRes) + read_len + W + 16);
+  D.eff_batch = (int)std::max(64.0, std::min((double)s->max_batch, budget / per_read));
+  const int B = D.eff_batch, rs = 2 * B;
   (void)ix;
-  s->ops_stride = ((read_len + W + 15) / 16) * 16;
-  s->back_stride = (((size_t)read_len * W + 255) / 256) * 256;
-  GM_HIP(hipMalloc(&s->d_reads, (size_t)B * read_words * 4 + 64));
-  GM_HIP(hipMalloc(&s->d_surv, (size_t)rs * s->scap * 8));
-  GM_HIP(hipMalloc(&s->d_surv_cnt, (size_t)rs * 4));
-  GM_HIP(hipMalloc(&s->d_hits, (size_t)rs * s->hcap * sizeof(GmHit)));
-  GM_HIP(hipMalloc(&s->d_perm, (size_t)rs * s->hcap * 2));
-  GM_HIP(hipMalloc(&s->d_hit_cnt, (size_t)rs * 4));
-  GM_HIP(hipMalloc(&s->d_slots, (size_t)rs * s->hcap * 8));
-  GM_HIP(hipMalloc(&s->d_heavy_list, (size_t)rs * 4));
-  GM_HIP(hipMalloc(&s->d_heavy_cnt, 4));
-  GM_HIP(hipMalloc(&s->d_sel, (size_t)B * GM_SEL_MAX * 4));
-  GM_HIP(hipMalloc(&s->d_sel_cnt, (size_t)B * 4));
-  GM_HIP(hipMalloc(&s->d_sel_off, (size_t)B * 4));
-  const size_t rcap = (size_t)B * s->rcap_per_read;
-  GM_HIP(hipMalloc(&s->d_work, (size_t)B * GM_SEL_MAX * 4));
-  GM_HIP(hipMalloc(&s->d_n_work, 4));
-  GM_HIP(hipMalloc(&s->d_res, rcap * sizeof(GmFullRes)));
-  GM_HIP(hipMalloc(&s->d_ops, rcap * s->ops_stride));
-  GM_HIP(hipMalloc(&s->d_back, (size_t)s->p2_grid * s->back_stride));
-  s->cur_len = read_len;
+  D.ops_stride = ((read_len + W + 15) / 16) * 16;
+  D.back_stride = (((size_t)read_len * W + 255) / 256) * 256;
+  GM_HIP(hipMalloc(&D.d_reads, (size_t)B * read_words * 4 + 64));
+  GM_HIP(hipMalloc(&D.d_surv, (size_t)rs * D.scap * 8));
+  GM_HIP(hipMalloc(&D.d_surv_cnt, (size_t)rs * 4));
+  GM_HIP(hipMalloc(&D.d_hits, (size_t)rs * D.hcap * sizeof(GmHit)));
+  GM_HIP(hipMalloc(&D.d_perm, (size_t)rs * D.hcap * 2));
+  GM_HIP(hipMalloc(&D.d_hit_cnt, (size_t)rs * 4));
+  GM_HIP(hipMalloc(&D.d_slots, (size_t)rs * D.hcap * 8));
+  GM_HIP(hipMalloc(&D.d_heavy_list, (size_t)rs * 4));
+  GM_HIP(hipMalloc(&D.d_heavy_cnt, 4));
+  GM_HIP(hipMalloc(&D.d_sel, (size_t)B * GM_SEL_MAX * 4));
+  GM_HIP(hipMalloc(&D.d_sel_cnt, (size_t)B * 4));
+  GM_HIP(hipMalloc(&D.d_sel_off, (size_t)B * 4));
+  const size_t rcap = (size_t)B * D.rcap_per_read;
+  GM_HIP(hipMalloc(&D.d_work, (size_t)B * GM_SEL_MAX * 4));
+  GM_HIP(hipMalloc(&D.d_n_work, 4));
+  GM_HIP(hipMalloc(&D.d_res, rcap * sizeof(GmFullRes)));
+  GM_HIP(hipMalloc(&D.d_ops, rcap * D.ops_stride));
+  GM_HIP(hipMalloc(&D.d_back, (size_t)s->p2_grid * D.back_stride));
+  if (paired) {
+    GM_HIP(hipMalloc(&D.d_sel_sidx, (size_t)B * GM_SEL_MAX * 4));
+    GM_HIP(hipMalloc(&D.d_pmin, (size_t)rs * D.hcap * 4)); GM_HIP(hipMalloc(&D.d_pmax, (size_t)rs * D.hcap * 4));
+    GM_HIP(hipMalloc(&D.d_saved, (size_t)rs * D.hcap)); GM_HIP(hipMalloc(&D.d_saved_list, (size_t)B * GM_SEL_MAX * 4));
+  }
+  D.cur_len = read_len;
   return GM_OK;
 }
 
-static void choose_caps(gm_session* s, int read_len) {
+static void choose_caps(gm_session* s, DevSet& D, int read_len) {
   const gm_index* ix = s->ix;
   const int max_n_kmers = std::max(0, read_len - ix->min_seed_span + 1);
   double lists = 0, avg_len = 0;
@@ -314,10 +331,10 @@ static void choose_caps(gm_session* s, int read_len) {
   const double region = (double)(1 << ix->params.region_bits) + ix->params.region_overlap;
   const double expected = entries * std::min(1.0, entries * region / std::max(1.0, (double)ix->total_len)) + lists;
   // scap = capacity of the LDS tier of K2 (16 B of LDS per entry); read-strands beyond it take the heavy tier
-  s->scap = std::min(4096, std::max(256, pow2ceil((long long)(1.5 * expected) + 128)));
-  s->hcap = 64;
-  if (const char* e = getenv("GM_SCAP")) s->scap = std::min(8192, std::max(64, pow2ceil(atoi(e))));
-  if (const char* e = getenv("GM_HCAP")) s->hcap = std::min(32768, std::max(4, pow2ceil(atoi(e))));
+  D.scap = std::min(4096, std::max(256, pow2ceil((long long)(1.5 * expected) + 128)));
+  D.hcap = 64;
+  if (const char* e = getenv("GM_SCAP")) D.scap = std::min(8192, std::max(64, pow2ceil(atoi(e))));
+  if (const char* e = getenv("GM_HCAP")) D.hcap = std::min(32768, std::max(4, pow2ceil(atoi(e))));
   (void)max_n_kmers;
 }
 
@@ -341,7 +358,9 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
 extern "C" void gm_session_free(gm_session_t* s) {
   if (!s) return;
   (void)hipSetDevice(s->ix->device);
-  free_buffers(s);
+  free_buffers(s->set[0]); free_buffers(s->set[1]);
+  if (s->d_pairs) (void)hipFree(s->d_pairs);
+  if (s->d_pair_cnt) (void)hipFree(s->d_pair_cnt);
   (void)hipFree(s->d_stats);
   for (auto& e : s->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(s->stream);
@@ -352,6 +371,7 @@ extern "C" void gm_session_free(gm_session_t* s) {
 struct FHit {            // one pass-2 candidate on the host (read_hit + sw_full_results subset)
   const GmFullRes* r; const uint8_t* ops;
   int score_full, pass2_key; double pct_score_full; double posterior; int mqv; double z0, z1;
+  double z2, z3, pr_top_random, insert_size_denom, pr_missed_mp;   // paired mode (ref: sw-full-common.h:30-44)
 };
 
 static inline char* put_uint(char* p, unsigned long long v) {
@@ -400,23 +420,29 @@ struct Finalizer {
   const gm_session* s; int read_len, read_words; const uint32_t* reads;   // host copy of the packed reads of this sub-batch
   const char* const* name_ptr; const int* name_len; long name_base;
 
-  // emits the SAM records of read `rd` (local index) into out; returns number of records
-  int finalize_read(int rd, const GmFullRes* res, const uint8_t* ops, int ops_stride, int n, std::string& out, std::vector<FHit>& fh, std::vector<FHit*>& p2) const {
-    const gm_params_t& P = s->P; const gm_index* ix = s->ix;
+  // hit_run_post_sw for one pass-2 result (ref: mapping.c:1609-1625)
+  void post_sw(FHit& h, const GmFullRes* r, const uint8_t* ops) const {
+    const gm_params_t& P = s->P;
+    h.r = r; h.ops = ops + (size_t)r->ops_off; h.mqv = 255; h.z0 = h.z1 = 0; h.posterior = 0;
+    h.z2 = h.z3 = h.pr_top_random = h.insert_size_denom = h.pr_missed_mp = 0;
+    h.score_full = r->score;
+    h.pct_score_full = (1000 * 100 * h.score_full) / r->score_max;                 // ref: mapping.c:400-401
+    if (h.score_full > 0) {
+      const double a = s->score_alpha, b = s->score_beta;
+      h.posterior = pow(2.0, ((double)r->score - (double)r->rmapped * (2.0 * a + b)) / a);
+      int ps = (int)rint(a * log(h.posterior) / log(2.0) + (double)r->rmapped * (2.0 * a + b));
+      if (ps < 0) ps = 0;
+      h.score_full = ps; h.pct_score_full = (1000 * 100 * ps) / r->score_max;
+    }
+    h.pass2_key = P.sw_full_threshold < 0 ? h.score_full : (int)h.pct_score_full;
+  }
+  // read_pass2's selection over the n pass-2 results of one read (ref: mapping.c:1628-1750): p2 = final hits in output order
+  void select_hits(const GmFullRes* res, const uint8_t* ops, int n, std::vector<FHit>& fh, std::vector<FHit*>& p2) const {
+    const gm_params_t& P = s->P;
     fh.clear(); p2.clear();
     fh.resize(n);
     for (int i = 0; i < n; i++) {
-      FHit& h = fh[i]; h.r = &res[i]; h.ops = ops + (size_t)res[i].ops_off; h.mqv = 255; h.z0 = h.z1 = 0; h.posterior = 0;
-      h.score_full = h.r->score;
-      h.pct_score_full = (1000 * 100 * h.score_full) / h.r->score_max;             // ref: mapping.c:400-401
-      if (h.score_full > 0) {                                                      // hit_run_post_sw, ref: mapping.c:1609-1625
-        const double a = s->score_alpha, b = s->score_beta;
-        h.posterior = pow(2.0, ((double)h.r->score - (double)h.r->rmapped * (2.0 * a + b)) / a);
-        int ps = (int)rint(a * log(h.posterior) / log(2.0) + (double)h.r->rmapped * (2.0 * a + b));
-        if (ps < 0) ps = 0;
-        h.score_full = ps; h.pct_score_full = (1000 * 100 * ps) / h.r->score_max;
-      }
-      h.pass2_key = P.sw_full_threshold < 0 ? h.score_full : (int)h.pct_score_full;
+      FHit& h = fh[i]; post_sw(h, &res[i], ops);
       const double thr = P.sw_full_threshold < 0 ? -P.sw_full_threshold : h.r->score_max * (P.sw_full_threshold / 100.0);
       if (h.score_full >= thr) p2.push_back(&h);                                   // ref: mapping.c:1661 (double compare)
     }
@@ -424,6 +450,12 @@ struct Finalizer {
     dedup_pass(p2, cmp_gen_end);
     std::stable_sort(p2.begin(), p2.end(), [](const FHit* a, const FHit* b) { return (b->pass2_key - a->pass2_key) < 0; });   // ref :1479-1482,1678
     if ((int)p2.size() > P.num_outputs) p2.resize(P.num_outputs);
+  }
+
+  // emits the SAM records of read `rd` (local index) into out; returns number of records
+  int finalize_read(int rd, const GmFullRes* res, const uint8_t* ops, int ops_stride, int n, std::string& out, std::vector<FHit>& fh, std::vector<FHit*>& p2) const {
+    const gm_params_t& P = s->P; const gm_index* ix = s->ix;
+    select_hits(res, ops, n, fh, p2);
     const uint32_t* rw = reads + (size_t)rd * read_words;
     char nbuf[32]; const char* nm; size_t nl;
     if (name_ptr) { nm = name_ptr[rd]; nl = (size_t)name_len[rd]; }
@@ -487,11 +519,11 @@ struct Finalizer {
 // Heavy tier of K2: the few read-strands whose survivors exceed the LDS tier (low-complexity reads,
 // repeats).  Sizes are known now, so every array is allocated exactly, the keys are re-emitted by K1
 // and sorted by one segmented radix sort; then K2 runs on global arrays.  Rare by construction.
-static int run_heavy_tier(gm_session* s, const GmIndexDev& dv, int n, int read_len, int read_words, int W, int n_heavy) {
+static int run_heavy_tier(gm_session* s, DevSet& D, const GmIndexDev& dv, int n, int read_len, int read_words, int W, int n_heavy) {
   hipStream_t q = s->stream;
   std::vector<uint32_t> list(n_heavy), cnt_all((size_t)n * 2);
-  GM_HIP(hipMemcpy(list.data(), s->d_heavy_list, (size_t)n_heavy * 4, hipMemcpyDeviceToHost));
-  GM_HIP(hipMemcpy(cnt_all.data(), s->d_surv_cnt, cnt_all.size() * 4, hipMemcpyDeviceToHost));
+  GM_HIP(hipMemcpy(list.data(), D.d_heavy_list, (size_t)n_heavy * 4, hipMemcpyDeviceToHost));
+  GM_HIP(hipMemcpy(cnt_all.data(), D.d_surv_cnt, cnt_all.size() * 4, hipMemcpyDeviceToHost));
   std::sort(list.begin(), list.end());
   std::vector<uint64_t> off(n_heavy + 1); std::vector<uint32_t> segn(n_heavy), b32(n_heavy), e32(n_heavy);
   uint64_t tot = 0;
@@ -513,17 +545,17 @@ static int run_heavy_tier(gm_session* s, const GmIndexDev& dv, int n, int read_l
   GM_HIP(hipMemcpyAsync(d_e32, e32.data(), (size_t)n_heavy * 4, hipMemcpyHostToDevice, q));
   GM_HIP(hipMemcpyAsync(d_off, off.data(), (size_t)(n_heavy + 1) * 8, hipMemcpyHostToDevice, q));
   GM_HIP(hipMemsetAsync(d_ks, 0xff, tot * 8, q));
-  int rc = gm_launch_lookup_redo(dv, s->d_reads, n, read_len, read_words, n_heavy, d_list, d_off, d_kin, s->d_stats, q);
+  int rc = gm_launch_lookup_redo(dv, D.d_reads, n, read_len, read_words, n_heavy, d_list, d_off, d_kin, s->d_stats, q);
   if (rc == GM_OK)
     rc = gm_launch_anchors_heavy(dv, s->sc, n, read_len, W, n_heavy, d_list, d_off, d_segn, d_b32, d_e32, tot, d_kin, d_ks, d_aux, d_nxt, d_ord,
-                                 s->d_hits, s->d_perm, s->d_hit_cnt, s->hcap, s->d_stats, q);
+                                 D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, s->d_stats, q);
   GM_HIP(hipStreamSynchronize(q));
   (void)hipFree(d_list); (void)hipFree(d_segn); (void)hipFree(d_b32); (void)hipFree(d_e32); (void)hipFree(d_off);
   (void)hipFree(d_kin); (void)hipFree(d_ks); (void)hipFree(d_aux); (void)hipFree(d_nxt); (void)hipFree(d_ord);
   return rc;
 }
 
-static int run_device_pipeline(gm_session* s, int n, int read_len, gm_map_stats_t* st, float* lookup_ms) {
+static int run_device_pipeline(gm_session* s, DevSet& D, int n, int read_len, gm_map_stats_t* st, float* lookup_ms) {
   const gm_index* ix = s->ix;
   const GmIndexDev dv = ix->dev_view();
   const int read_words = (read_len + 7) / 8;
@@ -533,50 +565,50 @@ static int run_device_pipeline(gm_session* s, int n, int read_len, gm_map_stats_
   {
     GM_HIP(hipMemsetAsync(s->d_stats, 0, (size_t)GS_STRIPES * GS_STRIDE * 8, q));
     GM_HIP(hipEventRecord(s->ev[0], q));
-    int rc = gm_launch_lookup(dv, s->d_reads, n, read_len, read_words, s->d_surv, s->d_surv_cnt, s->scap, s->d_heavy_list, s->d_heavy_cnt, 2 * s->eff_batch, s->d_stats, q);
+    int rc = gm_launch_lookup(dv, D.d_reads, n, read_len, read_words, D.d_surv, D.d_surv_cnt, D.scap, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, s->d_stats, q);
     if (rc) return rc;
     GM_HIP(hipEventRecord(s->ev[1], q));
-    rc = gm_launch_anchors(dv, s->sc, n, read_len, W, s->d_surv, s->d_surv_cnt, s->scap, s->d_hits, s->d_perm, s->d_hit_cnt, s->hcap, s->d_stats, q);
+    rc = gm_launch_anchors(dv, s->sc, n, read_len, W, D.d_surv, D.d_surv_cnt, D.scap, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, s->d_stats, q);
     if (rc) return rc;
     uint32_t n_heavy = 0;
-    GM_HIP(hipMemcpyAsync(&n_heavy, s->d_heavy_cnt, 4, hipMemcpyDeviceToHost, q));
+    GM_HIP(hipMemcpyAsync(&n_heavy, D.d_heavy_cnt, 4, hipMemcpyDeviceToHost, q));
     GM_HIP(hipStreamSynchronize(q));
-    if (n_heavy) { rc = run_heavy_tier(s, dv, n, read_len, read_words, W, (int)n_heavy); if (rc) return rc; if (st) st->exact_order_reads += 0; }
+    if (n_heavy) { rc = run_heavy_tier(s, D, dv, n, read_len, read_words, W, (int)n_heavy); if (rc) return rc; if (st) st->exact_order_reads += 0; }
     GM_HIP(hipEventRecord(s->ev[2], q));
-    rc = gm_launch_pass1(dv, s->sc, s->d_reads, n, read_len, read_words, W, overlap_abs, s->d_hits, s->d_perm, s->d_hit_cnt, s->hcap, s->d_slots, s->d_stats, q);
+    rc = gm_launch_pass1(dv, s->sc, D.d_reads, n, read_len, read_words, W, overlap_abs, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, D.d_slots, s->d_stats, q);
     if (rc) return rc;
     GM_HIP(hipEventRecord(s->ev[3], q));
-    rc = gm_launch_select(s->sc, n, read_len, s->d_hits, s->d_perm, s->d_hit_cnt, s->hcap, s->d_sel, s->d_sel_cnt, s->d_sel_off, s->d_work, s->d_n_work, q);
+    rc = gm_launch_select(s->sc, n, read_len, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, D.d_sel, D.d_sel_cnt, D.d_sel_off, D.d_work, D.d_n_work, q);
     if (rc) return rc;
     GM_HIP(hipEventRecord(s->ev[4], q));
     unsigned long long hs[GS_N]; uint32_t n_work = 0;
     std::vector<unsigned long long> hraw((size_t)GS_STRIPES * GS_STRIDE);
     auto fold = [&]() { for (int k = 0; k < GS_N; k++) { hs[k] = 0; for (int t = 0; t < GS_STRIPES; t++) hs[k] += hraw[(size_t)t * GS_STRIDE + k]; } };
-    GM_HIP(hipMemcpyAsync(&n_work, s->d_n_work, 4, hipMemcpyDeviceToHost, q));
+    GM_HIP(hipMemcpyAsync(&n_work, D.d_n_work, 4, hipMemcpyDeviceToHost, q));
     GM_HIP(hipMemcpyAsync(hraw.data(), s->d_stats, hraw.size() * 8, hipMemcpyDeviceToHost, q));
     GM_HIP(hipStreamSynchronize(q));
     fold();
-    const size_t rcap = (size_t)s->eff_batch * s->rcap_per_read;
+    const size_t rcap = (size_t)D.eff_batch * D.rcap_per_read;
     bool retry = false;
     if (hs[GS_OVERFLOW_SURV]) { gm_set_error("heavy list overflow"); return GM_E_OVERFLOW; }
-    if (hs[GS_OVERFLOW_HITS]) { if (s->hcap >= 32768) { gm_set_error("window list overflow at capacity %d", s->hcap); return GM_E_OVERFLOW; } s->hcap *= 4; retry = true; }
-    if (n_work > rcap) { if (s->rcap_per_read >= 32) { gm_set_error("pass-2 work overflow"); return GM_E_OVERFLOW; } s->rcap_per_read = std::min(32, s->rcap_per_read * 2); retry = true; }
+    if (hs[GS_OVERFLOW_HITS]) { if (D.hcap >= 32768) { gm_set_error("window list overflow at capacity %d", D.hcap); return GM_E_OVERFLOW; } D.hcap *= 4; retry = true; }
+    if (n_work > rcap) { if (D.rcap_per_read >= 32) { gm_set_error("pass-2 work overflow"); return GM_E_OVERFLOW; } D.rcap_per_read = std::min(32, D.rcap_per_read * 2); retry = true; }
     if (retry) {   // capacities grew: re-allocate and let the caller re-submit (the sub-batch size may have shrunk)
       if (st) st->retries++;
-      rc = alloc_buffers(s, read_len); if (rc) return rc;
+      rc = alloc_buffers(s, D, read_len); if (rc) return rc;
       return 1;
     }
-    rc = gm_launch_pass2(dv, s->sc, s->d_reads, n, read_len, read_words, W, s->d_hits, s->d_perm, s->hcap, s->d_sel, s->d_sel_cnt, s->d_work, s->d_n_work,
-                         s->d_res, s->d_ops, s->ops_stride, s->d_back, s->back_stride, s->p2_grid, s->d_stats, q);
+    rc = gm_launch_pass2(dv, s->sc, D.d_reads, n, read_len, read_words, W, D.d_hits, D.d_perm, D.hcap, D.d_sel, D.d_sel_cnt, D.d_work, D.d_n_work,
+                         D.d_res, D.d_ops, D.ops_stride, D.d_back, D.back_stride, s->p2_grid, s->d_stats, q);
     if (rc) return rc;
     GM_HIP(hipEventRecord(s->ev[5], q));
-    s->h_res.resize(n_work); s->h_ops.resize((size_t)n_work * s->ops_stride); s->h_sel_cnt.resize(n); s->h_sel_off.resize(n);
+    D.h_res.resize(n_work); D.h_ops.resize((size_t)n_work * D.ops_stride); D.h_sel_cnt.resize(n); D.h_sel_off.resize(n);
     if (n_work) {
-      GM_HIP(hipMemcpyAsync(s->h_res.data(), s->d_res, (size_t)n_work * sizeof(GmFullRes), hipMemcpyDeviceToHost, q));
-      GM_HIP(hipMemcpyAsync(s->h_ops.data(), s->d_ops, (size_t)n_work * s->ops_stride, hipMemcpyDeviceToHost, q));
+      GM_HIP(hipMemcpyAsync(D.h_res.data(), D.d_res, (size_t)n_work * sizeof(GmFullRes), hipMemcpyDeviceToHost, q));
+      GM_HIP(hipMemcpyAsync(D.h_ops.data(), D.d_ops, (size_t)n_work * D.ops_stride, hipMemcpyDeviceToHost, q));
     }
-    GM_HIP(hipMemcpyAsync(s->h_sel_cnt.data(), s->d_sel_cnt, (size_t)n * 4, hipMemcpyDeviceToHost, q));
-    GM_HIP(hipMemcpyAsync(s->h_sel_off.data(), s->d_sel_off, (size_t)n * 4, hipMemcpyDeviceToHost, q));
+    GM_HIP(hipMemcpyAsync(D.h_sel_cnt.data(), D.d_sel_cnt, (size_t)n * 4, hipMemcpyDeviceToHost, q));
+    GM_HIP(hipMemcpyAsync(D.h_sel_off.data(), D.d_sel_off, (size_t)n * 4, hipMemcpyDeviceToHost, q));
     GM_HIP(hipMemcpyAsync(hraw.data(), s->d_stats, hraw.size() * 8, hipMemcpyDeviceToHost, q));
     GM_HIP(hipStreamSynchronize(q));
     fold();
@@ -600,8 +632,9 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   if (!s || n_reads < 0 || read_len < 1) { gm_set_error("gm_map_reads: bad arguments"); return GM_E_ARG; }
   if (read_len > s->P.longest_read_len || read_len >= 32768 / std::max(1, s->P.match_score)) { gm_set_error("read length %d out of range (ref: sw-vector.c:393-398)", read_len); return GM_E_RANGE; }
   GM_HIP(hipSetDevice(s->ix->device));
+  DevSet& D = s->set[0];
   if (stats) memset(stats, 0, sizeof *stats);
-  if (s->cur_len != read_len) { choose_caps(s, read_len); int rc = alloc_buffers(s, read_len); if (rc) return rc; }
+  if (D.cur_len != read_len) { choose_caps(s, D, read_len); int rc = alloc_buffers(s, D, read_len); if (rc) return rc; }
   const int read_words = (read_len + 7) / 8;
   s->last_lookup_ms = 0; s->last_lookup_bytes = 0; s->last_lookup_launches = 0;
   // names
@@ -618,7 +651,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   std::vector<std::unique_ptr<Job>> jobs;
   int nthreads = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
   if (const char* e = getenv("GM_HOST_THREADS")) nthreads = std::max(1, atoi(e));
-  const int ops_stride = s->ops_stride;
+  const int ops_stride = D.ops_stride;
   auto run_job = [&, nthreads, ops_stride](Job* J) {
     auto t0 = std::chrono::steady_clock::now();
     const int n = J->n; const int chunk = 4096; const int nchunks = (n + chunk - 1) / chunk;
@@ -649,18 +682,18 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   for (int base = 0; base < n_reads;) {
     int n, rc; float lk = 0;
     do {
-      n = std::min(s->eff_batch, n_reads - base);
-      if (reads_host) GM_HIP(hipMemcpyAsync(s->d_reads, reads_host + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyHostToDevice, s->stream));
-      else GM_HIP(hipMemcpyAsync(s->d_reads, (const uint32_t*)reads_dev + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyDeviceToDevice, s->stream));
-      rc = run_device_pipeline(s, n, read_len, stats, &lk);
+      n = std::min(D.eff_batch, n_reads - base);
+      if (reads_host) GM_HIP(hipMemcpyAsync(D.d_reads, reads_host + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyHostToDevice, s->stream));
+      else GM_HIP(hipMemcpyAsync(D.d_reads, (const uint32_t*)reads_dev + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyDeviceToDevice, s->stream));
+      rc = run_device_pipeline(s, D, n, read_len, stats, &lk);
     } while (rc == 1);
     if (rc) { for (auto& j : jobs) if (j->th.joinable()) j->th.join(); return rc; }
     s->last_lookup_ms += lk; s->last_lookup_launches++;
     std::unique_ptr<Job> J(new Job());
     J->base = base; J->n = n;
-    J->res.swap(s->h_res); J->ops.swap(s->h_ops); J->sel_cnt.swap(s->h_sel_cnt); J->sel_off.swap(s->h_sel_off);
+    J->res.swap(D.h_res); J->ops.swap(D.h_ops); J->sel_cnt.swap(D.h_sel_cnt); J->sel_off.swap(D.h_sel_off);
     if (reads_host) J->hreads = reads_host + (size_t)base * read_words;
-    else { J->reads.resize((size_t)n * read_words); GM_HIP(hipMemcpy(J->reads.data(), s->d_reads, (size_t)n * read_words * 4, hipMemcpyDeviceToHost)); J->hreads = J->reads.data(); }
+    else { J->reads.resize((size_t)n * read_words); GM_HIP(hipMemcpy(J->reads.data(), D.d_reads, (size_t)n * read_words * 4, hipMemcpyDeviceToHost)); J->hreads = J->reads.data(); }
     // at most two host jobs outstanding
     while (jobs.size() - joined >= 2) { jobs[joined]->th.join(); joined++; }
     Job* jp = J.get();
@@ -705,29 +738,32 @@ extern "C" int gm_last_lookup_timing(gm_session_t* s, double* ms, uint64_t* alg_
   return GM_OK;
 }
 
+#include "gm_host_pairs.inc"
+
 // stage dump for parity tests: hits selected by pass 1, in ext-heap array order (before pass 2 / reverse_hit)
 extern "C" int gm_debug_tophits(gm_session_t* s, int n_reads, int read_len, const uint32_t* reads_packed, long long* rows, long cap, long* n_rows) {
   if (!s) return GM_E_ARG;
   GM_HIP(hipSetDevice(s->ix->device));
-  if (s->cur_len != read_len) { choose_caps(s, read_len); int rc = alloc_buffers(s, read_len); if (rc) return rc; }
-  if (n_reads > s->eff_batch) { gm_set_error("gm_debug_tophits: at most %d reads per call", s->eff_batch); return GM_E_ARG; }
+  DevSet& D = s->set[0];
+  if (D.cur_len != read_len) { choose_caps(s, D, read_len); int rc = alloc_buffers(s, D, read_len); if (rc) return rc; }
+  if (n_reads > D.eff_batch) { gm_set_error("gm_debug_tophits: at most %d reads per call", D.eff_batch); return GM_E_ARG; }
   const int read_words = (read_len + 7) / 8;
   float lk; int rc;
   do {
-    if (n_reads > s->eff_batch) { gm_set_error("gm_debug_tophits: at most %d reads per call", s->eff_batch); return GM_E_ARG; }
-    GM_HIP(hipMemcpyAsync(s->d_reads, reads_packed, (size_t)n_reads * read_words * 4, hipMemcpyHostToDevice, s->stream));
-    rc = run_device_pipeline(s, n_reads, read_len, nullptr, &lk);
+    if (n_reads > D.eff_batch) { gm_set_error("gm_debug_tophits: at most %d reads per call", D.eff_batch); return GM_E_ARG; }
+    GM_HIP(hipMemcpyAsync(D.d_reads, reads_packed, (size_t)n_reads * read_words * 4, hipMemcpyHostToDevice, s->stream));
+    rc = run_device_pipeline(s, D, n_reads, read_len, nullptr, &lk);
   } while (rc == 1);
   if (rc) return rc;
-  std::vector<int32_t> sel((size_t)n_reads * GM_SEL_MAX); std::vector<GmHit> hits((size_t)n_reads * 2 * s->hcap);
-  GM_HIP(hipMemcpy(sel.data(), s->d_sel, sel.size() * 4, hipMemcpyDeviceToHost));
-  GM_HIP(hipMemcpy(hits.data(), s->d_hits, hits.size() * sizeof(GmHit), hipMemcpyDeviceToHost));
+  std::vector<int32_t> sel((size_t)n_reads * GM_SEL_MAX); std::vector<GmHit> hits((size_t)n_reads * 2 * D.hcap);
+  GM_HIP(hipMemcpy(sel.data(), D.d_sel, sel.size() * 4, hipMemcpyDeviceToHost));
+  GM_HIP(hipMemcpy(hits.data(), D.d_hits, hits.size() * sizeof(GmHit), hipMemcpyDeviceToHost));
   long w = 0;
   for (int rd = 0; rd < n_reads; rd++)
-    for (uint32_t k = 0; k < s->h_sel_cnt[rd]; k++) {
+    for (uint32_t k = 0; k < D.h_sel_cnt[rd]; k++) {
       if (w >= cap) { *n_rows = w; return GM_OK; }
       const int id = sel[(size_t)rd * GM_SEL_MAX + k]; const int st = id >> 16, hi = id & 0xFFFF;
-      const GmHit& h = hits[((size_t)rd * 2 + st) * s->hcap + hi];
+      const GmHit& h = hits[((size_t)rd * 2 + st) * D.hcap + hi];
       long long r[12] = {rd, st, h.cn, h.g_off, h.w_len, h.score_vector, h.pct_score_vector, h.matches, h.ax, h.ay, h.alen, h.awidth};
       memcpy(rows + w * 12, r, sizeof r); w++;
     }

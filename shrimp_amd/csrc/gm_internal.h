@@ -62,17 +62,32 @@ int gm_launch_anchors_heavy(const GmIndexDev& ix, const GmScoreDev& sc, int n_re
 // K3 pass 1 (vector SW + overlap rule), one wave per read-strand
 int gm_launch_pass1(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
                     int window_len, int window_overlap_abs, GmHit* d_hits, const uint16_t* d_perm, const uint32_t* d_hit_cnt, int hcap,
-                    unsigned long long* d_slots, unsigned long long* d_stats, hipStream_t stream);
+                    unsigned long long* d_slots, unsigned long long* d_stats, hipStream_t stream,
+                    const int32_t* d_pair_min = nullptr, const uint8_t* d_saved = nullptr);   // paired mode: only_paired / saved windows
 
 // K4a top-K selection (ref: read_get_vector_hits), one thread per read; K4b pass 2, one wave per selected hit
 #define GM_SEL_MAX 64
 int gm_launch_select(const GmScoreDev& sc, int n_reads, int read_len, const GmHit* d_hits, const uint16_t* d_perm,
                      const uint32_t* d_hit_cnt, int hcap, int32_t* d_sel, uint32_t* d_sel_cnt, uint32_t* d_sel_off,
-                     uint32_t* d_work, uint32_t* d_n_work, hipStream_t stream);
+                     uint32_t* d_work, uint32_t* d_n_work, hipStream_t stream, const uint8_t* d_saved = nullptr);
+int gm_launch_build_work(int n_reads, const uint32_t* d_sel_cnt, uint32_t* d_sel_off, uint32_t* d_work, uint32_t* d_n_work, hipStream_t stream);
 int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
-                    int window_len, const GmHit* d_hits, const uint16_t* d_perm, int hcap, const int32_t* d_sel, const uint32_t* d_sel_cnt,
+                    int window_len, GmHit* d_hits, const uint16_t* d_perm, int hcap, const int32_t* d_sel, const uint32_t* d_sel_cnt,
                     const uint32_t* d_work, const uint32_t* d_n_work, GmFullRes* d_res, uint8_t* d_ops, int ops_stride,
-                    uint8_t* d_back, size_t back_stride, int grid, unsigned long long* d_stats, hipStream_t stream);
+                    uint8_t* d_back, size_t back_stride, int grid, unsigned long long* d_stats, hipStream_t stream,
+                    const int32_t* d_sel_sidx = nullptr, int input_strand = 0, int write_back = 0);
+
+// paired mode (gm_pair.hip): mate ranges per window, pair top-K, saved marks, mate reversal
+int gm_launch_revcomp_reads(uint32_t* d_reads, int n_reads, int read_len, int read_words, hipStream_t stream);
+int gm_launch_pair_up(int n_pairs, const GmHit* hits1, const uint16_t* perm1, const uint32_t* cnt1, int hcap1,
+                      const GmHit* hits2, const uint16_t* perm2, const uint32_t* cnt2, int hcap2,
+                      int32_t* pmin1, int32_t* pmax1, int32_t* pmin2, int32_t* pmax2, const int* delta_min, const int* delta_max, hipStream_t stream);
+int gm_launch_pair_select(const GmScoreDev& sc, int n_pairs, int len1, int len2,
+                          const GmHit* hits1, const uint16_t* perm1, const uint32_t* cnt1, int hcap1, const int32_t* pmin1, const int32_t* pmax1,
+                          const GmHit* hits2, const uint16_t* perm2, const uint32_t* cnt2, int hcap2,
+                          int32_t* sel1, int32_t* sidx1, uint32_t* selcnt1, int32_t* sel2, int32_t* sidx2, uint32_t* selcnt2,
+                          uint32_t* pairs, uint32_t* pair_cnt, hipStream_t stream);
+int gm_launch_mark_saved(uint8_t* d_saved, const uint32_t* d_list, int n, hipStream_t stream);
 
 // S1 batch kernel on caller-provided bitfields
 int gm_launch_sw_vector_batch(const GmScoreDev& sc, int n, const uint32_t* d_genome, const long long* d_goff, const int* d_glen,

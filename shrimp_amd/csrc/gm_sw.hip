@@ -158,7 +158,8 @@ __device__ __forceinline__ int thr_of(double frac, int absval, int base) { retur
 __global__ void __launch_bounds__(GM_WAVE)
 k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words,
         int window_len, int overlap_abs, GmHit* __restrict__ hits, const uint16_t* __restrict__ perm,
-        const uint32_t* __restrict__ hit_cnt, int hcap, unsigned long long* __restrict__ slots, unsigned long long* __restrict__ stats) {
+        const uint32_t* __restrict__ hit_cnt, int hcap, unsigned long long* __restrict__ slots, unsigned long long* __restrict__ stats,
+        const int32_t* __restrict__ pair_min, const uint8_t* __restrict__ saved) {
   extern __shared__ __align__(16) uint8_t sm[];
   const int lane = threadIdx.x;
   const int rs = blockIdx.x, rd = rs >> 1, st = rs & 1;
@@ -180,13 +181,16 @@ k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
     const int hi = P[t];
     GmHit* h = &H[hi];
     const int matches = h->matches; const int cn = h->cn; const uint32_t goff = h->g_off; const int w_len = h->w_len;
+    if (pair_min && pair_min[(size_t)rs * hcap + t] < 0) continue;                      // only_paired, ref: mapping.c:1271-1273
     if (matches < sc.min_matches) continue;                                             // ref: mapping.c:1275
+    if (saved && saved[(size_t)rs * hcap + hi]) { last_good_cn = cn; last_good_goff = goff; continue; }   // ref :1279-1284
     if (last_good_cn >= 0 && cn == last_good_cn &&
         (long long)goff + (long long)(uint32_t)overlap_abs <= (long long)(uint32_t)(last_good_goff + (uint32_t)window_len)) {  // ref :1287-1293
       if (lane == 0) { h->score_vector = 0; h->pct_score_vector = 0; }
       continue;
     }
-    // (score_vector <= 0 always holds here in unpaired mode, ref :1295)
+    // ref :1295 -- a window keeps a positive score from an earlier pass (paired mode runs pass 1 twice); unpaired: always <= 0 here
+    if (h->score_vector > 0) continue;
     const uint64_t g0 = (uint64_t)ix.contig_off[cn] + goff;
     load_window(ix.genome, g0, w_len, false, db, lane);
     __syncthreads();
@@ -229,7 +233,8 @@ k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
 #define SEL_MAX 64
 __global__ void __launch_bounds__(64)
 k_select(GmScoreDev sc, int n_reads, int read_len, const GmHit* __restrict__ hits, const uint16_t* __restrict__ perm,
-         const uint32_t* __restrict__ hit_cnt, int hcap, int32_t* __restrict__ sel, uint32_t* __restrict__ sel_cnt) {
+         const uint32_t* __restrict__ hit_cnt, int hcap, int32_t* __restrict__ sel, uint32_t* __restrict__ sel_cnt,
+         const uint8_t* __restrict__ saved) {
   const int rd = blockIdx.x * blockDim.x + threadIdx.x;
   if (rd >= n_reads) return;
   int key[SEL_MAX]; int id[SEL_MAX];
@@ -243,6 +248,7 @@ k_select(GmScoreDev sc, int n_reads, int read_len, const GmHit* __restrict__ hit
     const uint16_t* P = perm + (size_t)rs * hcap;
     for (int t = 0; t < nh; t++) {
       const GmHit& h = H[P[t]];
+      if (saved && saved[(size_t)rs * hcap + P[t]]) continue;                             // ref: mapping.c:1388
       const int score_max = (read_len < (int)h.w_len ? read_len : (int)h.w_len) * sc.match;
       const int k = absthr ? h.score_vector : h.pct_score_vector;
       if (h.score_vector >= thr_of(sc.vect_thr_frac, sc.vect_abs, score_max) && (load < K || k > key[0])) {   // ref: mapping.c:1391-1396
@@ -389,8 +395,9 @@ __device__ FullOut full_sw_wave(const uint8_t* db, int glen, const uint8_t* qr, 
 template <bool BACK_LDS>
 __global__ void __launch_bounds__(GM_WAVE)
 k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words,
-        const GmHit* __restrict__ hits, const uint16_t* __restrict__ perm, int hcap,
-        const int32_t* __restrict__ sel, const uint32_t* __restrict__ sel_cnt,
+        GmHit* __restrict__ hits, const uint16_t* __restrict__ perm, int hcap,
+        const int32_t* __restrict__ sel, const int32_t* __restrict__ sel_sidx, int input_strand, int write_back,
+        const uint32_t* __restrict__ sel_cnt,
         const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work_p,
         GmFullRes* __restrict__ res, uint8_t* __restrict__ ops, int ops_stride,
         uint8_t* __restrict__ back_pool, size_t back_stride, int max_w, unsigned long long* __restrict__ stats) {
@@ -410,15 +417,17 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
     const int id = sel[(size_t)rd * SEL_MAX + k];
     int st = id >> 16; const int hi = id & 0xFFFF;
     const GmHit h = hits[((size_t)rd * 2 + st) * hcap + hi];
-    if (rd != cur_rd) { __syncthreads(); load_read(reads + (size_t)rd * read_words, read_len, false, qr, lane); cur_rd = rd; }
+    // the read in its input orientation == read[input_strand]; a read_reverse'd mate (ref: gmapper.c:174-185) is stored reverse-complemented
+    if (rd != cur_rd) { __syncthreads(); load_read(reads + (size_t)rd * read_words, read_len, input_strand != 0, qr, lane); cur_rd = rd; }
     const int cn = h.cn, w_len = h.w_len;
     const long long clen = (long long)ix.contig_off[cn + 1] - ix.contig_off[cn];
     long long g_off = h.g_off; long long ax = h.ax, ay = h.ay; int gen_st = 0;
-    if (st != 0) {                                              // reverse_hit, ref: mapping.c:254-263; anchor_reverse anchors.h:30-34
+    const size_t slot = ((size_t)rd * 2 + st) * hcap + hi;
+    if (st != input_strand) {                                   // reverse_hit, ref: mapping.c:254-263,337-339; anchor_reverse anchors.h:30-34
       g_off = clen - g_off - w_len;
       ax = -ax + (w_len - 1) - (h.alen - 1) - (h.awidth - 1);
       ay = -ay + (read_len - 1) - (h.alen - 1) + (h.awidth - 1);
-      gen_st = 1; st = 0;
+      gen_st = 1; st = input_strand;
     }
     // the window on the gen_st strand == the + strand window of the original hit, reverse-complemented
     const uint64_t g0 = (uint64_t)ix.contig_off[cn] + h.g_off;
@@ -434,7 +443,8 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
     R.score_vector = sv; R.score_max = score_max; R.matches = h.matches; R.score_window_gen = h.score_window_gen;
     R.score = 0; R.read_start = 0; R.rmapped = 0; R.genome_start = 0; R.gmapped = 0;
     R.n_match = R.n_mismatch = R.n_ins = R.n_del = 0; R.n_ops = 0; R.ops_off = (uint32_t)(wi * (uint32_t)ops_stride);
-    R.sort_idx = (h.cn);   // filled by host
+    R.sort_idx = sel_sidx ? sel_sidx[(size_t)rd * SEL_MAX + k] : 0; R.hit_slot = (uint32_t)slot;
+    if (write_back && lane == 0) hits[slot].score_vector = sv;          // hit_run_full_sw keeps the re-scored value in the hit (ref: mapping.c:386-388)
     if (sv >= thresh) {
       fcalls++;
       // rectangle = anchor_join(1 anchor) + anchor_widen(anchor_width), ref: sw-full-ls.c:176-178, anchors.c:9-61
@@ -600,20 +610,28 @@ int gm_launch_sw_full_single(const GmScoreDev& sc, const uint32_t* d_genome, lon
 // ---- launchers ---------------------------------------------------------------------------------
 int gm_launch_pass1(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
                     int window_len, int window_overlap_abs, GmHit* d_hits, const uint16_t* d_perm, const uint32_t* d_hit_cnt, int hcap,
-                    unsigned long long* d_slots, unsigned long long* d_stats, hipStream_t stream) {
+                    unsigned long long* d_slots, unsigned long long* d_stats, hipStream_t stream, const int32_t* d_pair_min, const uint8_t* d_saved) {
   if (n_reads == 0) return GM_OK;
   const size_t lds = ((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 4 + 64;
   hipLaunchKernelGGL(k_pass1, dim3(n_reads * 2), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
-                     window_len, window_overlap_abs, d_hits, d_perm, d_hit_cnt, hcap, d_slots, d_stats);
+                     window_len, window_overlap_abs, d_hits, d_perm, d_hit_cnt, hcap, d_slots, d_stats, d_pair_min, d_saved);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }
 
 int gm_launch_select(const GmScoreDev& sc, int n_reads, int read_len, const GmHit* d_hits, const uint16_t* d_perm,
                      const uint32_t* d_hit_cnt, int hcap, int32_t* d_sel, uint32_t* d_sel_cnt, uint32_t* d_sel_off,
-                     uint32_t* d_work, uint32_t* d_n_work, hipStream_t stream) {
+                     uint32_t* d_work, uint32_t* d_n_work, hipStream_t stream, const uint8_t* d_saved) {
   if (n_reads == 0) return GM_OK;
-  hipLaunchKernelGGL(k_select, dim3((n_reads + 63) / 64), dim3(64), 0, stream, sc, n_reads, read_len, d_hits, d_perm, d_hit_cnt, hcap, d_sel, d_sel_cnt);
+  hipLaunchKernelGGL(k_select, dim3((n_reads + 63) / 64), dim3(64), 0, stream, sc, n_reads, read_len, d_hits, d_perm, d_hit_cnt, hcap, d_sel, d_sel_cnt, d_saved);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, stream, n_reads, d_sel_cnt, d_sel_off, d_n_work);
+  hipLaunchKernelGGL(k_build_work, dim3((n_reads + 255) / 256), dim3(256), 0, stream, n_reads, d_sel_cnt, d_sel_off, d_work);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+int gm_launch_build_work(int n_reads, const uint32_t* d_sel_cnt, uint32_t* d_sel_off, uint32_t* d_work, uint32_t* d_n_work, hipStream_t stream) {
+  if (n_reads == 0) return GM_OK;
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, stream, n_reads, d_sel_cnt, d_sel_off, d_n_work);
   hipLaunchKernelGGL(k_build_work, dim3((n_reads + 255) / 256), dim3(256), 0, stream, n_reads, d_sel_cnt, d_sel_off, d_work);
   GM_HIP(hipGetLastError());
@@ -621,19 +639,20 @@ int gm_launch_select(const GmScoreDev& sc, int n_reads, int read_len, const GmHi
 }
 
 int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
-                    int window_len, const GmHit* d_hits, const uint16_t* d_perm, int hcap, const int32_t* d_sel, const uint32_t* d_sel_cnt,
+                    int window_len, GmHit* d_hits, const uint16_t* d_perm, int hcap, const int32_t* d_sel, const uint32_t* d_sel_cnt,
                     const uint32_t* d_work, const uint32_t* d_n_work, GmFullRes* d_res, uint8_t* d_ops, int ops_stride,
-                    uint8_t* d_back, size_t back_stride, int grid, unsigned long long* d_stats, hipStream_t stream) {
+                    uint8_t* d_back, size_t back_stride, int grid, unsigned long long* d_stats, hipStream_t stream,
+                    const int32_t* d_sel_sidx, int input_strand, int write_back) {
   if (n_reads == 0) return GM_OK;
   size_t lds = ((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 12 + 64;
   const size_t back_bytes = (size_t)read_len * window_len;
   if (back_bytes <= 40 * 1024) {
     lds += back_bytes + 16;
     hipLaunchKernelGGL(k_pass2<true>, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
-                       d_hits, d_perm, hcap, d_sel, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats);
+                       d_hits, d_perm, hcap, d_sel, d_sel_sidx, input_strand, write_back, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats);
   } else {
     hipLaunchKernelGGL(k_pass2<false>, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
-                       d_hits, d_perm, hcap, d_sel, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats);
+                       d_hits, d_perm, hcap, d_sel, d_sel_sidx, input_strand, write_back, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats);
   }
   GM_HIP(hipGetLastError());
   return GM_OK;

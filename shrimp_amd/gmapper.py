@@ -43,6 +43,21 @@ class MapStats(C.Structure):   # gm_map_stats_t
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+PAIR_MODES = {"opp-in": 1, "opp-out": 2, "col-fw": 3, "col-bw": 4}   # ref: gmapper-definitions.h:42-46, -p option gmapper.c:1583-1600
+
+
+class PairOpts(C.Structure):    # gm_pair_opts_t
+    _fields_ = [("pair_mode", C.c_int), ("min_insert_size", C.c_int), ("max_insert_size", C.c_int),
+                ("insert_size_mean", C.c_double), ("insert_size_stddev", C.c_double), ("half_paired", C.c_int)]
+
+    @staticmethod
+    def default(mode="opp-in", min_insert=0, max_insert=1000):
+        o = PairOpts(); lib().gm_pair_opts_default(C.byref(o))
+        o.pair_mode = PAIR_MODES[mode] if isinstance(mode, str) else int(mode)
+        o.min_insert_size = int(min_insert); o.max_insert_size = int(max_insert)
+        return o
+
+
 class Anchor(C.Structure):      # struct gm_anchor == the reference's struct anchor (gmapper-definitions.h:66-74)
     _fields_ = [("x", C.c_longlong), ("y", C.c_longlong), ("length", C.c_int), ("width", C.c_int),
                 ("weight", C.c_int), ("cn", C.c_int), ("score", C.c_int)]
@@ -59,6 +74,7 @@ EXPORTS = ["gm_last_error", "gm_device_count", "gm_params_default", "gm_index_bu
            "sw_vector_setup", "sw_vector", "sw_vector_stats", "sw_vector_cleanup", "gm_sw_vector_batch",
            "sw_full_ls_setup", "sw_full_ls", "sw_full_ls_cleanup",
            "gm_session_create", "gm_session_free", "gm_map_reads", "gm_map_reads_device", "gm_free", "gm_debug_tophits",
+           "gm_pair_opts_default", "gm_map_pairs",
            "gm_last_lookup_timing"]
 
 _lib = None
@@ -97,6 +113,9 @@ def lib():
     L.gm_map_reads.argtypes = [vp, C.c_int, C.c_int, u32p, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_map_reads_device.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_free.argtypes = [vp]
+    L.gm_pair_opts_default.argtypes = [C.POINTER(PairOpts)]
+    L.gm_map_pairs.argtypes = [vp, C.c_int, C.c_int, u32p, C.c_int, u32p, C.c_char_p, C.c_char_p, C.POINTER(PairOpts),
+                               C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_debug_tophits.argtypes = [vp, C.c_int, C.c_int, u32p, C.POINTER(C.c_longlong), C.c_long, C.POINTER(C.c_long)]
     L.gm_last_lookup_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
     _lib = L
@@ -217,6 +236,24 @@ class Session:
         if names is not None:
             nm = b"\n".join(x if isinstance(x, bytes) else x.encode() for x in names)
         _check(L.gm_map_reads(self.h, n, read_len, packed.ctypes.data_as(C.POINTER(C.c_uint32)), nm, C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_reads")
+        out = C.string_at(sam, sl.value) if sam.value else b""
+        L.gm_free(sam)
+        self.stats = st.as_dict()
+        return out
+
+    def map_pairs(self, mates1: np.ndarray, mates2: np.ndarray, names1=None, names2=None, mode="opp-in", min_insert=0, max_insert=1000,
+                  opts: "PairOpts | None" = None) -> bytes:
+        """Paired mode (-p mode -I min,max): mates1 [n, L1], mates2 [n, L2] uint8 codes -> SAM records of every pair, input order."""
+        from .synth import pack_reads
+        L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
+        m1 = np.ascontiguousarray(mates1, dtype=np.uint8); m2 = np.ascontiguousarray(mates2, dtype=np.uint8)
+        if m1.shape[0] != m2.shape[0]:
+            raise ValueError("mates1 and mates2 must hold the same number of reads")
+        p1 = np.ascontiguousarray(pack_reads(m1)); p2 = np.ascontiguousarray(pack_reads(m2))
+        join = lambda names: None if names is None else b"\n".join(x if isinstance(x, bytes) else x.encode() for x in names)
+        o = opts if opts is not None else PairOpts.default(mode, min_insert, max_insert)
+        _check(L.gm_map_pairs(self.h, m1.shape[0], m1.shape[1], p1.ctypes.data_as(C.POINTER(C.c_uint32)), m2.shape[1], p2.ctypes.data_as(C.POINTER(C.c_uint32)),
+                              join(names1), join(names2), C.byref(o), C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_pairs")
         out = C.string_at(sam, sl.value) if sam.value else b""
         L.gm_free(sam)
         self.stats = st.as_dict()

@@ -112,6 +112,40 @@ def test_sam_matches_reference_golden(gm, name):
     assert got == sam, (_first_diff(got, sam), st)
 
 
+PAIRED = ["pairfix_opp-in", "pairfix_opp-out", "pairfix_col-fw", "pairfix_col-bw", "cfg5s_2x150_1Mbp", "stress_pairs_2x100"]
+
+
+@pytest.mark.parametrize("name", PAIRED)
+def test_paired_sam_matches_reference_golden(gm, name):
+    """paired mode (-p, -I): pair-up, paired pass 1/2, half-paired fall-back, paired MAPQ and mate fields --
+    byte-identical to the reference binary, incl. its own pairing fixture (mates of 30 and 50 bp) in all four modes."""
+    g = oa.load_golden_pairs(name)
+    ix = gm.Index(g["contigs"], names=g["contig_names"])
+    s = gm.Session(ix, max_batch_reads=4096)
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs(g["m1"], g["m2"], g["names1"], g["names2"], mode=g["mode"],
+                                                                        min_insert=g["ins"][0], max_insert=g["ins"][1])
+    st = s.stats
+    s.close(); ix.close()
+    assert got == g["sam"], (_first_diff(got, g["sam"]), st)
+
+
+def test_paired_small_subbatches_and_unpaired_after(gm, oracle_lib):
+    """sub-batch boundaries must not show: 300 pairs in sub-batches of 64, then the same session maps unpaired reads"""
+    g = oa.load_golden_pairs("stress_pairs_2x100")
+    ix = gm.Index(g["contigs"], names=g["contig_names"])
+    s = gm.Session(ix, max_batch_reads=64)
+    n = 300
+    got = s.map_pairs(g["m1"][:n], g["m2"][:n], mode=g["mode"], min_insert=g["ins"][0], max_insert=g["ins"][1])
+    o = oa.Session(g["contigs"], g["contig_names"]); o.set_pairing(g["mode"], *g["ins"])
+    want = o.map_pairs_sam(g["m1"][:n], g["m2"][:n], nthreads=4)
+    assert got == want, _first_diff(got, want)
+    got_u = s.map_reads(g["m1"][:n])
+    o.set_pairing(0, 0, 1000)
+    want_u = o.map_sam(g["m1"][:n], nthreads=4)
+    o.close(); s.close(); ix.close()
+    assert got_u == want_u, _first_diff(got_u, want_u)
+
+
 def test_tophits_match_oracle_on_stress(gm, oracle_lib):
     """stage parity: the pass-1 survivors (ext-heap array order, scores, anchor boxes)"""
     contigs, reads, _ = oa.load_golden("stress_60bp")
