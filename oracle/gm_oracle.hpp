@@ -20,8 +20,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
+#include <omp.h>
+#include <omp.h>
 
 namespace gmo {
 
@@ -168,7 +171,7 @@ static inline uint32_t mapidx_from_window(uint64_t w, const int* sel, int weight
   return m;
 }
 
-static inline void build_index(const Params& P, const Genome& G, Index& I) {
+static inline void build_index_seq(const Params& P, const Genome& G, Index& I) {
   int ns = (int)P.seeds.size();
   I.start.assign(ns, {}); I.pos.assign(ns, {});
 #pragma omp parallel for schedule(dynamic, 1)
@@ -202,6 +205,92 @@ static inline void build_index(const Params& P, const Genome& G, Index& I) {
         }
       }
     }
+  }
+}
+
+// Same index, built by T threads over consecutive genome pieces (test-infrastructure speed only: the
+// 3 Gbp bench baseline needs it in tens of seconds).  Piece t counts into its own histogram, the
+// histograms are turned into per-piece write cursors in genome order, so every list comes out
+// ascending exactly as the sequential builder (and genome.c:1156-1163) produce it.
+static inline void build_index(const Params& P, const Genome& G, Index& I, int nthreads = 0) {
+  const int ns = (int)P.seeds.size();
+  uint64_t total = 0; for (auto l : G.len) total += l;
+  int T = nthreads > 0 ? nthreads : omp_get_max_threads();
+  if (nthreads <= 0 && total < (1u << 22)) T = 1;
+  struct Piece { int cn; uint32_t a, b; };
+  std::vector<std::vector<Piece>> slots(T);
+  {  // cut the genome into T runs of (nearly) equal length, in genome order
+    const uint64_t per = (total + T - 1) / T; uint64_t acc = 0;
+    for (int cn = 0; cn < G.num_contigs(); cn++) {
+      uint32_t a = 0;
+      while (a < G.len[cn]) {
+        const int t = (int)std::min<uint64_t>(T - 1, acc / std::max<uint64_t>(1, per));
+        const uint64_t room = (uint64_t)(t + 1) * per - acc;
+        const uint32_t b = (uint32_t)std::min<uint64_t>(G.len[cn], (uint64_t)a + std::max<uint64_t>(1, room));
+        slots[t].push_back({cn, a, b}); acc += b - a; a = b;
+      }
+    }
+  }
+  std::vector<std::vector<int>> sel(ns); std::vector<size_t> cap(ns);
+  for (int sn = 0; sn < ns; sn++) {
+    cap[sn] = (size_t)1 << (2 * P.seeds[sn].weight);
+    for (int t = 0; t < P.seeds[sn].span; t++) if ((P.seeds[sn].mask >> t) & 1) sel[sn].push_back(t);
+  }
+  I.start.assign(ns, {}); I.pos.assign(ns, {});
+  // k-mers of seed sn that end inside slot t's pieces, in genome order
+  auto scan = [&](int t, int sn, auto&& emit) {
+    const Seed& sd = P.seeds[sn];
+    for (const Piece& pc : slots[t]) {
+      const uint32_t* g = G.fwd[pc.cn].data();
+      int load = 0; uint64_t w = 0;
+      const uint32_t p0 = pc.a >= (uint32_t)(P.max_seed_span - 1) ? pc.a - (uint32_t)(P.max_seed_span - 1) : 0;   // warm-up for the k-mers ending in [a, b)
+      for (uint32_t p = p0; p < pc.b; p++) {
+        const int base = EXTRACT(g, p);
+        w = (w >> 2) | ((uint64_t)(base & 3) << 62);
+        if (base == 15) load = 0; else if (load < P.max_seed_span) load++;      // genome.c:1139-1154
+        if (p < pc.a || load < sd.span) continue;
+        emit(mapidx_from_window(w, sel[sn].data(), (int)sel[sn].size()), G.offsets[pc.cn] + p - sd.span + 1);
+      }
+    }
+  };
+  // Two-level counting sort so that every scatter stays cache-resident: first by the high key bits
+  // into <= 4096 buckets (each slot writes its own sub-range of a bucket, slots in genome order),
+  // then inside each bucket by the low key bits.  Both levels are stable, so lists stay ascending.
+  std::unique_ptr<uint64_t[]> tmp; uint64_t tmp_cap = 0;
+  for (int sn = 0; sn < ns; sn++) {
+    const bool vb = getenv("GMO_VERBOSE") != nullptr; double tv = omp_get_wtime();
+    auto lap = [&](const char* what) { if (vb) { const double n = omp_get_wtime(); fprintf(stderr, "  seed %d %s %.2f s\n", sn, what, n - tv); tv = n; } };
+    const int kbits = 2 * P.seeds[sn].weight, lo_bits = std::min(kbits, 12), nb = 1 << (kbits - lo_bits);
+    std::vector<std::vector<uint64_t>> cur(T, std::vector<uint64_t>(nb, 0));
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+    for (int t = 0; t < T; t++) { uint64_t* c = cur[t].data(); scan(t, sn, [&](uint32_t mi, uint32_t) { c[mi >> lo_bits]++; }); }
+    lap("count");
+    std::vector<uint64_t> bbase(nb + 1, 0);
+    { uint64_t acc = 0;
+      for (int b = 0; b < nb; b++) { bbase[b] = acc; for (int t = 0; t < T; t++) { const uint64_t c = cur[t][b]; cur[t][b] = acc; acc += c; } }
+      bbase[nb] = acc; }
+    const uint64_t n_ent = bbase[nb];
+    if (n_ent > tmp_cap) { tmp.reset(new uint64_t[n_ent]); tmp_cap = n_ent; }   // uninitialised on purpose: every slot is written by the scatter
+    lap("alloc");
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+    for (int t = 0; t < T; t++) {
+      uint64_t* c = cur[t].data(); uint64_t* out = tmp.get();
+      scan(t, sn, [&](uint32_t mi, uint32_t pos) { out[c[mi >> lo_bits]++] = ((uint64_t)(mi & ((1u << lo_bits) - 1)) << 32) | pos; });
+    }
+    lap("scatter");
+    I.start[sn].assign(cap[sn] + 1, 0); I.pos[sn].resize(n_ent);
+    lap("alloc2");
+    uint32_t* st = I.start[sn].data(); uint32_t* ps = I.pos[sn].data();
+#pragma omp parallel for schedule(dynamic, 16) num_threads(T)
+    for (int b = 0; b < nb; b++) {
+      std::vector<uint32_t> c((size_t)1 << lo_bits, 0);
+      for (uint64_t i = bbase[b]; i < bbase[b + 1]; i++) c[tmp[i] >> 32]++;
+      uint64_t acc = bbase[b];
+      for (uint32_t k = 0; k < (1u << lo_bits); k++) { st[((size_t)b << lo_bits) + k] = (uint32_t)acc; const uint32_t n = c[k]; c[k] = (uint32_t)(acc - bbase[b]); acc += n; }
+      for (uint64_t i = bbase[b]; i < bbase[b + 1]; i++) ps[bbase[b] + c[tmp[i] >> 32]++] = (uint32_t)tmp[i];
+    }
+    st[cap[sn]] = (uint32_t)n_ent;
+    lap("buckets");
   }
 }
 

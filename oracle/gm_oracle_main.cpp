@@ -159,13 +159,22 @@ void* gmo_session_create(int n_contigs, const uint8_t* const* codes, const uint6
     char nm[64]; snprintf(nm, sizeof nm, "contig%d", c + 1);
     S->G.add_contig(names && names[c] ? names[c] : nm, codes[c], (size_t)lens[c]);
   }
+  const double t0 = omp_get_wtime();
   build_index(S->M.P, S->G, S->I);
+  if (getenv("GMO_VERBOSE")) fprintf(stderr, "gm_oracle: index built in %.1f s\n", omp_get_wtime() - t0);
   S->M.P.list_cutoff = auto_list_cutoff(S->M.P, S->G);
   S->M.G = &S->G; S->M.I = &S->I;
   return S;
 }
 void gmo_session_destroy(void* s) { delete (Session*)s; }
 unsigned gmo_session_cutoff(void* s) { return ((Session*)s)->M.P.list_cutoff; }
+// the chunk-parallel index builder against the sequential restatement of load_genome (genome.c:1012-1182)
+int gmo_index_selfcheck(void* s, int nthreads) {
+  Session* S = (Session*)s; Index a, b;
+  build_index_seq(S->M.P, S->G, a); build_index(S->M.P, S->G, b, nthreads);
+  return a.start == b.start && a.pos == b.pos && b.start == S->I.start && b.pos == S->I.pos;
+}
+void gmo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 void gmo_session_set_pairing(void* s, int pair_mode, int min_insert, int max_insert) {
   Session* S = (Session*)s; S->M.P.pair_mode = pair_mode; S->M.P.min_insert_size = min_insert; S->M.P.max_insert_size = max_insert;
 }

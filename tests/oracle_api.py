@@ -37,6 +37,8 @@ def load():
     L.gmo_session_set_pairing.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.gmo_map_pairs_sam.argtypes = [C.c_void_p, C.c_int, C.c_int, u8p, C.c_int, u8p, C.c_char_p, C.c_char_p, C.c_int]; L.gmo_map_pairs_sam.restype = C.c_void_p
     L.gmo_free.argtypes = [C.c_void_p]
+    L.gmo_index_selfcheck.argtypes = [C.c_void_p, C.c_int]; L.gmo_index_selfcheck.restype = C.c_int
+    L.gmo_set_threads.argtypes = [C.c_int]
     L.gmo_map_tophits.argtypes = [C.c_void_p, C.c_int, C.c_int, u8p, C.c_int, C.POINTER(C.c_longlong), C.c_long]; L.gmo_map_tophits.restype = C.c_long
     _LIB = L
     return L
@@ -56,6 +58,10 @@ class Session:
         if contig_names is not None:
             self._names = (C.c_char_p * n)(*[bytes(x) for x in contig_names]); names = C.cast(self._names, C.c_void_p)
         self.h = self.L.gmo_session_create(n, ptrs, lens, names)
+
+    def index_selfcheck(self, nthreads):
+        """chunk-parallel index builder == sequential restatement of load_genome (genome.c:1012-1182)"""
+        return bool(self.L.gmo_index_selfcheck(self.h, int(nthreads)))
 
     def set_pairing(self, mode, min_insert, max_insert):
         self.L.gmo_session_set_pairing(self.h, PAIR_MODES[mode] if isinstance(mode, str) else int(mode), int(min_insert), int(max_insert))

@@ -64,3 +64,18 @@ def test_oracle_paired_sam_matches_reference(name, oracle_lib):
     got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_sam(g["m1"], g["m2"], g["names1"], g["names2"], nthreads=4)
     s.close()
     assert got == g["sam"], "oracle paired SAM differs from the reference for %s" % name
+
+
+def test_oracle_parallel_index_builder_equals_sequential(oracle_lib):
+    """the bench's 3 Gbp CPU baseline uses the chunk-parallel builder; it must produce the sequential builder's index
+    (N runs, contig boundaries and pieces that start inside a k-mer included)"""
+    import numpy as np
+    from shrimp_amd import synth
+    contigs = synth.make_genome([1_300_000, 400_000, 700, 25], 9)
+    contigs[0][1000:1200] = 15; contigs[1][:30] = 15; contigs[0][650_000:650_019] = 15
+    s = oa.Session(contigs)
+    try:
+        for t in (1, 2, 3, 7, 16):
+            assert s.index_selfcheck(t), t
+    finally:
+        s.close()
