@@ -136,6 +136,7 @@ def main():
         out["stages_ms_per_step"] = {k: agg[k] / args.steps for k in agg if k.startswith("ms_")}
         out["per_read"] = {"lookups": agg["lookups"] / (R * args.steps), "list_entries": agg["list_entries"] / (R * args.steps),
                            "alg_bytes": agg["list_bytes"] / (R * args.steps), "survivors": agg["survivors"] / (R * args.steps),
+                           "survivors_pruned": agg["survivors_pruned"] / (R * args.steps),
                            "vec_sw_calls": agg["vec_calls"] / (R * args.steps), "full_sw_calls": agg["full_calls"] / (R * args.steps),
                            "mapped_frac": agg["reads_matched"] / (R * args.steps), "exact_order_frac": agg["exact_order_reads"] / (2 * R * args.steps)}
         out["setup_s"] = {"genome_gen": t_gen, "index_build": t_index, "index_bcast": t_bcast, "index_bytes": ix.nbytes}

@@ -146,6 +146,7 @@ typedef struct gm_map_stats {
   uint64_t full_calls, full_cells;                 /* pass-2 (vector re-score + banded full SW) */
   uint64_t exact_order_reads;                      /* read-strands that needed heap-order emulation */
   uint64_t retries;                                /* capacity-overflow re-runs */
+  uint64_t survivors_pruned;                       /* survivors with no neighbour within window_len + read_len, removed before K2 (exact) */
   double   ms_lookup, ms_anchors, ms_pass1, ms_select, ms_pass2, ms_host;   /* device time per stage (events) */
 } gm_map_stats_t;
 

@@ -234,8 +234,9 @@ extern "C" int gm_index_alloc_like(gm_index_t** out, int device, const void* met
 // mapping uses set[0]; paired mapping uses set[0] for the first mates and set[1] for the second.
 struct DevSet {
   // capacities (grown on overflow)
-  int cur_len = -1, scap = 0, hcap = 0, rcap_per_read = 8, ops_stride = 0, eff_batch = 0;
+  int cur_len = -1, scap = 0, scap2 = 0, hcap = 0, rcap_per_read = 8, ops_stride = 0, eff_batch = 0;
   uint32_t* d_reads = nullptr; uint64_t* d_surv = nullptr; uint32_t* d_surv_cnt = nullptr;
+  uint64_t* d_surv2 = nullptr; uint32_t* d_surv_cnt2 = nullptr;            // survivors after the exact isolation prune (K1b) = input of K2
   GmHit* d_hits = nullptr; uint16_t* d_perm = nullptr; uint32_t* d_hit_cnt = nullptr; unsigned long long* d_slots = nullptr;
   uint32_t* d_heavy_list = nullptr; uint32_t* d_heavy_cnt = nullptr;   // read-strands beyond the LDS tier of K2
   int32_t* d_sel = nullptr; int32_t* d_sel_sidx = nullptr; uint32_t* d_sel_cnt = nullptr; uint32_t* d_sel_off = nullptr; uint32_t* d_work = nullptr; uint32_t* d_n_work = nullptr;
@@ -261,11 +262,11 @@ struct gm_session {
 };
 
 static void free_buffers(DevSet& D) {
-  void* ptrs[] = {D.d_reads, D.d_surv, D.d_surv_cnt, D.d_hits, D.d_perm, D.d_hit_cnt, D.d_slots, D.d_heavy_list, D.d_heavy_cnt,
+  void* ptrs[] = {D.d_reads, D.d_surv, D.d_surv_cnt, D.d_surv2, D.d_surv_cnt2, D.d_hits, D.d_perm, D.d_hit_cnt, D.d_slots, D.d_heavy_list, D.d_heavy_cnt,
                   D.d_sel, D.d_sel_sidx, D.d_sel_cnt, D.d_sel_off, D.d_work, D.d_n_work, D.d_res, D.d_ops, D.d_back,
                   D.d_pmin, D.d_pmax, D.d_saved, D.d_saved_list};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  D.d_reads = nullptr; D.d_surv = nullptr; D.d_surv_cnt = nullptr; D.d_hits = nullptr; D.d_perm = nullptr; D.d_hit_cnt = nullptr; D.d_slots = nullptr;
+  D.d_reads = nullptr; D.d_surv = nullptr; D.d_surv_cnt = nullptr; D.d_surv2 = nullptr; D.d_surv_cnt2 = nullptr; D.d_hits = nullptr; D.d_perm = nullptr; D.d_hit_cnt = nullptr; D.d_slots = nullptr;
   D.d_heavy_list = nullptr; D.d_heavy_cnt = nullptr; D.d_sel = nullptr; D.d_sel_sidx = nullptr; D.d_sel_cnt = nullptr; D.d_sel_off = nullptr;
   D.d_work = nullptr; D.d_n_work = nullptr; D.d_res = nullptr; D.d_ops = nullptr; D.d_back = nullptr;
   D.d_pmin = nullptr; D.d_pmax = nullptr; D.d_saved = nullptr; D.d_saved_list = nullptr;
@@ -286,7 +287,7 @@ static int alloc_buffers(gm_session* s, DevSet& D, int read_len, bool paired = f
   const int W = window_len_of(s->P, read_len);
   // sub-batch size under a device-memory budget (candidate windows dominate when hcap has grown)
   const double budget = 16e9;
-  const double per_read = 2.0 * ((double)D.scap * 8 + (double)D.hcap * (sizeof(GmHit) + 2 + 8)) + (double)D.rcap_per_read * (sizeof(GmFullRes) + read_len + W + 16);
+  const double per_read = 2.0 * ((double)(D.scap + D.scap2) * 8 + (double)D.hcap * (sizeof(GmHit) + 2 + 8)) + (double)D.rcap_per_read * (sizeof(GmFullRes) + read_len + W + 16);
   D.eff_batch = (int)std::max(64.0, std::min((double)s->max_batch, budget / per_read));
   const int B = D.eff_batch, rs = 2 * B;
   (void)ix;
@@ -295,6 +296,7 @@ static int alloc_buffers(gm_session* s, DevSet& D, int read_len, bool paired = f
   GM_HIP(hipMalloc(&D.d_reads, (size_t)B * read_words * 4 + 64));
   GM_HIP(hipMalloc(&D.d_surv, (size_t)rs * D.scap * 8));
   GM_HIP(hipMalloc(&D.d_surv_cnt, (size_t)rs * 4));
+  if (D.scap2 > 0) { GM_HIP(hipMalloc(&D.d_surv2, (size_t)rs * D.scap2 * 8)); GM_HIP(hipMalloc(&D.d_surv_cnt2, (size_t)rs * 4)); }
   GM_HIP(hipMalloc(&D.d_hits, (size_t)rs * D.hcap * sizeof(GmHit)));
   GM_HIP(hipMalloc(&D.d_perm, (size_t)rs * D.hcap * 2));
   GM_HIP(hipMalloc(&D.d_hit_cnt, (size_t)rs * 4));
@@ -333,7 +335,10 @@ static void choose_caps(gm_session* s, DevSet& D, int read_len) {
   // scap = capacity of the LDS tier of K2 (16 B of LDS per entry); read-strands beyond it take the heavy tier
   D.scap = std::min(4096, std::max(256, pow2ceil((long long)(1.5 * expected) + 128)));
   D.hcap = 64;
+  // K1b (exact isolation prune) shrinks K2's input; its LDS tier is sized for what typically remains
+  D.scap2 = (s->P.match_mode == 2 && !getenv("GM_NO_PRUNE")) ? std::max(std::min(D.scap, 256), D.scap / 2) : 0;
   if (const char* e = getenv("GM_SCAP")) D.scap = std::min(8192, std::max(64, pow2ceil(atoi(e))));
+  if (const char* e = getenv("GM_SCAP2")) { if (D.scap2) D.scap2 = std::min(D.scap, std::max(64, pow2ceil(atoi(e)))); }
   if (const char* e = getenv("GM_HCAP")) D.hcap = std::min(32768, std::max(4, pow2ceil(atoi(e))));
   (void)max_n_kmers;
 }
@@ -555,6 +560,27 @@ static int run_heavy_tier(gm_session* s, DevSet& D, const GmIndexDev& dv, int n,
   return rc;
 }
 
+// K1b + K2 on the survivors of K1
+static int launch_prune_anchors(gm_session* s, DevSet& D, const GmIndexDev& dv, int n, int read_len, int W) {
+  hipStream_t q = s->stream;
+  if (D.scap2 > 0) {
+    // tight-cluster bound (gm_prune.hip): smallest window-generation threshold over all contigs, in survivors' x extent
+    int e_max = -1;
+    if (s->sc.match > 0 && s->sc.b_go >= 0 && s->sc.b_ge >= 0) {
+      long long min_clen = 1ll << 40;
+      for (int c = 0; c < s->ix->n_contigs; c++) min_clen = std::min<long long>(min_clen, (long long)s->ix->contig_off[c + 1] - s->ix->contig_off[c]);
+      const int w_len = (int)std::min<long long>(W, min_clen);
+      const int base = std::min(read_len, w_len) * s->sc.match;
+      const int thr = s->sc.wgen_thr_frac < 0 ? s->sc.wgen_abs : (int)((double)base * s->sc.wgen_thr_frac);
+      e_max = (thr + s->sc.match - 1) / s->sc.match - s->ix->max_seed_span - 1;
+    }
+    int rc = gm_launch_prune(n, read_len, W, e_max, D.d_surv, D.d_surv_cnt, D.scap, D.d_surv2, D.d_surv_cnt2, D.scap2, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, s->d_stats, q);
+    if (rc) return rc;
+    return gm_launch_anchors(dv, s->sc, n, read_len, W, D.d_surv2, D.d_surv_cnt2, D.scap2, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, s->d_stats, q);
+  }
+  return gm_launch_anchors(dv, s->sc, n, read_len, W, D.d_surv, D.d_surv_cnt, D.scap, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, s->d_stats, q);
+}
+
 static int run_device_pipeline(gm_session* s, DevSet& D, int n, int read_len, gm_map_stats_t* st, float* lookup_ms) {
   const gm_index* ix = s->ix;
   const GmIndexDev dv = ix->dev_view();
@@ -568,7 +594,7 @@ static int run_device_pipeline(gm_session* s, DevSet& D, int n, int read_len, gm
     int rc = gm_launch_lookup(dv, D.d_reads, n, read_len, read_words, D.d_surv, D.d_surv_cnt, D.scap, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, s->d_stats, q);
     if (rc) return rc;
     GM_HIP(hipEventRecord(s->ev[1], q));
-    rc = gm_launch_anchors(dv, s->sc, n, read_len, W, D.d_surv, D.d_surv_cnt, D.scap, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, s->d_stats, q);
+    rc = launch_prune_anchors(s, D, dv, n, read_len, W);
     if (rc) return rc;
     uint32_t n_heavy = 0;
     GM_HIP(hipMemcpyAsync(&n_heavy, D.d_heavy_cnt, 4, hipMemcpyDeviceToHost, q));
@@ -619,7 +645,7 @@ static int run_device_pipeline(gm_session* s, DevSet& D, int n, int read_len, gm
       st->lookups += hs[GS_LOOKUPS]; st->list_entries += hs[GS_ENTRIES]; st->list_bytes += 12ull * hs[GS_LOOKUPS] + 4ull * hs[GS_ENTRIES];
       st->survivors += hs[GS_SURVIVORS]; st->anchors += hs[GS_ANCHORS]; st->windows += hs[GS_WINDOWS];
       st->vec_calls += hs[GS_VEC_CALLS]; st->vec_cells += hs[GS_VEC_CELLS]; st->vec_bypassed += hs[GS_VEC_BYPASSED];
-      st->full_calls += hs[GS_FULL_CALLS]; st->full_cells += hs[GS_FULL_CELLS]; st->exact_order_reads += hs[GS_EXACT_ORDER];
+      st->full_calls += hs[GS_FULL_CALLS]; st->full_cells += hs[GS_FULL_CELLS]; st->exact_order_reads += hs[GS_EXACT_ORDER]; st->survivors_pruned += hs[GS_PRUNED];
       st->ms_lookup += ms[0]; st->ms_anchors += ms[1]; st->ms_pass1 += ms[2]; st->ms_select += ms[3]; st->ms_pass2 += ms[4];
     }
     s->last_lookup_bytes += 12ull * hs[GS_LOOKUPS] + 4ull * hs[GS_ENTRIES];

@@ -1,0 +1,129 @@
+// gm_prune.hip -- K1b: drop survivors that cannot take part in any anchor chain or window (gfx950 only).
+//
+// After the reference's region filter (K1) a read-strand on a 3 Gbp genome keeps ~2 600 list entries,
+// almost all of them chance pairs that merely share a 2 048 bp region.  The reference turns every one
+// into an anchor, merges them through its heap and then finds that nearly all are inert:
+//   * the collapse cache only joins, or is only disturbed between, anchors of one diagonal whose
+//     start positions differ by less than read_len            (ref: gmapper/mapping.c:957-971);
+//   * the window look-back of anchor i only visits anchors j with x_i - x_j <= window_len, and a lone
+//     weight-1 anchor never opens a window in match mode 2    (ref: gmapper/mapping.c:1084-1100,1102-1151).
+// Hence a survivor with no other survivor within D = max(window_len, read_len) positions changes
+// neither the anchor list seen by any other anchor nor the window list; removing it is exact.  (The
+// look-back stops at the first anchor below its bound; an isolated anchor between i and that bound
+// would itself be within window_len of i.  An isolated anchor that overwrites a cache slot could only
+// block a join between two anchors less than read_len apart that it lies between.)  K2 then sorts
+// 3-4x fewer keys on a 3 Gbp genome.  Only the `anchors` statistic changes.
+//
+//
+// Second rule (tight clusters).  In match mode 2 a window needs max_score >= thr = (int)abs_or_pct(window_gen_threshold,
+// min(read_len, w_len) * match) (ref: mapping.c:1153-1155) where max_score is at most short_len * match and
+// short_len = min(dx, dy) + length_i <= (x extent of the anchors involved) + max seed span (a collapsed anchor never
+// extends past its last survivor + span, ref: common/anchors.c:98-119; gap penalties only lower the score).  A group of
+// survivors that is more than D away from every other survivor and spans at most e_max = ceil(thr / match) - max_span - 1
+// positions can therefore open no window and touches nothing outside itself: chance partial matches (one seed hit
+// plus its shifted / other-seed echoes on the same diagonal) are exactly that.  Dropping any subset of such a group
+// is exact as well (the bound holds for the rest), so the test is made per survivor on what its three bins show.
+//
+// One workgroup per read-strand: survivors are binned by position >> bin_bits (bin size >= D) in an LDS
+// hash table holding, per occupied bin, a saturating count and the min/max offset; a survivor is kept
+// if its bin holds two entries or the adjacent bin's nearest entry lies within D.  Conservative where
+// it is not exact (bin size > D), never the other way.
+#include "gm_common.h"
+#include <algorithm>
+#include "gm_internal.h"
+
+__global__ void __launch_bounds__(256)
+k_prune(int n_rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict__ surv_cnt, int scap,
+        uint64_t* __restrict__ surv2, uint32_t* __restrict__ surv_cnt2, int scap2, uint32_t D, int e_max, int bin_bits, int hbits,
+        uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap, unsigned long long* __restrict__ stats) {
+  extern __shared__ __align__(16) uint32_t sm[];
+  __shared__ uint32_t n_keep;
+  const int rs = blockIdx.x, tid = threadIdx.x;
+  const uint32_t n = surv_cnt[rs];
+  if (n > (uint32_t)scap) { if (tid == 0) surv_cnt2[rs] = 0xFFFFFFFFu; return; }      // already on the heavy list (K1)
+  if (n == 0) { if (tid == 0) surv_cnt2[rs] = 0; return; }
+  const uint32_t H = 1u << hbits;
+  uint32_t* keys = sm; uint32_t* info = sm + H;        // info = cnt(2, saturating) << 24 | min_off << 12 | max_off
+  for (uint32_t i = tid; i < H; i += blockDim.x) { keys[i] = 0; info[i] = 0x00FFF000u; }
+  if (tid == 0) n_keep = 0;
+  __syncthreads();
+  const uint64_t* in = surv + (size_t)rs * scap;
+  const uint32_t omask = (1u << bin_bits) - 1u;
+  auto slot_of = [&](uint32_t key) { return (key * 2654435761u) >> (32 - hbits); };
+  for (uint32_t i = tid; i < n; i += blockDim.x) {
+    const uint32_t x = (uint32_t)(in[i] >> 32), key = (x >> bin_bits) + 1u, o = x & omask;
+    uint32_t h = slot_of(key);
+    for (;;) {
+      const uint32_t k = atomicCAS(&keys[h], 0u, key);
+      if (k == 0u || k == key) break;
+      h = (h + 1u) & (H - 1u);
+    }
+    uint32_t old = info[h];
+    for (;;) {
+      const uint32_t c = min(3u, (old >> 24) + 1u), mn = min((old >> 12) & 0xFFFu, o), mx = max(old & 0xFFFu, o);
+      const uint32_t prev = atomicCAS(&info[h], old, (c << 24) | (mn << 12) | mx);
+      if (prev == old) break;
+      old = prev;
+    }
+  }
+  __syncthreads();
+  auto find = [&](uint32_t key) -> uint32_t {          // info of the bin, or 0 when the bin is empty
+    uint32_t h = slot_of(key);
+    for (;;) {
+      const uint32_t k = keys[h];
+      if (k == key) return info[h];
+      if (k == 0u) return 0u;
+      h = (h + 1u) & (H - 1u);
+    }
+  };
+  uint64_t* out = surv2 + (size_t)rs * scap2;
+  for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
+    const uint32_t i = i0 + tid;
+    bool keep = false; uint64_t e = 0;
+    if (i < n) {
+      e = in[i];
+      const uint32_t x = (uint32_t)(e >> 32), bin = x >> bin_bits;
+      const uint32_t own = find(bin + 1u), lf = bin > 0 ? find(bin) : 0u, rt = find(bin + 2u);
+      // (1) isolation: two entries in the bin: the other one is max - min away; three or more: keep
+      keep = (own >> 24) >= 3u || ((own >> 24) == 2u && (own & 0xFFFu) - ((own >> 12) & 0xFFFu) <= D);
+      if (!keep && lf) keep = x - (((bin - 1u) << bin_bits) + (lf & 0xFFFu)) <= D;
+      if (!keep && rt) keep = (((bin + 1u) << bin_bits) + ((rt >> 12) & 0xFFFu)) - x <= D;
+      // (2) tight cluster: everything in the three bins (which cover x -+ (D + e_max)) spans at most e_max positions
+      if (keep && e_max >= 0) {
+        uint32_t gmin = (bin << bin_bits) + ((own >> 12) & 0xFFFu), gmax = (bin << bin_bits) + (own & 0xFFFu);
+        if (lf) gmin = ((bin - 1u) << bin_bits) + ((lf >> 12) & 0xFFFu);
+        if (rt) gmax = ((bin + 1u) << bin_bits) + (rt & 0xFFFu);
+        if (gmax - gmin <= (uint32_t)e_max) keep = false;
+      }
+    }
+    if (keep) { const uint32_t s = atomicAdd(&n_keep, 1u); if (s < (uint32_t)scap2) out[s] = e; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t k = n_keep;
+    if (k > (uint32_t)scap2) {             // still too many for the LDS tier of K2: heavy tier (re-emits all survivors)
+      surv_cnt2[rs] = 0xFFFFFFFFu;
+      const uint32_t hs = atomicAdd(heavy_cnt, 1u);
+      if (hs < (uint32_t)heavy_cap) heavy_list[hs] = (uint32_t)rs; else GS_ADD(stats, GS_OVERFLOW_SURV, 1ull);
+    } else surv_cnt2[rs] = k;
+    GS_ADD(stats, GS_PRUNED, (unsigned long long)(n - min(k, n)));
+  }
+}
+
+int gm_launch_prune(int n_reads, int read_len, int window_len, int e_max, const uint64_t* d_surv, const uint32_t* d_surv_cnt, int scap,
+                    uint64_t* d_surv2, uint32_t* d_surv_cnt2, int scap2, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
+                    unsigned long long* d_stats, hipStream_t stream) {
+  if (n_reads == 0) return GM_OK;
+  const uint32_t D = (uint32_t)std::max(window_len, read_len);
+  if (e_max > read_len) e_max = read_len;
+  int bin_bits = 1; while ((1u << bin_bits) < D + (uint32_t)std::max(0, e_max)) bin_bits++;
+  if (bin_bits > 12) { gm_set_error("prune: D = %u does not fit the 12-bit bin offsets", D); return GM_E_ARG; }
+  int hbits = 6; while ((1 << hbits) < 2 * scap) hbits++;
+  const size_t lds = (size_t)8 << hbits;
+  static size_t configured = 0;
+  if (lds > 48 * 1024 && lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_prune, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
+  hipLaunchKernelGGL(k_prune, dim3(n_reads * 2), dim3(256), lds, stream, n_reads * 2, d_surv, d_surv_cnt, scap, d_surv2, d_surv_cnt2, scap2,
+                     D, e_max, bin_bits, hbits, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
