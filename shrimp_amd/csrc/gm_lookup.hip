@@ -16,6 +16,7 @@
 // or region-1 when it lies in that strip, has count >= 2 (ref :733-742).  Counts do not depend on
 // the visiting order, so the slab sweep reproduces them exactly; slab borders are handled by
 // reading the (rare) entries of the neighbouring slices that can mark a border region.
+#include <algorithm>
 #include "gm_common.h"
 #include "gm_internal.h"
 
@@ -50,7 +51,7 @@ __device__ __forceinline__ bool k1_has2(const uint32_t* bm, uint32_t rloc) {
 
 // dynamic LDS layout: codes[read_len pad 4] | kS[NL] | lbeg[NL] | lend[NL] | lo[NL] | hi[NL] | pre[NL+1] | bitmap[bm_words]
 template <bool BKT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
          int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
          uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap,
@@ -432,6 +433,199 @@ k_lookup_bkt(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int
   if (lane == 0) { GS_ADD(stats, GS_LOOKUPS, lk); GS_ADD(stats, GS_ENTRIES, en); }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1 v3 (large genomes: several slabs, list slices of tens of entries).  Same slab sweep and the same
+// exact region counters as k_lookup; what differs is the lane mapping and the amount of code per entry.
+// rocprofv3 on the 3 Gbp workload showed the lane-per-list kernel neither HBM- nor L2-bound but
+// instruction-issue bound (profiles/r01c_*): ~125 VALU instructions per list entry.  Here
+//   * K1G = 8 lanes share one list slice and read it with ONE dwordx4 each (a 32-position window per
+//     list and wave-instruction), so the per-window bookkeeping is shared by up to 32 entries;
+//   * everything a window needs sits in a 12-byte LDS record per list (pointer to the list, read offset
+//     and seed) plus 16-bit per-slab offsets, fetched from the directory ONCE per list, not per slab;
+//   * one small loop body serves both phases (no unrolling: the first version of this kernel was 27 k
+//     instructions long and paid for it in instruction fetch);
+//   * out-of-slice lanes are steered to a spare counter instead of being branched around.
+// ---------------------------------------------------------------------------------------------
+#define K1G 8
+#define K1W (K1G * 4)    // positions per window
+
+__global__ void __launch_bounds__(1024)
+k_lookup_v3(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
+            int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
+            uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap, unsigned long long* __restrict__ stats) {
+  extern __shared__ __align__(16) uint32_t smem[];
+  __shared__ uint32_t n_surv, n_lists;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int rs = blockIdx.x, rd = rs >> 1, st = rs & 1;
+  uint64_t* out = surv + (size_t)rs * scap_all;
+  const uint32_t scap = (uint32_t)scap_all;
+  const int S = ix.n_slabs, rb = ix.region_bits;
+  const uint32_t rmask = (1u << rb) - 1u, ovl = (uint32_t)ix.region_overlap;
+  // LDS: codes | rec[NL] (3 words: list pointer lo/hi, y << 16 | seed) | doff[NL * (S + 1)] (u16) | bitmap
+  uint8_t* codes = (uint8_t*)smem;
+  const int code_words = (read_len + 3) / 4;
+  uint32_t* rec = smem + code_words;
+  uint16_t* doff = (uint16_t*)(rec + 3 * NL);
+  uint32_t* bm = smem + ((code_words + 3 * NL + (NL * (S + 1) + 1) / 2 + 3) & ~3);
+
+  const uint32_t* rw = reads + (size_t)rd * read_words;
+  for (int i = tid; i < read_len; i += nthr) {
+    int src = st ? (read_len - 1 - i) : i;
+    uint32_t c = (rw[src >> 3] >> ((src & 7) * 4)) & 0xf;
+    if (st) { const uint64_t cm = 0xFBCDE56879A00123ull; c = (uint32_t)(cm >> (c * 4)) & 0xf; }   // complement_base, ref: util.h:125-151
+    codes[i] = (uint8_t)c;
+  }
+  if (tid == 0) { n_surv = 0; n_lists = 0; }
+  __syncthreads();
+
+  const uint32_t* __restrict__ pos0 = ix.seed[0].pos;
+  // ---- map indexes, list bounds, per-slab offsets (ref: mapping.c:53-66, KMER_TO_MAPIDX gmapper.h:349-368) ----
+  // only non-empty lists get a record (compact, any order: the survivors are sorted later)
+  unsigned long long my_lookups = 0, my_entries = 0;
+  for (int off = tid; off < NL; off += nthr) {
+    const int sn = off / max_n_kmers, i = off - sn * max_n_kmers;
+    const int span = ix.seed[sn].span;
+    if (i + span > read_len) continue;
+    const uint64_t mask = ix.seed[sn].mask;
+    uint32_t mapidx = 0;
+    for (int t = 0; t < span; t++)
+      if ((mask >> t) & 1) mapidx = (mapidx << 2) | (codes[i + span - 1 - t] & 3u);
+    const uint32_t* dir = ix.seed[sn].dir + (size_t)mapidx * (uint32_t)S;
+    my_lookups++;
+    const uint32_t b = dir[0], e = dir[S];
+    if (e == b || e - b > ix.list_cutoff) continue;        // ref: mapping.c:497 (longer lists are skipped, not deleted)
+    my_entries += (e - b);
+    const uint32_t j = atomicAdd(&n_lists, 1u);
+    const uint64_t ptr = (uint64_t)((ix.seed[sn].pos + b) - pos0);        // element offset from seed 0's array (both hipMalloc'ed: 256-byte aligned)
+    rec[3 * j] = (uint32_t)ptr; rec[3 * j + 1] = (uint32_t)(ptr >> 32); rec[3 * j + 2] = ((uint32_t)i << 16) | (uint32_t)sn;
+    uint16_t* d = doff + (size_t)j * (S + 1);
+    d[0] = 0; d[S] = (uint16_t)(e - b);
+    for (int s = 1; s < S; s++) d[s] = (uint16_t)(dir[s] - b);
+  }
+  __syncthreads();
+  const int nl = (int)n_lists;
+
+  const int ng = nthr / K1G, g = tid / K1G, gl4 = (tid % K1G) * 4;
+  const uint32_t spare = (uint32_t)bm_words * 16u - 1u;     // counter slot no region of a slab maps to
+  for (int s = 0; s < S; s++) {
+    const uint64_t B = (uint64_t)s << ix.slab_bits;
+    const uint32_t rbase = (uint32_t)(B >> rb);             // local region index = region - rbase + 1
+    const uint32_t rend = (uint32_t)((B + (1ull << ix.slab_bits)) >> rb);
+    {
+      uint4* bm4 = (uint4*)bm; const int n4 = bm_words >> 2;
+      for (int w = tid; w < n4; w += nthr) bm4[w] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    for (int phase = 0; phase < 2; phase++) {
+      for (int j0 = 0; j0 < nl; j0 += ng) {               // uniform trip counts: the survival phase uses wave-wide prefix sums
+        const int j = j0 + g;
+        uint32_t d0 = 0, d1 = 0, dn = 0, ysn = 0;
+        const uint32_t* plist = pos0;
+        if (j < nl) {
+          const uint16_t* d = doff + (size_t)j * (S + 1);
+          d0 = d[s]; d1 = d[s + 1]; dn = d[S]; ysn = rec[3 * j + 2];
+          // the list, addressed from a kernel-argument pointer so that the loads stay global_load (not flat)
+          plist = pos0 + (long long)(((uint64_t)rec[3 * j + 1] << 32) | rec[3 * j]);
+        }
+        const uint32_t nrel = d1 - d0;
+        const uint32_t has_prev = (S > 1 && d0 > 0) ? 1u : 0u, has_next = (S > 1 && d1 < dn) ? 1u : 0u;
+        const uint32_t w_hi = d1 + (phase == 0 ? has_next : 0u);
+        uint32_t w = d0 - (phase == 0 ? has_prev : 0u) + (uint32_t)gl4;
+        if (j >= nl) w = 1u;                                  // w_hi == 0: never active
+        for (; __any(w < w_hi); w += K1W) {
+          const bool wact = w < w_hi;
+          k1_u32x4 v = {0, 0, 0, 0};
+          if (wact) v = *(const k1_u32x4*)(plist + w);
+          const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
+          const uint32_t r0 = w - d0;                                     // wraps to 0xFFFFFFFF for the previous slab's neighbour
+          const uint32_t nv = wact ? nrel : 0u;
+          uint32_t rl[4], widx[4], sh[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            rl[u] = (r0 + (uint32_t)u < nv) ? ((pv[u] >> rb) - rbase + 1u) : spare;     // lanes outside the slice hit a spare counter
+            widx[u] = rl[u] >> 4; sh[u] = (rl[u] & 15u) * 2u;
+          }
+          if (phase == 0) {
+            if (wact) {
+            uint32_t old[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) old[u] = atomicOr(&bm[widx[u]], 1u << sh[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) if ((old[u] >> sh[u]) & 1u) atomicOr(&bm[widx[u]], 2u << sh[u]);
+            uint32_t strip = 0;                                           // overlap strip (ref: mapping.c:521-533): rare
+#pragma unroll
+            for (int u = 0; u < 4; u++) if ((pv[u] & rmask) < ovl && r0 + (uint32_t)u < nv) strip |= 1u << u;
+            if (strip) {
+#pragma unroll
+              for (int u = 0; u < 4; u++) if ((strip >> u) & 1u) k1_mark(bm, rl[u] - 1u);     // region 0's lands on the unused slot 0
+            }
+            if (S > 1) {
+              if (r0 == 0xFFFFFFFFu) {
+                // entries of the previous slab inside the last region before B count for local region 0
+                if ((pv[0] >> rb) + 1u == rbase) {
+                  k1_mark(bm, 0u);
+                  for (uint32_t q = w; q > 0;) { --q; if ((plist[q] >> rb) + 1u != rbase) break; k1_mark(bm, 0u); }
+                }
+              }
+              const uint32_t un = nrel - r0;                              // lane element that is the next slab's first entry
+              if (has_next && un < 4u) {
+                const uint32_t p = un == 0 ? pv[0] : (un == 1 ? pv[1] : (un == 2 ? pv[2] : pv[3]));
+                // entries of the next slab inside the overlap strip count for this slab's last region
+                if ((p >> rb) == rend && (p & rmask) < ovl) {
+                  k1_mark(bm, rend - rbase);
+                  for (uint32_t q = w + un + 1u; q < dn; q++) { const uint32_t pq = plist[q]; if ((pq >> rb) != rend || (pq & rmask) >= ovl) break; k1_mark(bm, rend - rbase); }
+                }
+              }
+            }
+            }
+          } else {
+            uint32_t wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) wv[u] = bm[widx[u]];
+            uint32_t hit = 0, strip = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const bool valid = r0 + (uint32_t)u < nv;
+              if (valid && ((wv[u] >> (sh[u] + 1u)) & 1u)) hit |= 1u << u;
+              else if (valid && (pv[u] & rmask) < ovl && (pv[u] >> rb) > 0) strip |= 1u << u;
+            }
+            if (strip) {
+#pragma unroll
+              for (int u = 0; u < 4; u++) if (((strip >> u) & 1u) && k1_has2(bm, rl[u] - 1u)) hit |= 1u << u;
+            }
+            // one counter update per wave and window: exclusive prefix of the lanes' hit counts
+            const uint32_t c = __popc(hit);
+            uint32_t incl = c;
+#pragma unroll
+            for (int dd = 1; dd < GM_WAVE; dd <<= 1) { const uint32_t o = __shfl_up(incl, dd); if ((tid & (GM_WAVE - 1)) >= dd) incl += o; }
+            const uint32_t tot = __shfl(incl, GM_WAVE - 1);
+            if (tot) {
+              uint32_t basev = 0;
+              if ((tid & (GM_WAVE - 1)) == GM_WAVE - 1) basev = atomicAdd(&n_surv, tot);
+              basev = __shfl(basev, GM_WAVE - 1);
+              uint32_t slot = basev + incl - c;
+#pragma unroll
+              for (int u = 0; u < 4; u++)
+                if ((hit >> u) & 1u) { if (slot < scap) out[slot] = ((uint64_t)pv[u] << 32) | ysn; slot++; }   // sort key of K2: position, read offset y, seed
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    surv_cnt[rs] = n_surv;
+    GS_ADD(stats, GS_SURVIVORS, (unsigned long long)n_surv);
+    if (n_surv > scap) {
+      const uint32_t hs = atomicAdd(heavy_cnt, 1u);
+      if (hs < (uint32_t)heavy_cap) heavy_list[hs] = (uint32_t)rs; else GS_ADD(stats, GS_OVERFLOW_SURV, 1ull);
+    }
+  }
+  for (int d = GM_WAVE / 2; d > 0; d >>= 1) { my_lookups += __shfl_down(my_lookups, d); my_entries += __shfl_down(my_entries, d); }
+  if ((tid & (GM_WAVE - 1)) == 0) { GS_ADD(stats, GS_LOOKUPS, my_lookups); GS_ADD(stats, GS_ENTRIES, my_entries); }
+}
+
 static void k1_geometry(const GmIndexDev& ix, int read_len, int* max_n_kmers, int* NL, int* bm_words, size_t* lds) {
   *max_n_kmers = read_len - ix.min_seed_span + 1;
   if (*max_n_kmers < 0) *max_n_kmers = 0;
@@ -465,10 +659,23 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     const size_t lds_b = (size_t)((((read_len + 3) / 4) + 3) & ~3) * 4 + (size_t)bm_words * 4;
     hipLaunchKernelGGL(k_lookup_bkt, dim3(n_reads * 2), dim3((NL + 63) & ~63), lds_b, stream, ix, d_reads, n_reads, read_len, read_words,
                        max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats);
-  } else
-  hipLaunchKernelGGL(k_lookup<false>, dim3(n_reads * 2), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
-                     max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
-                     (const uint32_t*)nullptr, (const uint64_t*)nullptr, d_stats, getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0);
+  } else if (ix.list_cutoff < 65536u && !getenv("GM_K1_V2")) {
+    const size_t lds3 = (size_t)((((read_len + 3) / 4) + 3 * NL + (NL * (ix.n_slabs + 1) + 1) / 2 + 3) & ~3) * 4 + (size_t)bm_words * 4;
+    static size_t configured3 = 0;
+    if (lds3 > 160 * 1024) { gm_set_error("lookup kernel needs %zu bytes of LDS", lds3); return GM_E_ARG; }
+    if (lds3 > 48 * 1024 && lds3 > configured3) { GM_HIP(hipFuncSetAttribute((const void*)k_lookup_v3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); configured3 = lds3; }
+    int k1_threads = 768;
+    if (const char* e = getenv("GM_K1_THREADS")) k1_threads = std::max(64, std::min(1024, atoi(e) & ~63));
+    hipLaunchKernelGGL(k_lookup_v3, dim3(n_reads * 2), dim3(k1_threads), lds3, stream, ix, d_reads, n_reads, read_len, read_words,
+                       max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats);
+  } else {
+    // one list per lane when the read-strand's lists fit a workgroup: every list slice is in flight at once
+    int k1_threads = std::min(1024, (NL + 63) & ~63);
+    if (const char* e = getenv("GM_K1_THREADS")) k1_threads = std::max(64, std::min(1024, atoi(e) & ~63));
+    hipLaunchKernelGGL(k_lookup<false>, dim3(n_reads * 2), dim3(k1_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+                       max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
+                       (const uint32_t*)nullptr, (const uint64_t*)nullptr, d_stats, getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0);
+  }
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

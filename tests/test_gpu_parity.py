@@ -112,6 +112,37 @@ def test_sam_matches_reference_golden(gm, name):
     assert got == sam, (_first_diff(got, sam), st)
 
 
+KERNEL_VARIANTS = [
+    {"GM_NO_BUCKETS": "1"},                                  # generic lookup kernels on a one-slab index
+    {"GM_SLAB_BITS": "18"},                                  # several slabs: slab borders, per-slab directory (k_lookup_v3)
+    {"GM_SLAB_BITS": "17", "GM_K1_THREADS": "128"},          # more lists than lane groups x register windows
+    {"GM_SLAB_BITS": "18", "GM_K1_V2": "1"},                 # the lane-per-list kernel (also the heavy tier's re-emission)
+    {"GM_NO_PRUNE": "1"},                                    # K2 on the unpruned survivors
+    {"GM_SCAP": "256", "GM_SCAP2": "64"},                    # small LDS tiers: most read-strands take the heavy tier
+]
+
+
+@pytest.mark.parametrize("env", KERNEL_VARIANTS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+@pytest.mark.parametrize("name", ["cfg2s_100bp_2Mbp", "stress_60bp"])
+def test_kernel_variants_match_reference_golden(gm, name, env):
+    """every lookup / prune / anchor code path (bucket, lane-per-list, lane-group, multi-slab, heavy tier) gives the reference's SAM"""
+    import os
+    contigs, reads, sam = oa.load_golden(name)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ix = gm.Index(contigs)
+        s = gm.Session(ix, max_batch_reads=4096)
+        got = oa.sam_header(contigs) + s.map_reads(reads)
+        st = s.stats
+        s.close(); ix.close()
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    assert got == sam, (_first_diff(got, sam), st)
+
+
 PAIRED = ["pairfix_opp-in", "pairfix_opp-out", "pairfix_col-fw", "pairfix_col-bw", "cfg5s_2x150_1Mbp", "stress_pairs_2x100"]
 
 
