@@ -448,25 +448,28 @@ k_lookup_bkt(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int
 // ---------------------------------------------------------------------------------------------
 #define K1G 8
 #define K1W (K1G * 4)    // positions per window
+#define K1Q 4            // windows per lane group whose loads are in flight together
 
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(768)
 k_lookup_v3(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
             int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
-            uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap, unsigned long long* __restrict__ stats) {
+            uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap, unsigned long long* __restrict__ stats, int ablate) {
   extern __shared__ __align__(16) uint32_t smem[];
-  __shared__ uint32_t n_surv, n_lists;
+  __shared__ uint32_t n_surv, n_lists, any_long;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int rs = blockIdx.x, rd = rs >> 1, st = rs & 1;
   uint64_t* out = surv + (size_t)rs * scap_all;
   const uint32_t scap = (uint32_t)scap_all;
   const int S = ix.n_slabs, rb = ix.region_bits;
   const uint32_t rmask = (1u << rb) - 1u, ovl = (uint32_t)ix.region_overlap;
-  // LDS: codes | rec[NL] (3 words: list pointer lo/hi, y << 16 | seed) | doff[NL * (S + 1)] (u16) | bitmap
+  // LDS: codes | rec[NL] (3 words: list offset lo/hi, y << 16 | seed) | wmap[S][2 NL] (u16) | nwin[S] (u16) | doff[NL * (S + 1)] (u16) | bitmap
   uint8_t* codes = (uint8_t*)smem;
   const int code_words = (read_len + 3) / 4;
   uint32_t* rec = smem + code_words;
-  uint16_t* doff = (uint16_t*)(rec + 3 * NL);
-  uint32_t* bm = smem + ((code_words + 3 * NL + (NL * (S + 1) + 1) / 2 + 3) & ~3);
+  uint16_t* wmap_all = (uint16_t*)(rec + 3 * NL);      // [S][2 * NL] window -> list | window number << 15
+  uint16_t* nwin_s = wmap_all + (size_t)S * 2 * NL;    // [S] windows in the flat array of slab s (padded to 2 * ((S + 1) / 2))
+  uint16_t* doff = nwin_s + ((S + 1) & ~1);
+  uint32_t* bm = smem + ((code_words + 3 * NL + S * NL + (S + 1) / 2 + (NL * (S + 1) + 1) / 2 + 3) & ~3);
 
   const uint32_t* rw = reads + (size_t)rd * read_words;
   for (int i = tid; i < read_len; i += nthr) {
@@ -475,7 +478,7 @@ k_lookup_v3(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
     if (st) { const uint64_t cm = 0xFBCDE56879A00123ull; c = (uint32_t)(cm >> (c * 4)) & 0xf; }   // complement_base, ref: util.h:125-151
     codes[i] = (uint8_t)c;
   }
-  if (tid == 0) { n_surv = 0; n_lists = 0; }
+  if (tid == 0) { n_surv = 0; n_lists = 0; any_long = 0; }
   __syncthreads();
 
   const uint32_t* __restrict__ pos0 = ix.seed[0].pos;
@@ -504,8 +507,31 @@ k_lookup_v3(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
   }
   __syncthreads();
   const int nl = (int)n_lists;
+  // Windows per slab: list j contributes ceil((slice + neighbours) / 32) windows; the first two of every list are laid
+  // out in one flat array per slab (wave w builds the array of slab w, w + nwaves, ...), the rest (repeats) is handled apart.
+  for (int sl = tid / GM_WAVE; sl < S; sl += nthr / GM_WAVE) {
+    const int ln = tid & (GM_WAVE - 1);
+    const int per = (nl + GM_WAVE - 1) / GM_WAVE;
+    const int a0 = ln * per, a1 = min(nl, a0 + per);
+    auto nw_of = [&](int a) -> uint32_t {
+      const uint16_t* d = doff + (size_t)a * (S + 1);
+      const uint32_t d0 = d[sl], d1 = d[sl + 1], dn = d[S];
+      const uint32_t lo = d0 - ((S > 1 && d0 > 0) ? 1u : 0u), hi = d1 + ((S > 1 && d1 < dn) ? 1u : 0u);
+      return (hi - lo + K1W - 1) / K1W;
+    };
+    uint32_t sum = 0, lng = 0;
+    for (int a = a0; a < a1; a++) { const uint32_t nw = nw_of(a); sum += min(nw, 2u); lng |= (nw > 2) ? 1u : 0u; }
+    uint32_t incl = sum;
+    for (int dd = 1; dd < GM_WAVE; dd <<= 1) { const uint32_t o = __shfl_up(incl, dd); if (ln >= dd) incl += o; }
+    uint32_t run = incl - sum;
+    uint16_t* wm = wmap_all + (size_t)sl * 2 * NL;
+    for (int a = a0; a < a1; a++) { const uint32_t c = min(nw_of(a), 2u); for (uint32_t k = 0; k < c; k++) wm[run + k] = (uint16_t)((uint32_t)a | (k << 15)); run += c; }
+    if (__any(lng != 0) && ln == 0) any_long = 1u;
+    if (ln == GM_WAVE - 1) nwin_s[sl] = (uint16_t)incl;
+  }
 
   const int ng = nthr / K1G, g = tid / K1G, gl4 = (tid % K1G) * 4;
+  const int lane = tid & (GM_WAVE - 1);
   const uint32_t spare = (uint32_t)bm_words * 16u - 1u;     // counter slot no region of a slab maps to
   for (int s = 0; s < S; s++) {
     const uint64_t B = (uint64_t)s << ix.slab_bits;
@@ -516,98 +542,137 @@ k_lookup_v3(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
       for (int w = tid; w < n4; w += nthr) bm4[w] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    for (int phase = 0; phase < 2; phase++) {
-      for (int j0 = 0; j0 < nl; j0 += ng) {               // uniform trip counts: the survival phase uses wave-wide prefix sums
-        const int j = j0 + g;
-        uint32_t d0 = 0, d1 = 0, dn = 0, ysn = 0;
-        const uint32_t* plist = pos0;
-        if (j < nl) {
-          const uint16_t* d = doff + (size_t)j * (S + 1);
-          d0 = d[s]; d1 = d[s + 1]; dn = d[S]; ysn = rec[3 * j + 2];
-          // the list, addressed from a kernel-argument pointer so that the loads stay global_load (not flat)
-          plist = pos0 + (long long)(((uint64_t)rec[3 * j + 1] << 32) | rec[3 * j]);
-        }
-        const uint32_t nrel = d1 - d0;
-        const uint32_t has_prev = (S > 1 && d0 > 0) ? 1u : 0u, has_next = (S > 1 && d1 < dn) ? 1u : 0u;
-        const uint32_t w_hi = d1 + (phase == 0 ? has_next : 0u);
-        uint32_t w = d0 - (phase == 0 ? has_prev : 0u) + (uint32_t)gl4;
-        if (j >= nl) w = 1u;                                  // w_hi == 0: never active
-        for (; __any(w < w_hi); w += K1W) {
-          const bool wact = w < w_hi;
-          k1_u32x4 v = {0, 0, 0, 0};
-          if (wact) v = *(const k1_u32x4*)(plist + w);
-          const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
-          const uint32_t r0 = w - d0;                                     // wraps to 0xFFFFFFFF for the previous slab's neighbour
-          const uint32_t nv = wact ? nrel : 0u;
-          uint32_t rl[4], widx[4], sh[4];
+    const int nwin = (int)nwin_s[s]; const bool have_long = any_long != 0;
+    const uint16_t* wmap = wmap_all + (size_t)s * 2 * NL;
+    // One 32-position window: the lane owns positions [w, w + 4) of list j (relative to the list's first entry).
+    // rl[u] = local region counter of element u, or `spare` when the element is outside the slice (neighbour, padding).
+    auto region_slots = [&](const bool act, const int j, const uint32_t w, const uint32_t pv[4], uint32_t rl[4], uint32_t& r0, uint32_t& nv, uint32_t& d1, uint32_t& dn) {
+      uint32_t d0 = 0; d1 = 0; dn = 0;
+      if (act) { const uint16_t* d = doff + (size_t)j * (S + 1); d0 = d[s]; d1 = d[s + 1]; dn = d[S]; }
+      nv = d1 - d0;                                                      // 0 for inactive lanes
+      r0 = w - d0;                                                       // wraps to 0xFFFFFFFF for the previous slab's neighbour
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            rl[u] = (r0 + (uint32_t)u < nv) ? ((pv[u] >> rb) - rbase + 1u) : spare;     // lanes outside the slice hit a spare counter
-            widx[u] = rl[u] >> 4; sh[u] = (rl[u] & 15u) * 2u;
+      for (int u = 0; u < 4; u++) rl[u] = (r0 + (uint32_t)u < nv) ? ((pv[u] >> rb) - rbase + 1u) : spare;
+    };
+    auto mark_window = [&](const bool act, const int j, const uint32_t w, const uint32_t pv[4], uint32_t rl[4]) {
+      uint32_t r0, nv, d1, dn;
+      region_slots(act, j, w, pv, rl, r0, nv, d1, dn);
+      if (!act) return;
+      if (ablate & 4) { if ((pv[0] ^ pv[1] ^ pv[2] ^ pv[3]) == 0x12345u) bm[0] = 1; return; }
+      uint32_t old[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) old[u] = atomicOr(&bm[rl[u] >> 4], 1u << ((rl[u] & 15u) * 2u));
+#pragma unroll
+      for (int u = 0; u < 4; u++) if ((old[u] >> ((rl[u] & 15u) * 2u)) & 1u) atomicOr(&bm[rl[u] >> 4], 2u << ((rl[u] & 15u) * 2u));
+      uint32_t strip = 0;                                                // overlap strip (ref: mapping.c:521-533): rare
+#pragma unroll
+      for (int u = 0; u < 4; u++) if ((pv[u] & rmask) < ovl && rl[u] != spare) strip |= 1u << u;
+      if (strip) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) if ((strip >> u) & 1u) k1_mark(bm, rl[u] - 1u);          // region 0's lands on the unused slot 0
+      }
+      if (S > 1) {
+        const uint32_t un = nv - r0;                                     // lane element that is the next slab's first entry
+        if (r0 == 0xFFFFFFFFu || (d1 < dn && un < 4u)) {
+          const uint32_t* plist = pos0 + (long long)(((uint64_t)rec[3 * j + 1] << 32) | rec[3 * j]);
+          if (r0 == 0xFFFFFFFFu) {
+            // entries of the previous slab inside the last region before B count for local region 0
+            if ((pv[0] >> rb) + 1u == rbase) {
+              k1_mark(bm, 0u);
+              for (uint32_t q = w; q > 0;) { --q; if ((plist[q] >> rb) + 1u != rbase) break; k1_mark(bm, 0u); }
+            }
           }
-          if (phase == 0) {
-            if (wact) {
-            uint32_t old[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) old[u] = atomicOr(&bm[widx[u]], 1u << sh[u]);
-#pragma unroll
-            for (int u = 0; u < 4; u++) if ((old[u] >> sh[u]) & 1u) atomicOr(&bm[widx[u]], 2u << sh[u]);
-            uint32_t strip = 0;                                           // overlap strip (ref: mapping.c:521-533): rare
-#pragma unroll
-            for (int u = 0; u < 4; u++) if ((pv[u] & rmask) < ovl && r0 + (uint32_t)u < nv) strip |= 1u << u;
-            if (strip) {
-#pragma unroll
-              for (int u = 0; u < 4; u++) if ((strip >> u) & 1u) k1_mark(bm, rl[u] - 1u);     // region 0's lands on the unused slot 0
+          if (d1 < dn && un < 4u) {
+            const uint32_t p = un == 0 ? pv[0] : (un == 1 ? pv[1] : (un == 2 ? pv[2] : pv[3]));
+            // entries of the next slab inside the overlap strip count for this slab's last region
+            if ((p >> rb) == rend && (p & rmask) < ovl) {
+              k1_mark(bm, rend - rbase);
+              for (uint32_t q = w + un + 1u; q < dn; q++) { const uint32_t pq = plist[q]; if ((pq >> rb) != rend || (pq & rmask) >= ovl) break; k1_mark(bm, rend - rbase); }
             }
-            if (S > 1) {
-              if (r0 == 0xFFFFFFFFu) {
-                // entries of the previous slab inside the last region before B count for local region 0
-                if ((pv[0] >> rb) + 1u == rbase) {
-                  k1_mark(bm, 0u);
-                  for (uint32_t q = w; q > 0;) { --q; if ((plist[q] >> rb) + 1u != rbase) break; k1_mark(bm, 0u); }
-                }
-              }
-              const uint32_t un = nrel - r0;                              // lane element that is the next slab's first entry
-              if (has_next && un < 4u) {
-                const uint32_t p = un == 0 ? pv[0] : (un == 1 ? pv[1] : (un == 2 ? pv[2] : pv[3]));
-                // entries of the next slab inside the overlap strip count for this slab's last region
-                if ((p >> rb) == rend && (p & rmask) < ovl) {
-                  k1_mark(bm, rend - rbase);
-                  for (uint32_t q = w + un + 1u; q < dn; q++) { const uint32_t pq = plist[q]; if ((pq >> rb) != rend || (pq & rmask) >= ovl) break; k1_mark(bm, rend - rbase); }
-                }
-              }
-            }
-            }
-          } else {
-            uint32_t wv[4];
+          }
+        }
+      }
+    };
+    // survival test of a window whose region slots are known; every lane of the wave must call it (ballots)
+    auto test_window = [&](const int j, const uint32_t pv[4], const uint32_t rl[4]) {
+      uint32_t wv[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) wv[u] = bm[widx[u]];
-            uint32_t hit = 0, strip = 0;
+      for (int u = 0; u < 4; u++) wv[u] = bm[rl[u] >> 4];
+      uint32_t hit = 0, strip = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const bool valid = r0 + (uint32_t)u < nv;
-              if (valid && ((wv[u] >> (sh[u] + 1u)) & 1u)) hit |= 1u << u;
-              else if (valid && (pv[u] & rmask) < ovl && (pv[u] >> rb) > 0) strip |= 1u << u;
-            }
-            if (strip) {
+      for (int u = 0; u < 4; u++) {
+        const bool valid = rl[u] != spare;
+        if (valid && ((wv[u] >> ((rl[u] & 15u) * 2u + 1u)) & 1u)) hit |= 1u << u;
+        else if (valid && (pv[u] & rmask) < ovl && (pv[u] >> rb) > 0) strip |= 1u << u;
+      }
+      if (strip) {
 #pragma unroll
-              for (int u = 0; u < 4; u++) if (((strip >> u) & 1u) && k1_has2(bm, rl[u] - 1u)) hit |= 1u << u;
-            }
-            // one counter update per wave and window: exclusive prefix of the lanes' hit counts
-            const uint32_t c = __popc(hit);
-            uint32_t incl = c;
+        for (int u = 0; u < 4; u++) if (((strip >> u) & 1u) && k1_has2(bm, rl[u] - 1u)) hit |= 1u << u;
+      }
+      // one counter update per wave and window; slots are handed out element-major (any order will do: K2 sorts)
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      uint32_t tot = 0, pre[4];
 #pragma unroll
-            for (int dd = 1; dd < GM_WAVE; dd <<= 1) { const uint32_t o = __shfl_up(incl, dd); if ((tid & (GM_WAVE - 1)) >= dd) incl += o; }
-            const uint32_t tot = __shfl(incl, GM_WAVE - 1);
-            if (tot) {
-              uint32_t basev = 0;
-              if ((tid & (GM_WAVE - 1)) == GM_WAVE - 1) basev = atomicAdd(&n_surv, tot);
-              basev = __shfl(basev, GM_WAVE - 1);
-              uint32_t slot = basev + incl - c;
+      for (int u = 0; u < 4; u++) { const unsigned long long bal = __ballot((hit >> u) & 1u); pre[u] = tot + (uint32_t)__popcll(bal & lt); tot += (uint32_t)__popcll(bal); }
+      if (tot) {
+        uint32_t basev = 0;
+        if (lane == 0) basev = atomicAdd(&n_surv, tot);
+        basev = __shfl(basev, 0);
+        if (hit) {
+          const uint32_t ysn = rec[3 * j + 2];
 #pragma unroll
-              for (int u = 0; u < 4; u++)
-                if ((hit >> u) & 1u) { if (slot < scap) out[slot] = ((uint64_t)pv[u] << 32) | ysn; slot++; }   // sort key of K2: position, read offset y, seed
-            }
+          for (int u = 0; u < 4; u++)
+            if ((hit >> u) & 1u) { const uint32_t slot = basev + pre[u]; if (slot < scap) out[slot] = ((uint64_t)pv[u] << 32) | ysn; }   // sort key of K2: position, read offset y, seed
+        }
+      }
+    };
+    // window t of the flat array -> (list, start); false past the slice (no load issued); with_next: include the next slab's neighbour
+    auto locate = [&](const int t, const bool with_next, int& j, uint32_t& w) -> bool {
+      if (t >= nwin) return false;
+      const uint32_t m = wmap[t];
+      j = (int)(m & 0x7FFFu);
+      const uint16_t* d = doff + (size_t)j * (S + 1);
+      const uint32_t d0 = d[s], d1 = d[s + 1], dn = d[S];
+      w = d0 - ((S > 1 && d0 > 0) ? 1u : 0u) + (m >> 15) * K1W + (uint32_t)gl4;
+      return w < d1 + ((with_next && S > 1 && d1 < dn) ? 1u : 0u);
+    };
+    auto load_window = [&](const int j, const uint32_t w) -> k1_u32x4 {
+      return *(const k1_u32x4*)(pos0 + (long long)(((uint64_t)rec[3 * j + 1] << 32) | rec[3 * j]) + w);
+    };
+    for (int phase = 0; phase < ((ablate & 1) ? 1 : 2); phase++) {   // mark, then test
+      for (int t0 = 0; t0 < nwin; t0 += K1Q * ng) {        // K1Q windows per lane group in flight
+        int jq[K1Q]; uint32_t wq[K1Q], pq[K1Q][4]; bool aq[K1Q];
+#pragma unroll
+        for (int q = 0; q < K1Q; q++) {
+          jq[q] = 0; wq[q] = 0;
+          k1_u32x4 v = {0, 0, 0, 0};
+          aq[q] = locate(t0 + q * ng + g, phase == 0, jq[q], wq[q]);
+          if (aq[q] && !(ablate & 16)) v = load_window(jq[q], wq[q]);
+          pq[q][0] = v.x; pq[q][1] = v.y; pq[q][2] = v.z; pq[q][3] = v.w;
+        }
+#pragma unroll
+        for (int q = 0; q < K1Q; q++) {
+          uint32_t rl[4];
+          if (phase == 0) mark_window(aq[q], jq[q], wq[q], pq[q], rl);
+          else { uint32_t r0, nv, d1, dn; region_slots(aq[q], jq[q], wq[q], pq[q], rl, r0, nv, d1, dn); test_window(jq[q], pq[q], rl); }
+        }
+      }
+      if (have_long) {                                      // third and later windows of long slices (repeats)
+        for (int j0 = 0; j0 < nl; j0 += ng) {
+          const int j = j0 + g;
+          uint32_t w = 1u, w_hi = 0u;
+          if (j < nl) {
+            const uint16_t* d = doff + (size_t)j * (S + 1);
+            const uint32_t d0 = d[s], d1 = d[s + 1], dn = d[S];
+            w = d0 - ((S > 1 && d0 > 0) ? 1u : 0u) + 2u * K1W + (uint32_t)gl4;
+            w_hi = d1 + ((phase == 0 && S > 1 && d1 < dn) ? 1u : 0u);
+          }
+          for (; __any(w < w_hi); w += K1W) {
+            const bool act = w < w_hi;
+            uint32_t pv[4] = {0, 0, 0, 0}, rl[4];
+            if (act) { const k1_u32x4 v = load_window(j, w); pv[0] = v.x; pv[1] = v.y; pv[2] = v.z; pv[3] = v.w; }
+            if (phase == 0) mark_window(act, j, w, pv, rl);
+            else { uint32_t r0, nv, d1, dn; region_slots(act, j, w, pv, rl, r0, nv, d1, dn); test_window(j, pv, rl); }
           }
         }
       }
@@ -660,14 +725,15 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     hipLaunchKernelGGL(k_lookup_bkt, dim3(n_reads * 2), dim3((NL + 63) & ~63), lds_b, stream, ix, d_reads, n_reads, read_len, read_words,
                        max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats);
   } else if (ix.list_cutoff < 65536u && !getenv("GM_K1_V2")) {
-    const size_t lds3 = (size_t)((((read_len + 3) / 4) + 3 * NL + (NL * (ix.n_slabs + 1) + 1) / 2 + 3) & ~3) * 4 + (size_t)bm_words * 4;
+    const size_t lds3 = (size_t)((((read_len + 3) / 4) + 3 * NL + ix.n_slabs * NL + (ix.n_slabs + 1) / 2 + (NL * (ix.n_slabs + 1) + 1) / 2 + 3) & ~3) * 4 + (size_t)bm_words * 4;
     static size_t configured3 = 0;
     if (lds3 > 160 * 1024) { gm_set_error("lookup kernel needs %zu bytes of LDS", lds3); return GM_E_ARG; }
     if (lds3 > 48 * 1024 && lds3 > configured3) { GM_HIP(hipFuncSetAttribute((const void*)k_lookup_v3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); configured3 = lds3; }
     int k1_threads = 768;
-    if (const char* e = getenv("GM_K1_THREADS")) k1_threads = std::max(64, std::min(1024, atoi(e) & ~63));
+    if (const char* e = getenv("GM_K1_THREADS")) k1_threads = std::max(64, std::min(768, atoi(e) & ~63));
     hipLaunchKernelGGL(k_lookup_v3, dim3(n_reads * 2), dim3(k1_threads), lds3, stream, ix, d_reads, n_reads, read_len, read_words,
-                       max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats);
+                       max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats,
+                       getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0);
   } else {
     // one list per lane when the read-strand's lists fit a workgroup: every list slice is in flight at once
     int k1_threads = std::min(1024, (NL + 63) & ~63);
