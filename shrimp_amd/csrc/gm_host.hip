@@ -336,7 +336,7 @@ static void choose_caps(gm_session* s, DevSet& D, int read_len) {
   D.scap = std::min(4096, std::max(256, pow2ceil((long long)(1.5 * expected) + 128)));
   D.hcap = 64;
   // K1b (exact isolation prune) shrinks K2's input; its LDS tier is sized for what typically remains
-  D.scap2 = (s->P.match_mode == 2 && !getenv("GM_NO_PRUNE")) ? std::max(std::min(D.scap, 256), D.scap / 2) : 0;
+  D.scap2 = (s->P.match_mode == 2 && !getenv("GM_NO_PRUNE")) ? std::max(std::min(D.scap, 256), D.scap / 8) : 0;
   if (const char* e = getenv("GM_SCAP")) D.scap = std::min(8192, std::max(64, pow2ceil(atoi(e))));
   if (const char* e = getenv("GM_SCAP2")) { if (D.scap2) D.scap2 = std::min(D.scap, std::max(64, pow2ceil(atoi(e)))); }
   if (const char* e = getenv("GM_HCAP")) D.hcap = std::min(32768, std::max(4, pow2ceil(atoi(e))));

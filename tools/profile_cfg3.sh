@@ -6,7 +6,8 @@ R=$PWD; O=$R/gpurun_out/prof_cfg3; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 ARGS="$R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --reads-per-step 262144"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $ARGS > $O/bench_stats.json 2> $O/stats.err
-for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_WAVES" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+PASSES=${PASSES:-"FETCH_SIZE|WRITE_SIZE|SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_LDS|SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES|TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"}
+IFS="|"; for pass in $PASSES; do unset IFS
   tag=$(echo $pass | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $O/pmc_$tag -- python3 $ARGS > $O/bench_$tag.json 2> $O/pmc_$tag.err || echo "pass $tag failed"
   python3 $R/tools/pmc_summary.py $O/pmc_$tag $O/pmc_$tag.summary.csv || true
