@@ -58,6 +58,8 @@ typedef struct gm_params {
   int tiebreak_rev;                            /* Tflag, ref: gmapper.h:87 true */
   int sam_unaligned;                           /* ref: gmapper.h:185 false */
   int longest_read_len;                        /* ref: gmapper-defaults.h:72 1000 */
+  int strata;                                  /* --strata: only the best-scoring hits (ref: gmapper.h:85, mapping.c:1706-1712,2268-2274) false */
+  int max_alignments;                          /* --max-alignments: drop reads with more final hits (ref: gmapper.h:54, mapping.c:1713-1722) 0 = all */
 } gm_params_t;
 
 void gm_params_default(gm_params_t *p);        /* letter-space defaults of the reference binary */

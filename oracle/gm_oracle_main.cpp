@@ -152,9 +152,43 @@ int gmo_sw_full_ls(const uint32_t* genome, int goff, int glen, const uint32_t* r
   return 0;
 }
 
+// opts = "key=value;key=value": the reference's command-line options by their long names (gmapper.c:1040-1140):
+// match mismatch open-r ext-r open-q ext-q match-window cmw-overlap cmw-threshold vec-threshold full-threshold
+// cmw-mode report anchor-width cutoff strata max-alignments seeds (comma separated 0/1 strings)
+static void apply_opts(Params& P, const char* opts) {
+  if (!opts) return;
+  std::string s(opts); size_t i = 0;
+  while (i < s.size()) {
+    size_t e = s.find(';', i); if (e == std::string::npos) e = s.size();
+    std::string kv = s.substr(i, e - i); i = e + 1;
+    size_t q = kv.find('='); if (q == std::string::npos) continue;
+    const std::string k = kv.substr(0, q), v = kv.substr(q + 1); const double d = atof(v.c_str());
+    if (k == "match") P.match_score = (int)d; else if (k == "mismatch") P.mismatch_score = (int)d;
+    else if (k == "open-r") P.a_gap_open_score = (int)d; else if (k == "ext-r") P.a_gap_extend_score = (int)d;
+    else if (k == "open-q") P.b_gap_open_score = (int)d; else if (k == "ext-q") P.b_gap_extend_score = (int)d;
+    else if (k == "match-window") P.window_len = d; else if (k == "cmw-overlap") P.window_overlap = d;
+    else if (k == "cmw-threshold") P.window_gen_threshold = d; else if (k == "vec-threshold") P.sw_vect_threshold = d;
+    else if (k == "full-threshold") P.sw_full_threshold = d; else if (k == "cmw-mode") P.match_mode = (int)d;
+    else if (k == "report") P.num_outputs = (int)d; else if (k == "anchor-width") P.anchor_width = (int)d;
+    else if (k == "cutoff") P.list_cutoff = (uint32_t)d; else if (k == "strata") P.strata = d != 0;
+    else if (k == "max-alignments") P.max_alignments = (int)d;
+    else if (k == "seeds") {
+      P.seeds.clear(); P.max_seed_span = 0; P.min_seed_span = 64;
+      size_t a = 0; while (a < v.size()) { size_t b = v.find(',', a); if (b == std::string::npos) b = v.size(); add_spaced_seed(P, v.substr(a, b - a).c_str()); a = b + 1; }
+    }
+  }
+  derive_score_probs(P);
+}
+
+void* gmo_session_create_opts(int n_contigs, const uint8_t* const* codes, const uint64_t* lens, const char* const* names, const char* opts);
 void* gmo_session_create(int n_contigs, const uint8_t* const* codes, const uint64_t* lens, const char* const* names) {
+  return gmo_session_create_opts(n_contigs, codes, lens, names, nullptr);
+}
+void* gmo_session_create_opts(int n_contigs, const uint8_t* const* codes, const uint64_t* lens, const char* const* names, const char* opts) {
   Session* S = new Session();
   S->M.P = default_params();
+  S->M.P.list_cutoff = 4294967295u;
+  apply_opts(S->M.P, opts);
   for (int c = 0; c < n_contigs; c++) {
     char nm[64]; snprintf(nm, sizeof nm, "contig%d", c + 1);
     S->G.add_contig(names && names[c] ? names[c] : nm, codes[c], (size_t)lens[c]);
@@ -162,7 +196,7 @@ void* gmo_session_create(int n_contigs, const uint8_t* const* codes, const uint6
   const double t0 = omp_get_wtime();
   build_index(S->M.P, S->G, S->I);
   if (getenv("GMO_VERBOSE")) fprintf(stderr, "gm_oracle: index built in %.1f s\n", omp_get_wtime() - t0);
-  S->M.P.list_cutoff = auto_list_cutoff(S->M.P, S->G);
+  if (S->M.P.list_cutoff == 4294967295u) S->M.P.list_cutoff = auto_list_cutoff(S->M.P, S->G);     // DEF_LIST_CUTOFF = automatic (gmapper.c:2811-2837)
   S->M.G = &S->G; S->M.I = &S->I;
   return S;
 }

@@ -36,7 +36,7 @@ extern "C" void gm_params_default(gm_params_t* p) {
   p->sw_vect_threshold = 50.0; p->sw_full_threshold = 50.0;     // LS: vect := full (ref: gmapper.c:2456-2458)
   p->match_mode = 2; p->num_outputs = 10; p->num_tmp_outputs = 30; p->anchor_width = 8;
   p->region_bits = 11; p->region_overlap = 50; p->list_cutoff = 0; p->hash_filter_calls = 1; p->tiebreak_rev = 1;
-  p->sam_unaligned = 0; p->longest_read_len = 1000;
+  p->sam_unaligned = 0; p->longest_read_len = 1000; p->strata = 0; p->max_alignments = 0;
 }
 
 static GmScoreDev make_score(const gm_params_t& P) {
@@ -455,6 +455,8 @@ struct Finalizer {
     dedup_pass(p2, cmp_gen_end);
     std::stable_sort(p2.begin(), p2.end(), [](const FHit* a, const FHit* b) { return (b->pass2_key - a->pass2_key) < 0; });   // ref :1479-1482,1678
     if ((int)p2.size() > P.num_outputs) p2.resize(P.num_outputs);
+    if (P.strata && !p2.empty()) { size_t i = 1; while (i < p2.size() && p2[0]->score_full == p2[i]->score_full) i++; p2.resize(i); }   // ref :1706-1712
+    if (P.max_alignments != 0 && (int)p2.size() > P.max_alignments) p2.clear();                                                        // ref :1713-1722
   }
 
   // emits the SAM records of read `rd` (local index) into out; returns number of records

@@ -30,7 +30,8 @@ class Params(C.Structure):   # gm_params_t (include/gmapper_hip.h)
                 ("sw_vect_threshold", C.c_double), ("sw_full_threshold", C.c_double),
                 ("match_mode", C.c_int), ("num_outputs", C.c_int), ("num_tmp_outputs", C.c_int), ("anchor_width", C.c_int),
                 ("region_bits", C.c_int), ("region_overlap", C.c_int), ("list_cutoff", C.c_uint32),
-                ("hash_filter_calls", C.c_int), ("tiebreak_rev", C.c_int), ("sam_unaligned", C.c_int), ("longest_read_len", C.c_int)]
+                ("hash_filter_calls", C.c_int), ("tiebreak_rev", C.c_int), ("sam_unaligned", C.c_int), ("longest_read_len", C.c_int),
+                ("strata", C.c_int), ("max_alignments", C.c_int)]
 
 
 class MapStats(C.Structure):   # gm_map_stats_t

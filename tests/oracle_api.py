@@ -30,6 +30,7 @@ def load():
                                  C.POINTER(C.c_int), C.c_char_p, C.c_char_p, C.c_int]
     L.gmo_sw_full_ls.restype = C.c_int
     L.gmo_session_create.argtypes = [C.c_int, C.POINTER(u8p), C.POINTER(C.c_uint64), C.c_void_p]; L.gmo_session_create.restype = C.c_void_p
+    L.gmo_session_create_opts.argtypes = [C.c_int, C.POINTER(u8p), C.POINTER(C.c_uint64), C.c_void_p, C.c_char_p]; L.gmo_session_create_opts.restype = C.c_void_p
     L.gmo_session_destroy.argtypes = [C.c_void_p]
     L.gmo_session_cutoff.argtypes = [C.c_void_p]; L.gmo_session_cutoff.restype = C.c_uint
     L.gmo_session_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -48,7 +49,7 @@ PAIR_MODES = {"none": 0, "opp-in": 1, "opp-out": 2, "col-fw": 3, "col-bw": 4}
 
 
 class Session:
-    def __init__(self, contigs, contig_names=None):
+    def __init__(self, contigs, contig_names=None, opts=None):
         self.L = load()
         self.contigs = [np.ascontiguousarray(c, dtype=np.uint8) for c in contigs]
         n = len(self.contigs)
@@ -57,7 +58,7 @@ class Session:
         names = None
         if contig_names is not None:
             self._names = (C.c_char_p * n)(*[bytes(x) for x in contig_names]); names = C.cast(self._names, C.c_void_p)
-        self.h = self.L.gmo_session_create(n, ptrs, lens, names)
+        self.h = self.L.gmo_session_create_opts(n, ptrs, lens, names, opts.encode() if opts else None)
 
     def index_selfcheck(self, nthreads):
         """chunk-parallel index builder == sequential restatement of load_genome (genome.c:1012-1182)"""
@@ -148,3 +149,24 @@ def load_kat():
             else:
                 yield ("F", int(t[1]), int(t[2]), int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7]), int(t[8]),
                        parse_words(t[9]), parse_words(t[10]), [int(x) for x in t[11:20]], t[20], t[21])
+
+
+# Non-default option sets whose reference output is committed as <base>@<tag>.sam.gz (tools/make_golden.py OPTION_CASES):
+# tag -> (base golden, oracle option string (the reference's long option names), product gm_params_t fields, seeds, sam_unaligned)
+OPTION_CASES = {
+    "strata": ("stress_60bp", "strata=1", dict(strata=1), None),
+    "max3_o5": ("stress_60bp", "max-alignments=3;report=5", dict(max_alignments=3, num_outputs=5), None),
+    "scores": ("stress_100bp_unal", "match=8;mismatch=-12;open-r=-30;open-q=-28;ext-r=-5;ext-q=-4;full-threshold=60;vec-threshold=60;"
+               "match-window=150;cmw-overlap=80;cmw-threshold=50;report=6;anchor-width=10",
+               dict(match_score=8, mismatch_score=-12, a_gap_open_score=-30, b_gap_open_score=-28, a_gap_extend_score=-5, b_gap_extend_score=-4,
+                    sw_full_threshold=60.0, sw_vect_threshold=60.0, window_len=150.0, window_overlap=80.0, window_gen_threshold=50.0,
+                    num_outputs=6, anchor_width=10, sam_unaligned=1), None),
+    "seeds": ("cfg2s_100bp_2Mbp", "seeds=1111101111,110110110110111,1110100111010111;cutoff=40", dict(list_cutoff=40),
+              ["1111101111", "110110110110111", "1110100111010111"]),
+    "pairs_strata": ("stress_pairs_2x100", "strata=1;report=4", dict(strata=1, num_outputs=4), None),
+}
+
+
+def load_option_sam(base, tag):
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "%s@%s.sam.gz" % (base, tag)), "rb") as f:
+        return f.read()

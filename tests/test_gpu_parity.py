@@ -143,6 +143,30 @@ def test_kernel_variants_match_reference_golden(gm, name, env):
     assert got == sam, (_first_diff(got, sam), st)
 
 
+@pytest.mark.parametrize("tag", sorted(oa.OPTION_CASES))
+def test_option_sets_match_reference_golden(gm, tag):
+    """non-default options through gm_params_t / custom seeds: --strata, --max-alignments, -o, scores, thresholds, window geometry,
+    anchor width, cutoff; paired --strata -- byte-identical to the reference binary run with the same options"""
+    base, _, fields, seeds = oa.OPTION_CASES[tag]
+    want = oa.load_option_sam(base, tag)
+    p = gm.default_params()
+    for k, v in fields.items(): setattr(p, k, v)
+    if base.startswith("stress_pairs"):
+        g = oa.load_golden_pairs(base)
+        ix = gm.Index(g["contigs"], names=g["contig_names"], seeds=seeds, params=p)
+        s = gm.Session(ix, params=p, max_batch_reads=4096)
+        got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs(g["m1"], g["m2"], g["names1"], g["names2"], mode=g["mode"],
+                                                                            min_insert=g["ins"][0], max_insert=g["ins"][1])
+    else:
+        contigs, reads, _ = oa.load_golden(base)
+        ix = gm.Index(contigs, seeds=seeds, params=p)
+        s = gm.Session(ix, params=p, max_batch_reads=4096)
+        got = oa.sam_header(contigs) + s.map_reads(reads)
+    st = s.stats
+    s.close(); ix.close()
+    assert got == want, (_first_diff(got, want), st)
+
+
 PAIRED = ["pairfix_opp-in", "pairfix_opp-out", "pairfix_col-fw", "pairfix_col-bw", "cfg5s_2x150_1Mbp", "stress_pairs_2x100"]
 
 

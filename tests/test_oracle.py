@@ -79,3 +79,23 @@ def test_oracle_parallel_index_builder_equals_sequential(oracle_lib):
             assert s.index_selfcheck(t), t
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("tag", sorted(oa.OPTION_CASES))
+def test_oracle_option_sets_match_reference(tag, oracle_lib):
+    """non-default options (--strata, --max-alignments, -o, scores, thresholds, window geometry, anchor width, custom seeds,
+    cutoff; paired --strata) against the reference binary run with the same options"""
+    base, opts, _, _ = oa.OPTION_CASES[tag]
+    want = oa.load_option_sam(base, tag)
+    if base.startswith("stress_pairs"):
+        g = oa.load_golden_pairs(base)
+        s = oa.Session(g["contigs"], g["contig_names"], opts=opts)
+        s.set_pairing(g["mode"], *g["ins"])
+        got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_sam(g["m1"], g["m2"], g["names1"], g["names2"], nthreads=4)
+    else:
+        contigs, reads, _ = oa.load_golden(base)
+        s = oa.Session(contigs, opts=opts)
+        if "unal" in base: s.set(True, True)
+        got = oa.sam_header(contigs) + s.map_sam(reads, nthreads=4)
+    s.close()
+    assert got == want, "oracle SAM differs from the reference for option set %s" % tag

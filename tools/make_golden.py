@@ -137,8 +137,45 @@ def paired_cases():
                   [b"q%d:1" % i for i in range(n)], [b"q%d:2" % i for i in range(n)], "opp-in", (100, 600))
 
 
+OPTION_CASES = {
+    # tag: (base golden whose inputs are reused, reference command-line options)
+    "strata":    ("stress_60bp", ["--strata"]),
+    "max3_o5":   ("stress_60bp", ["--max-alignments", "3", "-o", "5"]),
+    "scores":    ("stress_100bp_unal", ["-m", "8", "-i", "-12", "-g", "-30", "-q", "-28", "-e", "-5", "-f", "-4", "-h", "60%", "-w", "150%",
+                                        "-l", "80%", "-r", "50%", "-o", "6", "-a", "10", "--sam-unaligned"]),
+    "seeds":     ("cfg2s_100bp_2Mbp", ["-s", "1111101111,110110110110111,1110100111010111", "-z", "40"]),
+    "pairs_strata": ("stress_pairs_2x100", ["--strata", "-o", "4"]),
+}
+
+
+def option_cases():
+    """non-default options on inputs that are already committed: only the reference's SAM body is stored (<base>@<tag>.sam.gz)"""
+    for tag, (base, extra) in OPTION_CASES.items():
+        z = np.load(os.path.join(OUT, base + ".npz"))
+        contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
+        with tempfile.TemporaryDirectory() as d:
+            g = os.path.join(d, "g.fa"); r = os.path.join(d, "r.fa")
+            if "mates1" in z.files:
+                cn = [bytes(x) for x in z["contig_names"]]
+                write_fa_codes(g, cn, contigs)
+                names = [bytes(n) for pair in zip(z["names1"], z["names2"]) for n in pair]
+                seqs = [q for pair in zip(list(z["mates1"]), list(z["mates2"])) for q in pair]
+                write_fa_codes(r, names, seqs)
+                extra = ["-p", str(z["mode"]), "-I", "%d,%d" % tuple(int(x) for x in z["ins"]), *extra]
+            else:
+                write_fa_codes(g, [b"contig%d" % (i + 1) for i in range(len(contigs))], contigs)
+                write_fa_codes(r, [b"r%d" % i for i in range(len(z["reads"]))], list(z["reads"]))
+            p = subprocess.run([REF, "-N", "4", *extra, r, g], capture_output=True, check=True)
+            body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+        with gzip.open(os.path.join(OUT, "%s@%s.sam.gz" % (base, tag)), "wb", compresslevel=9) as f:
+            f.write(body)
+        print("%s@%s: %d SAM records" % (base, tag, sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@"))))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--options-only" in sys.argv:
+        option_cases(); return
     if "--paired-only" in sys.argv:
         paired_cases(); return
     contigs, reads, _ = synth.make_config("cfg1")
@@ -153,6 +190,7 @@ def main():
         f.write(kat)
     print("sw_kat:", kat.count(b"\nV ") + 1, "vector,", kat.count(b"\nF "), "full")
     paired_cases()
+    option_cases()
 
 
 if __name__ == "__main__":
