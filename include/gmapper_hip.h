@@ -78,6 +78,11 @@ int  gm_index_build(gm_index_t **out, int device, int n_contigs, const uint32_t 
                     const uint32_t *contig_len, const char *const *contig_names,
                     int n_seeds, const char *const *seeds, const gm_params_t *params);
 void gm_index_free(gm_index_t *ix);
+/* The reference's on-disk index ("-S prefix" / "-L prefix": <prefix>.genome + <prefix>.seed.<n>, gzip; ref: gmapper/genome.c:15-270,
+ * 670-831).  gm_index_save writes files stock gmapper can load; gm_index_load reads files stock gmapper wrote (letter space, no -H)
+ * and uploads them -- the lists are taken as they are, only the per-slab directory is derived on the device. */
+int  gm_index_save(const gm_index_t *ix, const char *prefix);
+int  gm_index_load(gm_index_t **out, int device, const char *prefix, const gm_params_t *params);
 /* introspection (mirrors the reference's globals) */
 uint32_t gm_index_list_cutoff(const gm_index_t *ix);
 uint64_t gm_index_bytes(const gm_index_t *ix);

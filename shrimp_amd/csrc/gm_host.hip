@@ -92,20 +92,8 @@ static void choose_slabs(GmIndexHost* ix) {
   if (ix->n_slabs < 1) ix->n_slabs = 1;
 }
 
-extern "C" int gm_index_build(gm_index_t** out, int device, int n_contigs, const uint32_t* const* contigs,
-                              const uint32_t* contig_len, const char* const* contig_names,
-                              int n_seeds, const char* const* seeds, const gm_params_t* params) {
-  if (!out || n_contigs < 1 || !contigs || !contig_len) { gm_set_error("gm_index_build: bad arguments"); return GM_E_ARG; }
-  if (gm_device_count() <= device) { gm_set_error("no HIP device %d (the seed index lives in HBM; there is no CPU path)", device); return GM_E_NODEVICE; }
-  GM_HIP(hipSetDevice(device));
-  gm_index* ix = new gm_index();
-  ix->device = device;
-  if (params) ix->params = *params; else gm_params_default(&ix->params);
-  int rc = GM_OK;
-  if (n_seeds == 0) {   // load_default_seeds(0), letter space: ref gmapper-defaults.h:212-227
-    rc |= add_seed(ix, "11110111101111"); rc |= add_seed(ix, "1111011100100001111"); rc |= add_seed(ix, "1111000011001101111");
-  } else for (int i = 0; i < n_seeds; i++) rc |= add_seed(ix, seeds[i]);
-  if (rc != GM_OK) { delete ix; gm_set_error("invalid spaced seed"); return GM_E_ARG; }
+// shared by gm_index_build and gm_index_load: contig table, cutoff, slabs, genome re-packed into global coordinates and uploaded
+static int index_prepare(gm_index* ix, int n_contigs, const uint32_t* const* contigs, const uint32_t* contig_len, const char* const* contig_names) {
   ix->n_contigs = n_contigs;
   ix->contig_off.resize(n_contigs + 1);
   uint64_t tot = 0;
@@ -114,7 +102,7 @@ extern "C" int gm_index_build(gm_index_t** out, int device, int n_contigs, const
     char nm[64]; snprintf(nm, sizeof nm, "contig%d", c + 1);
     ix->names.push_back(contig_names && contig_names[c] ? contig_names[c] : nm);
   }
-  if (tot >= (1ull << 32)) { delete ix; gm_set_error("genome of %llu bp exceeds the reference's 32-bit global coordinates", (unsigned long long)tot); return GM_E_ARG; }
+  if (tot >= (1ull << 32)) { gm_set_error("genome of %llu bp exceeds the reference's 32-bit global coordinates", (unsigned long long)tot); return GM_E_ARG; }
   ix->contig_off[n_contigs] = (uint32_t)tot;
   ix->total_len = tot;
   // automatic list cutoff (ref: gmapper.c:2811-2837): max(1000, 100*total/4^maxW)
@@ -138,12 +126,31 @@ extern "C" int gm_index_build(gm_index_t** out, int device, int n_contigs, const
       if (sh) g[w0 + k + 1] |= w >> (32 - sh);
     }
   }
-  hipStream_t stream; GM_HIP(hipStreamCreate(&stream));
   GM_HIP(hipMalloc(&ix->d_genome, ix->genome_words * 4));
-  GM_HIP(hipMemcpyAsync(ix->d_genome, g.data(), ix->genome_words * 4, hipMemcpyHostToDevice, stream));
+  GM_HIP(hipMemcpy(ix->d_genome, g.data(), ix->genome_words * 4, hipMemcpyHostToDevice));
   GM_HIP(hipMalloc(&ix->d_contig_off, (size_t)(n_contigs + 1) * 4));
-  GM_HIP(hipMemcpyAsync(ix->d_contig_off, ix->contig_off.data(), (size_t)(n_contigs + 1) * 4, hipMemcpyHostToDevice, stream));
-  GM_HIP(hipStreamSynchronize(stream));
+  GM_HIP(hipMemcpy(ix->d_contig_off, ix->contig_off.data(), (size_t)(n_contigs + 1) * 4, hipMemcpyHostToDevice));
+  return GM_OK;
+}
+
+extern "C" void gm_index_free(gm_index_t* ix);
+extern "C" int gm_index_build(gm_index_t** out, int device, int n_contigs, const uint32_t* const* contigs,
+                              const uint32_t* contig_len, const char* const* contig_names,
+                              int n_seeds, const char* const* seeds, const gm_params_t* params) {
+  if (!out || n_contigs < 1 || !contigs || !contig_len) { gm_set_error("gm_index_build: bad arguments"); return GM_E_ARG; }
+  if (gm_device_count() <= device) { gm_set_error("no HIP device %d (the seed index lives in HBM; there is no CPU path)", device); return GM_E_NODEVICE; }
+  GM_HIP(hipSetDevice(device));
+  gm_index* ix = new gm_index();
+  ix->device = device;
+  if (params) ix->params = *params; else gm_params_default(&ix->params);
+  int rc = GM_OK;
+  if (n_seeds == 0) {   // load_default_seeds(0), letter space: ref gmapper-defaults.h:212-227
+    rc |= add_seed(ix, "11110111101111"); rc |= add_seed(ix, "1111011100100001111"); rc |= add_seed(ix, "1111000011001101111");
+  } else for (int i = 0; i < n_seeds; i++) rc |= add_seed(ix, seeds[i]);
+  if (rc != GM_OK) { delete ix; gm_set_error("invalid spaced seed"); return GM_E_ARG; }
+  rc = index_prepare(ix, n_contigs, contigs, contig_len, contig_names);
+  if (rc != GM_OK) { gm_index_free(ix); return rc; }
+  hipStream_t stream; GM_HIP(hipStreamCreate(&stream));
   rc = gm_index_build_device(ix, stream);
   (void)hipStreamDestroy(stream);
   if (rc != GM_OK) { gm_index_free(ix); return rc; }
@@ -767,6 +774,7 @@ extern "C" int gm_last_lookup_timing(gm_session_t* s, double* ms, uint64_t* alg_
 }
 
 #include "gm_host_pairs.inc"
+#include "gm_index_io.inc"
 
 // stage dump for parity tests: hits selected by pass 1, in ext-heap array order (before pass 2 / reverse_hit)
 extern "C" int gm_debug_tophits(gm_session_t* s, int n_reads, int read_len, const uint32_t* reads_packed, long long* rows, long cap, long* n_rows) {

@@ -77,6 +77,53 @@ __global__ void __launch_bounds__(256) k_build_buckets(const uint32_t* __restric
   }
 }
 
+// directory from CSR lists (index files): dir[k*S + s] = first entry of list k with position >= s << slab_bits
+__global__ void __launch_bounds__(256) k_dir_from_lists(const uint32_t* __restrict__ start, const uint32_t* __restrict__ pos, uint64_t K, int S, int slab_bits,
+                                                        uint32_t* __restrict__ dir) {
+  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; k < K; k += stride) {
+    const uint32_t b = start[k], e = start[k + 1];
+    dir[k * S] = b;
+    for (int s = 1; s < S; s++) {
+      const uint64_t lim = (uint64_t)s << slab_bits;
+      uint32_t lo = b, hi = e;
+      while (lo < hi) { const uint32_t m = lo + ((hi - lo) >> 1); if ((uint64_t)pos[m] < lim) lo = m + 1; else hi = m; }
+      dir[k * S + s] = lo;
+    }
+    if (k == K - 1) dir[K * S] = e;
+  }
+}
+
+// uploads one seed's lists as read from a reference index file (lens[4^w], positions back to back, each list ascending)
+int gm_index_from_lists_device(GmIndexHost* ix, int sn, const uint32_t* lens, const uint32_t* pos, uint32_t total) {
+  GmSeedHost& sd = ix->seeds[sn];
+  const uint64_t K = 1ull << (2 * sd.weight);
+  const uint64_t KS = K * (uint64_t)ix->n_slabs;
+  std::vector<uint32_t> start(K + 1);
+  uint64_t acc = 0;
+  for (uint64_t k = 0; k < K; k++) { start[k] = (uint32_t)acc; acc += lens[k]; }
+  start[K] = (uint32_t)acc;
+  if (acc != total) { gm_set_error("seed %d: list lengths sum to %llu, file says %u", sn, (unsigned long long)acc, total); return GM_E_ARG; }
+  uint32_t* d_start = nullptr;
+  GM_HIP(hipMalloc(&d_start, (K + 1) * 4));
+  GM_HIP(hipMemcpy(d_start, start.data(), (K + 1) * 4, hipMemcpyHostToDevice));
+  sd.n_pos = total;
+  GM_HIP(hipMalloc(&sd.d_pos, (size_t)(total + 64) * 4));
+  GM_HIP(hipMemset(sd.d_pos, 0xff, (size_t)(total + 64) * 4));
+  if (total) GM_HIP(hipMemcpy(sd.d_pos, pos, (size_t)total * 4, hipMemcpyHostToDevice));
+  GM_HIP(hipMalloc(&sd.d_dir, (size_t)(KS + 1 + 16) * 4));
+  hipLaunchKernelGGL(k_dir_from_lists, dim3(256 * 16), dim3(256), 0, 0, d_start, sd.d_pos, K, ix->n_slabs, ix->slab_bits, sd.d_dir);
+  if (ix->n_slabs == 1 && (double)total / (double)K <= 12.0 && !getenv("GM_NO_BUCKETS")) {
+    GM_HIP(hipMalloc(&sd.d_bkt, (size_t)K * 16 * 4));
+    hipLaunchKernelGGL(k_build_buckets, dim3(256 * 16), dim3(256), 0, 0, sd.d_dir, sd.d_pos, K, sd.d_bkt);
+  }
+  GM_HIP(hipDeviceSynchronize());
+  (void)hipFree(d_start);
+  sd.dir_words = KS + 1;
+  return GM_OK;
+}
+
 int gm_index_build_device(GmIndexHost* ix, hipStream_t stream) {
   const uint64_t n = ix->total_len;
   uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_b = nullptr, *d_cnt = nullptr;

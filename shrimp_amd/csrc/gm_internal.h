@@ -38,6 +38,7 @@ enum { GS_LOOKUPS = 0, GS_ENTRIES, GS_SURVIVORS, GS_ANCHORS, GS_WINDOWS, GS_VEC_
 
 // ---- kernel launchers (one per .hip file) -----------------------------------------------------
 int gm_index_build_device(GmIndexHost* ix, hipStream_t stream);
+int gm_index_from_lists_device(GmIndexHost* ix, int sn, const uint32_t* lens, const uint32_t* pos, uint32_t total);
 
 // K1 seed lookup + region filter: one workgroup per read-strand; read-strands with more than scap
 // survivors are listed in d_heavy_list (count in d_surv_cnt) and re-run by gm_launch_lookup_redo

@@ -71,7 +71,7 @@ class SwFullResults(C.Structure):
 
 # every entry point include/gmapper_hip.h declares
 EXPORTS = ["gm_last_error", "gm_device_count", "gm_params_default", "gm_index_build", "gm_index_free", "gm_index_list_cutoff",
-           "gm_index_bytes", "gm_index_n_slabs", "gm_index_has_buckets", "gm_index_get_list", "gm_index_device_array", "gm_index_meta", "gm_index_alloc_like",
+           "gm_index_save", "gm_index_load", "gm_index_bytes", "gm_index_n_slabs", "gm_index_has_buckets", "gm_index_get_list", "gm_index_device_array", "gm_index_meta", "gm_index_alloc_like",
            "sw_vector_setup", "sw_vector", "sw_vector_stats", "sw_vector_cleanup", "gm_sw_vector_batch",
            "sw_full_ls_setup", "sw_full_ls", "sw_full_ls_cleanup",
            "gm_session_create", "gm_session_free", "gm_map_reads", "gm_map_reads_device", "gm_free", "gm_debug_tophits",
@@ -95,6 +95,8 @@ def lib():
     L.gm_params_default.argtypes = [C.POINTER(Params)]
     L.gm_index_build.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(u32p), u32p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_char_p), C.POINTER(Params)]
     L.gm_index_free.argtypes = [vp]
+    L.gm_index_save.argtypes = [vp, C.c_char_p]
+    L.gm_index_load.argtypes = [C.POINTER(vp), C.c_int, C.c_char_p, C.POINTER(Params)]
     L.gm_index_list_cutoff.argtypes = [vp]; L.gm_index_list_cutoff.restype = C.c_uint32
     L.gm_index_bytes.argtypes = [vp]; L.gm_index_bytes.restype = C.c_uint64
     L.gm_index_n_slabs.argtypes = [vp]; L.gm_index_n_slabs.restype = C.c_int
@@ -161,6 +163,19 @@ class Index:
         self.h = C.c_void_p()
         _check(L.gm_index_build(C.byref(self.h), device, n, ptrs, lens, cn, ns, sd, C.byref(self.params)), "gm_index_build")
         self.device = device
+
+    @classmethod
+    def load(cls, prefix: str, params: "Params | None" = None, device: int = 0) -> "Index":
+        """the reference's -L: <prefix>.genome + <prefix>.seed.<n> as written by stock gmapper -S (or by save())"""
+        self = cls.__new__(cls)
+        self.params = params or default_params()
+        self.h = C.c_void_p(); self.device = device; self._packed = []; self.contig_len = []
+        _check(lib().gm_index_load(C.byref(self.h), device, prefix.encode(), C.byref(self.params)), "gm_index_load")
+        return self
+
+    def save(self, prefix: str) -> None:
+        """the reference's -S: files stock gmapper can load with -L"""
+        _check(lib().gm_index_save(self.h, prefix.encode()), "gm_index_save")
 
     @property
     def list_cutoff(self): return lib().gm_index_list_cutoff(self.h)

@@ -1,5 +1,6 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path, through the C ABI, against
 (a) the reference's own golden outputs, (b) the CPU oracle on seeded inputs."""
+import os
 import numpy as np
 import pytest
 from tests import oracle_api as oa
@@ -165,6 +166,49 @@ def test_option_sets_match_reference_golden(gm, tag):
     st = s.stats
     s.close(); ix.close()
     assert got == want, (_first_diff(got, want), st)
+
+
+def _idxfix():
+    import gzip, os
+    d = os.path.join(oa.ROOT, "tests", "golden", "idxfix")
+    z = np.load(os.path.join(d, "inputs.npz"))
+    with gzip.open(os.path.join(d, "from_index.sam.gz"), "rb") as f:
+        sam = f.read()
+    return d, [z["contig0"], z["contig1"]], [bytes(x) for x in z["contig_names"]], z["reads"], str(z["seeds"]).split(","), sam
+
+
+def test_index_files_written_by_the_reference_load_and_map(gm):
+    """gm_index_load on the reference's own -S files (.genome + .seed.N): the SAM equals the reference's -L run, and the
+    index equals the one built here from the same contigs"""
+    d, contigs, names, reads, seeds, sam = _idxfix()
+    ix = gm.Index.load(os.path.join(d, "idx"))
+    s = gm.Session(ix, max_batch_reads=1024)
+    got = oa.sam_header(contigs, names) + s.map_reads(reads)
+    s.close()
+    assert got == sam, _first_diff(got, sam)
+    ix2 = gm.Index(contigs, names=names, seeds=seeds)
+    for sn in range(2):
+        for k in (0, 1, 77, 4095, 4 ** 7 - 1, 12345 % 4 ** 7):
+            assert ix.get_list(sn, k).tolist() == ix2.get_list(sn, k).tolist(), (sn, k)
+    ix.close(); ix2.close()
+
+
+def test_index_files_saved_here_are_the_reference_files(gm, tmp_path):
+    """gm_index_save output, decompressed, is byte-identical to what stock gmapper -S wrote for the same genome and seeds"""
+    import gzip
+    d, contigs, names, reads, seeds, sam = _idxfix()
+    ix = gm.Index(contigs, names=names, seeds=seeds)
+    ix.save(str(tmp_path / "mine"))
+    ix.close()
+    for suffix in (".genome", ".seed.0", ".seed.1"):
+        with gzip.open(os.path.join(d, "idx" + suffix), "rb") as f: want = f.read()
+        with gzip.open(str(tmp_path / ("mine" + suffix)), "rb") as f: got = f.read()
+        assert got == want, (suffix, len(got), len(want))
+    ix = gm.Index.load(str(tmp_path / "mine"))            # and round-trips
+    s = gm.Session(ix, max_batch_reads=1024)
+    got = oa.sam_header(contigs, names) + s.map_reads(reads)
+    s.close(); ix.close()
+    assert got == sam
 
 
 PAIRED = ["pairfix_opp-in", "pairfix_opp-out", "pairfix_col-fw", "pairfix_col-bw", "cfg5s_2x150_1Mbp", "stress_pairs_2x100"]
