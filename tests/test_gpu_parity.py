@@ -277,3 +277,33 @@ def test_index_lists_match_oracle_semantics(gm):
         tot += 1
     ix.close()
     assert tot > 50
+
+
+def test_edge_cases_empty_tiny_long_and_degenerate_reads(gm, oracle_lib):
+    """empty input, reads shorter than every seed, reads of exactly one k-mer, all-N and homopolymer reads, 600 and 1000 bp reads
+    (multi-stripe vector SW, global back-pointer scratch), over-long reads: HIP == oracle, errors as documented"""
+    rng = np.random.default_rng(11)
+    contigs, _, _ = oa.load_golden("stress_60bp")
+    big = max(contigs, key=len)
+    ix = gm.Index(contigs); s = gm.Session(ix, max_batch_reads=256)
+    o = oa.Session(contigs)
+    assert s.map_reads(np.zeros((0, 50), dtype=np.uint8)) == b""                       # empty batch
+    assert s.map_pairs(np.zeros((0, 50), dtype=np.uint8), np.zeros((0, 40), dtype=np.uint8)) == b""
+    for L in (8, 13, 14, 15, 19, 20, 33):                                               # around the seed spans 14 / 19 / 19
+        st0 = rng.integers(0, len(big) - L - 1, size=40)
+        reads = np.stack([big[a:a + L] for a in st0]).astype(np.uint8)
+        assert s.map_reads(reads) == o.map_sam(reads, nthreads=2), L
+    L = 70
+    reads = np.stack([big[a:a + L] for a in rng.integers(0, len(big) - L - 1, size=24)]).astype(np.uint8)
+    reads[0] = 15; reads[1] = 0; reads[2] = 3; reads[3, ::2] = 15; reads[4, :40] = 15   # all N, poly-A, poly-T, every other base N, N prefix
+    assert s.map_reads(reads) == o.map_sam(reads, nthreads=2)
+    for L, n in ((600, 12), (1000, 6)):
+        st0 = rng.integers(0, len(big) - L - 1, size=n)
+        reads = np.stack([big[a:a + L].copy() for a in st0]).astype(np.uint8)
+        mut = rng.random(reads.shape) < 0.03
+        reads = np.where(mut, rng.integers(0, 4, size=reads.shape), reads).astype(np.uint8)
+        reads[1] = reads[1][::-1].copy()                                                # a read that should not map as is
+        assert s.map_reads(reads) == o.map_sam(reads, nthreads=2), L
+    with pytest.raises(gm.GmError):                                                     # longer than --longest-read (ref: gmapper.c:497-507 skips it)
+        s.map_reads(np.zeros((1, 1001), dtype=np.uint8))
+    o.close(); s.close(); ix.close()
