@@ -194,7 +194,7 @@ k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
     const uint64_t g0 = (uint64_t)ix.contig_off[cn] + goff;
     load_window(ix.genome, g0, w_len, false, db, lane);
     __syncthreads();
-    int score = -1;
+    int score = -1; bool computed = false;
     uint32_t slot = 0;
     if (sc.hash_filter_calls) {                                                          // f1_run look-up, ref: f1-wrapper.h:103-114
       slot = window_hash_slot(db, w_len, lane);
@@ -209,7 +209,7 @@ k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
       if (found >= 0) { score = (int)(__hip_atomic_load(&SL[found], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32); bypass++; }
     }
     if (score < 0) {
-      score = sw_vector_wave(db, w_len, qr, read_len, sc, carry, lane);
+      score = sw_vector_wave(db, w_len, qr, read_len, sc, carry, lane); computed = true;
       calls++; cells += (unsigned long long)w_len * read_len;
       if (sc.hash_filter_calls) {
         if (lane == 0) __hip_atomic_store(&SL[n_comp], (unsigned long long)slot | ((unsigned long long)(uint32_t)score << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -217,7 +217,8 @@ k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
       }
     }
     const int score_max = (read_len < w_len ? read_len : w_len) * sc.match;
-    if (lane == 0) { h->score_vector = score; h->pct_score_vector = (1000 * 100 * score) / score_max; }
+    // flags bit 0: the score was computed for this very window (not taken from the f1 cache): pass 2 need not re-score it
+    if (lane == 0) { h->score_vector = score; h->pct_score_vector = (1000 * 100 * score) / score_max; h->flags = (uint16_t)((h->flags & ~1u) | (computed ? 1u : 0u)); }
     if (score >= thr_of(sc.vect_thr_frac, sc.vect_abs, score_max)) { last_good_cn = cn; last_good_goff = goff; }   // ref :1332-1335
     __syncthreads();
   }
@@ -400,7 +401,7 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
         const uint32_t* __restrict__ sel_cnt,
         const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work_p,
         GmFullRes* __restrict__ res, uint8_t* __restrict__ ops, int ops_stride,
-        uint8_t* __restrict__ back_pool, size_t back_stride, int max_w, unsigned long long* __restrict__ stats) {
+        uint8_t* __restrict__ back_pool, size_t back_stride, int max_w, unsigned long long* __restrict__ stats, int ablate) {
   extern __shared__ __align__(16) uint8_t sm[];
   const int lane = threadIdx.x;
   uint8_t* qr = sm;
@@ -436,8 +437,12 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
     __syncthreads();
     const int score_max = (read_len < w_len ? read_len : w_len) * sc.match;
     const int thresh = thr_of(sc.full_thr_frac, sc.full_abs, score_max);
-    const int sv = sw_vector_wave(db, w_len, qr, read_len, sc, (int16_t*)carry, lane);    // ref: mapping.c:386-388
-    vcalls++; vcells += (unsigned long long)w_len * read_len;
+    // ref: mapping.c:386-388 re-scores because the pass-1 value may come from the f1 cache (another window with the same hash slot).
+    // When pass 1 computed it for this very window the re-score is the same number: local SW with direction-free gap costs is
+    // invariant under reversing + complementing both sequences (N and IUPAC codes map one-to-one), which is all reverse_hit does.
+    int sv;
+    if ((h.flags & 1u) && !(ablate & 4)) sv = h.score_vector;
+    else { sv = sw_vector_wave(db, w_len, qr, read_len, sc, (int16_t*)carry, lane); vcalls++; vcells += (unsigned long long)w_len * read_len; }
     GmFullRes R;
     R.read_idx = rd; R.st = 0; R.gen_st = (int16_t)gen_st; R.cn = (uint32_t)cn; R.g_off = (uint32_t)g_off; R.w_len = w_len;
     R.score_vector = sv; R.score_max = score_max; R.matches = h.matches; R.score_window_gen = h.score_window_gen;
@@ -445,7 +450,7 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
     R.n_match = R.n_mismatch = R.n_ins = R.n_del = 0; R.n_ops = 0; R.ops_off = (uint32_t)(wi * (uint32_t)ops_stride);
     R.sort_idx = sel_sidx ? sel_sidx[(size_t)rd * SEL_MAX + k] : 0; R.hit_slot = (uint32_t)slot;
     if (write_back && lane == 0) hits[slot].score_vector = sv;          // hit_run_full_sw keeps the re-scored value in the hit (ref: mapping.c:386-388)
-    if (sv >= thresh) {
+    if (sv >= thresh && !(ablate & 1)) {
       fcalls++;
       // rectangle = anchor_join(1 anchor) + anchor_widen(anchor_width), ref: sw-full-ls.c:176-178, anchors.c:9-61
       long long nw = ax + ay, sw = ax - ay, ne = sw + 2 * (h.awidth - 1), se = nw + 2 * (h.alen - 1);
@@ -462,7 +467,7 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
       R.score = fo.score;
       if (fo.score > 0) {
         // do_backtrace, ref: sw-full-ls.c:413-516 -- lane 0 walks; ops are emitted reversed then flipped
-        if (lane == 0) {
+        if (lane == 0 && !(ablate & 2)) {
           int i = fo.max_i, j = fo.max_j;
           // from-state: 0 nw, 1 n, 2 w  (ref :420-427: nw, then w if strictly greater, then n if strictly greater)
           int state = 0, fs = fo.e_nw;
@@ -644,15 +649,16 @@ int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
                     uint8_t* d_back, size_t back_stride, int grid, unsigned long long* d_stats, hipStream_t stream,
                     const int32_t* d_sel_sidx, int input_strand, int write_back) {
   if (n_reads == 0) return GM_OK;
+  const int p2_ablate = getenv("GM_P2_ABLATE") ? atoi(getenv("GM_P2_ABLATE")) : 0;
   size_t lds = ((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 12 + 64;
   const size_t back_bytes = (size_t)read_len * window_len;
   if (back_bytes <= 40 * 1024) {
     lds += back_bytes + 16;
     hipLaunchKernelGGL(k_pass2<true>, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
-                       d_hits, d_perm, hcap, d_sel, d_sel_sidx, input_strand, write_back, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats);
+                       d_hits, d_perm, hcap, d_sel, d_sel_sidx, input_strand, write_back, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats, p2_ablate);
   } else {
     hipLaunchKernelGGL(k_pass2<false>, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
-                       d_hits, d_perm, hcap, d_sel, d_sel_sidx, input_strand, write_back, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats);
+                       d_hits, d_perm, hcap, d_sel, d_sel_sidx, input_strand, write_back, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats, p2_ablate);
   }
   GM_HIP(hipGetLastError());
   return GM_OK;
