@@ -119,8 +119,7 @@ int gm_launch_prune(int n_reads, int read_len, int window_len, int e_max, const 
   int bin_bits = 1; while ((1u << bin_bits) < D + (uint32_t)std::max(0, e_max)) bin_bits++;
   if (bin_bits > 12) { gm_set_error("prune: D = %u does not fit the 12-bit bin offsets", D); return GM_E_ARG; }
   int hbits = 6; while ((1 << hbits) < 2 * scap) hbits++;
-  if (const char* e = getenv("GM_PRUNE_HSHRINK")) hbits = std::max(6, hbits - atoi(e));     // table of scap (1) entries instead of 2 * scap
-  if ((1 << hbits) < scap + scap / 8) { gm_set_error("prune: hash table smaller than the survivor capacity"); return GM_E_ARG; }
+
   const size_t lds = (size_t)8 << hbits;
   static size_t configured = 0;
   if (lds > 48 * 1024 && lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_prune, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
