@@ -32,7 +32,7 @@
 #include <algorithm>
 #include "gm_internal.h"
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_prune(int n_rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict__ surv_cnt, int scap,
         uint64_t* __restrict__ surv2, uint32_t* __restrict__ surv_cnt2, int scap2, uint32_t D, int e_max, int bin_bits, int hbits,
         uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap, unsigned long long* __restrict__ stats) {
@@ -123,7 +123,9 @@ int gm_launch_prune(int n_reads, int read_len, int window_len, int e_max, const 
   const size_t lds = (size_t)8 << hbits;
   static size_t configured = 0;
   if (lds > 48 * 1024 && lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_prune, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
-  hipLaunchKernelGGL(k_prune, dim3(n_reads * 2), dim3(256), lds, stream, n_reads * 2, d_surv, d_surv_cnt, scap, d_surv2, d_surv_cnt2, scap2,
+  // latency-bound (hash probes): as many lanes per read-strand as there is work for (about 4 survivors per lane at capacity)
+  const int pthreads = getenv("GM_PRUNE_THREADS") ? atoi(getenv("GM_PRUNE_THREADS")) : std::min(1024, std::max(128, scap / 4));
+  hipLaunchKernelGGL(k_prune, dim3(n_reads * 2), dim3(pthreads), lds, stream, n_reads * 2, d_surv, d_surv_cnt, scap, d_surv2, d_surv_cnt2, scap2,
                      D, e_max, bin_bits, hbits, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats);
   GM_HIP(hipGetLastError());
   return GM_OK;
