@@ -250,9 +250,28 @@ struct DevSet {
   GmFullRes* d_res = nullptr; uint8_t* d_ops = nullptr; uint8_t* d_back = nullptr; size_t back_stride = 0;
   // paired mode only: mate range of every window (by sorted position) and the "saved" mark (by hit slot)
   int32_t* d_pmin = nullptr; int32_t* d_pmax = nullptr; uint8_t* d_saved = nullptr; uint32_t* d_saved_list = nullptr;
-  // host staging
-  std::vector<GmFullRes> h_res; std::vector<uint8_t> h_ops; std::vector<uint32_t> h_sel_cnt, h_sel_off; std::vector<uint32_t> h_reads;
 };
+
+// Pinned host staging for one sub-batch's results: device-to-host copies run at link rate and the buffers are reused
+// (three slots: one being filled while the host threads still work on the two sub-batches before it).
+struct HostSlot {
+  GmFullRes* res = nullptr; uint8_t* ops = nullptr; uint32_t* sel_cnt = nullptr; uint32_t* sel_off = nullptr; uint32_t* reads = nullptr;
+  size_t res_cap = 0, ops_cap = 0, n_cap = 0, reads_cap = 0; uint32_t n_work = 0;
+};
+static int slot_reserve(void** p, size_t* cap, size_t bytes) {
+  if (bytes <= *cap) return GM_OK;
+  if (*p) (void)hipHostFree(*p);
+  *p = nullptr; *cap = 0;
+  const size_t want = bytes + bytes / 4 + 4096;
+  GM_HIP(hipHostMalloc(p, want, hipHostMallocDefault));
+  *cap = want;
+  return GM_OK;
+}
+static void slot_free(HostSlot& h) {
+  void* ptrs[] = {h.res, h.ops, h.sel_cnt, h.sel_off, h.reads};
+  for (void* p : ptrs) if (p) (void)hipHostFree(p);
+  h = HostSlot();
+}
 
 struct gm_session {
   const gm_index* ix = nullptr;
@@ -262,6 +281,7 @@ struct gm_session {
   hipStream_t stream = nullptr;
   hipEvent_t ev[12];
   DevSet set[2];
+  HostSlot slot[3];
   uint32_t* d_pairs = nullptr; uint32_t* d_pair_cnt = nullptr; int pairs_cap = 0;   // paired mode: selected (mate 1, mate 2) window pairs
   unsigned long long* d_stats = nullptr;
   // last lookup timing
@@ -371,6 +391,7 @@ extern "C" void gm_session_free(gm_session_t* s) {
   if (!s) return;
   (void)hipSetDevice(s->ix->device);
   free_buffers(s->set[0]); free_buffers(s->set[1]);
+  for (auto& h : s->slot) slot_free(h);
   if (s->d_pairs) (void)hipFree(s->d_pairs);
   if (s->d_pair_cnt) (void)hipFree(s->d_pair_cnt);
   (void)hipFree(s->d_stats);
@@ -590,7 +611,7 @@ static int launch_prune_anchors(gm_session* s, DevSet& D, const GmIndexDev& dv, 
   return gm_launch_anchors(dv, s->sc, n, read_len, W, D.d_surv, D.d_surv_cnt, D.scap, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, s->d_stats, q);
 }
 
-static int run_device_pipeline(gm_session* s, DevSet& D, int n, int read_len, gm_map_stats_t* st, float* lookup_ms) {
+static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int read_len, gm_map_stats_t* st, float* lookup_ms) {
   const gm_index* ix = s->ix;
   const GmIndexDev dv = ix->dev_view();
   const int read_words = (read_len + 7) / 8;
@@ -637,13 +658,18 @@ static int run_device_pipeline(gm_session* s, DevSet& D, int n, int read_len, gm
                          D.d_res, D.d_ops, D.ops_stride, D.d_back, D.back_stride, s->p2_grid, s->d_stats, q);
     if (rc) return rc;
     GM_HIP(hipEventRecord(s->ev[5], q));
-    D.h_res.resize(n_work); D.h_ops.resize((size_t)n_work * D.ops_stride); D.h_sel_cnt.resize(n); D.h_sel_off.resize(n);
+    { size_t cap;
+      cap = H.res_cap; rc = slot_reserve((void**)&H.res, &cap, (size_t)n_work * sizeof(GmFullRes)); H.res_cap = cap; if (rc) return rc;
+      cap = H.ops_cap; rc = slot_reserve((void**)&H.ops, &cap, (size_t)n_work * D.ops_stride); H.ops_cap = cap; if (rc) return rc;
+      cap = H.n_cap; rc = slot_reserve((void**)&H.sel_cnt, &cap, (size_t)n * 4); if (rc) return rc;
+      cap = H.n_cap; rc = slot_reserve((void**)&H.sel_off, &cap, (size_t)n * 4); H.n_cap = cap; if (rc) return rc; }
+    H.n_work = n_work;
     if (n_work) {
-      GM_HIP(hipMemcpyAsync(D.h_res.data(), D.d_res, (size_t)n_work * sizeof(GmFullRes), hipMemcpyDeviceToHost, q));
-      GM_HIP(hipMemcpyAsync(D.h_ops.data(), D.d_ops, (size_t)n_work * D.ops_stride, hipMemcpyDeviceToHost, q));
+      GM_HIP(hipMemcpyAsync(H.res, D.d_res, (size_t)n_work * sizeof(GmFullRes), hipMemcpyDeviceToHost, q));
+      GM_HIP(hipMemcpyAsync(H.ops, D.d_ops, (size_t)n_work * D.ops_stride, hipMemcpyDeviceToHost, q));
     }
-    GM_HIP(hipMemcpyAsync(D.h_sel_cnt.data(), D.d_sel_cnt, (size_t)n * 4, hipMemcpyDeviceToHost, q));
-    GM_HIP(hipMemcpyAsync(D.h_sel_off.data(), D.d_sel_off, (size_t)n * 4, hipMemcpyDeviceToHost, q));
+    GM_HIP(hipMemcpyAsync(H.sel_cnt, D.d_sel_cnt, (size_t)n * 4, hipMemcpyDeviceToHost, q));
+    GM_HIP(hipMemcpyAsync(H.sel_off, D.d_sel_off, (size_t)n * 4, hipMemcpyDeviceToHost, q));
     GM_HIP(hipMemcpyAsync(hraw.data(), s->d_stats, hraw.size() * 8, hipMemcpyDeviceToHost, q));
     GM_HIP(hipStreamSynchronize(q));
     fold();
@@ -678,7 +704,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   // Sub-batches are pipelined: while the GPU works on sub-batch i+1, host threads finish sub-batch i
   // (pass-2 selection, MAPQ, SAM text).  Output stays in input order.
   struct Job {
-    std::vector<GmFullRes> res; std::vector<uint8_t> ops; std::vector<uint32_t> sel_cnt, sel_off, reads;
+    HostSlot* hs = nullptr;
     const uint32_t* hreads = nullptr; int base = 0, n = 0;
     std::vector<std::string> outs; std::vector<uint64_t> cm, cr; double ms = 0;
     std::thread th;
@@ -699,8 +725,8 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
         int c = next.fetch_add(1); if (c >= nchunks) break;
         std::string& o = J->outs[c]; if (emit_sam) o.reserve((size_t)chunk * (read_len + 120));
         for (int rd = c * chunk; rd < std::min(n, (c + 1) * chunk); rd++) {
-          const uint32_t cnt = J->sel_cnt[rd], off = J->sel_off[rd];
-          int k = F.finalize_read(rd, cnt ? &J->res[off] : nullptr, J->ops.data(), ops_stride, (int)cnt, o, fh, p2);
+          const uint32_t cnt = J->hs->sel_cnt[rd], off = J->hs->sel_off[rd];
+          int k = F.finalize_read(rd, cnt ? &J->hs->res[off] : nullptr, J->hs->ops, ops_stride, (int)cnt, o, fh, p2);
           if (!p2.empty()) J->cm[c]++;
           J->cr[c] += k;
           if (!emit_sam) o.clear();
@@ -720,15 +746,19 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
       n = std::min(D.eff_batch, n_reads - base);
       if (reads_host) GM_HIP(hipMemcpyAsync(D.d_reads, reads_host + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyHostToDevice, s->stream));
       else GM_HIP(hipMemcpyAsync(D.d_reads, (const uint32_t*)reads_dev + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyDeviceToDevice, s->stream));
-      rc = run_device_pipeline(s, D, n, read_len, stats, &lk);
+      rc = run_device_pipeline(s, D, s->slot[jobs.size() % 3], n, read_len, stats, &lk);
     } while (rc == 1);
     if (rc) { for (auto& j : jobs) if (j->th.joinable()) j->th.join(); return rc; }
     s->last_lookup_ms += lk; s->last_lookup_launches++;
     std::unique_ptr<Job> J(new Job());
     J->base = base; J->n = n;
-    J->res.swap(D.h_res); J->ops.swap(D.h_ops); J->sel_cnt.swap(D.h_sel_cnt); J->sel_off.swap(D.h_sel_off);
+    J->hs = &s->slot[jobs.size() % 3];
     if (reads_host) J->hreads = reads_host + (size_t)base * read_words;
-    else { J->reads.resize((size_t)n * read_words); GM_HIP(hipMemcpy(J->reads.data(), D.d_reads, (size_t)n * read_words * 4, hipMemcpyDeviceToHost)); J->hreads = J->reads.data(); }
+    else {
+      size_t cap = J->hs->reads_cap; rc = slot_reserve((void**)&J->hs->reads, &cap, (size_t)n * read_words * 4); J->hs->reads_cap = cap;
+      if (rc) { for (auto& j : jobs) if (j->th.joinable()) j->th.join(); return rc; }
+      GM_HIP(hipMemcpy(J->hs->reads, D.d_reads, (size_t)n * read_words * 4, hipMemcpyDeviceToHost)); J->hreads = J->hs->reads;
+    }
     // at most two host jobs outstanding
     while (jobs.size() - joined >= 2) { jobs[joined]->th.join(); joined++; }
     Job* jp = J.get();
@@ -788,7 +818,7 @@ extern "C" int gm_debug_tophits(gm_session_t* s, int n_reads, int read_len, cons
   do {
     if (n_reads > D.eff_batch) { gm_set_error("gm_debug_tophits: at most %d reads per call", D.eff_batch); return GM_E_ARG; }
     GM_HIP(hipMemcpyAsync(D.d_reads, reads_packed, (size_t)n_reads * read_words * 4, hipMemcpyHostToDevice, s->stream));
-    rc = run_device_pipeline(s, D, n_reads, read_len, nullptr, &lk);
+    rc = run_device_pipeline(s, D, s->slot[0], n_reads, read_len, nullptr, &lk);
   } while (rc == 1);
   if (rc) return rc;
   std::vector<int32_t> sel((size_t)n_reads * GM_SEL_MAX); std::vector<GmHit> hits((size_t)n_reads * 2 * D.hcap);
@@ -796,7 +826,7 @@ extern "C" int gm_debug_tophits(gm_session_t* s, int n_reads, int read_len, cons
   GM_HIP(hipMemcpy(hits.data(), D.d_hits, hits.size() * sizeof(GmHit), hipMemcpyDeviceToHost));
   long w = 0;
   for (int rd = 0; rd < n_reads; rd++)
-    for (uint32_t k = 0; k < D.h_sel_cnt[rd]; k++) {
+    for (uint32_t k = 0; k < s->slot[0].sel_cnt[rd]; k++) {
       if (w >= cap) { *n_rows = w; return GM_OK; }
       const int id = sel[(size_t)rd * GM_SEL_MAX + k]; const int st = id >> 16, hi = id & 0xFFFF;
       const GmHit& h = hits[((size_t)rd * 2 + st) * D.hcap + hi];
