@@ -243,6 +243,7 @@ struct DevSet {
   // capacities (grown on overflow)
   int cur_len = -1, scap = 0, scap2 = 0, hcap = 0, rcap_per_read = 8, ops_stride = 0, eff_batch = 0;
   uint32_t* d_reads = nullptr; uint64_t* d_surv = nullptr; uint32_t* d_surv_cnt = nullptr;
+  uint32_t* d_surv_seg = nullptr;                                          // [2B][S + 1] survivors after each slab (K1 emits slab by slab)
   uint64_t* d_surv2 = nullptr; uint32_t* d_surv_cnt2 = nullptr;            // survivors after the exact isolation prune (K1b) = input of K2
   GmHit* d_hits = nullptr; uint16_t* d_perm = nullptr; uint32_t* d_hit_cnt = nullptr; unsigned long long* d_slots = nullptr;
   uint32_t* d_heavy_list = nullptr; uint32_t* d_heavy_cnt = nullptr;   // read-strands beyond the LDS tier of K2
@@ -289,11 +290,11 @@ struct gm_session {
 };
 
 static void free_buffers(DevSet& D) {
-  void* ptrs[] = {D.d_reads, D.d_surv, D.d_surv_cnt, D.d_surv2, D.d_surv_cnt2, D.d_hits, D.d_perm, D.d_hit_cnt, D.d_slots, D.d_heavy_list, D.d_heavy_cnt,
+  void* ptrs[] = {D.d_reads, D.d_surv, D.d_surv_cnt, D.d_surv_seg, D.d_surv2, D.d_surv_cnt2, D.d_hits, D.d_perm, D.d_hit_cnt, D.d_slots, D.d_heavy_list, D.d_heavy_cnt,
                   D.d_sel, D.d_sel_sidx, D.d_sel_cnt, D.d_sel_off, D.d_work, D.d_n_work, D.d_res, D.d_ops, D.d_back,
                   D.d_pmin, D.d_pmax, D.d_saved, D.d_saved_list};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  D.d_reads = nullptr; D.d_surv = nullptr; D.d_surv_cnt = nullptr; D.d_surv2 = nullptr; D.d_surv_cnt2 = nullptr; D.d_hits = nullptr; D.d_perm = nullptr; D.d_hit_cnt = nullptr; D.d_slots = nullptr;
+  D.d_reads = nullptr; D.d_surv = nullptr; D.d_surv_cnt = nullptr; D.d_surv_seg = nullptr; D.d_surv2 = nullptr; D.d_surv_cnt2 = nullptr; D.d_hits = nullptr; D.d_perm = nullptr; D.d_hit_cnt = nullptr; D.d_slots = nullptr;
   D.d_heavy_list = nullptr; D.d_heavy_cnt = nullptr; D.d_sel = nullptr; D.d_sel_sidx = nullptr; D.d_sel_cnt = nullptr; D.d_sel_off = nullptr;
   D.d_work = nullptr; D.d_n_work = nullptr; D.d_res = nullptr; D.d_ops = nullptr; D.d_back = nullptr;
   D.d_pmin = nullptr; D.d_pmax = nullptr; D.d_saved = nullptr; D.d_saved_list = nullptr;
@@ -323,7 +324,10 @@ static int alloc_buffers(gm_session* s, DevSet& D, int read_len, bool paired = f
   GM_HIP(hipMalloc(&D.d_reads, (size_t)B * read_words * 4 + 64));
   GM_HIP(hipMalloc(&D.d_surv, (size_t)rs * D.scap * 8));
   GM_HIP(hipMalloc(&D.d_surv_cnt, (size_t)rs * 4));
-  if (D.scap2 > 0) { GM_HIP(hipMalloc(&D.d_surv2, (size_t)rs * D.scap2 * 8)); GM_HIP(hipMalloc(&D.d_surv_cnt2, (size_t)rs * 4)); }
+  if (D.scap2 > 0) {
+    GM_HIP(hipMalloc(&D.d_surv2, (size_t)rs * D.scap2 * 8)); GM_HIP(hipMalloc(&D.d_surv_cnt2, (size_t)rs * 4));
+    GM_HIP(hipMalloc(&D.d_surv_seg, (size_t)rs * (ix->n_slabs + 1) * 4));
+  }
   GM_HIP(hipMalloc(&D.d_hits, (size_t)rs * D.hcap * sizeof(GmHit)));
   GM_HIP(hipMalloc(&D.d_perm, (size_t)rs * D.hcap * 2));
   GM_HIP(hipMalloc(&D.d_hit_cnt, (size_t)rs * 4));
@@ -360,11 +364,12 @@ static void choose_caps(gm_session* s, DevSet& D, int read_len) {
   const double region = (double)(1 << ix->params.region_bits) + ix->params.region_overlap;
   const double expected = entries * std::min(1.0, entries * region / std::max(1.0, (double)ix->total_len)) + lists;
   // scap = capacity of the LDS tier of K2 (16 B of LDS per entry); read-strands beyond it take the heavy tier
-  D.scap = std::min(4096, std::max(256, pow2ceil((long long)(1.5 * expected) + 128)));
+  // chance partial matches echo on neighbouring offsets / other seeds, so the survivors come out ~1.6x the independence estimate
+  D.scap = std::min(16384, std::max(256, pow2ceil((long long)(2.2 * expected) + 128)));
   D.hcap = 64;
   // K1b (exact isolation prune) shrinks K2's input; its LDS tier is sized for what typically remains
   D.scap2 = (s->P.match_mode == 2 && !getenv("GM_NO_PRUNE")) ? std::max(std::min(D.scap, 256), D.scap / 8) : 0;
-  if (const char* e = getenv("GM_SCAP")) D.scap = std::min(8192, std::max(64, pow2ceil(atoi(e))));
+  if (const char* e = getenv("GM_SCAP")) D.scap = std::min(16384, std::max(64, pow2ceil(atoi(e))));
   if (const char* e = getenv("GM_SCAP2")) { if (D.scap2) D.scap2 = std::min(D.scap, std::max(64, pow2ceil(atoi(e)))); }
   if (const char* e = getenv("GM_HCAP")) D.hcap = std::min(32768, std::max(4, pow2ceil(atoi(e))));
   (void)max_n_kmers;
@@ -604,7 +609,7 @@ static int launch_prune_anchors(gm_session* s, DevSet& D, const GmIndexDev& dv, 
       const int thr = s->sc.wgen_thr_frac < 0 ? s->sc.wgen_abs : (int)((double)base * s->sc.wgen_thr_frac);
       e_max = (thr + s->sc.match - 1) / s->sc.match - s->ix->max_seed_span - 1;
     }
-    int rc = gm_launch_prune(n, read_len, W, e_max, D.d_surv, D.d_surv_cnt, D.scap, D.d_surv2, D.d_surv_cnt2, D.scap2, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, s->d_stats, q);
+    int rc = gm_launch_prune(n, read_len, W, e_max, s->ix->n_slabs, s->ix->slab_bits, D.d_surv, D.d_surv_cnt, D.d_surv_seg, D.scap, D.d_surv2, D.d_surv_cnt2, D.scap2, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, s->d_stats, q);
     if (rc) return rc;
     return gm_launch_anchors(dv, s->sc, n, read_len, W, D.d_surv2, D.d_surv_cnt2, D.scap2, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, s->d_stats, q);
   }
@@ -621,7 +626,7 @@ static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int
   {
     GM_HIP(hipMemsetAsync(s->d_stats, 0, (size_t)GS_STRIPES * GS_STRIDE * 8, q));
     GM_HIP(hipEventRecord(s->ev[0], q));
-    int rc = gm_launch_lookup(dv, D.d_reads, n, read_len, read_words, D.d_surv, D.d_surv_cnt, D.scap, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, s->d_stats, q);
+    int rc = gm_launch_lookup(dv, D.d_reads, n, read_len, read_words, D.d_surv, D.d_surv_cnt, D.scap, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, s->d_stats, q, D.d_surv_seg);
     if (rc) return rc;
     GM_HIP(hipEventRecord(s->ev[1], q));
     rc = launch_prune_anchors(s, D, dv, n, read_len, W);

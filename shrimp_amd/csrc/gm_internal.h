@@ -44,7 +44,7 @@ int gm_index_from_lists_device(GmIndexHost* ix, int sn, const uint32_t* lens, co
 // survivors are listed in d_heavy_list (count in d_surv_cnt) and re-run by gm_launch_lookup_redo
 int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
                      uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
-                     unsigned long long* d_stats, hipStream_t stream);
+                     unsigned long long* d_stats, hipStream_t stream, uint32_t* d_surv_seg = nullptr);   // d_surv_seg[rs][S + 1]: survivors after each slab
 int gm_launch_lookup_redo(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
                           int n_heavy, const uint32_t* d_redo_list, const uint64_t* d_redo_off, uint64_t* d_out,
                           unsigned long long* d_stats, hipStream_t stream);
@@ -52,7 +52,8 @@ size_t gm_lookup_lds_bytes(const GmIndexDev& ix, int read_len);
 
 // K1b: exact removal of survivors with no other survivor within window_len + read_len (gm_prune.hip); the kept
 // ones go to d_surv2 (stride scap2), d_surv_cnt2 = their number, or 0xFFFFFFFF for read-strands of the heavy tier
-int gm_launch_prune(int n_reads, int read_len, int window_len, int e_max, const uint64_t* d_surv, const uint32_t* d_surv_cnt, int scap,
+int gm_launch_prune(int n_reads, int read_len, int window_len, int e_max, int n_slabs, int slab_bits, const uint64_t* d_surv, const uint32_t* d_surv_cnt,
+                    const uint32_t* d_surv_seg, int scap,
                     uint64_t* d_surv2, uint32_t* d_surv_cnt2, int scap2, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
                     unsigned long long* d_stats, hipStream_t stream);
 

@@ -56,7 +56,7 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
          int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
          uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap,
          const uint32_t* __restrict__ redo_list, const uint64_t* __restrict__ redo_off,
-         unsigned long long* __restrict__ stats, int ablate) {
+         unsigned long long* __restrict__ stats, int ablate, uint32_t* __restrict__ surv_seg) {
   extern __shared__ __align__(16) uint32_t smem[];
   __shared__ K1Smem sh;
   const int tid = threadIdx.x;
@@ -305,6 +305,7 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
       }
       __syncthreads();
     }
+    if (surv_seg && tid == 0) surv_seg[(size_t)rs * (S + 1) + s + 1] = sh.n_surv;      // survivors come out slab by slab: K1b prunes per slab
   }
   if (redo) return;                      // counters were taken by the first run
   if (tid == 0) {
@@ -330,7 +331,7 @@ __global__ void __launch_bounds__(512)
 k_lookup_bkt(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
              int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
              uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap,
-             unsigned long long* __restrict__ stats) {
+             unsigned long long* __restrict__ stats, uint32_t* __restrict__ surv_seg) {
   extern __shared__ __align__(16) uint32_t smem[];
   __shared__ uint32_t n_surv;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -422,6 +423,7 @@ k_lookup_bkt(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int
   __syncthreads();
   if (tid == 0) {
     surv_cnt[rs] = n_surv;
+    if (surv_seg) surv_seg[(size_t)rs * 2 + 1] = n_surv;      // one slab
     GS_ADD(stats, GS_SURVIVORS, n_surv);
     if (n_surv > scap) {
       const uint32_t hs = atomicAdd(heavy_cnt, 1u);
@@ -453,7 +455,8 @@ k_lookup_bkt(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int
 __global__ void __launch_bounds__(768)
 k_lookup_v3(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
             int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
-            uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap, unsigned long long* __restrict__ stats, int ablate) {
+            uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap, unsigned long long* __restrict__ stats, int ablate,
+            uint32_t* __restrict__ surv_seg) {
   extern __shared__ __align__(16) uint32_t smem[];
   __shared__ uint32_t n_surv, n_lists, any_long;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -678,6 +681,7 @@ k_lookup_v3(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
       }
       __syncthreads();
     }
+    if (surv_seg && tid == 0) surv_seg[(size_t)rs * (S + 1) + s + 1] = n_surv;         // survivors come out slab by slab: K1b prunes per slab
   }
   if (tid == 0) {
     surv_cnt[rs] = n_surv;
@@ -708,7 +712,7 @@ size_t gm_lookup_lds_bytes(const GmIndexDev& ix, int read_len) {
 
 int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
                      uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
-                     unsigned long long* d_stats, hipStream_t stream) {
+                     unsigned long long* d_stats, hipStream_t stream, uint32_t* d_surv_seg) {
   int max_n_kmers, NL, bm_words; size_t lds;
   k1_geometry(ix, read_len, &max_n_kmers, &NL, &bm_words, &lds);
   if (lds > 160 * 1024) { gm_set_error("lookup kernel needs %zu bytes of LDS (read_len %d, slab_bits %d)", lds, read_len, ix.slab_bits); return GM_E_ARG; }
@@ -723,7 +727,7 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
   if (bkt) {
     const size_t lds_b = (size_t)((((read_len + 3) / 4) + 3) & ~3) * 4 + (size_t)bm_words * 4;
     hipLaunchKernelGGL(k_lookup_bkt, dim3(n_reads * 2), dim3((NL + 63) & ~63), lds_b, stream, ix, d_reads, n_reads, read_len, read_words,
-                       max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats);
+                       max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, d_surv_seg);
   } else if (ix.list_cutoff < 65536u && !getenv("GM_K1_V2")) {
     const size_t lds3 = (size_t)((((read_len + 3) / 4) + 3 * NL + ix.n_slabs * NL + (ix.n_slabs + 1) / 2 + (NL * (ix.n_slabs + 1) + 1) / 2 + 3) & ~3) * 4 + (size_t)bm_words * 4;
     static size_t configured3 = 0;
@@ -733,14 +737,14 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     if (const char* e = getenv("GM_K1_THREADS")) k1_threads = std::max(64, std::min(768, atoi(e) & ~63));
     hipLaunchKernelGGL(k_lookup_v3, dim3(n_reads * 2), dim3(k1_threads), lds3, stream, ix, d_reads, n_reads, read_len, read_words,
                        max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats,
-                       getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0);
+                       getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0, d_surv_seg);
   } else {
     // one list per lane when the read-strand's lists fit a workgroup: every list slice is in flight at once
     int k1_threads = std::min(1024, (NL + 63) & ~63);
     if (const char* e = getenv("GM_K1_THREADS")) k1_threads = std::max(64, std::min(1024, atoi(e) & ~63));
     hipLaunchKernelGGL(k_lookup<false>, dim3(n_reads * 2), dim3(k1_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words,
                        max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
-                       (const uint32_t*)nullptr, (const uint64_t*)nullptr, d_stats, getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0);
+                       (const uint32_t*)nullptr, (const uint64_t*)nullptr, d_stats, getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0, d_surv_seg);
   }
   GM_HIP(hipGetLastError());
   return GM_OK;
@@ -755,7 +759,7 @@ int gm_launch_lookup_redo(const GmIndexDev& ix, const uint32_t* d_reads, int n_r
   if (n_heavy == 0) return GM_OK;
   hipLaunchKernelGGL(k_lookup<false>, dim3(n_heavy), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
                      max_n_kmers, NL, bm_words, d_out, (uint32_t*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0,
-                     d_redo_list, d_redo_off, d_stats, 0);
+                     d_redo_list, d_redo_off, d_stats, 0, (uint32_t*)nullptr);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

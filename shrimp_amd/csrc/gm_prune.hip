@@ -33,40 +33,23 @@
 #include "gm_internal.h"
 
 __global__ void __launch_bounds__(1024)
-k_prune(int n_rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict__ surv_cnt, int scap,
+k_prune(int n_rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict__ surv_cnt, const uint32_t* __restrict__ surv_seg, int scap,
         uint64_t* __restrict__ surv2, uint32_t* __restrict__ surv_cnt2, int scap2, uint32_t D, int e_max, int bin_bits, int hbits,
+        int n_slabs, int slab_bits,
         uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap, unsigned long long* __restrict__ stats) {
   extern __shared__ __align__(16) uint32_t sm[];
-  __shared__ uint32_t n_keep;
+  __shared__ uint32_t n_keep, too_many;
   const int rs = blockIdx.x, tid = threadIdx.x;
   const uint32_t n = surv_cnt[rs];
   if (n > (uint32_t)scap) { if (tid == 0) surv_cnt2[rs] = 0xFFFFFFFFu; return; }      // already on the heavy list (K1)
   if (n == 0) { if (tid == 0) surv_cnt2[rs] = 0; return; }
   const uint32_t H = 1u << hbits;
   uint32_t* keys = sm; uint32_t* info = sm + H;        // info = cnt(2, saturating) << 24 | min_off << 12 | max_off
-  for (uint32_t i = tid; i < H; i += blockDim.x) { keys[i] = 0; info[i] = 0x00FFF000u; }
-  if (tid == 0) n_keep = 0;
-  __syncthreads();
+  if (tid == 0) { n_keep = 0; too_many = 0; }
   const uint64_t* in = surv + (size_t)rs * scap;
+  uint64_t* out = surv2 + (size_t)rs * scap2;
   const uint32_t omask = (1u << bin_bits) - 1u;
   auto slot_of = [&](uint32_t key) { return (key * 2654435761u) >> (32 - hbits); };
-  for (uint32_t i = tid; i < n; i += blockDim.x) {
-    const uint32_t x = (uint32_t)(in[i] >> 32), key = (x >> bin_bits) + 1u, o = x & omask;
-    uint32_t h = slot_of(key);
-    for (;;) {
-      const uint32_t k = atomicCAS(&keys[h], 0u, key);
-      if (k == 0u || k == key) break;
-      h = (h + 1u) & (H - 1u);
-    }
-    uint32_t old = info[h];
-    for (;;) {
-      const uint32_t c = min(3u, (old >> 24) + 1u), mn = min((old >> 12) & 0xFFFu, o), mx = max(old & 0xFFFu, o);
-      const uint32_t prev = atomicCAS(&info[h], old, (c << 24) | (mn << 12) | mx);
-      if (prev == old) break;
-      old = prev;
-    }
-  }
-  __syncthreads();
   auto find = [&](uint32_t key) -> uint32_t {          // info of the bin, or 0 when the bin is empty
     uint32_t h = slot_of(key);
     for (;;) {
@@ -76,32 +59,62 @@ k_prune(int n_rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict_
       h = (h + 1u) & (H - 1u);
     }
   };
-  uint64_t* out = surv2 + (size_t)rs * scap2;
-  for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
-    const uint32_t i = i0 + tid;
-    bool keep = false; uint64_t e = 0;
-    if (i < n) {
-      e = in[i];
-      const uint32_t x = (uint32_t)(e >> 32), bin = x >> bin_bits;
-      const uint32_t own = find(bin + 1u), lf = bin > 0 ? find(bin) : 0u, rt = find(bin + 2u);
-      // (1) isolation: two entries in the bin: the other one is max - min away; three or more: keep
-      keep = (own >> 24) >= 3u || ((own >> 24) == 2u && (own & 0xFFFu) - ((own >> 12) & 0xFFFu) <= D);
-      if (!keep && lf) keep = x - (((bin - 1u) << bin_bits) + (lf & 0xFFFu)) <= D;
-      if (!keep && rt) keep = (((bin + 1u) << bin_bits) + ((rt >> 12) & 0xFFFu)) - x <= D;
-      // (2) tight cluster: everything in the three bins (which cover x -+ (D + e_max)) spans at most e_max positions
-      if (keep && e_max >= 0) {
-        uint32_t gmin = (bin << bin_bits) + ((own >> 12) & 0xFFFu), gmax = (bin << bin_bits) + (own & 0xFFFu);
-        if (lf) gmin = ((bin - 1u) << bin_bits) + ((lf >> 12) & 0xFFFu);
-        if (rt) gmax = ((bin + 1u) << bin_bits) + (rt & 0xFFFu);
-        if (gmax - gmin <= (uint32_t)e_max) keep = false;
+  // K1 emits the survivors slab by slab (surv_seg[s + 1] = how many after slab s), so each slab's segment is pruned on its own
+  // with a small table; survivors closer than D + e_max to a slab border are kept as they are (their neighbours may sit in the
+  // other segment) -- a superset of what the rules keep, hence still exact.
+  const uint32_t guard = D + (uint32_t)max(0, e_max);
+  for (int s = 0; s < n_slabs; s++) {
+    const uint32_t b = (s == 0 || !surv_seg) ? 0u : min(n, surv_seg[(size_t)rs * (n_slabs + 1) + s]);
+    const uint32_t e = (!surv_seg || s == n_slabs - 1) ? n : min(n, surv_seg[(size_t)rs * (n_slabs + 1) + s + 1]);
+    if (e <= b) continue;
+    if (e - b > H / 2) { if (tid == 0) too_many = 1; continue; }       // segment larger than the table allows: heavy tier
+    for (uint32_t i = tid; i < H; i += blockDim.x) { keys[i] = 0; info[i] = 0x00FFF000u; }
+    __syncthreads();
+    for (uint32_t i = b + tid; i < e; i += blockDim.x) {
+      const uint32_t x = (uint32_t)(in[i] >> 32), key = (x >> bin_bits) + 1u, o = x & omask;
+      uint32_t h = slot_of(key);
+      for (;;) {
+        const uint32_t k = atomicCAS(&keys[h], 0u, key);
+        if (k == 0u || k == key) break;
+        h = (h + 1u) & (H - 1u);
+      }
+      uint32_t old = info[h];
+      for (;;) {
+        const uint32_t c = min(3u, (old >> 24) + 1u), mn = min((old >> 12) & 0xFFFu, o), mx = max(old & 0xFFFu, o);
+        const uint32_t prev = atomicCAS(&info[h], old, (c << 24) | (mn << 12) | mx);
+        if (prev == old) break;
+        old = prev;
       }
     }
-    if (keep) { const uint32_t s = atomicAdd(&n_keep, 1u); if (s < (uint32_t)scap2) out[s] = e; }
+    __syncthreads();
+    const uint64_t B = (uint64_t)s << slab_bits, E = B + (1ull << slab_bits);
+    for (uint32_t i = b + tid; i < e; i += blockDim.x) {
+      const uint64_t ent = in[i];
+      const uint32_t x = (uint32_t)(ent >> 32), bin = x >> bin_bits;
+      bool keep;
+      if (n_slabs > 1 && ((uint64_t)x < B + guard || (uint64_t)x + guard >= E)) keep = true;
+      else {
+        const uint32_t own = find(bin + 1u), lf = bin > 0 ? find(bin) : 0u, rt = find(bin + 2u);
+        // (1) isolation: two entries in the bin: the other one is max - min away; three or more: keep
+        keep = (own >> 24) >= 3u || ((own >> 24) == 2u && (own & 0xFFFu) - ((own >> 12) & 0xFFFu) <= D);
+        if (!keep && lf) keep = x - (((bin - 1u) << bin_bits) + (lf & 0xFFFu)) <= D;
+        if (!keep && rt) keep = (((bin + 1u) << bin_bits) + ((rt >> 12) & 0xFFFu)) - x <= D;
+        // (2) tight cluster: everything in the three bins (which cover x -+ (D + e_max)) spans at most e_max positions
+        if (keep && e_max >= 0) {
+          uint32_t gmin = (bin << bin_bits) + ((own >> 12) & 0xFFFu), gmax = (bin << bin_bits) + (own & 0xFFFu);
+          if (lf) gmin = ((bin - 1u) << bin_bits) + ((lf >> 12) & 0xFFFu);
+          if (rt) gmax = ((bin + 1u) << bin_bits) + (rt & 0xFFFu);
+          if (gmax - gmin <= (uint32_t)e_max) keep = false;
+        }
+      }
+      if (keep) { const uint32_t sl = atomicAdd(&n_keep, 1u); if (sl < (uint32_t)scap2) out[sl] = ent; }
+    }
+    __syncthreads();
   }
   __syncthreads();
   if (tid == 0) {
     const uint32_t k = n_keep;
-    if (k > (uint32_t)scap2) {             // still too many for the LDS tier of K2: heavy tier (re-emits all survivors)
+    if (k > (uint32_t)scap2 || too_many) {  // still too many for the LDS tier of K2: heavy tier (re-emits all survivors)
       surv_cnt2[rs] = 0xFFFFFFFFu;
       const uint32_t hs = atomicAdd(heavy_cnt, 1u);
       if (hs < (uint32_t)heavy_cap) heavy_list[hs] = (uint32_t)rs; else GS_ADD(stats, GS_OVERFLOW_SURV, 1ull);
@@ -110,7 +123,8 @@ k_prune(int n_rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict_
   }
 }
 
-int gm_launch_prune(int n_reads, int read_len, int window_len, int e_max, const uint64_t* d_surv, const uint32_t* d_surv_cnt, int scap,
+int gm_launch_prune(int n_reads, int read_len, int window_len, int e_max, int n_slabs, int slab_bits, const uint64_t* d_surv, const uint32_t* d_surv_cnt,
+                    const uint32_t* d_surv_seg, int scap,
                     uint64_t* d_surv2, uint32_t* d_surv_cnt2, int scap2, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
                     unsigned long long* d_stats, hipStream_t stream) {
   if (n_reads == 0) return GM_OK;
@@ -118,15 +132,16 @@ int gm_launch_prune(int n_reads, int read_len, int window_len, int e_max, const 
   if (e_max > read_len) e_max = read_len;
   int bin_bits = 1; while ((1u << bin_bits) < D + (uint32_t)std::max(0, e_max)) bin_bits++;
   if (bin_bits > 12) { gm_set_error("prune: D = %u does not fit the 12-bit bin offsets", D); return GM_E_ARG; }
-  int hbits = 6; while ((1 << hbits) < 2 * scap) hbits++;
-
+  // table for one slab's segment: twice the expected share of the survivor capacity (segments beyond half the table go to the heavy tier)
+  const int segs = d_surv_seg ? std::max(1, n_slabs) : 1;
+  int hbits = 8; while ((1 << hbits) < 2 * std::max(128, (segs > 1 ? (2 * scap) / segs : scap))) hbits++;
   const size_t lds = (size_t)8 << hbits;
   static size_t configured = 0;
   if (lds > 48 * 1024 && lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_prune, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
-  // latency-bound (hash probes): as many lanes per read-strand as there is work for (about 4 survivors per lane at capacity)
-  const int pthreads = getenv("GM_PRUNE_THREADS") ? atoi(getenv("GM_PRUNE_THREADS")) : std::min(1024, std::max(128, scap / 4));
-  hipLaunchKernelGGL(k_prune, dim3(n_reads * 2), dim3(pthreads), lds, stream, n_reads * 2, d_surv, d_surv_cnt, scap, d_surv2, d_surv_cnt2, scap2,
-                     D, e_max, bin_bits, hbits, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats);
+  // latency-bound (hash probes): as many lanes per read-strand as a segment has work for
+  const int pthreads = getenv("GM_PRUNE_THREADS") ? atoi(getenv("GM_PRUNE_THREADS")) : std::min(1024, std::max(128, (1 << hbits) / 8));
+  hipLaunchKernelGGL(k_prune, dim3(n_reads * 2), dim3(pthreads), lds, stream, n_reads * 2, d_surv, d_surv_cnt, d_surv_seg, scap, d_surv2, d_surv_cnt2, scap2,
+                     D, e_max, bin_bits, hbits, segs, slab_bits, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }
