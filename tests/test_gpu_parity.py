@@ -307,3 +307,42 @@ def test_edge_cases_empty_tiny_long_and_degenerate_reads(gm, oracle_lib):
     with pytest.raises(gm.GmError):                                                     # longer than --longest-read (ref: gmapper.c:497-507 skips it)
         s.map_reads(np.zeros((1, 1001), dtype=np.uint8))
     o.close(); s.close(); ix.close()
+
+
+def test_index_replication_path_of_the_multi_gpu_start_up(gm):
+    """what a non-root rank does at start-up (shrimp_amd/parallel.py): allocate from the metadata blob, receive every resident
+    array through a zero-copy torch view of the raw device pointer -- here with a 1-rank RCCL group (the broadcast call itself)
+    and, for the data movement, a device-to-device copy between the two indexes' views; the replica must map like the original"""
+    import torch
+    import torch.distributed as dist
+    from shrimp_amd import parallel
+    dev = torch.device("cuda", 0)
+    for name, env in (("cfg2s_100bp_2Mbp", {}), ("stress_60bp", {"GM_SLAB_BITS": "18"})):      # bucket layout / multi-slab layout
+        old = {k: os.environ.get(k) for k in env}; os.environ.update(env)
+        try:
+            contigs, reads, sam = oa.load_golden(name)
+            src = gm.Index(contigs)
+            rep = gm.Index.alloc_like(src.meta(), device=0)
+            a, b = src.device_arrays(), rep.device_arrays()
+            assert [n for _, n in a] == [n for _, n in b] and len(a) == 1 + 3 * 3
+            for (pa, na), (pb, nb) in zip(a, b):
+                if not na: continue
+                ta = torch.as_tensor(parallel._DevArray(pa, na), device=dev); tb = torch.as_tensor(parallel._DevArray(pb, nb), device=dev)
+                assert ta.data_ptr() == pa and tb.data_ptr() == pb          # views, not copies
+                tb.copy_(ta)
+            torch.cuda.synchronize()
+            s = gm.Session(rep, max_batch_reads=4096)
+            got = oa.sam_header(contigs) + s.map_reads(reads)
+            s.close(); rep.close()
+            assert got == sam, _first_diff(got, sam)
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            same = parallel.broadcast_index(src, 0, dev, src=0)            # 1-rank group: exercises meta + dist.broadcast on the views
+            assert same is src
+            src.close()
+        finally:
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+    if dist.is_initialized(): dist.destroy_process_group()
