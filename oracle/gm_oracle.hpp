@@ -401,6 +401,44 @@ static inline int sw_vector(const Params& P, const uint32_t* genome, llint goff,
   return score;
 }
 
+// lstocs / cstols (common/util.h:157-205), is_rna = false
+static inline int lstocs(int first_letter, int second_letter) {
+  static const int colourmat[4][4] = {{0, 1, 2, 3}, {1, 0, 3, 2}, {2, 3, 0, 1}, {3, 2, 1, 0}};
+  if (first_letter > 3 || second_letter > 3) return 15;     // anything non-{A,C,G,T} -> N
+  return colourmat[first_letter][second_letter];
+}
+static inline int cstols(int first_letter, int colour) {
+  if (first_letter == 15 || !(colour >= 0 && colour <= 3)) return 15;
+  return (first_letter % 2 == 0) ? ((4 + first_letter + colour) % 4) : ((4 + first_letter - colour) % 4);
+}
+
+// Colour-space vector SW (common/sw-vector.c:112-146 first row, then the same recurrence on colours; sw_vector :453-515).
+// genome_cs / read hold colours, genome_ls the letters of the same window; the first read colour is compared with the
+// colour between the read's initial base and the genome letter.  `mismatch` is what sw_vector_setup got: match + crossover
+// in colour space (gmapper.c:2935).
+static inline int sw_vector_cs(const Params& P, int mismatch, const uint32_t* genome_cs, llint goff, int glen,
+                               const uint32_t* read, int rlen, const uint32_t* genome_ls, int initbp) {
+  const int a_go = -P.a_gap_open_score, a_ge = -P.a_gap_extend_score;
+  const int b_go = -P.b_gap_open_score, b_ge = -P.b_gap_extend_score;
+  std::vector<int> H(glen + 1, 0), B(glen + 1, -b_go);
+  int score = 0;
+  for (int i = 0; i < rlen; i++) {
+    const int q = EXTRACT(read, i);
+    int hdiag = 0, hleft = 0, a = -a_go;
+    for (int j = 0; j < glen; j++) {
+      const int gcode = (i == 0) ? lstocs((int)EXTRACT(genome_ls, goff + j), initbp) : (int)EXTRACT(genome_cs, goff + j);
+      a = std::max(a - a_ge, hleft - a_go - a_ge);
+      const int b = std::max(B[j + 1] - b_ge, H[j + 1] - b_go - b_ge);
+      int h = hdiag + (gcode == q ? P.match_score : mismatch);
+      h = std::max(h, 0); h = std::max(h, a); h = std::max(h, b);
+      hdiag = H[j + 1];
+      H[j + 1] = h; B[j + 1] = b; hleft = h;
+      score = std::max(score, h);
+    }
+  }
+  return score;
+}
+
 // hash_genome_window (common/util.h:224-245) with common/hash.h:70-95
 static inline uint32_t hash_genome_window(const uint32_t* genome, uint32_t goff, uint32_t glen) {
   uint32_t key = 0;
@@ -567,6 +605,191 @@ static inline void sw_full_ls(const Params& P, SwFullWorkspace& W, const uint32_
   sfr->genome_start += (int)goff;
   sfr->rmapped = max_i - sfr->read_start + 1;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Full SW, colour space (common/sw-full-cs.c:249-623 full_sw, :633-937 do_backtrace, :945-1060 pretty_print,
+// :1146-1236 sw_full_cs).  Four letter-space translations of the colour read (start letter (k + initbp) % 4), a
+// 3-state affine DP in four layers; the NW and N transitions may come from another layer at +xover_penalty, the W
+// transition may not; N-vs-anything scores 0.  Global mode (Gflag) only; crossover_score == NULL (no read qualities).
+// ---------------------------------------------------------------------------------------------
+struct CsParams { int match = 10, mismatch = -24, xover = -20, a_go = 33, a_ge = 7, b_go = 33, b_ge = 3, anchor_width = 8, indel_taboo_len = 0; };
+struct SwFullCsResults : SwFullResults { int crossovers = 0; };
+
+static inline void sw_full_cs(const CsParams& C, const uint32_t* genome_ls, llint goff, int glen, const uint32_t* read, int rlen, int initbp,
+                              int threshscore, SwFullCsResults* sfr, bool revcmpl, const Anchor* anchors, int anchors_cnt) {
+  const int lena = glen, lenb = rlen;
+  struct Lay { int n, w, nw; int8_t bn, bw, bnw; };
+  struct Cell { Lay from[4]; };
+  std::vector<Cell> m((size_t)(lena + 1) * (lenb + 1));
+  for (auto& c : m) for (int k = 0; k < 4; k++) c.from[k] = Lay{INT_MIN / 4, INT_MIN / 4, INT_MIN / 4, 0, 0, 0};   // poison: every cell read is written first
+  std::vector<int8_t> db(lena); std::vector<int8_t> qr[4];
+  for (int i = 0; i < lena; i++) db[i] = (int8_t)EXTRACT(genome_ls, goff + i);
+  for (int k = 0; k < 4; k++) {                                          // :1182-1197
+    qr[k].resize(lenb);
+    int letter = (k + initbp) % 4;
+    for (int j = 0; j < lenb; j++) {
+      const int base = EXTRACT(read, j);
+      if (base == 15) { qr[k][j] = 15; letter = (k + initbp) % 4; }
+      else { qr[k][j] = (int8_t)cstols(letter, base); letter = qr[k][j]; }
+    }
+  }
+  const int xo = C.xover;
+  auto init_cell = [&](size_t idx, int local) {                          // :201-247
+    for (int k = 0; k < 4; k++) {
+      Lay& l = m[idx].from[k];
+      if (local) { const int x = (k == 0) ? 0 : xo; l.nw = x; l.n = -C.b_go + x; l.w = -C.a_go + x; }
+      else { l.nw = l.n = l.w = -INT_MAX / 2; }
+      l.bn = l.bw = l.bnw = 0;
+    }
+  };
+  auto FROM_x = [](int mat, int dir) { return (int8_t)((dir << 2) | mat); };
+  Anchor rectangle;
+  anchor_join(anchors, anchors_cnt, &rectangle); anchor_widen(&rectangle, C.anchor_width);      // :284-287
+  for (int j = 0; j < lena + 1; j++) init_cell(j, 1);                     // :266-268
+  int score = 0, max_i = 0, max_j = 0, max_k = 0;
+  for (int i = 0; i < lenb; i++) {
+    int x_min, x_max;
+    anchor_get_x_range(&rectangle, lena, lenb, i, &x_min, &x_max);
+    init_cell((size_t)(i + 1) * (lena + 1) + (x_min - 1) + 1, 0);         // :319 (global)
+    const bool notaboo = i < lenb - C.indel_taboo_len;
+    for (int j = x_min; j <= x_max; j++) {
+      Cell* cnw = &m[(size_t)i * (lena + 1) + j]; Cell* cn = cnw + 1; Cell* cw = cnw + (lena + 1); Cell* cur = cw + 1;
+      for (int k = 0; k < 4; k++) {
+        int ms;
+        if (db[j] == 15 || qr[k][i] == 15) ms = 0; else ms = (db[j] == qr[k][i]) ? C.match : C.mismatch;
+        int tmp; int8_t tmp2;
+        // ---- northwest :356-438
+        if (!revcmpl) {
+          tmp = cnw->from[k].nw + ms; tmp2 = FROM_x(k, FROM_NORTHWEST_NORTHWEST);
+          if (notaboo && cnw->from[k].n + ms > tmp) { tmp = cnw->from[k].n + ms; tmp2 = FROM_x(k, FROM_NORTHWEST_NORTH); }
+          if (cnw->from[k].w + ms > tmp) { tmp = cnw->from[k].w + ms; tmp2 = FROM_x(k, FROM_NORTHWEST_WEST); }
+        } else {
+          tmp = cnw->from[k].w + ms; tmp2 = FROM_x(k, FROM_NORTHWEST_WEST);
+          if (notaboo && cnw->from[k].n + ms > tmp) { tmp = cnw->from[k].n + ms; tmp2 = FROM_x(k, FROM_NORTHWEST_NORTH); }
+          if (cnw->from[k].nw + ms > tmp) { tmp = cnw->from[k].nw + ms; tmp2 = FROM_x(k, FROM_NORTHWEST_NORTHWEST); }
+        }
+        for (int l = 0; l < 4; l++) {
+          if (l == k) continue;
+          if (!revcmpl) {
+            if (cnw->from[l].nw + ms + xo > tmp) { tmp = cnw->from[l].nw + ms + xo; tmp2 = FROM_x(l, FROM_NORTHWEST_NORTHWEST); }
+            if (notaboo && cnw->from[l].n + ms + xo > tmp) { tmp = cnw->from[l].n + ms + xo; tmp2 = FROM_x(l, FROM_NORTHWEST_NORTH); }
+            if (cnw->from[l].w + ms + xo > tmp) { tmp = cnw->from[l].w + ms + xo; tmp2 = FROM_x(l, FROM_NORTHWEST_WEST); }
+          } else {
+            if (cnw->from[l].w + ms + xo > tmp) { tmp = cnw->from[l].w + ms + xo; tmp2 = FROM_x(l, FROM_NORTHWEST_WEST); }
+            if (notaboo && cnw->from[l].n + ms + xo > tmp) { tmp = cnw->from[l].n + ms + xo; tmp2 = FROM_x(l, FROM_NORTHWEST_NORTH); }
+            if (cnw->from[l].nw + ms + xo > tmp) { tmp = cnw->from[l].nw + ms + xo; tmp2 = FROM_x(l, FROM_NORTHWEST_NORTHWEST); }
+          }
+        }
+        cur->from[k].nw = tmp; cur->from[k].bnw = tmp2;
+        // ---- north :447-503
+        if (!revcmpl) {
+          tmp = cn->from[k].nw - C.b_go - C.b_ge; tmp2 = FROM_x(k, FROM_NORTH_NORTHWEST);
+          if (!notaboo || cn->from[k].n - C.b_ge > tmp) { tmp = cn->from[k].n - C.b_ge; tmp2 = FROM_x(k, FROM_NORTH_NORTH); }
+        } else {
+          tmp = cn->from[k].n - C.b_ge; tmp2 = FROM_x(k, FROM_NORTH_NORTH);
+          if (notaboo && cn->from[k].nw - C.b_go - C.b_ge > tmp) { tmp = cn->from[k].nw - C.b_go - C.b_ge; tmp2 = FROM_x(k, FROM_NORTH_NORTHWEST); }
+        }
+        for (int l = 0; l < 4; l++) {
+          if (l == k) continue;
+          if (!revcmpl) {
+            if (notaboo && cn->from[l].nw - C.b_go - C.b_ge + xo > tmp) { tmp = cn->from[l].nw - C.b_go - C.b_ge + xo; tmp2 = FROM_x(l, FROM_NORTH_NORTHWEST); }
+            if (cn->from[l].n - C.b_ge + xo > tmp) { tmp = cn->from[l].n - C.b_ge + xo; tmp2 = FROM_x(l, FROM_NORTH_NORTH); }
+          } else {
+            if (cn->from[l].n - C.b_ge + xo > tmp) { tmp = cn->from[l].n - C.b_ge + xo; tmp2 = FROM_x(l, FROM_NORTH_NORTH); }
+            if (notaboo && cn->from[l].nw - C.b_go - C.b_ge + xo > tmp) { tmp = cn->from[l].nw - C.b_go - C.b_ge + xo; tmp2 = FROM_x(l, FROM_NORTH_NORTHWEST); }
+          }
+        }
+        cur->from[k].n = tmp; cur->from[k].bn = tmp2;
+        // ---- west :512-541 (no crossover on a genomic gap)
+        if (!revcmpl) {
+          tmp = cw->from[k].nw - C.a_go - C.a_ge; tmp2 = FROM_x(k, FROM_WEST_NORTHWEST);
+          if (!notaboo || cw->from[k].w - C.a_ge > tmp) { tmp = cw->from[k].w - C.a_ge; tmp2 = FROM_x(k, FROM_WEST_WEST); }
+        } else {
+          tmp = cw->from[k].w - C.a_ge; tmp2 = FROM_x(k, FROM_WEST_WEST);
+          if (notaboo && cw->from[k].nw - C.a_go - C.a_ge > tmp) { tmp = cw->from[k].nw - C.a_go - C.a_ge; tmp2 = FROM_x(k, FROM_WEST_NORTHWEST); }
+        }
+        cur->from[k].w = tmp; cur->from[k].bw = tmp2;
+        // ---- max on the last read row :547-575
+        if (i == lenb - 1) {
+          const Lay& c = cur->from[k];
+          if (!revcmpl) {
+            if (c.nw > score) { score = c.nw; max_i = i; max_j = j; max_k = k; }
+            if (c.n > score) { score = c.n; max_i = i; max_j = j; max_k = k; }
+            if (c.w > score) { score = c.w; max_i = i; max_j = j; max_k = k; }
+          } else {
+            if (c.w > score) { score = c.w; max_i = i; max_j = j; max_k = k; }
+            if (c.n > score) { score = c.n; max_i = i; max_j = j; max_k = k; }
+            if (c.nw > score) { score = c.nw; max_i = i; max_j = j; max_k = k; }
+          }
+        }
+      }
+    }
+    if (i + 1 < lenb) {                                                   // :598-606
+      int nx_min, nx_max;
+      anchor_get_x_range(&rectangle, lena, lenb, i + 1, &nx_min, &nx_max);
+      for (int j = x_max + 1; j <= nx_max; j++) init_cell((size_t)(i + 1) * (lena + 1) + (j + 1), 0);
+    }
+  }
+  *sfr = SwFullCsResults();
+  sfr->score = score;
+  if (!(score >= 0 && score >= threshscore)) { sfr->score = 0; return; }  // :1216-1226
+  // do_backtrace :633-937: bt entries = type | 0x80 when the step crosses over
+  enum { BACK_INSERTION = 1, BACK_A_DELETION, BACK_B_DELETION, BACK_C_DELETION, BACK_D_DELETION, BACK_A_MM, BACK_B_MM, BACK_C_MM, BACK_D_MM };
+  int i = max_i, j = max_j, k = max_k;
+  const Cell* cell = &m[(size_t)(i + 1) * (lena + 1) + j + 1];
+  int from = cell->from[k].bnw, fromscore = cell->from[k].nw;
+  if (cell->from[k].w > fromscore) { from = cell->from[k].bw; fromscore = cell->from[k].w; }
+  if (cell->from[k].n > fromscore) from = cell->from[k].bn;
+  assert(from != 0);
+  std::vector<uint8_t> rev;
+  while (i >= 0 && j >= 0) {
+    const int dir = from >> 2, lay = from & 3;
+    uint8_t bt;
+    if (dir == FROM_NORTH_NORTH || dir == FROM_NORTH_NORTHWEST) { sfr->deletions++; sfr->read_start = i--; bt = (uint8_t)(BACK_A_DELETION + k); }
+    else if (dir == FROM_WEST_WEST || dir == FROM_WEST_NORTHWEST) { sfr->insertions++; sfr->genome_start = j--; bt = BACK_INSERTION; }
+    else {
+      if (db[j] == qr[k][i] || db[j] == 15 || qr[k][i] == 15) sfr->matches++; else sfr->mismatches++;
+      sfr->read_start = i--; sfr->genome_start = j--; bt = (uint8_t)(BACK_A_MM + k);
+    }
+    if (k != lay) { bt |= 0x80; sfr->crossovers++; k = lay; }
+    rev.push_back(bt);
+    cell = &m[(size_t)(i + 1) * (lena + 1) + j + 1];
+    switch (dir) {
+      case FROM_NORTH_NORTH: from = cell->from[k].bn; break;
+      case FROM_NORTH_NORTHWEST: from = cell->from[k].bnw; break;
+      case FROM_WEST_WEST: from = cell->from[k].bw; break;
+      case FROM_WEST_NORTHWEST: from = cell->from[k].bnw; break;
+      case FROM_NORTHWEST_NORTH: from = cell->from[k].bn; break;
+      case FROM_NORTHWEST_NORTHWEST: from = cell->from[k].bnw; break;
+      case FROM_NORTHWEST_WEST: from = cell->from[k].bw; break;
+      default: assert(0);
+    }
+    if (from == 0) break;
+  }
+  if (k != 0) { rev.back() |= 0x80; sfr->crossovers++; }                   // :929-932 (first step of the alignment)
+  // pretty_print :945-1060
+  {
+    int pi = sfr->read_start, pj = sfr->genome_start;
+    for (size_t t = rev.size(); t-- > 0;) {
+      const uint8_t bt = rev[t]; const int type = bt & 0x0f; const bool xov = (bt & 0x80) != 0;
+      if (type == BACK_INSERTION) { sfr->dbalign.push_back(LSTRANS[db[pj++]]); sfr->qralign.push_back('-'); sfr->ops.push_back('I'); continue; }
+      const bool del = type >= BACK_A_DELETION && type <= BACK_D_DELETION;
+      const int lay = del ? type - BACK_A_DELETION : type - BACK_A_MM;
+      char q = LSTRANS[qr[lay][pi++]];
+      if (xov) q = (char)tolower((int)q);
+      if (del) { sfr->dbalign.push_back('-'); sfr->qralign.push_back(q); sfr->ops.push_back('D'); }
+      else {
+        const char d = LSTRANS[db[pj++]];
+        if (q == 'n' || q == 'N') q = xov ? (char)tolower((int)d) : d;
+        sfr->dbalign.push_back(d); sfr->qralign.push_back(q); sfr->ops.push_back('M');
+      }
+    }
+  }
+  sfr->gmapped = max_j - sfr->genome_start + 1;                          // :1219-1223
+  sfr->genome_start += (int)goff;
+  sfr->rmapped = max_i - sfr->read_start + 1;
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // Per-read pipeline (gmapper/mapping.c)

@@ -152,6 +152,23 @@ int gmo_sw_full_ls(const uint32_t* genome, int goff, int glen, const uint32_t* r
   return 0;
 }
 
+// colour space kernels with the binary's CS defaults (gmapper-defaults.h:52-58); out[10] = ... deletions crossovers
+int gmo_sw_vector_cs(const uint32_t* genome_cs, int goff, int glen, const uint32_t* read, int rlen, const uint32_t* genome_ls, int initbp) {
+  Params P = default_params();
+  return sw_vector_cs(P, 10 + (-20), genome_cs, goff, glen, read, rlen, genome_ls, initbp);
+}
+int gmo_sw_full_cs(const uint32_t* genome_ls, int goff, int glen, const uint32_t* read, int rlen, int initbp, int thresh,
+                   long long ax, long long ay, int alen, int awidth, int revcmpl, int* out, char* dbalign, char* qralign, int cap) {
+  CsParams C; SwFullCsResults s;
+  Anchor a; a.x = ax; a.y = ay; a.length = alen; a.width = awidth; a.weight = 1;
+  sw_full_cs(C, genome_ls, goff, glen, read, rlen, initbp, thresh, &s, revcmpl != 0, &a, 1);
+  int v[10] = {s.score, s.read_start, s.rmapped, s.genome_start, s.gmapped, s.matches, s.mismatches, s.insertions, s.deletions, s.crossovers};
+  memcpy(out, v, sizeof v);
+  if ((int)s.dbalign.size() + 1 > cap) return -1;
+  strcpy(dbalign, s.dbalign.c_str()); strcpy(qralign, s.qralign.c_str());
+  return 0;
+}
+
 // opts = "key=value;key=value": the reference's command-line options by their long names (gmapper.c:1040-1140):
 // match mismatch open-r ext-r open-q ext-q match-window cmw-overlap cmw-threshold vec-threshold full-threshold
 // cmw-mode report anchor-width cutoff strata max-alignments seeds (comma separated 0/1 strings)

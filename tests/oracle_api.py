@@ -38,6 +38,9 @@ def load():
     L.gmo_session_set_pairing.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.gmo_map_pairs_sam.argtypes = [C.c_void_p, C.c_int, C.c_int, u8p, C.c_int, u8p, C.c_char_p, C.c_char_p, C.c_int]; L.gmo_map_pairs_sam.restype = C.c_void_p
     L.gmo_free.argtypes = [C.c_void_p]
+    L.gmo_sw_vector_cs.argtypes = [u32p, C.c_int, C.c_int, u32p, C.c_int, u32p, C.c_int]; L.gmo_sw_vector_cs.restype = C.c_int
+    L.gmo_sw_full_cs.argtypes = [u32p, C.c_int, C.c_int, u32p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(C.c_int), C.c_char_p, C.c_char_p, C.c_int]; L.gmo_sw_full_cs.restype = C.c_int
     L.gmo_index_selfcheck.argtypes = [C.c_void_p, C.c_int]; L.gmo_index_selfcheck.restype = C.c_int
     L.gmo_set_threads.argtypes = [C.c_int]
     L.gmo_map_tophits.argtypes = [C.c_void_p, C.c_int, C.c_int, u8p, C.c_int, C.POINTER(C.c_longlong), C.c_long]; L.gmo_map_tophits.restype = C.c_long
@@ -170,3 +173,18 @@ OPTION_CASES = {
 def load_option_sam(base, tag):
     with gzip.open(os.path.join(ROOT, "tests", "golden", "%s@%s.sam.gz" % (base, tag)), "rb") as f:
         return f.read()
+
+
+def load_kat_cs():
+    """colour-space known answers produced by the reference's own sw_vector(use_colours) / sw_full_cs (oracle/ref_kat_cs.cpp)"""
+    recs = []
+    words = lambda t: np.array([int(x, 16) for x in t.split(b",")], dtype=np.uint32)
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "sw_kat_cs.txt.gz"), "rb") as f:
+        for line in f:
+            t = line.split()
+            if t[0] == b"C":
+                recs.append(("C", int(t[1]), int(t[2]), int(t[3]), int(t[4]), words(t[5]), words(t[6]), words(t[7]), int(t[8])))
+            else:
+                recs.append(("S", [int(x) for x in t[1:11]], words(t[11]), words(t[12]), [int(x) for x in t[13:23]],
+                             b"" if t[23] == b"-" else t[23], b"" if t[24] == b"-" else t[24]))
+    return recs

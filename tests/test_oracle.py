@@ -99,3 +99,27 @@ def test_oracle_option_sets_match_reference(tag, oracle_lib):
         got = oa.sam_header(contigs) + s.map_sam(reads, nthreads=4)
     s.close()
     assert got == want, "oracle SAM differs from the reference for option set %s" % tag
+
+
+def test_oracle_colour_space_kernels_match_reference_known_answers(oracle_lib):
+    """S1/S2 in colour space: the restated sw_vector (first-colour row) and sw_full_cs (4 layers, crossovers, traceback,
+    alignment strings) against the reference's own functions on 700 random cases x 2 tie-break directions"""
+    import ctypes as C
+    L = oa.load(); u32p = C.POINTER(C.c_uint32)
+    nc = ns = 0
+    for r in oa.load_kat_cs():
+        if r[0] == "C":
+            _, goff, glen, rlen, initbp, gcs, gls, rd, score = r
+            got = L.gmo_sw_vector_cs(gcs.ctypes.data_as(u32p), goff, glen, rd.ctypes.data_as(u32p), rlen, gls.ctypes.data_as(u32p), initbp)
+            assert got == score, (goff, glen, rlen, initbp, got, score); nc += 1
+        else:
+            _, (goff, glen, rlen, initbp, ax, ay, alen, awidth, rv, thresh), gls, rd, want, db, qr = r
+            out = (C.c_int * 10)(); dba = C.create_string_buffer(4096); qra = C.create_string_buffer(4096)
+            assert L.gmo_sw_full_cs(gls.ctypes.data_as(u32p), goff, glen, rd.ctypes.data_as(u32p), rlen, initbp, thresh, ax, ay, alen, awidth, rv,
+                                    out, dba, qra, 4096) == 0
+            if want[0] == 0:
+                assert out[0] == 0
+            else:
+                assert list(out) == want and dba.value == db and qra.value == qr, (list(out), want, dba.value, db, qra.value, qr)
+            ns += 1
+    assert nc >= 700 and ns >= 1400

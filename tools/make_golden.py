@@ -195,8 +195,17 @@ def index_cases():
     print("idxfix: %d SAM records from the reference's -L run; files:" % sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@")), sorted(os.listdir(d)))
 
 
+def cs_kat_cases():
+    kat = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_kat_cs"), "700"], capture_output=True, check=True).stdout
+    with gzip.open(os.path.join(OUT, "sw_kat_cs.txt.gz"), "wb", compresslevel=9) as f:
+        f.write(kat)
+    print("sw_kat_cs:", kat.count(b"\nC ") + 1, "colour-space vector,", kat.count(b"\nS "), "sw_full_cs")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--cs-kat-only" in sys.argv:
+        cs_kat_cases(); return
     if "--index-only" in sys.argv:
         index_cases(); return
     if "--options-only" in sys.argv:
@@ -217,6 +226,7 @@ def main():
     paired_cases()
     option_cases()
     index_cases()
+    cs_kat_cases()
 
 
 if __name__ == "__main__":
