@@ -123,9 +123,14 @@ int gm_sw_vector_batch(int n, const uint32_t *genome, uint64_t genome_words, con
  * as with the reference's xstrdup (ref: sw-full-ls.c:676-677).
  * ------------------------------------------------------------------------------------------- */
 struct gm_anchor { long long x, y; int length, width, weight, cn, score; };
-struct gm_sw_full_results {
+struct gm_sw_full_results {                    /* field for field struct sw_full_results (ref: common/sw-full-common.h:13-48) */
   int read_start, rmapped, genome_start, gmapped, matches, mismatches, insertions, deletions, score;
-  char *dbalign, *qralign;
+  int posterior_score, pct_posterior_score;   /* filled by hit_run_post_sw in the reference, untouched here */
+  char *dbalign, *qralign, *qual;
+  double posterior;
+  int mqv; double z0, z1, z2, z3, pr_top_random_at_location, pr_missed_mp, insert_size_denom;
+  int crossovers;                             /* colour space only */
+  bool dup, in_use;
 };
 int sw_full_ls_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
                      int match, int mismatch, bool reset_stats, int anchor_width);
@@ -133,6 +138,25 @@ void sw_full_ls(uint32_t *genome, int goff, int glen, uint32_t *read, int rlen, 
                 struct gm_sw_full_results *sfr, bool revcmpl, struct gm_anchor *anchors, int anchors_cnt,
                 int local_alignment);
 int sw_full_ls_cleanup(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * S1/S2 in colour space.  sw_vector_setup(..., use_colours = 1, ...) makes sw_vector() compare the read's first colour with
+ * lstocs(genome_ls[j], initbp) (ref: common/sw-vector.c:112-146); `mismatch` is then match + crossover (ref: gmapper.c:2935).
+ * sw_full_cs: four letter-space translations of the colour read, 3-state affine DP in four layers with crossovers between
+ * layers on the NW and N transitions, traceback with crossover marks (lower-case in qralign), ref: common/sw-full-cs.c:249-1236.
+ * Global mode (local_alignment == 0) and one anchor box, as gmapper calls it (ref: mapping.c:375-379); crossover_score
+ * (per-position penalties from read qualities) must be NULL.  The colour-space read pipeline around these two kernels
+ * (CS index, post_sw, CS SAM tags) is not built yet.
+ * ------------------------------------------------------------------------------------------- */
+int sw_full_cs_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
+                     int match, int mismatch, int global_xover_penalty, bool reset_stats, int anchor_width, int indel_taboo_len);
+void sw_full_cs(uint32_t *genome_ls, int goff, int glen, uint32_t *read, int rlen, int initbp, int threshscore,
+                struct gm_sw_full_results *sfr, bool revcmpl, bool is_rna, struct gm_anchor *anchors, int anchors_cnt,
+                int local_alignment, int *crossover_score);
+int sw_full_cs_cleanup(void);
+/* batch form of the colour-space vector filter: as gm_sw_vector_batch plus the letter-space genome and one initial base per read */
+int gm_sw_vector_batch_cs(int n, const uint32_t *genome_cs, const uint32_t *genome_ls, uint64_t genome_words, const int64_t *g_off,
+                          const int *glen, const uint32_t *reads, int read_words, const int *rlen, const int *initbp, int *scores);
 
 /* ---------------------------------------------------------------------------------------------
  * S4: the per-read pipeline.  Replaces handle_read() for unpaired letter-space reads

@@ -843,18 +843,17 @@ extern "C" int gm_debug_tophits(gm_session_t* s, int n_reads, int read_len, cons
 }
 
 // ---- S1: vector SW on caller bitfields ----------------------------------------------------------
-struct SwVecState { bool init = false; GmScoreDev sc; int dblen = 0, qrlen = 0; uint64_t invocs = 0, cells = 0; double secs = 0; };
+struct SwVecState { bool init = false, colours = false; GmScoreDev sc; int dblen = 0, qrlen = 0; uint64_t invocs = 0, cells = 0; double secs = 0; };
 static thread_local SwVecState g_sv;
 
 extern "C" int sw_vector_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
                                int match, int mismatch, int use_colours, bool reset_stats) {
   if (match * qrlen >= 32768) { gm_set_error("match * qrlen >= 32768 (ref: sw-vector.c:393-398)"); return GM_E_RANGE; }
-  if (use_colours) { gm_set_error("colour space is not implemented"); return GM_E_ARG; }
   if (gm_device_count() < 1) { gm_set_error("no HIP device"); return GM_E_NODEVICE; }
   gm_params_t P; gm_params_default(&P);
   P.match_score = match; P.mismatch_score = mismatch; P.a_gap_open_score = a_gap_open; P.a_gap_extend_score = a_gap_ext;
   P.b_gap_open_score = b_gap_open; P.b_gap_extend_score = b_gap_ext;
-  g_sv.sc = make_score(P); g_sv.dblen = dblen; g_sv.qrlen = qrlen; g_sv.init = true;
+  g_sv.sc = make_score(P); g_sv.dblen = dblen; g_sv.qrlen = qrlen; g_sv.init = true; g_sv.colours = use_colours != 0;
   if (reset_stats) { g_sv.invocs = g_sv.cells = 0; g_sv.secs = 0; }
   return 0;
 }
@@ -887,10 +886,15 @@ extern "C" int gm_sw_vector_batch(int n, const uint32_t* genome, uint64_t genome
 }
 
 extern "C" int sw_vector(uint32_t* genome, int goff, int glen, uint32_t* read, int rlen, uint32_t* genome_ls, int initbp, bool is_rna) {
-  (void)genome_ls; (void)initbp; (void)is_rna;
+  (void)is_rna;
   if (!g_sv.init) abort();   // ref: sw-vector.c:462-463
   int64_t go = goff; int score = 0;
   const uint64_t gw = ((uint64_t)goff + glen + 7) / 8;
+  if (g_sv.colours) {        // colour space: genome = colours, genome_ls = letters of the same contig (ref: sw-vector.c:476-479)
+    if (!genome_ls) { gm_set_error("sw_vector: colour space needs genome_ls"); return GM_E_ARG; }
+    int rc = gm_sw_vector_batch_cs(1, genome, genome_ls, gw, &go, &glen, read, (rlen + 7) / 8, &rlen, &initbp, &score);
+    return rc == GM_OK ? score : rc;
+  }
   int rc = gm_sw_vector_batch(1, genome, gw, &go, &glen, read, (rlen + 7) / 8, &rlen, &score);
   return rc == GM_OK ? score : rc;
 }
@@ -953,3 +957,97 @@ extern "C" void sw_full_ls(uint32_t* genome, int goff, int glen, uint32_t* read,
   }
   sfr->dbalign = strdup(db.c_str()); sfr->qralign = strdup(qr.c_str());
 }
+
+extern "C" int gm_sw_vector_batch_cs(int n, const uint32_t* genome_cs, const uint32_t* genome_ls, uint64_t genome_words, const int64_t* g_off,
+                                     const int* glen, const uint32_t* reads, int read_words, const int* rlen, const int* initbp, int* scores) {
+  if (!g_sv.init) { gm_set_error("sw_vector called before sw_vector_setup"); return GM_E_NOTSETUP; }
+  if (n <= 0) return GM_OK;
+  int max_g = 0, max_r = 0;
+  for (int i = 0; i < n; i++) { max_g = std::max(max_g, glen[i]); max_r = std::max(max_r, rlen[i]); if (glen[i] < 1 || rlen[i] < 1 || initbp[i] < 0 || initbp[i] > 3) return GM_E_ARG; }
+  if (max_g > g_sv.dblen || max_r > g_sv.qrlen) { gm_set_error("window/read longer than sw_vector_setup sizes"); return GM_E_ARG; }
+  uint32_t *dgc = nullptr, *dgl = nullptr, *dr = nullptr; long long* dgo = nullptr; int *dgn = nullptr, *drl = nullptr, *dib = nullptr, *ds = nullptr;
+  GM_HIP(hipMalloc(&dgc, (genome_words + 8) * 4)); GM_HIP(hipMalloc(&dgl, (genome_words + 8) * 4)); GM_HIP(hipMalloc(&dr, (size_t)n * read_words * 4 + 32));
+  GM_HIP(hipMalloc(&dgo, (size_t)n * 8)); GM_HIP(hipMalloc(&dgn, (size_t)n * 4)); GM_HIP(hipMalloc(&drl, (size_t)n * 4)); GM_HIP(hipMalloc(&dib, (size_t)n * 4)); GM_HIP(hipMalloc(&ds, (size_t)n * 4));
+  GM_HIP(hipMemset(dgc, 0, (genome_words + 8) * 4)); GM_HIP(hipMemset(dgl, 0, (genome_words + 8) * 4));
+  GM_HIP(hipMemcpy(dgc, genome_cs, genome_words * 4, hipMemcpyHostToDevice)); GM_HIP(hipMemcpy(dgl, genome_ls, genome_words * 4, hipMemcpyHostToDevice));
+  GM_HIP(hipMemcpy(dr, reads, (size_t)n * read_words * 4, hipMemcpyHostToDevice));
+  GM_HIP(hipMemcpy(dgo, g_off, (size_t)n * 8, hipMemcpyHostToDevice)); GM_HIP(hipMemcpy(dgn, glen, (size_t)n * 4, hipMemcpyHostToDevice));
+  GM_HIP(hipMemcpy(drl, rlen, (size_t)n * 4, hipMemcpyHostToDevice)); GM_HIP(hipMemcpy(dib, initbp, (size_t)n * 4, hipMemcpyHostToDevice));
+  int rc = gm_launch_sw_vector_batch_cs(g_sv.sc, n, dgc, dgl, dgo, dgn, dr, read_words, drl, dib, max_g, max_r, ds, 0);
+  if (rc == GM_OK) { GM_HIP(hipDeviceSynchronize()); GM_HIP(hipMemcpy(scores, ds, (size_t)n * 4, hipMemcpyDeviceToHost)); }
+  (void)hipFree(dgc); (void)hipFree(dgl); (void)hipFree(dr); (void)hipFree(dgo); (void)hipFree(dgn); (void)hipFree(drl); (void)hipFree(dib); (void)hipFree(ds);
+  for (int i = 0; i < n; i++) { g_sv.invocs++; g_sv.cells += (uint64_t)glen[i] * rlen[i]; }
+  return rc;
+}
+
+// ---- S2 in colour space: sw_full_cs on caller bitfields (ref: common/sw-full-cs.c:1084-1236) --------------
+struct SwFullCsState { bool init = false; int p[9]; int dblen = 0, qrlen = 0; };
+static thread_local SwFullCsState g_sc;
+extern "C" int sw_full_cs_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
+                                int match, int mismatch, int global_xover_penalty, bool reset_stats, int anchor_width, int indel_taboo_len) {
+  (void)reset_stats;
+  if (gm_device_count() < 1) { gm_set_error("no HIP device"); return GM_E_NODEVICE; }
+  const int p[9] = {match, mismatch, global_xover_penalty, -a_gap_open, -a_gap_ext, -b_gap_open, -b_gap_ext, anchor_width, indel_taboo_len};
+  memcpy(g_sc.p, p, sizeof p); g_sc.dblen = dblen; g_sc.qrlen = qrlen; g_sc.init = true;
+  return 0;
+}
+extern "C" int sw_full_cs_cleanup(void) { g_sc.init = false; return 0; }
+
+extern "C" void sw_full_cs(uint32_t* genome_ls, int goff, int glen, uint32_t* read, int rlen, int initbp, int threshscore,
+                           struct gm_sw_full_results* sfr, bool revcmpl, bool is_rna, struct gm_anchor* anchors, int anchors_cnt,
+                           int local_alignment, int* crossover_score) {
+  (void)is_rna;
+  if (!g_sc.init) abort();   // ref: sw-full-cs.c:1155-1156
+  auto fail = [&](const char* why) { gm_set_error("sw_full_cs: %s", why); sfr->score = 0; sfr->dbalign = nullptr; sfr->qralign = nullptr; };
+  if (local_alignment || crossover_score || anchors == nullptr || anchors_cnt != 1 || glen > g_sc.dblen || rlen > g_sc.qrlen || glen < 1 || rlen < 1 ||
+      initbp < 0 || initbp > 3 || g_sc.p[7] < 0) {
+    fail("only the global mode with one anchor box and the global crossover penalty (gmapper's call, ref: mapping.c:375-379) is implemented"); return;
+  }
+  const uint64_t gw = ((uint64_t)goff + glen + 7) / 8 + 8; const int rwords = (rlen + 7) / 8 + 1;
+  const int ops_cap = glen + rlen + 8;
+  const size_t back_bytes = ((size_t)glen * rlen * 3 + 64) * 4;
+  uint32_t *dg = nullptr, *dr = nullptr, *dback = nullptr; uint8_t* dops = nullptr; int* dout = nullptr;
+  bool ok = hipMalloc(&dg, gw * 4) == hipSuccess && hipMalloc(&dr, (size_t)rwords * 4) == hipSuccess && hipMalloc(&dback, back_bytes) == hipSuccess &&
+            hipMalloc(&dops, ops_cap) == hipSuccess && hipMalloc(&dout, 16 * 4) == hipSuccess;
+  int out[16] = {0}; std::vector<uint8_t> ops(ops_cap);
+  if (ok) {
+    ok = hipMemset(dg, 0, gw * 4) == hipSuccess && hipMemcpy(dg, genome_ls, (gw - 8) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemset(dr, 0, (size_t)rwords * 4) == hipSuccess && hipMemcpy(dr, read, (size_t)(rwords - 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemset(dback, 0, back_bytes) == hipSuccess &&                                     // out-of-band cells: back == 0 (ref: init_cell)
+         gm_launch_sw_full_cs_single(g_sc.p, dg, goff, glen, dr, rlen, initbp, threshscore, anchors[0].x, anchors[0].y, anchors[0].length, anchors[0].width,
+                                     revcmpl ? 1 : 0, dback, dout, dops, ops_cap, 0) == GM_OK &&
+         hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, dout, 12 * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(ops.data(), dops, ops_cap, hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  (void)hipFree(dg); (void)hipFree(dr); (void)hipFree(dback); (void)hipFree(dops); (void)hipFree(dout);
+  if (!ok) { fail("HIP failure"); return; }
+  sfr->score = out[0];
+  if (out[0] <= 0) { sfr->score = 0; sfr->dbalign = nullptr; sfr->qralign = nullptr; return; }          // below threshold: no strings (ref :1224-1226)
+  sfr->read_start = out[1]; sfr->rmapped = out[2]; sfr->genome_start = out[3]; sfr->gmapped = out[4];
+  sfr->matches += out[5]; sfr->mismatches += out[6]; sfr->insertions += out[7]; sfr->deletions += out[8]; sfr->crossovers += out[9];
+  // pretty_print, ref :945-1060: the four translations of the colour read, lower case on crossovers, N in the read shows the genome letter
+  auto nib = [](const uint32_t* b, long long i) { return (int)((b[i / 8] >> (4 * (i % 8))) & 0xf); };
+  std::vector<uint8_t> qr[4];
+  for (int k = 0; k < 4; k++) {
+    qr[k].resize(rlen); int letter = (k + initbp) % 4;
+    for (int j = 0; j < rlen; j++) {
+      const int base = nib(read, j);
+      if (base == 15) { qr[k][j] = 15; letter = (k + initbp) % 4; }
+      else { const int l2 = (letter % 2 == 0) ? ((4 + letter + base) % 4) : ((4 + letter - base) % 4); qr[k][j] = (uint8_t)((letter == 15 || base > 3) ? 15 : l2); letter = qr[k][j]; }
+    }
+  }
+  std::string db, q;
+  int pi = out[1], pj = out[3];
+  for (int t = 0; t < std::min(out[10], ops_cap); t++) {
+    const int type = ops[t] & 0x0f; const bool xov = (ops[t] & 0x80) != 0;
+    if (type == 1) { db.push_back(LSTRANS[nib(genome_ls, pj++)]); q.push_back('-'); continue; }
+    const bool del = type >= 2 && type <= 5;
+    const int lay = del ? type - 2 : type - 6;
+    char c = LSTRANS[qr[lay][pi++]];
+    if (xov) c = (char)tolower((int)c);
+    if (del) { db.push_back('-'); q.push_back(c); }
+    else { const char d = LSTRANS[nib(genome_ls, pj++)]; if (c == 'n' || c == 'N') c = xov ? (char)tolower((int)d) : d; db.push_back(d); q.push_back(c); }
+  }
+  sfr->dbalign = strdup(db.c_str()); sfr->qralign = strdup(q.c_str());
+}
+

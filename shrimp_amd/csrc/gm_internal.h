@@ -105,3 +105,11 @@ int gm_launch_sw_vector_batch(const GmScoreDev& sc, int n, const uint32_t* d_gen
 int gm_launch_sw_full_single(const GmScoreDev& sc, const uint32_t* d_genome, long long goff, int glen, const uint32_t* d_read, int rlen,
                              long long ax, long long ay, int alen, int awidth, int revcmpl, uint8_t* d_back, int* d_out, uint8_t* d_ops, int ops_cap,
                              hipStream_t stream);
+
+// colour space S1/S2 (gm_sw.hip): cs_params9 = match mismatch xover a_go a_ge b_go b_ge anchor_width indel_taboo_len (penalties positive)
+int gm_launch_sw_vector_batch_cs(const GmScoreDev& sc, int n, const uint32_t* d_genome_cs, const uint32_t* d_genome_ls, const long long* d_goff,
+                                 const int* d_glen, const uint32_t* d_reads, int read_words, const int* d_rlen, const int* d_initbp, int max_g, int max_r,
+                                 int* d_scores, hipStream_t stream);
+int gm_launch_sw_full_cs_single(const int* cs_params9, const uint32_t* d_genome_ls, long long goff, int glen, const uint32_t* d_read, int rlen, int initbp,
+                                int thresh, long long ax, long long ay, int alen, int awidth, int revcmpl, uint32_t* d_back, int* d_out, uint8_t* d_ops,
+                                int ops_cap, hipStream_t stream);

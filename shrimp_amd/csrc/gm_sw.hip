@@ -41,8 +41,11 @@ __device__ __forceinline__ uint32_t up_of(uint32_t own, uint32_t shifted) { retu
 
 // Score-only SW of db[0..glen) x qr[0..rlen) by one wave.  db/qr are byte arrays of 4-bit codes in
 // LDS; carry is 2*(glen) int16 in LDS, used only when rlen > 128.  Every lane returns the score.
-__device__ int sw_vector_wave(const uint8_t* db, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc,
-                              int16_t* carry, int lane) {
+// CS: colour space -- read row 0 (the first colour) is compared with db0[c] = lstocs(genome_ls[c], initbp) instead of the colour
+// genome (ref: common/sw-vector.c:112-146); the colour codes still flow on to row 1.
+template <bool CS>
+__device__ int sw_vector_wave_t(const uint8_t* db, const uint8_t* db0, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc,
+                                int16_t* carry, int lane) {
   const uint32_t v_match = pk(sc.match, sc.match);
   const uint32_t v_delta = pk(sc.mismatch - sc.match, sc.mismatch - sc.match);
   const uint32_t v_a_ext = pk(sc.a_ge, sc.a_ge), v_a_oe = pk(sc.a_go + sc.a_ge, sc.a_go + sc.a_ge);
@@ -60,11 +63,12 @@ __device__ int sw_vector_wave(const uint8_t* db, int glen, const uint8_t* qr, in
     uint32_t Gprev = pk(SW_DB_SENT, SW_DB_SENT);
     uint32_t upH_prev = 0;                     // H(r-1, c-1) for the step to come
     const bool more = (s + 1 < n_stripes);
-    uint32_t dbv = 0, chv = 0, cbv = 0;
+    uint32_t dbv = 0, chv = 0, cbv = 0, db0v = 0;
     for (int t = 0; t < steps; t++) {
       if ((t & 63) == 0) {                     // refill the per-lane staging of the next 64 columns
         const int c = t + lane;
         dbv = (c < glen) ? (uint32_t)db[c] : SW_DB_SENT;
+        if (CS && s == 0) db0v = (c < glen) ? (uint32_t)db0[c] : SW_DB_SENT;
         if (s > 0) { chv = (c < glen) ? (uint32_t)(uint16_t)carryH[c] : 0u; cbv = (c < glen) ? (uint32_t)(uint16_t)carryB[c] : (uint32_t)(uint16_t)(-sc.b_go); }
       }
       const int sl = t & 63;
@@ -79,7 +83,12 @@ __device__ int sw_vector_wave(const uint8_t* db, int glen, const uint8_t* qr, in
       const uint32_t a = pk_max(pk_sub(Aprev, v_a_ext), pk_sub(Hprev, v_a_oe));
       const uint32_t b = pk_max(pk_sub(upB, v_b_ext), pk_sub(upH, v_b_oe));
       // s = match where codes are equal, else mismatch:  match + delta * min(code_xor, 1)
-      const uint32_t x = G ^ q;
+      uint32_t Gc = G;
+      if (CS && s == 0) {                      // row 0 lives in the low half of lane 0
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)db0v, sl);
+        if (lane == 0) Gc = (G & 0xFFFF0000u) | g0;
+      }
+      const uint32_t x = Gc ^ q;
       const uint32_t ne = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, x), __builtin_bit_cast(u16x2, v_one)));
       const uint32_t sv = as_u(as_s(ne) * as_s(v_delta) + as_s(v_match));
       uint32_t h = pk_add(upH_prev, sv);
@@ -98,6 +107,9 @@ __device__ int sw_vector_wave(const uint8_t* db, int glen, const uint8_t* qr, in
   int best = max((int)(int16_t)(v_score & 0xFFFF), (int)(int16_t)(v_score >> 16));
   for (int d = 32; d > 0; d >>= 1) best = max(best, __shfl_xor(best, d));
   return best;
+}
+__device__ int sw_vector_wave(const uint8_t* db, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc, int16_t* carry, int lane) {
+  return sw_vector_wave_t<false>(db, nullptr, glen, qr, rlen, sc, carry, lane);
 }
 
 // unpack `len` codes starting at global position g0 into dst (forward) or reverse-complemented
@@ -670,6 +682,271 @@ int gm_launch_sw_vector_batch(const GmScoreDev& sc, int n, const uint32_t* d_gen
   const size_t lds = ((max_r + 15) & ~15) + ((max_g + 15) & ~15) + (size_t)max_g * 4 + 64;
   const int grid = std::min(n, 256 * 16);
   hipLaunchKernelGGL(k_sw_vector_batch, dim3(grid), dim3(GM_WAVE), lds, stream, sc, n, d_genome, d_goff, d_glen, d_reads, read_words, d_rlen, max_g, max_r, d_scores);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+// =============================================================================================
+// Colour space (S1/S2 seams; the CS read pipeline around them is not built yet)
+// =============================================================================================
+__device__ __forceinline__ int cs_lstocs(int a, int b) {           // ref: common/util.h:182-205 (is_rna = false)
+  return (a > 3 || b > 3) ? 15 : (a ^ b);             // colourmat[a][b] == a ^ b
+}
+__device__ __forceinline__ int cs_cstols(int first_letter, int colour) {   // ref: common/util.h:157-180
+  if (first_letter == 15 || colour < 0 || colour > 3) return 15;
+  return (first_letter % 2 == 0) ? ((4 + first_letter + colour) % 4) : ((4 + first_letter - colour) % 4);
+}
+
+__global__ void __launch_bounds__(GM_WAVE)
+k_sw_vector_batch_cs(GmScoreDev sc, int n, const uint32_t* __restrict__ genome_cs, const uint32_t* __restrict__ genome_ls,
+                     const long long* __restrict__ goff, const int* __restrict__ glen, const uint32_t* __restrict__ reads, int read_words,
+                     const int* __restrict__ rlen, const int* __restrict__ initbp, int max_g, int max_r, int* __restrict__ scores) {
+  extern __shared__ __align__(16) uint8_t sm[];
+  const int lane = threadIdx.x;
+  uint8_t* qr = sm;
+  uint8_t* db = sm + ((max_r + 15) & ~15);
+  uint8_t* db0 = db + ((max_g + 15) & ~15);
+  int16_t* carry = (int16_t*)(db0 + ((max_g + 15) & ~15));
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    __syncthreads();
+    load_read(reads + (size_t)i * read_words, rlen[i], false, qr, lane);
+    load_window(genome_cs, (uint64_t)goff[i], glen[i], false, db, lane);
+    load_window(genome_ls, (uint64_t)goff[i], glen[i], false, db0, lane);
+    __syncthreads();
+    for (int c = lane; c < glen[i]; c += GM_WAVE) db0[c] = (uint8_t)cs_lstocs(db0[c], initbp[i]);     // first-colour row, ref: sw-vector.c:131
+    __syncthreads();
+    const int s = sw_vector_wave_t<true>(db, db0, glen[i], qr, rlen[i], sc, carry, lane);
+    if (lane == 0) scores[i] = s;
+  }
+}
+
+struct GmCsDev { int match, mismatch, xover, a_go, a_ge, b_go, b_ge, anchor_width, taboo; };
+
+// sw_full_cs (ref: common/sw-full-cs.c:249-623): lane = read row, column t - lane at step t, twelve running values per cell
+// (4 layers x {nw, n, w}); what row r needs from row r - 1 arrives by DPP shifts.  back[cell] = three words of four codes
+// (dir << 2 | layer) for the nw / n / w states of the four layers.  Out-of-band cells are -INT_MAX/2 as init_cell(.., 0, ..) leaves them.
+struct CsBest { int score, i, j, k, e_nw, e_n, e_w; };
+__device__ CsBest full_sw_cs_wave(const uint8_t* db, int glen, const uint8_t* qr4, int qstride, int rlen, const GmCsDev& P, bool revcmpl,
+                                  long long rx, long long ry, int rl, int rw, uint32_t* back, int* carry, int lane) {
+  CsBest best; best.score = 0; best.i = best.j = best.k = 0; best.e_nw = best.e_n = best.e_w = 0;
+  const int xo = P.xover;
+  const int n_stripes = (rlen + 63) >> 6;
+  for (int s = 0; s < n_stripes; s++) {
+    const int r = s * 64 + lane;
+    const bool row_ok = r < rlen;
+    int q[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = row_ok ? qr4[k * qstride + r] : 0x7F;
+    int x_min = 0, x_max = -1;
+    if (row_ok) band_range(rx, ry, rl, rw, glen, r, &x_min, &x_max);
+    const bool notaboo = r < rlen - P.taboo;
+    const int rows = min(64, rlen - s * 64);
+    const int steps = glen + rows - 1;
+    int pw[12], d[12], cur[12];                      // (r, c-1), (r-1, c-1), this lane's latest cell; index = layer * 3 + {0 nw, 1 n, 2 w}
+#pragma unroll
+    for (int x = 0; x < 12; x++) { pw[x] = FS_NEG; d[x] = FS_NEG; cur[x] = FS_NEG; }
+    if (s == 0 && lane == 0) {                       // virtual row -1, column -1: init_cell(.., 1, xover), ref :201-215
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const int x = k ? xo : 0; d[k * 3] = x; d[k * 3 + 1] = -P.b_go + x; d[k * 3 + 2] = -P.a_go + x; }
+    }
+    const bool more = (s + 1 < n_stripes);
+    const bool last_row_lane = row_ok && (r == rlen - 1);
+    for (int t = 0; t < steps; t++) {
+      const int c = t - lane;
+      int u[12];
+#pragma unroll
+      for (int x = 0; x < 12; x++) {
+        int in;
+        if (s == 0) { const int k = x / 3, st = x % 3; const int xv = k ? xo : 0; in = (st == 0 ? 0 : (st == 1 ? -P.b_go : -P.a_go)) + xv; }
+        else in = (t < glen) ? carry[x * glen + t] : FS_NEG;
+        u[x] = shr1_i(cur[x], in);                    // cell (r-1, c)
+      }
+      const bool inband = row_ok && c >= x_min && c <= x_max;
+      int nv[12];
+#pragma unroll
+      for (int x = 0; x < 12; x++) nv[x] = FS_NEG;
+      if (inband) {
+        const int dbc = db[c];
+        uint32_t bw_nw = 0, bw_n = 0, bw_w = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int ms = (dbc == 15 || q[k] == 15) ? 0 : (dbc == q[k] ? P.match : P.mismatch);
+          int tmp, b;
+          // northwest, ref :356-438
+          if (!revcmpl) {
+            tmp = d[k * 3] + ms; b = (6 << 2) | k;
+            if (notaboo && d[k * 3 + 1] + ms > tmp) { tmp = d[k * 3 + 1] + ms; b = (5 << 2) | k; }
+            if (d[k * 3 + 2] + ms > tmp) { tmp = d[k * 3 + 2] + ms; b = (7 << 2) | k; }
+          } else {
+            tmp = d[k * 3 + 2] + ms; b = (7 << 2) | k;
+            if (notaboo && d[k * 3 + 1] + ms > tmp) { tmp = d[k * 3 + 1] + ms; b = (5 << 2) | k; }
+            if (d[k * 3] + ms > tmp) { tmp = d[k * 3] + ms; b = (6 << 2) | k; }
+          }
+#pragma unroll
+          for (int l = 0; l < 4; l++) {
+            if (l == k) continue;
+            if (!revcmpl) {
+              if (d[l * 3] + ms + xo > tmp) { tmp = d[l * 3] + ms + xo; b = (6 << 2) | l; }
+              if (notaboo && d[l * 3 + 1] + ms + xo > tmp) { tmp = d[l * 3 + 1] + ms + xo; b = (5 << 2) | l; }
+              if (d[l * 3 + 2] + ms + xo > tmp) { tmp = d[l * 3 + 2] + ms + xo; b = (7 << 2) | l; }
+            } else {
+              if (d[l * 3 + 2] + ms + xo > tmp) { tmp = d[l * 3 + 2] + ms + xo; b = (7 << 2) | l; }
+              if (notaboo && d[l * 3 + 1] + ms + xo > tmp) { tmp = d[l * 3 + 1] + ms + xo; b = (5 << 2) | l; }
+              if (d[l * 3] + ms + xo > tmp) { tmp = d[l * 3] + ms + xo; b = (6 << 2) | l; }
+            }
+          }
+          nv[k * 3] = tmp; bw_nw |= (uint32_t)b << (8 * k);
+          // north, ref :447-503
+          if (!revcmpl) {
+            tmp = u[k * 3] - P.b_go - P.b_ge; b = (2 << 2) | k;
+            if (!notaboo || u[k * 3 + 1] - P.b_ge > tmp) { tmp = u[k * 3 + 1] - P.b_ge; b = (1 << 2) | k; }
+          } else {
+            tmp = u[k * 3 + 1] - P.b_ge; b = (1 << 2) | k;
+            if (notaboo && u[k * 3] - P.b_go - P.b_ge > tmp) { tmp = u[k * 3] - P.b_go - P.b_ge; b = (2 << 2) | k; }
+          }
+#pragma unroll
+          for (int l = 0; l < 4; l++) {
+            if (l == k) continue;
+            if (!revcmpl) {
+              if (notaboo && u[l * 3] - P.b_go - P.b_ge + xo > tmp) { tmp = u[l * 3] - P.b_go - P.b_ge + xo; b = (2 << 2) | l; }
+              if (u[l * 3 + 1] - P.b_ge + xo > tmp) { tmp = u[l * 3 + 1] - P.b_ge + xo; b = (1 << 2) | l; }
+            } else {
+              if (u[l * 3 + 1] - P.b_ge + xo > tmp) { tmp = u[l * 3 + 1] - P.b_ge + xo; b = (1 << 2) | l; }
+              if (notaboo && u[l * 3] - P.b_go - P.b_ge + xo > tmp) { tmp = u[l * 3] - P.b_go - P.b_ge + xo; b = (2 << 2) | l; }
+            }
+          }
+          nv[k * 3 + 1] = tmp; bw_n |= (uint32_t)b << (8 * k);
+          // west, ref :512-541 (no crossover on a genomic gap)
+          if (!revcmpl) {
+            tmp = pw[k * 3] - P.a_go - P.a_ge; b = (3 << 2) | k;
+            if (!notaboo || pw[k * 3 + 2] - P.a_ge > tmp) { tmp = pw[k * 3 + 2] - P.a_ge; b = (4 << 2) | k; }
+          } else {
+            tmp = pw[k * 3 + 2] - P.a_ge; b = (4 << 2) | k;
+            if (notaboo && pw[k * 3] - P.a_go - P.a_ge > tmp) { tmp = pw[k * 3] - P.a_go - P.a_ge; b = (3 << 2) | k; }
+          }
+          nv[k * 3 + 2] = tmp; bw_w |= (uint32_t)b << (8 * k);
+          if (last_row_lane) {                         // ref :547-575
+            const int a0 = revcmpl ? nv[k * 3 + 2] : nv[k * 3], a1 = nv[k * 3 + 1], a2 = revcmpl ? nv[k * 3] : nv[k * 3 + 2];
+            const int m = max(a0, max(a1, a2));
+            if (m > best.score) { best.score = m; best.i = r; best.j = c; best.k = k; best.e_nw = nv[k * 3]; best.e_n = nv[k * 3 + 1]; best.e_w = nv[k * 3 + 2]; }
+          }
+        }
+        uint32_t* bp = back + ((size_t)r * glen + c) * 3;
+        bp[0] = bw_nw; bp[1] = bw_n; bp[2] = bw_w;
+      }
+      if (more && lane == 63 && c >= 0 && c < glen) {
+#pragma unroll
+        for (int x = 0; x < 12; x++) carry[x * glen + c] = nv[x];
+      }
+#pragma unroll
+      for (int x = 0; x < 12; x++) { d[x] = u[x]; pw[x] = nv[x]; cur[x] = nv[x]; }
+    }
+    if (more) __syncthreads();
+  }
+  const int src = (rlen - 1) & 63;
+  best.score = __shfl(best.score, src); best.i = __shfl(best.i, src); best.j = __shfl(best.j, src); best.k = __shfl(best.k, src);
+  best.e_nw = __shfl(best.e_nw, src); best.e_n = __shfl(best.e_n, src); best.e_w = __shfl(best.e_w, src);
+  return best;
+}
+
+// out[0..11] = score read_start rmapped genome_start gmapped matches mismatches insertions deletions crossovers n_ops 0;
+// ops[] = the reference's backtrace bytes in alignment order (type 1 insertion, 2-5 deletion in layer A-D, 6-9 match/mismatch in layer A-D; | 0x80 crossover)
+__global__ void __launch_bounds__(GM_WAVE)
+k_sw_full_cs_single(GmCsDev P, const uint32_t* __restrict__ genome_ls, long long goff, int glen, const uint32_t* __restrict__ read, int rlen, int initbp,
+                    int thresh, long long ax, long long ay, int alen, int awidth, int revcmpl, uint32_t* __restrict__ back, int* __restrict__ out,
+                    uint8_t* __restrict__ ops, int ops_cap) {
+  extern __shared__ __align__(16) uint8_t sm[];
+  const int lane = threadIdx.x;
+  const int qstride = (rlen + 15) & ~15;
+  uint8_t* rc = sm;                                   // colours
+  uint8_t* qr4 = rc + qstride;                        // four translations
+  uint8_t* db = qr4 + 4 * qstride;
+  int* carry = (int*)(db + ((glen + 15) & ~15));
+  load_read(read, rlen, false, rc, lane);
+  load_window(genome_ls, (uint64_t)goff, glen, false, db, lane);
+  __syncthreads();
+  if (lane < 4) {                                     // ref :1182-1197
+    int letter = (lane + initbp) % 4;
+    for (int j = 0; j < rlen; j++) {
+      const int base = rc[j];
+      if (base == 15) { qr4[lane * qstride + j] = 15; letter = (lane + initbp) % 4; }
+      else { const int l2 = cs_cstols(letter, base); qr4[lane * qstride + j] = (uint8_t)l2; letter = l2; }
+    }
+  }
+  __syncthreads();
+  long long nw = ax + ay, sw = ax - ay, ne = sw + 2 * (awidth - 1), se = nw + 2 * (alen - 1);      // anchor_join + anchor_widen, ref: anchors.c:9-61
+  if ((nw + sw) % 2 != 0) nw--;
+  long long rx = (nw + sw) / 2, ry = nw - rx;
+  if ((ne - sw) % 2 != 0) ne++;
+  int rw = (int)((ne - sw) / 2 + 1);
+  if ((se - nw) % 2 != 0) se++;
+  int rl = (int)((se - nw) / 2 + 1);
+  rx -= P.anchor_width / 2; ry += P.anchor_width / 2; rw += P.anchor_width;
+  const CsBest fo = full_sw_cs_wave(db, glen, qr4, qstride, rlen, P, revcmpl != 0, rx, ry, rl, rw, back, carry, lane);
+  __syncthreads();
+  __threadfence();
+  if (lane == 0) {
+    int res[12] = {0};
+    if (fo.score >= 0 && fo.score >= thresh) {         // ref :1216; do_backtrace :633-937
+      auto code_at = [&](int ci, int cj, int word, int lay) -> int {
+        const uint32_t w = __hip_atomic_load(&back[((size_t)ci * glen + cj) * 3 + word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (int)((w >> (8 * lay)) & 0xFFu);
+      };
+      int i = fo.i, j = fo.j, k = fo.k;
+      int from = code_at(i, j, 0, k), fromscore = fo.e_nw;
+      if (fo.e_w > fromscore) { from = code_at(i, j, 2, k); fromscore = fo.e_w; }
+      if (fo.e_n > fromscore) from = code_at(i, j, 1, k);
+      int no = 0, rstart = 0, gstart = 0, nm = 0, nmm = 0, nin = 0, ndel = 0, nx = 0;
+      while (i >= 0 && j >= 0 && from != 0) {
+        const int dir = from >> 2, lay = from & 3;
+        uint8_t bt;
+        if (dir == 1 || dir == 2) { ndel++; rstart = i--; bt = (uint8_t)(2 + k); }
+        else if (dir == 3 || dir == 4) { nin++; gstart = j--; bt = 1; }
+        else {
+          const int qv = qr4[k * qstride + i];
+          if (db[j] == qv || db[j] == 15 || qv == 15) nm++; else nmm++;
+          rstart = i--; gstart = j--; bt = (uint8_t)(6 + k);
+        }
+        if (k != lay) { bt |= 0x80; nx++; k = lay; }
+        if (no < ops_cap) ops[no] = bt;
+        no++;
+        if (i < 0 || j < 0) break;                    // the virtual row / left sentinel: back == 0 in the reference
+        const int word = (dir == 1 || dir == 5) ? 1 : ((dir == 4 || dir == 7) ? 2 : 0);
+        from = code_at(i, j, word, k);
+      }
+      if (k != 0 && no > 0) { if (no - 1 < ops_cap) ops[no - 1] |= 0x80; nx++; }     // ref :929-932
+      const int nov = min(no, ops_cap);
+      for (int a2 = 0, b2 = nov - 1; a2 < b2; a2++, b2--) { const uint8_t tt = ops[a2]; ops[a2] = ops[b2]; ops[b2] = tt; }
+      res[0] = fo.score; res[1] = rstart; res[2] = fo.i - rstart + 1; res[3] = gstart + (int)goff; res[4] = fo.j - gstart + 1;
+      res[5] = nm; res[6] = nmm; res[7] = nin; res[8] = ndel; res[9] = nx; res[10] = no;
+    }
+    for (int x = 0; x < 12; x++) out[x] = res[x];
+  }
+}
+
+int gm_launch_sw_vector_batch_cs(const GmScoreDev& sc, int n, const uint32_t* d_genome_cs, const uint32_t* d_genome_ls, const long long* d_goff,
+                                 const int* d_glen, const uint32_t* d_reads, int read_words, const int* d_rlen, const int* d_initbp, int max_g, int max_r,
+                                 int* d_scores, hipStream_t stream) {
+  if (n == 0) return GM_OK;
+  const size_t lds = ((max_r + 15) & ~15) + 2 * ((max_g + 15) & ~15) + (size_t)max_g * 4 + 64;
+  const int grid = std::min(n, 256 * 16);
+  hipLaunchKernelGGL(k_sw_vector_batch_cs, dim3(grid), dim3(GM_WAVE), lds, stream, sc, n, d_genome_cs, d_genome_ls, d_goff, d_glen, d_reads, read_words,
+                     d_rlen, d_initbp, max_g, max_r, d_scores);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+int gm_launch_sw_full_cs_single(const int* cs_params9, const uint32_t* d_genome_ls, long long goff, int glen, const uint32_t* d_read, int rlen, int initbp,
+                                int thresh, long long ax, long long ay, int alen, int awidth, int revcmpl, uint32_t* d_back, int* d_out, uint8_t* d_ops,
+                                int ops_cap, hipStream_t stream) {
+  GmCsDev P; P.match = cs_params9[0]; P.mismatch = cs_params9[1]; P.xover = cs_params9[2]; P.a_go = cs_params9[3]; P.a_ge = cs_params9[4];
+  P.b_go = cs_params9[5]; P.b_ge = cs_params9[6]; P.anchor_width = cs_params9[7]; P.taboo = cs_params9[8];
+  const size_t lds = 5 * (size_t)((rlen + 15) & ~15) + ((glen + 15) & ~15) + (size_t)glen * 48 + 64;
+  static size_t configured = 0;
+  if (lds > 160 * 1024) { gm_set_error("sw_full_cs: window of %d does not fit LDS", glen); return GM_E_ARG; }
+  if (lds > 48 * 1024 && lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_sw_full_cs_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
+  hipLaunchKernelGGL(k_sw_full_cs_single, dim3(1), dim3(GM_WAVE), lds, stream, P, d_genome_ls, goff, glen, d_read, rlen, initbp, thresh, ax, ay, alen, awidth,
+                     revcmpl, d_back, d_out, d_ops, ops_cap);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

@@ -64,9 +64,12 @@ class Anchor(C.Structure):      # struct gm_anchor == the reference's struct anc
                 ("weight", C.c_int), ("cn", C.c_int), ("score", C.c_int)]
 
 
-class SwFullResults(C.Structure):
+class SwFullResults(C.Structure):   # struct gm_sw_full_results == the reference's struct sw_full_results (sw-full-common.h:13-48)
     _fields_ = [(n, C.c_int) for n in ("read_start", "rmapped", "genome_start", "gmapped", "matches", "mismatches",
-                                       "insertions", "deletions", "score")] + [("dbalign", C.c_void_p), ("qralign", C.c_void_p)]
+                                       "insertions", "deletions", "score", "posterior_score", "pct_posterior_score")] + \
+               [("dbalign", C.c_void_p), ("qralign", C.c_void_p), ("qual", C.c_void_p), ("posterior", C.c_double), ("mqv", C.c_int)] + \
+               [(n, C.c_double) for n in ("z0", "z1", "z2", "z3", "pr_top_random_at_location", "pr_missed_mp", "insert_size_denom")] + \
+               [("crossovers", C.c_int), ("dup", C.c_bool), ("in_use", C.c_bool)]
 
 
 # every entry point include/gmapper_hip.h declares
@@ -74,6 +77,7 @@ EXPORTS = ["gm_last_error", "gm_device_count", "gm_params_default", "gm_index_bu
            "gm_index_save", "gm_index_load", "gm_index_bytes", "gm_index_n_slabs", "gm_index_has_buckets", "gm_index_get_list", "gm_index_device_array", "gm_index_meta", "gm_index_alloc_like",
            "sw_vector_setup", "sw_vector", "sw_vector_stats", "sw_vector_cleanup", "gm_sw_vector_batch",
            "sw_full_ls_setup", "sw_full_ls", "sw_full_ls_cleanup",
+           "sw_full_cs_setup", "sw_full_cs", "sw_full_cs_cleanup", "gm_sw_vector_batch_cs",
            "gm_session_create", "gm_session_free", "gm_map_reads", "gm_map_reads_device", "gm_free", "gm_debug_tophits",
            "gm_pair_opts_default", "gm_map_pairs",
            "gm_last_lookup_timing"]
@@ -111,6 +115,10 @@ def lib():
     L.sw_full_ls_setup.argtypes = [C.c_int] * 8 + [C.c_bool, C.c_int]
     L.sw_full_ls.argtypes = [u32p, C.c_int, C.c_int, u32p, C.c_int, C.c_int, C.c_int, C.POINTER(SwFullResults), C.c_bool, C.POINTER(Anchor), C.c_int, C.c_int]
     L.sw_full_ls.restype = None
+    L.sw_full_cs_setup.argtypes = [C.c_int] * 9 + [C.c_bool, C.c_int, C.c_int]
+    L.sw_full_cs.argtypes = [u32p, C.c_int, C.c_int, u32p, C.c_int, C.c_int, C.c_int, C.POINTER(SwFullResults), C.c_bool, C.c_bool, C.POINTER(Anchor), C.c_int, C.c_int, vp]
+    L.sw_full_cs.restype = None
+    L.gm_sw_vector_batch_cs.argtypes = [C.c_int, u32p, u32p, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int), u32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.gm_session_create.argtypes = [C.POINTER(vp), vp, C.POINTER(Params), C.c_int]
     L.gm_session_free.argtypes = [vp]
     L.gm_map_reads.argtypes = [vp, C.c_int, C.c_int, u32p, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
@@ -330,9 +338,12 @@ def sw_vector_batch(genome_words: np.ndarray, g_off, glen, reads_words: np.ndarr
     return out
 
 
-def sw_vector(genome_words, goff, glen, read_words, rlen) -> int:
+def sw_vector(genome_words, goff, glen, read_words, rlen, genome_ls=None, initbp=-1) -> int:
     g = np.ascontiguousarray(genome_words, dtype=np.uint32); r = np.ascontiguousarray(read_words, dtype=np.uint32)
-    return lib().sw_vector(g.ctypes.data_as(C.POINTER(C.c_uint32)), goff, glen, r.ctypes.data_as(C.POINTER(C.c_uint32)), rlen, None, -1, False)
+    gl = None
+    if genome_ls is not None:
+        gla = np.ascontiguousarray(genome_ls, dtype=np.uint32); gl = gla.ctypes.data_as(C.POINTER(C.c_uint32))
+    return lib().sw_vector(g.ctypes.data_as(C.POINTER(C.c_uint32)), goff, glen, r.ctypes.data_as(C.POINTER(C.c_uint32)), rlen, gl, initbp, False)
 
 
 def sw_full_ls_setup(dblen, qrlen, a_gap_open, a_gap_ext, b_gap_open, b_gap_ext, match, mismatch, reset_stats=True, anchor_width=8):
@@ -351,3 +362,40 @@ def sw_full_ls(genome_words, goff, glen, read_words, rlen, anchor, revcmpl=False
     qr = C.string_at(s.qralign).decode() if s.qralign else ""
     L.gm_free(s.dbalign); L.gm_free(s.qralign)
     return {n: getattr(s, n) for n, _ in SwFullResults._fields_[:9]}, db, qr
+
+
+# ---- colour space S1/S2 (the CS read pipeline around them is not built yet) ----
+def sw_vector_batch_cs(genome_cs, genome_ls, g_off, glen, reads_words, rlen, initbp):
+    """colour-space vector filter: genome_cs / genome_ls = colour and letter bitfields of the same contig; one initial base per read"""
+    L = lib()
+    gc = np.ascontiguousarray(genome_cs, dtype=np.uint32); gl = np.ascontiguousarray(genome_ls, dtype=np.uint32)
+    r = np.ascontiguousarray(reads_words, dtype=np.uint32)
+    n = r.shape[0]
+    go = np.ascontiguousarray(g_off, dtype=np.int64); gn = np.ascontiguousarray(glen, dtype=np.int32); rl = np.ascontiguousarray(rlen, dtype=np.int32)
+    ib = np.ascontiguousarray(initbp, dtype=np.int32); out = np.zeros(n, dtype=np.int32)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    _check(L.gm_sw_vector_batch_cs(n, gc.ctypes.data_as(C.POINTER(C.c_uint32)), gl.ctypes.data_as(C.POINTER(C.c_uint32)), min(gc.size, gl.size),
+                                   go.ctypes.data_as(C.POINTER(C.c_int64)), ip(gn), r.ctypes.data_as(C.POINTER(C.c_uint32)), r.shape[1], ip(rl), ip(ib), ip(out)),
+           "gm_sw_vector_batch_cs")
+    return out
+
+
+def sw_full_cs_setup(dblen, qrlen, a_gap_open, a_gap_ext, b_gap_open, b_gap_ext, match, mismatch, xover, reset_stats=True, anchor_width=8, indel_taboo_len=0):
+    _check(lib().sw_full_cs_setup(dblen, qrlen, a_gap_open, a_gap_ext, b_gap_open, b_gap_ext, match, mismatch, xover, reset_stats, anchor_width, indel_taboo_len),
+           "sw_full_cs_setup")
+
+
+def sw_full_cs(genome_ls, goff, glen, read_words, rlen, initbp, thresh, anchor, revcmpl=False):
+    """anchor = (x, y, length, width); returns (fields dict incl. crossovers, dbalign, qralign)."""
+    L = lib()
+    g = np.ascontiguousarray(genome_ls, dtype=np.uint32); r = np.ascontiguousarray(read_words, dtype=np.uint32)
+    a = Anchor(anchor[0], anchor[1], anchor[2], anchor[3], 1, 0, 0)
+    s = SwFullResults()
+    L.sw_full_cs(g.ctypes.data_as(C.POINTER(C.c_uint32)), goff, glen, r.ctypes.data_as(C.POINTER(C.c_uint32)), rlen, initbp, thresh,
+                 C.byref(s), bool(revcmpl), False, C.byref(a), 1, 0, None)
+    db = C.string_at(s.dbalign).decode() if s.dbalign else ""
+    qr = C.string_at(s.qralign).decode() if s.qralign else ""
+    if s.dbalign: L.gm_free(s.dbalign)
+    if s.qralign: L.gm_free(s.qralign)
+    f = {n: getattr(s, n) for n in ("score", "read_start", "rmapped", "genome_start", "gmapped", "matches", "mismatches", "insertions", "deletions", "crossovers")}
+    return f, db, qr

@@ -346,3 +346,29 @@ def test_index_replication_path_of_the_multi_gpu_start_up(gm):
                 if v is None: os.environ.pop(k, None)
                 else: os.environ[k] = v
     if dist.is_initialized(): dist.destroy_process_group()
+
+
+def test_colour_space_kernels_known_answers(gm):
+    """S1/S2 in colour space on the GPU: sw_vector with use_colours (first-colour row) and sw_full_cs (4 layers, crossovers,
+    traceback, alignment strings) against the reference's own functions: 700 vector + 1400 full-SW known answers"""
+    recs = oa.load_kat_cs()
+    vec = [r for r in recs if r[0] == "C"]
+    gm.sw_vector_setup(1400, 1000, -33, -7, -33, -3, 10, 10 - 20, 1, True)          # mismatch = match + crossover (ref: gmapper.c:2935)
+    for _, goff, glen, rlen, initbp, gcs, gls, rd, score in vec:
+        got = gm.sw_vector_batch_cs(gcs, gls, [goff], [glen], rd[None, :], [rlen], [initbp])[0]
+        assert got == score, (goff, glen, rlen, initbp, got, score)
+    _, goff, glen, rlen, initbp, gcs, gls, rd, score = vec[0]                       # the reference's own parameter list
+    assert gm.sw_vector(gcs, goff, glen, rd, rlen, genome_ls=gls, initbp=initbp) == score
+    gm.sw_full_cs_setup(1400, 1000, -33, -7, -33, -3, 10, -24, -20, True, 8, 0)
+    n = 0
+    for r in recs:
+        if r[0] != "S": continue
+        _, (goff, glen, rlen, initbp, ax, ay, alen, awidth, rv, thresh), gls, rd, want, db, qr = r
+        f, gdb, gqr = gm.sw_full_cs(gls, goff, glen, rd, rlen, initbp, thresh, (ax, ay, alen, awidth), revcmpl=bool(rv))
+        if want[0] == 0:
+            assert f["score"] == 0, (f, want)
+        else:
+            got = [f[k] for k in ("score", "read_start", "rmapped", "genome_start", "gmapped", "matches", "mismatches", "insertions", "deletions", "crossovers")]
+            assert got == want and gdb.encode() == db and gqr.encode() == qr, (got, want, gdb, db, gqr, qr)
+        n += 1
+    assert n >= 1400
