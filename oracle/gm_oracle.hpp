@@ -101,6 +101,10 @@ struct Params {
   int min_insert_size = 0, max_insert_size = 1000;
   double insert_size_mean = 200, insert_size_stddev = 100;
   bool half_paired = true;
+  // colour space (gmapper/gmapper.h:55-57,119; gmapper-defaults.h:52-58): set by set_colour_space()
+  bool colour = false;
+  int crossover_score = -20, indel_taboo_len = 0;
+  double pr_xover = 0.03, pr_mismatch = .01, pr_del_open = 0, pr_del_extend = 0, pr_ins_open = 0, pr_ins_extend = 0;
 };
 
 #define GMO_IS_ABSOLUTE(x) ((x) < 0)
@@ -121,11 +125,39 @@ static inline void load_default_seeds(Params& P) {
   add_spaced_seed(P, "1111011100100001111");
   add_spaced_seed(P, "1111000011001101111");
 }
-// score -> probability derivation, LS branch (gmapper/gmapper.c:2557-2572)
+// score -> probability derivation (gmapper/gmapper.c:2557-2572)
 static inline void derive_score_probs(Params& P) {
-  double pr_mismatch = .01;
-  P.score_alpha = ((double)P.match_score - (double)P.mismatch_score) / (log((1 - pr_mismatch) / (pr_mismatch / 3.0)) / log(2.0));
-  P.score_beta = (double)P.match_score - 2 * P.score_alpha - P.score_alpha * log(1 - pr_mismatch) / log(2.0);
+  if (P.colour) {   // CS: pr_xover => alpha => pr_mismatch => rest
+    P.score_alpha = (double)P.crossover_score / (log(P.pr_xover / 3) / log(2.0));
+    P.pr_mismatch = 1.0 / (1.0 + 1.0 / 3.0 * pow(2.0, ((double)P.match_score - (double)P.mismatch_score) / P.score_alpha));
+  } else {          // LS: pr_mismatch => alpha => rest
+    P.pr_mismatch = .01;
+    P.score_alpha = ((double)P.match_score - (double)P.mismatch_score) / (log((1 - P.pr_mismatch) / (P.pr_mismatch / 3.0)) / log(2.0));
+  }
+  P.score_beta = (double)P.match_score - 2 * P.score_alpha - P.score_alpha * log(1 - P.pr_mismatch) / log(2.0);
+  P.pr_del_open = pow(2.0, (double)P.a_gap_open_score / P.score_alpha);
+  P.pr_ins_open = pow(2.0, (double)P.b_gap_open_score / P.score_alpha);
+  P.pr_del_extend = pow(2.0, (double)P.a_gap_extend_score / P.score_alpha);
+  P.pr_ins_extend = pow(2.0, ((double)P.b_gap_extend_score - P.score_beta) / P.score_alpha);
+}
+// the gmapper-cs binary's defaults (gmapper.c:1748-1755; gmapper-defaults.h:52-58,64-66): same seeds, same gap scores
+static inline void set_colour_space(Params& P) {
+  P.colour = true;
+  P.match_score = 10; P.mismatch_score = -24; P.crossover_score = -20;
+  P.a_gap_open_score = -33; P.a_gap_extend_score = -7; P.b_gap_open_score = -33; P.b_gap_extend_score = -3;
+  P.sw_vect_threshold = 47.0; P.sw_full_threshold = 50.0;
+  derive_score_probs(P);
+}
+
+// lstocs / cstols (common/util.h:157-205), is_rna = false
+static inline int lstocs(int first_letter, int second_letter) {
+  static const int colourmat[4][4] = {{0, 1, 2, 3}, {1, 0, 3, 2}, {2, 3, 0, 1}, {3, 2, 1, 0}};
+  if (first_letter > 3 || second_letter > 3) return 15;     // anything non-{A,C,G,T} -> N
+  return colourmat[first_letter][second_letter];
+}
+static inline int cstols(int first_letter, int colour) {
+  if (first_letter == 15 || !(colour >= 0 && colour <= 3)) return 15;
+  return (first_letter % 2 == 0) ? ((4 + first_letter + colour) % 4) : ((4 + first_letter - colour) % 4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -135,13 +167,28 @@ struct Genome {
   std::vector<std::string> names;
   std::vector<uint32_t> len, offsets;            // genome_len[], contig_offsets[]
   std::vector<std::vector<uint32_t>> fwd, rc;    // genome_contigs[], genome_contigs_rc[]
+  std::vector<std::vector<uint32_t>> cs_fwd, cs_rc;   // genome_cs_contigs[], genome_cs_contigs_rc[] (colour space only)
+  bool colour = false;
   int num_contigs() const { return (int)len.size(); }
+  // bitfield_to_colourspace (common/fasta.c:586-606): colour i = lstocs(letter i-1, letter i), a T before the first letter
+  static std::vector<uint32_t> to_colourspace(const uint32_t* src, size_t n) {
+    std::vector<uint32_t> dst((n + 7) / 8, 0u);
+    int lastbp = 3;
+    for (size_t i = 0; i < n; i++) { int a = EXTRACT(src, (llint)i); dst[i / 8] |= (uint32_t)lstocs(lastbp, a) << (4 * (i % 8)); lastbp = a; }
+    return dst;
+  }
   void add_contig(const std::string& name, const uint8_t* codes, size_t n) {
     uint32_t off = offsets.empty() ? 0u : offsets.back() + len.back();
     names.push_back(name); offsets.push_back(off); len.push_back((uint32_t)n);
     fwd.push_back(pack_codes(codes, n));
     rc.push_back(revcomp_ls(fwd.back().data(), n));
+    if (colour) {   // genome.c:1108-1119
+      cs_fwd.push_back(to_colourspace(fwd.back().data(), n));
+      cs_rc.push_back(to_colourspace(rc.back().data(), n));
+    }
   }
+  // the sequence the seed index is built over (genome.c:1126-1136: the colour translation in colour space)
+  const uint32_t* index_seq(int cn) const { return colour ? cs_fwd[cn].data() : fwd[cn].data(); }
 };
 
 // kmer_to_mapidx_orig (gmapper/gmapper.h:349-368) for the k-mer whose most recent base is seq[end]
@@ -191,7 +238,7 @@ static inline void build_index_seq(const Params& P, const Genome& G, Index& I) {
         fill.assign(st.begin(), st.end() - 1);
       }
       for (int cn = 0; cn < G.num_contigs(); cn++) {
-        const uint32_t* g = G.fwd[cn].data();
+        const uint32_t* g = G.index_seq(cn);
         int load = 0;  // genome.c:1139-1154: N/X resets the run; k-mers never span contigs
         uint64_t w = 0;
         for (uint32_t p = 0; p < G.len[cn]; p++) {
@@ -241,7 +288,7 @@ static inline void build_index(const Params& P, const Genome& G, Index& I, int n
   auto scan = [&](int t, int sn, auto&& emit) {
     const Seed& sd = P.seeds[sn];
     for (const Piece& pc : slots[t]) {
-      const uint32_t* g = G.fwd[pc.cn].data();
+      const uint32_t* g = G.index_seq(pc.cn);
       int load = 0; uint64_t w = 0;
       const uint32_t p0 = pc.a >= (uint32_t)(P.max_seed_span - 1) ? pc.a - (uint32_t)(P.max_seed_span - 1) : 0;   // warm-up for the k-mers ending in [a, b)
       for (uint32_t p = p0; p < pc.b; p++) {
@@ -401,17 +448,6 @@ static inline int sw_vector(const Params& P, const uint32_t* genome, llint goff,
   return score;
 }
 
-// lstocs / cstols (common/util.h:157-205), is_rna = false
-static inline int lstocs(int first_letter, int second_letter) {
-  static const int colourmat[4][4] = {{0, 1, 2, 3}, {1, 0, 3, 2}, {2, 3, 0, 1}, {3, 2, 1, 0}};
-  if (first_letter > 3 || second_letter > 3) return 15;     // anything non-{A,C,G,T} -> N
-  return colourmat[first_letter][second_letter];
-}
-static inline int cstols(int first_letter, int colour) {
-  if (first_letter == 15 || !(colour >= 0 && colour <= 3)) return 15;
-  return (first_letter % 2 == 0) ? ((4 + first_letter + colour) % 4) : ((4 + first_letter - colour) % 4);
-}
-
 // Colour-space vector SW (common/sw-vector.c:112-146 first row, then the same recurrence on colours; sw_vector :453-515).
 // genome_cs / read hold colours, genome_ls the letters of the same window; the first read colour is compared with the
 // colour between the read's initial base and the genome letter.  `mismatch` is what sw_vector_setup got: match + crossover
@@ -466,6 +502,7 @@ struct SwFullResults {
   std::string dbalign, qralign;
   double posterior = 0;
   int mqv = 255; double z0 = 0, z1 = 0, z2 = 0, z3 = 0, pr_top_random_at_location = 0, pr_missed_mp = 0, insert_size_denom = 0;
+  int crossovers = 0; std::string qual;   // colour space: sw_full_cs / post_sw (sw-full-common.h:29-31)
   std::string ops;   // backtrace ops in alignment order: 'M' match/mismatch, 'I' BACK_INSERTION (gap in read), 'D' BACK_DELETION (gap in genome)
 };
 
@@ -613,7 +650,7 @@ static inline void sw_full_ls(const Params& P, SwFullWorkspace& W, const uint32_
 // transition may not; N-vs-anything scores 0.  Global mode (Gflag) only; crossover_score == NULL (no read qualities).
 // ---------------------------------------------------------------------------------------------
 struct CsParams { int match = 10, mismatch = -24, xover = -20, a_go = 33, a_ge = 7, b_go = 33, b_ge = 3, anchor_width = 8, indel_taboo_len = 0; };
-struct SwFullCsResults : SwFullResults { int crossovers = 0; };
+typedef SwFullResults SwFullCsResults;
 
 static inline void sw_full_cs(const CsParams& C, const uint32_t* genome_ls, llint goff, int glen, const uint32_t* read, int rlen, int initbp,
                               int threshscore, SwFullCsResults* sfr, bool revcmpl, const Anchor* anchors, int anchors_cnt) {
@@ -792,6 +829,141 @@ static inline void sw_full_cs(const CsParams& C, const uint32_t* genome_ls, llin
 
 
 // ---------------------------------------------------------------------------------------------
+// post_sw (common/sw-post.c:639-758), reads without quality values: a 16-state forward-backward
+// over the aligned columns of a colour-space alignment.  State j = (previous letter << 2 | letter);
+// all sums run in the reference's order, in doubles, through the same libm calls, so that the
+// truncations downstream (QV characters, Z0/Z1, MAPQ, posterior_score) see the same bits.
+// ---------------------------------------------------------------------------------------------
+struct PostSwColumn {              // struct column, sw-post.c:61-78 (one letter and one colour emission at most)
+  double forwards[16], backwards[16], forwscale, backscale;
+  int nlets, ncols, let, col; double leterr, colerr;
+  double posterior[4]; int max_posterior, base_call;
+};
+static inline int qv_from_pr_err(double pr_err) {  // util.h:267-276
+  if (pr_err > .99999999) return 0; else if (pr_err < 1E-25) return 250;
+  return (int)(-10.0 * log(pr_err) / log(10.0));
+}
+static inline double post_node_prior(const PostSwColumn& c, int j) {   // nodePrior, sw-post.c:111-138
+  double val = 0;
+  const int l = (j >> 2) & 3, r = j & 3;
+  if (c.nlets) { if (r == c.let) val = val - log(1 - c.leterr); else val = val - log(c.leterr / 3.0); }
+  if (c.ncols) { if ((l ^ r) == c.col) val = val - log(1 - c.colerr); else val = val - log(c.colerr / 3.0); }
+  return val;
+}
+static inline void post_sw(const Params& P, const uint32_t* read, int init_bp, SwFullResults* sfr) {
+  std::vector<PostSwColumn> cols;
+  {  // load_local_vectors (sw-post.c:448-528)
+    int start_run = 0, j;
+    for (j = 0; j < sfr->read_start; j++) {
+      int col = EXTRACT(read, j);
+      if (col == 15) { start_run = 15; j = sfr->read_start; break; }
+      start_run ^= col;
+    }
+    for (size_t i = 0; i < sfr->dbalign.size(); i++) {
+      if (sfr->qralign[i] == '-') continue;       // deletion: nothing to emit
+      PostSwColumn c; memset(&c, 0, sizeof c);
+      if (sfr->dbalign[i] != '-') {
+        c.nlets = 1; c.leterr = P.pr_mismatch;
+        switch (sfr->dbalign[i]) {                // fasta_get_initial_base (fasta.c:556-577): A/C/G/T, anything else -1
+          case 'A': case 'a': c.let = 0; break; case 'C': case 'c': c.let = 1; break;
+          case 'G': case 'g': c.let = 2; break; case 'T': case 't': c.let = 3; break; default: c.let = -1;
+        }
+      }
+      c.ncols = 1;
+      const int col = EXTRACT(read, j); const bool first = cols.empty();
+      if ((first && start_run == 15) || col == 15) { c.col = 0; c.colerr = .75; }
+      else { c.col = col ^ (first ? start_run : 0); c.colerr = P.pr_xover; }
+      int bc = char_to_code_ls((unsigned char)sfr->qralign[i]);   // char_to_base (fasta.c:28-42): case-insensitive
+      c.base_call = bc;
+      cols.push_back(c); j++;
+    }
+  }
+  const int len = (int)cols.size();
+  if (len == 0) { sfr->posterior = 0; return; }
+  PostSwColumn* a = cols.data();
+  double total;
+  {  // do_forwards (sw-post.c:317-360)
+    a[0].forwscale = 999999999;
+    for (int j = 0; j < 16; j++) {
+      if (((j >> 2) & 3) == init_bp) { a[0].forwards[j] = post_node_prior(a[0], j); a[0].forwscale = std::min(a[0].forwscale, a[0].forwards[j]); }
+      else a[0].forwards[j] = HUGE_VAL;
+    }
+    for (int j = 0; j < 16; j++) a[0].forwards[j] -= a[0].forwscale;
+    for (int i = 1; i < len; i++) {
+      a[i].forwscale = 999999999;
+      for (int j = 0; j < 16; j++) a[i].forwards[j] = 0;
+      for (int j = 0; j < 16; j++) {
+        const double val = post_node_prior(a[i], j);
+        for (int k = 0; k < 16; k++) if (((j >> 2) & 3) == (k & 3)) a[i].forwards[j] += exp(-1 * (a[i - 1].forwards[k]));
+        a[i].forwards[j] = val - log(a[i].forwards[j]);
+        a[i].forwscale = (a[i].forwscale < a[i].forwards[j]) ? a[i].forwscale : a[i].forwards[j];   // MIN2
+      }
+      for (int j = 0; j < 16; j++) a[i].forwards[j] -= a[i].forwscale;
+      a[i].forwscale += a[i - 1].forwscale;
+    }
+    double val = 0;
+    for (int j = 0; j < 16; j++) val += exp(-1 * (a[len - 1].forwards[j]));
+    total = -log(val) + a[len - 1].forwscale;
+  }
+  {  // do_backwards (sw-post.c:269-315); its own total is only a sanity value in the reference
+    int i = len - 1;
+    a[i].backscale = 999999999;
+    for (int j = 0; j < 16; j++) { a[i].backwards[j] = 0; a[i].backscale = (a[i].backscale < a[i].backwards[j]) ? a[i].backscale : a[i].backwards[j]; }
+    for (int j = 0; j < 16; j++) a[i].backwards[j] -= a[i].backscale;
+    for (i = len - 2; i >= 0; i--) {
+      a[i].backscale = 999999999;
+      for (int j = 0; j < 16; j++) a[i].backwards[j] = 0;
+      for (int j = 0; j < 16; j++) {
+        for (int k = 0; k < 16; k++)
+          if ((j & 3) == ((k >> 2) & 3)) { const double val = post_node_prior(a[i + 1], k); a[i].backwards[j] += exp(-1 * (val + a[i + 1].backwards[k])); }
+        a[i].backwards[j] = -log(a[i].backwards[j]);
+        a[i].backscale = (a[i].backscale < a[i].backwards[j]) ? a[i].backscale : a[i].backwards[j];
+      }
+      for (int j = 0; j < 16; j++) a[i].backwards[j] -= a[i].backscale;
+      a[i].backscale += a[i + 1].backscale;
+    }
+  }
+  for (int i = 0; i < len; i++) {   // post_traceback (sw-post.c:183-212)
+    for (int j = 0; j < 4; j++) a[i].posterior[j] = 0;
+    for (int j = 0; j < 16; j++)
+      a[i].posterior[j & 3] += exp(-1 * (a[i].forwards[j] + a[i].backwards[j] + a[i].forwscale + a[i].backscale - total));
+    int mx = 0;
+    for (int j = 1; j < 4; j++) if (a[i].posterior[j] > a[i].posterior[mx]) mx = j;
+    a[i].max_posterior = mx;
+  }
+  {  // fix_base_calls (sw-post.c:531-565)
+    int j = 0, prev_base = init_bp;
+    sfr->matches = 0; sfr->mismatches = 0; sfr->crossovers = 0;
+    for (size_t i = 0; i < sfr->qralign.size(); i++) {
+      if (sfr->qralign[i] == '-') continue;
+      const int crt = a[j].max_posterior;
+      if ((prev_base ^ crt) == a[j].col) sfr->qralign[i] = "ACGT"[crt];
+      else { sfr->qralign[i] = "acgt"[crt]; ++sfr->crossovers; }
+      if (sfr->dbalign[i] != '-') { if (toupper(sfr->dbalign[i]) == toupper(sfr->qralign[i])) ++sfr->matches; else ++sfr->mismatches; }
+      prev_base = crt; ++j;
+    }
+  }
+  {  // get_base_qualities (sw-post.c:568-586): the posterior of the base sw_full_cs had called, capped at 40
+    sfr->qual.assign(len, '!');
+    for (int k = 0; k < len; k++) {
+      // (the reference indexes posterior[] with any 4-bit code; only A/C/G/T and N are defined behaviour)
+      int tmp = (a[k].base_call >= 0 && a[k].base_call <= 3) ? qv_from_pr_err(1 - a[k].posterior[a[k].base_call]) : 0;
+      if (tmp > 40) tmp = 40;
+      sfr->qual[k] = (char)(33 + tmp);
+    }
+  }
+  {  // get_posterior (sw-post.c:589-612)
+    double res = exp(-total);
+    for (size_t i = 0; i < sfr->dbalign.size(); i++) {
+      if (sfr->dbalign[i] == '-') { res *= P.pr_ins_extend; if (i == 0 || sfr->dbalign[i - 1] != '-') res *= P.pr_ins_open; }
+      else if (sfr->qralign[i] == '-') { res *= P.pr_del_extend; if (i == 0 || sfr->qralign[i - 1] != '-') res *= P.pr_del_open; }
+    }
+    sfr->posterior = res;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // Per-read pipeline (gmapper/mapping.c)
 // ---------------------------------------------------------------------------------------------
 struct Hit {                       // struct read_hit, gmapper-definitions.h:131-160
@@ -811,6 +983,7 @@ struct Read {
   std::string name, seq;
   std::vector<uint32_t> bits[2];   // read[0] forward, read[1] reverse complement
   int read_len = 0, window_len = 0, max_n_kmers = 0, min_kmer_pos = 0, input_strand = 0;
+  int initbp[2] = {0, 0};          // colour space: the primer letter (gmapper.c:481-482)
   std::vector<uint32_t> mapidx[2];
   std::vector<Anchor> anchors[2];
   std::vector<Hit> hits[2];
@@ -845,6 +1018,7 @@ struct Mapper {
 
   // launch_scan_threads body, LS unpaired part (gmapper/gmapper.c:436-531)
   void prepare_read(Read& re) const {
+    if (P.colour) { prepare_read_cs(re); return; }
     re.read_len = (int)re.seq.size();
     re.max_n_kmers = re.read_len - P.min_seed_span + 1;
     std::vector<uint8_t> codes(re.read_len);
@@ -854,6 +1028,33 @@ struct Mapper {
     if (re.max_n_kmers < 0) re.max_n_kmers = 0;
     re.min_kmer_pos = 0; re.input_strand = 0;
     re.window_len = (uint16_t)GMO_ABS_OR_PCT(P.window_len, re.read_len);  // gmapper.c:530
+  }
+  // colour space: seq = primer letter + colours (gmapper.c:475-487; fasta.c:609-673, colour table :154-163)
+  static int char_to_code_cs(unsigned char c) {
+    switch (c) { case '0': return 0; case '1': return 1; case '2': return 2; case '3': return 3;
+                 case '4': case 'N': case 'n': case '.': case 'X': case 'x': return 15; default: return -1; }
+  }
+  void prepare_read_cs(Read& re) const {
+    re.read_len = (int)re.seq.size();
+    re.max_n_kmers = re.read_len - P.min_seed_span + 1;
+    std::vector<uint8_t> codes(re.read_len > 0 ? re.read_len - 1 : 0);
+    for (int i = 1; i < re.read_len; i++) codes[i - 1] = (uint8_t)char_to_code_cs((unsigned char)re.seq[i]);
+    re.bits[0] = pack_codes(codes.data(), codes.size());
+    re.read_len--;
+    re.max_n_kmers -= 2;                           // 1st colour never enters a k-mer
+    re.min_kmer_pos = 1;
+    re.initbp[0] = re.initbp[1] = char_to_code_ls((unsigned char)re.seq[0]);
+    {  // reverse_complement_read_cs (util.c:600-617)
+      const uint32_t* r = re.bits[0].data(); const int len = re.read_len;
+      std::vector<uint8_t> rc(len, 0);
+      int base = cstols(re.initbp[0], EXTRACT(r, 0));
+      for (int i = 1; i < len; i++) { base = cstols(base, EXTRACT(r, i)); rc[len - i] = (uint8_t)EXTRACT(r, i); }
+      rc[0] = (uint8_t)lstocs(base, complement_base(re.initbp[1]));
+      re.bits[1] = pack_codes(rc.data(), rc.size());
+    }
+    if (re.max_n_kmers < 0) re.max_n_kmers = 0;
+    re.input_strand = 0;
+    re.window_len = (uint16_t)GMO_ABS_OR_PCT(P.window_len, re.read_len);
   }
 
   // read_get_mapidxs_per_strand (mapping.c:37-70)
@@ -1035,14 +1236,16 @@ struct Mapper {
     }
   }
 
-  // f1_run (common/f1-wrapper.h:97-134), gapped branch
-  int f1_run(ThreadState& T, const uint32_t* genome, llint goff, int wlen, const uint32_t* read, int rlen, uint32_t tag) const {
+  // f1_run (common/f1-wrapper.h:97-134), gapped branch; genome_ls != nullptr selects the colour-space filter
+  int f1_run(ThreadState& T, const uint32_t* genome, llint goff, int wlen, const uint32_t* read, int rlen, uint32_t tag,
+             const uint32_t* genome_ls = nullptr, int initbp = -1) const {
     uint32_t hv = 0;
     if (P.hash_filter_calls && tag != 0) {
       hv = hash_genome_window(genome, (uint32_t)goff, (uint32_t)wlen) % f1_window_cache_size;
       if (T.f1_tag[hv] == tag) { T.stats.vec_bypassed++; return (int)T.f1_score[hv]; }
     }
-    int score = sw_vector(P, genome, goff, wlen, read, rlen);
+    int score = genome_ls ? sw_vector_cs(P, P.match_score + P.crossover_score, genome, goff, wlen, read, rlen, genome_ls, initbp)   // gmapper.c:2935
+                          : sw_vector(P, genome, goff, wlen, read, rlen);
     T.stats.vec_calls++; T.stats.vec_cells += (uint64_t)wlen * rlen;
     if (P.hash_filter_calls && tag != 0) { T.f1_tag[hv] = tag; T.f1_score[hv] = (uint32_t)score; }
     return score;
@@ -1061,6 +1264,12 @@ struct Mapper {
         h.score_vector = 0; h.pct_score_vector = 0; continue;
       }
       if (h.score_vector <= 0) {
+        if (P.colour) {   // mapping.c:1297-1319: the hit is first turned onto the read's input strand
+          if (h.st != re.input_strand) reverse_hit(re, h);
+          const uint32_t* gen_cs = (h.gen_st == 0 ? G->cs_fwd[h.cn].data() : G->cs_rc[h.cn].data());
+          const uint32_t* gen_ls = (h.gen_st == 0 ? G->fwd[h.cn].data() : G->rc[h.cn].data());
+          h.score_vector = f1_run(T, gen_cs, h.g_off, h.w_len, re.bits[h.st].data(), re.read_len, T.f1_hash_tag, gen_ls, re.initbp[st]);
+        } else
         h.score_vector = f1_run(T, G->fwd[h.cn].data(), h.g_off, h.w_len, re.bits[st].data(), re.read_len, T.f1_hash_tag);
         h.pct_score_vector = (1000 * 100 * h.score_vector) / h.score_max;
         if (h.score_vector >= (int)GMO_ABS_OR_PCT(P.sw_vect_threshold, h.score_max)) { last_good_cn = h.cn; last_good_g_off = (unsigned int)h.g_off_pos_strand; }
@@ -1111,6 +1320,16 @@ struct Mapper {
     if (h.st != re.input_strand) reverse_hit(re, h);
     const uint32_t* gen = (h.gen_st == 0 ? G->fwd[h.cn].data() : G->rc[h.cn].data());
     h.has_sfr = true; h.sfr = SwFullResults();
+    if (P.colour) {   // mapping.c:375-379
+      CsParams C; C.match = P.match_score; C.mismatch = P.mismatch_score; C.xover = P.crossover_score;
+      C.a_go = -P.a_gap_open_score; C.a_ge = -P.a_gap_extend_score; C.b_go = -P.b_gap_open_score; C.b_ge = -P.b_gap_extend_score;
+      C.anchor_width = P.anchor_width; C.indel_taboo_len = P.indel_taboo_len;
+      T.stats.full_calls++;
+      sw_full_cs(C, gen, h.g_off, h.w_len, re.bits[h.st].data(), re.read_len, re.initbp[h.st], thresh, &h.sfr, h.gen_st && P.Tflag, &h.anchor, 1);
+      h.score_full = h.sfr.score;
+      h.pct_score_full = (1000 * 100 * h.score_full) / h.score_max;
+      return;
+    }
     h.score_vector = sw_vector(P, gen, h.g_off, h.w_len, re.bits[h.st].data(), re.read_len);
     T.stats.vec_calls++; T.stats.vec_cells += (uint64_t)h.w_len * re.read_len;
     if (h.score_vector >= thresh) {
@@ -1123,9 +1342,10 @@ struct Mapper {
   }
 
   // hit_run_post_sw (mapping.c:1609-1625), letter space
-  void hit_run_post_sw(Hit& h) const {
+  void hit_run_post_sw(const Read& re, Hit& h) const {
     SwFullResults& s = h.sfr;
-    s.posterior = pow(2.0, ((double)s.score - (double)s.rmapped * (2.0 * P.score_alpha + P.score_beta)) / P.score_alpha);
+    if (P.colour) post_sw(P, re.bits[h.st].data(), re.initbp[h.st], &s);
+    else s.posterior = pow(2.0, ((double)s.score - (double)s.rmapped * (2.0 * P.score_alpha + P.score_beta)) / P.score_alpha);
     s.posterior_score = (int)rint(P.score_alpha * log(s.posterior) / log(2.0) + (double)s.rmapped * (2.0 * P.score_alpha + P.score_beta));
     if (s.posterior_score < 0) s.posterior_score = 0;
     s.pct_posterior_score = (1000 * 100 * s.posterior_score) / h.score_max;
@@ -1164,7 +1384,7 @@ struct Mapper {
       Hit* rh = p1[i];
       if (rh->score_full < 0 || !rh->has_sfr) {
         hit_run_full_sw(T, re, *rh, (int)GMO_ABS_OR_PCT(P.sw_full_threshold, rh->score_max));
-        if (P.compute_mapping_qualities && rh->score_full > 0) hit_run_post_sw(*rh);
+        if (P.compute_mapping_qualities && rh->score_full > 0) hit_run_post_sw(re, *rh);
         rh->pass2_key = GMO_IS_ABSOLUTE(P.sw_full_threshold) ? rh->score_full : (int)rh->pct_score_full;
       }
       if (rh->score_full >= GMO_ABS_OR_PCT(P.sw_full_threshold, rh->score_max)) p2.push_back(rh);
@@ -1220,15 +1440,19 @@ struct Mapper {
   void hit_output(const Read& re, const Hit* rh, std::string& out) const {
     char buf[256];
     std::string seq(re.read_len, 'N');
-    for (int i = 0; i < re.read_len; i++) {   // output.c:320-352
-      char c = re.seq[i];
-      switch (c) {
-        case 'R': case 'Y': case 'S': case 'W': case 'K': case 'M': case 'B': case 'D': case 'H': case 'V': seq[i] = 'N'; break;
-        default: if (c >= 'a') c -= 32; seq[i] = c; break;
+    if (!P.colour) {
+      for (int i = 0; i < re.read_len; i++) {   // output.c:320-352
+        char c = re.seq[i];
+        switch (c) {
+          case 'R': case 'Y': case 'S': case 'W': case 'K': case 'M': case 'B': case 'D': case 'H': case 'V': seq[i] = 'N'; break;
+          default: if (c >= 'a') c -= 32; seq[i] = c; break;
+        }
       }
-    }
-    if (rh == nullptr) {                      // unmapped (output.c:411-466), unpaired, letter space, no qualities
-      out += re.name; out += "\t4\t*\t0\t0\t*\t*\t0\t0\t"; out += seq; out += "\t*\n";
+    } else seq = "*";                           // output.c:353-355
+    if (rh == nullptr) {                        // unmapped (output.c:411-466), unpaired, no read qualities
+      out += re.name; out += "\t4\t*\t0\t0\t*\t*\t0\t0\t"; out += seq; out += "\t*";
+      if (P.colour) { out += "\tCQ:Z:*\tCS:Z:"; out += re.seq; }   // output.c:441-451
+      out += "\n";
       return;
     }
     const SwFullResults& s = rh->sfr;
@@ -1237,8 +1461,9 @@ struct Mapper {
     int genome_length = (int)G->len[rh->cn];
     std::vector<std::pair<int, char>> cigar;
     make_cigar(read_start, read_end, re.read_len, s.qralign, s.dbalign, &cigar);
-    int j = read_start - 1;
-    for (size_t i = 0; i < s.qralign.size(); i++) {   // output.c:485-533
+    int j = P.colour ? 0 : read_start - 1;      // output.c:485-493: colour space prints the aligned part only
+    if (P.colour) seq.assign(read_end - read_start + 1, 'N');
+    for (size_t i = 0; i < s.qralign.size(); i++) {   // output.c:494-533
       char c = s.qralign[i];
       if (c != '-') {
         if (c >= 'a') c -= 32;
@@ -1246,7 +1471,11 @@ struct Mapper {
         seq[j++] = c;
       }
     }
-    seq.resize(j + (re.read_len - read_end));
+    std::string qual = "*";
+    if (!P.colour) seq.resize(j + (re.read_len - read_end));
+    else {                                      // output.c:572-580: hard clips.  QUAL stays "*": post_sw's base qualities are
+      for (auto& c : cigar) if (c.second == 'S') c.second = 'H';   // only printed for reads that came with QVs (:581-621, Qflag)
+    }
     int genome_start;
     if (!reverse_strand) genome_start = s.genome_start + 1;
     else {
@@ -1263,10 +1492,15 @@ struct Mapper {
     out += G->names[rh->cn];
     snprintf(buf, sizeof buf, "\t%u\t%i\t", (unsigned)genome_start, s.mqv); out += buf;
     for (auto& c : cigar) { snprintf(buf, sizeof buf, "%d%c", c.first, c.second); out += buf; }
-    out += "\t*\t0\t0\t"; out += seq; out += "\t*";
+    out += "\t*\t0\t0\t"; out += seq; out += "\t"; out += qual;
     snprintf(buf, sizeof buf, "\tAS:i:%d", rh->score_full); out += buf;
     if (P.compute_mapping_qualities) { snprintf(buf, sizeof buf, "\tZ0:i:%d\tZ1:i:%d", double_to_neglog(s.z0), double_to_neglog(s.z1)); out += buf; }
-    snprintf(buf, sizeof buf, "\tNM:i:%d\n", s.mismatches + s.deletions + s.insertions); out += buf;
+    snprintf(buf, sizeof buf, "\tNM:i:%d", s.mismatches + s.deletions + s.insertions); out += buf;
+    if (P.colour) {                             // output.c:717-730
+      out += "\tCS:Z:"; out += re.seq;
+      snprintf(buf, sizeof buf, "\tCM:i:%d\tXX:Z:", s.crossovers); out += buf; out += s.qralign;
+    }
+    out += "\n";
   }
 
   // read_output (output.c:955-1008) + compute_unpaired_mqv (output.c:777-793)
@@ -1436,7 +1670,7 @@ struct Mapper {
         Hit* rh = p1[i].rh[j]; Read& re = (j == 0 ? re1 : re2);
         if (rh->score_full < 0 || !rh->has_sfr) {
           hit_run_full_sw(T, re, *rh, (int)GMO_ABS_OR_PCT(mate_thres, rh->score_max));
-          if (P.compute_mapping_qualities && rh->score_full > 0) hit_run_post_sw(*rh);
+          if (P.compute_mapping_qualities && rh->score_full > 0) hit_run_post_sw(re, *rh);
         }
       }
       if (p1[i].rh[0]->score_full == 0 || p1[i].rh[1]->score_full == 0) continue;

@@ -75,7 +75,7 @@ static void map_all(const Session& S, std::vector<Read>& reads, int nthreads, st
 
 #ifdef GM_ORACLE_MAIN
 int main(int argc, char** argv) {
-  int nthreads = 1; bool noz = false, unal = false; int pair_mode = 0, ins_min = 0, ins_max = 1000;
+  int nthreads = 1; bool noz = false, unal = false, colour = strstr(argv[0], "-cs") != nullptr; int pair_mode = 0, ins_min = 0, ins_max = 1000;
   std::vector<const char*> pos;
   std::string cl;
   for (int i = 0; i < argc; i++) { if (i) cl += ' '; cl += argv[i]; }
@@ -83,6 +83,7 @@ int main(int argc, char** argv) {
     if (!strcmp(argv[i], "-N") && i + 1 < argc) nthreads = atoi(argv[++i]);
     else if (!strcmp(argv[i], "-Z")) noz = true;
     else if (!strcmp(argv[i], "--sam-unaligned")) unal = true;
+    else if (!strcmp(argv[i], "--cs")) colour = true;       // the reference picks the mode from the binary's name (util.c:28-38)
     else if (!strcmp(argv[i], "-p") && i + 1 < argc) { const char* m = argv[++i]; pair_mode = !strcmp(m, "opp-in") ? 1 : !strcmp(m, "opp-out") ? 2 : !strcmp(m, "col-fw") ? 3 : !strcmp(m, "col-bw") ? 4 : 0; }
     else if (!strcmp(argv[i], "-I") && i + 1 < argc) { sscanf(argv[++i], "%d,%d", &ins_min, &ins_max); }
     else pos.push_back(argv[i]);
@@ -90,6 +91,7 @@ int main(int argc, char** argv) {
   if (pos.size() != 2) { fprintf(stderr, "usage: gm_oracle [-N n] [-Z] [--sam-unaligned] reads.fa genome.fa\n"); return 1; }
   Session S;
   load_default_seeds(S.M.P); derive_score_probs(S.M.P);
+  if (colour) { set_colour_space(S.M.P); S.G.colour = true; }
   S.M.P.hash_filter_calls = !noz; S.M.P.sam_unaligned = unal;
   S.M.P.pair_mode = pair_mode; S.M.P.min_insert_size = ins_min; S.M.P.max_insert_size = ins_max;
   std::vector<std::string> gn, gs;
@@ -175,6 +177,7 @@ int gmo_sw_full_cs(const uint32_t* genome_ls, int goff, int glen, const uint32_t
 static void apply_opts(Params& P, const char* opts) {
   if (!opts) return;
   std::string s(opts); size_t i = 0;
+  if (s.find("colour=1") != std::string::npos) set_colour_space(P);   // first: it changes the defaults the other keys override
   while (i < s.size()) {
     size_t e = s.find(';', i); if (e == std::string::npos) e = s.size();
     std::string kv = s.substr(i, e - i); i = e + 1;
@@ -189,6 +192,7 @@ static void apply_opts(Params& P, const char* opts) {
     else if (k == "report") P.num_outputs = (int)d; else if (k == "anchor-width") P.anchor_width = (int)d;
     else if (k == "cutoff") P.list_cutoff = (uint32_t)d; else if (k == "strata") P.strata = d != 0;
     else if (k == "max-alignments") P.max_alignments = (int)d;
+    else if (k == "crossover") P.crossover_score = (int)d; else if (k == "indel-taboo-len") P.indel_taboo_len = (int)d;
     else if (k == "seeds") {
       P.seeds.clear(); P.max_seed_span = 0; P.min_seed_span = 64;
       size_t a = 0; while (a < v.size()) { size_t b = v.find(',', a); if (b == std::string::npos) b = v.size(); add_spaced_seed(P, v.substr(a, b - a).c_str()); a = b + 1; }
@@ -206,6 +210,7 @@ void* gmo_session_create_opts(int n_contigs, const uint8_t* const* codes, const 
   S->M.P = default_params();
   S->M.P.list_cutoff = 4294967295u;
   apply_opts(S->M.P, opts);
+  S->G.colour = S->M.P.colour;
   for (int c = 0; c < n_contigs; c++) {
     char nm[64]; snprintf(nm, sizeof nm, "contig%d", c + 1);
     S->G.add_contig(names && names[c] ? names[c] : nm, codes[c], (size_t)lens[c]);
@@ -234,6 +239,8 @@ void gmo_session_set(void* s, int hash_filter_calls, int sam_unaligned) {
 }
 
 static std::string code_seq(const uint8_t* c, int L) { std::string s(L, 'N'); for (int i = 0; i < L; i++) s[i] = LSTRANS[c[i] & 15]; return s; }
+// colour-space read: code 0 is the primer letter, the rest are colours (0-3, anything else '.')
+static std::string code_seq_cs(const uint8_t* c, int L) { std::string s(L, '.'); if (L) s[0] = LSTRANS[c[0] & 3]; for (int i = 1; i < L; i++) if (c[i] < 4) s[i] = (char)('0' + c[i]); return s; }
 
 // reads: n x L code matrix (row-major); names: '\n'-separated or NULL (-> r<i>); returns malloc'd SAM body (no header)
 char* gmo_map_sam(void* s, int n, int L, const uint8_t* codes, const char* names, int nthreads, uint64_t* stats7) {
@@ -243,7 +250,7 @@ char* gmo_map_sam(void* s, int n, int L, const uint8_t* codes, const char* names
   for (int i = 0; i < n; i++) {
     if (p) { const char* e = strchr(p, '\n'); if (!e) e = p + strlen(p); reads[i].name.assign(p, e); p = *e ? e + 1 : e; }
     else { char nm[32]; snprintf(nm, sizeof nm, "r%d", i); reads[i].name = nm; }
-    reads[i].seq = code_seq(codes + (size_t)i * L, L);
+    reads[i].seq = S->M.P.colour ? code_seq_cs(codes + (size_t)i * L, L) : code_seq(codes + (size_t)i * L, L);
   }
   std::string out; Stats st;
   map_all(*S, reads, nthreads > 0 ? nthreads : 1, out, &st);

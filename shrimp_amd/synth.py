@@ -116,6 +116,61 @@ def make_pairs(contigs: list[np.ndarray], n_pairs: int, read_len: int, seed: int
     return out, {"cn": cn.astype(np.int32), "pos": pos, "ins": ins, "strand": strand}
 
 
+def make_cs_reads(contigs: list[np.ndarray], n_reads: int, n_colours: int, seed: int, p_col: float = 0.04, p_rc: float = 0.5,
+                  p_dot: float = 0.0):
+    """Colour-space (SOLiD) reads as SURVEY.md 8(d) cfg4 describes them: a letter-space fragment of `n_colours` bases
+    with exactly one indel of 1-3 bases, translated to colours behind a 'T' primer (colour = XOR of adjacent 2-bit
+    codes), then per-colour substitution with probability `p_col` (and, optionally, skipped cycles '.', code 15).
+    Returns codes[n_reads, n_colours + 1] uint8 -- column 0 is the primer letter code (3 = T) -- and the truth dict."""
+    rng = np.random.Generator(np.random.PCG64(seed + 3_000_003))
+    L = n_colours
+    lens = np.array([len(c) for c in contigs], dtype=np.int64)
+    margin = L + 8
+    usable = np.maximum(lens - margin, 1)
+    cum = np.concatenate([[0], np.cumsum(usable)])
+    u = rng.integers(0, cum[-1], size=n_reads, dtype=np.int64)
+    cn = np.searchsorted(cum, u, side="right") - 1
+    pos = u - cum[cn]
+    strand = (rng.random(n_reads) < p_rc).astype(np.uint8)
+    src = np.empty((n_reads, margin), dtype=np.uint8)
+    ar = np.arange(margin, dtype=np.int64)
+    for c in range(len(contigs)):
+        m = np.nonzero(cn == c)[0]
+        if m.size:
+            src[m] = contigs[c][pos[m, None] + ar[None, :]]
+    rc = strand == 1
+    src[rc] = COMPLEMENT[src[rc][:, ::-1]]
+    src = np.where(src > 3, rng.integers(0, 4, size=src.shape, dtype=np.uint8), src)   # the sequenced molecule has real bases
+    at = rng.integers(5, L - 5, size=n_reads)
+    k = rng.integers(1, 4, size=n_reads)
+    is_ins = rng.random(n_reads) < 0.5
+    j = np.arange(L, dtype=np.int64)[None, :]
+    idx = np.where(j < at[:, None], j, np.where(is_ins[:, None], np.maximum(j - k[:, None], 0), j + k[:, None]))
+    bases = np.take_along_axis(src, idx, axis=1)
+    inserted = is_ins[:, None] & (j >= at[:, None]) & (j < (at + k)[:, None])
+    bases = np.where(inserted, rng.integers(0, 4, size=bases.shape, dtype=np.uint8), bases).astype(np.uint8)
+    prev = np.concatenate([np.full((n_reads, 1), 3, dtype=np.uint8), bases[:, :-1]], axis=1)
+    col = prev ^ bases
+    err = rng.random(col.shape) < p_col
+    col = np.where(err, (col + rng.integers(1, 4, size=col.shape, dtype=np.uint8)) & 3, col).astype(np.uint8)
+    if p_dot > 0:
+        col = np.where(rng.random(col.shape) < p_dot, 15, col).astype(np.uint8)
+    out = np.concatenate([np.full((n_reads, 1), 3, dtype=np.uint8), col], axis=1)
+    return out, {"cn": cn.astype(np.int32), "pos": pos, "strand": strand}
+
+
+def write_csfasta_reads(path: str, reads: np.ndarray) -> None:
+    """codes[n, 1 + colours] -> csfasta (primer letter, then colours 0-3 or '.')"""
+    n, L = reads.shape
+    tab = np.full(16, ord("."), dtype=np.uint8); tab[:4] = np.frombuffer(b"0123", dtype=np.uint8)
+    body = tab[reads[:, 1:]]
+    with open(path, "wb") as f:
+        for i in range(n):
+            f.write(b">r%d\n" % i)
+            f.write(LETTERS[reads[i, :1]].tobytes() + body[i].tobytes())
+            f.write(b"\n")
+
+
 def pack_nibbles(codes: np.ndarray) -> np.ndarray:
     """Pack a 1-D code array 8 bases per uint32, base i in nibble i%8 of word i/8
     (the reference's bitfield layout, common/util.h:41 EXTRACT).  Little-endian bytes: byte k of

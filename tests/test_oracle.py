@@ -123,3 +123,18 @@ def test_oracle_colour_space_kernels_match_reference_known_answers(oracle_lib):
                 assert list(out) == want and dba.value == db and qra.value == qr, (list(out), want, dba.value, db, qra.value, qr)
             ns += 1
     assert nc >= 700 and ns >= 1400
+
+
+CS_GOLDEN = ["cfg4s_50col_2Mbp", "stress_cs_60col_unal"]
+
+
+@pytest.mark.parametrize("name", CS_GOLDEN)
+def test_oracle_colour_space_sam_matches_reference(name, oracle_lib):
+    """the whole colour-space pipeline (colour index, first-colour skip, CS vector filter on the input strand, sw_full_cs,
+    post_sw forward-backward, CS SAM fields) against the reference's gmapper-cs"""
+    contigs, reads, sam = oa.load_golden(name)
+    s = oa.Session(contigs, opts="colour=1")
+    s.set(hash_filter_calls=True, sam_unaligned=name.endswith("_unal"))
+    got = oa.sam_header(contigs) + s.map_sam(reads, nthreads=4)
+    s.close()
+    assert got == sam, "oracle colour-space SAM differs from the reference's for %s" % name

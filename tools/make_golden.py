@@ -202,8 +202,35 @@ def cs_kat_cases():
     print("sw_kat_cs:", kat.count(b"\nC ") + 1, "colour-space vector,", kat.count(b"\nS "), "sw_full_cs")
 
 
+def run_cs_case(name, contigs, reads, extra=()):
+    """colour-space reads (codes[n, 1 + colours]) through the reference's gmapper-cs"""
+    with tempfile.TemporaryDirectory() as d:
+        g = os.path.join(d, "g.fa"); r = os.path.join(d, "r.csfasta")
+        write_fa_codes(g, [b"contig%d" % (i + 1) for i in range(len(contigs))], contigs)
+        synth.write_csfasta_reads(r, reads)
+        p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "gmapper-cs"), "-N", "4", *extra, r, g], capture_output=True, check=True)
+        body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                        **{"contig%d" % i: c for i, c in enumerate(contigs)}, reads=reads)
+    with gzip.open(os.path.join(OUT, name + ".sam.gz"), "wb", compresslevel=9) as f:
+        f.write(body)
+    n_map = sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@"))
+    print(f"{name}: {len(reads)} colour-space reads -> {n_map} SAM records")
+
+
+def cs_cases():
+    contigs = synth.make_genome(synth.contig_lengths("cfg2", 0.02), 4)
+    reads, _ = synth.make_cs_reads(contigs, 3000, 50, 4)
+    run_cs_case("cfg4s_50col_2Mbp", contigs, reads)
+    sg = stress_genome()
+    reads, _ = synth.make_cs_reads([c for c in sg if len(c) > 200], 2000, 60, 5, p_col=0.03, p_dot=0.004)
+    run_cs_case("stress_cs_60col_unal", sg, reads, extra=("--sam-unaligned",))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--cs-only" in sys.argv:
+        cs_cases(); return
     if "--cs-kat-only" in sys.argv:
         cs_kat_cases(); return
     if "--index-only" in sys.argv:
@@ -227,6 +254,7 @@ def main():
     option_cases()
     index_cases()
     cs_kat_cases()
+    cs_cases()
 
 
 if __name__ == "__main__":
