@@ -60,9 +60,14 @@ typedef struct gm_params {
   int longest_read_len;                        /* ref: gmapper-defaults.h:72 1000 */
   int strata;                                  /* --strata: only the best-scoring hits (ref: gmapper.h:85, mapping.c:1706-1712,2268-2274) false */
   int max_alignments;                          /* --max-alignments: drop reads with more final hits (ref: gmapper.h:54, mapping.c:1713-1722) 0 = all */
+  int colour_space;                            /* shrimp_mode == MODE_COLOUR_SPACE, i.e. the gmapper-cs binary (ref: util.c:28-38) 0 */
+  int crossover_score;                         /* ref: gmapper-defaults.h:54  -20; the vector filter's mismatch is match + crossover (gmapper.c:2935) */
+  int indel_taboo_len;                         /* ref: gmapper.h:57  0 */
+  double pr_xover;                             /* ref: gmapper.h:119  0.03: fixes score_alpha in colour space (gmapper.c:2557-2563) */
 } gm_params_t;
 
-void gm_params_default(gm_params_t *p);        /* letter-space defaults of the reference binary */
+void gm_params_default(gm_params_t *p);        /* letter-space defaults of the reference binary (gmapper-ls) */
+void gm_params_default_cs(gm_params_t *p);     /* colour-space defaults (gmapper-cs): mismatch -24, vector threshold 47%, ref: gmapper.c:1748-1755 */
 
 /* ---------------------------------------------------------------------------------------------
  * S5: index.  Replaces load_genome() and the globals genomemap / genomemap_len / genome_contigs /
@@ -189,6 +194,14 @@ int gm_map_reads(gm_session_t *s, int n_reads, int read_len, const uint32_t *rea
  * unless emit_sam == 0, in which case only the alignment records are produced and counted. */
 int gm_map_reads_device(gm_session_t *s, int n_reads, int read_len, const void *reads_dev,
                         int emit_sam, char **sam, size_t *sam_len, gm_map_stats_t *stats);
+/* colour-space reads (SOLiD): colours_packed holds n_colours 4-bit colour codes per read (0-3, 15 for a skipped cycle) in the
+ * same bitfield layout, initbp[i] the primer letter code (A0 C1 G2 T3) -- what fasta_sequence_to_bitfield / fasta_get_initial_base
+ * produce (ref: gmapper.c:475-487).  The session's index must have been built with colour_space = 1.  Replaces handle_read() for
+ * the gmapper-cs binary: colour k-mers from colour 1 on, the colour vector filter on the read's input strand, sw_full_cs, the
+ * post_sw forward-backward pass and the colour-space SAM fields (ref: mapping.c:1297-1319,375-379,1613-1614; sw-post.c:639-758;
+ * output.c:441-451,485-493,572-580,717-730). */
+int gm_map_reads_cs(gm_session_t *s, int n_reads, int n_colours, const uint32_t *colours_packed, const uint8_t *initbp,
+                    const char *names, char **sam, size_t *sam_len, gm_map_stats_t *stats);
 void gm_free(void *p);
 
 /* ---------------------------------------------------------------------------------------------

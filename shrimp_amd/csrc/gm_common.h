@@ -41,6 +41,8 @@ struct GmSeedDev {
 
 struct GmIndexDev {
   const uint32_t* genome;
+  const uint32_t* genome_cs;          // colour space only: colour p = lstocs(letter p-1, letter p), 'T' before a contig's first letter (ref: fasta.c:586-606)
+  int colour;                         // 1 in colour space (== min_kmer_pos, ref: gmapper.c:477-480)
   uint64_t total_len;                 // sum of contig lengths (< 2^32)
   int n_contigs;
   const uint32_t* contig_off;         // [n_contigs+1] global offsets (ref: contig_offsets[])
@@ -92,6 +94,22 @@ struct GmFullRes {
   int32_t n_ops; uint32_t ops_off;   // ops bytes ('M','I','D') in the batch's op pool
   int32_t sort_idx;              // paired mode: position in the read's (strand 0, strand 1) window list (ref: mapping.c:2545-2552)
   uint32_t hit_slot;             // index of the window in the batch's GmHit array
+  int32_t n_xover;               // colour space: crossovers on the sw_full_cs path (ref: sw-full-cs.c:929-932)
 };
+
+// 4-bit code i of strand st of a packed read.  Letter space: strand 1 is the reverse complement (ref: util.c:540-596).
+// Colour space: strand 1 holds the colours in reverse order, rc[i] = read[len - i] for i >= 1 (ref: util.c:600-617); rc[0]
+// involves the primer letter and is never used: k-mers start at colour 1 and the alignment kernels only see strand 0.
+__device__ __forceinline__ uint32_t gm_read_code(const uint32_t* __restrict__ rw, int read_len, int st, int colour, int i) {
+  if (colour) {
+    if (st && i == 0) return 15u;
+    const int src = st ? (read_len - i) : i;
+    return (rw[src >> 3] >> ((src & 7) * 4)) & 0xf;
+  }
+  const int src = st ? (read_len - 1 - i) : i;
+  uint32_t c = (rw[src >> 3] >> ((src & 7) * 4)) & 0xf;
+  if (st) { const uint64_t cm = 0xFBCDE56879A00123ull; c = (uint32_t)(cm >> (c * 4)) & 0xf; }   // complement_base, ref: util.h:125-151
+  return c;
+}
 
 static inline int gm_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -37,11 +37,18 @@ extern "C" void gm_params_default(gm_params_t* p) {
   p->match_mode = 2; p->num_outputs = 10; p->num_tmp_outputs = 30; p->anchor_width = 8;
   p->region_bits = 11; p->region_overlap = 50; p->list_cutoff = 0; p->hash_filter_calls = 1; p->tiebreak_rev = 1;
   p->sam_unaligned = 0; p->longest_read_len = 1000; p->strata = 0; p->max_alignments = 0;
+  p->colour_space = 0; p->crossover_score = -20; p->indel_taboo_len = 0; p->pr_xover = 0.03;
+}
+// the gmapper-cs binary's defaults (ref: gmapper.c:1748-1755, gmapper-defaults.h:52-58,64-66)
+extern "C" void gm_params_default_cs(gm_params_t* p) {
+  gm_params_default(p);
+  p->colour_space = 1; p->mismatch_score = -24; p->sw_vect_threshold = 47.0; p->sw_full_threshold = 50.0;
 }
 
 static GmScoreDev make_score(const gm_params_t& P) {
   GmScoreDev s; memset(&s, 0, sizeof s);
-  s.match = P.match_score; s.mismatch = P.mismatch_score;
+  s.match = P.match_score;
+  s.mismatch = P.colour_space ? P.match_score + P.crossover_score : P.mismatch_score;   // what f1_setup hands the vector filter (ref: gmapper.c:2933-2936)
   s.a_go = -P.a_gap_open_score; s.a_ge = -P.a_gap_extend_score; s.b_go = -P.b_gap_open_score; s.b_ge = -P.b_gap_extend_score;
   s.anchor_width = P.anchor_width; s.match_mode = P.match_mode; s.min_matches = P.match_mode;   // ref: gmapper.c:2625
   s.num_tmp_outputs = P.num_tmp_outputs; s.tiebreak_rev = P.tiebreak_rev; s.hash_filter_calls = P.hash_filter_calls;
@@ -55,7 +62,7 @@ static GmScoreDev make_score(const gm_params_t& P) {
 // ---- index ------------------------------------------------------------------------------------
 GmIndexDev GmIndexHost::dev_view() const {
   GmIndexDev d; memset(&d, 0, sizeof d);
-  d.genome = d_genome; d.total_len = total_len; d.n_contigs = n_contigs; d.contig_off = d_contig_off;
+  d.genome = d_genome; d.genome_cs = d_genome_cs; d.colour = params.colour_space ? 1 : 0; d.total_len = total_len; d.n_contigs = n_contigs; d.contig_off = d_contig_off;
   d.n_seeds = n_seeds; d.min_seed_span = min_seed_span; d.max_seed_span = max_seed_span;
   d.slab_bits = slab_bits; d.n_slabs = n_slabs; d.region_bits = params.region_bits; d.region_overlap = params.region_overlap;
   d.list_cutoff = list_cutoff;
@@ -161,7 +168,7 @@ extern "C" int gm_index_build(gm_index_t** out, int device, int n_contigs, const
 extern "C" void gm_index_free(gm_index_t* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
-  (void)hipFree(ix->d_genome); (void)hipFree(ix->d_contig_off);
+  (void)hipFree(ix->d_genome); (void)hipFree(ix->d_genome_cs); (void)hipFree(ix->d_contig_off);
   for (int i = 0; i < ix->n_seeds; i++) { (void)hipFree(ix->seeds[i].d_dir); (void)hipFree(ix->seeds[i].d_pos); (void)hipFree(ix->seeds[i].d_bkt); }
   delete ix;
 }
@@ -242,7 +249,7 @@ extern "C" int gm_index_alloc_like(gm_index_t** out, int device, const void* met
 struct DevSet {
   // capacities (grown on overflow)
   int cur_len = -1, scap = 0, scap2 = 0, hcap = 0, rcap_per_read = 8, ops_stride = 0, eff_batch = 0;
-  uint32_t* d_reads = nullptr; uint64_t* d_surv = nullptr; uint32_t* d_surv_cnt = nullptr;
+  uint32_t* d_reads = nullptr; uint8_t* d_initbp = nullptr; uint64_t* d_surv = nullptr; uint32_t* d_surv_cnt = nullptr;   // d_initbp: colour space primer letters
   uint32_t* d_surv_seg = nullptr;                                          // [2B][S + 1] survivors after each slab (K1 emits slab by slab)
   uint64_t* d_surv2 = nullptr; uint32_t* d_surv_cnt2 = nullptr;            // survivors after the exact isolation prune (K1b) = input of K2
   GmHit* d_hits = nullptr; uint16_t* d_perm = nullptr; uint32_t* d_hit_cnt = nullptr; unsigned long long* d_slots = nullptr;
@@ -278,6 +285,7 @@ struct gm_session {
   const gm_index* ix = nullptr;
   gm_params_t P; GmScoreDev sc;
   double score_alpha = 0, score_beta = 0;
+  double pr_mismatch = .01, pr_del_open = 0, pr_del_extend = 0, pr_ins_open = 0, pr_ins_extend = 0;   // post_sw_setup's arguments (ref: gmapper.c:2568-2571,2959-2963)
   int max_batch = 0, p2_grid = 2560;
   hipStream_t stream = nullptr;
   hipEvent_t ev[12];
@@ -290,11 +298,11 @@ struct gm_session {
 };
 
 static void free_buffers(DevSet& D) {
-  void* ptrs[] = {D.d_reads, D.d_surv, D.d_surv_cnt, D.d_surv_seg, D.d_surv2, D.d_surv_cnt2, D.d_hits, D.d_perm, D.d_hit_cnt, D.d_slots, D.d_heavy_list, D.d_heavy_cnt,
+  void* ptrs[] = {D.d_reads, D.d_initbp, D.d_surv, D.d_surv_cnt, D.d_surv_seg, D.d_surv2, D.d_surv_cnt2, D.d_hits, D.d_perm, D.d_hit_cnt, D.d_slots, D.d_heavy_list, D.d_heavy_cnt,
                   D.d_sel, D.d_sel_sidx, D.d_sel_cnt, D.d_sel_off, D.d_work, D.d_n_work, D.d_res, D.d_ops, D.d_back,
                   D.d_pmin, D.d_pmax, D.d_saved, D.d_saved_list};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  D.d_reads = nullptr; D.d_surv = nullptr; D.d_surv_cnt = nullptr; D.d_surv_seg = nullptr; D.d_surv2 = nullptr; D.d_surv_cnt2 = nullptr; D.d_hits = nullptr; D.d_perm = nullptr; D.d_hit_cnt = nullptr; D.d_slots = nullptr;
+  D.d_reads = nullptr; D.d_initbp = nullptr; D.d_surv = nullptr; D.d_surv_cnt = nullptr; D.d_surv_seg = nullptr; D.d_surv2 = nullptr; D.d_surv_cnt2 = nullptr; D.d_hits = nullptr; D.d_perm = nullptr; D.d_hit_cnt = nullptr; D.d_slots = nullptr;
   D.d_heavy_list = nullptr; D.d_heavy_cnt = nullptr; D.d_sel = nullptr; D.d_sel_sidx = nullptr; D.d_sel_cnt = nullptr; D.d_sel_off = nullptr;
   D.d_work = nullptr; D.d_n_work = nullptr; D.d_res = nullptr; D.d_ops = nullptr; D.d_back = nullptr;
   D.d_pmin = nullptr; D.d_pmax = nullptr; D.d_saved = nullptr; D.d_saved_list = nullptr;
@@ -321,7 +329,9 @@ static int alloc_buffers(gm_session* s, DevSet& D, int read_len, bool paired = f
   (void)ix;
   D.ops_stride = ((read_len + W + 15) / 16) * 16;
   D.back_stride = (((size_t)read_len * W + 255) / 256) * 256;
+  if (s->P.colour_space) { D.ops_stride *= 2; D.back_stride *= 12; }   // backtrace byte + letter codes per column; three words of back pointers per cell
   GM_HIP(hipMalloc(&D.d_reads, (size_t)B * read_words * 4 + 64));
+  if (s->P.colour_space) GM_HIP(hipMalloc(&D.d_initbp, (size_t)B + 64));
   GM_HIP(hipMalloc(&D.d_surv, (size_t)rs * D.scap * 8));
   GM_HIP(hipMalloc(&D.d_surv_cnt, (size_t)rs * 4));
   if (D.scap2 > 0) {
@@ -381,10 +391,20 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   gm_session* s = new gm_session();
   s->ix = ix; s->P = params ? *params : ix->params;
   s->sc = make_score(s->P);
-  // score -> probability derivation, LS branch (ref: gmapper.c:2557-2572)
-  const double pr_mismatch = .01;
-  s->score_alpha = ((double)s->P.match_score - (double)s->P.mismatch_score) / (log((1 - pr_mismatch) / (pr_mismatch / 3.0)) / log(2.0));
-  s->score_beta = (double)s->P.match_score - 2 * s->score_alpha - s->score_alpha * log(1 - pr_mismatch) / log(2.0);
+  // score -> probability derivation (ref: gmapper.c:2557-2572)
+  if (s->P.colour_space) {   // pr_xover => alpha => pr_mismatch
+    s->score_alpha = (double)s->P.crossover_score / (log(s->P.pr_xover / 3) / log(2.0));
+    s->pr_mismatch = 1.0 / (1.0 + 1.0 / 3.0 * pow(2.0, ((double)s->P.match_score - (double)s->P.mismatch_score) / s->score_alpha));
+  } else {                   // pr_mismatch => alpha
+    s->pr_mismatch = .01;
+    s->score_alpha = ((double)s->P.match_score - (double)s->P.mismatch_score) / (log((1 - s->pr_mismatch) / (s->pr_mismatch / 3.0)) / log(2.0));
+  }
+  s->score_beta = (double)s->P.match_score - 2 * s->score_alpha - s->score_alpha * log(1 - s->pr_mismatch) / log(2.0);
+  s->pr_del_open = pow(2.0, (double)s->P.a_gap_open_score / s->score_alpha);
+  s->pr_ins_open = pow(2.0, (double)s->P.b_gap_open_score / s->score_alpha);
+  s->pr_del_extend = pow(2.0, (double)s->P.a_gap_extend_score / s->score_alpha);
+  s->pr_ins_extend = pow(2.0, ((double)s->P.b_gap_extend_score - s->score_beta) / s->score_alpha);
+  if ((s->P.colour_space != 0) != (ix->params.colour_space != 0)) { delete s; gm_set_error("session and index disagree on colour space"); return GM_E_ARG; }
   s->max_batch = std::max(64, std::min(max_batch_reads > 0 ? max_batch_reads : 131072, 1 << 20));
   GM_HIP(hipStreamCreate(&s->stream));
   for (auto& e : s->ev) GM_HIP(hipEventCreate(&e));
@@ -410,6 +430,7 @@ struct FHit {            // one pass-2 candidate on the host (read_hit + sw_full
   const GmFullRes* r; const uint8_t* ops;
   int score_full, pass2_key; double pct_score_full; double posterior; int mqv; double z0, z1;
   double z2, z3, pr_top_random, insert_size_denom, pr_missed_mp;   // paired mode (ref: sw-full-common.h:30-44)
+  std::string db, qr; int cs_match = 0, cs_mismatch = 0, cs_xover = 0;   // colour space: dbalign / qralign and the counts post_sw leaves (ref: sw-post.c:531-565)
 };
 
 static inline char* put_uint(char* p, unsigned long long v) {
@@ -454,9 +475,121 @@ static void dedup_pass(std::vector<FHit*>& v, Cmp cmp) {     // ref: mapping.c:1
 static const char CODE2SEQ[17] = "ACGTNNNNNNNNNNNN";   // SEQ letter of an aligned read base (ref: output.c:485-533: non-ACGTN -> N)
 static inline char rc_char(char c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'N'; } }
 
+// ---- colour space: post_sw (ref: common/sw-post.c:639-758) for reads without quality values -----------------------------------
+// A 16-state forward-backward over the aligned columns; state j = previous letter << 2 | letter.  The sums run in the reference's
+// order in doubles through the same libm calls, so posterior (-> Z0/Z1, MAPQ, AS) carries the same bits; what is hoisted out of
+// the reference's inner loops (node priors, exp() of the previous column, log() of a sum shared by four states) is computed from
+// identical operands, once instead of four or sixteen times.
+struct CsPostConsts { double let_m, let_x, col_m[2], col_x[2]; };   // log(1 - e), log(e / 3) for the letter and the two colour error rates
+static CsPostConsts cs_post_consts(const gm_session* s) {
+  CsPostConsts c; const double ce[2] = {s->P.pr_xover, .75};
+  c.let_m = log(1 - s->pr_mismatch); c.let_x = log(s->pr_mismatch / 3.0);
+  for (int k = 0; k < 2; k++) { c.col_m[k] = log(1 - ce[k]); c.col_x[k] = log(ce[k] / 3.0); }
+  return c;
+}
+static void cs_post_sw(const gm_session* s, const CsPostConsts& K, const uint32_t* rw, int init_bp, int read_start, FHit& h) {
+  struct Col { double prior[16], fw[16], bw[16], fs, bs; int col; };
+  std::string& db = h.db; std::string& qr = h.qr;
+  static thread_local std::vector<Col> colbuf;
+  if (colbuf.size() < db.size() + 1) colbuf.resize(db.size() + 1);
+  Col* cols = colbuf.data(); int len = 0;
+  auto colour = [&](int j) { return (int)((rw[j >> 3] >> ((j & 7) * 4)) & 0xf); };
+  {  // load_local_vectors, ref: sw-post.c:448-528
+    int start_run = 0, j;
+    for (j = 0; j < read_start; j++) { const int c = colour(j); if (c == 15) { start_run = 15; j = read_start; break; } start_run ^= c; }
+    for (size_t i = 0; i < db.size(); i++) {
+      if (qr[i] == '-') continue;
+      Col& c = cols[len];
+      int let = -2;                                     // -2: no letter emission (insertion); -1: a letter no state matches
+      if (db[i] != '-') switch (db[i]) { case 'A': case 'a': let = 0; break; case 'C': case 'c': let = 1; break; case 'G': case 'g': let = 2; break;
+                                         case 'T': case 't': let = 3; break; default: let = -1; }
+      const int cc = colour(j); int which;
+      if ((len == 0 && start_run == 15) || cc == 15) { c.col = 0; which = 1; } else { c.col = cc ^ (len == 0 ? start_run : 0); which = 0; }
+      for (int st = 0; st < 16; st++) {                 // nodePrior, ref: sw-post.c:111-138
+        const int l = (st >> 2) & 3, r = st & 3; double val = 0;
+        if (let != -2) val = val - ((r == let) ? K.let_m : K.let_x);
+        val = val - (((l ^ r) == c.col) ? K.col_m[which] : K.col_x[which]);
+        c.prior[st] = val;
+      }
+      len++; j++;
+    }
+  }
+  if (len == 0) { h.posterior = 0; return; }
+  double total;
+  {  // do_forwards, ref: sw-post.c:317-360
+    Col& a = cols[0]; a.fs = 999999999;
+    for (int j = 0; j < 16; j++) { if (((j >> 2) & 3) == init_bp) { a.fw[j] = a.prior[j]; a.fs = (a.fs < a.fw[j]) ? a.fs : a.fw[j]; } else a.fw[j] = HUGE_VAL; }
+    for (int j = 0; j < 16; j++) a.fw[j] -= a.fs;
+    for (int i = 1; i < len; i++) {
+      Col& c = cols[i]; const Col& p = cols[i - 1];
+      double e[16], lg[4];
+      for (int k = 0; k < 16; k++) e[k] = exp(-1 * (p.fw[k]));
+      for (int l = 0; l < 4; l++) { double sum = 0; for (int k = l; k < 16; k += 4) sum += e[k]; lg[l] = log(sum); }   // states k with right(k) == l, ascending
+      c.fs = 999999999;
+      for (int j = 0; j < 16; j++) { c.fw[j] = c.prior[j] - lg[(j >> 2) & 3]; c.fs = (c.fs < c.fw[j]) ? c.fs : c.fw[j]; }
+      for (int j = 0; j < 16; j++) c.fw[j] -= c.fs;
+      c.fs += p.fs;
+    }
+    double val = 0;
+    for (int j = 0; j < 16; j++) val += exp(-1 * (cols[len - 1].fw[j]));
+    total = -log(val) + cols[len - 1].fs;
+  }
+  {  // do_backwards, ref: sw-post.c:269-315
+    Col& z = cols[len - 1]; z.bs = 999999999;
+    for (int j = 0; j < 16; j++) { z.bw[j] = 0; z.bs = (z.bs < z.bw[j]) ? z.bs : z.bw[j]; }
+    for (int j = 0; j < 16; j++) z.bw[j] -= z.bs;
+    for (int i = len - 2; i >= 0; i--) {
+      Col& c = cols[i]; const Col& n = cols[i + 1];
+      double e[16], nl[4];
+      for (int k = 0; k < 16; k++) e[k] = exp(-1 * (n.prior[k] + n.bw[k]));
+      for (int r = 0; r < 4; r++) { double sum = 0; for (int k = 4 * r; k < 4 * r + 4; k++) sum += e[k]; nl[r] = -log(sum); }     // states k with left(k) == r
+      c.bs = 999999999;
+      for (int j = 0; j < 16; j++) { c.bw[j] = nl[j & 3]; c.bs = (c.bs < c.bw[j]) ? c.bs : c.bw[j]; }
+      for (int j = 0; j < 16; j++) c.bw[j] -= c.bs;
+      c.bs += n.bs;
+    }
+  }
+  {  // post_traceback + fix_base_calls, ref: sw-post.c:183-212,531-565
+    int j = 0, prev_base = init_bp; h.cs_match = h.cs_mismatch = h.cs_xover = 0;
+    for (size_t i = 0; i < qr.size(); i++) {
+      if (qr[i] == '-') continue;
+      const Col& c = cols[j];
+      double post[4] = {0, 0, 0, 0};
+      for (int st = 0; st < 16; st++) post[st & 3] += exp(-1 * (c.fw[st] + c.bw[st] + c.fs + c.bs - total));
+      int crt = 0; for (int b = 1; b < 4; b++) if (post[b] > post[crt]) crt = b;
+      if ((prev_base ^ crt) == c.col) qr[i] = "ACGT"[crt]; else { qr[i] = "acgt"[crt]; h.cs_xover++; }
+      if (db[i] != '-') { if (toupper((unsigned char)db[i]) == toupper((unsigned char)qr[i])) h.cs_match++; else h.cs_mismatch++; }
+      prev_base = crt; j++;
+    }
+  }
+  {  // get_posterior, ref: sw-post.c:589-612
+    double res = exp(-total);
+    for (size_t i = 0; i < db.size(); i++) {
+      if (db[i] == '-') { res *= s->pr_ins_extend; if (i == 0 || db[i - 1] != '-') res *= s->pr_ins_open; }
+      else if (qr[i] == '-') { res *= s->pr_del_extend; if (i == 0 || qr[i - 1] != '-') res *= s->pr_del_open; }
+    }
+    h.posterior = res;
+  }
+}
+// dbalign / qralign of a colour-space alignment from the backtrace bytes and letter codes k_pass2_cs wrote (pretty_print, ref: sw-full-cs.c:945-1060)
+static void cs_alignment_strings(const uint8_t* bt, const uint8_t* codes, int n, std::string& db, std::string& qr) {
+  static const char L[17] = "ACGTUMRWSYKVHDBN";
+  db.clear(); qr.clear();
+  for (int t = 0; t < n; t++) {
+    const int type = bt[t] & 0x0f; const bool xov = (bt[t] & 0x80) != 0;
+    if (type == 1) { db.push_back(L[codes[t] >> 4]); qr.push_back('-'); continue; }
+    char q = L[codes[t] & 15]; if (xov) q = (char)tolower((unsigned char)q);
+    if (type >= 2 && type <= 5) { db.push_back('-'); qr.push_back(q); continue; }
+    const char d = L[codes[t] >> 4];
+    if (q == 'n' || q == 'N') q = xov ? (char)tolower((unsigned char)d) : d;      // an unknown read letter is shown as the genome's
+    db.push_back(d); qr.push_back(q);
+  }
+}
+
 struct Finalizer {
   const gm_session* s; int read_len, read_words; const uint32_t* reads;   // host copy of the packed reads of this sub-batch
   const char* const* name_ptr; const int* name_len; long name_base;
+  const uint8_t* initbp = nullptr; int ops_half = 0; CsPostConsts csk = CsPostConsts();   // colour space: primer letters of this sub-batch, ops_stride / 2
 
   // hit_run_post_sw for one pass-2 result (ref: mapping.c:1609-1625)
   void post_sw(FHit& h, const GmFullRes* r, const uint8_t* ops) const {
@@ -467,6 +600,10 @@ struct Finalizer {
     h.pct_score_full = (1000 * 100 * h.score_full) / r->score_max;                 // ref: mapping.c:400-401
     if (h.score_full > 0) {
       const double a = s->score_alpha, b = s->score_beta;
+      if (P.colour_space) {
+        cs_alignment_strings(h.ops, h.ops + ops_half, std::min(r->n_ops, ops_half), h.db, h.qr);
+        cs_post_sw(s, csk, reads + (size_t)r->read_idx * read_words, (int)initbp[r->read_idx], r->read_start, h);
+      } else
       h.posterior = pow(2.0, ((double)r->score - (double)r->rmapped * (2.0 * a + b)) / a);
       int ps = (int)rint(a * log(h.posterior) / log(2.0) + (double)r->rmapped * (2.0 * a + b));
       if (ps < 0) ps = 0;
@@ -500,11 +637,14 @@ struct Finalizer {
     char nbuf[32]; const char* nm; size_t nl;
     if (name_ptr) { nm = name_ptr[rd]; nl = (size_t)name_len[rd]; }
     else { nl = (size_t)snprintf(nbuf, sizeof nbuf, "r%ld", name_base + rd); nm = nbuf; }
-    const size_t need = 64 + nl + 4 * (size_t)read_len + 256;
+    const size_t need = 64 + nl + 6 * (size_t)read_len + 320;
+    // colour space: the read as csfasta text, primer letter + colours ('.' for a skipped cycle), for the CS:Z tag (ref: output.c:451,730)
+    auto put_csfasta = [&](char* p) { *p++ = "ACGT"[initbp[rd] & 3]; for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = (c < 4) ? (char)('0' + c) : '.'; } return p; };
     if (p2.empty()) {
       if (P.sam_unaligned) {                                                       // ref: output.c:411-466
         size_t o = out.size(); out.resize(o + need); char* p = &out[o];
         p = put_str(p, nm, nl); p = put_str(p, "\t4\t*\t0\t0\t*\t*\t0\t0\t", 17);
+        if (P.colour_space) { p = put_str(p, "*\t*\tCQ:Z:*\tCS:Z:", 16); p = put_csfasta(p); *p++ = '\n'; out.resize(p - out.data()); return 1; }   // ref: output.c:353-355,441-451
         for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = (c < 4) ? "ACGT"[c] : 'N'; }
         p = put_str(p, "\t*\n", 3);
         out.resize(p - out.data());
@@ -531,17 +671,44 @@ struct Finalizer {
       p = put_int(p, h->mqv); *p++ = '\t';
       // CIGAR (make_cigar, ref: output.c:15-64): 'I' op = gap in the read -> D; 'D' op = gap in the genome -> I
       struct Run { int len; char op; }; Run runs[GM_MAX_OPS]; int nr = 0;
-      if (read_start > 1) runs[nr++] = {read_start - 1, 'S'};
+      const char clip = P.colour_space ? 'H' : 'S';                                 // ref: output.c:575-579
+      if (read_start > 1) runs[nr++] = {read_start - 1, clip};
+      if (P.colour_space) {
+        const int na = (int)h->qr.size();
+        for (int i = 0; i < na;) {
+          const char op = h->qr[i] == '-' ? 'D' : (h->db[i] == '-' ? 'I' : 'M'); int j = i;
+          while (j < na && (h->qr[j] == '-' ? 'D' : (h->db[j] == '-' ? 'I' : 'M')) == op) j++;
+          if (nr < GM_MAX_OPS - 1) runs[nr++] = {j - i, op};
+          i = j;
+        }
+      } else {
       const int nops = std::min(r.n_ops, ops_stride);
       for (int i = 0; i < nops;) {
         const char op = (char)h->ops[i]; int j = i; while (j < nops && h->ops[j] == (uint8_t)op) j++;
         if (nr < GM_MAX_OPS - 1) runs[nr++] = {j - i, op == 'M' ? 'M' : (op == 'I' ? 'D' : 'I')};
         i = j;
       }
-      if (read_end != read_len) runs[nr++] = {read_len - read_end, 'S'};
+      }
+      if (read_end != read_len) runs[nr++] = {read_len - read_end, clip};
       if (!rev) for (int i = 0; i < nr; i++) { p = put_uint(p, (unsigned)runs[i].len); *p++ = runs[i].op; }
       else for (int i = nr - 1; i >= 0; i--) { p = put_uint(p, (unsigned)runs[i].len); *p++ = runs[i].op; }
       p = put_str(p, "\t*\t0\t0\t", 7);
+      if (P.colour_space) {   // SEQ = the aligned letters post_sw called (ref: output.c:485-537), then the colour-space tags (:717-730)
+        auto up = [](char c) { if (c >= 'a') c -= 32; return (c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N') ? c : 'N'; };
+        const int na = (int)h->qr.size();
+        if (!rev) { for (int i = 0; i < na; i++) if (h->qr[i] != '-') *p++ = up(h->qr[i]); }
+        else for (int i = na - 1; i >= 0; i--) if (h->qr[i] != '-') *p++ = rc_char(up(h->qr[i]));
+        p = put_str(p, "\t*\tAS:i:", 8); p = put_int(p, h->score_full);
+        p = put_str(p, "\tZ0:i:", 6); p = put_int(p, double_to_neglog(h->z0));
+        p = put_str(p, "\tZ1:i:", 6); p = put_int(p, double_to_neglog(h->z1));
+        p = put_str(p, "\tNM:i:", 6); p = put_int(p, h->cs_mismatch + r.n_del + r.n_ins);
+        p = put_str(p, "\tCS:Z:", 6); p = put_csfasta(p);
+        p = put_str(p, "\tCM:i:", 6); p = put_int(p, h->cs_xover);
+        p = put_str(p, "\tXX:Z:", 6); p = put_str(p, h->qr.data(), h->qr.size());
+        *p++ = '\n';
+        out.resize(p - out.data());
+        continue;
+      }
       // SEQ: read bases in input orientation (aligned part from qralign == the read's own letters), revcomp on '-'
       if (!rev) for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = CODE2SEQ[c]; }
       else for (int i = read_len - 1; i >= 0; i--) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = rc_char(CODE2SEQ[c]); }
@@ -636,7 +803,8 @@ static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int
     GM_HIP(hipStreamSynchronize(q));
     if (n_heavy) { rc = run_heavy_tier(s, D, dv, n, read_len, read_words, W, (int)n_heavy); if (rc) return rc; if (st) st->exact_order_reads += 0; }
     GM_HIP(hipEventRecord(s->ev[2], q));
-    rc = gm_launch_pass1(dv, s->sc, D.d_reads, n, read_len, read_words, W, overlap_abs, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, D.d_slots, s->d_stats, q);
+    rc = gm_launch_pass1(dv, s->sc, D.d_reads, n, read_len, read_words, W, overlap_abs, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, D.d_slots, s->d_stats, q,
+                         nullptr, nullptr, D.d_initbp);
     if (rc) return rc;
     GM_HIP(hipEventRecord(s->ev[3], q));
     rc = gm_launch_select(s->sc, n, read_len, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, D.d_sel, D.d_sel_cnt, D.d_sel_off, D.d_work, D.d_n_work, q);
@@ -659,6 +827,12 @@ static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int
       rc = alloc_buffers(s, D, read_len); if (rc) return rc;
       return 1;
     }
+    if (s->P.colour_space) {
+      const int cs9[9] = {s->P.match_score, s->P.mismatch_score, s->P.crossover_score, -s->P.a_gap_open_score, -s->P.a_gap_extend_score,
+                          -s->P.b_gap_open_score, -s->P.b_gap_extend_score, s->P.anchor_width, s->P.indel_taboo_len};   // sw_full_cs_setup's arguments (ref: gmapper.c:2944-2947)
+      rc = gm_launch_pass2_cs(dv, s->sc, cs9, D.d_reads, D.d_initbp, n, read_len, read_words, W, D.d_hits, D.hcap, D.d_sel, D.d_work, D.d_n_work,
+                              D.d_res, D.d_ops, D.ops_stride, (uint32_t*)D.d_back, D.back_stride / 4, s->p2_grid, s->d_stats, q);
+    } else
     rc = gm_launch_pass2(dv, s->sc, D.d_reads, n, read_len, read_words, W, D.d_hits, D.d_perm, D.hcap, D.d_sel, D.d_sel_cnt, D.d_work, D.d_n_work,
                          D.d_res, D.d_ops, D.ops_stride, D.d_back, D.back_stride, s->p2_grid, s->d_stats, q);
     if (rc) return rc;
@@ -694,8 +868,10 @@ static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int
 }
 
 static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* reads_host, const void* reads_dev,
-                    const char* names, int emit_sam, char** sam, size_t* sam_len, gm_map_stats_t* stats) {
+                    const char* names, int emit_sam, char** sam, size_t* sam_len, gm_map_stats_t* stats, const uint8_t* initbp_host = nullptr) {
   if (!s || n_reads < 0 || read_len < 1) { gm_set_error("gm_map_reads: bad arguments"); return GM_E_ARG; }
+  if ((s->P.colour_space != 0) != (initbp_host != nullptr)) {
+    gm_set_error(s->P.colour_space ? "colour-space session: use gm_map_reads_cs (colours + primer letters)" : "gm_map_reads_cs needs a colour-space session"); return GM_E_ARG; }
   if (read_len > s->P.longest_read_len || read_len >= 32768 / std::max(1, s->P.match_score)) { gm_set_error("read length %d out of range (ref: sw-vector.c:393-398)", read_len); return GM_E_RANGE; }
   GM_HIP(hipSetDevice(s->ix->device));
   DevSet& D = s->set[0];
@@ -724,6 +900,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     J->outs.assign(nchunks, std::string()); J->cm.assign(nchunks, 0); J->cr.assign(nchunks, 0);
     std::atomic<int> next(0);
     Finalizer F{s, read_len, read_words, J->hreads, names ? nptr.data() + J->base : nullptr, names ? nlen.data() + J->base : nullptr, (long)J->base};
+    if (s->P.colour_space) { F.initbp = initbp_host + J->base; F.ops_half = ops_stride / 2; F.csk = cs_post_consts(s); }
     auto worker = [&]() {
       std::vector<FHit> fh; std::vector<FHit*> p2;
       for (;;) {
@@ -751,6 +928,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
       n = std::min(D.eff_batch, n_reads - base);
       if (reads_host) GM_HIP(hipMemcpyAsync(D.d_reads, reads_host + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyHostToDevice, s->stream));
       else GM_HIP(hipMemcpyAsync(D.d_reads, (const uint32_t*)reads_dev + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyDeviceToDevice, s->stream));
+      if (initbp_host) GM_HIP(hipMemcpyAsync(D.d_initbp, initbp_host + base, (size_t)n, hipMemcpyHostToDevice, s->stream));
       rc = run_device_pipeline(s, D, s->slot[jobs.size() % 3], n, read_len, stats, &lk);
     } while (rc == 1);
     if (rc) { for (auto& j : jobs) if (j->th.joinable()) j->th.join(); return rc; }
@@ -798,6 +976,12 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
 extern "C" int gm_map_reads(gm_session_t* s, int n_reads, int read_len, const uint32_t* reads_packed, const char* names,
                             char** sam, size_t* sam_len, gm_map_stats_t* stats) {
   return map_impl(s, n_reads, read_len, reads_packed, nullptr, names, 1, sam, sam_len, stats);
+}
+extern "C" int gm_map_reads_cs(gm_session_t* s, int n_reads, int n_colours, const uint32_t* colours_packed, const uint8_t* initbp, const char* names,
+                               char** sam, size_t* sam_len, gm_map_stats_t* stats) {
+  if (!colours_packed || !initbp) { gm_set_error("gm_map_reads_cs: bad arguments"); return GM_E_ARG; }
+  for (int i = 0; i < n_reads; i++) if (initbp[i] > 3) { gm_set_error("read %d: primer letter code %d (the reference rejects such reads, fasta.c:636-645)", i, (int)initbp[i]); return GM_E_ARG; }
+  return map_impl(s, n_reads, n_colours, colours_packed, nullptr, names, 1, sam, sam_len, stats, initbp);
 }
 extern "C" int gm_map_reads_device(gm_session_t* s, int n_reads, int read_len, const void* reads_dev, int emit_sam, char** sam, size_t* sam_len, gm_map_stats_t* stats) {
   return map_impl(s, n_reads, read_len, nullptr, reads_dev, nullptr, emit_sam, sam, sam_len, stats);

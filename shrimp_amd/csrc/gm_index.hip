@@ -124,8 +124,38 @@ int gm_index_from_lists_device(GmIndexHost* ix, int sn, const uint32_t* lens, co
   return GM_OK;
 }
 
+// colour-space translation of the resident genome (ref: common/fasta.c:586-606, genome.c:1108-1136): colour p =
+// lstocs(letter p-1, letter p) with a 'T' before the first letter of every contig; anything but A/C/G/T gives 15.
+__global__ void __launch_bounds__(256) k_colour_genome(const uint32_t* __restrict__ genome, uint64_t total_len, const uint32_t* __restrict__ contig_off,
+                                                       int n_contigs, uint32_t* __restrict__ genome_cs, uint64_t n_words) {
+  uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; w < n_words; w += stride) {
+    uint32_t out = 0;
+    for (int n = 0; n < 8; n++) {
+      const uint64_t p = w * 8 + n;
+      if (p >= total_len) break;
+      int lo = 0, hi = n_contigs;
+      while (hi - lo > 1) { int m = (lo + hi) >> 1; if (contig_off[m] <= p) lo = m; else hi = m; }
+      const uint32_t a = (p == contig_off[lo]) ? 3u : gm_nib(genome, p - 1), b = gm_nib(genome, p);
+      out |= ((a > 3u || b > 3u) ? 15u : (a ^ b)) << (4 * n);
+    }
+    genome_cs[w] = out;
+  }
+}
+int gm_index_colour_genome_device(GmIndexHost* ix, hipStream_t stream) {
+  if (!ix->d_genome_cs) GM_HIP(hipMalloc(&ix->d_genome_cs, ix->genome_words * 4));
+  hipLaunchKernelGGL(k_colour_genome, dim3(256 * 16), dim3(256), 0, stream, ix->d_genome, ix->total_len, ix->d_contig_off, ix->n_contigs,
+                     ix->d_genome_cs, ix->genome_words);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(stream));
+  return GM_OK;
+}
+
 int gm_index_build_device(GmIndexHost* ix, hipStream_t stream) {
   const uint64_t n = ix->total_len;
+  if (ix->params.colour_space) { int rc = gm_index_colour_genome_device(ix, stream); if (rc) return rc; }
+  const uint32_t* d_seq = ix->params.colour_space ? ix->d_genome_cs : ix->d_genome;     // the sequence the seeds are cut from (ref: genome.c:1126-1136)
   uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_b = nullptr, *d_cnt = nullptr;
   void* tmp = nullptr;
   GM_HIP(hipMalloc(&keys_a, n * 4));
@@ -144,7 +174,7 @@ int gm_index_build_device(GmIndexHost* ix, hipStream_t stream) {
     GmSeedHost& sd = ix->seeds[sn];
     const uint64_t K = 1ull << (2 * sd.weight);
     const uint64_t KS = K * (uint64_t)ix->n_slabs;
-    hipLaunchKernelGGL(k_emit_keys, dim3(grid), dim3(256), 0, stream, ix->d_genome, n, ix->d_contig_off, ix->n_contigs,
+    hipLaunchKernelGGL(k_emit_keys, dim3(grid), dim3(256), 0, stream, d_seq, n, ix->d_contig_off, ix->n_contigs,
                        sd.mask, sd.span, sd.weight, keys_a);
     e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_a, keys_b, iota, vals_b, (size_t)n, 0, 2 * sd.weight + 1, stream);
     if (e != hipSuccess) { gm_set_error("radix_sort_pairs: %s", hipGetErrorString(e)); return GM_E_NODEVICE; }

@@ -16,6 +16,7 @@ struct GmIndexHost {
   std::vector<uint32_t> contig_off;     // n_contigs + 1
   std::vector<std::string> names;
   uint32_t* d_genome = nullptr; uint64_t genome_words = 0;
+  uint32_t* d_genome_cs = nullptr;      // colour space: colour translation of d_genome (same coordinates)
   uint32_t* d_contig_off = nullptr;
   int n_seeds = 0, min_seed_span = 64, max_seed_span = 0;
   GmSeedHost seeds[GM_MAX_SEEDS];
@@ -38,6 +39,7 @@ enum { GS_LOOKUPS = 0, GS_ENTRIES, GS_SURVIVORS, GS_ANCHORS, GS_WINDOWS, GS_VEC_
 
 // ---- kernel launchers (one per .hip file) -----------------------------------------------------
 int gm_index_build_device(GmIndexHost* ix, hipStream_t stream);
+int gm_index_colour_genome_device(GmIndexHost* ix, hipStream_t stream);   // derives d_genome_cs from d_genome
 int gm_index_from_lists_device(GmIndexHost* ix, int sn, const uint32_t* lens, const uint32_t* pos, uint32_t total);
 
 // K1 seed lookup + region filter: one workgroup per read-strand; read-strands with more than scap
@@ -71,7 +73,8 @@ int gm_launch_anchors_heavy(const GmIndexDev& ix, const GmScoreDev& sc, int n_re
 int gm_launch_pass1(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
                     int window_len, int window_overlap_abs, GmHit* d_hits, const uint16_t* d_perm, const uint32_t* d_hit_cnt, int hcap,
                     unsigned long long* d_slots, unsigned long long* d_stats, hipStream_t stream,
-                    const int32_t* d_pair_min = nullptr, const uint8_t* d_saved = nullptr);   // paired mode: only_paired / saved windows
+                    const int32_t* d_pair_min = nullptr, const uint8_t* d_saved = nullptr,   // paired mode: only_paired / saved windows
+                    const uint8_t* d_initbp = nullptr);                                        // colour space: primer letter per read
 
 // K4a top-K selection (ref: read_get_vector_hits), one thread per read; K4b pass 2, one wave per selected hit
 #define GM_SEL_MAX 64
@@ -84,6 +87,12 @@ int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
                     const uint32_t* d_work, const uint32_t* d_n_work, GmFullRes* d_res, uint8_t* d_ops, int ops_stride,
                     uint8_t* d_back, size_t back_stride, int grid, unsigned long long* d_stats, hipStream_t stream,
                     const int32_t* d_sel_sidx = nullptr, int input_strand = 0, int write_back = 0);
+
+// colour-space pass 2 (sw_full_cs per selected window); ops_stride bytes per result: backtrace bytes, then (genome << 4 | read) codes
+int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs_params9, const uint32_t* d_reads, const uint8_t* d_initbp, int n_reads,
+                       int read_len, int read_words, int window_len, const GmHit* d_hits, int hcap, const int32_t* d_sel, const uint32_t* d_work,
+                       const uint32_t* d_n_work, GmFullRes* d_res, uint8_t* d_ops, int ops_stride, uint32_t* d_back, size_t back_words, int grid,
+                       unsigned long long* d_stats, hipStream_t stream);
 
 // paired mode (gm_pair.hip): mate ranges per window, pair top-K, saved marks, mate reversal
 int gm_launch_revcomp_reads(uint32_t* d_reads, int n_reads, int read_len, int read_words, hipStream_t stream);

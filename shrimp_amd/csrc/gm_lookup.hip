@@ -83,13 +83,7 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
   // ---- 0. read codes of this strand (strand 1 = reverse complement, ref: util.c:540-596) ----
   const uint32_t* rw = reads + (size_t)rd * read_words;
   for (int i = tid; i < read_len; i += nthr) {
-    int src = st ? (read_len - 1 - i) : i;
-    uint32_t c = (rw[src >> 3] >> ((src & 7) * 4)) & 0xf;
-    if (st) {   // complement_base, ref: util.h:125-151
-      const uint64_t cm = 0xFBCDE56879A00123ull;   // nibble i = complement of code i
-      c = (uint32_t)(cm >> (c * 4)) & 0xf;
-    }
-    codes[i] = (uint8_t)c;
+    codes[i] = (uint8_t)gm_read_code(rw, read_len, st, ix.colour, i);   // strand 1 = reverse complement (ref: util.c:540-617)
   }
   if (tid == 0) sh.n_surv = 0;
   __syncthreads();
@@ -106,7 +100,7 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
     const int sn = off / max_n_kmers, i = off - sn * max_n_kmers;
     uint32_t k = 0, b = 0, e = 0;
     const int span = ix.seed[sn].span;
-    if (i + span <= read_len) {
+    if (i >= ix.colour && i + span <= read_len) {           // colour space: min_kmer_pos = 1 (ref: gmapper.c:477-480)
       const uint64_t mask = ix.seed[sn].mask;
       uint32_t mapidx = 0;
       for (int t = 0; t < span; t++)
@@ -344,10 +338,7 @@ k_lookup_bkt(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int
   const uint32_t scap = (uint32_t)scap_all;
   const uint32_t* rw = reads + (size_t)rd * read_words;
   for (int i = tid; i < read_len; i += blockDim.x) {
-    int src = st ? (read_len - 1 - i) : i;
-    uint32_t c = (rw[src >> 3] >> ((src & 7) * 4)) & 0xf;
-    if (st) { const uint64_t cm = 0xFBCDE56879A00123ull; c = (uint32_t)(cm >> (c * 4)) & 0xf; }
-    codes[i] = (uint8_t)c;
+    codes[i] = (uint8_t)gm_read_code(rw, read_len, st, ix.colour, i);
   }
   { uint4* bm4 = (uint4*)bm; for (int w = tid; w < (bm_words >> 2); w += blockDim.x) bm4[w] = make_uint4(0, 0, 0, 0); }
   if (tid == 0) n_surv = 0;
@@ -357,7 +348,7 @@ k_lookup_bkt(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int
   uint32_t len = 0, lb = 0; bool longl = false; uint32_t lookups = 0, y = (uint32_t)i;
   uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
   const uint32_t* plist = nullptr;
-  if (tid < NL && i + ix.seed[sn].span <= read_len) {
+  if (tid < NL && i >= ix.colour && i + ix.seed[sn].span <= read_len) {
     const int span = ix.seed[sn].span; const uint64_t mask = ix.seed[sn].mask;
     uint32_t mapidx = 0;
     for (int t = 0; t < span; t++) if ((mask >> t) & 1) mapidx = (mapidx << 2) | (codes[i + span - 1 - t] & 3u);
@@ -476,10 +467,7 @@ k_lookup_v3(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
 
   const uint32_t* rw = reads + (size_t)rd * read_words;
   for (int i = tid; i < read_len; i += nthr) {
-    int src = st ? (read_len - 1 - i) : i;
-    uint32_t c = (rw[src >> 3] >> ((src & 7) * 4)) & 0xf;
-    if (st) { const uint64_t cm = 0xFBCDE56879A00123ull; c = (uint32_t)(cm >> (c * 4)) & 0xf; }   // complement_base, ref: util.h:125-151
-    codes[i] = (uint8_t)c;
+    codes[i] = (uint8_t)gm_read_code(rw, read_len, st, ix.colour, i);
   }
   if (tid == 0) { n_surv = 0; n_lists = 0; any_long = 0; }
   __syncthreads();
@@ -491,7 +479,7 @@ k_lookup_v3(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
   for (int off = tid; off < NL; off += nthr) {
     const int sn = off / max_n_kmers, i = off - sn * max_n_kmers;
     const int span = ix.seed[sn].span;
-    if (i + span > read_len) continue;
+    if (i < ix.colour || i + span > read_len) continue;
     const uint64_t mask = ix.seed[sn].mask;
     uint32_t mapidx = 0;
     for (int t = 0; t < span; t++)

@@ -162,16 +162,49 @@ __device__ uint32_t window_hash_slot(const uint8_t* db, int glen, int lane) {
   return key & (1048576u - 1u);
 }
 
+// ---- colour space helpers -------------------------------------------------------------------------
+__device__ __forceinline__ int cs_lstocs(int a, int b) {           // ref: common/util.h:182-205 (is_rna = false)
+  return (a > 3 || b > 3) ? 15 : (a ^ b);             // colourmat[a][b] == a ^ b
+}
+__device__ __forceinline__ int cs_cstols(int first_letter, int colour) {   // ref: common/util.h:157-180
+  if (first_letter == 15 || colour < 0 || colour > 3) return 15;
+  return (first_letter % 2 == 0) ? ((4 + first_letter + colour) % 4) : ((4 + first_letter - colour) % 4);
+}
+
+// The window a colour-space hit is scored on (ref: mapping.c:1297-1319): db = colours, db0[c] = lstocs(letter c, primer) for the
+// first-colour row (ref: sw-vector.c:116-146).  rc = the hit was turned onto the read's input strand (reverse_hit): the window
+// then lives on the reverse-complement contig, whose colour translation is the forward one read backwards, shifted by one
+// (complementing both letters keeps their colour), with 'T' + complement(last letter) at its very first position.
+__device__ void load_window_cs(const GmIndexDev& ix, int cn, uint32_t goff, int w_len, bool rc, int initbp, uint8_t* db, uint8_t* db0, int lane) {
+  const uint64_t cbase = ix.contig_off[cn]; const uint64_t clen = (uint64_t)ix.contig_off[cn + 1] - cbase;
+  const uint64_t cm = 0xFBCDE56879A00123ull;   // complement_base as nibbles (ref: util.h:125-151)
+  for (int c = lane; c < w_len; c += GM_WAVE) {
+    uint32_t col, let;
+    if (!rc) {
+      const uint64_t p = cbase + goff + (uint64_t)c;
+      col = (ix.genome_cs[p >> 3] >> ((p & 7) * 4)) & 0xf; let = (ix.genome[p >> 3] >> ((p & 7) * 4)) & 0xf;
+    } else {
+      const uint64_t q = (uint64_t)goff + (uint64_t)w_len - (uint64_t)c;      // forward colour index; letter index q - 1
+      const uint64_t pl = cbase + q - 1;
+      let = (ix.genome[pl >> 3] >> ((pl & 7) * 4)) & 0xf; let = (uint32_t)(cm >> (let * 4)) & 0xf;
+      if (q == clen) col = (uint32_t)cs_lstocs(3, (int)let);
+      else { const uint64_t p = cbase + q; col = (ix.genome_cs[p >> 3] >> ((p & 7) * 4)) & 0xf; }
+    }
+    db[c] = (uint8_t)col; db0[c] = (uint8_t)cs_lstocs((int)let, initbp);
+  }
+}
+
 __device__ __forceinline__ int thr_of(double frac, int absval, int base) { return frac < 0 ? absval : (int)((double)base * frac); }
 
 // ---------------------------------------------------------------------------------------------
 // K3: pass 1.  One wave per read-strand walks its windows in (contig, g_off) order.
 // ---------------------------------------------------------------------------------------------
+template <bool CS>
 __global__ void __launch_bounds__(GM_WAVE)
 k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words,
         int window_len, int overlap_abs, GmHit* __restrict__ hits, const uint16_t* __restrict__ perm,
         const uint32_t* __restrict__ hit_cnt, int hcap, unsigned long long* __restrict__ slots, unsigned long long* __restrict__ stats,
-        const int32_t* __restrict__ pair_min, const uint8_t* __restrict__ saved) {
+        const int32_t* __restrict__ pair_min, const uint8_t* __restrict__ saved, const uint8_t* __restrict__ initbp) {
   extern __shared__ __align__(16) uint8_t sm[];
   const int lane = threadIdx.x;
   const int rs = blockIdx.x, rd = rs >> 1, st = rs & 1;
@@ -180,8 +213,11 @@ k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
   const int max_w = window_len;
   uint8_t* qr = sm;                                   // read_len
   uint8_t* db = sm + ((read_len + 15) & ~15);         // max_w
-  int16_t* carry = (int16_t*)(db + ((max_w + 15) & ~15));
-  load_read(reads + (size_t)rd * read_words, read_len, st != 0, qr, lane);
+  uint8_t* db0 = db + ((max_w + 15) & ~15);           // colour space: first-colour row (max_w)
+  int16_t* carry = (int16_t*)(db0 + (CS ? ((max_w + 15) & ~15) : 0));
+  // colour space scores every window against the read as it was sequenced (strand 0): the hit is reversed instead (ref: mapping.c:1302-1303)
+  load_read(reads + (size_t)rd * read_words, read_len, CS ? false : (st != 0), qr, lane);
+  const int ib = CS ? (int)initbp[rd] : 0;
   __syncthreads();
   GmHit* H = hits + (size_t)rs * hcap;
   const uint16_t* P = perm + (size_t)rs * hcap;
@@ -204,7 +240,8 @@ k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
     // ref :1295 -- a window keeps a positive score from an earlier pass (paired mode runs pass 1 twice); unpaired: always <= 0 here
     if (h->score_vector > 0) continue;
     const uint64_t g0 = (uint64_t)ix.contig_off[cn] + goff;
-    load_window(ix.genome, g0, w_len, false, db, lane);
+    if (CS) load_window_cs(ix, cn, goff, w_len, st != 0, ib, db, db0, lane);
+    else load_window(ix.genome, g0, w_len, false, db, lane);
     __syncthreads();
     int score = -1; bool computed = false;
     uint32_t slot = 0;
@@ -221,7 +258,7 @@ k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
       if (found >= 0) { score = (int)(__hip_atomic_load(&SL[found], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32); bypass++; }
     }
     if (score < 0) {
-      score = sw_vector_wave(db, w_len, qr, read_len, sc, carry, lane); computed = true;
+      score = sw_vector_wave_t<CS>(db, db0, w_len, qr, read_len, sc, carry, lane); computed = true;
       calls++; cells += (unsigned long long)w_len * read_len;
       if (sc.hash_filter_calls) {
         if (lane == 0) __hip_atomic_store(&SL[n_comp], (unsigned long long)slot | ((unsigned long long)(uint32_t)score << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -627,11 +664,19 @@ int gm_launch_sw_full_single(const GmScoreDev& sc, const uint32_t* d_genome, lon
 // ---- launchers ---------------------------------------------------------------------------------
 int gm_launch_pass1(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
                     int window_len, int window_overlap_abs, GmHit* d_hits, const uint16_t* d_perm, const uint32_t* d_hit_cnt, int hcap,
-                    unsigned long long* d_slots, unsigned long long* d_stats, hipStream_t stream, const int32_t* d_pair_min, const uint8_t* d_saved) {
+                    unsigned long long* d_slots, unsigned long long* d_stats, hipStream_t stream, const int32_t* d_pair_min, const uint8_t* d_saved,
+                    const uint8_t* d_initbp) {
   if (n_reads == 0) return GM_OK;
-  const size_t lds = ((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 4 + 64;
-  hipLaunchKernelGGL(k_pass1, dim3(n_reads * 2), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
-                     window_len, window_overlap_abs, d_hits, d_perm, d_hit_cnt, hcap, d_slots, d_stats, d_pair_min, d_saved);
+  if (ix.colour) {
+    if (!d_initbp) { gm_set_error("pass 1 in colour space needs the primer letters"); return GM_E_ARG; }
+    const size_t lds = ((read_len + 15) & ~15) + 2 * (size_t)((window_len + 15) & ~15) + (size_t)window_len * 4 + 64;
+    hipLaunchKernelGGL(k_pass1<true>, dim3(n_reads * 2), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
+                       window_len, window_overlap_abs, d_hits, d_perm, d_hit_cnt, hcap, d_slots, d_stats, d_pair_min, d_saved, d_initbp);
+  } else {
+    const size_t lds = ((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 4 + 64;
+    hipLaunchKernelGGL(k_pass1<false>, dim3(n_reads * 2), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
+                       window_len, window_overlap_abs, d_hits, d_perm, d_hit_cnt, hcap, d_slots, d_stats, d_pair_min, d_saved, (const uint8_t*)nullptr);
+  }
   GM_HIP(hipGetLastError());
   return GM_OK;
 }
@@ -689,14 +734,6 @@ int gm_launch_sw_vector_batch(const GmScoreDev& sc, int n, const uint32_t* d_gen
 // =============================================================================================
 // Colour space (S1/S2 seams; the CS read pipeline around them is not built yet)
 // =============================================================================================
-__device__ __forceinline__ int cs_lstocs(int a, int b) {           // ref: common/util.h:182-205 (is_rna = false)
-  return (a > 3 || b > 3) ? 15 : (a ^ b);             // colourmat[a][b] == a ^ b
-}
-__device__ __forceinline__ int cs_cstols(int first_letter, int colour) {   // ref: common/util.h:157-180
-  if (first_letter == 15 || colour < 0 || colour > 3) return 15;
-  return (first_letter % 2 == 0) ? ((4 + first_letter + colour) % 4) : ((4 + first_letter - colour) % 4);
-}
-
 __global__ void __launch_bounds__(GM_WAVE)
 k_sw_vector_batch_cs(GmScoreDev sc, int n, const uint32_t* __restrict__ genome_cs, const uint32_t* __restrict__ genome_ls,
                      const long long* __restrict__ goff, const int* __restrict__ glen, const uint32_t* __restrict__ reads, int read_words,
@@ -922,6 +959,144 @@ k_sw_full_cs_single(GmCsDev P, const uint32_t* __restrict__ genome_ls, long long
     }
     for (int x = 0; x < 12; x++) out[x] = res[x];
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4b in colour space (ref: mapping.c:331-402 with the :375-379 branch): one wave per selected window.  No vector re-score;
+// the window is taken on the strand pass 1 left the hit on (strand-1 windows were reversed there, ref :1302-1303), the read is
+// translated into its four letter sequences (ref: sw-full-cs.c:1182-1197) and aligned by full_sw_cs_wave; lane 0 walks the
+// back pointers (ref :633-937).  Per alignment column the host gets the reference's backtrace byte (ops[0 .. ops_stride/2)) and
+// the two 4-bit codes it prints (ops[ops_stride/2 ..): genome letter << 4 | read letter), enough to rebuild dbalign / qralign
+// (ref :945-1060) without the genome.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GM_WAVE)
+k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__ reads, const uint8_t* __restrict__ initbp, int n_reads, int read_len,
+           int read_words, const GmHit* __restrict__ hits, int hcap, const int32_t* __restrict__ sel,
+           const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work_p, GmFullRes* __restrict__ res, uint8_t* __restrict__ ops, int ops_stride,
+           uint32_t* __restrict__ back_pool, size_t back_words, int max_w, unsigned long long* __restrict__ stats) {
+  extern __shared__ __align__(16) uint8_t sm[];
+  const int lane = threadIdx.x;
+  const int qstride = (read_len + 15) & ~15;
+  uint8_t* rc = sm;                                   // colours of the read
+  uint8_t* qr4 = rc + qstride;                        // its four letter translations
+  uint8_t* db = qr4 + 4 * qstride;
+  int* carry = (int*)(db + ((max_w + 15) & ~15));
+  uint32_t* back = back_pool + (size_t)blockIdx.x * back_words;
+  const uint32_t n_work = *n_work_p;
+  const int half = ops_stride >> 1;
+  unsigned long long fcalls = 0, fcells = 0;
+  int cur_rd = -1;
+  for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+    const uint32_t wk = work[wi];
+    const int rd = (int)(wk >> 6), k = (int)(wk & 63);
+    const int id = sel[(size_t)rd * SEL_MAX + k];
+    const int st = id >> 16, hi = id & 0xFFFF;
+    const size_t slot = ((size_t)rd * 2 + st) * hcap + hi;
+    const GmHit h = hits[slot];
+    __syncthreads();
+    if (rd != cur_rd) {
+      load_read(reads + (size_t)rd * read_words, read_len, false, rc, lane);
+      __syncthreads();
+      if (lane < 4) {                                   // ref: sw-full-cs.c:1182-1197
+        const int ib = (int)initbp[rd];
+        int letter = (lane + ib) % 4;
+        for (int j = 0; j < read_len; j++) {
+          const int base = rc[j];
+          if (base == 15) { qr4[lane * qstride + j] = 15; letter = (lane + ib) % 4; }
+          else { const int l2 = cs_cstols(letter, base); qr4[lane * qstride + j] = (uint8_t)l2; letter = l2; }
+        }
+      }
+      cur_rd = rd;
+    }
+    const int cn = h.cn, w_len = h.w_len;
+    const long long clen = (long long)ix.contig_off[cn + 1] - ix.contig_off[cn];
+    long long g_off = h.g_off; long long ax = h.ax, ay = h.ay; int gen_st = 0;
+    if (st != 0) {                                      // reverse_hit, ref: mapping.c:254-263; anchor_reverse anchors.h:30-34
+      g_off = clen - g_off - w_len;
+      ax = -ax + (w_len - 1) - (h.alen - 1) - (h.awidth - 1);
+      ay = -ay + (read_len - 1) - (h.alen - 1) + (h.awidth - 1);
+      gen_st = 1;
+    }
+    load_window(ix.genome, (uint64_t)ix.contig_off[cn] + h.g_off, w_len, gen_st != 0, db, lane);
+    __syncthreads();
+    const int score_max = (read_len < w_len ? read_len : w_len) * sc.match;
+    const int thresh = thr_of(sc.full_thr_frac, sc.full_abs, score_max);
+    GmFullRes R;
+    R.read_idx = rd; R.st = 0; R.gen_st = (int16_t)gen_st; R.cn = (uint32_t)cn; R.g_off = (uint32_t)g_off; R.w_len = w_len;
+    R.score_vector = h.score_vector; R.score_max = score_max; R.matches = h.matches; R.score_window_gen = h.score_window_gen;
+    R.score = 0; R.read_start = 0; R.rmapped = 0; R.genome_start = 0; R.gmapped = 0;
+    R.n_match = R.n_mismatch = R.n_ins = R.n_del = 0; R.n_ops = 0; R.ops_off = (uint32_t)(wi * (uint32_t)ops_stride);
+    R.sort_idx = 0; R.hit_slot = (uint32_t)slot; R.n_xover = 0;
+    long long nw = ax + ay, sw = ax - ay, ne = sw + 2 * (h.awidth - 1), se = nw + 2 * (h.alen - 1);      // anchor_join + anchor_widen, ref: anchors.c:9-61
+    if ((nw + sw) % 2 != 0) nw--;
+    long long rx = (nw + sw) / 2, ry = nw - rx;
+    if ((ne - sw) % 2 != 0) ne++;
+    int rw = (int)((ne - sw) / 2 + 1);
+    if ((se - nw) % 2 != 0) se++;
+    int rl = (int)((se - nw) / 2 + 1);
+    rx -= P.anchor_width / 2; ry += P.anchor_width / 2; rw += P.anchor_width;
+    fcalls++; fcells += (unsigned long long)w_len * read_len;
+    const CsBest fo = full_sw_cs_wave(db, w_len, qr4, qstride, read_len, P, (gen_st != 0) && sc.tiebreak_rev, rx, ry, rl, rw, back, carry, lane);
+    __syncthreads();
+    __threadfence();
+    if (lane == 0 && fo.score >= 0 && fo.score >= thresh) {     // ref: sw-full-cs.c:1216; do_backtrace :633-937
+      auto code_at = [&](int ci, int cj, int word, int lay) -> int {
+        int x_min, x_max; band_range(rx, ry, rl, rw, w_len, ci, &x_min, &x_max);
+        if (cj < x_min || cj > x_max) return 0;         // a cell outside the band keeps back == 0 in the reference
+        const uint32_t w = __hip_atomic_load(&back[((size_t)ci * w_len + cj) * 3 + word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (int)((w >> (8 * lay)) & 0xFFu);
+      };
+      uint8_t* o = ops + (size_t)R.ops_off; uint8_t* oc = o + half;
+      int i = fo.i, j = fo.j, kk = fo.k;
+      int from = code_at(i, j, 0, kk), fromscore = fo.e_nw;
+      if (fo.e_w > fromscore) { from = code_at(i, j, 2, kk); fromscore = fo.e_w; }
+      if (fo.e_n > fromscore) from = code_at(i, j, 1, kk);
+      int no = 0, rstart = 0, gstart = 0, nm = 0, nmm = 0, nin = 0, ndel = 0, nx = 0;
+      while (i >= 0 && j >= 0 && from != 0) {
+        const int dir = from >> 2, lay = from & 3;
+        uint8_t bt, cc;
+        if (dir == 1 || dir == 2) { ndel++; cc = qr4[kk * qstride + i]; rstart = i--; bt = (uint8_t)(2 + kk); }
+        else if (dir == 3 || dir == 4) { nin++; cc = (uint8_t)(db[j] << 4); gstart = j--; bt = 1; }
+        else {
+          const int qv = qr4[kk * qstride + i];
+          if (db[j] == qv || db[j] == 15 || qv == 15) nm++; else nmm++;
+          cc = (uint8_t)((db[j] << 4) | qv);
+          rstart = i--; gstart = j--; bt = (uint8_t)(6 + kk);
+        }
+        if (kk != lay) { bt |= 0x80; nx++; kk = lay; }
+        if (no < half) { o[no] = bt; oc[no] = cc; }
+        no++;
+        if (i < 0 || j < 0) break;                      // the virtual row / left sentinel: back == 0 in the reference
+        const int word = (dir == 1 || dir == 5) ? 1 : ((dir == 4 || dir == 7) ? 2 : 0);
+        from = code_at(i, j, word, kk);
+      }
+      if (kk != 0 && no > 0) { if (no - 1 < half) o[no - 1] |= 0x80; nx++; }     // ref :929-932
+      const int nov = min(no, half);
+      for (int a2 = 0, b2 = nov - 1; a2 < b2; a2++, b2--) { uint8_t tt = o[a2]; o[a2] = o[b2]; o[b2] = tt; tt = oc[a2]; oc[a2] = oc[b2]; oc[b2] = tt; }
+      R.score = fo.score; R.n_ops = no; R.read_start = rstart; R.genome_start = gstart + (int)g_off;
+      R.gmapped = fo.j - gstart + 1; R.rmapped = fo.i - rstart + 1;
+      R.n_match = nm; R.n_mismatch = nmm; R.n_ins = nin; R.n_del = ndel; R.n_xover = nx;
+    }
+    if (lane == 0) res[wi] = R;
+  }
+  if (lane == 0) { GS_ADD(stats, GS_FULL_CALLS, fcalls); GS_ADD(stats, GS_FULL_CELLS, fcells); }
+}
+
+int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs_params9, const uint32_t* d_reads, const uint8_t* d_initbp, int n_reads,
+                       int read_len, int read_words, int window_len, const GmHit* d_hits, int hcap, const int32_t* d_sel, const uint32_t* d_work,
+                       const uint32_t* d_n_work, GmFullRes* d_res, uint8_t* d_ops, int ops_stride, uint32_t* d_back, size_t back_words, int grid,
+                       unsigned long long* d_stats, hipStream_t stream) {
+  if (n_reads == 0) return GM_OK;
+  GmCsDev P; P.match = cs_params9[0]; P.mismatch = cs_params9[1]; P.xover = cs_params9[2]; P.a_go = cs_params9[3]; P.a_ge = cs_params9[4];
+  P.b_go = cs_params9[5]; P.b_ge = cs_params9[6]; P.anchor_width = cs_params9[7]; P.taboo = cs_params9[8];
+  const size_t lds = 5 * (size_t)((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 48 + 64;
+  if (lds > 160 * 1024) { gm_set_error("colour-space pass 2: window of %d does not fit LDS", window_len); return GM_E_ARG; }
+  static size_t configured = 0;
+  if (lds > 48 * 1024 && lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
+  hipLaunchKernelGGL(k_pass2_cs, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, P, d_reads, d_initbp, n_reads, read_len, read_words, d_hits, hcap, d_sel,
+                     d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_words, window_len, d_stats);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
 }
 
 int gm_launch_sw_vector_batch_cs(const GmScoreDev& sc, int n, const uint32_t* d_genome_cs, const uint32_t* d_genome_ls, const long long* d_goff,

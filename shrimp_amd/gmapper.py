@@ -31,7 +31,8 @@ class Params(C.Structure):   # gm_params_t (include/gmapper_hip.h)
                 ("match_mode", C.c_int), ("num_outputs", C.c_int), ("num_tmp_outputs", C.c_int), ("anchor_width", C.c_int),
                 ("region_bits", C.c_int), ("region_overlap", C.c_int), ("list_cutoff", C.c_uint32),
                 ("hash_filter_calls", C.c_int), ("tiebreak_rev", C.c_int), ("sam_unaligned", C.c_int), ("longest_read_len", C.c_int),
-                ("strata", C.c_int), ("max_alignments", C.c_int)]
+                ("strata", C.c_int), ("max_alignments", C.c_int),
+                ("colour_space", C.c_int), ("crossover_score", C.c_int), ("indel_taboo_len", C.c_int), ("pr_xover", C.c_double)]
 
 
 class MapStats(C.Structure):   # gm_map_stats_t
@@ -73,12 +74,12 @@ class SwFullResults(C.Structure):   # struct gm_sw_full_results == the reference
 
 
 # every entry point include/gmapper_hip.h declares
-EXPORTS = ["gm_last_error", "gm_device_count", "gm_params_default", "gm_index_build", "gm_index_free", "gm_index_list_cutoff",
+EXPORTS = ["gm_last_error", "gm_device_count", "gm_params_default", "gm_params_default_cs", "gm_index_build", "gm_index_free", "gm_index_list_cutoff",
            "gm_index_save", "gm_index_load", "gm_index_bytes", "gm_index_n_slabs", "gm_index_has_buckets", "gm_index_get_list", "gm_index_device_array", "gm_index_meta", "gm_index_alloc_like",
            "sw_vector_setup", "sw_vector", "sw_vector_stats", "sw_vector_cleanup", "gm_sw_vector_batch",
            "sw_full_ls_setup", "sw_full_ls", "sw_full_ls_cleanup",
            "sw_full_cs_setup", "sw_full_cs", "sw_full_cs_cleanup", "gm_sw_vector_batch_cs",
-           "gm_session_create", "gm_session_free", "gm_map_reads", "gm_map_reads_device", "gm_free", "gm_debug_tophits",
+           "gm_session_create", "gm_session_free", "gm_map_reads", "gm_map_reads_cs", "gm_map_reads_device", "gm_free", "gm_debug_tophits",
            "gm_pair_opts_default", "gm_map_pairs",
            "gm_last_lookup_timing"]
 
@@ -97,6 +98,7 @@ def lib():
     L.gm_last_error.restype = C.c_char_p
     L.gm_device_count.restype = C.c_int
     L.gm_params_default.argtypes = [C.POINTER(Params)]
+    L.gm_params_default_cs.argtypes = [C.POINTER(Params)]
     L.gm_index_build.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(u32p), u32p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_char_p), C.POINTER(Params)]
     L.gm_index_free.argtypes = [vp]
     L.gm_index_save.argtypes = [vp, C.c_char_p]
@@ -122,6 +124,7 @@ def lib():
     L.gm_session_create.argtypes = [C.POINTER(vp), vp, C.POINTER(Params), C.c_int]
     L.gm_session_free.argtypes = [vp]
     L.gm_map_reads.argtypes = [vp, C.c_int, C.c_int, u32p, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
+    L.gm_map_reads_cs.argtypes = [vp, C.c_int, C.c_int, u32p, C.POINTER(C.c_uint8), C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_map_reads_device.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_free.argtypes = [vp]
     L.gm_pair_opts_default.argtypes = [C.POINTER(PairOpts)]
@@ -141,6 +144,13 @@ def _check(rc, what):
 def default_params() -> Params:
     p = Params()
     lib().gm_params_default(C.byref(p))
+    return p
+
+
+def default_params_cs() -> Params:
+    """the gmapper-cs binary's defaults (colour space; ref: gmapper.c:1748-1755)"""
+    p = Params()
+    lib().gm_params_default_cs(C.byref(p))
     return p
 
 
@@ -253,6 +263,25 @@ class Session:
         n, Lr = reads_codes.shape
         packed = np.ascontiguousarray(pack_reads(reads_codes))
         return self.map_packed(packed, n, Lr, names)
+
+    def map_reads_cs(self, reads_codes: np.ndarray, names=None) -> bytes:
+        """Colour-space reads: reads_codes [n, 1 + colours] uint8, column 0 the primer letter code (A0 C1 G2 T3), then colours
+        (0-3, 15 = skipped cycle) -- csfasta without the text.  Needs an index / session made with default_params_cs()."""
+        from .synth import pack_reads
+        reads_codes = np.ascontiguousarray(reads_codes, dtype=np.uint8)
+        n, L1 = reads_codes.shape
+        initbp = np.ascontiguousarray(reads_codes[:, 0])
+        packed = np.ascontiguousarray(pack_reads(np.ascontiguousarray(reads_codes[:, 1:])))
+        L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
+        nm = None
+        if names is not None:
+            nm = b"\n".join(x if isinstance(x, bytes) else x.encode() for x in names)
+        _check(L.gm_map_reads_cs(self.h, n, L1 - 1, packed.ctypes.data_as(C.POINTER(C.c_uint32)), initbp.ctypes.data_as(C.POINTER(C.c_uint8)), nm,
+                                 C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_reads_cs")
+        out = C.string_at(sam, sl.value) if sam.value else b""
+        L.gm_free(sam)
+        self.stats = st.as_dict()
+        return out
 
     def map_packed(self, packed: np.ndarray, n: int, read_len: int, names=None) -> bytes:
         L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()

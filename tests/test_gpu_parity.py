@@ -372,3 +372,78 @@ def test_colour_space_kernels_known_answers(gm):
             assert got == want and gdb.encode() == db and gqr.encode() == qr, (got, want, gdb, db, gqr, qr)
         n += 1
     assert n >= 1400
+
+
+CS_GOLDEN = ["cfg4s_50col_2Mbp", "stress_cs_60col_unal"]
+
+
+@pytest.mark.parametrize("name", CS_GOLDEN)
+def test_colour_space_sam_matches_reference_golden(gm, name):
+    """the colour-space read path (colour index, first-colour skip, CS filter on the input strand, sw_full_cs, post_sw,
+    CS SAM fields) -> SAM byte-identical to the reference's gmapper-cs"""
+    contigs, reads, sam = oa.load_golden(name)
+    p = gm.default_params_cs()
+    p.sam_unaligned = 1 if name.endswith("_unal") else 0
+    ix = gm.Index(contigs, params=p)
+    s = gm.Session(ix, params=p, max_batch_reads=1024)
+    got = oa.sam_header(contigs) + s.map_reads_cs(reads)
+    st = s.stats
+    s.close(); ix.close()
+    assert got == sam, (_first_diff(got, sam), st)
+
+
+@pytest.mark.parametrize("env", [{"GM_SLAB_BITS": "18"}, {"GM_NO_BUCKETS": "1"}, {"GM_SLAB_BITS": "18", "GM_K1_V2": "1"}, {"GM_SCAP": "256", "GM_SCAP2": "64"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_colour_space_kernel_variants(gm, env):
+    """every lookup kernel skips the first colour and reads strand 1 the colour-space way"""
+    contigs, reads, sam = oa.load_golden("cfg4s_50col_2Mbp")
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        p = gm.default_params_cs()
+        ix = gm.Index(contigs, params=p)
+        s = gm.Session(ix, params=p, max_batch_reads=4096)
+        got = oa.sam_header(contigs) + s.map_reads_cs(reads)
+        st = s.stats
+        s.close(); ix.close()
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    assert got == sam, (_first_diff(got, sam), st)
+
+
+def test_colour_space_longer_reads_vs_oracle(gm, oracle_lib):
+    """100-colour reads (two row stripes in sw_full_cs, windows of 140) with skipped cycles, against the CPU restatement"""
+    from shrimp_amd import synth
+    contigs = synth.make_genome([300_000, 150_000], 21)
+    reads, _ = synth.make_cs_reads(contigs, 1500, 100, 22, p_col=0.05, p_dot=0.003)
+    o = oa.Session(contigs, opts="colour=1"); o.set(True, True)
+    want = o.map_sam(reads, nthreads=4); o.close()
+    p = gm.default_params_cs(); p.sam_unaligned = 1
+    ix = gm.Index(contigs, params=p)
+    s = gm.Session(ix, params=p, max_batch_reads=512)
+    got = s.map_reads_cs(reads)
+    st = s.stats
+    s.close(); ix.close()
+    assert got == want, (_first_diff(got, want), st)
+    assert st["reads_matched"] > 1300
+
+
+def test_colour_space_api_misuse_is_refused(gm):
+    from shrimp_amd import synth
+    contigs = synth.make_genome([50_000], 3)
+    ix = gm.Index(contigs); s = gm.Session(ix)
+    with pytest.raises(gm.GmError):
+        s.map_reads_cs(np.zeros((4, 51), dtype=np.uint8))        # letter-space session
+    s.close(); ix.close()
+    p = gm.default_params_cs()
+    ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p)
+    with pytest.raises(gm.GmError):
+        s.map_reads(np.zeros((4, 50), dtype=np.uint8))           # colour-space session needs primer letters
+    bad = np.zeros((4, 51), dtype=np.uint8); bad[2, 0] = 15
+    with pytest.raises(gm.GmError):
+        s.map_reads_cs(bad)                                      # primer letter must be A/C/G/T
+    with pytest.raises(gm.GmError):
+        gm.Session(ix, params=gm.default_params())               # session / index mode mismatch
+    s.close(); ix.close()
