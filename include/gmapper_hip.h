@@ -97,7 +97,8 @@ int      gm_index_has_buckets(const gm_index_t *ix);   /* 1 when the 64-byte buc
 int gm_index_get_list(const gm_index_t *ix, int sn, uint32_t mapidx, uint32_t *len, uint32_t *positions, uint32_t cap);
 /* raw device pointers + sizes of the resident arrays, for the single RCCL broadcast at start-up
  * (SURVEY.md section 8(e)); kind: 0 genome, 1+3*sn directory of seed sn, 2+3*sn positions of seed sn,
- * 3+3*sn the 64-byte buckets of seed sn (bytes == 0 when that layout is not resident) */
+ * 3+3*sn the 64-byte buckets of seed sn (bytes == 0 when that layout is not resident), 1+3*n_seeds the colour translation
+ * of the genome (bytes == 0 in letter space); larger kinds return GM_E_ARG */
 int gm_index_device_array(const gm_index_t *ix, int kind, void **dev_ptr, uint64_t *bytes);
 /* allocate an index with the same shape (from the metadata blob of a built index) so that a
  * non-root rank can receive the arrays; meta is host memory */

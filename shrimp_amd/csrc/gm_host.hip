@@ -176,7 +176,7 @@ extern "C" uint32_t gm_index_list_cutoff(const gm_index_t* ix) { return ix->list
 extern "C" int gm_index_n_slabs(const gm_index_t* ix) { return ix->n_slabs; }
 extern "C" int gm_index_has_buckets(const gm_index_t* ix) { return ix->seeds[0].d_bkt != nullptr; }
 extern "C" uint64_t gm_index_bytes(const gm_index_t* ix) {
-  uint64_t b = ix->genome_words * 4;
+  uint64_t b = ix->genome_words * 4 * (ix->d_genome_cs ? 2 : 1);
   for (int i = 0; i < ix->n_seeds; i++) b += (ix->seeds[i].dir_words + (uint64_t)ix->seeds[i].n_pos + (ix->seeds[i].d_bkt ? (16ull << (2 * ix->seeds[i].weight)) : 0ull)) * 4;
   return b;
 }
@@ -193,7 +193,8 @@ extern "C" int gm_index_get_list(const gm_index_t* ix, int sn, uint32_t mapidx, 
 }
 extern "C" int gm_index_device_array(const gm_index_t* ix, int kind, void** dev_ptr, uint64_t* bytes) {
   if (kind == 0) { *dev_ptr = ix->d_genome; *bytes = ix->genome_words * 4; return GM_OK; }
-  const int sn = (kind - 1) / 3, what = (kind - 1) % 3; if (sn < 0 || sn >= ix->n_seeds) return GM_E_ARG;
+  if (kind == 1 + 3 * ix->n_seeds) { *dev_ptr = ix->d_genome_cs; *bytes = ix->d_genome_cs ? ix->genome_words * 4 : 0; return GM_OK; }   // colour translation of the genome
+  const int sn = (kind - 1) / 3, what = (kind - 1) % 3; if (kind < 0 || sn < 0 || sn >= ix->n_seeds) return GM_E_ARG;
   if (what == 0) { *dev_ptr = ix->seeds[sn].d_dir; *bytes = (ix->seeds[sn].dir_words + 16) * 4; }
   else if (what == 1) { *dev_ptr = ix->seeds[sn].d_pos; *bytes = ((uint64_t)ix->seeds[sn].n_pos + 64) * 4; }
   else { *dev_ptr = ix->seeds[sn].d_bkt; *bytes = ix->seeds[sn].d_bkt ? (16ull << (2 * ix->seeds[sn].weight)) * 4 : 0; }
@@ -231,6 +232,7 @@ extern "C" int gm_index_alloc_like(gm_index_t** out, int device, const void* met
   for (int c = 0; c < h.n_contigs; c++) { ix->names.push_back(p); p += strlen(p) + 1; }
   for (int i = 0; i < h.n_seeds; i++) { if (add_seed(ix, p) != GM_OK) { delete ix; return GM_E_ARG; } p += strlen(p) + 1; }
   GM_HIP(hipMalloc(&ix->d_genome, ix->genome_words * 4));
+  if (ix->params.colour_space) GM_HIP(hipMalloc(&ix->d_genome_cs, ix->genome_words * 4));
   GM_HIP(hipMalloc(&ix->d_contig_off, (size_t)(h.n_contigs + 1) * 4));
   GM_HIP(hipMemcpy(ix->d_contig_off, ix->contig_off.data(), (size_t)(h.n_contigs + 1) * 4, hipMemcpyHostToDevice));
   for (int i = 0; i < h.n_seeds; i++) {

@@ -12,6 +12,13 @@ GOLDEN = ["cfg1_36bp_1Mbp", "cfg2s_100bp_2Mbp", "stress_60bp", "stress_100bp_una
 
 @pytest.fixture(scope="module")
 def gm():
+    # torch's wheel carries its own HIP runtime: it must initialise before libgmapper_hip.so's (the order bench.py uses),
+    # or torch finds no device later in the same process (test_index_replication_path_of_the_multi_gpu_start_up)
+    try:
+        import torch
+        torch.cuda.init()
+    except Exception:
+        pass
     from shrimp_amd import gmapper
     if gmapper.lib().gm_device_count() < 1:
         pytest.fail("no HIP device: the product path has no CPU fallback")
@@ -168,9 +175,9 @@ def test_option_sets_match_reference_golden(gm, tag):
     assert got == want, (_first_diff(got, want), st)
 
 
-def _idxfix():
+def _idxfix(which="idxfix"):
     import gzip, os
-    d = os.path.join(oa.ROOT, "tests", "golden", "idxfix")
+    d = os.path.join(oa.ROOT, "tests", "golden", which)
     z = np.load(os.path.join(d, "inputs.npz"))
     with gzip.open(os.path.join(d, "from_index.sam.gz"), "rb") as f:
         sam = f.read()
@@ -317,22 +324,24 @@ def test_index_replication_path_of_the_multi_gpu_start_up(gm):
     import torch.distributed as dist
     from shrimp_amd import parallel
     dev = torch.device("cuda", 0)
-    for name, env in (("cfg2s_100bp_2Mbp", {}), ("stress_60bp", {"GM_SLAB_BITS": "18"})):      # bucket layout / multi-slab layout
+    for name, env in (("cfg2s_100bp_2Mbp", {}), ("stress_60bp", {"GM_SLAB_BITS": "18"}), ("cfg4s_50col_2Mbp", {})):      # bucket layout / multi-slab layout / colour space
         old = {k: os.environ.get(k) for k in env}; os.environ.update(env)
         try:
             contigs, reads, sam = oa.load_golden(name)
-            src = gm.Index(contigs)
+            cs = "col" in name
+            par = gm.default_params_cs() if cs else gm.default_params()
+            src = gm.Index(contigs, params=par)
             rep = gm.Index.alloc_like(src.meta(), device=0)
             a, b = src.device_arrays(), rep.device_arrays()
-            assert [n for _, n in a] == [n for _, n in b] and len(a) == 1 + 3 * 3
+            assert [n for _, n in a] == [n for _, n in b] and len(a) == 2 + 3 * 3 and (a[-1][1] > 0) == cs      # last = colour translation of the genome
             for (pa, na), (pb, nb) in zip(a, b):
                 if not na: continue
                 ta = torch.as_tensor(parallel._DevArray(pa, na), device=dev); tb = torch.as_tensor(parallel._DevArray(pb, nb), device=dev)
                 assert ta.data_ptr() == pa and tb.data_ptr() == pb          # views, not copies
                 tb.copy_(ta)
             torch.cuda.synchronize()
-            s = gm.Session(rep, max_batch_reads=4096)
-            got = oa.sam_header(contigs) + s.map_reads(reads)
+            s = gm.Session(rep, params=par, max_batch_reads=4096)
+            got = oa.sam_header(contigs) + (s.map_reads_cs(reads) if cs else s.map_reads(reads))
             s.close(); rep.close()
             assert got == sam, _first_diff(got, sam)
             if not dist.is_initialized():
@@ -447,3 +456,24 @@ def test_colour_space_api_misuse_is_refused(gm):
     with pytest.raises(gm.GmError):
         gm.Session(ix, params=gm.default_params())               # session / index mode mismatch
     s.close(); ix.close()
+
+
+def test_colour_space_index_files_of_the_reference(gm, tmp_path):
+    """gmapper-cs -S files: loaded here they give the SAM of the reference's -L run; saved here they are the same bytes"""
+    import gzip
+    d, contigs, names, reads, seeds, sam = _idxfix("idxfix_cs")
+    p = gm.default_params_cs()
+    ix = gm.Index.load(os.path.join(d, "idx"), params=p)
+    s = gm.Session(ix, params=p, max_batch_reads=1024)
+    got = oa.sam_header(contigs, names) + s.map_reads_cs(reads)
+    s.close(); ix.close()
+    assert got == sam, _first_diff(got, sam)
+    ix = gm.Index(contigs, names=names, seeds=seeds, params=p)
+    ix.save(str(tmp_path / "mine"))
+    ix.close()
+    for suffix in (".genome", ".seed.0", ".seed.1"):
+        with gzip.open(os.path.join(d, "idx" + suffix), "rb") as f: want = f.read()
+        with gzip.open(str(tmp_path / ("mine" + suffix)), "rb") as f: got = f.read()
+        assert got == want, (suffix, len(got), len(want))
+    with pytest.raises(gm.GmError):
+        gm.Index.load(os.path.join(d, "idx"))               # a colour-space index is refused by a letter-space load

@@ -138,3 +138,17 @@ def test_oracle_colour_space_sam_matches_reference(name, oracle_lib):
     got = oa.sam_header(contigs) + s.map_sam(reads, nthreads=4)
     s.close()
     assert got == sam, "oracle colour-space SAM differs from the reference's for %s" % name
+
+
+def test_oracle_colour_space_on_the_reference_index_fixture(oracle_lib):
+    """custom seeds in colour space: the oracle's SAM equals what gmapper-cs printed from its own -S index files"""
+    import gzip, os
+    d = os.path.join(oa.ROOT, "tests", "golden", "idxfix_cs")
+    z = np.load(os.path.join(d, "inputs.npz"))
+    with gzip.open(os.path.join(d, "from_index.sam.gz"), "rb") as f:
+        sam = f.read()
+    contigs = [z["contig0"], z["contig1"]]; names = [bytes(x) for x in z["contig_names"]]
+    s = oa.Session(contigs, contig_names=names, opts="colour=1;seeds=%s" % str(z["seeds"]))
+    got = oa.sam_header(contigs, names) + s.map_sam(z["reads"], nthreads=2)
+    s.close()
+    assert got == sam

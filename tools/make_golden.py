@@ -225,6 +225,27 @@ def cs_cases():
     sg = stress_genome()
     reads, _ = synth.make_cs_reads([c for c in sg if len(c) > 200], 2000, 60, 5, p_col=0.03, p_dot=0.004)
     run_cs_case("stress_cs_60col_unal", sg, reads, extra=("--sam-unaligned",))
+    # the reference's own colour-space index files (-S) for a tiny genome + the SAM gmapper-cs produces from them (-L)
+    import shutil
+    rng = np.random.default_rng(6)
+    c1 = rng.integers(0, 4, 12000, dtype=np.uint8); c1[3000:3040] = 15; c1[7000:7003] = [5, 6, 14]
+    c2 = rng.integers(0, 4, 7003, dtype=np.uint8)
+    contigs = [c1, c2]; names = [b"chrA", b"chrB"]
+    reads, _ = synth.make_cs_reads(contigs, 400, 40, 92)
+    seeds = "11110111,1101011011"
+    refcs = os.path.join(ROOT, "oracle", "_ref", "gmapper-cs")
+    d = os.path.join(OUT, "idxfix_cs"); shutil.rmtree(d, ignore_errors=True); os.makedirs(d)
+    with tempfile.TemporaryDirectory() as t:
+        g = os.path.join(t, "g.fa"); r = os.path.join(t, "r.csfasta")
+        write_fa_codes(g, names, contigs)
+        synth.write_csfasta_reads(r, reads)
+        subprocess.run([refcs, "-s", seeds, "-S", os.path.join(d, "idx"), g], capture_output=True, check=True)
+        p = subprocess.run([refcs, "-N", "2", "-L", os.path.join(d, "idx"), r], capture_output=True, check=True)
+        body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+    np.savez_compressed(os.path.join(d, "inputs.npz"), contig0=c1, contig1=c2, reads=reads, seeds=np.array(seeds), contig_names=np.array(names))
+    with gzip.open(os.path.join(d, "from_index.sam.gz"), "wb", compresslevel=9) as f:
+        f.write(body)
+    print("idxfix_cs: %d SAM records from gmapper-cs -L; files:" % sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@")), sorted(os.listdir(d)))
 
 
 def main():
