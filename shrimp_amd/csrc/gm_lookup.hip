@@ -56,6 +56,7 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
          int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
          uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap,
          const uint32_t* __restrict__ redo_list, const uint64_t* __restrict__ redo_off,
+         const uint32_t* __restrict__ fb_list, const uint32_t* __restrict__ fb_cnt,     // list mode: block b runs read-strand fb_list[b] (b < *fb_cnt) as in normal mode
          unsigned long long* __restrict__ stats, int ablate, uint32_t* __restrict__ surv_seg) {
   extern __shared__ __align__(16) uint32_t smem[];
   __shared__ K1Smem sh;
@@ -64,7 +65,8 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
   // normal mode: block b = read-strand b, output slot surv[b*scap_all .. +scap_all).
   // redo mode (redo_list != 0): block b re-runs heavy read-strand redo_list[b] into surv[redo_off[b] .. redo_off[b+1])
   const bool redo = (redo_list != nullptr);
-  const int rs = redo ? (int)redo_list[blockIdx.x] : (int)blockIdx.x;
+  if (fb_cnt && blockIdx.x >= *fb_cnt) return;
+  const int rs = redo ? (int)redo_list[blockIdx.x] : (fb_cnt ? (int)fb_list[blockIdx.x] : (int)blockIdx.x);
   const int rd = rs >> 1, st = rs & 1;
   uint64_t* out = redo ? (surv + redo_off[blockIdx.x]) : (surv + (size_t)rs * scap_all);
   const uint32_t scap = redo ? (uint32_t)(redo_off[blockIdx.x + 1] - redo_off[blockIdx.x]) : (uint32_t)scap_all;
@@ -311,6 +313,7 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
     }
   }
   // per-wave reduction of the work counters
+  if (fb_cnt) return;                    // the work counters were taken by the first run
   for (int d = GM_WAVE / 2; d > 0; d >>= 1) { my_lookups += __shfl_down(my_lookups, d); my_entries += __shfl_down(my_entries, d); }
   if ((tid & (GM_WAVE - 1)) == 0) { GS_ADD(stats, GS_LOOKUPS, my_lookups); GS_ADD(stats, GS_ENTRIES, my_entries); }
 }
@@ -683,6 +686,267 @@ k_lookup_v3(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
   if ((tid & (GM_WAVE - 1)) == 0) { GS_ADD(stats, GS_LOOKUPS, my_lookups); GS_ADD(stats, GS_ENTRIES, my_entries); }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1 v4 (large genomes, several slabs): hashed pre-count, exact count on the few candidates.
+//
+// The slab sweep above visits every list once per slab, so each visit handles a ~30-entry slice and most of its
+// instructions are bookkeeping (rocprofv3: ~1.4 VALU wave-instructions per list entry and pass; VALU-issue bound).
+// Here the region counters of the WHOLE genome are folded into one LDS table of 2^tab_bits 2-bit counters
+// (counter = region mod 2^tab_bits).  Pass A streams every list once, whole, 32 entries per 8-lane group and
+// instruction, and counts into the folded table; pass B streams them again and keeps the entries whose folded
+// counter (or that of region-1 for an entry in the overlap strip) reached 2: the *candidates*.  A folded counter is
+// >= the true counter of each region mapped to it, so every entry that marks a region with true count >= 2 is a
+// candidate; hence for a candidate's regions the exact count taken over candidates alone equals the true count
+// whenever that is >= 2, and stays < 2 otherwise.  Pass C therefore redoes the exact count per slab on the
+// candidates only (a flat array, one entry per lane: ~10 % of the entries), with the reference's rule
+// (ref: mapping.c:521-533,733-742), and emits the survivors slab by slab as the kernels above do.
+// Slab borders: an entry of a slab's last region is also fed (mark only) to the next slab's list, whose bitmap has
+// one extra counter below its first region; an overlap-strip entry of a slab's first region is fed (mark only) to
+// the previous slab.  Workgroups are persistent (one per CU, looping over read-strands) so that each owns one
+// candidate scratch in global memory (L2-resident).  A read-strand whose candidates do not fit its scratch bins is
+// handed to the slab-sweep kernel in list mode (rare: repeats).
+// ---------------------------------------------------------------------------------------------
+#define K4Q 4                // windows per lane group and pipeline stage
+#define K4_MO_SELF 0x8000u   // candidate copy in the NEXT slab's bin: marks its own region only (counter 0 there)
+#define K4_MO_PREV 0x4000u   // candidate copy in the PREVIOUS slab's bin: marks region - 1 only (that slab's last region)
+
+__global__ void __launch_bounds__(1024)
+k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
+            int NL, int tab_bits, int cbits, int SC, int wcap, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
+            uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap, unsigned long long* __restrict__ stats,
+            uint32_t* __restrict__ surv_seg, uint64_t* __restrict__ scratch, int bin_cap, uint32_t* __restrict__ fb_list, uint32_t* __restrict__ fb_cnt,
+            int fb_cap, int ablate) {
+  extern __shared__ __align__(16) uint32_t smem[];
+  __shared__ uint32_t n_surv, n_lists, n_win, overflow;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & (GM_WAVE - 1);
+  const int S = ix.n_slabs, rb = ix.region_bits;
+  const uint32_t rmask = (1u << rb) - 1u, ovl = (uint32_t)ix.region_overlap;
+  const uint32_t R = 1u << (cbits - rb);                     // regions per exact-count bin (a bin = 2^cbits positions, cbits <= slab_bits)
+  const uint32_t tmask = (1u << tab_bits) - 1u;
+  // LDS: codes | rec[NL] (4 words: list offset lo/hi from seed 0's array, length, y << 16 | seed) | wbase[NL + 1] | bin_cnt[SC] | wmap[wcap] (u16) | table
+  uint8_t* codes = (uint8_t*)smem;
+  const int code_words = (read_len + 3) / 4;
+  uint32_t* rec = smem + ((code_words + 3) & ~3);
+  uint32_t* wbase = rec + 4 * NL;
+  uint32_t* bin_cnt = wbase + NL + 1;
+  uint16_t* wmap = (uint16_t*)(bin_cnt + SC);
+  uint32_t* tab = smem + ((((code_words + 3) & ~3) + 4 * NL + NL + 1 + SC + (wcap + 1) / 2 + 3) & ~3);
+  const int tab_words = 1 << (tab_bits - 4);
+  const uint32_t* __restrict__ pos0 = ix.seed[0].pos;
+  uint64_t* my_scratch = scratch + (size_t)blockIdx.x * SC * bin_cap;
+  const int ng = nthr / 8, g = tid / 8, gl4 = (tid & 7) * 4;
+  unsigned long long my_lookups = 0, my_entries = 0;
+
+  for (int rs = blockIdx.x; rs < 2 * n_reads; rs += gridDim.x) {
+    const int rd = rs >> 1, st = rs & 1;
+    uint64_t* out = surv + (size_t)rs * scap_all;
+    const uint32_t scap = (uint32_t)scap_all;
+    __syncthreads();                                         // the previous read-strand is done with the LDS
+    const uint32_t* rw = reads + (size_t)rd * read_words;
+    for (int i = tid; i < read_len; i += nthr) codes[i] = (uint8_t)gm_read_code(rw, read_len, st, ix.colour, i);
+    { uint4* t4 = (uint4*)tab; for (int w = tid; w < (tab_words >> 2); w += nthr) t4[w] = make_uint4(0, 0, 0, 0); }
+    for (int c = tid; c < SC; c += nthr) bin_cnt[c] = 0;
+    if (tid == 0) { n_surv = 0; n_lists = 0; overflow = 0; }
+    __syncthreads();
+    // ---- map indexes and whole-list bounds (ref: mapping.c:53-66, KMER_TO_MAPIDX gmapper.h:349-368) ----
+    for (int off = tid; off < NL; off += nthr) {
+      const int sn = off / max_n_kmers, i = off - sn * max_n_kmers;
+      const int span = ix.seed[sn].span;
+      if (i < ix.colour || i + span > read_len) continue;
+      const uint64_t mask = ix.seed[sn].mask;
+      uint32_t mapidx = 0;
+      for (int t = 0; t < span; t++)
+        if ((mask >> t) & 1) mapidx = (mapidx << 2) | (codes[i + span - 1 - t] & 3u);
+      const uint32_t* dir = ix.seed[sn].dir + (size_t)mapidx * (uint32_t)S;
+      my_lookups++;
+      const uint32_t b = dir[0], e = dir[S];
+      if (e == b || e - b > ix.list_cutoff) continue;        // ref: mapping.c:497 (longer lists are skipped, not deleted)
+      my_entries += (e - b);
+      const uint32_t j = atomicAdd(&n_lists, 1u);
+      const uint64_t ptr = (uint64_t)((ix.seed[sn].pos + b) - pos0);
+      rec[4 * j] = (uint32_t)ptr; rec[4 * j + 1] = (uint32_t)(ptr >> 32); rec[4 * j + 2] = e - b; rec[4 * j + 3] = ((uint32_t)i << 16) | (uint32_t)sn;
+    }
+    __syncthreads();
+    const int nl = (int)n_lists;
+    // ---- windows of 32 entries: prefix over the lists, and the window -> list map of the first wcap windows (wave 0) ----
+    if (tid < GM_WAVE) {
+      const int per = (nl + GM_WAVE - 1) / GM_WAVE;
+      const int a0 = min(nl, lane * per), a1 = min(nl, a0 + per);
+      uint32_t sum = 0;
+      for (int a = a0; a < a1; a++) sum += (rec[4 * a + 2] + 31u) >> 5;
+      uint32_t incl = sum;
+      for (int dd = 1; dd < GM_WAVE; dd <<= 1) { const uint32_t o = __shfl_up(incl, dd); if (lane >= dd) incl += o; }
+      uint32_t run = incl - sum;
+      for (int a = a0; a < a1; a++) {
+        wbase[a] = run;
+        const uint32_t c = (rec[4 * a + 2] + 31u) >> 5;
+        for (uint32_t k = 0; k < c && run + k < (uint32_t)wcap; k++) wmap[run + k] = (uint16_t)a;
+        run += c;
+      }
+      if (lane == GM_WAVE - 1) { wbase[nl] = incl; n_win = incl; }
+    }
+    __syncthreads();
+    const int nwin = (int)n_win;
+    // window t -> list j, first entry e0 of this lane, number of this lane's valid entries (0..4)
+    auto locate = [&](const int t, int& j, uint32_t& e0) -> int {
+      if (t >= nwin) return 0;
+      if (t < wcap) j = (int)wmap[t];
+      else { int lo = 0, hi = nl; while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (wbase[m] <= (uint32_t)t) lo = m; else hi = m; } j = lo; }
+      e0 = ((uint32_t)t - wbase[j]) * 32u + (uint32_t)gl4;
+      const uint32_t len = rec[4 * j + 2];
+      return e0 >= len ? 0 : (int)min(4u, len - e0);
+    };
+    auto load_window = [&](const int j, const uint32_t e0) -> k1_u32x4 {
+      return *(const k1_u32x4*)(pos0 + (long long)(((uint64_t)rec[4 * j + 1] << 32) | rec[4 * j]) + e0);
+    };
+    // Both passes are software pipelines: the loads of the next K4Q windows are in flight while this group's current ones are
+    // processed (one workgroup per CU: without it the memory system idles during every processing stretch).
+    struct Win { int j, nv; uint32_t p[4]; };
+    auto fetch = [&](const int t, Win& w) {
+      uint32_t e0 = 0; w.j = 0;
+      w.nv = locate(t, w.j, e0);
+      k1_u32x4 v = {0, 0, 0, 0};
+      if (w.nv) v = load_window(w.j, e0);
+      w.p[0] = v.x; w.p[1] = v.y; w.p[2] = v.z; w.p[3] = v.w;
+    };
+    // ---- pass A: folded counts ----
+    if (!(ablate & 8)) {
+      Win cur[K4Q], nxt[K4Q];
+#pragma unroll
+      for (int q = 0; q < K4Q; q++) fetch(q * ng + g, cur[q]);
+      for (int t0 = 0; t0 < nwin; t0 += K4Q * ng) {
+#pragma unroll
+        for (int q = 0; q < K4Q; q++) fetch(t0 + (K4Q + q) * ng + g, nxt[q]);
+#pragma unroll
+        for (int q = 0; q < K4Q; q++) {
+          const Win& w = cur[q];
+          if (ablate & 2) { if ((w.p[0] ^ w.p[1] ^ w.p[2] ^ w.p[3]) == 0x12345u) tab[0] = 1; continue; }   // loads only
+          uint32_t old[4], h[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { h[u] = (w.p[u] >> rb) & tmask; old[u] = 0; if (u < w.nv) old[u] = atomicOr(&tab[h[u] >> 4], 1u << ((h[u] & 15u) * 2u)); }
+#pragma unroll
+          for (int u = 0; u < 4; u++) if (u < w.nv && ((old[u] >> ((h[u] & 15u) * 2u)) & 3u) == 1u) atomicOr(&tab[h[u] >> 4], 2u << ((h[u] & 15u) * 2u));
+#pragma unroll
+          for (int u = 0; u < 4; u++)                            // overlap strip (ref: mapping.c:521-533): 2.4 % of the entries
+            if (u < w.nv && (w.p[u] & rmask) < ovl && (w.p[u] >> rb) > 0) k1_mark(tab, ((w.p[u] >> rb) - 1u) & tmask);
+        }
+#pragma unroll
+        for (int q = 0; q < K4Q; q++) cur[q] = nxt[q];
+      }
+    }
+    __syncthreads();
+    // ---- pass B: candidates = entries whose folded counter reached 2, binned by position ----
+    if (!(ablate & 1)) {
+      Win cur[K4Q], nxt[K4Q];
+#pragma unroll
+      for (int q = 0; q < K4Q; q++) fetch(q * ng + g, cur[q]);
+      for (int t0 = 0; t0 < nwin; t0 += K4Q * ng) {
+#pragma unroll
+        for (int q = 0; q < K4Q; q++) fetch(t0 + (K4Q + q) * ng + g, nxt[q]);
+#pragma unroll
+        for (int q = 0; q < K4Q; q++) {
+          const Win& w = cur[q];
+          uint32_t hit = 0;
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (u >= w.nv) continue;
+            const uint32_t r = w.p[u] >> rb;
+            if (k1_has2(tab, r & tmask)) hit |= 1u << u;
+            else if ((w.p[u] & rmask) < ovl && r > 0 && k1_has2(tab, (r - 1u) & tmask)) hit |= 1u << u;
+          }
+          if (hit && (ablate & 16)) { if (hit == 0x55u) tab[1] = 1; hit = 0; }
+          if (hit) {
+            const uint32_t ysn = rec[4 * w.j + 3];
+            while (hit) {
+              const int u = __builtin_ctz(hit); hit &= hit - 1u;
+              const uint32_t p = u == 0 ? w.p[0] : (u == 1 ? w.p[1] : (u == 2 ? w.p[2] : w.p[3]));
+              const uint32_t r = p >> rb, sl = p >> cbits, rloc = r & (R - 1u);
+              const uint64_t key = ((uint64_t)p << 32) | ysn;
+              uint32_t idx = atomicAdd(&bin_cnt[sl], 1u);
+              if (idx < (uint32_t)bin_cap) my_scratch[(size_t)sl * bin_cap + idx] = key; else overflow = 1u;
+              if (rloc == R - 1u && (int)sl + 1 < SC) {          // also counts for the next bin's counter 0
+                idx = atomicAdd(&bin_cnt[sl + 1], 1u);
+                if (idx < (uint32_t)bin_cap) my_scratch[(size_t)(sl + 1) * bin_cap + idx] = key | K4_MO_SELF; else overflow = 1u;
+              }
+              if (rloc == 0u && sl > 0 && (p & rmask) < ovl) {   // its strip mark belongs to the previous bin's last region
+                idx = atomicAdd(&bin_cnt[sl - 1], 1u);
+                if (idx < (uint32_t)bin_cap) my_scratch[(size_t)(sl - 1) * bin_cap + idx] = key | K4_MO_PREV; else overflow = 1u;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < K4Q; q++) cur[q] = nxt[q];
+      }
+    }
+    __syncthreads();
+    if (overflow) {                                            // bins too small for this read-strand: the slab-sweep kernel redoes it
+      if (tid == 0) {
+        const uint32_t f = atomicAdd(fb_cnt, 1u);
+        if (f < (uint32_t)fb_cap) fb_list[f] = (uint32_t)rs; else GS_ADD(stats, GS_OVERFLOW_SURV, 1ull);
+      }
+      continue;
+    }
+    // ---- pass C: exact counts per slab over the candidates (local counter = region - first region of the slab + 1) ----
+    if (ablate & 4) continue;
+    __threadfence_block();
+    { uint4* t4 = (uint4*)tab; for (int w = tid; w < (tab_words >> 2); w += nthr) t4[w] = make_uint4(0, 0, 0, 0); }
+    __syncthreads();
+    const int per_slab = 1 << (ix.slab_bits - cbits);        // bins per index slab
+    for (int s = 0; s < SC; s++) {
+      const int nc = (int)bin_cnt[s];
+      const uint64_t* cand = my_scratch + (size_t)s * bin_cap;
+      const uint32_t rbase = (uint32_t)s * R;
+      for (int i = tid; i < nc; i += nthr) {
+        const uint64_t key = cand[i]; const uint32_t p = (uint32_t)(key >> 32), fl = (uint32_t)key;
+        const uint32_t loc = (p >> rb) - rbase + 1u;             // MO_SELF copy: 0; MO_PREV copy: R + 1
+        if (fl & K4_MO_PREV) k1_mark(tab, loc - 1u);
+        else {
+          k1_mark(tab, loc);
+          if (!(fl & K4_MO_SELF) && (p & rmask) < ovl && (p >> rb) > 0) k1_mark(tab, loc - 1u);
+        }
+      }
+      __syncthreads();
+      for (int i0 = 0; i0 < nc; i0 += nthr) {
+        const int i = i0 + tid;
+        bool hit = false; uint64_t key = 0;
+        if (i < nc) {
+          key = cand[i]; const uint32_t p = (uint32_t)(key >> 32), fl = (uint32_t)key;
+          if (!(fl & (K4_MO_SELF | K4_MO_PREV))) {
+            const uint32_t loc = (p >> rb) - rbase + 1u;
+            hit = k1_has2(tab, loc) || ((p & rmask) < ovl && (p >> rb) > 0 && k1_has2(tab, loc - 1u));
+          }
+        }
+        const unsigned long long bal = __ballot(hit);
+        if (bal) {
+          uint32_t basev = 0;
+          if (lane == 0) basev = atomicAdd(&n_surv, (uint32_t)__popcll(bal));
+          basev = __shfl(basev, 0);
+          if (hit) { const uint32_t slot = basev + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull)); if (slot < scap) out[slot] = key; }
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < nc; i += nthr) {                   // un-mark: zero the words this slab touched
+        const uint32_t loc = ((uint32_t)(cand[i] >> 32) >> rb) - rbase + 1u;
+        tab[loc >> 4] = 0; if (loc) tab[(loc - 1u) >> 4] = 0;
+      }
+      if (surv_seg && tid == 0 && (((s + 1) % per_slab) == 0 || s + 1 == SC)) surv_seg[(size_t)rs * (S + 1) + s / per_slab + 1] = n_surv;   // survivors come out slab by slab
+      __syncthreads();
+    }
+    if (tid == 0) {
+      if (surv_seg) surv_seg[(size_t)rs * (S + 1)] = 0;
+      surv_cnt[rs] = n_surv;
+      GS_ADD(stats, GS_SURVIVORS, (unsigned long long)n_surv);
+      if (n_surv > scap) {
+        const uint32_t hs = atomicAdd(heavy_cnt, 1u);
+        if (hs < (uint32_t)heavy_cap) heavy_list[hs] = (uint32_t)rs; else GS_ADD(stats, GS_OVERFLOW_SURV, 1ull);
+      }
+    }
+  }
+  for (int d = GM_WAVE / 2; d > 0; d >>= 1) { my_lookups += __shfl_down(my_lookups, d); my_entries += __shfl_down(my_entries, d); }
+  if ((tid & (GM_WAVE - 1)) == 0) { GS_ADD(stats, GS_LOOKUPS, my_lookups); GS_ADD(stats, GS_ENTRIES, my_entries); }
+}
+
 static void k1_geometry(const GmIndexDev& ix, int read_len, int* max_n_kmers, int* NL, int* bm_words, size_t* lds) {
   *max_n_kmers = read_len - ix.min_seed_span + 1;
   if (*max_n_kmers < 0) *max_n_kmers = 0;
@@ -692,6 +956,55 @@ static void k1_geometry(const GmIndexDev& ix, int read_len, int* max_n_kmers, in
   *bm_words = (int)((regions + 15) / 16);
   *bm_words = (*bm_words + 3) & ~3;
   *lds = (size_t)((((read_len + 3) / 4) + 6 * (*NL) + 1 + 3) & ~3) * 4 + (size_t)(*bm_words) * 4;
+}
+
+// v4 launch: returns false when the geometry does not fit (the caller falls back to the slab-sweep kernels)
+struct K4Scratch { uint64_t* scratch = nullptr; size_t words = 0; uint32_t* fb = nullptr; int cus = 0; };
+static K4Scratch g_k4[16];
+static bool k4_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words, int max_n_kmers, int NL,
+                      uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
+                      unsigned long long* d_stats, hipStream_t stream, uint32_t* d_surv_seg, size_t lds_generic, int bm_words) {
+  int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+  K4Scratch& K = g_k4[dev];
+  const int S = ix.n_slabs;
+  int tab_bits = 19; if (const char* e = getenv("GM_K4_TABBITS")) tab_bits = std::max(6, std::min(19, atoi(e)));
+  // pass C keeps the exact counters of one bin of 2^cbits positions (+2) in the table's LDS; bins nest inside the index slabs
+  const int cbits = std::min(ix.slab_bits, tab_bits + ix.region_bits - 1);
+  if (cbits < ix.region_bits + 1) return false;
+  const int SC = (int)((ix.total_len + (1ull << cbits) - 1) >> cbits);
+  if (SC < 1 || SC > 4096) return false;
+  int wcap = 4096; if (const char* e = getenv("GM_K4_WCAP")) wcap = std::max(2, std::min(4096, atoi(e) & ~1));   // windows with a direct window -> list entry (the rest: binary search)
+  const int fb_cap = 4096;
+  int bin_cap = 4096; if (const char* e = getenv("GM_K4_BINCAP")) bin_cap = std::max(16, atoi(e));
+  const int code_words = (read_len + 3) / 4;
+  const size_t lds = (size_t)(((((code_words + 3) & ~3) + 4 * NL + NL + 1 + SC + (wcap + 1) / 2 + 3) & ~3) + (1 << (tab_bits - 4))) * 4;
+  if (lds > 160 * 1024 - 64) return false;
+  int wgs_per_cu = 1; if (const char* e = getenv("GM_K4_WGS")) wgs_per_cu = std::max(1, std::min(8, atoi(e)));
+  if (!K.cus) { if (hipDeviceGetAttribute(&K.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || K.cus < 1) K.cus = 256; }
+  int grid = std::min(2 * n_reads, K.cus * wgs_per_cu);
+  if (const char* e = getenv("GM_K4_GRID")) grid = std::max(1, std::min(2 * n_reads, atoi(e)));
+  const size_t need = (size_t)std::max(grid, K.cus) * SC * bin_cap;
+  if (need > K.words) {
+    if (K.scratch) (void)hipFree(K.scratch);
+    K.scratch = nullptr; K.words = 0;
+    if (hipMalloc(&K.scratch, need * 8) != hipSuccess) return false;
+    K.words = need;
+  }
+  if (!K.fb) { if (hipMalloc(&K.fb, (size_t)(fb_cap + 4) * 4) != hipSuccess) return false; }
+  if (hipMemsetAsync(K.fb + fb_cap, 0, 4, stream) != hipSuccess) return false;
+  static size_t configured4 = 0, configured_g = 0;
+  if (lds > 48 * 1024 && lds > configured4) { if (hipFuncSetAttribute((const void*)k_lookup_v4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false; configured4 = lds; }
+  if (lds_generic > 48 * 1024 && lds_generic > configured_g) {
+    if (hipFuncSetAttribute((const void*)k_lookup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_generic) != hipSuccess) return false; configured_g = lds_generic; }
+  int k4_threads = 1024; if (const char* e = getenv("GM_K1_THREADS")) k4_threads = std::max(64, std::min(1024, atoi(e) & ~63));
+  hipLaunchKernelGGL(k_lookup_v4, dim3(grid), dim3(k4_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words, max_n_kmers, NL, tab_bits, cbits, SC, wcap,
+                     d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, d_surv_seg, K.scratch, bin_cap, K.fb, K.fb + fb_cap, fb_cap,
+                     getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0);
+  // read-strands whose candidates overflowed their bins: the slab-sweep kernel in list mode (blocks beyond the list's end return at once)
+  hipLaunchKernelGGL(k_lookup<false>, dim3(fb_cap), dim3(K1_THREADS), lds_generic, stream, ix, d_reads, n_reads, read_len, read_words,
+                     max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
+                     (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)K.fb, (const uint32_t*)(K.fb + fb_cap), d_stats, 0, d_surv_seg);
+  return true;
 }
 
 size_t gm_lookup_lds_bytes(const GmIndexDev& ix, int read_len) {
@@ -716,6 +1029,9 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     const size_t lds_b = (size_t)((((read_len + 3) / 4) + 3) & ~3) * 4 + (size_t)bm_words * 4;
     hipLaunchKernelGGL(k_lookup_bkt, dim3(n_reads * 2), dim3((NL + 63) & ~63), lds_b, stream, ix, d_reads, n_reads, read_len, read_words,
                        max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, d_surv_seg);
+  } else if (ix.n_slabs > 1 && NL < 65536 && !getenv("GM_K1_V2") && !getenv("GM_K1_V3") && k4_launch(ix, d_reads, n_reads, read_len, read_words, max_n_kmers, NL, d_surv, d_surv_cnt, scap,
+                                                                                                   d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, stream, d_surv_seg, lds, bm_words)) {
+    // k_lookup_v4 ran (hashed pre-count + exact count on the candidates); read-strands it could not hold were redone in list mode
   } else if (ix.list_cutoff < 65536u && !getenv("GM_K1_V2")) {
     const size_t lds3 = (size_t)((((read_len + 3) / 4) + 3 * NL + ix.n_slabs * NL + (ix.n_slabs + 1) / 2 + (NL * (ix.n_slabs + 1) + 1) / 2 + 3) & ~3) * 4 + (size_t)bm_words * 4;
     static size_t configured3 = 0;
@@ -732,7 +1048,8 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     if (const char* e = getenv("GM_K1_THREADS")) k1_threads = std::max(64, std::min(1024, atoi(e) & ~63));
     hipLaunchKernelGGL(k_lookup<false>, dim3(n_reads * 2), dim3(k1_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words,
                        max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
-                       (const uint32_t*)nullptr, (const uint64_t*)nullptr, d_stats, getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0, d_surv_seg);
+                       (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_stats,
+                       getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0, d_surv_seg);
   }
   GM_HIP(hipGetLastError());
   return GM_OK;
@@ -747,7 +1064,7 @@ int gm_launch_lookup_redo(const GmIndexDev& ix, const uint32_t* d_reads, int n_r
   if (n_heavy == 0) return GM_OK;
   hipLaunchKernelGGL(k_lookup<false>, dim3(n_heavy), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
                      max_n_kmers, NL, bm_words, d_out, (uint32_t*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0,
-                     d_redo_list, d_redo_off, d_stats, 0, (uint32_t*)nullptr);
+                     d_redo_list, d_redo_off, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_stats, 0, (uint32_t*)nullptr);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

@@ -122,8 +122,12 @@ def test_sam_matches_reference_golden(gm, name):
 
 KERNEL_VARIANTS = [
     {"GM_NO_BUCKETS": "1"},                                  # generic lookup kernels on a one-slab index
-    {"GM_SLAB_BITS": "18"},                                  # several slabs: slab borders, per-slab directory (k_lookup_v3)
-    {"GM_SLAB_BITS": "17", "GM_K1_THREADS": "128"},          # more lists than lane groups x register windows
+    {"GM_SLAB_BITS": "18"},                                  # several slabs: k_lookup_v4 (hashed pre-count, exact count per slab on the candidates, slab borders)
+    {"GM_SLAB_BITS": "17", "GM_K1_THREADS": "128"},          # more lists than lane groups
+    {"GM_SLAB_BITS": "13", "GM_K4_TABBITS": "12"},           # v4 with a folded table far smaller than the genome: many false candidates, 2^2-region slabs
+    {"GM_SLAB_BITS": "18", "GM_K4_BINCAP": "16"},            # v4 candidate bins overflow: read-strands redone by the slab-sweep kernel in list mode
+    {"GM_SLAB_BITS": "18", "GM_K4_WCAP": "8"},               # v4 window -> list by binary search
+    {"GM_SLAB_BITS": "18", "GM_K1_V3": "1"},                 # the slab-sweep lane-group kernel (k_lookup_v3)
     {"GM_SLAB_BITS": "18", "GM_K1_V2": "1"},                 # the lane-per-list kernel (also the heavy tier's re-emission)
     {"GM_NO_PRUNE": "1"},                                    # K2 on the unpruned survivors
     {"GM_SCAP": "256", "GM_SCAP2": "64"},                    # small LDS tiers: most read-strands take the heavy tier
