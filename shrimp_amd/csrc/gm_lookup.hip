@@ -731,7 +731,7 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
   uint32_t* bin_cnt = wbase + NL + 1;
   uint16_t* wmap = (uint16_t*)(bin_cnt + SC);
   uint32_t* tab = smem + ((((code_words + 3) & ~3) + 4 * NL + NL + 1 + SC + (wcap + 1) / 2 + 3) & ~3);
-  const int tab_words = 1 << (tab_bits - 4);
+  const int tab_words = (1 << (tab_bits - 4)) + 4;            // + the spare counters of the empty lanes
   const uint32_t* __restrict__ pos0 = ix.seed[0].pos;
   uint64_t* my_scratch = scratch + (size_t)blockIdx.x * SC * bin_cap;
   const int ng = nthr / 8, g = tid / 8, gl4 = (tid & 7) * 4;
@@ -805,10 +805,12 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
     auto fetch = [&](const int t, Win& w) {
       uint32_t e0 = 0; w.j = 0;
       w.nv = locate(t, w.j, e0);
-      k1_u32x4 v = {0, 0, 0, 0};
+      k1_u32x4 v = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
       if (w.nv) v = load_window(w.j, e0);
-      w.p[0] = v.x; w.p[1] = v.y; w.p[2] = v.z; w.p[3] = v.w;
+      // 0xFFFFFFFF = no entry (never a k-mer start): such lanes count into a spare word, so the passes below are straight-line code
+      w.p[0] = v.x; w.p[1] = w.nv > 1 ? v.y : 0xFFFFFFFFu; w.p[2] = w.nv > 2 ? v.z : 0xFFFFFFFFu; w.p[3] = w.nv > 3 ? v.w : 0xFFFFFFFFu;
     };
+    const uint32_t spare = 1u << tab_bits, spare0 = spare + 16u;   // counters past the table: scratch for empty lanes (pass A) / always zero (pass B)
     // ---- pass A: folded counts ----
     if (!(ablate & 8)) {
       Win cur[K4Q], nxt[K4Q];
@@ -823,12 +825,12 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
           if (ablate & 2) { if ((w.p[0] ^ w.p[1] ^ w.p[2] ^ w.p[3]) == 0x12345u) tab[0] = 1; continue; }   // loads only
           uint32_t old[4], h[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) { h[u] = (w.p[u] >> rb) & tmask; old[u] = 0; if (u < w.nv) old[u] = atomicOr(&tab[h[u] >> 4], 1u << ((h[u] & 15u) * 2u)); }
+          for (int u = 0; u < 4; u++) { h[u] = (w.p[u] != 0xFFFFFFFFu) ? ((w.p[u] >> rb) & tmask) : spare; old[u] = atomicOr(&tab[h[u] >> 4], 1u << ((h[u] & 15u) * 2u)); }
 #pragma unroll
-          for (int u = 0; u < 4; u++) if (u < w.nv && ((old[u] >> ((h[u] & 15u) * 2u)) & 3u) == 1u) atomicOr(&tab[h[u] >> 4], 2u << ((h[u] & 15u) * 2u));
+          for (int u = 0; u < 4; u++) if (((old[u] >> ((h[u] & 15u) * 2u)) & 3u) == 1u) atomicOr(&tab[h[u] >> 4], 2u << ((h[u] & 15u) * 2u));
 #pragma unroll
-          for (int u = 0; u < 4; u++)                            // overlap strip (ref: mapping.c:521-533): 2.4 % of the entries
-            if (u < w.nv && (w.p[u] & rmask) < ovl && (w.p[u] >> rb) > 0) k1_mark(tab, ((w.p[u] >> rb) - 1u) & tmask);
+          for (int u = 0; u < 4; u++)                            // overlap strip (ref: mapping.c:521-533): 2.4 % of the entries (0xFFFFFFFF is never in it)
+            if ((w.p[u] & rmask) < ovl && (w.p[u] >> rb) > 0) k1_mark(tab, ((w.p[u] >> rb) - 1u) & tmask);
         }
 #pragma unroll
         for (int q = 0; q < K4Q; q++) cur[q] = nxt[q];
@@ -849,9 +851,8 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
           uint32_t hit = 0;
 #pragma unroll
           for (int u = 0; u < 4; u++) {
-            if (u >= w.nv) continue;
             const uint32_t r = w.p[u] >> rb;
-            if (k1_has2(tab, r & tmask)) hit |= 1u << u;
+            if (k1_has2(tab, (w.p[u] != 0xFFFFFFFFu) ? (r & tmask) : spare0)) hit |= 1u << u;
             else if ((w.p[u] & rmask) < ovl && r > 0 && k1_has2(tab, (r - 1u) & tmask)) hit |= 1u << u;
           }
           if (hit && (ablate & 16)) { if (hit == 0x55u) tab[1] = 1; hit = 0; }
@@ -977,7 +978,7 @@ static bool k4_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   const int fb_cap = 4096;
   int bin_cap = 4096; if (const char* e = getenv("GM_K4_BINCAP")) bin_cap = std::max(16, atoi(e));
   const int code_words = (read_len + 3) / 4;
-  const size_t lds = (size_t)(((((code_words + 3) & ~3) + 4 * NL + NL + 1 + SC + (wcap + 1) / 2 + 3) & ~3) + (1 << (tab_bits - 4))) * 4;
+  const size_t lds = (size_t)(((((code_words + 3) & ~3) + 4 * NL + NL + 1 + SC + (wcap + 1) / 2 + 3) & ~3) + (1 << (tab_bits - 4)) + 4) * 4;
   if (lds > 160 * 1024 - 64) return false;
   int wgs_per_cu = 1; if (const char* e = getenv("GM_K4_WGS")) wgs_per_cu = std::max(1, std::min(8, atoi(e)));
   if (!K.cus) { if (hipDeviceGetAttribute(&K.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || K.cus < 1) K.cus = 256; }
