@@ -64,6 +64,8 @@ typedef struct gm_params {
   int crossover_score;                         /* ref: gmapper-defaults.h:54  -20; the vector filter's mismatch is match + crossover (gmapper.c:2935) */
   int indel_taboo_len;                         /* ref: gmapper.h:57  0 */
   double pr_xover;                             /* ref: gmapper.h:119  0.03: fixes score_alpha in colour space (gmapper.c:2557-2563) */
+  int local_alignment;                         /* --local, i.e. Gflag off (ref: gmapper.c:2303-2305): sw_full_ls in local mode (soft clips); mapping qualities
+                                                  are then unavailable (gmapper.c:2325-2328): MAPQ 255, no Z0/Z1 tags.  Letter space only.  0 */
 } gm_params_t;
 
 void gm_params_default(gm_params_t *p);        /* letter-space defaults of the reference binary (gmapper-ls) */

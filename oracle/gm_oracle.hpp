@@ -510,6 +510,7 @@ enum { FROM_NORTH_NORTH = 1, FROM_NORTH_NORTHWEST = 2, FROM_WEST_NORTHWEST = 3, 
        FROM_NORTHWEST_NORTH = 5, FROM_NORTHWEST_NORTHWEST = 6, FROM_NORTHWEST_WEST = 7 };
 
 struct SwFullWorkspace {
+  uint64_t local_retries = 0;     // local mode: alignments that took the second, threshold-band run
   struct Cell { int n, w, nw; int8_t bn, bw, bnw; };
   std::vector<Cell> m;
   std::vector<int8_t> db, qr;
@@ -519,8 +520,6 @@ struct SwFullWorkspace {
 static inline void sw_full_ls(const Params& P, SwFullWorkspace& W, const uint32_t* genome, llint goff, int glen,
                               const uint32_t* read, int rlen, int threshscore, int maxscore, SwFullResults* sfr,
                               bool revcmpl, const Anchor* anchors, int anchors_cnt, int local_alignment) {
-  (void)threshscore; (void)maxscore;
-  assert(!local_alignment && "only the default global mode (Gflag) is restated");
   const int lena = glen, lenb = rlen;
   const int a_go = -P.a_gap_open_score, a_ge = -P.a_gap_extend_score;
   const int b_go = -P.b_gap_open_score, b_ge = -P.b_gap_extend_score;
@@ -528,66 +527,87 @@ static inline void sw_full_ls(const Params& P, SwFullWorkspace& W, const uint32_
   W.db.resize(lena); W.qr.resize(lenb);
   for (int i = 0; i < lena; i++) W.db[i] = (int8_t)EXTRACT(genome, goff + i);
   for (int i = 0; i < lenb; i++) W.qr[i] = (int8_t)EXTRACT(read, i);
-  // The reference never clears swmatrix between calls; every cell it reads is written first
-  // (band geometry is monotone), so a fresh poison fill is equivalent and catches mistakes.
-  W.m.assign((size_t)(lena + 1) * (lenb + 1), SwFullWorkspace::Cell{INT_MIN / 4, INT_MIN / 4, INT_MIN / 4, 0, 0, 0});
   auto init_cell = [&](size_t idx, int local) {  // sw-full-ls.c:66-80
     auto& c = W.m[idx];
     if (local) { c.nw = 0; c.n = -b_go; c.w = -a_go; }
     else { c.nw = -INT_MAX / 2; c.n = -INT_MAX / 2; c.w = -INT_MAX / 2; }
     c.bnw = c.bn = c.bw = 0;
   };
+  int score = 0, max_i = 0, max_j = 0;
+  // full_sw (sw-full-ls.c:154-403) over one band; local mode (Gflag off): states floor at 0 with a null back pointer, the best
+  // cell is the first in row-major order to reach the filter's score, where the scan stops (:293-374)
+  auto full_sw = [&](const Anchor& rectangle) {
+    // The reference never clears swmatrix between calls; every cell it reads is written first
+    // (band geometry is monotone), so a fresh poison fill is equivalent and catches mistakes.
+    W.m.assign((size_t)(lena + 1) * (lenb + 1), SwFullWorkspace::Cell{INT_MIN / 4, INT_MIN / 4, INT_MIN / 4, 0, 0, 0});
+    for (int j = 0; j < lena + 1; j++) init_cell(j, 1);  // sw-full-ls.c:194-196
+    score = 0; max_i = 0; max_j = 0;
+    for (int i = 0; i < lenb; i++) {
+      int x_min, x_max;
+      anchor_get_x_range(&rectangle, lena, lenb, i, &x_min, &x_max);
+      init_cell((size_t)(i + 1) * (lena + 1) + (x_min - 1) + 1, local_alignment ? 1 : 0);   // :228-233
+      W.cells += x_max - x_min + 1;
+      int j;
+      for (j = x_min; j <= x_max; j++) {
+        auto* cnw = &W.m[(size_t)i * (lena + 1) + j];
+        auto* cn = cnw + 1; auto* cw = cnw + (lena + 1); auto* cur = cw + 1;
+        int ms = (W.db[j] == W.qr[i]) ? match : mismatch;
+        int tmp; int8_t tmp2;
+        if (!revcmpl) {                                        // :264-278
+          tmp = cnw->nw + ms; tmp2 = FROM_NORTHWEST_NORTHWEST;
+          if (cnw->n + ms > tmp) { tmp = cnw->n + ms; tmp2 = FROM_NORTHWEST_NORTH; }
+          if (cnw->w + ms > tmp) { tmp = cnw->w + ms; tmp2 = FROM_NORTHWEST_WEST; }
+        } else {                                               // :279-292
+          tmp = cnw->w + ms; tmp2 = FROM_NORTHWEST_WEST;
+          if (cnw->n + ms > tmp) { tmp = cnw->n + ms; tmp2 = FROM_NORTHWEST_NORTH; }
+          if (cnw->nw + ms > tmp) { tmp = cnw->nw + ms; tmp2 = FROM_NORTHWEST_NORTHWEST; }
+        }
+        if (tmp <= 0 && local_alignment) { tmp = 0; tmp2 = 0; }
+        cur->nw = tmp; cur->bnw = tmp2;
+        if (!revcmpl) {                                        // north :303-320
+          tmp = cn->nw - b_go - b_ge; tmp2 = FROM_NORTH_NORTHWEST;
+          if (cn->n - b_ge > tmp) { tmp = cn->n - b_ge; tmp2 = FROM_NORTH_NORTH; }
+        } else {
+          tmp = cn->n - b_ge; tmp2 = FROM_NORTH_NORTH;
+          if (cn->nw - b_go - b_ge > tmp) { tmp = cn->nw - b_go - b_ge; tmp2 = FROM_NORTH_NORTHWEST; }
+        }
+        if (tmp <= 0 && local_alignment) { tmp = 0; tmp2 = 0; }
+        cur->n = tmp; cur->bn = tmp2;
+        if (!revcmpl) {                                        // west :330-347
+          tmp = cw->nw - a_go - a_ge; tmp2 = FROM_WEST_NORTHWEST;
+          if (cw->w - a_ge > tmp) { tmp = cw->w - a_ge; tmp2 = FROM_WEST_WEST; }
+        } else {
+          tmp = cw->w - a_ge; tmp2 = FROM_WEST_WEST;
+          if (cw->nw - a_go - a_ge > tmp) { tmp = cw->nw - a_go - a_ge; tmp2 = FROM_WEST_NORTHWEST; }
+        }
+        if (tmp <= 0 && local_alignment) { tmp = 0; tmp2 = 0; }
+        cur->w = tmp; cur->bw = tmp2;
+        if (local_alignment || i == lenb - 1) {                // :359-368 (global: last read row only)
+          int t = std::max(cur->n, cur->nw); t = std::max(t, cur->w);
+          if (t > score) { score = t; max_i = i; max_j = j; }
+        }
+        if (score == maxscore && local_alignment) break;      // :370-371
+      }
+      if (score == maxscore && local_alignment) break;        // :374-375
+      if (i + 1 < lenb) {                                      // :378-385
+        int nx_min, nx_max;
+        anchor_get_x_range(&rectangle, lena, lenb, i + 1, &nx_min, &nx_max);
+        for (int j2 = x_max + 1; j2 <= nx_max; j2++) init_cell((size_t)(i + 1) * (lena + 1) + (j2 + 1), local_alignment);
+      }
+    }
+  };
   Anchor rectangle;
   anchor_join(anchors, anchors_cnt, &rectangle);      // sw-full-ls.c:176-178 (anchors != NULL, anchor_width >= 0)
   anchor_widen(&rectangle, P.anchor_width);
-  for (int j = 0; j < lena + 1; j++) init_cell(j, 1);  // sw-full-ls.c:194-196
-  int score = 0, max_i = 0, max_j = 0;
-  for (int i = 0; i < lenb; i++) {
-    int x_min, x_max;
-    anchor_get_x_range(&rectangle, lena, lenb, i, &x_min, &x_max);
-    init_cell((size_t)(i + 1) * (lena + 1) + (x_min - 1) + 1, 0);   // :229-231 (global)
-    W.cells += x_max - x_min + 1;
-    for (int j = x_min; j <= x_max; j++) {
-      auto* cnw = &W.m[(size_t)i * (lena + 1) + j];
-      auto* cn = cnw + 1; auto* cw = cnw + (lena + 1); auto* cur = cw + 1;
-      int ms = (W.db[j] == W.qr[i]) ? match : mismatch;
-      int tmp; int8_t tmp2;
-      if (!revcmpl) {                                        // :264-278
-        tmp = cnw->nw + ms; tmp2 = FROM_NORTHWEST_NORTHWEST;
-        if (cnw->n + ms > tmp) { tmp = cnw->n + ms; tmp2 = FROM_NORTHWEST_NORTH; }
-        if (cnw->w + ms > tmp) { tmp = cnw->w + ms; tmp2 = FROM_NORTHWEST_WEST; }
-      } else {                                               // :279-292
-        tmp = cnw->w + ms; tmp2 = FROM_NORTHWEST_WEST;
-        if (cnw->n + ms > tmp) { tmp = cnw->n + ms; tmp2 = FROM_NORTHWEST_NORTH; }
-        if (cnw->nw + ms > tmp) { tmp = cnw->nw + ms; tmp2 = FROM_NORTHWEST_NORTHWEST; }
-      }
-      cur->nw = tmp; cur->bnw = tmp2;
-      if (!revcmpl) {                                        // north :303-320
-        tmp = cn->nw - b_go - b_ge; tmp2 = FROM_NORTH_NORTHWEST;
-        if (cn->n - b_ge > tmp) { tmp = cn->n - b_ge; tmp2 = FROM_NORTH_NORTH; }
-      } else {
-        tmp = cn->n - b_ge; tmp2 = FROM_NORTH_NORTH;
-        if (cn->nw - b_go - b_ge > tmp) { tmp = cn->nw - b_go - b_ge; tmp2 = FROM_NORTH_NORTHWEST; }
-      }
-      cur->n = tmp; cur->bn = tmp2;
-      if (!revcmpl) {                                        // west :330-347
-        tmp = cw->nw - a_go - a_ge; tmp2 = FROM_WEST_NORTHWEST;
-        if (cw->w - a_ge > tmp) { tmp = cw->w - a_ge; tmp2 = FROM_WEST_WEST; }
-      } else {
-        tmp = cw->w - a_ge; tmp2 = FROM_WEST_WEST;
-        if (cw->nw - a_go - a_ge > tmp) { tmp = cw->nw - a_go - a_ge; tmp2 = FROM_WEST_NORTHWEST; }
-      }
-      cur->w = tmp; cur->bw = tmp2;
-      if (i == lenb - 1) {                                   // :359-368 (global: last read row only)
-        int t = std::max(cur->n, cur->nw); t = std::max(t, cur->w);
-        if (t > score) { score = t; max_i = i; max_j = j; }
-      }
-    }
-    if (i + 1 < lenb) {                                      // :378-385
-      int nx_min, nx_max;
-      anchor_get_x_range(&rectangle, lena, lenb, i + 1, &nx_min, &nx_max);
-      for (int j = x_max + 1; j <= nx_max; j++) init_cell((size_t)(i + 1) * (lena + 1) + (j + 1), 0);
-    }
+  full_sw(rectangle);
+  if (local_alignment && score != maxscore) {         // :395-398: the filter's alignment left the band: once more over the band the threshold allows
+    W.local_retries++;
+    Anchor t[2];
+    t[0].x = 0; t[0].y = (lenb * match - threshscore) / match; t[0].length = 1; t[0].width = 1;
+    t[1].x = lena - 1; t[1].y = lenb - 1 - t[0].y; t[1].length = 1; t[1].width = 1;
+    anchor_join(t, 2, &rectangle);
+    full_sw(rectangle);
+    assert(score == maxscore);
   }
   sfr->score = score;
   sfr->ops.clear();

@@ -61,6 +61,7 @@ static void map_all(const Session& S, std::vector<Read>& reads, int nthreads, st
       }
     }
     st[omp_get_thread_num()] = T.stats;
+    st[omp_get_thread_num()].full_cells = T.sww.local_retries;      // reported in the stats' 7th slot
   }
   for (auto& o : outs) out += o;
   if (stats_out) {
@@ -69,7 +70,6 @@ static void map_all(const Session& S, std::vector<Read>& reads, int nthreads, st
       stats_out->full_calls += s.full_calls; stats_out->full_cells += s.full_cells; stats_out->reads_matched += s.reads_matched;
       stats_out->dup_pruned += s.dup_pruned;
     }
-    stats_out->full_cells = 0;
   }
 }
 
@@ -192,6 +192,7 @@ static void apply_opts(Params& P, const char* opts) {
     else if (k == "report") P.num_outputs = (int)d; else if (k == "anchor-width") P.anchor_width = (int)d;
     else if (k == "cutoff") P.list_cutoff = (uint32_t)d; else if (k == "strata") P.strata = d != 0;
     else if (k == "max-alignments") P.max_alignments = (int)d;
+    else if (k == "local") { P.Gflag = d == 0; if (!P.Gflag) P.compute_mapping_qualities = false; }   // --local (gmapper.c:2303-2305,2325-2328)
     else if (k == "crossover") P.crossover_score = (int)d; else if (k == "indel-taboo-len") P.indel_taboo_len = (int)d;
     else if (k == "seeds") {
       P.seeds.clear(); P.max_seed_span = 0; P.min_seed_span = 64;
@@ -254,7 +255,7 @@ char* gmo_map_sam(void* s, int n, int L, const uint8_t* codes, const char* names
   }
   std::string out; Stats st;
   map_all(*S, reads, nthreads > 0 ? nthreads : 1, out, &st);
-  if (stats7) { stats7[0] = st.vec_calls; stats7[1] = st.vec_cells; stats7[2] = st.vec_bypassed; stats7[3] = st.full_calls; stats7[4] = st.reads_matched; stats7[5] = st.dup_pruned; stats7[6] = 0; }
+  if (stats7) { stats7[0] = st.vec_calls; stats7[1] = st.vec_cells; stats7[2] = st.vec_bypassed; stats7[3] = st.full_calls; stats7[4] = st.reads_matched; stats7[5] = st.dup_pruned; stats7[6] = st.full_cells; }
   char* r = (char*)malloc(out.size() + 1);
   memcpy(r, out.data(), out.size()); r[out.size()] = 0;
   return r;

@@ -37,7 +37,7 @@ extern "C" void gm_params_default(gm_params_t* p) {
   p->match_mode = 2; p->num_outputs = 10; p->num_tmp_outputs = 30; p->anchor_width = 8;
   p->region_bits = 11; p->region_overlap = 50; p->list_cutoff = 0; p->hash_filter_calls = 1; p->tiebreak_rev = 1;
   p->sam_unaligned = 0; p->longest_read_len = 1000; p->strata = 0; p->max_alignments = 0;
-  p->colour_space = 0; p->crossover_score = -20; p->indel_taboo_len = 0; p->pr_xover = 0.03;
+  p->colour_space = 0; p->crossover_score = -20; p->indel_taboo_len = 0; p->pr_xover = 0.03; p->local_alignment = 0;
 }
 // the gmapper-cs binary's defaults (ref: gmapper.c:1748-1755, gmapper-defaults.h:52-58,64-66)
 extern "C" void gm_params_default_cs(gm_params_t* p) {
@@ -51,7 +51,7 @@ static GmScoreDev make_score(const gm_params_t& P) {
   s.mismatch = P.colour_space ? P.match_score + P.crossover_score : P.mismatch_score;   // what f1_setup hands the vector filter (ref: gmapper.c:2933-2936)
   s.a_go = -P.a_gap_open_score; s.a_ge = -P.a_gap_extend_score; s.b_go = -P.b_gap_open_score; s.b_ge = -P.b_gap_extend_score;
   s.anchor_width = P.anchor_width; s.match_mode = P.match_mode; s.min_matches = P.match_mode;   // ref: gmapper.c:2625
-  s.num_tmp_outputs = P.num_tmp_outputs; s.tiebreak_rev = P.tiebreak_rev; s.hash_filter_calls = P.hash_filter_calls;
+  s.num_tmp_outputs = P.num_tmp_outputs; s.tiebreak_rev = P.tiebreak_rev; s.hash_filter_calls = P.hash_filter_calls; s.local = P.local_alignment ? 1 : 0;
   auto frac = [](double thr, double* f, int* a) { if (thr < 0) { *f = -1.0; *a = (int)(-thr); } else { *f = thr / 100.0; *a = 0; } };
   frac(P.window_gen_threshold, &s.wgen_thr_frac, &s.wgen_abs);
   frac(P.sw_vect_threshold, &s.vect_thr_frac, &s.vect_abs);
@@ -406,6 +406,7 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   s->pr_ins_open = pow(2.0, (double)s->P.b_gap_open_score / s->score_alpha);
   s->pr_del_extend = pow(2.0, (double)s->P.a_gap_extend_score / s->score_alpha);
   s->pr_ins_extend = pow(2.0, ((double)s->P.b_gap_extend_score - s->score_beta) / s->score_alpha);
+  if (s->P.colour_space && s->P.local_alignment) { delete s; gm_set_error("local alignment is implemented for letter space only"); return GM_E_ARG; }
   if ((s->P.colour_space != 0) != (ix->params.colour_space != 0)) { delete s; gm_set_error("session and index disagree on colour space"); return GM_E_ARG; }
   s->max_batch = std::max(64, std::min(max_batch_reads > 0 ? max_batch_reads : 131072, 1 << 20));
   GM_HIP(hipStreamCreate(&s->stream));
@@ -600,7 +601,7 @@ struct Finalizer {
     h.z2 = h.z3 = h.pr_top_random = h.insert_size_denom = h.pr_missed_mp = 0;
     h.score_full = r->score;
     h.pct_score_full = (1000 * 100 * h.score_full) / r->score_max;                 // ref: mapping.c:400-401
-    if (h.score_full > 0) {
+    if (h.score_full > 0 && !P.local_alignment) {                  // local mode: mapping qualities are off (ref: gmapper.c:2325-2328, mapping.c:1648)
       const double a = s->score_alpha, b = s->score_beta;
       if (P.colour_space) {
         cs_alignment_strings(h.ops, h.ops + ops_half, std::min(r->n_ops, ops_half), h.db, h.qr);
@@ -654,9 +655,11 @@ struct Finalizer {
       }
       return 0;
     }
-    double z1 = 0.0;                                                               // compute_unpaired_mqv, ref: output.c:777-793
-    for (auto* h : p2) z1 += h->posterior;
-    for (auto* h : p2) { h->z0 = h->posterior; h->z1 = z1; h->mqv = qv_from_pr_corr(h->posterior / z1); if (h->mqv < 4) h->mqv = 0; }
+    if (!P.local_alignment) {                                                      // compute_unpaired_mqv, ref: output.c:777-793,975
+      double z1 = 0.0;
+      for (auto* h : p2) z1 += h->posterior;
+      for (auto* h : p2) { h->z0 = h->posterior; h->z1 = z1; h->mqv = qv_from_pr_corr(h->posterior / z1); if (h->mqv < 4) h->mqv = 0; }
+    }
     for (auto* h : p2) {
       const GmFullRes& r = *h->r;
       size_t o = out.size(); out.resize(o + need + 12 * (size_t)r.n_ops); char* p = &out[o];
@@ -715,8 +718,10 @@ struct Finalizer {
       if (!rev) for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = CODE2SEQ[c]; }
       else for (int i = read_len - 1; i >= 0; i--) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = rc_char(CODE2SEQ[c]); }
       p = put_str(p, "\t*\tAS:i:", 8); p = put_int(p, h->score_full);
-      p = put_str(p, "\tZ0:i:", 6); p = put_int(p, double_to_neglog(h->z0));
-      p = put_str(p, "\tZ1:i:", 6); p = put_int(p, double_to_neglog(h->z1));
+      if (!P.local_alignment) {                                                    // ref: output.c:691-696
+        p = put_str(p, "\tZ0:i:", 6); p = put_int(p, double_to_neglog(h->z0));
+        p = put_str(p, "\tZ1:i:", 6); p = put_int(p, double_to_neglog(h->z1));
+      }
       p = put_str(p, "\tNM:i:", 6); p = put_int(p, r.n_mismatch + r.n_del + r.n_ins);
       *p++ = '\n';
       out.resize(p - out.data());

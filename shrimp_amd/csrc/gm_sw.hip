@@ -360,10 +360,15 @@ __device__ __forceinline__ int shr1_i(int v, int lane0) { return __builtin_amdgc
 
 struct FullOut { int score, max_i, max_j, e_nw, e_n, e_w; };
 
-// back byte: bits 0-1 nw source (0 NW_NW, 1 NW_N, 2 NW_W), bit 2 n source (0 N_NW, 1 N_N), bit 3 w source (0 W_NW, 1 W_W), bit 7 = cell computed
+// back byte: bits 0-1 nw source (0 NW_NW, 1 NW_N, 2 NW_W), bit 2 n source (0 N_NW, 1 N_N), bit 3 w source (0 W_NW, 1 W_W), bit 7 = cell computed;
+// local mode: bits 4 / 5 / 6 = the nw / n / w state was floored at 0, i.e. carries the reference's null back pointer.
+// LOCAL (Gflag off, ref: sw-full-ls.c:66-80,293-374): every cell outside the band that a band cell can read holds (0, -b_open, -a_open);
+// a state <= 0 becomes 0 with a null back pointer; the result is the first cell in row-major order with the largest score.
+template <bool LOCAL>
 __device__ FullOut full_sw_wave(const uint8_t* db, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc, bool revcmpl,
                                 long long rx, long long ry, int rl, int rw, uint8_t* back, int* carry, int lane) {
   const int a_go = sc.a_go, a_ge = sc.a_ge, b_go = sc.b_go, b_ge = sc.b_ge;
+  const int o_nw = LOCAL ? 0 : FS_NEG, o_n = LOCAL ? -b_go : FS_NEG, o_w = LOCAL ? -a_go : FS_NEG;   // a cell outside the band
   FullOut out; out.score = 0; out.max_i = 0; out.max_j = 0; out.e_nw = out.e_n = out.e_w = 0;
   const int n_stripes = (rlen + 63) >> 6;
   int* cNW = carry; int* cN = carry + glen; int* cW = carry + 2 * glen;   // last row of the previous stripe, per column
@@ -376,9 +381,9 @@ __device__ FullOut full_sw_wave(const uint8_t* db, int glen, const uint8_t* qr, 
     const int rows = min(64, rlen - s * 64);
     const int steps = glen + rows - 1;
     // own previous cell (r, c-1) and the two cells of row r-1 needed next: (r-1, c) arrives by shift
-    int pw_nw = FS_NEG, pw_n = FS_NEG, pw_w = FS_NEG;          // cell_w  = (r, c-1); column -1 is out of band
-    int d_nw = FS_NEG, d_n = FS_NEG, d_w = FS_NEG;             // cell_nw = (r-1, c-1)
-    int cur_nw = FS_NEG, cur_n = FS_NEG, cur_w = FS_NEG;       // this lane's latest cell, shifted to lane+1 next step
+    int pw_nw = o_nw, pw_n = o_n, pw_w = o_w;                  // cell_w  = (r, c-1); column -1 is out of band
+    int d_nw = o_nw, d_n = o_n, d_w = o_w;                     // cell_nw = (r-1, c-1)
+    int cur_nw = o_nw, cur_n = o_n, cur_w = o_w;               // this lane's latest cell, shifted to lane+1 next step
     if (s == 0 && lane == 0) { d_nw = 0; d_n = -b_go; d_w = -a_go; }   // virtual row -1, column -1
     const bool more = (s + 1 < n_stripes);
     const bool last_row_lane = row_ok && (r == rlen - 1);
@@ -387,13 +392,13 @@ __device__ FullOut full_sw_wave(const uint8_t* db, int glen, const uint8_t* qr, 
       // lane 0's upper neighbour at column t: virtual row (stripe 0) or carry from the previous stripe
       int in_nw, in_n, in_w;
       if (s == 0) { in_nw = 0; in_n = -b_go; in_w = -a_go; }
-      else { const int cc = min(t, glen - 1); in_nw = cNW[cc]; in_n = cN[cc]; in_w = cW[cc]; if (t >= glen) { in_nw = in_n = in_w = FS_NEG; } }
+      else { const int cc = min(t, glen - 1); in_nw = cNW[cc]; in_n = cN[cc]; in_w = cW[cc]; if (t >= glen) { in_nw = o_nw; in_n = o_n; in_w = o_w; } }
       const int u_nw = shr1_i(cur_nw, in_nw), u_n = shr1_i(cur_n, in_n), u_w = shr1_i(cur_w, in_w);   // cell_n = (r-1, c)
       const bool inband = row_ok && c >= x_min && c <= x_max;
-      int n_nw = FS_NEG, n_n = FS_NEG, n_w = FS_NEG;
+      int n_nw = o_nw, n_n = o_n, n_w = o_w;
       if (inband) {
         const int ms = (db[c] == q) ? sc.match : sc.mismatch;
-        int tmp, b0, b1, b2;
+        int tmp, b0, b1, b2, nul = 0;
         if (!revcmpl) {                                            // ref: sw-full-ls.c:264-278
           tmp = d_nw + ms; b0 = 0;
           if (d_n + ms > tmp) { tmp = d_n + ms; b0 = 1; }
@@ -403,6 +408,7 @@ __device__ FullOut full_sw_wave(const uint8_t* db, int glen, const uint8_t* qr, 
           if (d_n + ms > tmp) { tmp = d_n + ms; b0 = 1; }
           if (d_nw + ms > tmp) { tmp = d_nw + ms; b0 = 0; }
         }
+        if (LOCAL && tmp <= 0) { tmp = 0; nul |= 0x10; }
         n_nw = tmp;
         if (!revcmpl) {                                            // north :303-320
           tmp = u_nw - b_go - b_ge; b1 = 0;
@@ -411,6 +417,7 @@ __device__ FullOut full_sw_wave(const uint8_t* db, int glen, const uint8_t* qr, 
           tmp = u_n - b_ge; b1 = 1;
           if (u_nw - b_go - b_ge > tmp) { tmp = u_nw - b_go - b_ge; b1 = 0; }
         }
+        if (LOCAL && tmp <= 0) { tmp = 0; nul |= 0x20; }
         n_n = tmp;
         if (!revcmpl) {                                            // west :330-347
           tmp = pw_nw - a_go - a_ge; b2 = 0;
@@ -419,9 +426,10 @@ __device__ FullOut full_sw_wave(const uint8_t* db, int glen, const uint8_t* qr, 
           tmp = pw_w - a_ge; b2 = 1;
           if (pw_nw - a_go - a_ge > tmp) { tmp = pw_nw - a_go - a_ge; b2 = 0; }
         }
+        if (LOCAL && tmp <= 0) { tmp = 0; nul |= 0x40; }
         n_w = tmp;
-        back[(size_t)r * glen + c] = (uint8_t)(0x80 | b0 | (b1 << 2) | (b2 << 3));
-        if (last_row_lane) {                                       // :359-368 leftmost strict maximum on the last read row
+        back[(size_t)r * glen + c] = (uint8_t)(0x80 | nul | b0 | (b1 << 2) | (b2 << 3));
+        if (LOCAL || last_row_lane) {                              // :359-368 leftmost strict maximum: of the last read row, or (local) of this lane's rows
           int m = max(n_n, n_nw); m = max(m, n_w);
           if (m > out.score) { out.score = m; out.max_i = r; out.max_j = c; out.e_nw = n_nw; out.e_n = n_n; out.e_w = n_w; }
         }
@@ -435,14 +443,21 @@ __device__ FullOut full_sw_wave(const uint8_t* db, int glen, const uint8_t* qr, 
     }
     if (more) __syncthreads();
   }
-  // broadcast the last row's result from its lane
-  const int src = (rlen - 1) & 63;
+  // broadcast the result: from the last row's lane, or (local) from the lane whose row comes first among those with the largest score
+  int src = (rlen - 1) & 63;
+  if (LOCAL) {
+    int best = out.score;
+    for (int d = 32; d > 0; d >>= 1) best = max(best, __shfl_xor(best, d));
+    int row = (out.score == best) ? out.max_i : INT_MAX;
+    for (int d = 32; d > 0; d >>= 1) row = min(row, __shfl_xor(row, d));
+    src = (best > 0) ? (row & 63) : 0;
+  }
   out.score = __shfl(out.score, src); out.max_i = __shfl(out.max_i, src); out.max_j = __shfl(out.max_j, src);
   out.e_nw = __shfl(out.e_nw, src); out.e_n = __shfl(out.e_n, src); out.e_w = __shfl(out.e_w, src);
   return out;
 }
 
-template <bool BACK_LDS>
+template <bool BACK_LDS, bool LOCAL>
 __global__ void __launch_bounds__(GM_WAVE)
 k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words,
         GmHit* __restrict__ hits, const uint16_t* __restrict__ perm, int hcap,
@@ -511,8 +526,27 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
       int rl = (int)((se - nw) / 2 + 1);
       rx -= sc.anchor_width / 2; ry += sc.anchor_width / 2; rw += sc.anchor_width;
       __syncthreads();
-      const FullOut fo = full_sw_wave(db, w_len, qr, read_len, sc, (gen_st != 0) && sc.tiebreak_rev, rx, ry, rl, rw, back, carry, lane);
+      FullOut fo = full_sw_wave<LOCAL>(db, w_len, qr, read_len, sc, (gen_st != 0) && sc.tiebreak_rev, rx, ry, rl, rw, back, carry, lane);
       __syncthreads();
+      if (LOCAL && fo.score != sv) {
+        // the filter's best local alignment leaves the anchor band: once more over the band the threshold allows, from the two
+        // corner anchors (0, y0) and (glen - 1, rlen - 1 - y0), y0 = (rlen * match - thresh) / match (ref: sw-full-ls.c:179-192,395-398)
+        const long long y0 = ((long long)read_len * sc.match - thresh) / sc.match;
+        const long long bx[2] = {0, w_len - 1}, by[2] = {y0, read_len - 1 - y0};
+        long long border_nw = bx[0] + by[0], border_sw = bx[0] - by[0], border_ne = border_sw, border_se = border_nw;   // anchor_join, ref: anchors.c:9-52 (length = width = 1)
+        for (int a = 1; a < 2; a++) {
+          border_nw = bx[a] + by[a] < border_nw ? bx[a] + by[a] : border_nw; border_sw = bx[a] - by[a] < border_sw ? bx[a] - by[a] : border_sw;
+          border_ne = bx[a] - by[a] > border_ne ? bx[a] - by[a] : border_ne; border_se = bx[a] + by[a] > border_se ? bx[a] + by[a] : border_se;
+        }
+        if ((border_nw + border_sw) % 2 != 0) border_nw--;
+        rx = (border_nw + border_sw) / 2; ry = border_nw - rx;
+        if ((border_ne - border_sw) % 2 != 0) border_ne++;
+        rw = (int)((border_ne - border_sw) / 2 + 1);
+        if ((border_se - border_nw) % 2 != 0) border_se++;
+        rl = (int)((border_se - border_nw) / 2 + 1);
+        fo = full_sw_wave<LOCAL>(db, w_len, qr, read_len, sc, (gen_st != 0) && sc.tiebreak_rev, rx, ry, rl, rw, back, carry, lane);
+        __syncthreads();
+      }
       R.score = fo.score;
       if (fo.score > 0) {
         // do_backtrace, ref: sw-full-ls.c:413-516 -- lane 0 walks; ops are emitted reversed then flipped
@@ -528,6 +562,11 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
             const uint8_t bb = BACK_LDS ? back[(size_t)i * w_len + j]
                                         : __hip_atomic_load(&back[(size_t)i * w_len + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!(bb & 0x80)) break;                // out-of-band cell: back == 0 in the reference
+            if (LOCAL) {                            // a floored state has a null back pointer; a cell outside the band was never computed (stale byte)
+              if ((bb >> (4 + state)) & 1) break;
+              int bx_min, bx_max; band_range(rx, ry, rl, rw, w_len, i, &bx_min, &bx_max);
+              if (j < bx_min || j > bx_max) break;
+            }
             int nstate;
             if (state == 1) {                       // FROM_NORTH_*: BACK_DELETION (gap in the genome)
               if (no < ops_stride) o[no] = 'D'; no++; ndel++; rstart = i; i--;
@@ -626,7 +665,7 @@ k_sw_full_single(GmScoreDev sc, const uint32_t* __restrict__ genome, long long g
   if ((se - nw) % 2 != 0) se++;
   int rl = (int)((se - nw) / 2 + 1);
   rx -= sc.anchor_width / 2; ry += sc.anchor_width / 2; rw += sc.anchor_width;
-  const FullOut fo = full_sw_wave(db, glen, qr, rlen, sc, revcmpl != 0, rx, ry, rl, rw, back, carry, lane);
+  const FullOut fo = full_sw_wave<false>(db, glen, qr, rlen, sc, revcmpl != 0, rx, ry, rl, rw, back, carry, lane);
   __syncthreads();
   if (lane == 0) {
     int i = fo.max_i, j = fo.max_j, no = 0, rstart = 0, gstart = 0, nm = 0, nmm = 0, nin = 0, ndel = 0;
@@ -709,14 +748,15 @@ int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
   const int p2_ablate = getenv("GM_P2_ABLATE") ? atoi(getenv("GM_P2_ABLATE")) : 0;
   size_t lds = ((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 12 + 64;
   const size_t back_bytes = (size_t)read_len * window_len;
+#define GM_P2_LAUNCH(BL, LOC) hipLaunchKernelGGL((k_pass2<BL, LOC>), dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words, \
+    d_hits, d_perm, hcap, d_sel, d_sel_sidx, input_strand, write_back, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats, p2_ablate)
   if (back_bytes <= 40 * 1024) {
     lds += back_bytes + 16;
-    hipLaunchKernelGGL(k_pass2<true>, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
-                       d_hits, d_perm, hcap, d_sel, d_sel_sidx, input_strand, write_back, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats, p2_ablate);
+    if (sc.local) GM_P2_LAUNCH(true, true); else GM_P2_LAUNCH(true, false);
   } else {
-    hipLaunchKernelGGL(k_pass2<false>, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
-                       d_hits, d_perm, hcap, d_sel, d_sel_sidx, input_strand, write_back, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats, p2_ablate);
+    if (sc.local) GM_P2_LAUNCH(false, true); else GM_P2_LAUNCH(false, false);
   }
+#undef GM_P2_LAUNCH
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

@@ -93,7 +93,7 @@ class Session:
         p = self.L.gmo_map_sam(self.h, n, Lr, reads.ctypes.data_as(C.POINTER(C.c_uint8)), None, nthreads, st)
         s = C.string_at(p)
         self.L.gmo_free(p)
-        self.stats = dict(vec_calls=st[0], vec_cells=st[1], vec_bypassed=st[2], full_calls=st[3], reads_matched=st[4], dup_pruned=st[5])
+        self.stats = dict(vec_calls=st[0], vec_cells=st[1], vec_bypassed=st[2], full_calls=st[3], reads_matched=st[4], dup_pruned=st[5], local_retries=st[6])
         return s
 
     def tophits(self, reads, nthreads=4):
@@ -167,6 +167,10 @@ OPTION_CASES = {
     "seeds": ("cfg2s_100bp_2Mbp", "seeds=1111101111,110110110110111,1110100111010111;cutoff=40", dict(list_cutoff=40),
               ["1111101111", "110110110110111", "1110100111010111"]),
     "pairs_strata": ("stress_pairs_2x100", "strata=1;report=4", dict(strata=1, num_outputs=4), None),
+    # --local: sw_full_ls with local_alignment = 1 (soft clips), no mapping qualities (MAPQ 255, no Z0/Z1)
+    "local": ("stress_100bp_unal", "local=1", dict(local_alignment=1, sam_unaligned=1), None),
+    "local60": ("stress_60bp", "local=1;full-threshold=40;vec-threshold=40", dict(local_alignment=1, sw_full_threshold=40.0, sw_vect_threshold=40.0), None),
+    "local_cfg2": ("cfg2s_100bp_2Mbp", "local=1", dict(local_alignment=1), None),
 }
 
 

@@ -481,3 +481,23 @@ def test_colour_space_index_files_of_the_reference(gm, tmp_path):
         assert got == want, (suffix, len(got), len(want))
     with pytest.raises(gm.GmError):
         gm.Index.load(os.path.join(d, "idx"))               # a colour-space index is refused by a letter-space load
+
+
+def test_local_mode_long_reads_and_band_escape_vs_oracle(gm, oracle_lib):
+    """--local on 250 bp reads (four row stripes in the full SW) with indel-rich ends, so that some best local alignments leave
+    the anchor band and take the threshold-band second run (ref: sw-full-ls.c:395-398); against the CPU restatement"""
+    from shrimp_amd import synth
+    contigs = synth.make_genome([400_000, 200_000], 31)
+    reads, _ = synth.make_reads(contigs, 1200, 250, 32, p_sub=0.04, p_ins=0.01, p_del=0.01)
+    rng = np.random.default_rng(33)
+    reads[:, :40] = np.where(rng.random((reads.shape[0], 40)) < 0.5, rng.integers(0, 4, (reads.shape[0], 40)), reads[:, :40]).astype(np.uint8)   # ragged heads: clipped
+    o = oa.Session(contigs, opts="local=1"); o.set(True, True)
+    want = o.map_sam(reads, nthreads=4); o.close()
+    p = gm.default_params(); p.local_alignment = 1; p.sam_unaligned = 1
+    ix = gm.Index(contigs, params=p)
+    s = gm.Session(ix, params=p, max_batch_reads=512)
+    got = s.map_reads(reads)
+    st = s.stats
+    s.close(); ix.close()
+    assert got == want, (_first_diff(got, want), st)
+    assert b"S" in got.split(b"\t")[5] or got.count(b"S\t") > 100      # soft clips are there

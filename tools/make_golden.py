@@ -145,6 +145,9 @@ OPTION_CASES = {
                                         "-l", "80%", "-r", "50%", "-o", "6", "-a", "10", "--sam-unaligned"]),
     "seeds":     ("cfg2s_100bp_2Mbp", ["-s", "1111101111,110110110110111,1110100111010111", "-z", "40"]),
     "pairs_strata": ("stress_pairs_2x100", ["--strata", "-o", "4"]),
+    "local":     ("stress_100bp_unal", ["--local", "--sam-unaligned"]),
+    "local60":   ("stress_60bp", ["--local", "-h", "40%"]),
+    "local_cfg2": ("cfg2s_100bp_2Mbp", ["--local"]),
 }
 
 
