@@ -88,6 +88,7 @@ struct Params {
   int region_bits = 11, region_overlap = 50;
   uint32_t list_cutoff = 4294967295u;
   bool hash_filter_calls = true;  // -Z turns this off
+  bool gapless = false;           // -U: ungapped filter (gapless_sw; gmapper.c:2057-2062 also sets anchor_width 0, gap opens -255, no f1 cache)
   bool Tflag = true, Gflag = true, compute_mapping_qualities = true;
   bool strata = false;
   int max_alignments = 0;
@@ -446,6 +447,20 @@ static inline int sw_vector(const Params& P, const uint32_t* genome, llint goff,
     }
   }
   return score;
+}
+
+// sw_gapless (common/sw-gapless.c:57-117), letter space: best ungapped segment on the diagonal through (g_idx, r_idx) of the contig
+static inline int sw_gapless(const Params& P, const uint32_t* genome, int glen, const uint32_t* read, int rlen, int g_idx, int r_idx) {
+  int g_left, r_left;
+  if (g_idx < r_idx) { g_left = 0; r_left = r_idx - g_idx; } else { g_left = g_idx - r_idx; r_left = 0; }
+  int g_right = g_left, r_right = r_left, score = 0, max_score = 0;
+  while (g_right < glen && r_right < rlen) {
+    score += (EXTRACT(genome, g_right) == EXTRACT(read, r_right)) ? P.match_score : P.mismatch_score;
+    if (score > max_score) max_score = score;
+    g_right++; r_right++;
+    if (score < 0) score = 0;
+  }
+  return max_score;
 }
 
 // Colour-space vector SW (common/sw-vector.c:112-146 first row, then the same recurrence on colours; sw_vector :453-515).
@@ -1212,8 +1227,8 @@ struct Mapper {
       llint gstart = (gend >= re.window_len) ? gend - re.window_len : 0;
       int max_idx = i;
       int max_score = A[i].length * P.match_score;
-      if (P.match_mode == 2 && A[i].weight == 1) max_score = -1;
-      for (int j = i - 1; j >= 0 && A[j].x >= (llint)G->offsets[cn] + gstart; j--) {
+      if (!P.gapless && P.match_mode == 2 && A[i].weight == 1) max_score = -1;
+      for (int j = i - 1; !P.gapless && j >= 0 && A[j].x >= (llint)G->offsets[cn] + gstart; j--) {   // gapless: only the anchor itself (mapping.c:1095)
         if (A[j].y >= A[i].y) continue;
         int short_len, long_len;
         if (A[i].x - (llint)G->offsets[cn] - A[i].y > A[j].x - (llint)G->offsets[cn] - A[j].y) {
@@ -1226,7 +1241,7 @@ struct Mapper {
         else tmp_score = short_len * P.match_score;
         if (tmp_score > max_score) { max_idx = j; max_score = tmp_score; }
       }
-      if (P.match_mode == 1 ||
+      if (P.gapless || P.match_mode == 1 ||
           max_score >= (int)GMO_ABS_OR_PCT(P.window_gen_threshold, (re.read_len < w_len ? re.read_len : w_len) * P.match_score)) {
         int x_len = (int)(A[i].x - A[max_idx].x) + A[i].length;
         llint goff;
@@ -1258,13 +1273,15 @@ struct Mapper {
 
   // f1_run (common/f1-wrapper.h:97-134), gapped branch; genome_ls != nullptr selects the colour-space filter
   int f1_run(ThreadState& T, const uint32_t* genome, llint goff, int wlen, const uint32_t* read, int rlen, uint32_t tag,
-             const uint32_t* genome_ls = nullptr, int initbp = -1) const {
+             const uint32_t* genome_ls = nullptr, int initbp = -1, bool gapless_call = false, int gapless_glen = 0, int gapless_g_idx = 0,
+             int gapless_r_idx = 0) const {
     uint32_t hv = 0;
     if (P.hash_filter_calls && tag != 0) {
       hv = hash_genome_window(genome, (uint32_t)goff, (uint32_t)wlen) % f1_window_cache_size;
       if (T.f1_tag[hv] == tag) { T.stats.vec_bypassed++; return (int)T.f1_score[hv]; }
     }
-    int score = genome_ls ? sw_vector_cs(P, P.match_score + P.crossover_score, genome, goff, wlen, read, rlen, genome_ls, initbp)   // gmapper.c:2935
+    int score = gapless_call ? sw_gapless(P, genome, gapless_glen, read, rlen, gapless_g_idx, gapless_r_idx) :
+                genome_ls ? sw_vector_cs(P, P.match_score + P.crossover_score, genome, goff, wlen, read, rlen, genome_ls, initbp)   // gmapper.c:2935
                           : sw_vector(P, genome, goff, wlen, read, rlen);
     T.stats.vec_calls++; T.stats.vec_cells += (uint64_t)wlen * rlen;
     if (P.hash_filter_calls && tag != 0) { T.f1_tag[hv] = tag; T.f1_score[hv] = (uint32_t)score; }
@@ -1290,7 +1307,8 @@ struct Mapper {
           const uint32_t* gen_ls = (h.gen_st == 0 ? G->fwd[h.cn].data() : G->rc[h.cn].data());
           h.score_vector = f1_run(T, gen_cs, h.g_off, h.w_len, re.bits[h.st].data(), re.read_len, T.f1_hash_tag, gen_ls, re.initbp[st]);
         } else
-        h.score_vector = f1_run(T, G->fwd[h.cn].data(), h.g_off, h.w_len, re.bits[st].data(), re.read_len, T.f1_hash_tag);
+        h.score_vector = f1_run(T, G->fwd[h.cn].data(), h.g_off, h.w_len, re.bits[st].data(), re.read_len, T.f1_hash_tag, nullptr, -1,
+                                P.gapless, (int)G->len[h.cn], (int)(h.g_off + h.anchor.x), (int)h.anchor.y);     // mapping.c:1321-1328
         h.pct_score_vector = (1000 * 100 * h.score_vector) / h.score_max;
         if (h.score_vector >= (int)GMO_ABS_OR_PCT(P.sw_vect_threshold, h.score_max)) { last_good_cn = h.cn; last_good_g_off = (unsigned int)h.g_off_pos_strand; }
       }

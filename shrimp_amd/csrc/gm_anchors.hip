@@ -260,9 +260,9 @@ __device__ int k2_windows(const GmIndexDev& ix, const GmScoreDev& sc, K2Ws<BIG>&
       const long long gstart = (gend >= window_len) ? gend - window_len : 0;
       int max_idx = i;
       int max_score = leni * match;
-      if (sc.match_mode == 2 && wi == 1) max_score = -1;
+      if (!sc.gapless && sc.match_mode == 2 && wi == 1) max_score = -1;
       bool tie_sibling = false;        // another candidate with the argmax's x reached the same score
-      for (int j = i - 1; j >= 0; j--) {
+      for (int j = i - 1; !sc.gapless && j >= 0; j--) {           // -U: only the anchor itself, no threshold (ref: mapping.c:1070,1095,1154)
         const uint64_t aj = ws.key[j];
         const long long xj = (long long)(aj >> 32);
         if (xj < coff + gstart) break;
@@ -278,7 +278,7 @@ __device__ int k2_windows(const GmIndexDev& ix, const GmScoreDev& sc, K2Ws<BIG>&
         else if (DETECT && tmp == max_score && max_idx != i && xj == (long long)(ws.key[max_idx] >> 32)) tie_sibling = true;
       }
       const int base = (read_len < w_len ? read_len : w_len) * match;
-      if (sc.match_mode == 1 || max_score >= k2_threshold(sc.wgen_thr_frac, sc.wgen_abs, base)) {
+      if (sc.gapless || sc.match_mode == 1 || max_score >= k2_threshold(sc.wgen_thr_frac, sc.wgen_abs, base)) {
         const uint64_t am = ws.key[max_idx]; const uint32_t aum = ws.aux[max_idx];
         const long long xm = (long long)(am >> 32);
         if (DETECT && max_idx != i && (tie_sibling || xm == xi)) sens = true;          // case (a)

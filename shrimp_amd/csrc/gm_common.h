@@ -62,6 +62,7 @@ struct GmScoreDev {
   int num_tmp_outputs;
   int tiebreak_rev;
   int hash_filter_calls;
+  int gapless;                        // -U: ungapped pass-1 filter, one window per anchor (ref: gmapper.c:2057-2062)
   int local;                          // Gflag off: sw_full_ls in local mode (ref: gmapper.c:2303-2305)
   double wgen_thr_frac;               // window_gen_threshold/100.0 (or <0: absolute = -value)
   double vect_thr_frac, full_thr_frac;

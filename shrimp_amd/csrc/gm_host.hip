@@ -37,7 +37,7 @@ extern "C" void gm_params_default(gm_params_t* p) {
   p->match_mode = 2; p->num_outputs = 10; p->num_tmp_outputs = 30; p->anchor_width = 8;
   p->region_bits = 11; p->region_overlap = 50; p->list_cutoff = 0; p->hash_filter_calls = 1; p->tiebreak_rev = 1;
   p->sam_unaligned = 0; p->longest_read_len = 1000; p->strata = 0; p->max_alignments = 0;
-  p->colour_space = 0; p->crossover_score = -20; p->indel_taboo_len = 0; p->pr_xover = 0.03; p->local_alignment = 0;
+  p->colour_space = 0; p->crossover_score = -20; p->indel_taboo_len = 0; p->pr_xover = 0.03; p->local_alignment = 0; p->ungapped = 0;
 }
 // the gmapper-cs binary's defaults (ref: gmapper.c:1748-1755, gmapper-defaults.h:52-58,64-66)
 extern "C" void gm_params_default_cs(gm_params_t* p) {
@@ -51,7 +51,7 @@ static GmScoreDev make_score(const gm_params_t& P) {
   s.mismatch = P.colour_space ? P.match_score + P.crossover_score : P.mismatch_score;   // what f1_setup hands the vector filter (ref: gmapper.c:2933-2936)
   s.a_go = -P.a_gap_open_score; s.a_ge = -P.a_gap_extend_score; s.b_go = -P.b_gap_open_score; s.b_ge = -P.b_gap_extend_score;
   s.anchor_width = P.anchor_width; s.match_mode = P.match_mode; s.min_matches = P.match_mode;   // ref: gmapper.c:2625
-  s.num_tmp_outputs = P.num_tmp_outputs; s.tiebreak_rev = P.tiebreak_rev; s.hash_filter_calls = P.hash_filter_calls; s.local = P.local_alignment ? 1 : 0;
+  s.num_tmp_outputs = P.num_tmp_outputs; s.tiebreak_rev = P.tiebreak_rev; s.hash_filter_calls = P.hash_filter_calls; s.local = P.local_alignment ? 1 : 0; s.gapless = P.ungapped ? 1 : 0;
   auto frac = [](double thr, double* f, int* a) { if (thr < 0) { *f = -1.0; *a = (int)(-thr); } else { *f = thr / 100.0; *a = 0; } };
   frac(P.window_gen_threshold, &s.wgen_thr_frac, &s.wgen_abs);
   frac(P.sw_vect_threshold, &s.vect_thr_frac, &s.vect_abs);
@@ -380,7 +380,8 @@ static void choose_caps(gm_session* s, DevSet& D, int read_len) {
   D.scap = std::min(16384, std::max(256, pow2ceil((long long)(2.2 * expected) + 128)));
   D.hcap = 64;
   // K1b (exact isolation prune) shrinks K2's input; its LDS tier is sized for what typically remains
-  D.scap2 = (s->P.match_mode == 2 && !getenv("GM_NO_PRUNE")) ? std::max(std::min(D.scap, 256), D.scap / 8) : 0;
+  // K1b's bounds assume the window-generation threshold: not in -U mode
+  D.scap2 = (s->P.match_mode == 2 && !s->P.ungapped && !getenv("GM_NO_PRUNE")) ? std::max(std::min(D.scap, 256), D.scap / 8) : 0;
   if (const char* e = getenv("GM_SCAP")) D.scap = std::min(16384, std::max(64, pow2ceil(atoi(e))));
   if (const char* e = getenv("GM_SCAP2")) { if (D.scap2) D.scap2 = std::min(D.scap, std::max(64, pow2ceil(atoi(e)))); }
   if (const char* e = getenv("GM_HCAP")) D.hcap = std::min(32768, std::max(4, pow2ceil(atoi(e))));
@@ -406,6 +407,7 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   s->pr_ins_open = pow(2.0, (double)s->P.b_gap_open_score / s->score_alpha);
   s->pr_del_extend = pow(2.0, (double)s->P.a_gap_extend_score / s->score_alpha);
   s->pr_ins_extend = pow(2.0, ((double)s->P.b_gap_extend_score - s->score_beta) / s->score_alpha);
+  if (s->P.ungapped && !s->P.local_alignment) { delete s; gm_set_error("ungapped mode needs local alignment (ref: gmapper.c:2330-2333)"); return GM_E_ARG; }
   if (s->P.colour_space && s->P.local_alignment) { delete s; gm_set_error("local alignment is implemented for letter space only"); return GM_E_ARG; }
   if ((s->P.colour_space != 0) != (ix->params.colour_space != 0)) { delete s; gm_set_error("session and index disagree on colour space"); return GM_E_ARG; }
   s->max_batch = std::max(64, std::min(max_batch_reads > 0 ? max_batch_reads : 131072, 1 << 20));

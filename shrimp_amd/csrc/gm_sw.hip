@@ -141,6 +141,39 @@ __device__ void load_read(const uint32_t* __restrict__ rw, int read_len, bool rc
   }
 }
 
+// sw_gapless (ref: common/sw-gapless.c:57-117) by one wave, letter space: the best ungapped segment on the contig diagonal through
+// (g_idx, r_idx).  The reference's running score with reset below zero is the maximum-subarray sum: max over r of
+// P[r] - min(0, P[j] for j < r) on the prefix sums P of the per-base scores -- two wave scans per 64 cells.
+__device__ int sw_gapless_wave(const uint32_t* __restrict__ genome, uint64_t cbase, long long clen, const uint8_t* qr, int rlen,
+                               long long g_idx, int r_idx, const GmScoreDev& sc, int lane) {
+  long long g_left; int r_left;
+  if (g_idx < r_idx) { g_left = 0; r_left = (int)(r_idx - g_idx); } else { g_left = g_idx - r_idx; r_left = 0; }
+  const long long room = clen - g_left;
+  const int n = (int)(room < (long long)(rlen - r_left) ? room : (long long)(rlen - r_left));
+  int carry_sum = 0, carry_min = 0, best = 0;
+  for (int k0 = 0; k0 < n; k0 += GM_WAVE) {
+    const int k = k0 + lane;
+    int sv = 0;
+    if (k < n) {
+      const uint64_t p = cbase + (uint64_t)g_left + (uint64_t)k;
+      const uint32_t gc = (genome[p >> 3] >> ((p & 7) * 4)) & 0xf;
+      sv = (gc == (uint32_t)qr[r_left + k]) ? sc.match : sc.mismatch;
+    }
+    int ps = sv;
+    for (int d = 1; d < GM_WAVE; d <<= 1) { const int o = __shfl_up(ps, d); if (lane >= d) ps += o; }
+    ps += carry_sum;
+    int pm = ps;
+    for (int d = 1; d < GM_WAVE; d <<= 1) { const int o = __shfl_up(pm, d); if (lane >= d) pm = min(pm, o); }
+    int excl = __shfl_up(pm, 1); if (lane == 0) excl = INT_MAX;
+    excl = min(excl, carry_min);
+    if (k < n) best = max(best, ps - excl);
+    carry_sum = __shfl(ps, GM_WAVE - 1);
+    carry_min = min(carry_min, __shfl(pm, GM_WAVE - 1));
+  }
+  for (int d = 32; d > 0; d >>= 1) best = max(best, __shfl_xor(best, d));
+  return best;
+}
+
 // hash_genome_window % f1_window_cache_size (ref: common/util.h:224-245, common/hash.h:70-95, f1-wrapper.h:27)
 __device__ uint32_t window_hash_slot(const uint8_t* db, int glen, int lane) {
   const int nbuf = (glen + 15) >> 4;
@@ -258,8 +291,14 @@ k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
       if (found >= 0) { score = (int)(__hip_atomic_load(&SL[found], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32); bypass++; }
     }
     if (score < 0) {
-      score = sw_vector_wave_t<CS>(db, db0, w_len, qr, read_len, sc, carry, lane); computed = true;
-      calls++; cells += (unsigned long long)w_len * read_len;
+      if (!CS && sc.gapless) {                                                           // -U: f1_run's ungapped branch, ref: f1-wrapper.h:122-125, mapping.c:1321-1328
+        score = sw_gapless_wave(ix.genome, (uint64_t)ix.contig_off[cn], (long long)ix.contig_off[cn + 1] - ix.contig_off[cn], qr, read_len,
+                                (long long)goff + h->ax, h->ay, sc, lane);
+        calls++; cells += (unsigned long long)read_len;
+      } else {
+        score = sw_vector_wave_t<CS>(db, db0, w_len, qr, read_len, sc, carry, lane); computed = true;
+        calls++; cells += (unsigned long long)w_len * read_len;
+      }
       if (sc.hash_filter_calls) {
         if (lane == 0) __hip_atomic_store(&SL[n_comp], (unsigned long long)slot | ((unsigned long long)(uint32_t)score << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         n_comp++; __syncthreads();

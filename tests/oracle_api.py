@@ -171,6 +171,12 @@ OPTION_CASES = {
     "local": ("stress_100bp_unal", "local=1", dict(local_alignment=1, sam_unaligned=1), None),
     "local60": ("stress_60bp", "local=1;full-threshold=40;vec-threshold=40", dict(local_alignment=1, sw_full_threshold=40.0, sw_vect_threshold=40.0), None),
     "local_cfg2": ("cfg2s_100bp_2Mbp", "local=1", dict(local_alignment=1), None),
+    # -U: ungapped filter (sw_gapless) in pass 1, one window per anchor, anchor_width 0, gap opens -255, no f1 cache; needs --local
+    "ungapped": ("stress_100bp_unal", "local=1;ungapped=1", dict(local_alignment=1, ungapped=1, anchor_width=0, a_gap_open_score=-255, b_gap_open_score=-255,
+                                                                    hash_filter_calls=0, sam_unaligned=1), None),
+    "ungapped60_n1": ("stress_60bp", "local=1;ungapped=1;cmw-mode=1;full-threshold=45;vec-threshold=45",
+                      dict(local_alignment=1, ungapped=1, anchor_width=0, a_gap_open_score=-255, b_gap_open_score=-255, hash_filter_calls=0, match_mode=1,
+                           sw_full_threshold=45.0, sw_vect_threshold=45.0), None),
 }
 
 

@@ -148,6 +148,8 @@ OPTION_CASES = {
     "local":     ("stress_100bp_unal", ["--local", "--sam-unaligned"]),
     "local60":   ("stress_60bp", ["--local", "-h", "40%"]),
     "local_cfg2": ("cfg2s_100bp_2Mbp", ["--local"]),
+    "ungapped":  ("stress_100bp_unal", ["--local", "-U", "--sam-unaligned"]),
+    "ungapped60_n1": ("stress_60bp", ["--local", "-U", "-n", "1", "-h", "45%"]),
 }
 
 
