@@ -69,6 +69,8 @@ typedef struct gm_params {
   int ungapped;                                /* -U (gapless_sw): pass 1 scores windows with sw_gapless (ref: sw-gapless.c:57-117), every anchor opens a window
                                                   (mapping.c:1095,1154).  As the reference's -U does, also set anchor_width 0, both gap opens -255 and
                                                   hash_filter_calls 0; requires local_alignment (gmapper.c:2330-2333).  0 */
+  int hash_seeds;                              /* -H (Hflag): lists are keyed by kmer_to_mapidx_hash -- 4^12 lists per seed whatever its weight, so seeds
+                                                  heavier than 14 are allowed (ref: gmapper.h:309-336, seeds.c:83-102,132-136).  An index property.  0 */
 } gm_params_t;
 
 void gm_params_default(gm_params_t *p);        /* letter-space defaults of the reference binary (gmapper-ls) */

@@ -88,6 +88,7 @@ struct Params {
   int region_bits = 11, region_overlap = 50;
   uint32_t list_cutoff = 4294967295u;
   bool hash_filter_calls = true;  // -Z turns this off
+  bool Hflag = false;             // -H: hashed seeds (kmer_to_mapidx_hash, 4^12 lists per seed whatever its weight; gmapper.h:323-336)
   bool gapless = false;           // -U: ungapped filter (gapless_sw; gmapper.c:2057-2062 also sets anchor_width 0, gap opens -255, no f1 cache)
   bool Tflag = true, Gflag = true, compute_mapping_qualities = true;
   bool strata = false;
@@ -203,6 +204,26 @@ static inline uint32_t kmer_to_mapidx(const Seed& sd, GetBase base_at, llint end
   return mapidx;
 }
 
+// -H: hash() and kmer_to_mapidx_hash (gmapper/gmapper.h:309-336) with seed_hash_mask (seeds.c:83-102).  The reference hashes the
+// 4-bit window words (newest base in nibble 0 of word 0) masked to the seed's 1-positions, over BPTO32BW(max_seed_span) words.
+static const int HASH_TABLE_POWER = 12;
+static inline uint32_t hash32(uint32_t a) {
+  a = (a + 0x7ed55d16) + (a << 12); a = (a ^ 0xc761c23c) ^ (a >> 19); a = (a + 0x165667b1) + (a << 5);
+  a = (a + 0xd3a2646c) ^ (a << 9); a = (a + 0xfd7046c5) + (a << 3); a = (a ^ 0xb55a4f09) ^ (a >> 16);
+  return a;
+}
+template <class GetBase>
+static inline uint32_t kmer_to_mapidx_hash(const Seed& sd, int max_seed_span, GetBase base_at, llint end) {
+  uint32_t mapidx = 0;
+  for (int w = 0; w < BPTO32BW(max_seed_span); w++) {
+    uint32_t word = 0;
+    for (int t = 0; t < 8; t++) { const int age = 8 * w + t; if (age < sd.span && ((sd.mask >> age) & 1)) word |= (uint32_t)(base_at(end - age) & 0xf) << (4 * t); }
+    mapidx = hash32(word ^ mapidx);
+  }
+  return mapidx & ((1u << (2 * HASH_TABLE_POWER)) - 1u);
+}
+static inline int index_key_bits(const Params& P, const Seed& sd) { return P.Hflag ? 2 * HASH_TABLE_POWER : 2 * sd.weight; }   // genome.c:1034
+
 struct Index {                    // genomemap / genomemap_len in CSR form (lists ascending, genome.c:1156-1163)
   std::vector<std::vector<uint32_t>> start;   // [sn][4^W + 1]  (total entries per seed < 2^32: positions are uint32)
   std::vector<std::vector<uint32_t>> pos;     // [sn][total]
@@ -225,7 +246,7 @@ static inline void build_index_seq(const Params& P, const Genome& G, Index& I) {
 #pragma omp parallel for schedule(dynamic, 1)
   for (int sn = 0; sn < ns; sn++) {
     const Seed& sd = P.seeds[sn];
-    size_t cap = (size_t)1 << (2 * sd.weight);
+    size_t cap = (size_t)1 << index_key_bits(P, sd);
     std::vector<uint32_t>& st = I.start[sn];
     st.assign(cap + 1, 0);
     int sel[64], nsel = 0;                       // ages (0 = newest base) of the mask's 1-bits, LSB first
@@ -247,7 +268,7 @@ static inline void build_index_seq(const Params& P, const Genome& G, Index& I) {
           w = (w >> 2) | ((uint64_t)(base & 3) << 62);
           if (base == 15) load = 0; else if (load < P.max_seed_span) load++;
           if (load < sd.span) continue;
-          uint32_t mi = mapidx_from_window(w, sel, nsel);
+          uint32_t mi = P.Hflag ? kmer_to_mapidx_hash(sd, P.max_seed_span, [&](llint q) { return EXTRACT(g, q); }, (llint)p) : mapidx_from_window(w, sel, nsel);
           if (pass == 0) st[mi]++;
           else I.pos[sn][fill[mi]++] = G.offsets[cn] + p - sd.span + 1;
         }
@@ -281,7 +302,7 @@ static inline void build_index(const Params& P, const Genome& G, Index& I, int n
   }
   std::vector<std::vector<int>> sel(ns); std::vector<size_t> cap(ns);
   for (int sn = 0; sn < ns; sn++) {
-    cap[sn] = (size_t)1 << (2 * P.seeds[sn].weight);
+    cap[sn] = (size_t)1 << index_key_bits(P, P.seeds[sn]);
     for (int t = 0; t < P.seeds[sn].span; t++) if ((P.seeds[sn].mask >> t) & 1) sel[sn].push_back(t);
   }
   I.start.assign(ns, {}); I.pos.assign(ns, {});
@@ -297,7 +318,8 @@ static inline void build_index(const Params& P, const Genome& G, Index& I, int n
         w = (w >> 2) | ((uint64_t)(base & 3) << 62);
         if (base == 15) load = 0; else if (load < P.max_seed_span) load++;      // genome.c:1139-1154
         if (p < pc.a || load < sd.span) continue;
-        emit(mapidx_from_window(w, sel[sn].data(), (int)sel[sn].size()), G.offsets[pc.cn] + p - sd.span + 1);
+        emit(P.Hflag ? kmer_to_mapidx_hash(sd, P.max_seed_span, [&](llint q) { return EXTRACT(g, q); }, (llint)p) : mapidx_from_window(w, sel[sn].data(), (int)sel[sn].size()),
+             G.offsets[pc.cn] + p - sd.span + 1);
       }
     }
   };
@@ -308,7 +330,7 @@ static inline void build_index(const Params& P, const Genome& G, Index& I, int n
   for (int sn = 0; sn < ns; sn++) {
     const bool vb = getenv("GMO_VERBOSE") != nullptr; double tv = omp_get_wtime();
     auto lap = [&](const char* what) { if (vb) { const double n = omp_get_wtime(); fprintf(stderr, "  seed %d %s %.2f s\n", sn, what, n - tv); tv = n; } };
-    const int kbits = 2 * P.seeds[sn].weight, lo_bits = std::min(kbits, 12), nb = 1 << (kbits - lo_bits);
+    const int kbits = index_key_bits(P, P.seeds[sn]), lo_bits = std::min(kbits, 12), nb = 1 << (kbits - lo_bits);
     std::vector<std::vector<uint64_t>> cur(T, std::vector<uint64_t>(nb, 0));
 #pragma omp parallel for schedule(static, 1) num_threads(T)
     for (int t = 0; t < T; t++) { uint64_t* c = cur[t].data(); scan(t, sn, [&](uint32_t mi, uint32_t) { c[mi >> lo_bits]++; }); }
@@ -346,6 +368,7 @@ static inline void build_index(const Params& P, const Genome& G, Index& I, int n
 static inline uint32_t auto_list_cutoff(const Params& P, const Genome& G) {
   unsigned long long tot = 0; for (auto l : G.len) tot += l;
   int maxw = 0; for (auto& s : P.seeds) maxw = std::max(maxw, s.weight);
+  if (P.Hflag) maxw = HASH_TABLE_POWER;                      // gmapper.c:2820-2822
   uint32_t cutoff = 1000;
   unsigned long long p4 = 1ull << (2 * maxw);
   if ((uint32_t)((100ull * tot) / p4) > cutoff) cutoff = (uint32_t)((100ull * tot) / p4);
@@ -1102,7 +1125,8 @@ struct Mapper {
         for (int sn = 0; sn < ns; sn++) {
           if (i < re.min_kmer_pos + P.seeds[sn].span - 1) continue;
           int r_idx = i - P.seeds[sn].span + 1;
-          re.mapidx[st][sn * re.max_n_kmers + (r_idx - re.min_kmer_pos)] =
+          re.mapidx[st][sn * re.max_n_kmers + (r_idx - re.min_kmer_pos)] = P.Hflag ?
+              kmer_to_mapidx_hash(P.seeds[sn], P.max_seed_span, [&](llint q) { return EXTRACT(r, q); }, i) :
               kmer_to_mapidx(P.seeds[sn], [&](llint q) { return EXTRACT(r, q); }, i);
         }
     }

@@ -194,6 +194,7 @@ static void apply_opts(Params& P, const char* opts) {
     else if (k == "max-alignments") P.max_alignments = (int)d;
     else if (k == "local") { P.Gflag = d == 0; if (!P.Gflag) P.compute_mapping_qualities = false; }   // --local (gmapper.c:2303-2305,2325-2328)
     else if (k == "ungapped") { if (d != 0) { P.gapless = true; P.anchor_width = 0; P.a_gap_open_score = -255; P.b_gap_open_score = -255; P.hash_filter_calls = false; } }   // -U (gmapper.c:2057-2062)
+    else if (k == "hash-spaced-kmers") P.Hflag = d != 0;     // -H
     else if (k == "crossover") P.crossover_score = (int)d; else if (k == "indel-taboo-len") P.indel_taboo_len = (int)d;
     else if (k == "seeds") {
       P.seeds.clear(); P.max_seed_span = 0; P.min_seed_span = 64;

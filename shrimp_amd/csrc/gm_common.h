@@ -43,6 +43,7 @@ struct GmIndexDev {
   const uint32_t* genome;
   const uint32_t* genome_cs;          // colour space only: colour p = lstocs(letter p-1, letter p), 'T' before a contig's first letter (ref: fasta.c:586-606)
   int colour;                         // 1 in colour space (== min_kmer_pos, ref: gmapper.c:477-480)
+  int hflag;                          // -H: lists are keyed by kmer_to_mapidx_hash, 4^12 of them per seed (ref: gmapper.h:323-336)
   uint64_t total_len;                 // sum of contig lengths (< 2^32)
   int n_contigs;
   const uint32_t* contig_off;         // [n_contigs+1] global offsets (ref: contig_offsets[])
@@ -112,6 +113,31 @@ __device__ __forceinline__ uint32_t gm_read_code(const uint32_t* __restrict__ rw
   uint32_t c = (rw[src >> 3] >> ((src & 7) * 4)) & 0xf;
   if (st) { const uint64_t cm = 0xFBCDE56879A00123ull; c = (uint32_t)(cm >> (c * 4)) & 0xf; }   // complement_base, ref: util.h:125-151
   return c;
+}
+
+// Map index of the k-mer whose bases are kmer[0 .. span) (one 4-bit code per byte).  Default: kmer_to_mapidx_orig (ref: gmapper.h:349-368):
+// walk the mask from its LSB (= the most recent base), every 1-bit appends the base's low 2 bits.  -H: kmer_to_mapidx_hash (ref: :323-336):
+// the 4-bit window words (newest base in nibble 0 of word 0), masked to the seed's 1-positions (seed_hash_mask, seeds.c:83-102), folded through
+// hash() over BPTO32BW(max_seed_span) words, low 24 bits.
+#define GM_HASH_TABLE_POWER 12
+__host__ __device__ __forceinline__ uint32_t gm_hash32(uint32_t a) {   // ref: gmapper.h:309-319
+  a = (a + 0x7ed55d16u) + (a << 12); a = (a ^ 0xc761c23cu) ^ (a >> 19); a = (a + 0x165667b1u) + (a << 5);
+  a = (a + 0xd3a2646cu) ^ (a << 9); a = (a + 0xfd7046c5u) + (a << 3); a = (a ^ 0xb55a4f09u) ^ (a >> 16);
+  return a;
+}
+__device__ __forceinline__ uint32_t gm_mapidx(const GmIndexDev& ix, uint64_t mask, int span, const uint8_t* kmer) {
+  uint32_t mapidx = 0;
+  if (!ix.hflag) {
+    for (int t = 0; t < span; t++) if ((mask >> t) & 1) mapidx = (mapidx << 2) | (kmer[span - 1 - t] & 3u);
+    return mapidx;
+  }
+  const int nw = (ix.max_seed_span + 7) >> 3;
+  for (int w = 0; w < nw; w++) {
+    uint32_t word = 0;
+    for (int t = 0; t < 8; t++) { const int age = 8 * w + t; if (age < span && ((mask >> age) & 1)) word |= (uint32_t)(kmer[span - 1 - age] & 0xfu) << (4 * t); }
+    mapidx = gm_hash32(word ^ mapidx);
+  }
+  return mapidx & ((1u << (2 * GM_HASH_TABLE_POWER)) - 1u);
 }
 
 static inline int gm_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

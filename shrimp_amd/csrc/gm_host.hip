@@ -37,7 +37,7 @@ extern "C" void gm_params_default(gm_params_t* p) {
   p->match_mode = 2; p->num_outputs = 10; p->num_tmp_outputs = 30; p->anchor_width = 8;
   p->region_bits = 11; p->region_overlap = 50; p->list_cutoff = 0; p->hash_filter_calls = 1; p->tiebreak_rev = 1;
   p->sam_unaligned = 0; p->longest_read_len = 1000; p->strata = 0; p->max_alignments = 0;
-  p->colour_space = 0; p->crossover_score = -20; p->indel_taboo_len = 0; p->pr_xover = 0.03; p->local_alignment = 0; p->ungapped = 0;
+  p->colour_space = 0; p->crossover_score = -20; p->indel_taboo_len = 0; p->pr_xover = 0.03; p->local_alignment = 0; p->ungapped = 0; p->hash_seeds = 0;
 }
 // the gmapper-cs binary's defaults (ref: gmapper.c:1748-1755, gmapper-defaults.h:52-58,64-66)
 extern "C" void gm_params_default_cs(gm_params_t* p) {
@@ -62,7 +62,7 @@ static GmScoreDev make_score(const gm_params_t& P) {
 // ---- index ------------------------------------------------------------------------------------
 GmIndexDev GmIndexHost::dev_view() const {
   GmIndexDev d; memset(&d, 0, sizeof d);
-  d.genome = d_genome; d.genome_cs = d_genome_cs; d.colour = params.colour_space ? 1 : 0; d.total_len = total_len; d.n_contigs = n_contigs; d.contig_off = d_contig_off;
+  d.genome = d_genome; d.genome_cs = d_genome_cs; d.colour = params.colour_space ? 1 : 0; d.hflag = params.hash_seeds ? 1 : 0; d.total_len = total_len; d.n_contigs = n_contigs; d.contig_off = d_contig_off;
   d.n_seeds = n_seeds; d.min_seed_span = min_seed_span; d.max_seed_span = max_seed_span;
   d.slab_bits = slab_bits; d.n_slabs = n_slabs; d.region_bits = params.region_bits; d.region_overlap = params.region_overlap;
   d.list_cutoff = list_cutoff;
@@ -82,7 +82,8 @@ static int add_seed(GmIndexHost* ix, const char* s) {   // add_spaced_seed, ref:
     if (s[i] != '0' && s[i] != '1') return GM_E_ARG;
     sd.mask = (sd.mask << 1) | (uint64_t)(s[i] == '1'); sd.weight += (s[i] == '1');
   }
-  if (sd.weight < 1 || sd.weight > 14) return GM_E_ARG;   // MAX_SEED_WEIGHT, ref: gmapper-definitions.h:52
+  if (sd.weight < 1 || (!ix->params.hash_seeds && sd.weight > 14)) return GM_E_ARG;   // MAX_SEED_WEIGHT, ref: gmapper-definitions.h:50, seeds.c:132-136
+  sd.kbits = ix->params.hash_seeds ? 2 * GM_HASH_TABLE_POWER : 2 * sd.weight;
   ix->max_seed_span = std::max(ix->max_seed_span, sd.span);
   ix->min_seed_span = std::min(ix->min_seed_span, sd.span);
   ix->n_seeds++;
@@ -115,6 +116,7 @@ static int index_prepare(gm_index* ix, int n_contigs, const uint32_t* const* con
   // automatic list cutoff (ref: gmapper.c:2811-2837): max(1000, 100*total/4^maxW)
   if (ix->params.list_cutoff == 0) {
     int maxw = 0; for (int i = 0; i < ix->n_seeds; i++) maxw = std::max(maxw, ix->seeds[i].weight);
+    if (ix->params.hash_seeds) maxw = GM_HASH_TABLE_POWER;            // ref: gmapper.c:2820-2822
     uint32_t cutoff = 1000; unsigned long long p4 = 1ull << (2 * maxw);
     if ((uint32_t)((100ull * tot) / p4) > cutoff) cutoff = (uint32_t)((100ull * tot) / p4);
     ix->list_cutoff = cutoff;
@@ -177,11 +179,11 @@ extern "C" int gm_index_n_slabs(const gm_index_t* ix) { return ix->n_slabs; }
 extern "C" int gm_index_has_buckets(const gm_index_t* ix) { return ix->seeds[0].d_bkt != nullptr; }
 extern "C" uint64_t gm_index_bytes(const gm_index_t* ix) {
   uint64_t b = ix->genome_words * 4 * (ix->d_genome_cs ? 2 : 1);
-  for (int i = 0; i < ix->n_seeds; i++) b += (ix->seeds[i].dir_words + (uint64_t)ix->seeds[i].n_pos + (ix->seeds[i].d_bkt ? (16ull << (2 * ix->seeds[i].weight)) : 0ull)) * 4;
+  for (int i = 0; i < ix->n_seeds; i++) b += (ix->seeds[i].dir_words + (uint64_t)ix->seeds[i].n_pos + (ix->seeds[i].d_bkt ? (16ull << ix->seeds[i].kbits) : 0ull)) * 4;
   return b;
 }
 extern "C" int gm_index_get_list(const gm_index_t* ix, int sn, uint32_t mapidx, uint32_t* len, uint32_t* positions, uint32_t cap) {
-  if (sn < 0 || sn >= ix->n_seeds || mapidx >= (1u << (2 * ix->seeds[sn].weight))) return GM_E_ARG;
+  if (sn < 0 || sn >= ix->n_seeds || mapidx >= (1u << ix->seeds[sn].kbits)) return GM_E_ARG;
   GM_HIP(hipSetDevice(ix->device));
   uint32_t be[2];
   GM_HIP(hipMemcpy(&be[0], ix->seeds[sn].d_dir + (size_t)mapidx * ix->n_slabs, 4, hipMemcpyDeviceToHost));
@@ -197,7 +199,7 @@ extern "C" int gm_index_device_array(const gm_index_t* ix, int kind, void** dev_
   const int sn = (kind - 1) / 3, what = (kind - 1) % 3; if (kind < 0 || sn < 0 || sn >= ix->n_seeds) return GM_E_ARG;
   if (what == 0) { *dev_ptr = ix->seeds[sn].d_dir; *bytes = (ix->seeds[sn].dir_words + 16) * 4; }
   else if (what == 1) { *dev_ptr = ix->seeds[sn].d_pos; *bytes = ((uint64_t)ix->seeds[sn].n_pos + 64) * 4; }
-  else { *dev_ptr = ix->seeds[sn].d_bkt; *bytes = ix->seeds[sn].d_bkt ? (16ull << (2 * ix->seeds[sn].weight)) * 4 : 0; }
+  else { *dev_ptr = ix->seeds[sn].d_bkt; *bytes = ix->seeds[sn].d_bkt ? (16ull << ix->seeds[sn].kbits) * 4 : 0; }
   return GM_OK;
 }
 
@@ -239,7 +241,7 @@ extern "C" int gm_index_alloc_like(gm_index_t** out, int device, const void* met
     ix->seeds[i].n_pos = h.n_pos[i]; ix->seeds[i].dir_words = h.dir_words[i];
     GM_HIP(hipMalloc(&ix->seeds[i].d_dir, (h.dir_words[i] + 16) * 4));
     GM_HIP(hipMalloc(&ix->seeds[i].d_pos, ((uint64_t)h.n_pos[i] + 64) * 4));
-    if (h.has_bkt[i]) GM_HIP(hipMalloc(&ix->seeds[i].d_bkt, (16ull << (2 * ix->seeds[i].weight)) * 4));
+    if (h.has_bkt[i]) GM_HIP(hipMalloc(&ix->seeds[i].d_bkt, (16ull << ix->seeds[i].kbits) * 4));
   }
   *out = ix;
   return GM_OK;
@@ -370,7 +372,7 @@ static void choose_caps(gm_session* s, DevSet& D, int read_len) {
   double lists = 0, avg_len = 0;
   for (int i = 0; i < ix->n_seeds; i++) {
     lists += std::max(0, read_len - ix->seeds[i].span + 1);
-    avg_len += (double)ix->seeds[i].n_pos / (double)(1ull << (2 * ix->seeds[i].weight)) / ix->n_seeds;
+    avg_len += (double)ix->seeds[i].n_pos / (double)(1ull << ix->seeds[i].kbits) / ix->n_seeds;
   }
   const double entries = lists * avg_len;
   const double region = (double)(1 << ix->params.region_bits) + ix->params.region_overlap;

@@ -17,10 +17,10 @@ __device__ __forceinline__ uint32_t gm_nib(const uint32_t* g, uint64_t p) { retu
 
 __global__ void __launch_bounds__(256) k_emit_keys(const uint32_t* __restrict__ genome, uint64_t total_len,
                                                    const uint32_t* __restrict__ contig_off, int n_contigs,
-                                                   uint64_t mask, int span, int weight, uint32_t* __restrict__ keys) {
+                                                   uint64_t mask, int span, int kbits, int hflag, int max_seed_span, uint32_t* __restrict__ keys) {
   uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint32_t invalid = 1u << (2 * weight);
+  const uint32_t invalid = 1u << kbits;
   for (; q < total_len; q += stride) {
     // contig of q: largest cn with contig_off[cn] <= q
     int lo = 0, hi = n_contigs;
@@ -30,15 +30,26 @@ __global__ void __launch_bounds__(256) k_emit_keys(const uint32_t* __restrict__ 
     if (q + span <= cend) {
       // bases q .. q+span-1; mask bit i <-> base at q+span-1-i
       uint32_t mapidx = 0; bool has_n = false;
-      uint64_t a = mask; int i = 0;
       // N/X anywhere inside the span (also under a 0 of the mask) resets the reference's `load`
       // counter (ref: genome.c:1147-1150), so the whole span must be free of code 15.
-      for (int t = 0; t < span; t++) {
-        uint32_t b = gm_nib(genome, q + span - 1 - t);
-        has_n |= (b == 15u);
-        if ((a >> t) & 1) { mapidx = (mapidx << 2) | (b & 3u); }
+      if (!hflag) {
+        for (int t = 0; t < span; t++) {
+          uint32_t b = gm_nib(genome, q + span - 1 - t);
+          has_n |= (b == 15u);
+          if ((mask >> t) & 1) { mapidx = (mapidx << 2) | (b & 3u); }
+        }
+      } else {                                       // kmer_to_mapidx_hash, ref: gmapper.h:323-336 (see gm_mapidx in gm_common.h)
+        const int nw = (max_seed_span + 7) >> 3;
+        for (int w = 0; w < nw; w++) {
+          uint32_t word = 0;
+          for (int t = 0; t < 8; t++) {
+            const int age = 8 * w + t;
+            if (age < span) { const uint32_t b = gm_nib(genome, q + span - 1 - age); has_n |= (b == 15u); if ((mask >> age) & 1) word |= b << (4 * t); }
+          }
+          mapidx = gm_hash32(word ^ mapidx);
+        }
+        mapidx &= (1u << (2 * GM_HASH_TABLE_POWER)) - 1u;
       }
-      (void)i;
       if (!has_n) key = mapidx;
     }
     keys[q] = key;
@@ -98,7 +109,7 @@ __global__ void __launch_bounds__(256) k_dir_from_lists(const uint32_t* __restri
 // uploads one seed's lists as read from a reference index file (lens[4^w], positions back to back, each list ascending)
 int gm_index_from_lists_device(GmIndexHost* ix, int sn, const uint32_t* lens, const uint32_t* pos, uint32_t total) {
   GmSeedHost& sd = ix->seeds[sn];
-  const uint64_t K = 1ull << (2 * sd.weight);
+  const uint64_t K = 1ull << sd.kbits;
   const uint64_t KS = K * (uint64_t)ix->n_slabs;
   std::vector<uint32_t> start(K + 1);
   uint64_t acc = 0;
@@ -165,18 +176,18 @@ int gm_index_build_device(GmIndexHost* ix, hipStream_t stream) {
   size_t tmp_bytes = 0;
   rocprim::counting_iterator<uint32_t> iota(0);
   int maxbits = 0;
-  for (int sn = 0; sn < ix->n_seeds; sn++) maxbits = std::max(maxbits, 2 * ix->seeds[sn].weight + 1);
+  for (int sn = 0; sn < ix->n_seeds; sn++) maxbits = std::max(maxbits, ix->seeds[sn].kbits + 1);
   hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, iota, vals_b, (size_t)n, 0, maxbits, stream);
   if (e != hipSuccess) { gm_set_error("radix_sort_pairs size query: %s", hipGetErrorString(e)); return GM_E_NODEVICE; }
   GM_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
   const int grid = 256 * 16;
   for (int sn = 0; sn < ix->n_seeds; sn++) {
     GmSeedHost& sd = ix->seeds[sn];
-    const uint64_t K = 1ull << (2 * sd.weight);
+    const uint64_t K = 1ull << sd.kbits;
     const uint64_t KS = K * (uint64_t)ix->n_slabs;
     hipLaunchKernelGGL(k_emit_keys, dim3(grid), dim3(256), 0, stream, d_seq, n, ix->d_contig_off, ix->n_contigs,
-                       sd.mask, sd.span, sd.weight, keys_a);
-    e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_a, keys_b, iota, vals_b, (size_t)n, 0, 2 * sd.weight + 1, stream);
+                       sd.mask, sd.span, sd.kbits, ix->params.hash_seeds ? 1 : 0, ix->max_seed_span, keys_a);
+    e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_a, keys_b, iota, vals_b, (size_t)n, 0, sd.kbits + 1, stream);
     if (e != hipSuccess) { gm_set_error("radix_sort_pairs: %s", hipGetErrorString(e)); return GM_E_NODEVICE; }
     hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(64), 0, stream, keys_b, n, (uint32_t)K, d_cnt);
     uint32_t n_valid = 0;

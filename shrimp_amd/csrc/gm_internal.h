@@ -4,6 +4,7 @@
 
 struct GmSeedHost {
   uint64_t mask = 0; int span = 0, weight = 0;
+  int kbits = 0;                        // log2(number of lists): 2 * weight, or 24 with -H (ref: genome.c:1034)
   uint32_t* d_dir = nullptr; uint32_t* d_pos = nullptr; uint32_t* d_bkt = nullptr;
   uint32_t n_pos = 0; uint64_t dir_words = 0;
   std::string text;

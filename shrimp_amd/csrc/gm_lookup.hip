@@ -104,9 +104,7 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
     const int span = ix.seed[sn].span;
     if (i >= ix.colour && i + span <= read_len) {           // colour space: min_kmer_pos = 1 (ref: gmapper.c:477-480)
       const uint64_t mask = ix.seed[sn].mask;
-      uint32_t mapidx = 0;
-      for (int t = 0; t < span; t++)
-        if ((mask >> t) & 1) mapidx = (mapidx << 2) | (codes[i + span - 1 - t] & 3u);
+      const uint32_t mapidx = gm_mapidx(ix, mask, span, codes + i);
       k = mapidx * (uint32_t)S;
       my_lookups++;
       if (BKT) {
@@ -353,8 +351,7 @@ k_lookup_bkt(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int
   const uint32_t* plist = nullptr;
   if (tid < NL && i >= ix.colour && i + ix.seed[sn].span <= read_len) {
     const int span = ix.seed[sn].span; const uint64_t mask = ix.seed[sn].mask;
-    uint32_t mapidx = 0;
-    for (int t = 0; t < span; t++) if ((mask >> t) & 1) mapidx = (mapidx << 2) | (codes[i + span - 1 - t] & 3u);
+    const uint32_t mapidx = gm_mapidx(ix, mask, span, codes + i);
     const uint4* bk = (const uint4*)(ix.seed[sn].bkt + (size_t)mapidx * 16);
     q0 = bk[0]; q1 = bk[1]; q2 = bk[2]; q3 = bk[3];
     lookups = 1;
@@ -484,9 +481,7 @@ k_lookup_v3(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
     const int span = ix.seed[sn].span;
     if (i < ix.colour || i + span > read_len) continue;
     const uint64_t mask = ix.seed[sn].mask;
-    uint32_t mapidx = 0;
-    for (int t = 0; t < span; t++)
-      if ((mask >> t) & 1) mapidx = (mapidx << 2) | (codes[i + span - 1 - t] & 3u);
+    const uint32_t mapidx = gm_mapidx(ix, mask, span, codes + i);
     const uint32_t* dir = ix.seed[sn].dir + (size_t)mapidx * (uint32_t)S;
     my_lookups++;
     const uint32_t b = dir[0], e = dir[S];
@@ -754,9 +749,7 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
       const int span = ix.seed[sn].span;
       if (i < ix.colour || i + span > read_len) continue;
       const uint64_t mask = ix.seed[sn].mask;
-      uint32_t mapidx = 0;
-      for (int t = 0; t < span; t++)
-        if ((mask >> t) & 1) mapidx = (mapidx << 2) | (codes[i + span - 1 - t] & 3u);
+      const uint32_t mapidx = gm_mapidx(ix, mask, span, codes + i);
       const uint32_t* dir = ix.seed[sn].dir + (size_t)mapidx * (uint32_t)S;
       my_lookups++;
       const uint32_t b = dir[0], e = dir[S];

@@ -177,6 +177,10 @@ OPTION_CASES = {
     "ungapped60_n1": ("stress_60bp", "local=1;ungapped=1;cmw-mode=1;full-threshold=45;vec-threshold=45",
                       dict(local_alignment=1, ungapped=1, anchor_width=0, a_gap_open_score=-255, b_gap_open_score=-255, hash_filter_calls=0, match_mode=1,
                            sw_full_threshold=45.0, sw_vect_threshold=45.0), None),
+    # -H: hashed seeds (4^12 lists per seed, any weight)
+    "hashed": ("stress_60bp", "hash-spaced-kmers=1", dict(hash_seeds=1), None),
+    "hashed_w16": ("cfg2s_100bp_2Mbp", "hash-spaced-kmers=1;seeds=11111111101111111,1111110111011101111,111101110010000101111011", dict(hash_seeds=1),
+                   ["11111111101111111", "1111110111011101111", "111101110010000101111011"]),
 }
 
 

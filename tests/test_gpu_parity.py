@@ -501,3 +501,27 @@ def test_local_mode_long_reads_and_band_escape_vs_oracle(gm, oracle_lib):
     s.close(); ix.close()
     assert got == want, (_first_diff(got, want), st)
     assert b"S" in got.split(b"\t")[5] or got.count(b"S\t") > 100      # soft clips are there
+
+
+def test_hashed_seed_index_files_of_the_reference(gm, tmp_path):
+    """-H index files (4^12 lists per seed, weight-13 and weight-16 seeds): loaded here they give the SAM of the reference's -L run;
+    saved here they are the same bytes; and the mode flags are checked on load"""
+    import gzip
+    d, contigs, names, reads, seeds, sam = _idxfix("idxfix_h")
+    p = gm.default_params(); p.hash_seeds = 1
+    ix = gm.Index.load(os.path.join(d, "idx"), params=p)
+    s = gm.Session(ix, params=p, max_batch_reads=1024)
+    got = oa.sam_header(contigs, names) + s.map_reads(reads)
+    s.close(); ix.close()
+    assert got == sam, _first_diff(got, sam)
+    ix = gm.Index(contigs, names=names, seeds=seeds, params=p)
+    ix.save(str(tmp_path / "mine"))
+    ix.close()
+    for suffix in (".genome", ".seed.0", ".seed.1"):
+        with gzip.open(os.path.join(d, "idx" + suffix), "rb") as f: want = f.read()
+        with gzip.open(str(tmp_path / ("mine" + suffix)), "rb") as f: got = f.read()
+        assert got == want, (suffix, len(got), len(want))
+    with pytest.raises(gm.GmError):
+        gm.Index.load(os.path.join(d, "idx"))                       # a hashed index is refused by a plain load
+    with pytest.raises(gm.GmError):
+        gm.Index(contigs, names=names, seeds=seeds)                 # a weight-16 seed needs -H

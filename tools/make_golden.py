@@ -178,26 +178,30 @@ def option_cases():
 
 
 def index_cases():
-    """the reference's own index files (-S) for a tiny genome + the SAM it produces from them (-L)"""
+    """the reference's own index files (-S) for a tiny genome + the SAM it produces from them (-L); also with hashed seeds (-H)"""
+    _index_case("idxfix", "11110111,1101011011", [])
+    _index_case("idxfix_h", "1111011101111011,11011101101110111011", ["-H"])
+
+
+def _index_case(dirname, seeds, extra):
     import shutil
     rng = np.random.default_rng(5)
     c1 = rng.integers(0, 4, 12000, dtype=np.uint8); c1[3000:3040] = 15; c1[7000:7003] = [5, 6, 14]
     c2 = rng.integers(0, 4, 7003, dtype=np.uint8)
     contigs = [c1, c2]; names = [b"chrA", b"chrB"]
     reads, _ = synth.make_reads(contigs, 400, 50, 91)
-    seeds = "11110111,1101011011"
-    d = os.path.join(OUT, "idxfix"); shutil.rmtree(d, ignore_errors=True); os.makedirs(d)
+    d = os.path.join(OUT, dirname); shutil.rmtree(d, ignore_errors=True); os.makedirs(d)
     with tempfile.TemporaryDirectory() as t:
         g = os.path.join(t, "g.fa"); r = os.path.join(t, "r.fa")
         write_fa_codes(g, names, contigs)
         write_fa_codes(r, [b"r%d" % i for i in range(len(reads))], list(reads))
-        subprocess.run([REF, "-s", seeds, "-S", os.path.join(d, "idx"), g], capture_output=True, check=True)
+        subprocess.run([REF, *extra, "-s", seeds, "-S", os.path.join(d, "idx"), g], capture_output=True, check=True)
         p = subprocess.run([REF, "-N", "2", "-L", os.path.join(d, "idx"), r], capture_output=True, check=True)
         body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
     np.savez_compressed(os.path.join(d, "inputs.npz"), contig0=c1, contig1=c2, reads=reads, seeds=np.array(seeds), contig_names=np.array(names))
     with gzip.open(os.path.join(d, "from_index.sam.gz"), "wb", compresslevel=9) as f:
         f.write(body)
-    print("idxfix: %d SAM records from the reference's -L run; files:" % sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@")), sorted(os.listdir(d)))
+    print(dirname + ": %d SAM records from the reference's -L run; files:" % sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@")), sorted(os.listdir(d)))
 
 
 def cs_kat_cases():
