@@ -202,6 +202,12 @@ int gm_map_reads(gm_session_t *s, int n_reads, int read_len, const uint32_t *rea
  * unless emit_sam == 0, in which case only the alignment records are produced and counted. */
 int gm_map_reads_device(gm_session_t *s, int n_reads, int read_len, const void *reads_dev,
                         int emit_sam, char **sam, size_t *sam_len, gm_map_stats_t *stats);
+/* FASTQ input (the reference's -Q, letter space): as gm_map_reads, plus the reads' QUAL strings ('\n' separated, as in the file) and the
+ * file's quality offset (--qv-offset; the binary's letter-space default is 64, gmapper-defaults.h:41).  QVs do not influence letter-space
+ * alignment; they travel to the SAM QUAL column: reversed with the read and re-based to PHRED+33 for mapped reads, verbatim for unmapped
+ * ones (ref: output.c:419-421,539-570). */
+int gm_map_reads_fastq(gm_session_t *s, int n_reads, int read_len, const uint32_t *reads_packed, const char *names,
+                       const char *quals, int qual_delta, char **sam, size_t *sam_len, gm_map_stats_t *stats);
 /* colour-space reads (SOLiD): colours_packed holds n_colours 4-bit colour codes per read (0-3, 15 for a skipped cycle) in the
  * same bitfield layout, initbp[i] the primer letter code (A0 C1 G2 T3) -- what fasta_sequence_to_bitfield / fasta_get_initial_base
  * produce (ref: gmapper.c:475-487).  The session's index must have been built with colour_space = 1.  Replaces handle_read() for

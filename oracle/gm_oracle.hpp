@@ -88,6 +88,7 @@ struct Params {
   int region_bits = 11, region_overlap = 50;
   uint32_t list_cutoff = 4294967295u;
   bool hash_filter_calls = true;  // -Z turns this off
+  bool Qflag = false; int qual_delta = 64;   // FASTQ input: QUAL strings travel to the SAM output (output.c:539-570; gmapper-defaults.h:41)
   bool Hflag = false;             // -H: hashed seeds (kmer_to_mapidx_hash, 4^12 lists per seed whatever its weight; gmapper.h:323-336)
   bool gapless = false;           // -U: ungapped filter (gapless_sw; gmapper.c:2057-2062 also sets anchor_width 0, gap opens -255, no f1 cache)
   bool Tflag = true, Gflag = true, compute_mapping_qualities = true;
@@ -1038,7 +1039,7 @@ struct Hit {                       // struct read_hit, gmapper-definitions.h:131
 };
 
 struct Read {
-  std::string name, seq;
+  std::string name, seq, qual;
   std::vector<uint32_t> bits[2];   // read[0] forward, read[1] reverse complement
   int read_len = 0, window_len = 0, max_n_kmers = 0, min_kmer_pos = 0, input_strand = 0;
   int initbp[2] = {0, 0};          // colour space: the primer letter (gmapper.c:481-482)
@@ -1511,8 +1512,9 @@ struct Mapper {
         }
       }
     } else seq = "*";                           // output.c:353-355
-    if (rh == nullptr) {                        // unmapped (output.c:411-466), unpaired, no read qualities
-      out += re.name; out += "\t4\t*\t0\t0\t*\t*\t0\t0\t"; out += seq; out += "\t*";
+    if (rh == nullptr) {                        // unmapped (output.c:411-466), unpaired
+      out += re.name; out += "\t4\t*\t0\t0\t*\t*\t0\t0\t"; out += seq; out += "\t";
+      out += (P.Qflag && !P.colour) ? re.qual : std::string("*");         // output.c:419-421: as read, no offset conversion
       if (P.colour) { out += "\tCQ:Z:*\tCS:Z:"; out += re.seq; }   // output.c:441-451
       out += "\n";
       return;
@@ -1534,6 +1536,11 @@ struct Mapper {
       }
     }
     std::string qual = "*";
+    if (!P.colour && P.Qflag) {                 // output.c:539-570: reversed with the read, re-based to PHRED+33
+      qual = re.qual;
+      if (reverse_strand) std::reverse(qual.begin(), qual.end());
+      if (P.qual_delta != 33) for (auto& c : qual) c = (char)(c - P.qual_delta + 33);
+    }
     if (!P.colour) seq.resize(j + (re.read_len - read_end));
     else {                                      // output.c:572-580: hard clips.  QUAL stays "*": post_sw's base qualities are
       for (auto& c : cigar) if (c.second == 'S') c.second = 'H';   // only printed for reads that came with QVs (:581-621, Qflag)

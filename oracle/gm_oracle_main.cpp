@@ -262,6 +262,26 @@ char* gmo_map_sam(void* s, int n, int L, const uint8_t* codes, const char* names
   memcpy(r, out.data(), out.size()); r[out.size()] = 0;
   return r;
 }
+// FASTQ reads: quals = '\n'-separated QUAL strings as read from the file, qual_delta = --qv-offset (64 by default in letter space)
+char* gmo_map_sam_q(void* s, int n, int L, const uint8_t* codes, const char* names, const char* quals, int qual_delta, int nthreads) {
+  Session* S = (Session*)s;
+  std::vector<Read> reads(n);
+  const char* p = names; const char* q = quals;
+  for (int i = 0; i < n; i++) {
+    if (p) { const char* e = strchr(p, '\n'); if (!e) e = p + strlen(p); reads[i].name.assign(p, e); p = *e ? e + 1 : e; }
+    else { char nm[32]; snprintf(nm, sizeof nm, "r%d", i); reads[i].name = nm; }
+    { const char* e = strchr(q, '\n'); if (!e) e = q + strlen(q); reads[i].qual.assign(q, e); q = *e ? e + 1 : e; }
+    reads[i].seq = code_seq(codes + (size_t)i * L, L);
+  }
+  const bool oq = S->M.P.Qflag; const int od = S->M.P.qual_delta;
+  S->M.P.Qflag = true; S->M.P.qual_delta = qual_delta;
+  std::string out;
+  map_all(*S, reads, nthreads > 0 ? nthreads : 1, out, nullptr);
+  S->M.P.Qflag = oq; S->M.P.qual_delta = od;
+  char* r = (char*)malloc(out.size() + 1);
+  memcpy(r, out.data(), out.size()); r[out.size()] = 0;
+  return r;
+}
 // pairs: mates 1 are n x L1 codes, mates 2 are n x L2 codes; names '\n'-separated (or NULL -> p<i>/1, p<i>/2)
 char* gmo_map_pairs_sam(void* s, int n, int L1, const uint8_t* codes1, int L2, const uint8_t* codes2,
                         const char* names1, const char* names2, int nthreads) {

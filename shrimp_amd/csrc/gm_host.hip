@@ -596,7 +596,8 @@ static void cs_alignment_strings(const uint8_t* bt, const uint8_t* codes, int n,
 struct Finalizer {
   const gm_session* s; int read_len, read_words; const uint32_t* reads;   // host copy of the packed reads of this sub-batch
   const char* const* name_ptr; const int* name_len; long name_base;
-  const uint8_t* initbp = nullptr; int ops_half = 0; CsPostConsts csk = CsPostConsts();   // colour space: primer letters of this sub-batch, ops_stride / 2
+  const uint8_t* initbp = nullptr; int ops_half = 0; CsPostConsts csk = CsPostConsts();
+  const char* const* qual_ptr = nullptr; int qual_delta = 33;                          // FASTQ input: QUAL string of every read of this sub-batch   // colour space: primer letters of this sub-batch, ops_stride / 2
 
   // hit_run_post_sw for one pass-2 result (ref: mapping.c:1609-1625)
   void post_sw(FHit& h, const GmFullRes* r, const uint8_t* ops) const {
@@ -653,7 +654,8 @@ struct Finalizer {
         p = put_str(p, nm, nl); p = put_str(p, "\t4\t*\t0\t0\t*\t*\t0\t0\t", 17);
         if (P.colour_space) { p = put_str(p, "*\t*\tCQ:Z:*\tCS:Z:", 16); p = put_csfasta(p); *p++ = '\n'; out.resize(p - out.data()); return 1; }   // ref: output.c:353-355,441-451
         for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = (c < 4) ? "ACGT"[c] : 'N'; }
-        p = put_str(p, "\t*\n", 3);
+        if (qual_ptr) { *p++ = '\t'; p = put_str(p, qual_ptr[rd], (size_t)read_len); *p++ = '\n'; }      // ref: output.c:419-421 (verbatim)
+        else p = put_str(p, "\t*\n", 3);
         out.resize(p - out.data());
         return 1;
       }
@@ -721,7 +723,14 @@ struct Finalizer {
       // SEQ: read bases in input orientation (aligned part from qralign == the read's own letters), revcomp on '-'
       if (!rev) for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = CODE2SEQ[c]; }
       else for (int i = read_len - 1; i >= 0; i--) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = rc_char(CODE2SEQ[c]); }
-      p = put_str(p, "\t*\tAS:i:", 8); p = put_int(p, h->score_full);
+      if (qual_ptr) {                                                              // ref: output.c:539-570
+        *p++ = '\t';
+        const char* q = qual_ptr[rd]; const int dq = 33 - qual_delta;
+        if (!rev) for (int i = 0; i < read_len; i++) *p++ = (char)(q[i] + dq);
+        else for (int i = read_len - 1; i >= 0; i--) *p++ = (char)(q[i] + dq);
+        p = put_str(p, "\tAS:i:", 6);
+      } else p = put_str(p, "\t*\tAS:i:", 8);
+      p = put_int(p, h->score_full);
       if (!P.local_alignment) {                                                    // ref: output.c:691-696
         p = put_str(p, "\tZ0:i:", 6); p = put_int(p, double_to_neglog(h->z0));
         p = put_str(p, "\tZ1:i:", 6); p = put_int(p, double_to_neglog(h->z1));
@@ -879,7 +888,8 @@ static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int
 }
 
 static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* reads_host, const void* reads_dev,
-                    const char* names, int emit_sam, char** sam, size_t* sam_len, gm_map_stats_t* stats, const uint8_t* initbp_host = nullptr) {
+                    const char* names, int emit_sam, char** sam, size_t* sam_len, gm_map_stats_t* stats, const uint8_t* initbp_host = nullptr,
+                    const char* quals = nullptr, int qual_delta = 33) {
   if (!s || n_reads < 0 || read_len < 1) { gm_set_error("gm_map_reads: bad arguments"); return GM_E_ARG; }
   if ((s->P.colour_space != 0) != (initbp_host != nullptr)) {
     gm_set_error(s->P.colour_space ? "colour-space session: use gm_map_reads_cs (colours + primer letters)" : "gm_map_reads_cs needs a colour-space session"); return GM_E_ARG; }
@@ -892,6 +902,15 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   s->last_lookup_ms = 0; s->last_lookup_bytes = 0; s->last_lookup_launches = 0;
   // names
   std::vector<const char*> nptr; std::vector<int> nlen;
+  std::vector<const char*> qptr;
+  if (quals) {
+    const char* p = quals;
+    for (int i = 0; i < n_reads; i++) {
+      const char* e = strchr(p, '\n'); if (!e) e = p + strlen(p);
+      if ((int)(e - p) != read_len) { gm_set_error("read %d: QUAL string of %d characters for %d bases", i, (int)(e - p), read_len); return GM_E_ARG; }
+      qptr.push_back(p); p = *e ? e + 1 : e;
+    }
+  }
   if (names) { const char* p = names; for (int i = 0; i < n_reads; i++) { const char* e = strchr(p, '\n'); if (!e) e = p + strlen(p); nptr.push_back(p); nlen.push_back((int)(e - p)); p = *e ? e + 1 : e; } }
   // Sub-batches are pipelined: while the GPU works on sub-batch i+1, host threads finish sub-batch i
   // (pass-2 selection, MAPQ, SAM text).  Output stays in input order.
@@ -912,6 +931,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     std::atomic<int> next(0);
     Finalizer F{s, read_len, read_words, J->hreads, names ? nptr.data() + J->base : nullptr, names ? nlen.data() + J->base : nullptr, (long)J->base};
     if (s->P.colour_space) { F.initbp = initbp_host + J->base; F.ops_half = ops_stride / 2; F.csk = cs_post_consts(s); }
+    if (quals) { F.qual_ptr = qptr.data() + J->base; F.qual_delta = qual_delta; }
     auto worker = [&]() {
       std::vector<FHit> fh; std::vector<FHit*> p2;
       for (;;) {
@@ -987,6 +1007,12 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
 extern "C" int gm_map_reads(gm_session_t* s, int n_reads, int read_len, const uint32_t* reads_packed, const char* names,
                             char** sam, size_t* sam_len, gm_map_stats_t* stats) {
   return map_impl(s, n_reads, read_len, reads_packed, nullptr, names, 1, sam, sam_len, stats);
+}
+extern "C" int gm_map_reads_fastq(gm_session_t* s, int n_reads, int read_len, const uint32_t* reads_packed, const char* names, const char* quals, int qual_delta,
+                                  char** sam, size_t* sam_len, gm_map_stats_t* stats) {
+  if (!quals) { gm_set_error("gm_map_reads_fastq: no QUAL strings"); return GM_E_ARG; }
+  if (s && s->P.colour_space) { gm_set_error("gm_map_reads_fastq: letter space only"); return GM_E_ARG; }
+  return map_impl(s, n_reads, read_len, reads_packed, nullptr, names, 1, sam, sam_len, stats, nullptr, quals, qual_delta);
 }
 extern "C" int gm_map_reads_cs(gm_session_t* s, int n_reads, int n_colours, const uint32_t* colours_packed, const uint8_t* initbp, const char* names,
                                char** sam, size_t* sam_len, gm_map_stats_t* stats) {

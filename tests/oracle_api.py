@@ -96,6 +96,17 @@ class Session:
         self.stats = dict(vec_calls=st[0], vec_cells=st[1], vec_bypassed=st[2], full_calls=st[3], reads_matched=st[4], dup_pruned=st[5], local_retries=st[6])
         return s
 
+    def map_sam_q(self, reads, quals, qual_delta=64, nthreads=4):
+        """FASTQ reads: quals = list of QUAL strings (bytes) as in the file"""
+        reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        n, Lr = reads.shape
+        self.L.gmo_map_sam_q.restype = C.c_void_p
+        self.L.gmo_map_sam_q.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+        p = self.L.gmo_map_sam_q(self.h, n, Lr, reads.ctypes.data_as(C.POINTER(C.c_uint8)), None, b"\n".join(quals), qual_delta, nthreads)
+        s = C.string_at(p)
+        self.L.gmo_free(p)
+        return s
+
     def tophits(self, reads, nthreads=4):
         reads = np.ascontiguousarray(reads, dtype=np.uint8)
         n, Lr = reads.shape

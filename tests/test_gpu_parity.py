@@ -525,3 +525,17 @@ def test_hashed_seed_index_files_of_the_reference(gm, tmp_path):
         gm.Index.load(os.path.join(d, "idx"))                       # a hashed index is refused by a plain load
     with pytest.raises(gm.GmError):
         gm.Index(contigs, names=names, seeds=seeds)                 # a weight-16 seed needs -H
+
+
+@pytest.mark.parametrize("tag", ["fq33", "fq64"])
+def test_fastq_quals_match_reference_golden(gm, tag):
+    """gm_map_reads_fastq: QUAL column as the reference prints it for FASTQ input (reversed / re-based for mapped reads, verbatim for unmapped)"""
+    from tests.test_oracle import _fastq_case
+    contigs, reads, quals, delta, sam = _fastq_case(tag)
+    p = gm.default_params(); p.sam_unaligned = 1
+    ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p, max_batch_reads=256)
+    got = oa.sam_header(contigs) + s.map_reads_fastq(reads, quals, delta)
+    with pytest.raises(gm.GmError):
+        s.map_reads_fastq(reads[:2], [quals[0], quals[1][:-1]], delta)          # QUAL length must equal the read length
+    s.close(); ix.close()
+    assert got == sam, _first_diff(got, sam)

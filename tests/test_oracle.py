@@ -152,3 +152,24 @@ def test_oracle_colour_space_on_the_reference_index_fixture(oracle_lib):
     got = oa.sam_header(contigs, names) + s.map_sam(z["reads"], nthreads=2)
     s.close()
     assert got == sam
+
+
+def _fastq_case(tag):
+    import gzip, os
+    d = os.path.join(oa.ROOT, "tests", "golden")
+    contigs, reads, _ = oa.load_golden("stress_100bp_unal")
+    z = np.load(os.path.join(d, "stress_100bp_%s.npz" % tag))
+    with gzip.open(os.path.join(d, "stress_100bp_%s.sam.gz" % tag), "rb") as f:
+        sam = f.read()
+    n = int(z["n_reads"])
+    return contigs, reads[:n], [bytes(q.tobytes()) for q in z["quals"]], int(z["qual_delta"]), sam
+
+
+@pytest.mark.parametrize("tag", ["fq33", "fq64"])
+def test_oracle_fastq_quals_match_reference(tag, oracle_lib):
+    """FASTQ input: QUAL strings reversed with the read and re-based to PHRED+33 for mapped reads, as read for unmapped ones"""
+    contigs, reads, quals, delta, sam = _fastq_case(tag)
+    s = oa.Session(contigs); s.set(True, True)
+    got = oa.sam_header(contigs) + s.map_sam_q(reads, quals, delta, nthreads=4)
+    s.close()
+    assert got == sam

@@ -257,8 +257,33 @@ def cs_cases():
     print("idxfix_cs: %d SAM records from gmapper-cs -L; files:" % sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@")), sorted(os.listdir(d)))
 
 
+def fastq_cases():
+    """FASTQ input (-Q autodetected): the QUAL strings in the SAM, once PHRED+33 (--qv-offset 33), once the default PHRED+64"""
+    z = np.load(os.path.join(OUT, "stress_100bp_unal.npz"))
+    contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
+    reads = z["reads"][:600]
+    rng = np.random.default_rng(17)
+    T = np.frombuffer(b"ACGTUMRWSYKVHDBN", dtype=np.uint8)
+    for tag, delta, extra in (("fq33", 33, ["--qv-offset", "33"]), ("fq64", 64, [])):
+        q = (rng.integers(2, 41, size=reads.shape) + delta).astype(np.uint8)
+        with tempfile.TemporaryDirectory() as d:
+            g = os.path.join(d, "g.fa"); r = os.path.join(d, "r.fq")
+            write_fa_codes(g, [b"contig%d" % (i + 1) for i in range(len(contigs))], contigs)
+            with open(r, "wb") as f:
+                for i in range(len(reads)):
+                    f.write(b"@r%d\n" % i + T[reads[i]].tobytes() + b"\n+\n" + q[i].tobytes() + b"\n")
+            p = subprocess.run([REF, "-N", "4", "--sam-unaligned", *extra, r, g], capture_output=True, check=True)
+            body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+        np.savez_compressed(os.path.join(OUT, "stress_100bp_%s.npz" % tag), quals=q, n_reads=np.array(len(reads)), qual_delta=np.array(delta))
+        with gzip.open(os.path.join(OUT, "stress_100bp_%s.sam.gz" % tag), "wb", compresslevel=9) as f:
+            f.write(body)
+        print("stress_100bp_%s: %d SAM records" % (tag, sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@"))))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--fastq-only" in sys.argv:
+        fastq_cases(); return
     if "--cs-only" in sys.argv:
         cs_cases(); return
     if "--cs-kat-only" in sys.argv:
@@ -285,6 +310,7 @@ def main():
     index_cases()
     cs_kat_cases()
     cs_cases()
+    fastq_cases()
 
 
 if __name__ == "__main__":
