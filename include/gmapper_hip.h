@@ -216,6 +216,11 @@ int gm_map_reads_fastq(gm_session_t *s, int n_reads, int read_len, const uint32_
  * output.c:441-451,485-493,572-580,717-730). */
 int gm_map_reads_cs(gm_session_t *s, int n_reads, int n_colours, const uint32_t *colours_packed, const uint8_t *initbp,
                     const char *names, char **sam, size_t *sam_len, gm_map_stats_t *stats);
+/* csfastq reads: as gm_map_reads_cs, plus one QV character per colour ('\n' separated strings, offset qual_delta; 33 is the binary's colour-space
+ * default, gmapper-defaults.h:42).  The QVs give per-position crossover scores in sw_full_cs (ref: gmapper.c:532-544, sw-full-cs.c:312), per-colour
+ * error rates in post_sw (sw-post.c:486-491), the SAM QUAL column (post_sw's base qualities) and the CQ:Z tag (output.c:613-621,724-727). */
+int gm_map_reads_cs_fastq(gm_session_t *s, int n_reads, int n_colours, const uint32_t *colours_packed, const uint8_t *initbp,
+                          const char *names, const char *quals, int qual_delta, char **sam, size_t *sam_len, gm_map_stats_t *stats);
 void gm_free(void *p);
 
 /* ---------------------------------------------------------------------------------------------

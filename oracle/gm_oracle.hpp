@@ -88,6 +88,7 @@ struct Params {
   int region_bits = 11, region_overlap = 50;
   uint32_t list_cutoff = 4294967295u;
   bool hash_filter_calls = true;  // -Z turns this off
+  bool use_sanger_qvs = true; int qual_vector_offset = 0;      // gmapper.h:78-79
   bool Qflag = false; int qual_delta = 64;   // FASTQ input: QUAL strings travel to the SAM output (output.c:539-570; gmapper-defaults.h:41)
   bool Hflag = false;             // -H: hashed seeds (kmer_to_mapidx_hash, 4^12 lists per seed whatever its weight; gmapper.h:323-336)
   bool gapless = false;           // -U: ungapped filter (gapless_sw; gmapper.c:2057-2062 also sets anchor_width 0, gap opens -255, no f1 cache)
@@ -712,7 +713,8 @@ struct CsParams { int match = 10, mismatch = -24, xover = -20, a_go = 33, a_ge =
 typedef SwFullResults SwFullCsResults;
 
 static inline void sw_full_cs(const CsParams& C, const uint32_t* genome_ls, llint goff, int glen, const uint32_t* read, int rlen, int initbp,
-                              int threshscore, SwFullCsResults* sfr, bool revcmpl, const Anchor* anchors, int anchors_cnt) {
+                              int threshscore, SwFullCsResults* sfr, bool revcmpl, const Anchor* anchors, int anchors_cnt,
+                              const int* crossover_score = nullptr) {   // per-position crossover scores from the read's QVs (gmapper.c:532-544), or null
   const int lena = glen, lenb = rlen;
   struct Lay { int n, w, nw; int8_t bn, bw, bnw; };
   struct Cell { Lay from[4]; };
@@ -729,7 +731,7 @@ static inline void sw_full_cs(const CsParams& C, const uint32_t* genome_ls, llin
       else { qr[k][j] = (int8_t)cstols(letter, base); letter = qr[k][j]; }
     }
   }
-  const int xo = C.xover;
+  int xo = C.xover;                                                      // global_xover_penalty; per row below (:312)
   auto init_cell = [&](size_t idx, int local) {                          // :201-247
     for (int k = 0; k < 4; k++) {
       Lay& l = m[idx].from[k];
@@ -746,6 +748,7 @@ static inline void sw_full_cs(const CsParams& C, const uint32_t* genome_ls, llin
   for (int i = 0; i < lenb; i++) {
     int x_min, x_max;
     anchor_get_x_range(&rectangle, lena, lenb, i, &x_min, &x_max);
+    xo = crossover_score ? crossover_score[i] : C.xover;                  // :312
     init_cell((size_t)(i + 1) * (lena + 1) + (x_min - 1) + 1, 0);         // :319 (global)
     const bool notaboo = i < lenb - C.indel_taboo_len;
     for (int j = x_min; j <= x_max; j++) {
@@ -909,14 +912,15 @@ static inline double post_node_prior(const PostSwColumn& c, int j) {   // nodePr
   if (c.ncols) { if ((l ^ r) == c.col) val = val - log(1 - c.colerr); else val = val - log(c.colerr / 3.0); }
   return val;
 }
-static inline void post_sw(const Params& P, const uint32_t* read, int init_bp, SwFullResults* sfr) {
+static inline void post_sw(const Params& P, const uint32_t* read, int init_bp, SwFullResults* sfr, const char* qual = nullptr) {   // qual: the read's QV string, or null
   std::vector<PostSwColumn> cols;
   {  // load_local_vectors (sw-post.c:448-528)
-    int start_run = 0, j;
+    int start_run = 0, j, min_qv = 10000;
     for (j = 0; j < sfr->read_start; j++) {
       int col = EXTRACT(read, j);
-      if (col == 15) { start_run = 15; j = sfr->read_start; break; }
+      if (col == 15) { start_run = 15; min_qv = 0; j = sfr->read_start; break; }
       start_run ^= col;
+      if (qual) min_qv = std::min(min_qv, (int)qual[P.qual_vector_offset + j]);
     }
     for (size_t i = 0; i < sfr->dbalign.size(); i++) {
       if (sfr->qralign[i] == '-') continue;       // deletion: nothing to emit
@@ -931,7 +935,16 @@ static inline void post_sw(const Params& P, const uint32_t* read, int init_bp, S
       c.ncols = 1;
       const int col = EXTRACT(read, j); const bool first = cols.empty();
       if ((first && start_run == 15) || col == 15) { c.col = 0; c.colerr = .75; }
-      else { c.col = col ^ (first ? start_run : 0); c.colerr = P.pr_xover; }
+      else {
+        c.col = col ^ (first ? start_run : 0);
+        if (qual) {                                  // sw-post.c:486-491
+          const int q = (int)qual[P.qual_vector_offset + j];
+          const int qv = (first ? std::min(min_qv, q) : q) - P.qual_delta;
+          c.colerr = (qv <= 0) ? .99999999 : (qv >= 250 ? 1E-25 : pow(10.0, -(double)qv / 10.0));
+          if (!P.use_sanger_qvs) c.colerr /= (1 + c.colerr);
+          if (c.colerr > .75) c.colerr = .75;
+        } else c.colerr = P.pr_xover;
+      }
       int bc = char_to_code_ls((unsigned char)sfr->qralign[i]);   // char_to_base (fasta.c:28-42): case-insensitive
       c.base_call = bc;
       cols.push_back(c); j++;
@@ -1043,6 +1056,7 @@ struct Read {
   std::vector<uint32_t> bits[2];   // read[0] forward, read[1] reverse complement
   int read_len = 0, window_len = 0, max_n_kmers = 0, min_kmer_pos = 0, input_strand = 0;
   int initbp[2] = {0, 0};          // colour space: the primer letter (gmapper.c:481-482)
+  std::vector<int> crossover_score; // colour space with QVs: per colour (gmapper.c:532-544)
   std::vector<uint32_t> mapidx[2];
   std::vector<Anchor> anchors[2];
   std::vector<Hit> hits[2];
@@ -1114,6 +1128,19 @@ struct Mapper {
     if (re.max_n_kmers < 0) re.max_n_kmers = 0;
     re.input_strand = 0;
     re.window_len = (uint16_t)GMO_ABS_OR_PCT(P.window_len, re.read_len);
+    re.crossover_score.clear();
+    if (P.Qflag) {                                 // gmapper.c:532-544
+      re.crossover_score.resize(re.read_len);
+      for (int j = 0; j < re.read_len; j++) {
+        int c = (int)(P.score_alpha * log(pr_err_from_qv((int)re.qual[j] - P.qual_delta) / 3.0) / log(2.0));
+        if (c > -1) c = -1; else if (c < 2 * P.crossover_score) c = 2 * P.crossover_score;
+        re.crossover_score[j] = c;
+      }
+    }
+  }
+  static double pr_err_from_qv(int qv) {           // util.h:285-293
+    if (qv <= 0) return .99999999; else if (qv >= 250) return 1E-25;
+    return pow(10.0, -(double)qv / 10.0);
   }
 
   // read_get_mapidxs_per_strand (mapping.c:37-70)
@@ -1388,7 +1415,8 @@ struct Mapper {
       C.a_go = -P.a_gap_open_score; C.a_ge = -P.a_gap_extend_score; C.b_go = -P.b_gap_open_score; C.b_ge = -P.b_gap_extend_score;
       C.anchor_width = P.anchor_width; C.indel_taboo_len = P.indel_taboo_len;
       T.stats.full_calls++;
-      sw_full_cs(C, gen, h.g_off, h.w_len, re.bits[h.st].data(), re.read_len, re.initbp[h.st], thresh, &h.sfr, h.gen_st && P.Tflag, &h.anchor, 1);
+      sw_full_cs(C, gen, h.g_off, h.w_len, re.bits[h.st].data(), re.read_len, re.initbp[h.st], thresh, &h.sfr, h.gen_st && P.Tflag, &h.anchor, 1,
+                 re.crossover_score.empty() ? nullptr : re.crossover_score.data());
       h.score_full = h.sfr.score;
       h.pct_score_full = (1000 * 100 * h.score_full) / h.score_max;
       return;
@@ -1407,7 +1435,7 @@ struct Mapper {
   // hit_run_post_sw (mapping.c:1609-1625), letter space
   void hit_run_post_sw(const Read& re, Hit& h) const {
     SwFullResults& s = h.sfr;
-    if (P.colour) post_sw(P, re.bits[h.st].data(), re.initbp[h.st], &s);
+    if (P.colour) post_sw(P, re.bits[h.st].data(), re.initbp[h.st], &s, P.Qflag ? re.qual.c_str() : nullptr);
     else s.posterior = pow(2.0, ((double)s.score - (double)s.rmapped * (2.0 * P.score_alpha + P.score_beta)) / P.score_alpha);
     s.posterior_score = (int)rint(P.score_alpha * log(s.posterior) / log(2.0) + (double)s.rmapped * (2.0 * P.score_alpha + P.score_beta));
     if (s.posterior_score < 0) s.posterior_score = 0;
@@ -1515,7 +1543,7 @@ struct Mapper {
     if (rh == nullptr) {                        // unmapped (output.c:411-466), unpaired
       out += re.name; out += "\t4\t*\t0\t0\t*\t*\t0\t0\t"; out += seq; out += "\t";
       out += (P.Qflag && !P.colour) ? re.qual : std::string("*");         // output.c:419-421: as read, no offset conversion
-      if (P.colour) { out += "\tCQ:Z:*\tCS:Z:"; out += re.seq; }   // output.c:441-451
+      if (P.colour) { out += "\tCQ:Z:"; out += P.Qflag ? re.qual : std::string("*"); out += "\tCS:Z:"; out += re.seq; }   // output.c:441-451
       out += "\n";
       return;
     }
@@ -1542,8 +1570,12 @@ struct Mapper {
       if (P.qual_delta != 33) for (auto& c : qual) c = (char)(c - P.qual_delta + 33);
     }
     if (!P.colour) seq.resize(j + (re.read_len - read_end));
-    else {                                      // output.c:572-580: hard clips.  QUAL stays "*": post_sw's base qualities are
-      for (auto& c : cigar) if (c.second == 'S') c.second = 'H';   // only printed for reads that came with QVs (:581-621, Qflag)
+    else {                                      // output.c:572-580: hard clips.  QUAL stays "*" unless the reads came with QVs:
+      for (auto& c : cigar) if (c.second == 'S') c.second = 'H';   // then it is post_sw's base qualities (:581-621, Qflag)
+      if (P.Qflag && P.compute_mapping_qualities) {
+        qual = s.qual;
+        if (reverse_strand) for (int i = 0; i < s.rmapped / 2; i++) std::swap(qual[i], qual[s.rmapped - i - 1]);
+      }
     }
     int genome_start;
     if (!reverse_strand) genome_start = s.genome_start + 1;
@@ -1566,6 +1598,7 @@ struct Mapper {
     if (P.compute_mapping_qualities) { snprintf(buf, sizeof buf, "\tZ0:i:%d\tZ1:i:%d", double_to_neglog(s.z0), double_to_neglog(s.z1)); out += buf; }
     snprintf(buf, sizeof buf, "\tNM:i:%d", s.mismatches + s.deletions + s.insertions); out += buf;
     if (P.colour) {                             // output.c:717-730
+      if (P.Qflag) { out += "\tCQ:Z:"; out += re.qual; }
       out += "\tCS:Z:"; out += re.seq;
       snprintf(buf, sizeof buf, "\tCM:i:%d\tXX:Z:", s.crossovers); out += buf; out += s.qralign;
     }

@@ -271,7 +271,7 @@ char* gmo_map_sam_q(void* s, int n, int L, const uint8_t* codes, const char* nam
     if (p) { const char* e = strchr(p, '\n'); if (!e) e = p + strlen(p); reads[i].name.assign(p, e); p = *e ? e + 1 : e; }
     else { char nm[32]; snprintf(nm, sizeof nm, "r%d", i); reads[i].name = nm; }
     { const char* e = strchr(q, '\n'); if (!e) e = q + strlen(q); reads[i].qual.assign(q, e); q = *e ? e + 1 : e; }
-    reads[i].seq = code_seq(codes + (size_t)i * L, L);
+    reads[i].seq = S->M.P.colour ? code_seq_cs(codes + (size_t)i * L, L) : code_seq(codes + (size_t)i * L, L);
   }
   const bool oq = S->M.P.Qflag; const int od = S->M.P.qual_delta;
   S->M.P.Qflag = true; S->M.P.qual_delta = qual_delta;

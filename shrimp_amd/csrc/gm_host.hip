@@ -253,6 +253,7 @@ extern "C" int gm_index_alloc_like(gm_index_t** out, int device, const void* met
 struct DevSet {
   // capacities (grown on overflow)
   int cur_len = -1, scap = 0, scap2 = 0, hcap = 0, rcap_per_read = 8, ops_stride = 0, eff_batch = 0;
+  int8_t* d_xover = nullptr; bool xover_on = false;        // colour space with QVs: per-position crossover scores [B][read_len]
   uint32_t* d_reads = nullptr; uint8_t* d_initbp = nullptr; uint64_t* d_surv = nullptr; uint32_t* d_surv_cnt = nullptr;   // d_initbp: colour space primer letters
   uint32_t* d_surv_seg = nullptr;                                          // [2B][S + 1] survivors after each slab (K1 emits slab by slab)
   uint64_t* d_surv2 = nullptr; uint32_t* d_surv_cnt2 = nullptr;            // survivors after the exact isolation prune (K1b) = input of K2
@@ -302,11 +303,11 @@ struct gm_session {
 };
 
 static void free_buffers(DevSet& D) {
-  void* ptrs[] = {D.d_reads, D.d_initbp, D.d_surv, D.d_surv_cnt, D.d_surv_seg, D.d_surv2, D.d_surv_cnt2, D.d_hits, D.d_perm, D.d_hit_cnt, D.d_slots, D.d_heavy_list, D.d_heavy_cnt,
+  void* ptrs[] = {D.d_xover, D.d_reads, D.d_initbp, D.d_surv, D.d_surv_cnt, D.d_surv_seg, D.d_surv2, D.d_surv_cnt2, D.d_hits, D.d_perm, D.d_hit_cnt, D.d_slots, D.d_heavy_list, D.d_heavy_cnt,
                   D.d_sel, D.d_sel_sidx, D.d_sel_cnt, D.d_sel_off, D.d_work, D.d_n_work, D.d_res, D.d_ops, D.d_back,
                   D.d_pmin, D.d_pmax, D.d_saved, D.d_saved_list};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  D.d_reads = nullptr; D.d_initbp = nullptr; D.d_surv = nullptr; D.d_surv_cnt = nullptr; D.d_surv_seg = nullptr; D.d_surv2 = nullptr; D.d_surv_cnt2 = nullptr; D.d_hits = nullptr; D.d_perm = nullptr; D.d_hit_cnt = nullptr; D.d_slots = nullptr;
+  D.d_xover = nullptr; D.d_reads = nullptr; D.d_initbp = nullptr; D.d_surv = nullptr; D.d_surv_cnt = nullptr; D.d_surv_seg = nullptr; D.d_surv2 = nullptr; D.d_surv_cnt2 = nullptr; D.d_hits = nullptr; D.d_perm = nullptr; D.d_hit_cnt = nullptr; D.d_slots = nullptr;
   D.d_heavy_list = nullptr; D.d_heavy_cnt = nullptr; D.d_sel = nullptr; D.d_sel_sidx = nullptr; D.d_sel_cnt = nullptr; D.d_sel_off = nullptr;
   D.d_work = nullptr; D.d_n_work = nullptr; D.d_res = nullptr; D.d_ops = nullptr; D.d_back = nullptr;
   D.d_pmin = nullptr; D.d_pmax = nullptr; D.d_saved = nullptr; D.d_saved_list = nullptr;
@@ -335,7 +336,7 @@ static int alloc_buffers(gm_session* s, DevSet& D, int read_len, bool paired = f
   D.back_stride = (((size_t)read_len * W + 255) / 256) * 256;
   if (s->P.colour_space) { D.ops_stride *= 2; D.back_stride *= 12; }   // backtrace byte + letter codes per column; three words of back pointers per cell
   GM_HIP(hipMalloc(&D.d_reads, (size_t)B * read_words * 4 + 64));
-  if (s->P.colour_space) GM_HIP(hipMalloc(&D.d_initbp, (size_t)B + 64));
+  if (s->P.colour_space) { GM_HIP(hipMalloc(&D.d_initbp, (size_t)B + 64)); GM_HIP(hipMalloc(&D.d_xover, (size_t)B * read_len + 64)); }
   GM_HIP(hipMalloc(&D.d_surv, (size_t)rs * D.scap * 8));
   GM_HIP(hipMalloc(&D.d_surv_cnt, (size_t)rs * 4));
   if (D.scap2 > 0) {
@@ -437,7 +438,7 @@ struct FHit {            // one pass-2 candidate on the host (read_hit + sw_full
   const GmFullRes* r; const uint8_t* ops;
   int score_full, pass2_key; double pct_score_full; double posterior; int mqv; double z0, z1;
   double z2, z3, pr_top_random, insert_size_denom, pr_missed_mp;   // paired mode (ref: sw-full-common.h:30-44)
-  std::string db, qr; int cs_match = 0, cs_mismatch = 0, cs_xover = 0;   // colour space: dbalign / qralign and the counts post_sw leaves (ref: sw-post.c:531-565)
+  std::string db, qr, qual; int cs_match = 0, cs_mismatch = 0, cs_xover = 0;   // colour space: dbalign / qralign and the counts post_sw leaves (ref: sw-post.c:531-565)
 };
 
 static inline char* put_uint(char* p, unsigned long long v) {
@@ -494,16 +495,22 @@ static CsPostConsts cs_post_consts(const gm_session* s) {
   for (int k = 0; k < 2; k++) { c.col_m[k] = log(1 - ce[k]); c.col_x[k] = log(ce[k] / 3.0); }
   return c;
 }
-static void cs_post_sw(const gm_session* s, const CsPostConsts& K, const uint32_t* rw, int init_bp, int read_start, FHit& h) {
-  struct Col { double prior[16], fw[16], bw[16], fs, bs; int col; };
+static void cs_post_sw(const gm_session* s, const CsPostConsts& K, const uint32_t* rw, int init_bp, int read_start, FHit& h,
+                       const char* qual = nullptr, int qual_delta = 33) {   // qual: the read's QV string (csfastq) or null
+  struct Col { double prior[16], fw[16], bw[16], fs, bs; int col, base_call; };
   std::string& db = h.db; std::string& qr = h.qr;
   static thread_local std::vector<Col> colbuf;
   if (colbuf.size() < db.size() + 1) colbuf.resize(db.size() + 1);
   Col* cols = colbuf.data(); int len = 0;
   auto colour = [&](int j) { return (int)((rw[j >> 3] >> ((j & 7) * 4)) & 0xf); };
   {  // load_local_vectors, ref: sw-post.c:448-528
-    int start_run = 0, j;
-    for (j = 0; j < read_start; j++) { const int c = colour(j); if (c == 15) { start_run = 15; j = read_start; break; } start_run ^= c; }
+    int start_run = 0, j, min_qv = 10000;
+    for (j = 0; j < read_start; j++) {
+      const int c = colour(j);
+      if (c == 15) { start_run = 15; min_qv = 0; j = read_start; break; }
+      start_run ^= c;
+      if (qual) min_qv = std::min(min_qv, (int)qual[j]);
+    }
     for (size_t i = 0; i < db.size(); i++) {
       if (qr[i] == '-') continue;
       Col& c = cols[len];
@@ -512,10 +519,20 @@ static void cs_post_sw(const gm_session* s, const CsPostConsts& K, const uint32_
                                          case 'T': case 't': let = 3; break; default: let = -1; }
       const int cc = colour(j); int which;
       if ((len == 0 && start_run == 15) || cc == 15) { c.col = 0; which = 1; } else { c.col = cc ^ (len == 0 ? start_run : 0); which = 0; }
+      double col_m = K.col_m[which], col_x = K.col_x[which];
+      if (qual && which == 0) {                         // the colour's own error rate, ref: sw-post.c:486-491 (use_sanger_qvs = true)
+        const int qv = (len == 0 ? std::min(min_qv, (int)qual[j]) : (int)qual[j]) - qual_delta;
+        double e = qv <= 0 ? .99999999 : (qv >= 250 ? 1E-25 : pow(10.0, -(double)qv / 10.0));
+        if (e > .75) e = .75;
+        col_m = log(1 - e); col_x = log(e / 3.0);
+      }
+      c.base_call = -1;
+      switch (qr[i]) { case 'A': case 'a': c.base_call = 0; break; case 'C': case 'c': c.base_call = 1; break; case 'G': case 'g': c.base_call = 2; break;
+                       case 'T': case 't': c.base_call = 3; break; default: break; }
       for (int st = 0; st < 16; st++) {                 // nodePrior, ref: sw-post.c:111-138
         const int l = (st >> 2) & 3, r = st & 3; double val = 0;
         if (let != -2) val = val - ((r == let) ? K.let_m : K.let_x);
-        val = val - (((l ^ r) == c.col) ? K.col_m[which] : K.col_x[which]);
+        val = val - (((l ^ r) == c.col) ? col_m : col_x);
         c.prior[st] = val;
       }
       len++; j++;
@@ -557,13 +574,18 @@ static void cs_post_sw(const gm_session* s, const CsPostConsts& K, const uint32_
     }
   }
   {  // post_traceback + fix_base_calls, ref: sw-post.c:183-212,531-565
-    int j = 0, prev_base = init_bp; h.cs_match = h.cs_mismatch = h.cs_xover = 0;
+    int j = 0, prev_base = init_bp; h.cs_match = h.cs_mismatch = h.cs_xover = 0; h.qual.clear();
     for (size_t i = 0; i < qr.size(); i++) {
       if (qr[i] == '-') continue;
       const Col& c = cols[j];
       double post[4] = {0, 0, 0, 0};
       for (int st = 0; st < 16; st++) post[st & 3] += exp(-1 * (c.fw[st] + c.bw[st] + c.fs + c.bs - total));
       int crt = 0; for (int b = 1; b < 4; b++) if (post[b] > post[crt]) crt = b;
+      if (qual) {                                       // get_base_qualities, ref: sw-post.c:568-586: of the letter sw_full_cs had called
+        int t = c.base_call >= 0 ? qv_from_pr_corr(post[c.base_call]) : 0;
+        if (t > 40) t = 40;
+        h.qual.push_back((char)(33 + t));
+      }
       if ((prev_base ^ crt) == c.col) qr[i] = "ACGT"[crt]; else { qr[i] = "acgt"[crt]; h.cs_xover++; }
       if (db[i] != '-') { if (toupper((unsigned char)db[i]) == toupper((unsigned char)qr[i])) h.cs_match++; else h.cs_mismatch++; }
       prev_base = crt; j++;
@@ -610,7 +632,8 @@ struct Finalizer {
       const double a = s->score_alpha, b = s->score_beta;
       if (P.colour_space) {
         cs_alignment_strings(h.ops, h.ops + ops_half, std::min(r->n_ops, ops_half), h.db, h.qr);
-        cs_post_sw(s, csk, reads + (size_t)r->read_idx * read_words, (int)initbp[r->read_idx], r->read_start, h);
+        cs_post_sw(s, csk, reads + (size_t)r->read_idx * read_words, (int)initbp[r->read_idx], r->read_start, h,
+                   qual_ptr ? qual_ptr[r->read_idx] : nullptr, qual_delta);
       } else
       h.posterior = pow(2.0, ((double)r->score - (double)r->rmapped * (2.0 * a + b)) / a);
       int ps = (int)rint(a * log(h.posterior) / log(2.0) + (double)r->rmapped * (2.0 * a + b));
@@ -645,14 +668,18 @@ struct Finalizer {
     char nbuf[32]; const char* nm; size_t nl;
     if (name_ptr) { nm = name_ptr[rd]; nl = (size_t)name_len[rd]; }
     else { nl = (size_t)snprintf(nbuf, sizeof nbuf, "r%ld", name_base + rd); nm = nbuf; }
-    const size_t need = 64 + nl + 6 * (size_t)read_len + 320;
+    const size_t need = 64 + nl + 8 * (size_t)read_len + 320;
     // colour space: the read as csfasta text, primer letter + colours ('.' for a skipped cycle), for the CS:Z tag (ref: output.c:451,730)
     auto put_csfasta = [&](char* p) { *p++ = "ACGT"[initbp[rd] & 3]; for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = (c < 4) ? (char)('0' + c) : '.'; } return p; };
     if (p2.empty()) {
       if (P.sam_unaligned) {                                                       // ref: output.c:411-466
         size_t o = out.size(); out.resize(o + need); char* p = &out[o];
         p = put_str(p, nm, nl); p = put_str(p, "\t4\t*\t0\t0\t*\t*\t0\t0\t", 17);
-        if (P.colour_space) { p = put_str(p, "*\t*\tCQ:Z:*\tCS:Z:", 16); p = put_csfasta(p); *p++ = '\n'; out.resize(p - out.data()); return 1; }   // ref: output.c:353-355,441-451
+        if (P.colour_space) {                                                        // ref: output.c:353-355,441-451
+          p = put_str(p, "*\t*\tCQ:Z:", 9);
+          if (qual_ptr) p = put_str(p, qual_ptr[rd], (size_t)read_len); else *p++ = '*';
+          p = put_str(p, "\tCS:Z:", 6); p = put_csfasta(p); *p++ = '\n'; out.resize(p - out.data()); return 1;
+        }
         for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = (c < 4) ? "ACGT"[c] : 'N'; }
         if (qual_ptr) { *p++ = '\t'; p = put_str(p, qual_ptr[rd], (size_t)read_len); *p++ = '\n'; }      // ref: output.c:419-421 (verbatim)
         else p = put_str(p, "\t*\n", 3);
@@ -709,10 +736,16 @@ struct Finalizer {
         const int na = (int)h->qr.size();
         if (!rev) { for (int i = 0; i < na; i++) if (h->qr[i] != '-') *p++ = up(h->qr[i]); }
         else for (int i = na - 1; i >= 0; i--) if (h->qr[i] != '-') *p++ = rc_char(up(h->qr[i]));
-        p = put_str(p, "\t*\tAS:i:", 8); p = put_int(p, h->score_full);
+        *p++ = '\t';
+        if (qual_ptr) {                                                             // post_sw's base qualities, ref: output.c:613-621
+          const int nq = (int)h->qual.size();
+          if (!rev) p = put_str(p, h->qual.data(), (size_t)nq); else for (int i = nq - 1; i >= 0; i--) *p++ = h->qual[i];
+        } else *p++ = '*';
+        p = put_str(p, "\tAS:i:", 6); p = put_int(p, h->score_full);
         p = put_str(p, "\tZ0:i:", 6); p = put_int(p, double_to_neglog(h->z0));
         p = put_str(p, "\tZ1:i:", 6); p = put_int(p, double_to_neglog(h->z1));
         p = put_str(p, "\tNM:i:", 6); p = put_int(p, h->cs_mismatch + r.n_del + r.n_ins);
+        if (qual_ptr) { p = put_str(p, "\tCQ:Z:", 6); p = put_str(p, qual_ptr[rd], (size_t)read_len); }   // ref: output.c:724-727
         p = put_str(p, "\tCS:Z:", 6); p = put_csfasta(p);
         p = put_str(p, "\tCM:i:", 6); p = put_int(p, h->cs_xover);
         p = put_str(p, "\tXX:Z:", 6); p = put_str(p, h->qr.data(), h->qr.size());
@@ -851,7 +884,7 @@ static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int
       const int cs9[9] = {s->P.match_score, s->P.mismatch_score, s->P.crossover_score, -s->P.a_gap_open_score, -s->P.a_gap_extend_score,
                           -s->P.b_gap_open_score, -s->P.b_gap_extend_score, s->P.anchor_width, s->P.indel_taboo_len};   // sw_full_cs_setup's arguments (ref: gmapper.c:2944-2947)
       rc = gm_launch_pass2_cs(dv, s->sc, cs9, D.d_reads, D.d_initbp, n, read_len, read_words, W, D.d_hits, D.hcap, D.d_sel, D.d_work, D.d_n_work,
-                              D.d_res, D.d_ops, D.ops_stride, (uint32_t*)D.d_back, D.back_stride / 4, s->p2_grid, s->d_stats, q);
+                              D.d_res, D.d_ops, D.ops_stride, (uint32_t*)D.d_back, D.back_stride / 4, s->p2_grid, s->d_stats, q, D.xover_on ? D.d_xover : nullptr);
     } else
     rc = gm_launch_pass2(dv, s->sc, D.d_reads, n, read_len, read_words, W, D.d_hits, D.d_perm, D.hcap, D.d_sel, D.d_sel_cnt, D.d_work, D.d_n_work,
                          D.d_res, D.d_ops, D.ops_stride, D.d_back, D.back_stride, s->p2_grid, s->d_stats, q);
@@ -902,7 +935,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   s->last_lookup_ms = 0; s->last_lookup_bytes = 0; s->last_lookup_launches = 0;
   // names
   std::vector<const char*> nptr; std::vector<int> nlen;
-  std::vector<const char*> qptr;
+  std::vector<const char*> qptr; std::vector<int8_t> xbuf;
   if (quals) {
     const char* p = quals;
     for (int i = 0; i < n_reads; i++) {
@@ -960,6 +993,22 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
       if (reads_host) GM_HIP(hipMemcpyAsync(D.d_reads, reads_host + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyHostToDevice, s->stream));
       else GM_HIP(hipMemcpyAsync(D.d_reads, (const uint32_t*)reads_dev + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyDeviceToDevice, s->stream));
       if (initbp_host) GM_HIP(hipMemcpyAsync(D.d_initbp, initbp_host + base, (size_t)n, hipMemcpyHostToDevice, s->stream));
+      D.xover_on = false;
+      if (initbp_host && quals) {                              // per-position crossover scores from the QVs, ref: gmapper.c:532-544
+        xbuf.resize((size_t)n * read_len);
+        for (int i = 0; i < n; i++) {
+          const char* q = qptr[base + i];
+          for (int j = 0; j < read_len; j++) {
+            const int qv = (int)q[j] - qual_delta;
+            const double pe = qv <= 0 ? .99999999 : (qv >= 250 ? 1E-25 : pow(10.0, -(double)qv / 10.0));   // pr_err_from_qv, ref: util.h:285-293
+            int c = (int)(s->score_alpha * log(pe / 3.0) / log(2.0));
+            if (c > -1) c = -1; else if (c < 2 * s->P.crossover_score) c = 2 * s->P.crossover_score;
+            xbuf[(size_t)i * read_len + j] = (int8_t)c;
+          }
+        }
+        GM_HIP(hipMemcpyAsync(D.d_xover, xbuf.data(), xbuf.size(), hipMemcpyHostToDevice, s->stream));
+        D.xover_on = true;
+      }
       rc = run_device_pipeline(s, D, s->slot[jobs.size() % 3], n, read_len, stats, &lk);
     } while (rc == 1);
     if (rc) { for (auto& j : jobs) if (j->th.joinable()) j->th.join(); return rc; }
@@ -1013,6 +1062,13 @@ extern "C" int gm_map_reads_fastq(gm_session_t* s, int n_reads, int read_len, co
   if (!quals) { gm_set_error("gm_map_reads_fastq: no QUAL strings"); return GM_E_ARG; }
   if (s && s->P.colour_space) { gm_set_error("gm_map_reads_fastq: letter space only"); return GM_E_ARG; }
   return map_impl(s, n_reads, read_len, reads_packed, nullptr, names, 1, sam, sam_len, stats, nullptr, quals, qual_delta);
+}
+extern "C" int gm_map_reads_cs_fastq(gm_session_t* s, int n_reads, int n_colours, const uint32_t* colours_packed, const uint8_t* initbp, const char* names,
+                                     const char* quals, int qual_delta, char** sam, size_t* sam_len, gm_map_stats_t* stats) {
+  if (!colours_packed || !initbp || !quals) { gm_set_error("gm_map_reads_cs_fastq: bad arguments"); return GM_E_ARG; }
+  if (s && 2 * s->P.crossover_score < -128) { gm_set_error("crossover score %d: per-position scores are kept in 8 bits", s->P.crossover_score); return GM_E_RANGE; }
+  for (int i = 0; i < n_reads; i++) if (initbp[i] > 3) { gm_set_error("read %d: primer letter code %d", i, (int)initbp[i]); return GM_E_ARG; }
+  return map_impl(s, n_reads, n_colours, colours_packed, nullptr, names, 1, sam, sam_len, stats, initbp, quals, qual_delta);
 }
 extern "C" int gm_map_reads_cs(gm_session_t* s, int n_reads, int n_colours, const uint32_t* colours_packed, const uint8_t* initbp, const char* names,
                                char** sam, size_t* sam_len, gm_map_stats_t* stats) {

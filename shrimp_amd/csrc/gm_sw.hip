@@ -842,14 +842,17 @@ struct GmCsDev { int match, mismatch, xover, a_go, a_ge, b_go, b_ge, anchor_widt
 // (4 layers x {nw, n, w}); what row r needs from row r - 1 arrives by DPP shifts.  back[cell] = three words of four codes
 // (dir << 2 | layer) for the nw / n / w states of the four layers.  Out-of-band cells are -INT_MAX/2 as init_cell(.., 0, ..) leaves them.
 struct CsBest { int score, i, j, k, e_nw, e_n, e_w; };
+// xrow: per-position crossover scores of this read (from its QVs, ref: gmapper.c:532-544) or null = the global one everywhere
 __device__ CsBest full_sw_cs_wave(const uint8_t* db, int glen, const uint8_t* qr4, int qstride, int rlen, const GmCsDev& P, bool revcmpl,
-                                  long long rx, long long ry, int rl, int rw, uint32_t* back, int* carry, int lane) {
+                                  long long rx, long long ry, int rl, int rw, uint32_t* back, int* carry, int lane, const int8_t* xrow = nullptr) {
   CsBest best; best.score = 0; best.i = best.j = best.k = 0; best.e_nw = best.e_n = best.e_w = 0;
-  const int xo = P.xover;
+  const int xg = P.xover;                                 // global_xover_penalty: the virtual row above the matrix (ref: sw-full-cs.c:270)
+  int xo = xg;
   const int n_stripes = (rlen + 63) >> 6;
   for (int s = 0; s < n_stripes; s++) {
     const int r = s * 64 + lane;
     const bool row_ok = r < rlen;
+    if (xrow) xo = row_ok ? (int)xrow[r] : xg;           // ref: sw-full-cs.c:312
     int q[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) q[k] = row_ok ? qr4[k * qstride + r] : 0x7F;
@@ -863,7 +866,7 @@ __device__ CsBest full_sw_cs_wave(const uint8_t* db, int glen, const uint8_t* qr
     for (int x = 0; x < 12; x++) { pw[x] = FS_NEG; d[x] = FS_NEG; cur[x] = FS_NEG; }
     if (s == 0 && lane == 0) {                       // virtual row -1, column -1: init_cell(.., 1, xover), ref :201-215
 #pragma unroll
-      for (int k = 0; k < 4; k++) { const int x = k ? xo : 0; d[k * 3] = x; d[k * 3 + 1] = -P.b_go + x; d[k * 3 + 2] = -P.a_go + x; }
+      for (int k = 0; k < 4; k++) { const int x = k ? xg : 0; d[k * 3] = x; d[k * 3 + 1] = -P.b_go + x; d[k * 3 + 2] = -P.a_go + x; }
     }
     const bool more = (s + 1 < n_stripes);
     const bool last_row_lane = row_ok && (r == rlen - 1);
@@ -873,7 +876,7 @@ __device__ CsBest full_sw_cs_wave(const uint8_t* db, int glen, const uint8_t* qr
 #pragma unroll
       for (int x = 0; x < 12; x++) {
         int in;
-        if (s == 0) { const int k = x / 3, st = x % 3; const int xv = k ? xo : 0; in = (st == 0 ? 0 : (st == 1 ? -P.b_go : -P.a_go)) + xv; }
+        if (s == 0) { const int k = x / 3, st = x % 3; const int xv = k ? xg : 0; in = (st == 0 ? 0 : (st == 1 ? -P.b_go : -P.a_go)) + xv; }
         else in = (t < glen) ? carry[x * glen + t] : FS_NEG;
         u[x] = shr1_i(cur[x], in);                    // cell (r-1, c)
       }
@@ -1052,7 +1055,8 @@ __global__ void __launch_bounds__(GM_WAVE)
 k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__ reads, const uint8_t* __restrict__ initbp, int n_reads, int read_len,
            int read_words, const GmHit* __restrict__ hits, int hcap, const int32_t* __restrict__ sel,
            const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work_p, GmFullRes* __restrict__ res, uint8_t* __restrict__ ops, int ops_stride,
-           uint32_t* __restrict__ back_pool, size_t back_words, int max_w, unsigned long long* __restrict__ stats) {
+           uint32_t* __restrict__ back_pool, size_t back_words, int max_w, unsigned long long* __restrict__ stats,
+           const int8_t* __restrict__ xover) {         // [n_reads][read_len] crossover scores from the QVs, or null
   extern __shared__ __align__(16) uint8_t sm[];
   const int lane = threadIdx.x;
   const int qstride = (read_len + 15) & ~15;
@@ -1115,7 +1119,8 @@ k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__
     int rl = (int)((se - nw) / 2 + 1);
     rx -= P.anchor_width / 2; ry += P.anchor_width / 2; rw += P.anchor_width;
     fcalls++; fcells += (unsigned long long)w_len * read_len;
-    const CsBest fo = full_sw_cs_wave(db, w_len, qr4, qstride, read_len, P, (gen_st != 0) && sc.tiebreak_rev, rx, ry, rl, rw, back, carry, lane);
+    const CsBest fo = full_sw_cs_wave(db, w_len, qr4, qstride, read_len, P, (gen_st != 0) && sc.tiebreak_rev, rx, ry, rl, rw, back, carry, lane,
+                                      xover ? xover + (size_t)rd * read_len : nullptr);
     __syncthreads();
     __threadfence();
     if (lane == 0 && fo.score >= 0 && fo.score >= thresh) {     // ref: sw-full-cs.c:1216; do_backtrace :633-937
@@ -1164,7 +1169,7 @@ k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__
 int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs_params9, const uint32_t* d_reads, const uint8_t* d_initbp, int n_reads,
                        int read_len, int read_words, int window_len, const GmHit* d_hits, int hcap, const int32_t* d_sel, const uint32_t* d_work,
                        const uint32_t* d_n_work, GmFullRes* d_res, uint8_t* d_ops, int ops_stride, uint32_t* d_back, size_t back_words, int grid,
-                       unsigned long long* d_stats, hipStream_t stream) {
+                       unsigned long long* d_stats, hipStream_t stream, const int8_t* d_xover) {
   if (n_reads == 0) return GM_OK;
   GmCsDev P; P.match = cs_params9[0]; P.mismatch = cs_params9[1]; P.xover = cs_params9[2]; P.a_go = cs_params9[3]; P.a_ge = cs_params9[4];
   P.b_go = cs_params9[5]; P.b_ge = cs_params9[6]; P.anchor_width = cs_params9[7]; P.taboo = cs_params9[8];
@@ -1173,7 +1178,7 @@ int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs
   static size_t configured = 0;
   if (lds > 48 * 1024 && lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
   hipLaunchKernelGGL(k_pass2_cs, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, P, d_reads, d_initbp, n_reads, read_len, read_words, d_hits, hcap, d_sel,
-                     d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_words, window_len, d_stats);
+                     d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_words, window_len, d_stats, d_xover);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

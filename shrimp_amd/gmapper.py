@@ -80,7 +80,7 @@ EXPORTS = ["gm_last_error", "gm_device_count", "gm_params_default", "gm_params_d
            "sw_vector_setup", "sw_vector", "sw_vector_stats", "sw_vector_cleanup", "gm_sw_vector_batch",
            "sw_full_ls_setup", "sw_full_ls", "sw_full_ls_cleanup",
            "sw_full_cs_setup", "sw_full_cs", "sw_full_cs_cleanup", "gm_sw_vector_batch_cs",
-           "gm_session_create", "gm_session_free", "gm_map_reads", "gm_map_reads_fastq", "gm_map_reads_cs", "gm_map_reads_device", "gm_free", "gm_debug_tophits",
+           "gm_session_create", "gm_session_free", "gm_map_reads", "gm_map_reads_fastq", "gm_map_reads_cs", "gm_map_reads_cs_fastq", "gm_map_reads_device", "gm_free", "gm_debug_tophits",
            "gm_pair_opts_default", "gm_map_pairs",
            "gm_last_lookup_timing"]
 
@@ -127,6 +127,7 @@ def lib():
     L.gm_map_reads.argtypes = [vp, C.c_int, C.c_int, u32p, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_map_reads_fastq.argtypes = [vp, C.c_int, C.c_int, u32p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_map_reads_cs.argtypes = [vp, C.c_int, C.c_int, u32p, C.POINTER(C.c_uint8), C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
+    L.gm_map_reads_cs_fastq.argtypes = [vp, C.c_int, C.c_int, u32p, C.POINTER(C.c_uint8), C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_map_reads_device.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_free.argtypes = [vp]
     L.gm_pair_opts_default.argtypes = [C.POINTER(PairOpts)]
@@ -276,6 +277,22 @@ class Session:
         nm = None if names is None else b"\n".join(x if isinstance(x, bytes) else x.encode() for x in names)
         _check(L.gm_map_reads_fastq(self.h, n, Lr, packed.ctypes.data_as(C.POINTER(C.c_uint32)), nm, b"\n".join(quals), int(qual_delta),
                                     C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_reads_fastq")
+        out = C.string_at(sam, sl.value) if sam.value else b""
+        L.gm_free(sam)
+        self.stats = st.as_dict()
+        return out
+
+    def map_reads_cs_fastq(self, reads_codes: np.ndarray, quals, qual_delta: int = 33, names=None) -> bytes:
+        """csfastq reads: reads_codes as for map_reads_cs; quals = one QV string (bytes, one character per colour) per read."""
+        from .synth import pack_reads
+        reads_codes = np.ascontiguousarray(reads_codes, dtype=np.uint8)
+        n, L1 = reads_codes.shape
+        initbp = np.ascontiguousarray(reads_codes[:, 0])
+        packed = np.ascontiguousarray(pack_reads(np.ascontiguousarray(reads_codes[:, 1:])))
+        L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
+        nm = None if names is None else b"\n".join(x if isinstance(x, bytes) else x.encode() for x in names)
+        _check(L.gm_map_reads_cs_fastq(self.h, n, L1 - 1, packed.ctypes.data_as(C.POINTER(C.c_uint32)), initbp.ctypes.data_as(C.POINTER(C.c_uint8)), nm,
+                                       b"\n".join(quals), int(qual_delta), C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_reads_cs_fastq")
         out = C.string_at(sam, sl.value) if sam.value else b""
         L.gm_free(sam)
         self.stats = st.as_dict()

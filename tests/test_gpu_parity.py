@@ -539,3 +539,21 @@ def test_fastq_quals_match_reference_golden(gm, tag):
         s.map_reads_fastq(reads[:2], [quals[0], quals[1][:-1]], delta)          # QUAL length must equal the read length
     s.close(); ix.close()
     assert got == sam, _first_diff(got, sam)
+
+
+def test_colour_space_fastq_matches_reference_golden(gm):
+    """gm_map_reads_cs_fastq: per-position crossover scores on the device, post_sw with per-colour error rates, QUAL from post_sw,
+    CQ:Z -- byte-identical to gmapper-cs on a csfastq file"""
+    from tests.test_oracle import _cs_fastq_case
+    contigs, reads, quals, delta, sam = _cs_fastq_case()
+    p = gm.default_params_cs(); p.sam_unaligned = 1
+    ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p, max_batch_reads=512)
+    got = oa.sam_header(contigs) + s.map_reads_cs_fastq(reads, quals, delta)
+    st = s.stats
+    plain = s.map_reads_cs(reads[:200])                    # the same session without QVs afterwards: global crossover score again
+    s.close(); ix.close()
+    assert got == sam, (_first_diff(got, sam), st)
+    _, _, want_plain = oa.load_golden("cfg4s_50col_2Mbp")
+    body = b"".join(l + b"\n" for l in want_plain.split(b"\n") if l and not l.startswith(b"@"))
+    plain = b"".join(l + b"\n" for l in plain.split(b"\n") if l and l.split(b"\t")[1] != b"4")      # that golden was made without --sam-unaligned
+    assert plain == b"".join(l + b"\n" for l in body.split(b"\n") if l and int(l.split(b"\t")[0][1:]) < 200)

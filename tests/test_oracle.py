@@ -173,3 +173,24 @@ def test_oracle_fastq_quals_match_reference(tag, oracle_lib):
     got = oa.sam_header(contigs) + s.map_sam_q(reads, quals, delta, nthreads=4)
     s.close()
     assert got == sam
+
+
+def _cs_fastq_case():
+    import gzip, os
+    d = os.path.join(oa.ROOT, "tests", "golden")
+    contigs, reads, _ = oa.load_golden("cfg4s_50col_2Mbp")
+    z = np.load(os.path.join(d, "cfg4s_50col_fq.npz"))
+    with gzip.open(os.path.join(d, "cfg4s_50col_fq.sam.gz"), "rb") as f:
+        sam = f.read()
+    n = int(z["n_reads"])
+    return contigs, reads[:n], [bytes(q.tobytes()) for q in z["quals"]], int(z["qual_delta"]), sam
+
+
+def test_oracle_colour_space_fastq_matches_reference(oracle_lib):
+    """csfastq: per-position crossover scores from the QVs in sw_full_cs, post_sw with per-colour error rates, QUAL = post_sw's base
+    qualities, CQ:Z -- against gmapper-cs"""
+    contigs, reads, quals, delta, sam = _cs_fastq_case()
+    s = oa.Session(contigs, opts="colour=1"); s.set(True, True)
+    got = oa.sam_header(contigs) + s.map_sam_q(reads, quals, delta, nthreads=4)
+    s.close()
+    assert got == sam

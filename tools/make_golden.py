@@ -280,10 +280,34 @@ def fastq_cases():
         print("stress_100bp_%s: %d SAM records" % (tag, sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@"))))
 
 
+def cs_fastq_cases():
+    """colour-space FASTQ (csfastq, PHRED+33): per-position crossover scores, post_sw with read QVs, QUAL from post_sw, CQ:Z"""
+    z = np.load(os.path.join(OUT, "cfg4s_50col_2Mbp.npz"))
+    contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
+    reads = z["reads"][:1500]
+    rng = np.random.default_rng(19)
+    q = (rng.integers(2, 36, size=(reads.shape[0], reads.shape[1] - 1)) + 33).astype(np.uint8)
+    tab = np.full(16, ord("."), dtype=np.uint8); tab[:4] = np.frombuffer(b"0123", dtype=np.uint8)
+    with tempfile.TemporaryDirectory() as d:
+        g = os.path.join(d, "g.fa"); r = os.path.join(d, "r.csfastq")
+        write_fa_codes(g, [b"contig%d" % (i + 1) for i in range(len(contigs))], contigs)
+        with open(r, "wb") as f:
+            for i in range(len(reads)):
+                f.write(b"@r%d\n" % i + b"ACGT"[reads[i, 0]:reads[i, 0] + 1] + tab[reads[i, 1:]].tobytes() + b"\n+\n" + q[i].tobytes() + b"\n")
+        p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "gmapper-cs"), "-N", "4", "--sam-unaligned", r, g], capture_output=True)
+        if p.returncode != 0:
+            print(p.stderr.decode()[-2000:]); raise SystemExit(1)
+        body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+    np.savez_compressed(os.path.join(OUT, "cfg4s_50col_fq.npz"), quals=q, n_reads=np.array(len(reads)), qual_delta=np.array(33))
+    with gzip.open(os.path.join(OUT, "cfg4s_50col_fq.sam.gz"), "wb", compresslevel=9) as f:
+        f.write(body)
+    print("cfg4s_50col_fq: %d SAM records" % sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@")))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--fastq-only" in sys.argv:
-        fastq_cases(); return
+        fastq_cases(); cs_fastq_cases(); return
     if "--cs-only" in sys.argv:
         cs_cases(); return
     if "--cs-kat-only" in sys.argv:
@@ -311,6 +335,7 @@ def main():
     cs_kat_cases()
     cs_cases()
     fastq_cases()
+    cs_fastq_cases()
 
 
 if __name__ == "__main__":
