@@ -133,7 +133,9 @@ int gm_sw_vector_batch(int n, const uint32_t *genome, uint64_t genome_words, con
  * S2: full Smith-Waterman with traceback, letter space.  ref: common/sw-full-ls.c:568-683
  * struct layouts follow the reference (ref: common/sw-full-common.h:13-48, gmapper-definitions.h:66-74)
  * for the fields this path fills; dbalign/qralign are malloc()ed and owned by the caller,
- * as with the reference's xstrdup (ref: sw-full-ls.c:676-677).
+ * as with the reference's xstrdup (ref: sw-full-ls.c:676-677).  Both alignment modes: local_alignment = 0 (global in the read, gmapper's
+ * default) and 1 (--local: floored states, and when the best score in the anchor band is not maxscore a second run over the band
+ * the threshold allows, :395-398); anchors = one box as gmapper passes it, or NULL (that threshold band, :179-192).
  * ------------------------------------------------------------------------------------------- */
 struct gm_anchor { long long x, y; int length, width, weight, cn, score; };
 struct gm_sw_full_results {                    /* field for field struct sw_full_results (ref: common/sw-full-common.h:13-48) */

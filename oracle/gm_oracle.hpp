@@ -637,15 +637,20 @@ static inline void sw_full_ls(const Params& P, SwFullWorkspace& W, const uint32_
     }
   };
   Anchor rectangle;
-  anchor_join(anchors, anchors_cnt, &rectangle);      // sw-full-ls.c:176-178 (anchors != NULL, anchor_width >= 0)
-  anchor_widen(&rectangle, P.anchor_width);
-  full_sw(rectangle);
-  if (local_alignment && score != maxscore) {         // :395-398: the filter's alignment left the band: once more over the band the threshold allows
-    W.local_retries++;
+  auto threshold_band = [&]() {                       // sw-full-ls.c:179-192
     Anchor t[2];
     t[0].x = 0; t[0].y = (lenb * match - threshscore) / match; t[0].length = 1; t[0].width = 1;
     t[1].x = lena - 1; t[1].y = lenb - 1 - t[0].y; t[1].length = 1; t[1].width = 1;
     anchor_join(t, 2, &rectangle);
+  };
+  if (anchors != nullptr && P.anchor_width >= 0) {    // sw-full-ls.c:176-178
+    anchor_join(anchors, anchors_cnt, &rectangle);
+    anchor_widen(&rectangle, P.anchor_width);
+  } else threshold_band();
+  full_sw(rectangle);
+  if (local_alignment && score != maxscore && anchors != nullptr) {         // :395-398: the filter's alignment left the band: once more over the band the threshold allows
+    W.local_retries++;
+    threshold_band();
     full_sw(rectangle);
     assert(score == maxscore);
   }

@@ -154,6 +154,22 @@ int gmo_sw_full_ls(const uint32_t* genome, int goff, int glen, const uint32_t* r
   return 0;
 }
 
+// local mode (Gflag off): anchors optional (has_anchor = 0: the threshold band), thresh / maxscore as gmapper passes them
+int gmo_sw_full_ls_local(const uint32_t* genome, int goff, int glen, const uint32_t* read, int rlen, int thresh, int maxscore,
+                         long long ax, long long ay, int alen, int awidth, int has_anchor, int revcmpl,
+                         int* out, char* dbalign, char* qralign, int cap) {
+  static const Params P = default_params();
+  SwFullWorkspace W; SwFullResults s;
+  Anchor a; a.x = ax; a.y = ay; a.length = alen; a.width = awidth; a.weight = 1;
+  if (has_anchor) sw_full_ls(P, W, genome, goff, glen, read, rlen, thresh, maxscore, &s, revcmpl != 0, &a, 1, 1);
+  else sw_full_ls(P, W, genome, goff, glen, read, rlen, thresh, maxscore, &s, revcmpl != 0, nullptr, 0, 1);
+  int v[9] = {s.score, s.read_start, s.rmapped, s.genome_start, s.gmapped, s.matches, s.mismatches, s.insertions, s.deletions};
+  memcpy(out, v, sizeof v);
+  if ((int)s.dbalign.size() + 1 > cap) return -1;
+  strcpy(dbalign, s.dbalign.c_str()); strcpy(qralign, s.qralign.c_str());
+  return 0;
+}
+
 // colour space kernels with the binary's CS defaults (gmapper-defaults.h:52-58); out[10] = ... deletions crossovers
 int gmo_sw_vector_cs(const uint32_t* genome_cs, int goff, int glen, const uint32_t* read, int rlen, const uint32_t* genome_ls, int initbp) {
   Params P = default_params();

@@ -20,6 +20,7 @@ static void dump(const std::vector<uint32_t>& bf) { for (size_t i = 0; i < bf.si
 
 int main(int argc, char** argv) {
   int n = argc > 1 ? atoi(argv[1]) : 2000;
+  const bool local_mode = argc > 2 && !strcmp(argv[2], "local");   // "L" records: sw_full_ls with local_alignment = 1, with and without an anchor
   std::mt19937_64 rng(20260101);
   sw_vector_setup(1400, 1000, -33, -7, -33, -3, 10, -15, 0, true);
   sw_full_ls_setup(1400, 1000, -33, -7, -33, -3, 10, -15, true, 8);
@@ -51,11 +52,27 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < g.size(); i++) put(gb, (int)i, g[i]);
     for (int i = 0; i < rlen; i++) put(rb, i, r[i]);
     int sv = sw_vector(gb.data(), goff, glen, rb.data(), rlen, NULL, -1, false);
-    printf("V %d %d %d ", goff, glen, rlen); dump(gb); printf(" "); dump(rb); printf(" %d\n", sv);
+    if (!local_mode) { printf("V %d %d %d ", goff, glen, rlen); dump(gb); printf(" "); dump(rb); printf(" %d\n", sv); }
     // full SW around a plausible anchor box
     struct anchor a; memset(&a, 0, sizeof a);
     a.x = (start - goff) + (int)(rng() % 7) - 3; a.y = 0; a.length = 14 + rng() % (rlen > 20 ? rlen - 14 : 6); a.width = 1 + rng() % 4; a.weight = 2;
     if (rng() % 4 == 0) { a.y = rng() % 10; a.x += a.y; }
+    if (local_mode) {
+      const int thresh = (rlen * 10) / 2;
+      if (sv < thresh) continue;                      // gmapper calls the full SW only then (mapping.c:390)
+      if (t % 3 == 0) { a.width = 1; a.length = 12; }  // thin anchors: the best local alignment leaves the band more often (the second run)
+      for (int rv = 0; rv < 2; rv++)
+        for (int na = 0; na < 2; na++) {              // with the anchor box, and without (threshold band)
+          struct sw_full_results sfr; memset(&sfr, 0, sizeof sfr);
+          sw_full_ls(gb.data(), goff, glen, rb.data(), rlen, thresh, sv, &sfr, rv, na ? NULL : &a, na ? 0 : 1, 1);
+          if (sfr.score <= 0) continue;
+          printf("L %d %d %d %lld %lld %d %d %d %d %d %d ", goff, glen, rlen, a.x, a.y, a.length, a.width, rv, na, thresh, sv); dump(gb); printf(" "); dump(rb);
+          printf(" %d %d %d %d %d %d %d %d %d %s %s\n", sfr.score, sfr.read_start, sfr.rmapped, sfr.genome_start, sfr.gmapped,
+                 sfr.matches, sfr.mismatches, sfr.insertions, sfr.deletions, sfr.dbalign, sfr.qralign);
+          free(sfr.dbalign); free(sfr.qralign);
+        }
+      continue;
+    }
     for (int rv = 0; rv < 2; rv++) {
       struct sw_full_results sfr; memset(&sfr, 0, sizeof sfr);
       sw_full_ls(gb.data(), goff, glen, rb.data(), rlen, 0, sv, &sfr, rv, &a, 1, 0);

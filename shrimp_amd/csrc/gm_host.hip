@@ -1195,10 +1195,9 @@ extern "C" int sw_full_ls_cleanup(void) { g_sf.init = false; return 0; }
 
 extern "C" void sw_full_ls(uint32_t* genome, int goff, int glen, uint32_t* read, int rlen, int threshscore, int maxscore,
                            struct gm_sw_full_results* sfr, bool revcmpl, struct gm_anchor* anchors, int anchors_cnt, int local_alignment) {
-  (void)threshscore; (void)maxscore;
   if (!g_sf.init) abort();   // ref: sw-full-ls.c:649-650
-  if (local_alignment || anchors == nullptr || anchors_cnt != 1 || glen > g_sf.dblen || rlen > g_sf.qrlen || glen < 1 || rlen < 1) {
-    gm_set_error("sw_full_ls: only the global mode with one anchor box (gmapper's call, ref: mapping.c:391-394) is implemented");
+  if ((anchors != nullptr && anchors_cnt != 1) || glen > g_sf.dblen || rlen > g_sf.qrlen || glen < 1 || rlen < 1) {
+    gm_set_error("sw_full_ls: one anchor box (gmapper's call, ref: mapping.c:391-394) or none (the threshold band) is implemented");
     sfr->score = 0; sfr->dbalign = strdup(""); sfr->qralign = strdup(""); return;
   }
   const uint64_t gw = ((uint64_t)goff + glen + 7) / 8 + 8; const int rwords = (rlen + 7) / 8 + 1;
@@ -1210,8 +1209,9 @@ extern "C" void sw_full_ls(uint32_t* genome, int goff, int glen, uint32_t* read,
   if (ok) {
     ok = hipMemset(dg, 0, gw * 4) == hipSuccess && hipMemcpy(dg, genome, (gw - 8) * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(dr, read, (size_t)(rwords - 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
-         gm_launch_sw_full_single(g_sf.sc, dg, goff, glen, dr, rlen, anchors[0].x, anchors[0].y, anchors[0].length, anchors[0].width, revcmpl ? 1 : 0,
-                                  dback, dout, dops, ops_cap, 0) == GM_OK &&
+         gm_launch_sw_full_single(g_sf.sc, dg, goff, glen, dr, rlen, anchors ? anchors[0].x : 0, anchors ? anchors[0].y : 0, anchors ? anchors[0].length : 1,
+                                  anchors ? anchors[0].width : 1, revcmpl ? 1 : 0, dback, dout, dops, ops_cap, 0, anchors ? 1 : 0, threshscore, maxscore,
+                                  local_alignment ? 1 : 0) == GM_OK &&
          hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, dout, sizeof out, hipMemcpyDeviceToHost) == hipSuccess &&
          hipMemcpy(ops.data(), dops, ops_cap, hipMemcpyDeviceToHost) == hipSuccess;
   }

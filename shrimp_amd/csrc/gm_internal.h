@@ -114,7 +114,7 @@ int gm_launch_sw_vector_batch(const GmScoreDev& sc, int n, const uint32_t* d_gen
 // S2 single alignment on caller-provided bitfields
 int gm_launch_sw_full_single(const GmScoreDev& sc, const uint32_t* d_genome, long long goff, int glen, const uint32_t* d_read, int rlen,
                              long long ax, long long ay, int alen, int awidth, int revcmpl, uint8_t* d_back, int* d_out, uint8_t* d_ops, int ops_cap,
-                             hipStream_t stream);
+                             hipStream_t stream, int has_anchor = 1, int thresh = 0, int maxscore = 0, int local = 0);   // no anchor: the threshold band; local: Gflag off
 
 // colour space S1/S2 (gm_sw.hip): cs_params9 = match mismatch xover a_go a_ge b_go b_ge anchor_width indel_taboo_len (penalties positive)
 int gm_launch_sw_vector_batch_cs(const GmScoreDev& sc, int n, const uint32_t* d_genome_cs, const uint32_t* d_genome_ls, const long long* d_goff,

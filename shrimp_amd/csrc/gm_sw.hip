@@ -496,6 +496,22 @@ __device__ FullOut full_sw_wave(const uint8_t* db, int glen, const uint8_t* qr, 
   return out;
 }
 
+// The band sw_full_ls falls back to without anchors (ref: sw-full-ls.c:179-192): anchor_join of the corner anchors (0, y0) and
+// (glen - 1, rlen - 1 - y0), y0 = (rlen * match - thresh) / match, both of length and width 1 (anchors.c:9-52).
+__device__ __forceinline__ void threshold_band(int glen, int rlen, int match, int thresh, long long* rx, long long* ry, int* rl, int* rw) {
+  const long long y0 = ((long long)rlen * match - thresh) / match;
+  const long long bx[2] = {0, glen - 1}, by[2] = {y0, rlen - 1 - y0};
+  long long b_nw = bx[0] + by[0], b_sw = bx[0] - by[0], b_ne = b_sw, b_se = b_nw;
+  b_nw = bx[1] + by[1] < b_nw ? bx[1] + by[1] : b_nw; b_sw = bx[1] - by[1] < b_sw ? bx[1] - by[1] : b_sw;
+  b_ne = bx[1] - by[1] > b_ne ? bx[1] - by[1] : b_ne; b_se = bx[1] + by[1] > b_se ? bx[1] + by[1] : b_se;
+  if ((b_nw + b_sw) % 2 != 0) b_nw--;
+  *rx = (b_nw + b_sw) / 2; *ry = b_nw - *rx;
+  if ((b_ne - b_sw) % 2 != 0) b_ne++;
+  *rw = (int)((b_ne - b_sw) / 2 + 1);
+  if ((b_se - b_nw) % 2 != 0) b_se++;
+  *rl = (int)((b_se - b_nw) / 2 + 1);
+}
+
 template <bool BACK_LDS, bool LOCAL>
 __global__ void __launch_bounds__(GM_WAVE)
 k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words,
@@ -568,21 +584,8 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
       FullOut fo = full_sw_wave<LOCAL>(db, w_len, qr, read_len, sc, (gen_st != 0) && sc.tiebreak_rev, rx, ry, rl, rw, back, carry, lane);
       __syncthreads();
       if (LOCAL && fo.score != sv) {
-        // the filter's best local alignment leaves the anchor band: once more over the band the threshold allows, from the two
-        // corner anchors (0, y0) and (glen - 1, rlen - 1 - y0), y0 = (rlen * match - thresh) / match (ref: sw-full-ls.c:179-192,395-398)
-        const long long y0 = ((long long)read_len * sc.match - thresh) / sc.match;
-        const long long bx[2] = {0, w_len - 1}, by[2] = {y0, read_len - 1 - y0};
-        long long border_nw = bx[0] + by[0], border_sw = bx[0] - by[0], border_ne = border_sw, border_se = border_nw;   // anchor_join, ref: anchors.c:9-52 (length = width = 1)
-        for (int a = 1; a < 2; a++) {
-          border_nw = bx[a] + by[a] < border_nw ? bx[a] + by[a] : border_nw; border_sw = bx[a] - by[a] < border_sw ? bx[a] - by[a] : border_sw;
-          border_ne = bx[a] - by[a] > border_ne ? bx[a] - by[a] : border_ne; border_se = bx[a] + by[a] > border_se ? bx[a] + by[a] : border_se;
-        }
-        if ((border_nw + border_sw) % 2 != 0) border_nw--;
-        rx = (border_nw + border_sw) / 2; ry = border_nw - rx;
-        if ((border_ne - border_sw) % 2 != 0) border_ne++;
-        rw = (int)((border_ne - border_sw) / 2 + 1);
-        if ((border_se - border_nw) % 2 != 0) border_se++;
-        rl = (int)((border_se - border_nw) / 2 + 1);
+        // the filter's best local alignment leaves the anchor band: once more over the band the threshold allows (ref: sw-full-ls.c:395-398)
+        threshold_band(w_len, read_len, sc.match, thresh, &rx, &ry, &rl, &rw);
         fo = full_sw_wave<LOCAL>(db, w_len, qr, read_len, sc, (gen_st != 0) && sc.tiebreak_rev, rx, ry, rl, rw, back, carry, lane);
         __syncthreads();
       }
@@ -684,10 +687,11 @@ k_sw_vector_batch(GmScoreDev sc, int n, const uint32_t* __restrict__ genome, con
 // S2 single call: sw_full_ls on caller bitfields (ref: common/sw-full-ls.c:637-683), global mode.
 // out[0..12] = score read_start rmapped genome_start gmapped matches mismatches insertions deletions n_ops max_i max_j 0
 // ---------------------------------------------------------------------------------------------
+template <bool LOCAL>
 __global__ void __launch_bounds__(GM_WAVE)
 k_sw_full_single(GmScoreDev sc, const uint32_t* __restrict__ genome, long long goff, int glen, const uint32_t* __restrict__ read, int rlen,
-                 long long ax, long long ay, int alen, int awidth, int revcmpl, uint8_t* __restrict__ back, int* __restrict__ out,
-                 uint8_t* __restrict__ ops, int ops_cap) {
+                 long long ax, long long ay, int alen, int awidth, int has_anchor, int thresh, int maxscore, int revcmpl,
+                 uint8_t* __restrict__ back, int* __restrict__ out, uint8_t* __restrict__ ops, int ops_cap) {
   extern __shared__ __align__(16) uint8_t sm[];
   const int lane = threadIdx.x;
   uint8_t* qr = sm;
@@ -696,16 +700,24 @@ k_sw_full_single(GmScoreDev sc, const uint32_t* __restrict__ genome, long long g
   load_read(read, rlen, false, qr, lane);
   load_window(genome, (uint64_t)goff, glen, false, db, lane);
   __syncthreads();
-  long long nw = ax + ay, sw = ax - ay, ne = sw + 2 * (awidth - 1), se = nw + 2 * (alen - 1);
-  if ((nw + sw) % 2 != 0) nw--;
-  long long rx = (nw + sw) / 2, ry = nw - rx;
-  if ((ne - sw) % 2 != 0) ne++;
-  int rw = (int)((ne - sw) / 2 + 1);
-  if ((se - nw) % 2 != 0) se++;
-  int rl = (int)((se - nw) / 2 + 1);
-  rx -= sc.anchor_width / 2; ry += sc.anchor_width / 2; rw += sc.anchor_width;
-  const FullOut fo = full_sw_wave<false>(db, glen, qr, rlen, sc, revcmpl != 0, rx, ry, rl, rw, back, carry, lane);
+  long long rx, ry; int rw, rl;
+  if (has_anchor) {
+    long long nw = ax + ay, sw = ax - ay, ne = sw + 2 * (awidth - 1), se = nw + 2 * (alen - 1);
+    if ((nw + sw) % 2 != 0) nw--;
+    rx = (nw + sw) / 2; ry = nw - rx;
+    if ((ne - sw) % 2 != 0) ne++;
+    rw = (int)((ne - sw) / 2 + 1);
+    if ((se - nw) % 2 != 0) se++;
+    rl = (int)((se - nw) / 2 + 1);
+    rx -= sc.anchor_width / 2; ry += sc.anchor_width / 2; rw += sc.anchor_width;
+  } else threshold_band(glen, rlen, sc.match, thresh, &rx, &ry, &rl, &rw);       // ref: sw-full-ls.c:179-192
+  FullOut fo = full_sw_wave<LOCAL>(db, glen, qr, rlen, sc, revcmpl != 0, rx, ry, rl, rw, back, carry, lane);
   __syncthreads();
+  if (LOCAL && has_anchor && fo.score != maxscore) {                              // ref: sw-full-ls.c:395-398
+    threshold_band(glen, rlen, sc.match, thresh, &rx, &ry, &rl, &rw);
+    fo = full_sw_wave<LOCAL>(db, glen, qr, rlen, sc, revcmpl != 0, rx, ry, rl, rw, back, carry, lane);
+    __syncthreads();
+  }
   if (lane == 0) {
     int i = fo.max_i, j = fo.max_j, no = 0, rstart = 0, gstart = 0, nm = 0, nmm = 0, nin = 0, ndel = 0;
     if (fo.score > 0) {
@@ -715,6 +727,11 @@ k_sw_full_single(GmScoreDev sc, const uint32_t* __restrict__ genome, long long g
       while (i >= 0 && j >= 0) {
         const uint8_t bb = __hip_atomic_load(&back[(size_t)i * glen + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!(bb & 0x80)) break;
+        if (LOCAL) {
+          if ((bb >> (4 + state)) & 1) break;
+          int bx_min, bx_max; band_range(rx, ry, rl, rw, glen, i, &bx_min, &bx_max);
+          if (j < bx_min || j > bx_max) break;
+        }
         int nstate;
         if (state == 1) { if (no < ops_cap) ops[no] = 'D'; no++; ndel++; rstart = i; i--; nstate = ((bb >> 2) & 1) ? 1 : 0; }
         else if (state == 2) { if (no < ops_cap) ops[no] = 'I'; no++; nin++; gstart = j; j--; nstate = ((bb >> 3) & 1) ? 2 : 0; }
@@ -731,10 +748,14 @@ k_sw_full_single(GmScoreDev sc, const uint32_t* __restrict__ genome, long long g
 
 int gm_launch_sw_full_single(const GmScoreDev& sc, const uint32_t* d_genome, long long goff, int glen, const uint32_t* d_read, int rlen,
                              long long ax, long long ay, int alen, int awidth, int revcmpl, uint8_t* d_back, int* d_out, uint8_t* d_ops, int ops_cap,
-                             hipStream_t stream) {
+                             hipStream_t stream, int has_anchor, int thresh, int maxscore, int local) {
   const size_t lds = ((rlen + 15) & ~15) + ((glen + 15) & ~15) + (size_t)glen * 12 + 64;
-  hipLaunchKernelGGL(k_sw_full_single, dim3(1), dim3(GM_WAVE), lds, stream, sc, d_genome, goff, glen, d_read, rlen, ax, ay, alen, awidth, revcmpl,
-                     d_back, d_out, d_ops, ops_cap);
+  if (local)
+    hipLaunchKernelGGL(k_sw_full_single<true>, dim3(1), dim3(GM_WAVE), lds, stream, sc, d_genome, goff, glen, d_read, rlen, ax, ay, alen, awidth, has_anchor, thresh,
+                       maxscore, revcmpl, d_back, d_out, d_ops, ops_cap);
+  else
+    hipLaunchKernelGGL(k_sw_full_single<false>, dim3(1), dim3(GM_WAVE), lds, stream, sc, d_genome, goff, glen, d_read, rlen, ax, ay, alen, awidth, has_anchor, thresh,
+                       maxscore, revcmpl, d_back, d_out, d_ops, ops_cap);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

@@ -413,14 +413,14 @@ def sw_full_ls_setup(dblen, qrlen, a_gap_open, a_gap_ext, b_gap_open, b_gap_ext,
     _check(lib().sw_full_ls_setup(dblen, qrlen, a_gap_open, a_gap_ext, b_gap_open, b_gap_ext, match, mismatch, reset_stats, anchor_width), "sw_full_ls_setup")
 
 
-def sw_full_ls(genome_words, goff, glen, read_words, rlen, anchor, revcmpl=False):
-    """anchor = (x, y, length, width); returns (fields dict, dbalign, qralign)."""
+def sw_full_ls(genome_words, goff, glen, read_words, rlen, anchor, revcmpl=False, threshscore=0, maxscore=0, local_alignment=False):
+    """anchor = (x, y, length, width) or None (the threshold band); returns (fields dict, dbalign, qralign)."""
     L = lib()
     g = np.ascontiguousarray(genome_words, dtype=np.uint32); r = np.ascontiguousarray(read_words, dtype=np.uint32)
-    a = Anchor(anchor[0], anchor[1], anchor[2], anchor[3], 1, 0, 0)
+    a = Anchor(anchor[0], anchor[1], anchor[2], anchor[3], 1, 0, 0) if anchor is not None else None
     s = SwFullResults()
-    L.sw_full_ls(g.ctypes.data_as(C.POINTER(C.c_uint32)), goff, glen, r.ctypes.data_as(C.POINTER(C.c_uint32)), rlen, 0, 0,
-                 C.byref(s), bool(revcmpl), C.byref(a), 1, 0)
+    L.sw_full_ls(g.ctypes.data_as(C.POINTER(C.c_uint32)), goff, glen, r.ctypes.data_as(C.POINTER(C.c_uint32)), rlen, int(threshscore), int(maxscore),
+                 C.byref(s), bool(revcmpl), C.byref(a) if a is not None else None, 1 if a is not None else 0, 1 if local_alignment else 0)
     db = C.string_at(s.dbalign).decode() if s.dbalign else ""
     qr = C.string_at(s.qralign).decode() if s.qralign else ""
     L.gm_free(s.dbalign); L.gm_free(s.qralign)

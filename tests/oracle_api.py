@@ -29,6 +29,9 @@ def load():
     L.gmo_sw_full_ls.argtypes = [u32p, C.c_int, C.c_int, u32p, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_int), C.c_char_p, C.c_char_p, C.c_int]
     L.gmo_sw_full_ls.restype = C.c_int
+    L.gmo_sw_full_ls_local.argtypes = [u32p, C.c_int, C.c_int, u32p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(C.c_int), C.c_char_p, C.c_char_p, C.c_int]
+    L.gmo_sw_full_ls_local.restype = C.c_int
     L.gmo_session_create.argtypes = [C.c_int, C.POINTER(u8p), C.POINTER(C.c_uint64), C.c_void_p]; L.gmo_session_create.restype = C.c_void_p
     L.gmo_session_create_opts.argtypes = [C.c_int, C.POINTER(u8p), C.POINTER(C.c_uint64), C.c_void_p, C.c_char_p]; L.gmo_session_create_opts.restype = C.c_void_p
     L.gmo_session_destroy.argtypes = [C.c_void_p]
@@ -198,6 +201,16 @@ OPTION_CASES = {
 def load_option_sam(base, tag):
     with gzip.open(os.path.join(ROOT, "tests", "golden", "%s@%s.sam.gz" % (base, tag)), "rb") as f:
         return f.read()
+
+
+def load_kat_local():
+    """sw_full_ls in local mode (Gflag off), with an anchor box and without, from the reference's own function (oracle/ref_kat.cpp local)"""
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "sw_kat_local.txt.gz"), "rt") as f:
+        for line in f:
+            t = line.split()
+            if t[0] != "L": continue
+            # goff glen rlen ax ay alen awidth rv no_anchor thresh sv | genome read | 9 ints | dbalign qralign
+            yield (tuple(int(x) for x in t[1:12]), parse_words(t[12]), parse_words(t[13]), [int(x) for x in t[14:23]], t[23], t[24])
 
 
 def load_kat_cs():

@@ -557,3 +557,18 @@ def test_colour_space_fastq_matches_reference_golden(gm):
     body = b"".join(l + b"\n" for l in want_plain.split(b"\n") if l and not l.startswith(b"@"))
     plain = b"".join(l + b"\n" for l in plain.split(b"\n") if l and l.split(b"\t")[1] != b"4")      # that golden was made without --sam-unaligned
     assert plain == b"".join(l + b"\n" for l in body.split(b"\n") if l and int(l.split(b"\t")[0][1:]) < 200)
+
+
+def test_sw_full_ls_local_mode_known_answers(gm):
+    """S2 seam with local_alignment = 1: anchor box (and the threshold-band second run when the filter's alignment leaves it) and
+    anchors == NULL, against the reference's own sw_full_ls"""
+    gm.sw_full_ls_setup(1400, 1000, -33, -7, -33, -3, 10, -15, True, 8)
+    n = 0
+    for (goff, glen, rlen, ax, ay, alen, aw, rv, no_anchor, thresh, sv), g, r, want, edb, eqr in oa.load_kat_local():
+        f, db, qr = gm.sw_full_ls(g, goff, glen, r, rlen, None if no_anchor else (ax, ay, alen, aw), revcmpl=bool(rv), threshscore=thresh, maxscore=sv,
+                                  local_alignment=True)
+        got = [f[k] for k in ("score", "read_start", "rmapped", "genome_start", "gmapped", "matches", "mismatches", "insertions", "deletions")]
+        assert got == want and db == edb and qr == eqr, (goff, glen, rlen, no_anchor, got, want)
+        n += 1
+        if n >= 500: break
+    assert n >= 500

@@ -194,3 +194,15 @@ def test_oracle_colour_space_fastq_matches_reference(oracle_lib):
     got = oa.sam_header(contigs) + s.map_sam_q(reads, quals, delta, nthreads=4)
     s.close()
     assert got == sam
+
+
+def test_oracle_sw_full_ls_local_known_answers(oracle_lib):
+    """S2 in local mode: with the anchor box (incl. the threshold-band second run) and without anchors, against the reference's own sw_full_ls"""
+    L = oa.load(); u32p = C.POINTER(C.c_uint32); n = 0
+    for (goff, glen, rlen, ax, ay, alen, aw, rv, no_anchor, thresh, sv), g, r, want, db, qr in oa.load_kat_local():
+        out = (C.c_int * 9)(); dba = C.create_string_buffer(4096); qra = C.create_string_buffer(4096)
+        assert L.gmo_sw_full_ls_local(g.ctypes.data_as(u32p), goff, glen, r.ctypes.data_as(u32p), rlen, thresh, sv, ax, ay, alen, aw, 0 if no_anchor else 1, rv,
+                                      out, dba, qra, 4096) == 0
+        assert list(out) == want and dba.value.decode() == db and qra.value.decode() == qr, (goff, glen, rlen, no_anchor, list(out), want)
+        n += 1
+    assert n >= 1000

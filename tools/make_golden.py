@@ -204,6 +204,13 @@ def _index_case(dirname, seeds, extra):
     print(dirname + ": %d SAM records from the reference's -L run; files:" % sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@")), sorted(os.listdir(d)))
 
 
+def local_kat_cases():
+    kat = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_kat"), "600", "local"], capture_output=True, check=True).stdout
+    with gzip.open(os.path.join(OUT, "sw_kat_local.txt.gz"), "wb", compresslevel=9) as f:
+        f.write(kat)
+    print("sw_kat_local:", kat.count(b"\nL ") + 1, "sw_full_ls local-mode answers")
+
+
 def cs_kat_cases():
     kat = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_kat_cs"), "700"], capture_output=True, check=True).stdout
     with gzip.open(os.path.join(OUT, "sw_kat_cs.txt.gz"), "wb", compresslevel=9) as f:
@@ -312,6 +319,8 @@ def main():
         cs_cases(); return
     if "--cs-kat-only" in sys.argv:
         cs_kat_cases(); return
+    if "--local-kat-only" in sys.argv:
+        local_kat_cases(); return
     if "--index-only" in sys.argv:
         index_cases(); return
     if "--options-only" in sys.argv:
@@ -333,6 +342,7 @@ def main():
     option_cases()
     index_cases()
     cs_kat_cases()
+    local_kat_cases()
     cs_cases()
     fastq_cases()
     cs_fastq_cases()
