@@ -128,6 +128,7 @@ KERNEL_VARIANTS = [
     {"GM_SLAB_BITS": "18", "GM_K4_BINCAP": "16"},            # v4 candidate bins overflow: read-strands redone by the slab-sweep kernel in list mode
     {"GM_SLAB_BITS": "18", "GM_K4_WCAP": "8"},               # v4 window -> list by binary search
     {"GM_SLAB_BITS": "18", "GM_K1_V3": "1"},                 # the slab-sweep lane-group kernel (k_lookup_v3)
+    {"GM_SLAB_BITS": "18", "GM_SCAP": "256", "GM_SCAP2": "64"},   # v4 survivors beyond the LDS tiers: heavy tier (re-emission by the lane-per-list kernel)
     {"GM_SLAB_BITS": "18", "GM_K1_V2": "1"},                 # the lane-per-list kernel (also the heavy tier's re-emission)
     {"GM_NO_PRUNE": "1"},                                    # K2 on the unpruned survivors
     {"GM_SCAP": "256", "GM_SCAP2": "64"},                    # small LDS tiers: most read-strands take the heavy tier
