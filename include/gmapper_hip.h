@@ -246,6 +246,11 @@ void gm_pair_opts_default(gm_pair_opts_t *o);
 int gm_map_pairs(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_packed, int len2, const uint32_t *mates2_packed,
                  const char *names1, const char *names2, const gm_pair_opts_t *opts,
                  char **sam, size_t *sam_len, gm_map_stats_t *stats);
+/* FASTQ pairs: as gm_map_pairs, plus the mates' QUAL strings ('\n' separated) and the file's quality offset; the QUAL column is printed as
+ * gm_map_reads_fastq prints it (mates keep their input orientation: read_reverse() leaves seq and qual alone, ref: gmapper.c:174-185). */
+int gm_map_pairs_fastq(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_packed, int len2, const uint32_t *mates2_packed,
+                       const char *names1, const char *names2, const char *quals1, const char *quals2, int qual_delta,
+                       const gm_pair_opts_t *opts, char **sam, size_t *sam_len, gm_map_stats_t *stats);
 
 /* per-read top-K candidate rows after pass 1 (heap array order), for stage parity tests:
  * 12 x int64 per row: read st cn g_off w_len score_vector pct_score_vector matches ax ay alen awidth */

@@ -1956,7 +1956,7 @@ struct Mapper {
     };
     if (query_unmapped) {                                                     // output.c:411-466 (half_paired => only this case)
       out += qname; snprintf(buf, sizeof buf, "\t%i\t*\t0\t0\t*\t%s\t%u\t0\t", flags(), mrnm, (unsigned)mpos); out += buf;
-      out += seq; out += "\t*\n";
+      out += seq; out += "\t"; out += P.Qflag ? re.qual : std::string("*"); out += "\n";     // output.c:419-421
       return;
     }
     const SwFullResults& s = rh->sfr;
@@ -1994,7 +1994,13 @@ struct Mapper {
     snprintf(buf, sizeof buf, "\t%u\t%i\t", (unsigned)genome_start, s.mqv); out += buf;
     for (auto& c : cigar) { snprintf(buf, sizeof buf, "%d%c", c.first, c.second); out += buf; }
     snprintf(buf, sizeof buf, "\t%s\t%u\t%i\t", mrnm, (unsigned)mpos, isize); out += buf;
-    out += seq; out += "\t*";
+    out += seq; out += "\t";
+    if (P.Qflag) {                               // output.c:539-570
+      std::string qual = re.qual;
+      if (reverse_strand) std::reverse(qual.begin(), qual.end());
+      if (P.qual_delta != 33) for (auto& c : qual) c = (char)(c - P.qual_delta + 33);
+      out += qual;
+    } else out += "*";
     snprintf(buf, sizeof buf, "\tAS:i:%d", rh->score_full); out += buf;
     if (P.compute_mapping_qualities) {
       if (rh != nullptr && rh_mp != nullptr && !improper)

@@ -318,6 +318,30 @@ char* gmo_map_pairs_sam(void* s, int n, int L1, const uint8_t* codes1, int L2, c
   memcpy(r, out.data(), out.size()); r[out.size()] = 0;
   return r;
 }
+// FASTQ pairs: as gmo_map_pairs_sam plus the mates' QUAL strings ('\n' separated) and the file's quality offset
+char* gmo_map_pairs_sam_q(void* s, int n, int L1, const uint8_t* codes1, int L2, const uint8_t* codes2, const char* names1, const char* names2,
+                          const char* quals1, const char* quals2, int qual_delta, int nthreads) {
+  Session* S = (Session*)s;
+  std::vector<Read> reads((size_t)2 * n);
+  const char* p1 = names1; const char* p2 = names2; const char* q1 = quals1; const char* q2 = quals2;
+  auto next = [](const char*& p, std::string& dst) { const char* e = strchr(p, '\n'); if (!e) e = p + strlen(p); dst.assign(p, e); p = *e ? e + 1 : e; };
+  for (int i = 0; i < n; i++) {
+    char nm[40];
+    if (p1) next(p1, reads[2 * i].name); else { snprintf(nm, sizeof nm, "p%d/1", i); reads[2 * i].name = nm; }
+    if (p2) next(p2, reads[2 * i + 1].name); else { snprintf(nm, sizeof nm, "p%d/2", i); reads[2 * i + 1].name = nm; }
+    next(q1, reads[2 * i].qual); next(q2, reads[2 * i + 1].qual);
+    reads[2 * i].seq = code_seq(codes1 + (size_t)i * L1, L1);
+    reads[2 * i + 1].seq = code_seq(codes2 + (size_t)i * L2, L2);
+  }
+  const bool oq = S->M.P.Qflag; const int od = S->M.P.qual_delta;
+  S->M.P.Qflag = true; S->M.P.qual_delta = qual_delta;
+  std::string out;
+  map_all(*S, reads, nthreads > 0 ? nthreads : 1, out, nullptr);
+  S->M.P.Qflag = oq; S->M.P.qual_delta = od;
+  char* r = (char*)malloc(out.size() + 1);
+  memcpy(r, out.data(), out.size()); r[out.size()] = 0;
+  return r;
+}
 void gmo_free(void* p) { free(p); }
 
 // Stage dump for one batch, for GPU-vs-oracle stage parity: for every read the pass-1 survivors

@@ -81,7 +81,7 @@ EXPORTS = ["gm_last_error", "gm_device_count", "gm_params_default", "gm_params_d
            "sw_full_ls_setup", "sw_full_ls", "sw_full_ls_cleanup",
            "sw_full_cs_setup", "sw_full_cs", "sw_full_cs_cleanup", "gm_sw_vector_batch_cs",
            "gm_session_create", "gm_session_free", "gm_map_reads", "gm_map_reads_fastq", "gm_map_reads_cs", "gm_map_reads_cs_fastq", "gm_map_reads_device", "gm_free", "gm_debug_tophits",
-           "gm_pair_opts_default", "gm_map_pairs",
+           "gm_pair_opts_default", "gm_map_pairs", "gm_map_pairs_fastq",
            "gm_last_lookup_timing"]
 
 _lib = None
@@ -131,6 +131,8 @@ def lib():
     L.gm_map_reads_device.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_free.argtypes = [vp]
     L.gm_pair_opts_default.argtypes = [C.POINTER(PairOpts)]
+    L.gm_map_pairs_fastq.argtypes = [vp, C.c_int, C.c_int, u32p, C.c_int, u32p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(PairOpts),
+                                     C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_map_pairs.argtypes = [vp, C.c_int, C.c_int, u32p, C.c_int, u32p, C.c_char_p, C.c_char_p, C.POINTER(PairOpts),
                                C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_debug_tophits.argtypes = [vp, C.c_int, C.c_int, u32p, C.POINTER(C.c_longlong), C.c_long, C.POINTER(C.c_long)]
@@ -341,6 +343,23 @@ class Session:
         o = opts if opts is not None else PairOpts.default(mode, min_insert, max_insert)
         _check(L.gm_map_pairs(self.h, m1.shape[0], m1.shape[1], p1.ctypes.data_as(C.POINTER(C.c_uint32)), m2.shape[1], p2.ctypes.data_as(C.POINTER(C.c_uint32)),
                               join(names1), join(names2), C.byref(o), C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_pairs")
+        out = C.string_at(sam, sl.value) if sam.value else b""
+        L.gm_free(sam)
+        self.stats = st.as_dict()
+        return out
+
+    def map_pairs_fastq(self, mates1: np.ndarray, mates2: np.ndarray, quals1, quals2, qual_delta: int = 64, names1=None, names2=None,
+                        mode="opp-in", min_insert=0, max_insert=1000, opts: "PairOpts | None" = None) -> bytes:
+        """Paired FASTQ: as map_pairs plus one QUAL string (bytes) per mate and the file's quality offset."""
+        from .synth import pack_reads
+        L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
+        m1 = np.ascontiguousarray(mates1, dtype=np.uint8); m2 = np.ascontiguousarray(mates2, dtype=np.uint8)
+        p1 = np.ascontiguousarray(pack_reads(m1)); p2 = np.ascontiguousarray(pack_reads(m2))
+        join = lambda names: None if names is None else b"\n".join(x if isinstance(x, bytes) else x.encode() for x in names)
+        o = opts if opts is not None else PairOpts.default(mode, min_insert, max_insert)
+        _check(L.gm_map_pairs_fastq(self.h, m1.shape[0], m1.shape[1], p1.ctypes.data_as(C.POINTER(C.c_uint32)), m2.shape[1], p2.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                    join(names1), join(names2), b"\n".join(quals1), b"\n".join(quals2), int(qual_delta), C.byref(o),
+                                    C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_pairs_fastq")
         out = C.string_at(sam, sl.value) if sam.value else b""
         L.gm_free(sam)
         self.stats = st.as_dict()

@@ -82,6 +82,18 @@ class Session:
         s = C.string_at(p); self.L.gmo_free(p)
         return s
 
+    def map_pairs_sam_q(self, m1, m2, quals1, quals2, qual_delta=64, names1=None, names2=None, nthreads=4):
+        m1 = np.ascontiguousarray(m1, dtype=np.uint8); m2 = np.ascontiguousarray(m2, dtype=np.uint8)
+        n1 = b"\n".join(bytes(x) for x in names1) if names1 is not None else None
+        n2 = b"\n".join(bytes(x) for x in names2) if names2 is not None else None
+        u8p = C.POINTER(C.c_uint8)
+        self.L.gmo_map_pairs_sam_q.restype = C.c_void_p
+        self.L.gmo_map_pairs_sam_q.argtypes = [C.c_void_p, C.c_int, C.c_int, u8p, C.c_int, u8p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+        p = self.L.gmo_map_pairs_sam_q(self.h, m1.shape[0], m1.shape[1], m1.ctypes.data_as(u8p), m2.shape[1], m2.ctypes.data_as(u8p), n1, n2,
+                                       b"\n".join(quals1), b"\n".join(quals2), qual_delta, nthreads)
+        s = C.string_at(p); self.L.gmo_free(p)
+        return s
+
     def set(self, hash_filter_calls=True, sam_unaligned=False):
         self.L.gmo_session_set(self.h, int(hash_filter_calls), int(sam_unaligned))
 

@@ -573,3 +573,16 @@ def test_sw_full_ls_local_mode_known_answers(gm):
         n += 1
         if n >= 500: break
     assert n >= 500
+
+
+def test_paired_fastq_matches_reference_golden(gm):
+    """gm_map_pairs_fastq: QUAL strings in paired and half-paired records as the reference prints them"""
+    from tests.test_oracle import _paired_fastq_case
+    g, q1, q2, delta, sam = _paired_fastq_case()
+    p = gm.default_params(); p.sam_unaligned = 1
+    ix = gm.Index(g["contigs"], names=g["contig_names"], params=p)
+    s = gm.Session(ix, params=p, max_batch_reads=256)
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_fastq(g["m1"], g["m2"], q1, q2, delta, g["names1"], g["names2"], mode=g["mode"],
+                                                                             min_insert=g["ins"][0], max_insert=g["ins"][1])
+    s.close(); ix.close()
+    assert got == sam, _first_diff(got, sam)

@@ -206,3 +206,24 @@ def test_oracle_sw_full_ls_local_known_answers(oracle_lib):
         assert list(out) == want and dba.value.decode() == db and qra.value.decode() == qr, (goff, glen, rlen, no_anchor, list(out), want)
         n += 1
     assert n >= 1000
+
+
+def _paired_fastq_case():
+    import gzip, os
+    d = os.path.join(oa.ROOT, "tests", "golden")
+    g = oa.load_golden_pairs("stress_pairs_2x100")
+    z = np.load(os.path.join(d, "stress_pairs_fq33.npz"))
+    with gzip.open(os.path.join(d, "stress_pairs_fq33.sam.gz"), "rb") as f:
+        sam = f.read()
+    n = int(z["n_pairs"])
+    g = dict(g, m1=g["m1"][:n], m2=g["m2"][:n], names1=g["names1"][:n], names2=g["names2"][:n])
+    return g, [bytes(q.tobytes()) for q in z["quals1"]], [bytes(q.tobytes()) for q in z["quals2"]], int(z["qual_delta"]), sam
+
+
+def test_oracle_paired_fastq_matches_reference(oracle_lib):
+    g, q1, q2, delta, sam = _paired_fastq_case()
+    s = oa.Session(g["contigs"], g["contig_names"]); s.set(True, True)
+    s.set_pairing(g["mode"], *g["ins"])
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_sam_q(g["m1"], g["m2"], q1, q2, delta, g["names1"], g["names2"], nthreads=4)
+    s.close()
+    assert got == sam

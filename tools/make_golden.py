@@ -311,10 +311,36 @@ def cs_fastq_cases():
     print("cfg4s_50col_fq: %d SAM records" % sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@")))
 
 
+def paired_fastq_case():
+    """paired FASTQ (mates adjacent in one file, PHRED+33): QUAL strings in the paired and half-paired records"""
+    z = np.load(os.path.join(OUT, "stress_pairs_2x100.npz"))
+    contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
+    cn = [bytes(x) for x in z["contig_names"]]
+    m1, m2 = z["mates1"][:400], z["mates2"][:400]
+    n1 = [bytes(x) for x in z["names1"]][:400]; n2 = [bytes(x) for x in z["names2"]][:400]
+    rng = np.random.default_rng(23)
+    q1 = (rng.integers(2, 41, size=m1.shape) + 33).astype(np.uint8); q2 = (rng.integers(2, 41, size=m2.shape) + 33).astype(np.uint8)
+    T = np.frombuffer(b"ACGTUMRWSYKVHDBN", dtype=np.uint8)
+    with tempfile.TemporaryDirectory() as d:
+        g = os.path.join(d, "g.fa"); r = os.path.join(d, "r.fq")
+        write_fa_codes(g, cn, contigs)
+        with open(r, "wb") as f:
+            for i in range(len(m1)):
+                f.write(b"@" + n1[i] + b"\n" + T[m1[i]].tobytes() + b"\n+\n" + q1[i].tobytes() + b"\n")
+                f.write(b"@" + n2[i] + b"\n" + T[m2[i]].tobytes() + b"\n+\n" + q2[i].tobytes() + b"\n")
+        p = subprocess.run([REF, "-N", "4", "--qv-offset", "33", "--sam-unaligned", "-p", str(z["mode"]), "-I", "%d,%d" % tuple(int(x) for x in z["ins"]), r, g],
+                           capture_output=True, check=True)
+        body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+    np.savez_compressed(os.path.join(OUT, "stress_pairs_fq33.npz"), quals1=q1, quals2=q2, n_pairs=np.array(len(m1)), qual_delta=np.array(33))
+    with gzip.open(os.path.join(OUT, "stress_pairs_fq33.sam.gz"), "wb", compresslevel=9) as f:
+        f.write(body)
+    print("stress_pairs_fq33: %d SAM records" % sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@")))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--fastq-only" in sys.argv:
-        fastq_cases(); cs_fastq_cases(); return
+        fastq_cases(); cs_fastq_cases(); paired_fastq_case(); return
     if "--cs-only" in sys.argv:
         cs_cases(); return
     if "--cs-kat-only" in sys.argv:
@@ -346,6 +372,7 @@ def main():
     cs_cases()
     fastq_cases()
     cs_fastq_cases()
+    paired_fastq_case()
 
 
 if __name__ == "__main__":
