@@ -207,6 +207,7 @@ OPTION_CASES = {
     "hashed": ("stress_60bp", "hash-spaced-kmers=1", dict(hash_seeds=1), None),
     "hashed_w16": ("cfg2s_100bp_2Mbp", "hash-spaced-kmers=1;seeds=11111111101111111,1111110111011101111,111101110010000101111011", dict(hash_seeds=1),
                    ["11111111101111111", "1111110111011101111", "111101110010000101111011"]),
+    "pairs_hashed": ("stress_pairs_2x100", "hash-spaced-kmers=1;report=3", dict(hash_seeds=1, num_outputs=3), None),
 }
 
 

@@ -150,6 +150,9 @@ OPTION_CASES = {
     "local_cfg2": ("cfg2s_100bp_2Mbp", ["--local"]),
     "ungapped":  ("stress_100bp_unal", ["--local", "-U", "--sam-unaligned"]),
     "ungapped60_n1": ("stress_60bp", ["--local", "-U", "-n", "1", "-h", "45%"]),
+    "hashed":    ("stress_60bp", ["-H"]),
+    "hashed_w16": ("cfg2s_100bp_2Mbp", ["-H", "-s", "11111111101111111,1111110111011101111,111101110010000101111011"]),
+    "pairs_hashed": ("stress_pairs_2x100", ["-H", "-o", "3"]),
 }
 
 
