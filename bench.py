@@ -119,8 +119,7 @@ def main():
     if rank == 0:
         # dominant kernel = seed lookup (k_lookup): algorithmic bytes / its own HIP-event time
         ach = (lk_bytes / 1e9) / (lk_ms / 1e3) if lk_ms > 0 else 0.0
-        # bucket kernel (one slab, short lists), the folded-count kernel (several slabs) or the slab-sweep kernel
-        kname = "k_lookup_bkt" if ix.has_buckets else ("k_lookup_v4" if ix.n_slabs > 1 and not os.environ.get("GM_K1_V3") else "k_lookup_v3")
+        kname = gm.lib().gm_last_lookup_kernel().decode()       # k_lookup_bkt (one slab, short lists), k_lookup_v4 (folded count), k_lookup_v3 (slab sweep)
         # HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, profiles/traffic.json),
         # valid only for the workload / sub-batch they were measured on
         traffic = None

@@ -260,6 +260,8 @@ int gm_debug_tophits(gm_session_t *s, int n_reads, int read_len, const uint32_t 
 /* time of the dominant kernel (seed lookup) during the last gm_map_* call, from HIP events on the
  * session's own stream, and the algorithmic bytes it moved */
 int gm_last_lookup_timing(gm_session_t *s, double *ms, uint64_t *alg_bytes, int *launches);
+/* name of the seed-lookup kernel the last mapping call launched (k_lookup_bkt / k_lookup_v4 / k_lookup_v3 / k_lookup): what the roofline figures refer to */
+const char *gm_last_lookup_kernel(void);
 
 #ifdef __cplusplus
 }

@@ -253,6 +253,7 @@ extern "C" int gm_index_alloc_like(gm_index_t** out, int device, const void* met
 struct DevSet {
   // capacities (grown on overflow)
   int cur_len = -1, scap = 0, scap2 = 0, hcap = 0, rcap_per_read = 8, ops_stride = 0, eff_batch = 0;
+  int p2_grid = 0;                                           // pass-2 grid for this read length: the session's, capped so that the back-pointer scratch stays within 2 GB
   int8_t* d_xover = nullptr; bool xover_on = false;        // colour space with QVs: per-position crossover scores [B][read_len]
   uint32_t* d_reads = nullptr; uint8_t* d_initbp = nullptr; uint64_t* d_surv = nullptr; uint32_t* d_surv_cnt = nullptr;   // d_initbp: colour space primer letters
   uint32_t* d_surv_seg = nullptr;                                          // [2B][S + 1] survivors after each slab (K1 emits slab by slab)
@@ -291,7 +292,7 @@ struct gm_session {
   gm_params_t P; GmScoreDev sc;
   double score_alpha = 0, score_beta = 0;
   double pr_mismatch = .01, pr_del_open = 0, pr_del_extend = 0, pr_ins_open = 0, pr_ins_extend = 0;   // post_sw_setup's arguments (ref: gmapper.c:2568-2571,2959-2963)
-  int max_batch = 0, p2_grid = 2560;
+  int max_batch = 0, p2_grid = 16384;             // pass-2 waves in flight (GM_P2_GRID); each owns a back-pointer scratch, see DevSet::p2_grid
   hipStream_t stream = nullptr;
   hipEvent_t ev[12];
   DevSet set[2];
@@ -357,7 +358,8 @@ static int alloc_buffers(gm_session* s, DevSet& D, int read_len, bool paired = f
   GM_HIP(hipMalloc(&D.d_n_work, 4));
   GM_HIP(hipMalloc(&D.d_res, rcap * sizeof(GmFullRes)));
   GM_HIP(hipMalloc(&D.d_ops, rcap * D.ops_stride));
-  GM_HIP(hipMalloc(&D.d_back, (size_t)s->p2_grid * D.back_stride));
+  D.p2_grid = (int)std::max<size_t>(256, std::min<size_t>((size_t)s->p2_grid, ((size_t)2 << 30) / D.back_stride));
+  GM_HIP(hipMalloc(&D.d_back, (size_t)D.p2_grid * D.back_stride));
   if (paired) {
     GM_HIP(hipMalloc(&D.d_sel_sidx, (size_t)B * GM_SEL_MAX * 4));
     GM_HIP(hipMalloc(&D.d_pmin, (size_t)rs * D.hcap * 4)); GM_HIP(hipMalloc(&D.d_pmax, (size_t)rs * D.hcap * 4));
@@ -414,6 +416,7 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   if (s->P.colour_space && s->P.local_alignment) { delete s; gm_set_error("local alignment is implemented for letter space only"); return GM_E_ARG; }
   if ((s->P.colour_space != 0) != (ix->params.colour_space != 0)) { delete s; gm_set_error("session and index disagree on colour space"); return GM_E_ARG; }
   s->max_batch = std::max(64, std::min(max_batch_reads > 0 ? max_batch_reads : 131072, 1 << 20));
+  if (const char* e = getenv("GM_P2_GRID")) s->p2_grid = std::max(64, std::min(65536, atoi(e)));
   GM_HIP(hipStreamCreate(&s->stream));
   for (auto& e : s->ev) GM_HIP(hipEventCreate(&e));
   GM_HIP(hipMalloc(&s->d_stats, (size_t)GS_STRIPES * GS_STRIDE * 8));
@@ -884,10 +887,10 @@ static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int
       const int cs9[9] = {s->P.match_score, s->P.mismatch_score, s->P.crossover_score, -s->P.a_gap_open_score, -s->P.a_gap_extend_score,
                           -s->P.b_gap_open_score, -s->P.b_gap_extend_score, s->P.anchor_width, s->P.indel_taboo_len};   // sw_full_cs_setup's arguments (ref: gmapper.c:2944-2947)
       rc = gm_launch_pass2_cs(dv, s->sc, cs9, D.d_reads, D.d_initbp, n, read_len, read_words, W, D.d_hits, D.hcap, D.d_sel, D.d_work, D.d_n_work,
-                              D.d_res, D.d_ops, D.ops_stride, (uint32_t*)D.d_back, D.back_stride / 4, s->p2_grid, s->d_stats, q, D.xover_on ? D.d_xover : nullptr);
+                              D.d_res, D.d_ops, D.ops_stride, (uint32_t*)D.d_back, D.back_stride / 4, D.p2_grid, s->d_stats, q, D.xover_on ? D.d_xover : nullptr);
     } else
     rc = gm_launch_pass2(dv, s->sc, D.d_reads, n, read_len, read_words, W, D.d_hits, D.d_perm, D.hcap, D.d_sel, D.d_sel_cnt, D.d_work, D.d_n_work,
-                         D.d_res, D.d_ops, D.ops_stride, D.d_back, D.back_stride, s->p2_grid, s->d_stats, q);
+                         D.d_res, D.d_ops, D.ops_stride, D.d_back, D.back_stride, D.p2_grid, s->d_stats, q);
     if (rc) return rc;
     GM_HIP(hipEventRecord(s->ev[5], q));
     { size_t cap;

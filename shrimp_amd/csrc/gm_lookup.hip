@@ -961,6 +961,15 @@ static bool k4_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
   K4Scratch& K = g_k4[dev];
   const int S = ix.n_slabs;
+  {  // v4's fixed cost per read-strand (two 128 KB table clears, per-bin passes) pays off from ~30 k list entries per read-strand
+     // (measured: 45 k at 100 bp / 3 Gbp 7 % faster than the slab sweep, 17 k at 50 colours 40 % slower)
+    double entries = 0;
+    for (int sn = 0; sn < ix.n_seeds; sn++) {
+      const double lists = std::max(0, read_len - ix.seed[sn].span + 1 - ix.colour);
+      entries += lists * (double)ix.seed[sn].n_pos / (double)(1ull << (ix.hflag ? 2 * GM_HASH_TABLE_POWER : 2 * ix.seed[sn].weight));
+    }
+    if (entries < 30000.0 && !getenv("GM_K1_V4")) return false;
+  }
   int tab_bits = 19; if (const char* e = getenv("GM_K4_TABBITS")) tab_bits = std::max(6, std::min(19, atoi(e)));
   // pass C keeps the exact counters of one bin of 2^cbits positions (+2) in the table's LDS; bins nest inside the index slabs
   const int cbits = std::min(ix.slab_bits, tab_bits + ix.region_bits - 1);
@@ -1005,6 +1014,9 @@ size_t gm_lookup_lds_bytes(const GmIndexDev& ix, int read_len) {
   int a, b, c; size_t l; k1_geometry(ix, read_len, &a, &b, &c, &l); return l;
 }
 
+static const char* g_k1_name = "";
+extern "C" const char* gm_last_lookup_kernel(void) { return g_k1_name; }   // which K1 variant the last gm_launch_lookup chose (for bench.py / profiles)
+
 int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
                      uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
                      unsigned long long* d_stats, hipStream_t stream, uint32_t* d_surv_seg) {
@@ -1020,13 +1032,16 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
   }
   const bool bkt = ix.seed[0].bkt != nullptr && ix.n_slabs == 1 && NL <= 512 && !getenv("GM_NO_BUCKETS");
   if (bkt) {
+    g_k1_name = "k_lookup_bkt";
     const size_t lds_b = (size_t)((((read_len + 3) / 4) + 3) & ~3) * 4 + (size_t)bm_words * 4;
     hipLaunchKernelGGL(k_lookup_bkt, dim3(n_reads * 2), dim3((NL + 63) & ~63), lds_b, stream, ix, d_reads, n_reads, read_len, read_words,
                        max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, d_surv_seg);
   } else if (ix.n_slabs > 1 && NL < 65536 && !getenv("GM_K1_V2") && !getenv("GM_K1_V3") && k4_launch(ix, d_reads, n_reads, read_len, read_words, max_n_kmers, NL, d_surv, d_surv_cnt, scap,
                                                                                                    d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, stream, d_surv_seg, lds, bm_words)) {
     // k_lookup_v4 ran (hashed pre-count + exact count on the candidates); read-strands it could not hold were redone in list mode
+    g_k1_name = "k_lookup_v4";
   } else if (ix.list_cutoff < 65536u && !getenv("GM_K1_V2")) {
+    g_k1_name = "k_lookup_v3";
     const size_t lds3 = (size_t)((((read_len + 3) / 4) + 3 * NL + ix.n_slabs * NL + (ix.n_slabs + 1) / 2 + (NL * (ix.n_slabs + 1) + 1) / 2 + 3) & ~3) * 4 + (size_t)bm_words * 4;
     static size_t configured3 = 0;
     if (lds3 > 160 * 1024) { gm_set_error("lookup kernel needs %zu bytes of LDS", lds3); return GM_E_ARG; }
@@ -1037,6 +1052,7 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
                        max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats,
                        getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0, d_surv_seg);
   } else {
+    g_k1_name = "k_lookup";
     // one list per lane when the read-strand's lists fit a workgroup: every list slice is in flight at once
     int k1_threads = std::min(1024, (NL + 63) & ~63);
     if (const char* e = getenv("GM_K1_THREADS")) k1_threads = std::max(64, std::min(1024, atoi(e) & ~63));

@@ -810,7 +810,9 @@ int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
   const size_t back_bytes = (size_t)read_len * window_len;
 #define GM_P2_LAUNCH(BL, LOC) hipLaunchKernelGGL((k_pass2<BL, LOC>), dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words, \
     d_hits, d_perm, hcap, d_sel, d_sel_sidx, input_strand, write_back, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats, p2_ablate)
-  if (back_bytes <= 40 * 1024) {
+  // Back pointers in LDS (14 KB per wave at 100 bp) cap the CU at ten waves; in a per-wave global scratch (L2-resident) the CU runs at full
+  // occupancy: measured 109 -> 37 ms per 1 M reads on the 3 Gbp workload.  The LDS form stays for comparison (GM_P2_BACK_LDS=1).
+  if (back_bytes <= 40 * 1024 && getenv("GM_P2_BACK_LDS")) {
     lds += back_bytes + 16;
     if (sc.local) GM_P2_LAUNCH(true, true); else GM_P2_LAUNCH(true, false);
   } else {

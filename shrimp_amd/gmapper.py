@@ -82,7 +82,7 @@ EXPORTS = ["gm_last_error", "gm_device_count", "gm_params_default", "gm_params_d
            "sw_full_cs_setup", "sw_full_cs", "sw_full_cs_cleanup", "gm_sw_vector_batch_cs",
            "gm_session_create", "gm_session_free", "gm_map_reads", "gm_map_reads_fastq", "gm_map_reads_cs", "gm_map_reads_cs_fastq", "gm_map_reads_device", "gm_free", "gm_debug_tophits",
            "gm_pair_opts_default", "gm_map_pairs", "gm_map_pairs_fastq",
-           "gm_last_lookup_timing"]
+           "gm_last_lookup_timing", "gm_last_lookup_kernel"]
 
 _lib = None
 
@@ -97,6 +97,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     u32p, vp = C.POINTER(C.c_uint32), C.c_void_p
     L.gm_last_error.restype = C.c_char_p
+    L.gm_last_lookup_kernel.restype = C.c_char_p
     L.gm_device_count.restype = C.c_int
     L.gm_params_default.argtypes = [C.POINTER(Params)]
     L.gm_params_default_cs.argtypes = [C.POINTER(Params)]

@@ -122,13 +122,14 @@ def test_sam_matches_reference_golden(gm, name):
 
 KERNEL_VARIANTS = [
     {"GM_NO_BUCKETS": "1"},                                  # generic lookup kernels on a one-slab index
-    {"GM_SLAB_BITS": "18"},                                  # several slabs: k_lookup_v4 (hashed pre-count, exact count per slab on the candidates, slab borders)
-    {"GM_SLAB_BITS": "17", "GM_K1_THREADS": "128"},          # more lists than lane groups
-    {"GM_SLAB_BITS": "13", "GM_K4_TABBITS": "12"},           # v4 with a folded table far smaller than the genome: many false candidates, 2^2-region slabs
-    {"GM_SLAB_BITS": "18", "GM_K4_BINCAP": "16"},            # v4 candidate bins overflow: read-strands redone by the slab-sweep kernel in list mode
-    {"GM_SLAB_BITS": "18", "GM_K4_WCAP": "8"},               # v4 window -> list by binary search
-    {"GM_SLAB_BITS": "18", "GM_K1_V3": "1"},                 # the slab-sweep lane-group kernel (k_lookup_v3)
-    {"GM_SLAB_BITS": "18", "GM_SCAP": "256", "GM_SCAP2": "64"},   # v4 survivors beyond the LDS tiers: heavy tier (re-emission by the lane-per-list kernel)
+    {"GM_SLAB_BITS": "18"},                                  # several slabs, few list entries per read-strand: the slab-sweep lane-group kernel (k_lookup_v3)
+    {"GM_SLAB_BITS": "18", "GM_K1_V4": "1"},                 # k_lookup_v4 forced (hashed pre-count, exact count per bin on the candidates, bin borders)
+    {"GM_SLAB_BITS": "17", "GM_K1_V4": "1", "GM_K1_THREADS": "128"},   # more lists than lane groups
+    {"GM_SLAB_BITS": "13", "GM_K1_V4": "1", "GM_K4_TABBITS": "12"},    # v4 with a folded table far smaller than the genome: many false candidates, 2^2-region bins
+    {"GM_SLAB_BITS": "18", "GM_K1_V4": "1", "GM_K4_BINCAP": "16"},     # v4 candidate bins overflow: read-strands redone by the slab-sweep kernel in list mode
+    {"GM_SLAB_BITS": "18", "GM_K1_V4": "1", "GM_K4_WCAP": "8"},        # v4 window -> list by binary search
+    {"GM_SLAB_BITS": "17", "GM_K1_THREADS": "128"},          # v3 with more lists than lane groups x register windows
+    {"GM_SLAB_BITS": "18", "GM_K1_V4": "1", "GM_SCAP": "256", "GM_SCAP2": "64"},   # v4 survivors beyond the LDS tiers: heavy tier (re-emission by the lane-per-list kernel)
     {"GM_SLAB_BITS": "18", "GM_K1_V2": "1"},                 # the lane-per-list kernel (also the heavy tier's re-emission)
     {"GM_NO_PRUNE": "1"},                                    # K2 on the unpruned survivors
     {"GM_SCAP": "256", "GM_SCAP2": "64"},                    # small LDS tiers: most read-strands take the heavy tier
@@ -406,7 +407,8 @@ def test_colour_space_sam_matches_reference_golden(gm, name):
     assert got == sam, (_first_diff(got, sam), st)
 
 
-@pytest.mark.parametrize("env", [{"GM_SLAB_BITS": "18"}, {"GM_NO_BUCKETS": "1"}, {"GM_SLAB_BITS": "18", "GM_K1_V2": "1"}, {"GM_SCAP": "256", "GM_SCAP2": "64"}],
+@pytest.mark.parametrize("env", [{"GM_SLAB_BITS": "18"}, {"GM_SLAB_BITS": "18", "GM_K1_V4": "1"}, {"GM_NO_BUCKETS": "1"}, {"GM_SLAB_BITS": "18", "GM_K1_V2": "1"},
+                                 {"GM_SCAP": "256", "GM_SCAP2": "64"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_colour_space_kernel_variants(gm, env):
     """every lookup kernel skips the first colour and reads strand 1 the colour-space way"""
