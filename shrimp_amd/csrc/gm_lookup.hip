@@ -1040,11 +1040,12 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
                                                                                                    d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, stream, d_surv_seg, lds, bm_words)) {
     // k_lookup_v4 ran (hashed pre-count + exact count on the candidates); read-strands it could not hold were redone in list mode
     g_k1_name = "k_lookup_v4";
-  } else if (ix.list_cutoff < 65536u && !getenv("GM_K1_V2")) {
+  } else if (ix.list_cutoff < 65536u && !getenv("GM_K1_V2") &&
+             (size_t)((((read_len + 3) / 4) + 3 * NL + ix.n_slabs * NL + (ix.n_slabs + 1) / 2 + (NL * (ix.n_slabs + 1) + 1) / 2 + 3) & ~3) * 4 + (size_t)bm_words * 4 <= 160 * 1024) {
+    // (long reads on many slabs: the per-slab window maps outgrow the LDS and the lane-per-list kernel below takes over)
     g_k1_name = "k_lookup_v3";
     const size_t lds3 = (size_t)((((read_len + 3) / 4) + 3 * NL + ix.n_slabs * NL + (ix.n_slabs + 1) / 2 + (NL * (ix.n_slabs + 1) + 1) / 2 + 3) & ~3) * 4 + (size_t)bm_words * 4;
     static size_t configured3 = 0;
-    if (lds3 > 160 * 1024) { gm_set_error("lookup kernel needs %zu bytes of LDS", lds3); return GM_E_ARG; }
     if (lds3 > 48 * 1024 && lds3 > configured3) { GM_HIP(hipFuncSetAttribute((const void*)k_lookup_v3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); configured3 = lds3; }
     int k1_threads = 768;
     if (const char* e = getenv("GM_K1_THREADS")) k1_threads = std::max(64, std::min(768, atoi(e) & ~63));

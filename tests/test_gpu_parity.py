@@ -588,3 +588,26 @@ def test_paired_fastq_matches_reference_golden(gm):
                                                                              min_insert=g["ins"][0], max_insert=g["ins"][1])
     s.close(); ix.close()
     assert got == sam, _first_diff(got, sam)
+
+
+def test_long_reads_on_many_slabs_vs_oracle(gm, oracle_lib):
+    """700 bp reads on an index cut into 23 slabs: the lane-group kernel's per-slab window maps do not fit the LDS, the lane-per-list kernel
+    takes over; three row stripes in the vector filter, eleven in the full SW"""
+    from shrimp_amd import synth
+    contigs = synth.make_genome([2_000_000, 900_000], 41)
+    reads, _ = synth.make_reads(contigs, 300, 700, 42, p_sub=0.03, p_ins=0.003, p_del=0.003)
+    o = oa.Session(contigs); o.set(True, True)
+    want = o.map_sam(reads, nthreads=4); o.close()
+    old = os.environ.get("GM_SLAB_BITS"); os.environ["GM_SLAB_BITS"] = "17"
+    try:
+        p = gm.default_params(); p.sam_unaligned = 1
+        ix = gm.Index(contigs, params=p)
+        s = gm.Session(ix, params=p, max_batch_reads=128)
+        got = s.map_reads(reads)
+        kern = gm.lib().gm_last_lookup_kernel().decode()
+        s.close(); ix.close()
+    finally:
+        if old is None: os.environ.pop("GM_SLAB_BITS", None)
+        else: os.environ["GM_SLAB_BITS"] = old
+    assert got == want, _first_diff(got, want)
+    assert kern == "k_lookup", kern
