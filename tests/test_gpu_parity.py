@@ -611,3 +611,20 @@ def test_long_reads_on_many_slabs_vs_oracle(gm, oracle_lib):
         else: os.environ["GM_SLAB_BITS"] = old
     assert got == want, _first_diff(got, want)
     assert kern == "k_lookup", kern
+
+
+def test_longest_default_read_length_vs_oracle(gm, oracle_lib):
+    """1000 bp reads (the reference's default --longest-read): eight row stripes in the vector filter, sixteen in the full SW, 1400 bp windows"""
+    from shrimp_amd import synth
+    contigs = synth.make_genome([1_500_000], 51)
+    reads, _ = synth.make_reads(contigs, 60, 1000, 52, p_sub=0.03, p_ins=0.003, p_del=0.003)
+    o = oa.Session(contigs); o.set(True, True)
+    want = o.map_sam(reads, nthreads=4); o.close()
+    p = gm.default_params(); p.sam_unaligned = 1
+    ix = gm.Index(contigs, params=p)
+    s = gm.Session(ix, params=p, max_batch_reads=64)
+    got = s.map_reads(reads)
+    with pytest.raises(gm.GmError):
+        s.map_reads(np.zeros((2, 1001), dtype=np.uint8))          # beyond longest_read_len: refused, as the reference skips such reads
+    s.close(); ix.close()
+    assert got == want, _first_diff(got, want)
