@@ -208,6 +208,9 @@ OPTION_CASES = {
     "hashed_w16": ("cfg2s_100bp_2Mbp", "hash-spaced-kmers=1;seeds=11111111101111111,1111110111011101111,111101110010000101111011", dict(hash_seeds=1),
                    ["11111111101111111", "1111110111011101111", "111101110010000101111011"]),
     "pairs_hashed": ("stress_pairs_2x100", "hash-spaced-kmers=1;report=3", dict(hash_seeds=1, num_outputs=3), None),
+    "pairs_local": ("stress_pairs_2x100", "local=1", dict(local_alignment=1), None),
+    "pairs_ungapped": ("stress_pairs_2x100", "local=1;ungapped=1", dict(local_alignment=1, ungapped=1, anchor_width=0, a_gap_open_score=-255, b_gap_open_score=-255,
+                                                                        hash_filter_calls=0), None),
 }
 
 

@@ -153,6 +153,8 @@ OPTION_CASES = {
     "hashed":    ("stress_60bp", ["-H"]),
     "hashed_w16": ("cfg2s_100bp_2Mbp", ["-H", "-s", "11111111101111111,1111110111011101111,111101110010000101111011"]),
     "pairs_hashed": ("stress_pairs_2x100", ["-H", "-o", "3"]),
+    "pairs_local": ("stress_pairs_2x100", ["--local"]),
+    "pairs_ungapped": ("stress_pairs_2x100", ["--local", "-U"]),
 }
 
 
