@@ -240,7 +240,7 @@ typedef struct gm_pair_opts {
   int pair_mode;                               /* ref: gmapper.h:140 */
   int min_insert_size, max_insert_size;        /* ref: gmapper-defaults.h:28-29  0 / 1000 */
   double insert_size_mean, insert_size_stddev; /* ref: gmapper-defaults.h:30-31  200 / 100 */
-  int half_paired;                             /* ref: gmapper.h:181 true */
+  int half_paired;                             /* ref: gmapper.h:181 true; 0 (mate-pair region counts, mapping.c:545-608) is refused: not implemented */
 } gm_pair_opts_t;
 void gm_pair_opts_default(gm_pair_opts_t *o);
 int gm_map_pairs(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_packed, int len2, const uint32_t *mates2_packed,
