@@ -412,6 +412,7 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   s->pr_ins_open = pow(2.0, (double)s->P.b_gap_open_score / s->score_alpha);
   s->pr_del_extend = pow(2.0, (double)s->P.a_gap_extend_score / s->score_alpha);
   s->pr_ins_extend = pow(2.0, ((double)s->P.b_gap_extend_score - s->score_beta) / s->score_alpha);
+  if (s->P.match_mode != 1 && s->P.match_mode != 2) { delete s; gm_set_error("match_mode %d: 1 or 2 (ref: gmapper.c:2624; 3 and 4 are paired-mode settings with mate-pair region counts)", s->P.match_mode); return GM_E_ARG; }
   if (s->P.ungapped && !s->P.local_alignment) { delete s; gm_set_error("ungapped mode needs local alignment (ref: gmapper.c:2330-2333)"); return GM_E_ARG; }
   if (s->P.colour_space && s->P.local_alignment) { delete s; gm_set_error("local alignment is implemented for letter space only"); return GM_E_ARG; }
   if ((s->P.colour_space != 0) != (ix->params.colour_space != 0)) { delete s; gm_set_error("session and index disagree on colour space"); return GM_E_ARG; }
