@@ -293,8 +293,14 @@ struct gm_session {
   double score_alpha = 0, score_beta = 0;
   double pr_mismatch = .01, pr_del_open = 0, pr_del_extend = 0, pr_ins_open = 0, pr_ins_extend = 0;   // post_sw_setup's arguments (ref: gmapper.c:2568-2571,2959-2963)
   int max_batch = 0, p2_grid = 16384;             // pass-2 waves in flight (GM_P2_GRID); each owns a back-pointer scratch, see DevSet::p2_grid
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;                   // front of the pipeline (reads in, K1, K1b, K2); the only stream of the paired path
+  hipStream_t stream_b = nullptr;                 // back of the pipeline (pass 1, selection, pass 2, results out): runs beside the next sub-batch's front
+  hipStream_t stream_c = nullptr;                 // host -> device copies of the next sub-batch (never queued behind kernels)
   hipEvent_t ev[12];
+  hipEvent_t pev[2][10];                           // per buffer set: stage boundaries, front done, copies done
+  unsigned long long* d_pstats[2] = {nullptr, nullptr};   // per buffer set: counters of one sub-batch
+  uint32_t* h_pin = nullptr;                      // pinned words the front writes (heavy count per set); from word 16 on: K1's start flags
+  uint32_t flag_epoch = 0, front_epoch[2] = {0, 0}; int front_flag_grid[2] = {0, 0};
   DevSet set[2];
   HostSlot slot[3];
   uint32_t* d_pairs = nullptr; uint32_t* d_pair_cnt = nullptr; int pairs_cap = 0;   // paired mode: selected (mate 1, mate 2) window pairs
@@ -419,8 +425,14 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   s->max_batch = std::max(64, std::min(max_batch_reads > 0 ? max_batch_reads : 131072, 1 << 20));
   if (const char* e = getenv("GM_P2_GRID")) s->p2_grid = std::max(64, std::min(65536, atoi(e)));
   GM_HIP(hipStreamCreate(&s->stream));
+  GM_HIP(hipStreamCreateWithFlags(&s->stream_b, hipStreamNonBlocking));
+  GM_HIP(hipStreamCreateWithFlags(&s->stream_c, hipStreamNonBlocking));
   for (auto& e : s->ev) GM_HIP(hipEventCreate(&e));
+  for (auto& row : s->pev) for (auto& e : row) GM_HIP(hipEventCreate(&e));
   GM_HIP(hipMalloc(&s->d_stats, (size_t)GS_STRIPES * GS_STRIDE * 8));
+  for (auto& d : s->d_pstats) GM_HIP(hipMalloc(&d, (size_t)GS_STRIPES * GS_STRIDE * 8));
+  GM_HIP(hipHostMalloc((void**)&s->h_pin, (16 + 1024) * 4, hipHostMallocDefault));
+  memset(s->h_pin, 0, (16 + 1024) * 4);
   *out = s;
   return GM_OK;
 }
@@ -432,8 +444,13 @@ extern "C" void gm_session_free(gm_session_t* s) {
   if (s->d_pairs) (void)hipFree(s->d_pairs);
   if (s->d_pair_cnt) (void)hipFree(s->d_pair_cnt);
   (void)hipFree(s->d_stats);
+  for (auto& d : s->d_pstats) if (d) (void)hipFree(d);
+  if (s->h_pin) (void)hipHostFree(s->h_pin);
   for (auto& e : s->ev) (void)hipEventDestroy(e);
+  for (auto& row : s->pev) for (auto& e : row) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(s->stream);
+  if (s->stream_b) (void)hipStreamDestroy(s->stream_b);
+  if (s->stream_c) (void)hipStreamDestroy(s->stream_c);
   delete s;
 }
 
@@ -783,11 +800,14 @@ struct Finalizer {
 // Heavy tier of K2: the few read-strands whose survivors exceed the LDS tier (low-complexity reads,
 // repeats).  Sizes are known now, so every array is allocated exactly, the keys are re-emitted by K1
 // and sorted by one segmented radix sort; then K2 runs on global arrays.  Rare by construction.
-static int run_heavy_tier(gm_session* s, DevSet& D, const GmIndexDev& dv, int n, int read_len, int read_words, int W, int n_heavy) {
+static int run_heavy_tier(gm_session* s, DevSet& D, const GmIndexDev& dv, int n, int read_len, int read_words, int W, int n_heavy,
+                          unsigned long long* d_stats = nullptr) {
   hipStream_t q = s->stream;
+  if (!d_stats) d_stats = s->d_stats;
   std::vector<uint32_t> list(n_heavy), cnt_all((size_t)n * 2);
-  GM_HIP(hipMemcpy(list.data(), D.d_heavy_list, (size_t)n_heavy * 4, hipMemcpyDeviceToHost));
-  GM_HIP(hipMemcpy(cnt_all.data(), D.d_surv_cnt, cnt_all.size() * 4, hipMemcpyDeviceToHost));
+  GM_HIP(hipMemcpyAsync(list.data(), D.d_heavy_list, (size_t)n_heavy * 4, hipMemcpyDeviceToHost, q));
+  GM_HIP(hipMemcpyAsync(cnt_all.data(), D.d_surv_cnt, cnt_all.size() * 4, hipMemcpyDeviceToHost, q));
+  GM_HIP(hipStreamSynchronize(q));
   std::sort(list.begin(), list.end());
   std::vector<uint64_t> off(n_heavy + 1); std::vector<uint32_t> segn(n_heavy), b32(n_heavy), e32(n_heavy);
   uint64_t tot = 0;
@@ -809,10 +829,10 @@ static int run_heavy_tier(gm_session* s, DevSet& D, const GmIndexDev& dv, int n,
   GM_HIP(hipMemcpyAsync(d_e32, e32.data(), (size_t)n_heavy * 4, hipMemcpyHostToDevice, q));
   GM_HIP(hipMemcpyAsync(d_off, off.data(), (size_t)(n_heavy + 1) * 8, hipMemcpyHostToDevice, q));
   GM_HIP(hipMemsetAsync(d_ks, 0xff, tot * 8, q));
-  int rc = gm_launch_lookup_redo(dv, D.d_reads, n, read_len, read_words, n_heavy, d_list, d_off, d_kin, s->d_stats, q);
+  int rc = gm_launch_lookup_redo(dv, D.d_reads, n, read_len, read_words, n_heavy, d_list, d_off, d_kin, d_stats, q);
   if (rc == GM_OK)
     rc = gm_launch_anchors_heavy(dv, s->sc, n, read_len, W, n_heavy, d_list, d_off, d_segn, d_b32, d_e32, tot, d_kin, d_ks, d_aux, d_nxt, d_ord,
-                                 D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, s->d_stats, q);
+                                 D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, d_stats, q);
   GM_HIP(hipStreamSynchronize(q));
   (void)hipFree(d_list); (void)hipFree(d_segn); (void)hipFree(d_b32); (void)hipFree(d_e32); (void)hipFree(d_off);
   (void)hipFree(d_kin); (void)hipFree(d_ks); (void)hipFree(d_aux); (void)hipFree(d_nxt); (void)hipFree(d_ord);
@@ -820,8 +840,9 @@ static int run_heavy_tier(gm_session* s, DevSet& D, const GmIndexDev& dv, int n,
 }
 
 // K1b + K2 on the survivors of K1
-static int launch_prune_anchors(gm_session* s, DevSet& D, const GmIndexDev& dv, int n, int read_len, int W) {
+static int launch_prune_anchors(gm_session* s, DevSet& D, const GmIndexDev& dv, int n, int read_len, int W, unsigned long long* d_stats = nullptr) {
   hipStream_t q = s->stream;
+  if (!d_stats) d_stats = s->d_stats;
   if (D.scap2 > 0) {
     // tight-cluster bound (gm_prune.hip): smallest window-generation threshold over all contigs, in survivors' x extent
     int e_max = -1;
@@ -833,45 +854,83 @@ static int launch_prune_anchors(gm_session* s, DevSet& D, const GmIndexDev& dv, 
       const int thr = s->sc.wgen_thr_frac < 0 ? s->sc.wgen_abs : (int)((double)base * s->sc.wgen_thr_frac);
       e_max = (thr + s->sc.match - 1) / s->sc.match - s->ix->max_seed_span - 1;
     }
-    int rc = gm_launch_prune(n, read_len, W, e_max, s->ix->n_slabs, s->ix->slab_bits, D.d_surv, D.d_surv_cnt, D.d_surv_seg, D.scap, D.d_surv2, D.d_surv_cnt2, D.scap2, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, s->d_stats, q);
+    int rc = gm_launch_prune(n, read_len, W, e_max, s->ix->n_slabs, s->ix->slab_bits, D.d_surv, D.d_surv_cnt, D.d_surv_seg, D.scap, D.d_surv2, D.d_surv_cnt2, D.scap2, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, d_stats, q);
     if (rc) return rc;
-    return gm_launch_anchors(dv, s->sc, n, read_len, W, D.d_surv2, D.d_surv_cnt2, D.scap2, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, s->d_stats, q);
+    return gm_launch_anchors(dv, s->sc, n, read_len, W, D.d_surv2, D.d_surv_cnt2, D.scap2, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, d_stats, q);
   }
-  return gm_launch_anchors(dv, s->sc, n, read_len, W, D.d_surv, D.d_surv_cnt, D.scap, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, s->d_stats, q);
+  return gm_launch_anchors(dv, s->sc, n, read_len, W, D.d_surv, D.d_surv_cnt, D.scap, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, d_stats, q);
 }
 
-static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int read_len, gm_map_stats_t* st, float* lookup_ms) {
-  const gm_index* ix = s->ix;
-  const GmIndexDev dv = ix->dev_view();
+// One sub-batch on the device, in two halves that run on different streams so that the back of sub-batch i (pass 1 and 2: VALU-bound,
+// 56-64 VGPRs, ~1 KB of LDS per wave) shares the CUs with the front of sub-batch i + 1 (K1: one 1 024-thread workgroup per CU that waits on
+// memory most of the time and leaves 96 VGPRs per SIMD and 26 KB of LDS free).  Each half uses the buffer set k of its sub-batch only.
+//
+// Front, stream A: K1, K1b, K2; nothing here waits on the host (the heavy count lands in pinned memory, event pev[k][6] marks the end).
+static int pipeline_front(gm_session* s, int k, int n, int read_len) {
+  DevSet& D = s->set[k];
+  const GmIndexDev dv = s->ix->dev_view();
+  const int read_words = (read_len + 7) / 8;
+  const int W = window_len_of(s->P, read_len);
+  hipStream_t q = s->stream;
+  unsigned long long* d_stats = s->d_pstats[k];
+  GM_HIP(hipMemsetAsync(d_stats, 0, (size_t)GS_STRIPES * GS_STRIDE * 8, q));
+  GM_HIP(hipEventRecord(s->pev[k][0], q));
+  gm_lookup_set_start_flags(s->h_pin + 16, 1024, ++s->flag_epoch);
+  int rc = gm_launch_lookup(dv, D.d_reads, n, read_len, read_words, D.d_surv, D.d_surv_cnt, D.scap, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, d_stats, q, D.d_surv_seg);
+  s->front_epoch[k] = s->flag_epoch; s->front_flag_grid[k] = rc ? 0 : gm_lookup_start_flag_grid();
+  gm_lookup_set_start_flags(nullptr, 0, 0);
+  if (rc) return rc;
+  GM_HIP(hipEventRecord(s->pev[k][1], q));
+  rc = launch_prune_anchors(s, D, dv, n, read_len, W, d_stats);
+  if (rc) return rc;
+  GM_HIP(hipMemcpyAsync(&s->h_pin[k], D.d_heavy_cnt, 4, hipMemcpyDeviceToHost, q));
+  GM_HIP(hipEventRecord(s->pev[k][2], q));
+  GM_HIP(hipEventRecord(s->pev[k][6], q));
+  return GM_OK;
+}
+
+// Back, stream B: heavy tier if any (stream A, rare), pass 1, selection, pass 2, results to the host slot.  Returns 1 when a capacity grew
+// (the buffers of set k were re-allocated: the caller re-submits the sub-batch from the front).
+static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len, gm_map_stats_t* st, float* lookup_ms, bool next_front_queued = false) {
+  DevSet& D = s->set[k];
+  const GmIndexDev dv = s->ix->dev_view();
   const int read_words = (read_len + 7) / 8;
   const int W = window_len_of(s->P, read_len);
   const int overlap_abs = (int)(unsigned int)(s->P.window_overlap < 0 ? -s->P.window_overlap : W * (s->P.window_overlap / 100.0));   // ref: mapping.c:1289
-  hipStream_t q = s->stream;
+  hipStream_t q = s->stream_b;
+  unsigned long long* d_stats = s->d_pstats[k];
   {
-    GM_HIP(hipMemsetAsync(s->d_stats, 0, (size_t)GS_STRIPES * GS_STRIDE * 8, q));
-    GM_HIP(hipEventRecord(s->ev[0], q));
-    int rc = gm_launch_lookup(dv, D.d_reads, n, read_len, read_words, D.d_surv, D.d_surv_cnt, D.scap, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, s->d_stats, q, D.d_surv_seg);
-    if (rc) return rc;
-    GM_HIP(hipEventRecord(s->ev[1], q));
-    rc = launch_prune_anchors(s, D, dv, n, read_len, W);
-    if (rc) return rc;
-    uint32_t n_heavy = 0;
-    GM_HIP(hipMemcpyAsync(&n_heavy, D.d_heavy_cnt, 4, hipMemcpyDeviceToHost, q));
-    GM_HIP(hipStreamSynchronize(q));
-    if (n_heavy) { rc = run_heavy_tier(s, D, dv, n, read_len, read_words, W, (int)n_heavy); if (rc) return rc; if (st) st->exact_order_reads += 0; }
-    GM_HIP(hipEventRecord(s->ev[2], q));
-    rc = gm_launch_pass1(dv, s->sc, D.d_reads, n, read_len, read_words, W, overlap_abs, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, D.d_slots, s->d_stats, q,
+    GM_HIP(hipEventSynchronize(s->pev[k][6]));
+    const uint32_t n_heavy = s->h_pin[k];
+    int rc;
+    if (n_heavy) {
+      rc = run_heavy_tier(s, D, dv, n, read_len, read_words, W, (int)n_heavy, d_stats); if (rc) return rc;
+      GM_HIP(hipEventRecord(s->pev[k][6], s->stream));
+    }
+    GM_HIP(hipStreamWaitEvent(q, s->pev[k][6], 0));
+    if (next_front_queued && s->front_flag_grid[k ^ 1] > 0) {
+      // K1 of the next sub-batch becomes runnable at the same moment as this pass 1.  Its persistent workgroups need a whole CU's LDS each; pass-1 waves
+      // that get there first keep them off the CUs until pass 1 is over.  So: wait (bounded) until all of them have raised their flag.
+      volatile uint32_t* f = s->h_pin + 16; const uint32_t want = s->front_epoch[k ^ 1]; const int g = s->front_flag_grid[k ^ 1];
+      const auto t0 = std::chrono::steady_clock::now();
+      for (;;) {
+        int up = 0; for (int i = 0; i < g; i++) up += f[i] == want;
+        if (up == g || std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 5.0) break;
+      }
+    }
+    GM_HIP(hipEventRecord(s->pev[k][3], q));
+    rc = gm_launch_pass1(dv, s->sc, D.d_reads, n, read_len, read_words, W, overlap_abs, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, D.d_slots, d_stats, q,
                          nullptr, nullptr, D.d_initbp);
     if (rc) return rc;
-    GM_HIP(hipEventRecord(s->ev[3], q));
+    GM_HIP(hipEventRecord(s->pev[k][4], q));
     rc = gm_launch_select(s->sc, n, read_len, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, D.d_sel, D.d_sel_cnt, D.d_sel_off, D.d_work, D.d_n_work, q);
     if (rc) return rc;
-    GM_HIP(hipEventRecord(s->ev[4], q));
+    GM_HIP(hipEventRecord(s->pev[k][5], q));
     unsigned long long hs[GS_N]; uint32_t n_work = 0;
     std::vector<unsigned long long> hraw((size_t)GS_STRIPES * GS_STRIDE);
-    auto fold = [&]() { for (int k = 0; k < GS_N; k++) { hs[k] = 0; for (int t = 0; t < GS_STRIPES; t++) hs[k] += hraw[(size_t)t * GS_STRIDE + k]; } };
+    auto fold = [&]() { for (int c = 0; c < GS_N; c++) { hs[c] = 0; for (int t = 0; t < GS_STRIPES; t++) hs[c] += hraw[(size_t)t * GS_STRIDE + c]; } };
     GM_HIP(hipMemcpyAsync(&n_work, D.d_n_work, 4, hipMemcpyDeviceToHost, q));
-    GM_HIP(hipMemcpyAsync(hraw.data(), s->d_stats, hraw.size() * 8, hipMemcpyDeviceToHost, q));
+    GM_HIP(hipMemcpyAsync(hraw.data(), d_stats, hraw.size() * 8, hipMemcpyDeviceToHost, q));
     GM_HIP(hipStreamSynchronize(q));
     fold();
     const size_t rcap = (size_t)D.eff_batch * D.rcap_per_read;
@@ -881,6 +940,7 @@ static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int
     if (n_work > rcap) { if (D.rcap_per_read >= 32) { gm_set_error("pass-2 work overflow"); return GM_E_OVERFLOW; } D.rcap_per_read = std::min(32, D.rcap_per_read * 2); retry = true; }
     if (retry) {   // capacities grew: re-allocate and let the caller re-submit (the sub-batch size may have shrunk)
       if (st) st->retries++;
+      GM_HIP(hipStreamSynchronize(s->stream));           // the other set's front may be in flight; nothing may touch freed buffers
       rc = alloc_buffers(s, D, read_len); if (rc) return rc;
       return 1;
     }
@@ -888,12 +948,12 @@ static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int
       const int cs9[9] = {s->P.match_score, s->P.mismatch_score, s->P.crossover_score, -s->P.a_gap_open_score, -s->P.a_gap_extend_score,
                           -s->P.b_gap_open_score, -s->P.b_gap_extend_score, s->P.anchor_width, s->P.indel_taboo_len};   // sw_full_cs_setup's arguments (ref: gmapper.c:2944-2947)
       rc = gm_launch_pass2_cs(dv, s->sc, cs9, D.d_reads, D.d_initbp, n, read_len, read_words, W, D.d_hits, D.hcap, D.d_sel, D.d_work, D.d_n_work,
-                              D.d_res, D.d_ops, D.ops_stride, (uint32_t*)D.d_back, D.back_stride / 4, D.p2_grid, s->d_stats, q, D.xover_on ? D.d_xover : nullptr);
+                              D.d_res, D.d_ops, D.ops_stride, (uint32_t*)D.d_back, D.back_stride / 4, D.p2_grid, d_stats, q, D.xover_on ? D.d_xover : nullptr);
     } else
     rc = gm_launch_pass2(dv, s->sc, D.d_reads, n, read_len, read_words, W, D.d_hits, D.d_perm, D.hcap, D.d_sel, D.d_sel_cnt, D.d_work, D.d_n_work,
-                         D.d_res, D.d_ops, D.ops_stride, D.d_back, D.back_stride, D.p2_grid, s->d_stats, q);
+                         D.d_res, D.d_ops, D.ops_stride, D.d_back, D.back_stride, D.p2_grid, d_stats, q);
     if (rc) return rc;
-    GM_HIP(hipEventRecord(s->ev[5], q));
+    GM_HIP(hipEventRecord(s->pev[k][7], q));
     { size_t cap;
       cap = H.res_cap; rc = slot_reserve((void**)&H.res, &cap, (size_t)n_work * sizeof(GmFullRes)); H.res_cap = cap; if (rc) return rc;
       cap = H.ops_cap; rc = slot_reserve((void**)&H.ops, &cap, (size_t)n_work * D.ops_stride); H.ops_cap = cap; if (rc) return rc;
@@ -906,11 +966,15 @@ static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int
     }
     GM_HIP(hipMemcpyAsync(H.sel_cnt, D.d_sel_cnt, (size_t)n * 4, hipMemcpyDeviceToHost, q));
     GM_HIP(hipMemcpyAsync(H.sel_off, D.d_sel_off, (size_t)n * 4, hipMemcpyDeviceToHost, q));
-    GM_HIP(hipMemcpyAsync(hraw.data(), s->d_stats, hraw.size() * 8, hipMemcpyDeviceToHost, q));
+    GM_HIP(hipMemcpyAsync(hraw.data(), d_stats, hraw.size() * 8, hipMemcpyDeviceToHost, q));
     GM_HIP(hipStreamSynchronize(q));
     fold();
     float ms[5];
-    for (int i = 0; i < 5; i++) GM_HIP(hipEventElapsedTime(&ms[i], s->ev[i], s->ev[i + 1]));
+    GM_HIP(hipEventElapsedTime(&ms[0], s->pev[k][0], s->pev[k][1]));
+    GM_HIP(hipEventElapsedTime(&ms[1], s->pev[k][1], s->pev[k][2]));
+    GM_HIP(hipEventElapsedTime(&ms[2], s->pev[k][3], s->pev[k][4]));
+    GM_HIP(hipEventElapsedTime(&ms[3], s->pev[k][4], s->pev[k][5]));
+    GM_HIP(hipEventElapsedTime(&ms[4], s->pev[k][5], s->pev[k][7]));
     *lookup_ms = ms[0];
     if (st) {
       st->lookups += hs[GS_LOOKUPS]; st->list_entries += hs[GS_ENTRIES]; st->list_bytes += 12ull * hs[GS_LOOKUPS] + 4ull * hs[GS_ENTRIES];
@@ -922,6 +986,14 @@ static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int
     s->last_lookup_bytes += 12ull * hs[GS_LOOKUPS] + 4ull * hs[GS_ENTRIES];
     return GM_OK;
   }
+}
+
+// both halves back to back on set 0 (stage dumps)
+static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int read_len, gm_map_stats_t* st, float* lookup_ms) {
+  (void)D;
+  int rc = pipeline_front(s, 0, n, read_len);
+  if (rc) return rc;
+  return pipeline_back(s, 0, H, n, read_len, st, lookup_ms);
 }
 
 static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* reads_host, const void* reads_dev,
@@ -990,41 +1062,84 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     J->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   };
   size_t joined = 0;
-  for (int base = 0; base < n_reads;) {
-    int n, rc; float lk = 0;
-    do {
-      n = std::min(D.eff_batch, n_reads - base);
-      if (reads_host) GM_HIP(hipMemcpyAsync(D.d_reads, reads_host + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyHostToDevice, s->stream));
-      else GM_HIP(hipMemcpyAsync(D.d_reads, (const uint32_t*)reads_dev + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyDeviceToDevice, s->stream));
-      if (initbp_host) GM_HIP(hipMemcpyAsync(D.d_initbp, initbp_host + base, (size_t)n, hipMemcpyHostToDevice, s->stream));
-      D.xover_on = false;
-      if (initbp_host && quals) {                              // per-position crossover scores from the QVs, ref: gmapper.c:532-544
-        xbuf.resize((size_t)n * read_len);
-        for (int i = 0; i < n; i++) {
-          const char* q = qptr[base + i];
-          for (int j = 0; j < read_len; j++) {
-            const int qv = (int)q[j] - qual_delta;
-            const double pe = qv <= 0 ? .99999999 : (qv >= 250 ? 1E-25 : pow(10.0, -(double)qv / 10.0));   // pr_err_from_qv, ref: util.h:285-293
-            int c = (int)(s->score_alpha * log(pe / 3.0) / log(2.0));
-            if (c > -1) c = -1; else if (c < 2 * s->P.crossover_score) c = 2 * s->P.crossover_score;
-            xbuf[(size_t)i * read_len + j] = (int8_t)c;
-          }
+  // Two buffer sets: the front of sub-batch i + 1 (stream A) is queued before the host turns to the back of sub-batch i (stream B),
+  // so K1 of the next sub-batch and pass 1 / pass 2 of this one share the CUs (see pipeline_front).  GM_OVERLAP=0: one set, in order.
+  bool overlap = n_reads > D.eff_batch;
+  if (const char* e = getenv("GM_OVERLAP")) overlap = overlap && atoi(e) != 0;
+  auto same_caps = [&](const DevSet& a, const DevSet& b) { return a.cur_len == b.cur_len && a.scap == b.scap && a.scap2 == b.scap2 && a.hcap == b.hcap &&
+                                                                  a.rcap_per_read == b.rcap_per_read && a.eff_batch == b.eff_batch && b.d_pmin == nullptr; };
+  auto match_sets = [&](int from) -> int {                       // give the other set the capacities of set `from`
+    DevSet& a = s->set[from]; DevSet& b = s->set[from ^ 1];
+    if (same_caps(a, b)) return GM_OK;
+    b.scap = a.scap; b.scap2 = a.scap2; b.hcap = a.hcap; b.rcap_per_read = a.rcap_per_read;
+    return alloc_buffers(s, b, read_len);
+  };
+  if (overlap) { int rc = match_sets(0); if (rc) return rc; if (s->set[1].eff_batch != D.eff_batch) overlap = false; }
+  auto join_all = [&]() { for (auto& j : jobs) if (j->th.joinable()) j->th.join(); };
+  // copies of one sub-batch into set k; host memory goes through stream C so that the call never waits behind queued kernels
+  auto queue_inputs = [&](int k, int base, int n) -> int {
+    DevSet& S = s->set[k];
+    if (!reads_host) {
+      GM_HIP(hipMemcpyAsync(S.d_reads, (const uint32_t*)reads_dev + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyDeviceToDevice, s->stream));
+      S.xover_on = false;
+      return GM_OK;
+    }
+    hipStream_t c = s->stream_c;
+    GM_HIP(hipMemcpyAsync(S.d_reads, reads_host + (size_t)base * read_words, (size_t)n * read_words * 4, hipMemcpyHostToDevice, c));
+    if (initbp_host) GM_HIP(hipMemcpyAsync(S.d_initbp, initbp_host + base, (size_t)n, hipMemcpyHostToDevice, c));
+    S.xover_on = false;
+    if (initbp_host && quals) {                              // per-position crossover scores from the QVs, ref: gmapper.c:532-544
+      xbuf.resize((size_t)n * read_len);
+      for (int i = 0; i < n; i++) {
+        const char* q = qptr[base + i];
+        for (int j = 0; j < read_len; j++) {
+          const int qv = (int)q[j] - qual_delta;
+          const double pe = qv <= 0 ? .99999999 : (qv >= 250 ? 1E-25 : pow(10.0, -(double)qv / 10.0));   // pr_err_from_qv, ref: util.h:285-293
+          int cx = (int)(s->score_alpha * log(pe / 3.0) / log(2.0));
+          if (cx > -1) cx = -1; else if (cx < 2 * s->P.crossover_score) cx = 2 * s->P.crossover_score;
+          xbuf[(size_t)i * read_len + j] = (int8_t)cx;
         }
-        GM_HIP(hipMemcpyAsync(D.d_xover, xbuf.data(), xbuf.size(), hipMemcpyHostToDevice, s->stream));
-        D.xover_on = true;
       }
-      rc = run_device_pipeline(s, D, s->slot[jobs.size() % 3], n, read_len, stats, &lk);
-    } while (rc == 1);
-    if (rc) { for (auto& j : jobs) if (j->th.joinable()) j->th.join(); return rc; }
+      GM_HIP(hipMemcpyAsync(S.d_xover, xbuf.data(), xbuf.size(), hipMemcpyHostToDevice, c));
+      GM_HIP(hipStreamSynchronize(c));                      // xbuf is reused by the next sub-batch
+      S.xover_on = true;
+    }
+    GM_HIP(hipEventRecord(s->pev[k][8], c));
+    GM_HIP(hipStreamWaitEvent(s->stream, s->pev[k][8], 0));
+    return GM_OK;
+  };
+  int cur = 0; bool have_front = false;
+  for (int base = 0; base < n_reads;) {
+    DevSet& C = s->set[cur];
+    const int n = std::min(C.eff_batch, n_reads - base);
+    int rc = GM_OK; float lk = 0;
+    if (!have_front) { rc = queue_inputs(cur, base, n); if (!rc) rc = pipeline_front(s, cur, n, read_len); }
+    bool have_next = false;
+    if (!rc && overlap && base + n < n_reads) {
+      const int n2 = std::min(s->set[cur ^ 1].eff_batch, n_reads - (base + n));
+      rc = queue_inputs(cur ^ 1, base + n, n2); if (!rc) rc = pipeline_front(s, cur ^ 1, n2, read_len);
+      have_next = true;
+    }
+    HostSlot& HS = s->slot[jobs.size() % 3];
+    if (!rc) rc = pipeline_back(s, cur, HS, n, read_len, stats, &lk, have_next);
+    if (rc == 1) {                                            // capacities of set `cur` grew: same for the other set, then again from the front
+      GM_HIP(hipStreamSynchronize(s->stream));
+      if (overlap) { rc = match_sets(cur); if (rc) { join_all(); return rc; } }
+      have_front = false;
+      continue;
+    }
+    if (rc) { (void)hipStreamSynchronize(s->stream); (void)hipStreamSynchronize(s->stream_b); join_all(); return rc; }
     s->last_lookup_ms += lk; s->last_lookup_launches++;
     std::unique_ptr<Job> J(new Job());
     J->base = base; J->n = n;
-    J->hs = &s->slot[jobs.size() % 3];
+    J->hs = &HS;
     if (reads_host) J->hreads = reads_host + (size_t)base * read_words;
     else {
       size_t cap = J->hs->reads_cap; rc = slot_reserve((void**)&J->hs->reads, &cap, (size_t)n * read_words * 4); J->hs->reads_cap = cap;
-      if (rc) { for (auto& j : jobs) if (j->th.joinable()) j->th.join(); return rc; }
-      GM_HIP(hipMemcpy(J->hs->reads, D.d_reads, (size_t)n * read_words * 4, hipMemcpyDeviceToHost)); J->hreads = J->hs->reads;
+      if (rc) { (void)hipStreamSynchronize(s->stream); join_all(); return rc; }
+      GM_HIP(hipMemcpyAsync(J->hs->reads, C.d_reads, (size_t)n * read_words * 4, hipMemcpyDeviceToHost, s->stream_b));
+      GM_HIP(hipStreamSynchronize(s->stream_b));
+      J->hreads = J->hs->reads;
     }
     // at most two host jobs outstanding
     while (jobs.size() - joined >= 2) { jobs[joined]->th.join(); joined++; }
@@ -1032,6 +1147,8 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     J->th = std::thread(run_job, jp);
     jobs.push_back(std::move(J));
     base += n;
+    if (overlap) cur ^= 1;
+    have_front = have_next;
   }
   for (auto& j : jobs) if (j->th.joinable()) j->th.join();
   uint64_t matched = 0, records = 0; size_t total = 0;

@@ -45,6 +45,8 @@ int gm_index_from_lists_device(GmIndexHost* ix, int sn, const uint32_t* lens, co
 
 // K1 seed lookup + region filter: one workgroup per read-strand; read-strands with more than scap
 // survivors are listed in d_heavy_list (count in d_surv_cnt) and re-run by gm_launch_lookup_redo
+void gm_lookup_set_start_flags(uint32_t* flags, int cap, uint32_t epoch);   // pinned words the persistent K1 grid raises when its workgroups are resident
+int gm_lookup_start_flag_grid(void);
 int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
                      uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
                      unsigned long long* d_stats, hipStream_t stream, uint32_t* d_surv_seg = nullptr);   // d_surv_seg[rs][S + 1]: survivors after each slab

@@ -705,12 +705,16 @@ k_lookup_v3(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
 #define K4_MO_SELF 0x8000u   // candidate copy in the NEXT slab's bin: marks its own region only (counter 0 there)
 #define K4_MO_PREV 0x4000u   // candidate copy in the PREVIOUS slab's bin: marks region - 1 only (that slab's last region)
 
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 5)))
 k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
             int NL, int tab_bits, int cbits, int SC, int wcap, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
             uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap, unsigned long long* __restrict__ stats,
             uint32_t* __restrict__ surv_seg, uint64_t* __restrict__ scratch, int bin_cap, uint32_t* __restrict__ fb_list, uint32_t* __restrict__ fb_cnt,
-            int fb_cap, int ablate) {
+            int fb_cap, int ablate, uint32_t* __restrict__ start_flags, uint32_t start_epoch) {
+  // resident: tell the host (pinned memory), which holds the other stream's pass-1 launch back until every workgroup of this grid has a CU
+  if (start_flags && threadIdx.x == 0) __hip_atomic_store(&start_flags[blockIdx.x], start_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __builtin_amdgcn_s_setprio(3);                            // memory-latency-bound: issue first when ready; VALU-bound kernels of the other stream fill the gaps
+
   extern __shared__ __align__(16) uint32_t smem[];
   __shared__ uint32_t n_surv, n_lists, n_win, overflow;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & (GM_WAVE - 1);
@@ -941,6 +945,11 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
   if ((tid & (GM_WAVE - 1)) == 0) { GS_ADD(stats, GS_LOOKUPS, my_lookups); GS_ADD(stats, GS_ENTRIES, my_entries); }
 }
 
+// start flags of the persistent K1 grid (see gm_host.hip, pipeline_back): set before a launch, consumed by it
+static uint32_t* g_k4_flags = nullptr; static uint32_t g_k4_epoch = 0; static int g_k4_flag_cap = 0, g_k4_flag_grid = 0;
+void gm_lookup_set_start_flags(uint32_t* flags, int cap, uint32_t epoch) { g_k4_flags = flags; g_k4_flag_cap = cap; g_k4_epoch = epoch; g_k4_flag_grid = 0; }
+int gm_lookup_start_flag_grid(void) { return g_k4_flag_grid; }   // workgroups that will raise a flag for the last launch (0: none)
+
 static void k1_geometry(const GmIndexDev& ix, int read_len, int* max_n_kmers, int* NL, int* bm_words, size_t* lds) {
   *max_n_kmers = read_len - ix.min_seed_span + 1;
   if (*max_n_kmers < 0) *max_n_kmers = 0;
@@ -1000,9 +1009,11 @@ static bool k4_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   if (lds_generic > 48 * 1024 && lds_generic > configured_g) {
     if (hipFuncSetAttribute((const void*)k_lookup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_generic) != hipSuccess) return false; configured_g = lds_generic; }
   int k4_threads = 1024; if (const char* e = getenv("GM_K1_THREADS")) k4_threads = std::max(64, std::min(1024, atoi(e) & ~63));
+  const bool use_flags = g_k4_flags && grid <= g_k4_flag_cap;
+  g_k4_flag_grid = use_flags ? grid : 0;
   hipLaunchKernelGGL(k_lookup_v4, dim3(grid), dim3(k4_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words, max_n_kmers, NL, tab_bits, cbits, SC, wcap,
                      d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, d_surv_seg, K.scratch, bin_cap, K.fb, K.fb + fb_cap, fb_cap,
-                     getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0);
+                     getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0, use_flags ? g_k4_flags : nullptr, g_k4_epoch);
   // read-strands whose candidates overflowed their bins: the slab-sweep kernel in list mode (blocks beyond the list's end return at once)
   hipLaunchKernelGGL(k_lookup<false>, dim3(fb_cap), dim3(K1_THREADS), lds_generic, stream, ix, d_reads, n_reads, read_len, read_words,
                      max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,

@@ -5,5 +5,5 @@ mkdir -p gpurun_out
 run() { echo "== $*"; env "$@" timeout -k 10 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
-print('reads/s %.0f  lookup %.1f ms  frac %.3f  surv/read %.2f  anchors %.1f' % (d['value'], d['stages_ms_per_step']['ms_lookup'], d['roofline']['frac'], d['per_read']['survivors'], d['stages_ms_per_step']['ms_anchors']))"; }
+st = d['stages_ms_per_step']; print('reads/s %.0f  step %.0f ms  lookup %.1f  frac %.3f  anchors %.1f  pass1 %.1f  pass2 %.1f  host %.1f' % (d['value'], d['ms_per_step'], st['ms_lookup'], d['roofline']['frac'], st['ms_anchors'], st['ms_pass1'], st['ms_pass2'], st.get('ms_host', 0)))"; }
 for cfg in "$@"; do run $cfg; done
