@@ -32,6 +32,13 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return as_u
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u(as_s(a) - as_s(b)); }
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return as_u(as_s(a) + as_s(b)); }
 
+// min(x, 1) and a * b + c on both halves: one VOP3P instruction each (the generic vector builtins expand to compares and selects)
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b_uniform, uint32_t c) { uint32_t r; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c)); return r; }
+// value of lane l-1, lane 0 gets 0 (bound_ctrl): no register to preset
+__device__ __forceinline__ uint32_t wave_shr1_z(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
+}
 // value of lane l-1 (lane 0 keeps `lane0`): v_mov_b32_dpp wave_shr:1
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t lane0) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0, (int)v, 0x138, 0xf, 0xf, false);
@@ -43,8 +50,9 @@ __device__ __forceinline__ uint32_t up_of(uint32_t own, uint32_t shifted) { retu
 // LDS; carry is 2*(glen) int16 in LDS, used only when rlen > 128.  Every lane returns the score.
 // CS: colour space -- read row 0 (the first colour) is compared with db0[c] = lstocs(genome_ls[c], initbp) instead of the colour
 // genome (ref: common/sw-vector.c:112-146); the colour codes still flow on to row 1.
-template <bool CS>
-__device__ int sw_vector_wave_t(const uint8_t* db, const uint8_t* db0, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc,
+// SINGLE: rlen <= 128, one stripe -- no carry rows, lane 0's H neighbour is the zero row (the usual case: reads up to 128 bases).
+template <bool CS, bool SINGLE>
+__device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc,
                                 int16_t* carry, int lane) {
   const uint32_t v_match = pk(sc.match, sc.match);
   const uint32_t v_delta = pk(sc.mismatch - sc.match, sc.mismatch - sc.match);
@@ -52,7 +60,7 @@ __device__ int sw_vector_wave_t(const uint8_t* db, const uint8_t* db0, int glen,
   const uint32_t v_b_ext = pk(sc.b_ge, sc.b_ge), v_b_oe = pk(sc.b_go + sc.b_ge, sc.b_go + sc.b_ge);
   const uint32_t v_one = pk(1, 1);
   uint32_t v_score = 0;
-  const int n_stripes = (rlen + 127) >> 7;
+  const int n_stripes = SINGLE ? 1 : ((rlen + 127) >> 7);
   int16_t* carryH = carry; int16_t* carryB = carry + glen;
   for (int s = 0; s < n_stripes; s++) {
     const int r0 = s * 128 + 2 * lane;
@@ -62,39 +70,34 @@ __device__ int sw_vector_wave_t(const uint8_t* db, const uint8_t* db0, int glen,
     uint32_t Hprev = 0, Aprev = pk(-sc.a_go, -sc.a_go), Bprev = pk(-sc.b_go, -sc.b_go);
     uint32_t Gprev = pk(SW_DB_SENT, SW_DB_SENT);
     uint32_t upH_prev = 0;                     // H(r-1, c-1) for the step to come
-    const bool more = (s + 1 < n_stripes);
+    const bool more = !SINGLE && (s + 1 < n_stripes);
     uint32_t dbv = 0, chv = 0, cbv = 0, db0v = 0;
     for (int t = 0; t < steps; t++) {
       if ((t & 63) == 0) {                     // refill the per-lane staging of the next 64 columns
         const int c = t + lane;
         dbv = (c < glen) ? (uint32_t)db[c] : SW_DB_SENT;
         if (CS && s == 0) db0v = (c < glen) ? (uint32_t)db0[c] : SW_DB_SENT;
-        if (s > 0) { chv = (c < glen) ? (uint32_t)(uint16_t)carryH[c] : 0u; cbv = (c < glen) ? (uint32_t)(uint16_t)carryB[c] : (uint32_t)(uint16_t)(-sc.b_go); }
+        if (!SINGLE && s > 0) { chv = (c < glen) ? (uint32_t)(uint16_t)carryH[c] : 0u; cbv = (c < glen) ? (uint32_t)(uint16_t)carryB[c] : (uint32_t)(uint16_t)(-sc.b_go); }
       }
       const int sl = t & 63;
       // lane 0's neighbour (row 128s - 1) comes from the carry arrays / the initial row
       const uint32_t in_g = (uint32_t)__builtin_amdgcn_readlane((int)dbv, sl) << 16;
-      const uint32_t in_h = (s > 0) ? ((uint32_t)__builtin_amdgcn_readlane((int)chv, sl) << 16) : 0u;
-      const uint32_t in_b = (s > 0) ? ((uint32_t)__builtin_amdgcn_readlane((int)cbv, sl) << 16) : ((uint32_t)(uint16_t)(-sc.b_go) << 16);
+      const uint32_t in_h = (!SINGLE && s > 0) ? ((uint32_t)__builtin_amdgcn_readlane((int)chv, sl) << 16) : 0u;
+      const uint32_t in_b = (!SINGLE && s > 0) ? ((uint32_t)__builtin_amdgcn_readlane((int)cbv, sl) << 16) : ((uint32_t)(uint16_t)(-sc.b_go) << 16);
       const uint32_t G = up_of(Gprev, wave_shr1(Gprev, in_g));
-      const uint32_t upH = up_of(Hprev, wave_shr1(Hprev, in_h));
+      const uint32_t upH = up_of(Hprev, SINGLE ? wave_shr1_z(Hprev) : wave_shr1(Hprev, in_h));
       const uint32_t upB = up_of(Bprev, wave_shr1(Bprev, in_b));
       // a: gap along the genome (from the left), b: gap along the read (from above)
       const uint32_t a = pk_max(pk_sub(Aprev, v_a_ext), pk_sub(Hprev, v_a_oe));
       const uint32_t b = pk_max(pk_sub(upB, v_b_ext), pk_sub(upH, v_b_oe));
-      // s = match where codes are equal, else mismatch:  match + delta * min(code_xor, 1)
       uint32_t Gc = G;
       if (CS && s == 0) {                      // row 0 lives in the low half of lane 0
         const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)db0v, sl);
         if (lane == 0) Gc = (G & 0xFFFF0000u) | g0;
       }
-      const uint32_t x = Gc ^ q;
-      const uint32_t ne = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, x), __builtin_bit_cast(u16x2, v_one)));
-      const uint32_t sv = as_u(as_s(ne) * as_s(v_delta) + as_s(v_match));
-      uint32_t h = pk_add(upH_prev, sv);
-      h = pk_max(h, 0u);
-      h = pk_max(h, a);
-      h = pk_max(h, b);
+      // s = match where the codes are equal, else mismatch: H(r-1, c-1) + min(code_xor, 1) * delta + match
+      uint32_t h = pk_add(pk_mad_i16(pk_min_u16(Gc ^ q, v_one), v_delta, upH_prev), v_match);
+      h = pk_max(pk_max(h, 0u), pk_max(a, b));
       v_score = pk_max(v_score, h);
       if (more && lane == 63) {                // row 128s+127 feeds the next stripe
         const int c = t - 127;
@@ -107,6 +110,11 @@ __device__ int sw_vector_wave_t(const uint8_t* db, const uint8_t* db0, int glen,
   int best = max((int)(int16_t)(v_score & 0xFFFF), (int)(int16_t)(v_score >> 16));
   for (int d = 32; d > 0; d >>= 1) best = max(best, __shfl_xor(best, d));
   return best;
+}
+template <bool CS>
+__device__ __forceinline__ int sw_vector_wave_t(const uint8_t* db, const uint8_t* db0, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc,
+                                                int16_t* carry, int lane) {
+  return rlen <= 128 ? sw_vector_wave_s<CS, true>(db, db0, glen, qr, rlen, sc, carry, lane) : sw_vector_wave_s<CS, false>(db, db0, glen, qr, rlen, sc, carry, lane);
 }
 __device__ int sw_vector_wave(const uint8_t* db, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc, int16_t* carry, int lane) {
   return sw_vector_wave_t<false>(db, nullptr, glen, qr, rlen, sc, carry, lane);
