@@ -63,9 +63,12 @@ k_prune(int n_rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict_
   // with a small table; survivors closer than D + e_max to a slab border are kept as they are (their neighbours may sit in the
   // other segment) -- a superset of what the rules keep, hence still exact.
   const uint32_t guard = D + (uint32_t)max(0, e_max);
-  for (int s = 0; s < n_slabs; s++) {
-    const uint32_t b = (s == 0 || !surv_seg) ? 0u : min(n, surv_seg[(size_t)rs * (n_slabs + 1) + s]);
-    const uint32_t e = (!surv_seg || s == n_slabs - 1) ? n : min(n, surv_seg[(size_t)rs * (n_slabs + 1) + s + 1]);
+  // All survivors fit the table at half load (the usual case): one round over the whole read-strand, no border guards.
+  const bool whole = n <= H / 2;
+  const int rounds = whole ? 1 : n_slabs;
+  for (int s = 0; s < rounds; s++) {
+    const uint32_t b = (whole || s == 0 || !surv_seg) ? 0u : min(n, surv_seg[(size_t)rs * (n_slabs + 1) + s]);
+    const uint32_t e = (whole || !surv_seg || s == n_slabs - 1) ? n : min(n, surv_seg[(size_t)rs * (n_slabs + 1) + s + 1]);
     if (e <= b) continue;
     if (e - b > H / 2) { if (tid == 0) too_many = 1; continue; }       // segment larger than the table allows: heavy tier
     for (uint32_t i = tid; i < H; i += blockDim.x) { keys[i] = 0; info[i] = 0x00FFF000u; }
@@ -92,7 +95,7 @@ k_prune(int n_rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict_
       const uint64_t ent = in[i];
       const uint32_t x = (uint32_t)(ent >> 32), bin = x >> bin_bits;
       bool keep;
-      if (n_slabs > 1 && ((uint64_t)x < B + guard || (uint64_t)x + guard >= E)) keep = true;
+      if (!whole && n_slabs > 1 && ((uint64_t)x < B + guard || (uint64_t)x + guard >= E)) keep = true;
       else {
         const uint32_t own = find(bin + 1u), lf = bin > 0 ? find(bin) : 0u, rt = find(bin + 2u);
         // (1) isolation: two entries in the bin: the other one is max - min away; three or more: keep

@@ -72,6 +72,7 @@ __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen,
     uint32_t upH_prev = 0;                     // H(r-1, c-1) for the step to come
     const bool more = !SINGLE && (s + 1 < n_stripes);
     uint32_t dbv = 0, chv = 0, cbv = 0, db0v = 0;
+#pragma unroll 2
     for (int t = 0; t < steps; t++) {
       if ((t & 63) == 0) {                     // refill the per-lane staging of the next 64 columns
         const int c = t + lane;
@@ -86,7 +87,9 @@ __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen,
       const uint32_t in_b = (!SINGLE && s > 0) ? ((uint32_t)__builtin_amdgcn_readlane((int)cbv, sl) << 16) : ((uint32_t)(uint16_t)(-sc.b_go) << 16);
       const uint32_t G = up_of(Gprev, wave_shr1(Gprev, in_g));
       const uint32_t upH = up_of(Hprev, SINGLE ? wave_shr1_z(Hprev) : wave_shr1(Hprev, in_h));
-      const uint32_t upB = up_of(Bprev, wave_shr1(Bprev, in_b));
+      // SINGLE: row -1's B may be anything <= 0 -- a B value that is not positive never changes an H (H >= 0), and starting from 0 instead of
+      // -b_open the B column stays <= 0 until an H - b_open - b_ext term takes over, which is the same term as in the exact recurrence.
+      const uint32_t upB = up_of(Bprev, SINGLE ? wave_shr1_z(Bprev) : wave_shr1(Bprev, in_b));
       // a: gap along the genome (from the left), b: gap along the read (from above)
       const uint32_t a = pk_max(pk_sub(Aprev, v_a_ext), pk_sub(Hprev, v_a_oe));
       const uint32_t b = pk_max(pk_sub(upB, v_b_ext), pk_sub(upH, v_b_oe));
