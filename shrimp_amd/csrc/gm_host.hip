@@ -15,6 +15,8 @@
 #include <cstring>
 #include <memory>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <functional>
 #include "gm_common.h"
 #include "gm_internal.h"
@@ -1024,6 +1026,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   // Sub-batches are pipelined: while the GPU works on sub-batch i+1, host threads finish sub-batch i
   // (pass-2 selection, MAPQ, SAM text).  Output stays in input order.
   struct Job {
+    int idx = 0;
     HostSlot* hs = nullptr;
     const uint32_t* hreads = nullptr; int base = 0, n = 0;
     std::vector<std::string> outs; std::vector<uint64_t> cm, cr; double ms = 0;
@@ -1033,6 +1036,9 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   int nthreads = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
   if (const char* e = getenv("GM_HOST_THREADS")) nthreads = std::max(1, atoi(e));
   const int ops_stride = D.ops_stride;
+  // The SAM text is assembled as the jobs finish, in input order (each job appends after its predecessor), so that the copy -- and the
+  // first touch of the output pages -- overlaps the device work instead of following it.
+  struct OutBuf { char* p = nullptr; size_t len = 0, cap = 0; int turn = 0; bool failed = false; std::mutex m; std::condition_variable cv; ~OutBuf() { free(p); } } ob;
   auto run_job = [&, nthreads, ops_stride](Job* J) {
     auto t0 = std::chrono::steady_clock::now();
     const int n = J->n; const int chunk = 4096; const int nchunks = (n + chunk - 1) / chunk;
@@ -1060,6 +1066,31 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     worker();
     for (auto& t : th) t.join();
     J->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (emit_sam) {
+      size_t sz = 0; for (auto& o : J->outs) sz += o.size();
+      std::unique_lock<std::mutex> lk(ob.m);
+      ob.cv.wait(lk, [&] { return ob.turn == J->idx; });
+      if (!ob.failed && ob.len + sz + 1 > ob.cap) {
+        // first guess: this job's bytes per read for all reads, then geometric growth (large blocks move by remapping)
+        size_t want = std::max(ob.len + sz + 1, ob.cap + ob.cap / 2);
+        if (!ob.cap) want = std::max(want, (size_t)((double)sz / std::max(1, n) * 1.02 * n_reads) + 4096);
+        char* np = (char*)realloc(ob.p, want);
+        if (!np) ob.failed = true; else { ob.p = np; ob.cap = want; }
+      }
+      if (!ob.failed) {
+        char* dst = ob.p + ob.len;
+        std::vector<size_t> off(J->outs.size()); size_t a = 0; for (size_t c = 0; c < J->outs.size(); c++) { off[c] = a; a += J->outs[c].size(); }
+        std::atomic<size_t> nextc(0);
+        auto copier = [&]() { for (;;) { const size_t c = nextc.fetch_add(1); if (c >= J->outs.size()) break; memcpy(dst + off[c], J->outs[c].data(), J->outs[c].size()); std::string().swap(J->outs[c]); } };
+        std::vector<std::thread> ct;
+        for (int t = 1; t < std::min(nthreads, 4); t++) ct.emplace_back(copier);
+        copier();
+        for (auto& t : ct) t.join();
+        ob.len += sz;
+      }
+      ob.turn = J->idx + 1;
+      lk.unlock(); ob.cv.notify_all();
+    }
   };
   size_t joined = 0;
   // Two buffer sets: the front of sub-batch i + 1 (stream A) is queued before the host turns to the back of sub-batch i (stream B),
@@ -1108,15 +1139,28 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     GM_HIP(hipStreamWaitEvent(s->stream, s->pev[k][8], 0));
     return GM_OK;
   };
+  // Sub-batch sizes: while the two halves overlap, the first sub-batch's front and the last one's back (and its host work) have nothing to
+  // run beside, so the sizes ramp up from 8 192 at the start and halve towards the end (results do not depend on the split).
+  int ramp_min = 8192; if (const char* e = getenv("GM_RAMP_MIN")) ramp_min = std::max(64, atoi(e));
+  auto size_at = [&](int base, int eff) {
+    const int R = n_reads - base;
+    int n = std::min(eff, R);
+    if (overlap && ramp_min < eff) {
+      n = std::min(n, std::max(ramp_min, base + ramp_min));
+      n = std::min(n, std::max(ramp_min, R / 2));
+      if (R - n < ramp_min / 2) n = std::min(eff, R);
+    }
+    return n;
+  };
   int cur = 0; bool have_front = false;
   for (int base = 0; base < n_reads;) {
     DevSet& C = s->set[cur];
-    const int n = std::min(C.eff_batch, n_reads - base);
+    const int n = size_at(base, C.eff_batch);
     int rc = GM_OK; float lk = 0;
     if (!have_front) { rc = queue_inputs(cur, base, n); if (!rc) rc = pipeline_front(s, cur, n, read_len); }
     bool have_next = false;
     if (!rc && overlap && base + n < n_reads) {
-      const int n2 = std::min(s->set[cur ^ 1].eff_batch, n_reads - (base + n));
+      const int n2 = size_at(base + n, s->set[cur ^ 1].eff_batch);
       rc = queue_inputs(cur ^ 1, base + n, n2); if (!rc) rc = pipeline_front(s, cur ^ 1, n2, read_len);
       have_next = true;
     }
@@ -1131,7 +1175,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     if (rc) { (void)hipStreamSynchronize(s->stream); (void)hipStreamSynchronize(s->stream_b); join_all(); return rc; }
     s->last_lookup_ms += lk; s->last_lookup_launches++;
     std::unique_ptr<Job> J(new Job());
-    J->base = base; J->n = n;
+    J->base = base; J->n = n; J->idx = (int)jobs.size();
     J->hs = &HS;
     if (reads_host) J->hreads = reads_host + (size_t)base * read_words;
     else {
@@ -1151,25 +1195,17 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     have_front = have_next;
   }
   for (auto& j : jobs) if (j->th.joinable()) j->th.join();
-  uint64_t matched = 0, records = 0; size_t total = 0;
-  std::vector<std::pair<const std::string*, size_t>> pieces;     // (chunk text, offset in the final buffer)
+  uint64_t matched = 0, records = 0;
   for (auto& j : jobs) {
-    for (size_t c = 0; c < j->outs.size(); c++) {
-      if (emit_sam) { pieces.push_back({&j->outs[c], total}); total += j->outs[c].size(); }
-      matched += j->cm[c]; records += j->cr[c];
-    }
+    for (size_t c = 0; c < j->cm.size(); c++) { matched += j->cm[c]; records += j->cr[c]; }
     if (stats) stats->ms_host += j->ms;
   }
   if (stats) { stats->reads = n_reads; stats->reads_matched = matched; stats->sam_records = records; }
   if (emit_sam && sam) {
-    char* r = (char*)malloc(total + 1); if (!r) return GM_E_NOMEM;
-    std::atomic<size_t> nextp(0);
-    auto copier = [&]() { for (;;) { size_t i = nextp.fetch_add(1); if (i >= pieces.size()) break; memcpy(r + pieces[i].second, pieces[i].first->data(), pieces[i].first->size()); } };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nthreads; t++) th.emplace_back(copier);
-    copier();
-    for (auto& t : th) t.join();
-    r[total] = 0; *sam = r; if (sam_len) *sam_len = total;
+    if (ob.failed) return GM_E_NOMEM;
+    char* r = (char*)realloc(ob.p, ob.len + 1); if (!r) return GM_E_NOMEM;
+    ob.p = nullptr;
+    r[ob.len] = 0; *sam = r; if (sam_len) *sam_len = ob.len;
   } else { if (sam) *sam = nullptr; if (sam_len) *sam_len = 0; }
   return GM_OK;
 }
