@@ -127,7 +127,9 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             t = tj.get("%s/%s/%d" % (args.workload, kname, min(R, int(os.environ.get("GM_SUBBATCH", "131072")))))
             if t and args.scale == 1.0:
-                traffic = t["bytes_per_launch"]
+                # measured on launches of 131 072 reads; the launches of this run differ in size (the sub-batch sizes ramp up and
+                # down around the overlapped pipeline), so the figure is scaled to this run's mean reads per launch
+                traffic = t["bytes_per_launch"] * ((R * args.steps / max(1, lk_launch)) / 131072.0)
         except Exception:
             pass
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
