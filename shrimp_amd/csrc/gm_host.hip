@@ -304,6 +304,7 @@ struct gm_session {
   uint32_t* h_pin = nullptr;                      // pinned words the front writes (heavy count per set); from word 16 on: K1's start flags
   uint32_t flag_epoch = 0, front_epoch[2] = {0, 0}; int front_flag_grid[2] = {0, 0};
   DevSet set[2];
+  DevSet set2[2];                                 // paired mode: the second pair of buffer sets of the two-stream pipeline
   HostSlot slot[3];
   uint32_t* d_pairs = nullptr; uint32_t* d_pair_cnt = nullptr; int pairs_cap = 0;   // paired mode: selected (mate 1, mate 2) window pairs
   unsigned long long* d_stats = nullptr;
@@ -441,7 +442,7 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
 extern "C" void gm_session_free(gm_session_t* s) {
   if (!s) return;
   (void)hipSetDevice(s->ix->device);
-  free_buffers(s->set[0]); free_buffers(s->set[1]);
+  free_buffers(s->set[0]); free_buffers(s->set[1]); free_buffers(s->set2[0]); free_buffers(s->set2[1]);
   for (auto& h : s->slot) slot_free(h);
   if (s->d_pairs) (void)hipFree(s->d_pairs);
   if (s->d_pair_cnt) (void)hipFree(s->d_pair_cnt);
