@@ -804,10 +804,9 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
       w.nv = locate(t, w.j, e0);
       k1_u32x4 v = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
       if (w.nv) v = load_window(w.j, e0);
-      // 0xFFFFFFFF = no entry (never a k-mer start): such lanes count into a spare word, so the passes below are straight-line code
+      // 0xFFFFFFFF = no entry (never a k-mer start); the passes below are straight-line code over all four slots
       w.p[0] = v.x; w.p[1] = w.nv > 1 ? v.y : 0xFFFFFFFFu; w.p[2] = w.nv > 2 ? v.z : 0xFFFFFFFFu; w.p[3] = w.nv > 3 ? v.w : 0xFFFFFFFFu;
     };
-    const uint32_t spare = 1u << tab_bits, spare0 = spare + 16u;   // counters past the table: scratch for empty lanes (pass A) / always zero (pass B)
     // ---- pass A: folded counts ----
     if (!(ablate & 8)) {
       Win cur[K4Q], nxt[K4Q];
@@ -820,14 +819,23 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
         for (int q = 0; q < K4Q; q++) {
           const Win& w = cur[q];
           if (ablate & 2) { if ((w.p[0] ^ w.p[1] ^ w.p[2] ^ w.p[3]) == 0x12345u) tab[0] = 1; continue; }   // loads only
+          // Folded counts only have to be >= the true ones (the exact rule is applied in pass C), so this pass takes two short cuts: an empty lane
+          // (0xFFFFFFFF) counts into the folded counter of its pseudo-region instead of a spare word, and a strip entry of region 0 marks
+          // counter (0 - 1) & tmask.  Both can only add candidates.
           uint32_t old[4], h[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) { h[u] = (w.p[u] != 0xFFFFFFFFu) ? ((w.p[u] >> rb) & tmask) : spare; old[u] = atomicOr(&tab[h[u] >> 4], 1u << ((h[u] & 15u) * 2u)); }
+          for (int u = 0; u < 4; u++) { h[u] = (w.p[u] >> rb) & tmask; old[u] = atomicOr(&tab[h[u] >> 4], 1u << ((h[u] & 15u) * 2u)); }
 #pragma unroll
           for (int u = 0; u < 4; u++) if (((old[u] >> ((h[u] & 15u) * 2u)) & 3u) == 1u) atomicOr(&tab[h[u] >> 4], 2u << ((h[u] & 15u) * 2u));
+          // overlap strip (ref: mapping.c:521-533): 2.4 % of the entries (0xFFFFFFFF is never in it) -- one rarely taken loop for the four
+          uint32_t sm = 0;
 #pragma unroll
-          for (int u = 0; u < 4; u++)                            // overlap strip (ref: mapping.c:521-533): 2.4 % of the entries (0xFFFFFFFF is never in it)
-            if ((w.p[u] & rmask) < ovl && (w.p[u] >> rb) > 0) k1_mark(tab, ((w.p[u] >> rb) - 1u) & tmask);
+          for (int u = 0; u < 4; u++) sm |= ((w.p[u] & rmask) < ovl) ? (1u << u) : 0u;
+          while (sm) {
+            const int u = __builtin_ctz(sm); sm &= sm - 1u;
+            const uint32_t pu = u == 0 ? w.p[0] : (u == 1 ? w.p[1] : (u == 2 ? w.p[2] : w.p[3]));
+            k1_mark(tab, ((pu >> rb) - 1u) & tmask);
+          }
         }
 #pragma unroll
         for (int q = 0; q < K4Q; q++) cur[q] = nxt[q];
@@ -845,13 +853,20 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
 #pragma unroll
         for (int q = 0; q < K4Q; q++) {
           const Win& w = cur[q];
-          uint32_t hit = 0;
+          uint32_t hit = 0, sm = 0;
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const uint32_t r = w.p[u] >> rb;
-            if (k1_has2(tab, (w.p[u] != 0xFFFFFFFFu) ? (r & tmask) : spare0)) hit |= 1u << u;
-            else if ((w.p[u] & rmask) < ovl && r > 0 && k1_has2(tab, (r - 1u) & tmask)) hit |= 1u << u;
+            hit |= k1_has2(tab, r & tmask) ? (1u << u) : 0u;
+            sm |= ((w.p[u] & rmask) < ovl) ? (1u << u) : 0u;
           }
+          sm &= ~hit;
+          while (sm) {                                             // strip entries whose own counter is below 2: the counter of region - 1 decides
+            const int u = __builtin_ctz(sm); sm &= sm - 1u;
+            const uint32_t pu = u == 0 ? w.p[0] : (u == 1 ? w.p[1] : (u == 2 ? w.p[2] : w.p[3]));
+            if (k1_has2(tab, ((pu >> rb) - 1u) & tmask)) hit |= 1u << u;
+          }
+          hit &= (1u << w.nv) - 1u;                                // empty lanes (their pseudo-region's counter may have reached 2) are no entries
           if (hit && (ablate & 16)) { if (hit == 0x55u) tab[1] = 1; hit = 0; }
           if (hit) {
             const uint32_t ysn = rec[4 * w.j + 3];
