@@ -733,6 +733,7 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
   const int tab_words = (1 << (tab_bits - 4)) + 4;            // + the spare counters of the empty lanes
   const uint32_t* __restrict__ pos0 = ix.seed[0].pos;
   uint64_t* my_scratch = scratch + (size_t)blockIdx.x * SC * bin_cap;
+  const int bin_shift = 31 - __builtin_clz((unsigned)bin_cap);        // bin_cap is a power of two (k4_launch)
   const int ng = nthr / 8, g = tid / 8, gl4 = (tid & 7) * 4;
   unsigned long long my_lookups = 0, my_entries = 0;
 
@@ -876,14 +877,15 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
               const uint32_t r = p >> rb, sl = p >> cbits, rloc = r & (R - 1u);
               const uint64_t key = ((uint64_t)p << 32) | ysn;
               uint32_t idx = atomicAdd(&bin_cnt[sl], 1u);
-              if (idx < (uint32_t)bin_cap) my_scratch[(size_t)sl * bin_cap + idx] = key; else overflow = 1u;
+              if (idx < (uint32_t)bin_cap) my_scratch[(sl << bin_shift) + idx] = key; else overflow = 1u;
+              if (((rloc + 1u) & (R - 1u)) > 1u) continue;         // not in a bin's first or last region: no border copy
               if (rloc == R - 1u && (int)sl + 1 < SC) {          // also counts for the next bin's counter 0
                 idx = atomicAdd(&bin_cnt[sl + 1], 1u);
-                if (idx < (uint32_t)bin_cap) my_scratch[(size_t)(sl + 1) * bin_cap + idx] = key | K4_MO_SELF; else overflow = 1u;
+                if (idx < (uint32_t)bin_cap) my_scratch[((sl + 1u) << bin_shift) + idx] = key | K4_MO_SELF; else overflow = 1u;
               }
               if (rloc == 0u && sl > 0 && (p & rmask) < ovl) {   // its strip mark belongs to the previous bin's last region
                 idx = atomicAdd(&bin_cnt[sl - 1], 1u);
-                if (idx < (uint32_t)bin_cap) my_scratch[(size_t)(sl - 1) * bin_cap + idx] = key | K4_MO_PREV; else overflow = 1u;
+                if (idx < (uint32_t)bin_cap) my_scratch[((sl - 1u) << bin_shift) + idx] = key | K4_MO_PREV; else overflow = 1u;
               }
             }
           }
@@ -1002,7 +1004,7 @@ static bool k4_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   if (SC < 1 || SC > 4096) return false;
   int wcap = 4096; if (const char* e = getenv("GM_K4_WCAP")) wcap = std::max(2, std::min(4096, atoi(e) & ~1));   // windows with a direct window -> list entry (the rest: binary search)
   const int fb_cap = 4096;
-  int bin_cap = 4096; if (const char* e = getenv("GM_K4_BINCAP")) bin_cap = std::max(16, atoi(e));
+  int bin_cap = 4096; if (const char* e = getenv("GM_K4_BINCAP")) { const int v = std::max(16, std::min(1 << 20, atoi(e))); bin_cap = 16; while (bin_cap < v) bin_cap <<= 1; }
   const int code_words = (read_len + 3) / 4;
   const size_t lds = (size_t)(((((code_words + 3) & ~3) + 4 * NL + NL + 1 + SC + (wcap + 1) / 2 + 3) & ~3) + (1 << (tab_bits - 4)) + 4) * 4;
   if (lds > 160 * 1024 - 64) return false;
