@@ -258,6 +258,34 @@ def test_paired_small_subbatches_and_unpaired_after(gm, oracle_lib):
     assert got_u == want_u, _first_diff(got_u, want_u)
 
 
+def test_two_stream_pipeline_equals_stage_order(gm):
+    """the overlapped sub-batch pipeline (front of sub-batch i+1 beside the back of sub-batch i, ramped sub-batch sizes, SAM text appended
+    by the host jobs) gives the same bytes as the strict stage order, unpaired and paired, and both equal the reference golden"""
+    import os
+    contigs, reads, sam = oa.load_golden("stress_60bp")
+    g = oa.load_golden_pairs("stress_pairs_2x100")
+    outs = {}
+    for mode in ("1", "0"):
+        old = os.environ.get("GM_OVERLAP"); os.environ["GM_OVERLAP"] = mode
+        os.environ["GM_RAMP_MIN"] = "64"
+        try:
+            ix = gm.Index(contigs); s = gm.Session(ix, max_batch_reads=256)
+            u = oa.sam_header(contigs) + s.map_reads(reads)
+            s.close(); ix.close()
+            ix = gm.Index(g["contigs"], names=g["contig_names"]); s = gm.Session(ix, max_batch_reads=64)
+            p = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs(g["m1"], g["m2"], g["names1"], g["names2"], mode=g["mode"],
+                                                                             min_insert=g["ins"][0], max_insert=g["ins"][1])
+            s.close(); ix.close()
+        finally:
+            os.environ.pop("GM_RAMP_MIN", None)
+            if old is None: os.environ.pop("GM_OVERLAP", None)
+            else: os.environ["GM_OVERLAP"] = old
+        outs[mode] = (u, p)
+    assert outs["1"][0] == sam, _first_diff(outs["1"][0], sam)
+    assert outs["1"] == outs["0"]
+    assert outs["1"][1] == g["sam"], _first_diff(outs["1"][1], g["sam"])
+
+
 def test_tophits_match_oracle_on_stress(gm, oracle_lib):
     """stage parity: the pass-1 survivors (ext-heap array order, scores, anchor boxes)"""
     contigs, reads, _ = oa.load_golden("stress_60bp")
