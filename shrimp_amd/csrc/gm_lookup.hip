@@ -736,6 +736,7 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
   const int bin_shift = 31 - __builtin_clz((unsigned)bin_cap);        // bin_cap is a power of two (k4_launch)
   const int ng = nthr / 8, g = tid / 8, gl4 = (tid & 7) * 4;
   unsigned long long my_lookups = 0, my_entries = 0;
+  bool tab_clean = false;                                   // uniform over the workgroup
 
   for (int rs = blockIdx.x; rs < 2 * n_reads; rs += gridDim.x) {
     const int rd = rs >> 1, st = rs & 1;
@@ -744,7 +745,9 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
     __syncthreads();                                         // the previous read-strand is done with the LDS
     const uint32_t* rw = reads + (size_t)rd * read_words;
     for (int i = tid; i < read_len; i += nthr) codes[i] = (uint8_t)gm_read_code(rw, read_len, st, ix.colour, i);
-    { uint4* t4 = (uint4*)tab; for (int w = tid; w < (tab_words >> 2); w += nthr) t4[w] = make_uint4(0, 0, 0, 0); }
+    // pass C un-marks every word it touched, so after a read-strand that went through it the table is already clear
+    if (!tab_clean) { uint4* t4 = (uint4*)tab; for (int w = tid; w < (tab_words >> 2); w += nthr) t4[w] = make_uint4(0, 0, 0, 0); }
+    tab_clean = false;
     for (int c = tid; c < SC; c += nthr) bin_cnt[c] = 0;
     if (tid == 0) { n_surv = 0; n_lists = 0; overflow = 0; }
     __syncthreads();
@@ -948,6 +951,7 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
       if (surv_seg && tid == 0 && (((s + 1) % per_slab) == 0 || s + 1 == SC)) surv_seg[(size_t)rs * (S + 1) + s / per_slab + 1] = n_surv;   // survivors come out slab by slab
       __syncthreads();
     }
+    tab_clean = !ablate;
     if (tid == 0) {
       if (surv_seg) surv_seg[(size_t)rs * (S + 1)] = 0;
       surv_cnt[rs] = n_surv;
