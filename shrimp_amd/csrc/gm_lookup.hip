@@ -716,7 +716,7 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
   __builtin_amdgcn_s_setprio(3);                            // memory-latency-bound: issue first when ready; VALU-bound kernels of the other stream fill the gaps
 
   extern __shared__ __align__(16) uint32_t smem[];
-  __shared__ uint32_t n_surv, n_lists, n_win, overflow;
+  __shared__ uint32_t n_surv, n_lists, n_win, overflow, pair_cnt[2];
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & (GM_WAVE - 1);
   const int S = ix.n_slabs, rb = ix.region_bits;
   const uint32_t rmask = (1u << rb) - 1u, ovl = (uint32_t)ix.region_overlap;
@@ -749,7 +749,7 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
     if (!tab_clean) { uint4* t4 = (uint4*)tab; for (int w = tid; w < (tab_words >> 2); w += nthr) t4[w] = make_uint4(0, 0, 0, 0); }
     tab_clean = false;
     for (int c = tid; c < SC; c += nthr) bin_cnt[c] = 0;
-    if (tid == 0) { n_surv = 0; n_lists = 0; overflow = 0; }
+    if (tid == 0) { n_surv = 0; n_lists = 0; overflow = 0; pair_cnt[0] = 0; pair_cnt[1] = 0; }
     __syncthreads();
     // ---- map indexes and whole-list bounds (ref: mapping.c:53-66, KMER_TO_MAPIDX gmapper.h:349-368) ----
     for (int off = tid; off < NL; off += nthr) {
@@ -911,7 +911,65 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
     { uint4* t4 = (uint4*)tab; for (int w = tid; w < (tab_words >> 2); w += nthr) t4[w] = make_uint4(0, 0, 0, 0); }
     __syncthreads();
     const int per_slab = 1 << (ix.slab_bits - cbits);        // bins per index slab
+    const uint32_t half = (R + 2u + 15u) & ~15u;             // counters of one bin, in whole table words: two bins fit the table
     for (int s = 0; s < SC; s++) {
+      // Two bins per round when each has at most one candidate per thread (the usual case): their bitmaps sit side by side in the table,
+      // the candidates are read once and stay in registers, and the survivors' slots come from per-bin counts -- three barriers for two bins.
+      if (s + 1 < SC && bin_cnt[s] <= (uint32_t)nthr && bin_cnt[s + 1] <= (uint32_t)nthr) {
+        const uint32_t ncA = bin_cnt[s], ncB = bin_cnt[s + 1];
+        const uint64_t keyA = (uint32_t)tid < ncA ? my_scratch[((uint32_t)s << bin_shift) + (uint32_t)tid] : 0ull;
+        const uint64_t keyB = (uint32_t)tid < ncB ? my_scratch[(((uint32_t)s + 1u) << bin_shift) + (uint32_t)tid] : 0ull;
+        const uint32_t base0 = n_surv;                           // stable since the last barrier
+        bool hitv[2] = {false, false}; uint32_t rank[2] = {0, 0}, locv[2] = {0, 0};
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+          const uint64_t key = b ? keyB : keyA;
+          if ((uint32_t)tid < (b ? ncB : ncA)) {
+            const uint32_t p = (uint32_t)(key >> 32), fl = (uint32_t)key;
+            const uint32_t loc = (p >> rb) - (uint32_t)(s + b) * R + 1u + (uint32_t)b * half;   // MO_SELF copy: 0; MO_PREV copy: R + 1
+            locv[b] = loc;
+            if (fl & K4_MO_PREV) k1_mark(tab, loc - 1u);
+            else {
+              k1_mark(tab, loc);
+              if (!(fl & K4_MO_SELF) && (p & rmask) < ovl && (p >> rb) > 0) k1_mark(tab, loc - 1u);
+            }
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+          const uint64_t key = b ? keyB : keyA;
+          bool hit = false;
+          if ((uint32_t)tid < (b ? ncB : ncA)) {
+            const uint32_t p = (uint32_t)(key >> 32), fl = (uint32_t)key;
+            if (!(fl & (K4_MO_SELF | K4_MO_PREV))) hit = k1_has2(tab, locv[b]) || ((p & rmask) < ovl && (p >> rb) > 0 && k1_has2(tab, locv[b] - 1u));
+          }
+          const unsigned long long bal = __ballot(hit);
+          uint32_t basev = 0;
+          if (bal) {
+            if (lane == 0) basev = atomicAdd(&pair_cnt[b], (uint32_t)__popcll(bal));
+            basev = __shfl(basev, 0);
+          }
+          hitv[b] = hit; rank[b] = basev + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        }
+        __syncthreads();
+        const uint32_t cA = pair_cnt[0], cB = pair_cnt[1];
+        if (hitv[0]) { const uint32_t slot = base0 + rank[0]; if (slot < scap) out[slot] = keyA; }
+        if (hitv[1]) { const uint32_t slot = base0 + cA + rank[1]; if (slot < scap) out[slot] = keyB; }
+        if ((uint32_t)tid < ncA) { tab[locv[0] >> 4] = 0; if (locv[0]) tab[(locv[0] - 1u) >> 4] = 0; }
+        if ((uint32_t)tid < ncB) { tab[locv[1] >> 4] = 0; tab[(locv[1] - 1u) >> 4] = 0; }
+        __syncthreads();
+        if (tid == 0) {
+          n_surv = base0 + cA + cB; pair_cnt[0] = 0; pair_cnt[1] = 0;
+          if (surv_seg) {
+            if (((s + 1) % per_slab) == 0) surv_seg[(size_t)rs * (S + 1) + s / per_slab + 1] = base0 + cA;
+            if (((s + 2) % per_slab) == 0 || s + 2 == SC) surv_seg[(size_t)rs * (S + 1) + (s + 1) / per_slab + 1] = base0 + cA + cB;
+          }
+        }
+        __syncthreads();
+        s++;
+        continue;
+      }
       const int nc = (int)bin_cnt[s];
       const uint64_t* cand = my_scratch + (size_t)s * bin_cap;
       const uint32_t rbase = (uint32_t)s * R;
