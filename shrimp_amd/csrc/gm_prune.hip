@@ -71,7 +71,8 @@ k_prune(int n_rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict_
     const uint32_t e = (whole || !surv_seg || s == n_slabs - 1) ? n : min(n, surv_seg[(size_t)rs * (n_slabs + 1) + s + 1]);
     if (e <= b) continue;
     if (e - b > H / 2) { if (tid == 0) too_many = 1; continue; }       // segment larger than the table allows: heavy tier
-    for (uint32_t i = tid; i < H; i += blockDim.x) { keys[i] = 0; info[i] = 0x00FFF000u; }
+    { uint4* k4 = (uint4*)keys; uint4* i4 = (uint4*)info;     // H >= 256: whole 16-byte stores
+      for (uint32_t i = tid; i < H / 4; i += blockDim.x) { k4[i] = make_uint4(0, 0, 0, 0); i4[i] = make_uint4(0x00FFF000u, 0x00FFF000u, 0x00FFF000u, 0x00FFF000u); } }
     __syncthreads();
     for (uint32_t i = b + tid; i < e; i += blockDim.x) {
       const uint32_t x = (uint32_t)(in[i] >> 32), key = (x >> bin_bits) + 1u, o = x & omask;
