@@ -114,7 +114,8 @@ def main():
                                 "cfg1": "36bp LS reads vs 1Mbp (BASELINE configs[0])"}[args.workload],
                    "reads_per_step_per_gpu": R, "read_len": L, "genome_bp": int(sum(len(c) for c in contigs)),
                    "parallelism": "read-sharded x%d, index replicated (1 RCCL broadcast at start-up)" % world,
-                   "sam_emitted": not args.no_sam, "scale": args.scale},
+                   "sam_emitted": not args.no_sam, "scale": args.scale,
+                   "sub_batch_pipeline": "stage order" if os.environ.get("GM_OVERLAP") == "0" else "two streams (lookup of sub-batch i+1 beside SW of sub-batch i)"},
     }
     if rank == 0:
         # dominant kernel = seed lookup (k_lookup): algorithmic bytes / its own HIP-event time
