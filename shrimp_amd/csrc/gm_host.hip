@@ -1042,7 +1042,8 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   struct OutBuf { char* p = nullptr; size_t len = 0, cap = 0; int turn = 0; bool failed = false; std::mutex m; std::condition_variable cv; ~OutBuf() { free(p); } } ob;
   auto run_job = [&, nthreads, ops_stride](Job* J) {
     auto t0 = std::chrono::steady_clock::now();
-    const int n = J->n; const int chunk = 4096; const int nchunks = (n + chunk - 1) / chunk;
+    const int n = J->n; const int chunk = std::max(256, std::min(4096, n / (2 * nthreads)));   // small sub-batches (the ramp) still use every thread
+    const int nchunks = (n + chunk - 1) / chunk;
     J->outs.assign(nchunks, std::string()); J->cm.assign(nchunks, 0); J->cr.assign(nchunks, 0);
     std::atomic<int> next(0);
     Finalizer F{s, read_len, read_words, J->hreads, names ? nptr.data() + J->base : nullptr, names ? nlen.data() + J->base : nullptr, (long)J->base};
