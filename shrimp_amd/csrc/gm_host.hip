@@ -519,6 +519,19 @@ static CsPostConsts cs_post_consts(const gm_session* s) {
   for (int k = 0; k < 2; k++) { c.col_m[k] = log(1 - ce[k]); c.col_x[k] = log(ce[k] / 3.0); }
   return c;
 }
+// exp() of 16 state values of one column.  The 16 arguments take few distinct values (a state's prior has four possible values, the
+// transition terms depend on one letter only), and exp is a pure function: computing it once per distinct bit pattern gives the very same
+// doubles as 16 calls do.
+static inline void exp_neg16(const double* in, double* out) {
+  uint64_t seen[16]; double val[16]; int ns = 0;
+  for (int k = 0; k < 16; k++) {
+    uint64_t b; memcpy(&b, &in[k], 8);
+    int j = 0; while (j < ns && seen[j] != b) j++;
+    if (j == ns) { seen[ns] = b; val[ns] = exp(-1 * in[k]); ns++; }
+    out[k] = val[j];
+  }
+}
+
 static void cs_post_sw(const gm_session* s, const CsPostConsts& K, const uint32_t* rw, int init_bp, int read_start, FHit& h,
                        const char* qual = nullptr, int qual_delta = 33) {   // qual: the read's QV string (csfastq) or null
   struct Col { double prior[16], fw[16], bw[16], fs, bs; int col, base_call; };
@@ -571,7 +584,7 @@ static void cs_post_sw(const gm_session* s, const CsPostConsts& K, const uint32_
     for (int i = 1; i < len; i++) {
       Col& c = cols[i]; const Col& p = cols[i - 1];
       double e[16], lg[4];
-      for (int k = 0; k < 16; k++) e[k] = exp(-1 * (p.fw[k]));
+      exp_neg16(p.fw, e);
       for (int l = 0; l < 4; l++) { double sum = 0; for (int k = l; k < 16; k += 4) sum += e[k]; lg[l] = log(sum); }   // states k with right(k) == l, ascending
       c.fs = 999999999;
       for (int j = 0; j < 16; j++) { c.fw[j] = c.prior[j] - lg[(j >> 2) & 3]; c.fs = (c.fs < c.fw[j]) ? c.fs : c.fw[j]; }
@@ -589,7 +602,7 @@ static void cs_post_sw(const gm_session* s, const CsPostConsts& K, const uint32_
     for (int i = len - 2; i >= 0; i--) {
       Col& c = cols[i]; const Col& n = cols[i + 1];
       double e[16], nl[4];
-      for (int k = 0; k < 16; k++) e[k] = exp(-1 * (n.prior[k] + n.bw[k]));
+      { double a[16]; for (int k = 0; k < 16; k++) a[k] = n.prior[k] + n.bw[k]; exp_neg16(a, e); }
       for (int r = 0; r < 4; r++) { double sum = 0; for (int k = 4 * r; k < 4 * r + 4; k++) sum += e[k]; nl[r] = -log(sum); }     // states k with left(k) == r
       c.bs = 999999999;
       for (int j = 0; j < 16; j++) { c.bw[j] = nl[j & 3]; c.bs = (c.bs < c.bw[j]) ? c.bs : c.bw[j]; }
@@ -603,7 +616,8 @@ static void cs_post_sw(const gm_session* s, const CsPostConsts& K, const uint32_
       if (qr[i] == '-') continue;
       const Col& c = cols[j];
       double post[4] = {0, 0, 0, 0};
-      for (int st = 0; st < 16; st++) post[st & 3] += exp(-1 * (c.fw[st] + c.bw[st] + c.fs + c.bs - total));
+      { double a[16], ev[16]; for (int st = 0; st < 16; st++) a[st] = c.fw[st] + c.bw[st] + c.fs + c.bs - total; exp_neg16(a, ev);
+        for (int st = 0; st < 16; st++) post[st & 3] += ev[st]; }
       int crt = 0; for (int b = 1; b < 4; b++) if (post[b] > post[crt]) crt = b;
       if (qual) {                                       // get_base_qualities, ref: sw-post.c:568-586: of the letter sw_full_cs had called
         int t = c.base_call >= 0 ? qv_from_pr_corr(post[c.base_call]) : 0;
