@@ -36,6 +36,8 @@ struct GmSeedDev {
   const uint32_t* dir;
   const uint32_t* pos;
   const uint32_t* bkt;   // optional [K][16]: list length + first 15 positions (small genomes; see gm_index.hip)
+  const uint32_t* sdir;  // optional [K+1]: strip list of k = spos[sdir[k] .. sdir[k+1]): list k's entries in the first region_overlap bases
+  const uint32_t* spos;  //   of a region > 0, in list order (derived on the device, gm_lookup5.hip)
   uint32_t n_pos;
 };
 

@@ -71,6 +71,7 @@ GmIndexDev GmIndexHost::dev_view() const {
   for (int i = 0; i < n_seeds; i++) {
     d.seed[i].mask = seeds[i].mask; d.seed[i].span = seeds[i].span; d.seed[i].weight = seeds[i].weight;
     d.seed[i].dir = seeds[i].d_dir; d.seed[i].pos = seeds[i].d_pos; d.seed[i].bkt = seeds[i].d_bkt; d.seed[i].n_pos = seeds[i].n_pos;
+    d.seed[i].sdir = strips_ready ? seeds[i].d_sdir : nullptr; d.seed[i].spos = strips_ready ? seeds[i].d_spos : nullptr;
   }
   return d;
 }
@@ -173,7 +174,8 @@ extern "C" void gm_index_free(gm_index_t* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
   (void)hipFree(ix->d_genome); (void)hipFree(ix->d_genome_cs); (void)hipFree(ix->d_contig_off);
-  for (int i = 0; i < ix->n_seeds; i++) { (void)hipFree(ix->seeds[i].d_dir); (void)hipFree(ix->seeds[i].d_pos); (void)hipFree(ix->seeds[i].d_bkt); }
+  for (int i = 0; i < ix->n_seeds; i++) { (void)hipFree(ix->seeds[i].d_dir); (void)hipFree(ix->seeds[i].d_pos); (void)hipFree(ix->seeds[i].d_bkt);
+                                           (void)hipFree(ix->seeds[i].d_sdir); (void)hipFree(ix->seeds[i].d_spos); }
   delete ix;
 }
 extern "C" uint32_t gm_index_list_cutoff(const gm_index_t* ix) { return ix->list_cutoff; }
@@ -181,7 +183,8 @@ extern "C" int gm_index_n_slabs(const gm_index_t* ix) { return ix->n_slabs; }
 extern "C" int gm_index_has_buckets(const gm_index_t* ix) { return ix->seeds[0].d_bkt != nullptr; }
 extern "C" uint64_t gm_index_bytes(const gm_index_t* ix) {
   uint64_t b = ix->genome_words * 4 * (ix->d_genome_cs ? 2 : 1);
-  for (int i = 0; i < ix->n_seeds; i++) b += (ix->seeds[i].dir_words + (uint64_t)ix->seeds[i].n_pos + (ix->seeds[i].d_bkt ? (16ull << ix->seeds[i].kbits) : 0ull)) * 4;
+  for (int i = 0; i < ix->n_seeds; i++) b += (ix->seeds[i].dir_words + (uint64_t)ix->seeds[i].n_pos + (ix->seeds[i].d_bkt ? (16ull << ix->seeds[i].kbits) : 0ull) +
+                                            (ix->seeds[i].d_sdir ? (1ull << ix->seeds[i].kbits) + 1 + ix->seeds[i].n_spos : 0ull)) * 4;
   return b;
 }
 extern "C" int gm_index_get_list(const gm_index_t* ix, int sn, uint32_t mapidx, uint32_t* len, uint32_t* positions, uint32_t cap) {
@@ -402,6 +405,7 @@ static void choose_caps(gm_session* s, DevSet& D, int read_len) {
   (void)max_n_kmers;
 }
 
+extern "C" void gm_session_free(gm_session_t* s);
 extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const gm_params_t* params, int max_batch_reads) {
   if (!out || !ix) return GM_E_ARG;
   GM_HIP(hipSetDevice(ix->device));
@@ -436,6 +440,11 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   for (auto& d : s->d_pstats) GM_HIP(hipMalloc(&d, (size_t)GS_STRIPES * GS_STRIDE * 8));
   GM_HIP(hipHostMalloc((void**)&s->h_pin, (16 + 1024) * 4, hipHostMallocDefault));
   memset(s->h_pin, 0, (16 + 1024) * 4);
+  // k_lookup_v5 streams large indexes with the help of per-list strip lists, derived once per index (not stored in the index files)
+  if (gm_tune("GM_K1_V5") && ix->params.region_bits >= 9 && ix->params.region_bits <= 16) {
+    const int rc = gm_index_derive_strips(const_cast<gm_index*>(ix), s->stream);
+    if (rc) { gm_session_free(s); return rc; }
+  }
   *out = s;
   return GM_OK;
 }
@@ -856,23 +865,38 @@ static int run_heavy_tier(gm_session* s, DevSet& D, const GmIndexDev& dv, int n,
   return rc;
 }
 
+// tight-cluster bound of the prune rules (gm_prune.hip): smallest window-generation threshold over all contigs, in survivors' x extent
+static int prune_e_max(const gm_session* s, int read_len, int W) {
+  int e_max = -1;
+  if (gm_tune("GM_PRUNE_NO_RULE2")) return e_max;
+  if (s->sc.match > 0 && s->sc.b_go >= 0 && s->sc.b_ge >= 0) {
+    long long min_clen = 1ll << 40;
+    for (int c = 0; c < s->ix->n_contigs; c++) min_clen = std::min<long long>(min_clen, (long long)s->ix->contig_off[c + 1] - s->ix->contig_off[c]);
+    const int w_len = (int)std::min<long long>(W, min_clen);
+    const int base = std::min(read_len, w_len) * s->sc.match;
+    const int thr = s->sc.wgen_thr_frac < 0 ? s->sc.wgen_abs : (int)((double)base * s->sc.wgen_thr_frac);
+    e_max = (thr + s->sc.match - 1) / s->sc.match - s->ix->max_seed_span - 1;
+  }
+  return e_max;
+}
+
+// K1 with K1b's prune fused where the chosen kernel can (k_lookup_v5); *fused tells launch_prune_anchors to skip K1b
+static int launch_lookup(gm_session* s, DevSet& D, const GmIndexDev& dv, int n, int read_len, int read_words, int W, unsigned long long* d_stats, int* fused) {
+  GmFusePrune f; f.d_surv2 = D.d_surv2; f.d_surv_cnt2 = D.d_surv_cnt2; f.scap2 = D.scap2; f.window_len = W; f.e_max = D.scap2 > 0 ? prune_e_max(s, read_len, W) : -1; f.fused = fused;
+  *fused = 0;
+  return gm_launch_lookup(dv, D.d_reads, n, read_len, read_words, D.d_surv, D.d_surv_cnt, D.scap, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, d_stats, s->stream, D.d_surv_seg, &f);
+}
+
 // K1b + K2 on the survivors of K1
-static int launch_prune_anchors(gm_session* s, DevSet& D, const GmIndexDev& dv, int n, int read_len, int W, unsigned long long* d_stats = nullptr) {
+static int launch_prune_anchors(gm_session* s, DevSet& D, const GmIndexDev& dv, int n, int read_len, int W, unsigned long long* d_stats = nullptr, int fused = 0) {
   hipStream_t q = s->stream;
   if (!d_stats) d_stats = s->d_stats;
   if (D.scap2 > 0) {
-    // tight-cluster bound (gm_prune.hip): smallest window-generation threshold over all contigs, in survivors' x extent
-    int e_max = -1;
-    if (s->sc.match > 0 && s->sc.b_go >= 0 && s->sc.b_ge >= 0) {
-      long long min_clen = 1ll << 40;
-      for (int c = 0; c < s->ix->n_contigs; c++) min_clen = std::min<long long>(min_clen, (long long)s->ix->contig_off[c + 1] - s->ix->contig_off[c]);
-      const int w_len = (int)std::min<long long>(W, min_clen);
-      const int base = std::min(read_len, w_len) * s->sc.match;
-      const int thr = s->sc.wgen_thr_frac < 0 ? s->sc.wgen_abs : (int)((double)base * s->sc.wgen_thr_frac);
-      e_max = (thr + s->sc.match - 1) / s->sc.match - s->ix->max_seed_span - 1;
+    if (!fused) {
+      const int e_max = prune_e_max(s, read_len, W);
+      int rc = gm_launch_prune(n, read_len, W, e_max, s->ix->n_slabs, s->ix->slab_bits, D.d_surv, D.d_surv_cnt, D.d_surv_seg, D.scap, D.d_surv2, D.d_surv_cnt2, D.scap2, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, d_stats, q);
+      if (rc) return rc;
     }
-    int rc = gm_launch_prune(n, read_len, W, e_max, s->ix->n_slabs, s->ix->slab_bits, D.d_surv, D.d_surv_cnt, D.d_surv_seg, D.scap, D.d_surv2, D.d_surv_cnt2, D.scap2, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, d_stats, q);
-    if (rc) return rc;
     return gm_launch_anchors(dv, s->sc, n, read_len, W, D.d_surv2, D.d_surv_cnt2, D.scap2, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, d_stats, q);
   }
   return gm_launch_anchors(dv, s->sc, n, read_len, W, D.d_surv, D.d_surv_cnt, D.scap, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, d_stats, q);
@@ -893,12 +917,13 @@ static int pipeline_front(gm_session* s, int k, int n, int read_len) {
   GM_HIP(hipMemsetAsync(d_stats, 0, (size_t)GS_STRIPES * GS_STRIDE * 8, q));
   GM_HIP(hipEventRecord(s->pev[k][0], q));
   gm_lookup_set_start_flags(s->h_pin + 16, 1024, ++s->flag_epoch);
-  int rc = gm_launch_lookup(dv, D.d_reads, n, read_len, read_words, D.d_surv, D.d_surv_cnt, D.scap, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, d_stats, q, D.d_surv_seg);
+  int fused = 0;
+  int rc = launch_lookup(s, D, dv, n, read_len, read_words, W, d_stats, &fused);
   s->front_epoch[k] = s->flag_epoch; s->front_flag_grid[k] = rc ? 0 : gm_lookup_start_flag_grid();
   gm_lookup_set_start_flags(nullptr, 0, 0);
   if (rc) return rc;
   GM_HIP(hipEventRecord(s->pev[k][1], q));
-  rc = launch_prune_anchors(s, D, dv, n, read_len, W, d_stats);
+  rc = launch_prune_anchors(s, D, dv, n, read_len, W, d_stats, fused);
   if (rc) return rc;
   GM_HIP(hipMemcpyAsync(&s->h_pin[k], D.d_heavy_cnt, 4, hipMemcpyDeviceToHost, q));
   GM_HIP(hipEventRecord(s->pev[k][2], q));

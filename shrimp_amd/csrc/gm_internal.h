@@ -6,6 +6,7 @@ struct GmSeedHost {
   uint64_t mask = 0; int span = 0, weight = 0;
   int kbits = 0;                        // log2(number of lists): 2 * weight, or 24 with -H (ref: genome.c:1034)
   uint32_t* d_dir = nullptr; uint32_t* d_pos = nullptr; uint32_t* d_bkt = nullptr;
+  uint32_t* d_sdir = nullptr; uint32_t* d_spos = nullptr; uint32_t n_spos = 0;   // strip lists (gm_index_derive_strips)
   uint32_t n_pos = 0; uint64_t dir_words = 0;
   std::string text;
 };
@@ -24,6 +25,7 @@ struct GmIndexHost {
   int slab_bits = 29, n_slabs = 1;
   gm_params_t params;
   uint32_t list_cutoff = 0;
+  bool strips_ready = false;
   GmIndexDev dev_view() const;
 };
 struct gm_index : GmIndexHost {};
@@ -38,6 +40,14 @@ enum { GS_LOOKUPS = 0, GS_ENTRIES, GS_SURVIVORS, GS_ANCHORS, GS_WINDOWS, GS_VEC_
 #define GS_STRIDE 16
 #define GS_ADD(stats, slot, val) atomicAdd(&(stats)[(size_t)(blockIdx.x & (GS_STRIPES - 1)) * GS_STRIDE + (slot)], (unsigned long long)(val))
 
+// Tuning / path-forcing knobs (environment variables): read through one function so that a build can compile them out.
+#include <cstdlib>
+#ifdef GM_NO_TUNING
+static inline const char* gm_tune(const char*) { return nullptr; }
+#else
+static inline const char* gm_tune(const char* name) { return getenv(name); }
+#endif
+
 // ---- kernel launchers (one per .hip file) -----------------------------------------------------
 int gm_index_build_device(GmIndexHost* ix, hipStream_t stream);
 int gm_index_colour_genome_device(GmIndexHost* ix, hipStream_t stream);   // derives d_genome_cs from d_genome
@@ -47,9 +57,20 @@ int gm_index_from_lists_device(GmIndexHost* ix, int sn, const uint32_t* lens, co
 // survivors are listed in d_heavy_list (count in d_surv_cnt) and re-run by gm_launch_lookup_redo
 void gm_lookup_set_start_flags(uint32_t* flags, int cap, uint32_t epoch);   // pinned words the persistent K1 grid raises when its workgroups are resident
 int gm_lookup_start_flag_grid(void);
+// Optional fusion of K1b into K1 (k_lookup_v5): when `fuse` is given and the chosen kernel can apply the prune rules itself, the kept
+// keys go straight to fuse->d_surv2 / d_surv_cnt2 and *fuse->fused is set to 1 (the caller then skips gm_launch_prune).
+struct GmFusePrune { uint64_t* d_surv2; uint32_t* d_surv_cnt2; int scap2; int window_len; int e_max; int* fused; };
 int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
                      uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
-                     unsigned long long* d_stats, hipStream_t stream, uint32_t* d_surv_seg = nullptr);   // d_surv_seg[rs][S + 1]: survivors after each slab
+                     unsigned long long* d_stats, hipStream_t stream, uint32_t* d_surv_seg = nullptr,   // d_surv_seg[rs][S + 1]: survivors after each slab
+                     const GmFusePrune* fuse = nullptr);
+int gm_index_derive_strips(GmIndexHost* ix, hipStream_t stream);     // strip lists for k_lookup_v5 (gm_lookup5.hip); idempotent
+void gm_lookup5_set_start_flags(uint32_t* flags, int cap, uint32_t epoch);
+int gm_lookup5_start_flag_grid(void);
+int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words, int max_n_kmers, int NL,
+                      uint64_t* d_out, uint32_t* d_out_cnt, int out_cap, uint32_t* d_surv_cnt, int prune, uint32_t D, int e_max,
+                      uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap, unsigned long long* d_stats, hipStream_t stream,
+                      uint32_t** fb_list, uint32_t** fb_cnt, int* fb_cap_out);
 int gm_launch_lookup_redo(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
                           int n_heavy, const uint32_t* d_redo_list, const uint64_t* d_redo_off, uint64_t* d_out,
                           unsigned long long* d_stats, hipStream_t stream);
@@ -60,7 +81,8 @@ size_t gm_lookup_lds_bytes(const GmIndexDev& ix, int read_len);
 int gm_launch_prune(int n_reads, int read_len, int window_len, int e_max, int n_slabs, int slab_bits, const uint64_t* d_surv, const uint32_t* d_surv_cnt,
                     const uint32_t* d_surv_seg, int scap,
                     uint64_t* d_surv2, uint32_t* d_surv_cnt2, int scap2, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
-                    unsigned long long* d_stats, hipStream_t stream);
+                    unsigned long long* d_stats, hipStream_t stream,
+                    const uint32_t* d_rs_list = nullptr, const uint32_t* d_rs_cnt = nullptr, int rs_cap = 0);   // list mode: only the listed read-strands
 
 // K2 anchors + candidate windows: one wave per read-strand (LDS tier) + heavy tier on global arrays
 int gm_launch_anchors(const GmIndexDev& ix, const GmScoreDev& sc, int n_reads, int read_len, int window_len,

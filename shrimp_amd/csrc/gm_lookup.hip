@@ -1068,7 +1068,8 @@ static bool k4_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   const int fb_cap = 4096;
   int bin_cap = 4096; if (const char* e = getenv("GM_K4_BINCAP")) { const int v = std::max(16, std::min(1 << 20, atoi(e))); bin_cap = 16; while (bin_cap < v) bin_cap <<= 1; }
   const int code_words = (read_len + 3) / 4;
-  const size_t lds = (size_t)(((((code_words + 3) & ~3) + 4 * NL + NL + 1 + SC + (wcap + 1) / 2 + 3) & ~3) + (1 << (tab_bits - 4)) + 4) * 4;
+  size_t lds = (size_t)(((((code_words + 3) & ~3) + 4 * NL + NL + 1 + SC + (wcap + 1) / 2 + 3) & ~3) + (1 << (tab_bits - 4)) + 4) * 4;
+  if (const char* e = gm_tune("GM_K4_LDS_PAD")) lds += (size_t)std::max(0, atoi(e));   // experiment: what the LDS footprint does to the co-residency with pass 1 / pass 2
   if (lds > 160 * 1024 - 64) return false;
   int wgs_per_cu = 1; if (const char* e = getenv("GM_K4_WGS")) wgs_per_cu = std::max(1, std::min(8, atoi(e)));
   if (!K.cus) { if (hipDeviceGetAttribute(&K.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || K.cus < 1) K.cus = 256; }
@@ -1109,11 +1110,12 @@ extern "C" const char* gm_last_lookup_kernel(void) { return g_k1_name; }   // wh
 
 int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
                      uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
-                     unsigned long long* d_stats, hipStream_t stream, uint32_t* d_surv_seg) {
+                     unsigned long long* d_stats, hipStream_t stream, uint32_t* d_surv_seg, const GmFusePrune* fuse) {
   int max_n_kmers, NL, bm_words; size_t lds;
   k1_geometry(ix, read_len, &max_n_kmers, &NL, &bm_words, &lds);
   if (lds > 160 * 1024) { gm_set_error("lookup kernel needs %zu bytes of LDS (read_len %d, slab_bits %d)", lds, read_len, ix.slab_bits); return GM_E_ARG; }
   GM_HIP(hipMemsetAsync(d_heavy_cnt, 0, 4, stream));
+  if (fuse && fuse->fused) *fuse->fused = 0;
   if (NL == 0 || n_reads == 0) { GM_HIP(hipMemsetAsync(d_surv_cnt, 0, (size_t)n_reads * 2 * 4, stream)); return GM_OK; }
   static size_t configured = 0;
   if (lds > 48 * 1024 && lds > configured) {
@@ -1121,6 +1123,42 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     configured = lds;
   }
   const bool bkt = ix.seed[0].bkt != nullptr && ix.n_slabs == 1 && NL <= 512 && !getenv("GM_NO_BUCKETS");
+  if (!bkt && NL < 65536 && !getenv("GM_K1_V2") && !getenv("GM_K1_V3") && !getenv("GM_K1_V4") && getenv("GM_K1_V5")) {
+    // k_lookup_v5 (gm_lookup5.hip): wave-per-list streaming, candidates and the exact rule in LDS, K1b's prune rules fused when the caller allows.
+    // Opt-in (GM_K1_V5=1): measured in round 2 it needs 24 % fewer VALU instructions than v4 + K1b but 152 KB of LDS, which keeps pass 1 / pass 2 of
+    // the other stream off its CUs -- end to end it is slower than v4 inside the two-stream pipeline.
+    const bool want_fuse = fuse && fuse->scap2 > 0;
+    const uint32_t D = (uint32_t)std::max(want_fuse ? fuse->window_len : 0, read_len);
+    const int e_max = want_fuse ? std::min(fuse->e_max, read_len) : -1;
+    uint32_t *fbl = nullptr, *fbc = nullptr; int fbcap = 0;
+    gm_lookup5_set_start_flags(g_k4_flags, g_k4_flag_cap, g_k4_epoch);
+    bool fused = want_fuse;
+    int r = gm_lookup5_launch(ix, d_reads, n_reads, read_len, read_words, max_n_kmers, NL, fused ? fuse->d_surv2 : d_surv, fused ? fuse->d_surv_cnt2 : d_surv_cnt,
+                              fused ? fuse->scap2 : scap, d_surv_cnt, fused ? 1 : 0, D, e_max, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, stream, &fbl, &fbc, &fbcap);
+    if (r == 0 && fused) {   // the prune rules do not fit region-sized bins (very long reads): v5 without them, K1b afterwards
+      fused = false;
+      r = gm_lookup5_launch(ix, d_reads, n_reads, read_len, read_words, max_n_kmers, NL, d_surv, d_surv_cnt, scap, d_surv_cnt, 0, D, -1,
+                            d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, stream, &fbl, &fbc, &fbcap);
+    }
+    g_k4_flag_grid = gm_lookup5_start_flag_grid();
+    gm_lookup5_set_start_flags(nullptr, 0, 0);
+    if (r < 0) return r;
+    if (r == 1) {
+      g_k1_name = "k_lookup_v5";
+      // read-strands whose candidates did not fit the LDS tiers: the slab-sweep kernel in list mode (blocks beyond the list's end return at once), then K1b for those
+      hipLaunchKernelGGL(k_lookup<false>, dim3(fbcap), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+                         max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
+                         (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)fbl, (const uint32_t*)fbc, d_stats, 0, d_surv_seg);
+      GM_HIP(hipGetLastError());
+      if (fused) {
+        const int rc = gm_launch_prune(n_reads, read_len, fuse->window_len, fuse->e_max, ix.n_slabs, ix.slab_bits, d_surv, d_surv_cnt, d_surv_seg, scap,
+                                       fuse->d_surv2, fuse->d_surv_cnt2, fuse->scap2, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, stream, fbl, fbc, fbcap);
+        if (rc) return rc;
+        if (fuse->fused) *fuse->fused = 1;
+      }
+      return GM_OK;
+    }
+  }
   if (bkt) {
     g_k1_name = "k_lookup_bkt";
     const size_t lds_b = (size_t)((((read_len + 3) / 4) + 3) & ~3) * 4 + (size_t)bm_words * 4;

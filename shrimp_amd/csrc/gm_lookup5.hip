@@ -1,0 +1,655 @@
+// gm_lookup5.hip -- K1 v5: spaced-seed lookup + exact region filter + exact prune in ONE kernel (gfx950 only).
+//
+// Same contract as gm_lookup.hip (which keeps the bucket / slab-sweep / lane-per-list kernels and documents the
+// reference lines replaced: read_get_mapidxs, read_get_region_counts, advance_index_in_genomemap,
+// ref: gmapper/mapping.c:37-70,459-542,646-805) plus the exact prune of gm_prune.hip, for read-strands with many
+// list entries (100 bp reads on a 3 Gbp genome: 251 lists of ~179 entries).  What is different from k_lookup_v4:
+//
+//  * One WAVE streams one list at a time: the list descriptor (pointer, length, y/seed) is wave-uniform (SGPRs),
+//    lane l takes W = ceil(n / 64) consecutive entries of a chunk of n <= 256, read with one dwordx4.  No window
+//    map, no prefix over the lists, no per-lane descriptor look-up.
+//  * Pre-count in two 1-bit tables: seen[2^(lsw+5)] (region folded onto its low bits) and, an eighth of its size,
+//    twice[]: the first mark of a counter sets its seen bit, every later one sets the twice bit.  Pass A marks,
+//    pass B streams the lists again and keeps the entries whose twice bit is set -- a superset of the entries
+//    whose region reaches the reference's count of 2 (a region's second mark always finds the seen bit set).
+//  * The overlap strip (an entry in the first region_overlap bases of a region also counts for the region before,
+//    ref: mapping.c:521-533,733-742) is not tested per entry: the index carries, per list, the few strip entries
+//    again as a second short list (sdir / spos, derived on the device from dir / pos, 2.4 % of the entries), and
+//    two small dense loops mark / test region - 1 for exactly those.
+//  * The candidates (~13 % of the entries) stay in LDS -- pass B needs only twice[], so they are written over the
+//    dead seen[] table -- and are resolved there: an open-addressing table keyed by region holds the exact mark
+//    count (the reference's rule; exact because every entry of a region with count >= 2 is a candidate) and, per
+//    region, the number and the min / max offset of the candidates inside it, from which the prune rules of
+//    gm_prune.hip are evaluated with region-sized bins.  Judging the prune on candidates instead of survivors
+//    only keeps more (both rules are monotone: more neighbours => keep), which is still exact.
+//  * 6 workgroup barriers per read-strand (v4: ~25), no candidate scratch in global memory.
+//
+// Read-strands whose candidates do not fit (repeats) are redone by k_lookup<false> in list mode + k_prune in
+// list mode (gm_lookup.hip / gm_prune.hip).
+#include <algorithm>
+#include <mutex>
+#include "gm_common.h"
+#include "gm_internal.h"
+#include <rocprim/device/device_scan.hpp>
+
+typedef uint32_t k5_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef __attribute__((address_space(3))) uint32_t k5_lds_u32;
+// LDS word at an absolute LDS byte address (the tables of k_lookup_v5 start at the workgroup's LDS base, which the kernel checks to be 0:
+// table offsets are then OR-ed, not added, into the address)
+#define K5_LDS(off) ((k5_lds_u32*)(uintptr_t)(uint32_t)(off))
+#define K5_LDS_OR(off, m) __hip_atomic_fetch_or(K5_LDS(off), (m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+
+#define K5_Q 6            // list chunks in flight per wave
+enum { C_NLISTS = 0, C_NCAND, C_OVERFLOW, C_NMEMB, C_NKEEP, C_WUP = 8, C_WDN = 24, C_PFX = 40, C_WORDS = 60 };   // C_WUP / C_WDN: candidates per wave segment (from the bottom / from the top); C_PFX: exclusive prefix of their sums (17 words)
+
+// Diagnostic build (-DK5_STAMPS): thread 0 of every workgroup adds the cycles between the phase boundaries of each read-strand to k5_stamps[]
+// (setup, pass A, pass B, region table, rules + output, clears); gm_debug_k5_stamps() reads and resets them.  No stamp executes in the normal build.
+#ifdef K5_STAMPS
+__device__ unsigned long long k5_stamps[8];
+#define K5_STAMP(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&k5_stamps[i], t_ - t_prev); t_prev = t_; } } while (0)
+extern "C" int gm_debug_k5_stamps(unsigned long long* out) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(k5_stamps), sizeof z) != hipSuccess) return GM_E_NODEVICE;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(k5_stamps), z, sizeof z) != hipSuccess) return GM_E_NODEVICE;
+  return GM_OK;
+}
+#else
+#define K5_STAMP(i) do { } while (0)
+#endif
+
+struct K5Args {
+  const uint32_t* reads; int n_reads, read_len, read_words, max_n_kmers, NL;
+  int lsw, ltw;             // log2(words) of seen[] and twice[]
+  int cand_cap, hbits;      // candidate records and log2(slots of the region table), both inside the seen[] area
+  int cand_limit;
+  uint64_t* out; uint32_t* out_cnt; int out_cap; uint32_t* surv_cnt;
+  int prune; uint32_t D; int e_max;
+  uint32_t* heavy_list; uint32_t* heavy_cnt; int heavy_cap;
+  unsigned long long* stats;
+  uint32_t* fb_list; uint32_t* fb_cnt; int fb_cap;
+  uint32_t* start_flags; uint32_t start_epoch;
+};
+
+// lane * W for a wave-uniform W in 1..4 without the quarter-rate 32-bit multiply
+__device__ __forceinline__ uint32_t k5_lane_times(int lane, uint32_t W) {
+  const uint32_t sh = W >> 2 ? 2u : (W >> 1), add3 = W == 3u ? 0xFFFFFFFFu : 0u;
+  return ((uint32_t)lane << sh) + ((uint32_t)lane & add3);
+}
+
+// Region table over the candidates (exact stage): open addressing, three parallel arrays of 2^hbits words.
+//   htag[h] = (region + 1) << 8 | flags     A: marked once, B: marked twice or more (the reference's count >= 2), C / D / E: 1 / 2 / >= 3 candidates inside
+//   hmin[h] = 0x10000 - smallest offset of a candidate inside the region (0: none), hmax[h] = largest offset + 1 (0: none)
+// Only single-shot atomics (one CAS to claim a slot, then OR / MAX): a read that really maps puts ~250 candidates into one region, and a
+// compare-and-swap retry loop on that slot serialises them (measured: 19 k cycles per read-strand for the insert phase alone).
+#define K5_FA 1u
+#define K5_FB 2u
+#define K5_FC 4u
+#define K5_FD 8u
+#define K5_FE 16u
+__device__ __forceinline__ uint32_t k5_hash(uint32_t r1, int hshift) { return (r1 * 2654435761u) >> hshift; }
+__device__ __forceinline__ uint32_t k5_step(uint32_t r1) { return ((r1 * 0x9E3779B1u) >> 15) | 1u; }      // odd: the probe sequence h, h + step, ... visits every slot (double hashing: no primary clustering)
+
+// returns the slot of region r (claiming one if needed) after OR-ing `first` into a fresh slot / `again` bookkeeping into an existing one; 0xFFFFFFFF: table full
+__device__ __forceinline__ uint32_t k5_insert(uint32_t* htag, uint32_t hmask, int hshift, uint32_t r, bool own) {
+  const uint32_t r1 = r + 1u, t = r1 << 8, first = own ? (K5_FA | K5_FC) : K5_FA;
+  uint32_t h = k5_hash(r1, hshift); const uint32_t step = k5_step(r1);
+  for (uint32_t n = 0; n <= hmask; n++) {
+    const uint32_t prev = atomicCAS(&htag[h], 0u, t | first);
+    if (prev == 0u) return h;
+    if ((prev >> 8) == r1) {
+      uint32_t old = prev;
+      if ((old & first) != first) old = atomicOr(&htag[h], first);     // (the claimer's flags are there already)
+      uint32_t need = ((old & K5_FA) ? K5_FB : 0u) | ((own && (old & K5_FC)) ? K5_FD : 0u) | ((own && (old & K5_FD)) ? K5_FE : 0u);
+      need &= ~old;
+      if (need) {
+        const uint32_t old2 = atomicOr(&htag[h], need);
+        if (own && (need & K5_FD) && (old2 & K5_FD) && !(old2 & K5_FE)) atomicOr(&htag[h], K5_FE);
+      }
+      return h;
+    }
+    h = (h + step) & hmask;
+  }
+  return 0xFFFFFFFFu;
+}
+// slot of region r, or 0xFFFFFFFF
+__device__ __forceinline__ uint32_t k5_find(const uint32_t* htag, uint32_t hmask, int hshift, uint32_t r, uint32_t& tagword) {
+  const uint32_t r1 = r + 1u;
+  uint32_t h = k5_hash(r1, hshift); const uint32_t step = k5_step(r1);
+  for (uint32_t n = 0; n <= hmask; n++) {
+    const uint32_t cur = htag[h];
+    if (cur == 0u) break;
+    if ((cur >> 8) == r1) { tagword = cur; return h; }
+    h = (h + step) & hmask;
+  }
+  tagword = 0u;
+  return 0xFFFFFFFFu;
+}
+
+__global__ void __launch_bounds__(1024)
+k_lookup_v5(GmIndexDev ix, K5Args a) {
+  if (a.start_flags && threadIdx.x == 0) __hip_atomic_store(&a.start_flags[blockIdx.x], a.start_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __builtin_amdgcn_s_setprio(3);
+  extern __shared__ __align__(16) uint32_t smem[];
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & (GM_WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
+  const int S = ix.n_slabs, rb = ix.region_bits, lsw = a.lsw;
+  const uint32_t rmask = (1u << rb) - 1u, ovl = (uint32_t)ix.region_overlap;
+  const uint32_t wmask = (1u << lsw) - 1u, tmask = (1u << a.ltw) - 1u;
+  // LDS: seen (later: candidates | region table) | twice | rec[NL] (4 words) | srec[NL] (4 words) | codes | ctrl
+  // Byte offsets into the tables come straight from the position: seen word of p at (p >> (rb - 2)) & smask4, its twice word at
+  // ((p >> (rb - 2)) & tmask4) | swb (twice[] starts at swb = the size of seen[], a power of two above tmask4), bit (p >> (rb + lsw)) & 31.
+  if ((uint32_t)(uintptr_t)(k5_lds_u32*)smem != 0u) __builtin_trap();      // no static LDS in this kernel: the dynamic segment starts at 0
+  uint32_t* seen = smem;
+  uint32_t* twice = smem + (1u << lsw);
+  // after pass A the seen[] area is re-used: htag | hmin | hmax (2^hbits = 2^(lsw - 2) words each: three quarters of it) | candidate positions
+  // (cand_cap words) | candidate y / seed (u16); cand_cap = the last quarter / 6 bytes, cut into one segment per wave
+  uint32_t* htag = seen;
+  uint32_t* hmin = htag + (1u << a.hbits);
+  uint32_t* hmax = hmin + (1u << a.hbits);
+  uint32_t* candp = hmax + (1u << a.hbits);
+  uint16_t* candy = (uint16_t*)(candp + a.cand_cap);
+  uint32_t* rec = twice + (1u << a.ltw);
+  uint32_t* srec = rec + 4 * a.NL;
+  uint8_t* codes = (uint8_t*)(srec + 4 * a.NL);
+  uint32_t* ctrl = (uint32_t*)(codes + ((a.read_len + 15) & ~15));
+  const uint32_t smask4 = wmask << 2, tmask4 = tmask << 2, swb = 4u << lsw;
+  const int sh_a = rb - 2, sh_b = rb + lsw;
+  const uint32_t hmask = (1u << a.hbits) - 1u; const int hshift = 32 - a.hbits;
+  const int hclr_q = (int)(3u << a.hbits) >> 2;                         // uint4 words of the region table (cleared during pass B)
+  const int tab_q = (int)(((1u << a.ltw) + (1u << lsw)) >> 2);             // uint4 words of twice + seen
+  const uint32_t* __restrict__ pos0 = ix.seed[0].pos;
+  const uint32_t* __restrict__ spos0 = ix.seed[0].spos;
+  unsigned long long my_lookups = 0, my_entries = 0;
+
+  { uint4* t4 = (uint4*)smem; for (int w = tid; w < tab_q; w += nthr) t4[w] = make_uint4(0, 0, 0, 0); }
+  if (tid < C_WORDS) ctrl[tid] = 0;                            // thread 0 re-zeroes them at the end of every read-strand
+
+  auto mark = [&](const uint32_t p) {                          // one mark of region p >> rb (strip loop; the main loop has its own batched form)
+    const uint32_t av = p >> sh_a, m = 1u << ((p >> sh_b) & 31u);
+    const uint32_t old = K5_LDS_OR(av & smask4, m);
+    if (old & m) K5_LDS_OR((av & tmask4) | swb, m);
+  };
+  auto has2 = [&](const uint32_t p) -> bool { return (*K5_LDS(((p >> sh_a) & tmask4) | swb) >> ((p >> sh_b) & 31u)) & 1u; };
+
+#ifdef K5_STAMPS
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
+  for (int rs = blockIdx.x; rs < 2 * a.n_reads; rs += gridDim.x) {
+    const int rd = rs >> 1, st = rs & 1;
+    const uint32_t* rw = a.reads + (size_t)rd * a.read_words;
+    for (int i = tid; i < a.read_len; i += nthr) codes[i] = (uint8_t)gm_read_code(rw, a.read_len, st, ix.colour, i);
+    __syncthreads();                                           // also: the tables and the control words are clear
+    // ---- map indexes, list bounds, strip-list bounds (ref: mapping.c:53-66, KMER_TO_MAPIDX gmapper.h:349-368) ----
+    for (int off = tid; off < a.NL; off += nthr) {
+      const int sn = off / a.max_n_kmers, i = off - sn * a.max_n_kmers;
+      const int span = ix.seed[sn].span;
+      if (i < ix.colour || i + span > a.read_len) continue;
+      const uint32_t mapidx = gm_mapidx(ix, ix.seed[sn].mask, span, codes + i);
+      const uint32_t* dir = ix.seed[sn].dir + (size_t)mapidx * (uint32_t)S;
+      my_lookups++;
+      const uint32_t b = dir[0], e = dir[S];
+      if (e == b || e - b > ix.list_cutoff) continue;          // ref: mapping.c:497 (longer lists are skipped, not deleted)
+      const uint32_t sb = ix.seed[sn].sdir[mapidx], se = ix.seed[sn].sdir[mapidx + 1];
+      my_entries += (e - b);
+      const uint32_t j = atomicAdd(&ctrl[C_NLISTS], 1u);
+      const uint64_t ptr = (uint64_t)((ix.seed[sn].pos + b) - pos0), sptr = (uint64_t)((ix.seed[sn].spos + sb) - spos0);
+      *(uint4*)&rec[4 * j] = make_uint4((uint32_t)ptr, (uint32_t)(ptr >> 32), e - b, ((uint32_t)i << 16) | (uint32_t)sn);
+      *(uint4*)&srec[4 * j] = make_uint4((uint32_t)sptr, (uint32_t)(sptr >> 32), se - sb, 0u);
+    }
+    __syncthreads();
+    K5_STAMP(0);
+    const int nl = (int)ctrl[C_NLISTS];
+
+    // One chunk of a list: n <= 256 entries from src, W = ceil(n / 64) per lane.  Wave-uniform (SGPRs).
+    struct Step { uint32_t n, ysn; const uint32_t* src; };
+    int gj = wv; uint32_t gc = 0;                              // generator: list, entries of it already handed out
+    uint4 gr = make_uint4(0, 0, 0, 0);                         // descriptor of list gj, read one step ahead of its use (an LDS round trip off the critical path)
+    auto gen_reset = [&]() { gj = wv; gc = 0; if (gj < nl) gr = *(const uint4*)&rec[4 * gj]; };
+    auto gen = [&](Step& s) {                                  // (every list in rec[] has at least one entry: no loop)
+      s.n = 0; s.ysn = 0; s.src = pos0;
+      if (gj < nl) {
+        const uint32_t len = __builtin_amdgcn_readfirstlane(gr.z);
+        const uint64_t o = ((uint64_t)__builtin_amdgcn_readfirstlane(gr.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(gr.x);
+        s.n = min(256u, len - gc); s.src = pos0 + o + gc; s.ysn = __builtin_amdgcn_readfirstlane(gr.w);
+        gc += 256u;
+        if (gc >= len) { gj += nwv; gc = 0; if (gj < nl) gr = *(const uint4*)&rec[4 * gj]; }
+      }
+    };
+    // EVERY step issues exactly one dwordx4 per lane -- lanes past the chunk re-read its last entry, an exhausted generator reads the first
+    // words of pos[] -- so that the loads form one straight pipeline of depth K5_Q.  The last lane may read up to 3 words past the chunk
+    // (next list / tail pad).  (Hand-issued inline-asm loads with a manual s_waitcnt vmcnt(K5_Q - 1) returned stale registers now and then on
+    // gfx950 -- tools/probes/vmcnt_order.hip -- so the loads are left to the compiler, which places the counted waits itself.)
+    auto issue = [&](const Step& s, k5_u32x4& v) {
+      const uint32_t W = (s.n + 63u) >> 6, x = k5_lane_times(lane, W), lim = s.n ? s.n - 1u : 0u;
+      const uint32_t e = (x < lim ? x : lim) << 2;
+#ifdef K5_ASM_LOADS
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(v) : "v"(e), "s"(s.src) : "memory");
+#else
+      v = *(const k5_u32x4*)((const char*)s.src + e);
+#endif
+    };
+#ifndef K5_ASM_LOADS
+// (compiler-tracked loads: the empty statement only pins the four words to one register tuple at the point of use, which keeps the register
+// allocator from copying them out of a shared temporary right behind the load -- and waiting for vmcnt(0) there)
+#define K5_WAIT_OLDEST(v) asm volatile("" : "+v"(v))
+#elif defined(K5_DEBUG_WAIT0)
+#define K5_WAIT_OLDEST(v) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory")
+#else
+#define K5_WAIT_OLDEST(v) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(K5_Q - 1) : "memory")
+#endif
+#ifdef K5_TWICE_BRANCH
+#define K5_TWICE(av, t) do { if (t) K5_LDS_OR(((av) & tmask4) | swb, (t)); } while (0)
+#else
+#define K5_TWICE(av, t) K5_LDS_OR(((av) & tmask4) | swb, (t))
+#endif
+
+    // ================= pass A: marks =================
+    {
+      // strip entries mark the region before theirs (region 0's strip entries are not in the strip lists)
+      for (int j0 = tid >> 2; j0 < nl; j0 += nthr >> 2) {
+        const uint4 sr = *(const uint4*)&srec[4 * j0];
+        const uint32_t* sp = spos0 + (((uint64_t)sr.y << 32) | sr.x);
+        for (uint32_t e = (uint32_t)(tid & 3) * 4u; e < sr.z; e += 16u) {
+          const k5_u32x4 v = *(const k5_u32x4*)(sp + e);
+          const uint32_t nv = min(4u, sr.z - e);
+          mark(v.x - (1u << rb));
+          if (nv > 1) mark(v.y - (1u << rb));
+          if (nv > 2) mark(v.z - (1u << rb));
+          if (nv > 3) mark(v.w - (1u << rb));
+        }
+      }
+      // (the first K5_Q loads go out behind the strip loop, so that the compiler's counter model sees the same six pending loads on both
+      // ways into the main loop and waits with vmcnt(K5_Q - 1), not vmcnt(0))
+      gen_reset();
+      Step sd[K5_Q]; k5_u32x4 sv[K5_Q];
+#pragma unroll
+      for (int q = 0; q < K5_Q; q++) { gen(sd[q]); issue(sd[q], sv[q]); }
+      bool more = true;
+      while (more) {
+#pragma unroll
+        for (int q = 0; q < K5_Q; q++) {
+          if (!sd[q].n) { more = false; break; }
+          K5_WAIT_OLDEST(sv[q]);
+          // Marks only have to cover every real entry (pass B and the region table apply the exact rule): the last active lane also
+          // marks the up-to-3 words it read past the chunk.
+          const uint32_t W = (sd[q].n + 63u) >> 6;
+          if (k5_lane_times(lane, W) < sd[q].n) {
+            // all seen[] updates of the step first, then the twice[] updates (old & m is 0 or m: the update is unconditional, a no-op for
+            // first marks -- cheaper than a branch per entry): one LDS round trip per step, not per entry
+            const uint32_t a0 = sv[q].x >> sh_a, a1 = sv[q].y >> sh_a, a2 = sv[q].z >> sh_a, a3 = sv[q].w >> sh_a;
+            const uint32_t m0 = 1u << ((sv[q].x >> sh_b) & 31u), m1 = 1u << ((sv[q].y >> sh_b) & 31u), m2 = 1u << ((sv[q].z >> sh_b) & 31u), m3 = 1u << ((sv[q].w >> sh_b) & 31u);
+            uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+            o0 = K5_LDS_OR(a0 & smask4, m0);
+            if (W > 1) o1 = K5_LDS_OR(a1 & smask4, m1);
+            if (W > 2) o2 = K5_LDS_OR(a2 & smask4, m2);
+            if (W > 3) o3 = K5_LDS_OR(a3 & smask4, m3);
+            K5_TWICE(a0, o0 & m0);
+            if (W > 1) K5_TWICE(a1, o1 & m1);
+            if (W > 2) K5_TWICE(a2, o2 & m2);
+            if (W > 3) K5_TWICE(a3, o3 & m3);
+          }
+          gen(sd[q]); issue(sd[q], sv[q]);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the dummy loads of the exhausted generator
+    }
+    __syncthreads();
+    K5_STAMP(1);
+    // ================= pass B: candidates (into the dead seen[] area) =================
+    { uint4* h4 = (uint4*)htag; for (int w = tid; w < hclr_q; w += nthr) h4[w] = make_uint4(0, 0, 0, 0); }
+    {
+      // Candidates go to per-wave segments of the candidate arrays (seg words each): the main loop fills its wave's segment from the bottom with
+      // a wave-uniform counter (no atomic, no LDS round trip per step), the strip loop below -- whose threads are not wave-uniform -- from the top.
+      // a strip entry whose own region stays below 2 is a candidate when the region before reaches 2
+      const uint32_t seg = (uint32_t)a.cand_cap / (uint32_t)nwv, cbase = (uint32_t)wv * seg;
+      for (int j0 = tid >> 2; j0 < nl; j0 += nthr >> 2) {
+        const uint4 sr = *(const uint4*)&srec[4 * j0];
+        const uint32_t* sp = spos0 + (((uint64_t)sr.y << 32) | sr.x);
+        const uint32_t ysn = rec[4 * j0 + 3];
+        for (uint32_t e = (uint32_t)(tid & 3) * 4u; e < sr.z; e += 16u) {
+          const k5_u32x4 v = *(const k5_u32x4*)(sp + e);
+          const uint32_t nv = min(4u, sr.z - e);               // >= 1
+          // (entry 0 is tested unconditionally: a load whose result is only used under a condition keeps the compiler's counter model
+          // "pending" into the main loop below, which then waits for vmcnt(0) at every step)
+          const bool c0 = !has2(v.x) && has2(v.x - (1u << rb));
+          const bool c1 = nv > 1 && !has2(v.y) && has2(v.y - (1u << rb));
+          const bool c2 = nv > 2 && !has2(v.z) && has2(v.z - (1u << rb));
+          const bool c3 = nv > 3 && !has2(v.w) && has2(v.w - (1u << rb));
+          if (c0 | c1 | c2 | c3) {
+            const uint32_t cn = (uint32_t)c0 + (uint32_t)c1 + (uint32_t)c2 + (uint32_t)c3;
+            const uint32_t d = atomicAdd(&ctrl[C_WDN + wv], cn);
+            if (d + cn <= seg) {
+              uint32_t idx = cbase + seg - 1u - d;
+              const uint16_t y16 = (uint16_t)(((ysn >> 12) & 0xFFF0u) | (ysn & 0xFu));
+              if (c0) { candp[idx] = v.x; candy[idx--] = y16; }
+              if (c1) { candp[idx] = v.y; candy[idx--] = y16; }
+              if (c2) { candp[idx] = v.z; candy[idx--] = y16; }
+              if (c3) { candp[idx] = v.w; candy[idx--] = y16; }
+            }
+          }
+        }
+      }
+      const uint32_t wdn = __builtin_amdgcn_readfirstlane(ctrl[C_WDN + wv]);     // this wave's strip candidates are all in (same wave, program order)
+      const uint32_t wlim = wdn <= seg ? seg - wdn : 0u;
+      uint32_t wup = 0;
+      gen_reset();
+      Step sd[K5_Q]; k5_u32x4 sv[K5_Q];
+#pragma unroll
+      for (int q = 0; q < K5_Q; q++) { gen(sd[q]); issue(sd[q], sv[q]); }
+      bool more = true;
+      while (more) {
+#pragma unroll
+        for (int q = 0; q < K5_Q; q++) {
+          const Step& s = sd[q];
+          if (!s.n) { more = false; break; }
+          K5_WAIT_OLDEST(sv[q]);
+          const uint32_t W = (s.n + 63u) >> 6;
+          const uint32_t e0 = k5_lane_times(lane, W);
+          bool h0 = false, h1 = false, h2 = false, h3 = false;
+          if (e0 < s.n) {
+            const uint32_t nv = s.n - e0;                      // >= 1; entries of this lane: min(W, nv)
+            uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            t0 = *K5_LDS(((sv[q].x >> sh_a) & tmask4) | swb);
+            if (W > 1) t1 = *K5_LDS(((sv[q].y >> sh_a) & tmask4) | swb);
+            if (W > 2) t2 = *K5_LDS(((sv[q].z >> sh_a) & tmask4) | swb);
+            if (W > 3) t3 = *K5_LDS(((sv[q].w >> sh_a) & tmask4) | swb);
+            h0 = (t0 >> ((sv[q].x >> sh_b) & 31u)) & 1u;
+            h1 = nv > 1 && ((t1 >> ((sv[q].y >> sh_b) & 31u)) & 1u);
+            h2 = nv > 2 && ((t2 >> ((sv[q].z >> sh_b) & 31u)) & 1u);
+            h3 = nv > 3 && ((t3 >> ((sv[q].w >> sh_b) & 31u)) & 1u);
+          }
+          const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1), b2 = __ballot(h2), b3 = __ballot(h3);
+          const uint32_t c0 = (uint32_t)__popcll(b0), c1 = (uint32_t)__popcll(b1), c2 = (uint32_t)__popcll(b2), c3 = (uint32_t)__popcll(b3);
+          const uint32_t tot = c0 + c1 + c2 + c3;
+          if (tot) {
+            if (wup + tot <= wlim) {
+              const unsigned long long lt = (1ull << lane) - 1ull;
+              const uint16_t y16 = (uint16_t)(((s.ysn >> 12) & 0xFFF0u) | (s.ysn & 0xFu));
+              uint32_t base = cbase + wup;
+              if (h0) { const uint32_t ci = base + (uint32_t)__popcll(b0 & lt); candp[ci] = sv[q].x; candy[ci] = y16; }
+              base += c0;
+              if (h1) { const uint32_t ci = base + (uint32_t)__popcll(b1 & lt); candp[ci] = sv[q].y; candy[ci] = y16; }
+              base += c1;
+              if (h2) { const uint32_t ci = base + (uint32_t)__popcll(b2 & lt); candp[ci] = sv[q].z; candy[ci] = y16; }
+              base += c2;
+              if (h3) { const uint32_t ci = base + (uint32_t)__popcll(b3 & lt); candp[ci] = sv[q].w; candy[ci] = y16; }
+            }
+            wup += tot;                                        // beyond wlim: nothing is written, the read-strand falls back
+          }
+          gen(sd[q]); issue(sd[q], sv[q]);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        const bool over = wup > wlim || wdn > seg;
+        ctrl[C_WUP + wv] = over ? 0u : wup;
+        if (over) { ctrl[C_WDN + wv] = 0u; ctrl[C_OVERFLOW] = 1u; } else atomicAdd(&ctrl[C_NCAND], wup + wdn);
+      }
+    }
+    __syncthreads();
+    K5_STAMP(2);
+    const uint32_t nc = ctrl[C_NCAND];
+    bool fallback = nc > (uint32_t)a.cand_limit || ctrl[C_OVERFLOW] != 0u;
+    const uint32_t seg = (uint32_t)a.cand_cap / (uint32_t)nwv;
+    // dense candidate index d (0 .. nc) -> slot in the per-wave segments: segment = number of prefix sums <= d, then bottom part first, top part after
+    auto slot_of = [&](const uint32_t d) -> uint32_t {         // (the 16 prefix words in four 16-byte reads: one LDS round trip, not sixteen)
+      const uint4 p0 = *(const uint4*)&ctrl[C_PFX], p1 = *(const uint4*)&ctrl[C_PFX + 4], p2 = *(const uint4*)&ctrl[C_PFX + 8], p3 = *(const uint4*)&ctrl[C_PFX + 12];
+      const uint32_t sg = (uint32_t)(d >= p0.y) + (uint32_t)(d >= p0.z) + (uint32_t)(d >= p0.w) + (uint32_t)(d >= p1.x) + (uint32_t)(d >= p1.y) + (uint32_t)(d >= p1.z) +
+                          (uint32_t)(d >= p1.w) + (uint32_t)(d >= p2.x) + (uint32_t)(d >= p2.y) + (uint32_t)(d >= p2.z) + (uint32_t)(d >= p2.w) + (uint32_t)(d >= p3.x) +
+                          (uint32_t)(d >= p3.y) + (uint32_t)(d >= p3.z) + (uint32_t)(d >= p3.w);
+      const uint32_t j = d - ctrl[C_PFX + sg], up = ctrl[C_WUP + sg];
+      return sg * seg + (j < up ? j : seg - 1u - (j - up));
+    };
+    // ================= exact stage 1: region table over the candidates =================
+    if (tid == 0) { uint32_t run = 0; for (int k = 0; k < 16; k++) { ctrl[C_PFX + k] = k < nwv ? run : 0xFFFFFFFFu; if (k < nwv) run += ctrl[C_WUP + k] + ctrl[C_WDN + k]; } }
+    __syncthreads();
+    if (!fallback) {
+      for (uint32_t d = tid; d < nc; d += nthr) {
+        const uint32_t i = slot_of(d);
+        const uint32_t p = candp[i], r = p >> rb, off = p & rmask;
+        const uint32_t h = k5_insert(htag, hmask, hshift, r, true);
+        bool ok = h != 0xFFFFFFFFu;
+        if (ok) { atomicMax(&hmin[h], 0x10000u - off); atomicMax(&hmax[h], off + 1u); }
+        if (off < ovl && r > 0) ok = (k5_insert(htag, hmask, hshift, r - 1u, false) != 0xFFFFFFFFu) && ok;   // ref: mapping.c:521-533
+        if (!ok) ctrl[C_OVERFLOW] = 1u;
+      }
+    }
+    __syncthreads();
+    K5_STAMP(3);
+    fallback = fallback || ctrl[C_OVERFLOW] != 0u;
+    // ================= exact stage 2: the reference's rule (ref: mapping.c:733-742), prune rules (gm_prune.hip), output =================
+    if (!fallback) {
+      unsigned long long* out = (unsigned long long*)a.out + (size_t)rs * a.out_cap;
+      for (uint32_t d0 = 0; d0 < nc; d0 += nthr) {
+        const uint32_t d = d0 + tid;
+        bool memb = false, keep = false; uint32_t p = 0, i = 0;
+        if (d < nc) {
+          i = slot_of(d);
+          p = candp[i];
+          const uint32_t r = p >> rb, off = p & rmask;
+          uint32_t town, tlf = 0, trt = 0;
+          const uint32_t hown = k5_find(htag, hmask, hshift, r, town);
+          memb = (town & K5_FB) != 0u;
+          uint32_t hlf = 0xFFFFFFFFu; bool have_lf = false;
+          if (!memb && off < ovl && r > 0) { hlf = k5_find(htag, hmask, hshift, r - 1u, tlf); have_lf = true; memb = (tlf & K5_FB) != 0u; }
+          if (memb) {
+            keep = true;
+            if (a.prune) {
+              // The neighbour regions only matter near the region's ends: a candidate at least D + e_max away from both has no neighbour-region
+              // candidate within D of it or of anything within e_max of it, so both rules see the same with the neighbours left out (83 % of the
+              // members at 2 048-base regions; each look-up of an absent region is a full probe sequence, and the wave pays its longest).
+              const uint32_t edge = a.D + (uint32_t)max(a.e_max, 0);
+              uint32_t hrt = 0xFFFFFFFFu; trt = 0;
+              if (off < edge) { if (!have_lf && r > 0) hlf = k5_find(htag, hmask, hshift, r - 1u, tlf); } else tlf = 0;
+              if (off + edge >= (1u << rb)) hrt = k5_find(htag, hmask, hshift, r + 1u, trt);
+              const uint32_t co = (town & K5_FE) ? 3u : ((town & K5_FD) ? 2u : 1u);
+              const uint32_t omin = 0x10000u - hmin[hown], omax = hmax[hown] - 1u;
+              const bool cl = (tlf & K5_FC) != 0u, cr = (trt & K5_FC) != 0u;
+              const uint32_t rbase = r << rb;
+              // (1) isolation: another candidate within D (two in the region: the other one is max - min away; three or more: keep)
+              keep = co >= 3u || (co == 2u && omax - omin <= a.D);
+              uint32_t lmin = 0, lmax = 0, rmin = 0, rmax = 0;
+              if (cl) { lmin = 0x10000u - hmin[hlf]; lmax = hmax[hlf] - 1u; }
+              if (cr) { rmin = 0x10000u - hmin[hrt]; rmax = hmax[hrt] - 1u; }
+              if (!keep && cl) keep = p - (rbase - (1u << rb) + lmax) <= a.D;
+              if (!keep && cr) keep = (rbase + (1u << rb) + rmin) - p <= a.D;
+              // (2) tight cluster: everything in the three regions (which cover p -+ (D + e_max)) spans at most e_max positions
+              if (keep && a.e_max >= 0) {
+                uint32_t gmin = rbase + omin, gmax = rbase + omax;
+                if (cl) gmin = rbase - (1u << rb) + lmin;
+                if (cr) gmax = rbase + (1u << rb) + rmax;
+                if (gmax - gmin <= (uint32_t)a.e_max) keep = false;
+              }
+            }
+          }
+        }
+        const unsigned long long bm = __ballot(memb), bk = __ballot(keep);
+        if (bm) {
+          uint32_t base = 0;
+          if (lane == 0) { atomicAdd(&ctrl[C_NMEMB], (uint32_t)__popcll(bm)); if (bk) base = atomicAdd(&ctrl[C_NKEEP], (uint32_t)__popcll(bk)); }
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (keep) {
+            const uint32_t slot = base + (uint32_t)__popcll(bk & ((1ull << lane) - 1ull));
+            const uint32_t y16 = candy[i];
+            if (slot < (uint32_t)a.out_cap) out[slot] = ((unsigned long long)p << 32) | ((unsigned long long)(y16 >> 4) << 16) | (y16 & 15u);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    K5_STAMP(4);
+#ifdef K5_STAMPS
+    if (tid == 0) { atomicAdd(&k5_stamps[6], (unsigned long long)nc); if (fallback) atomicAdd(&k5_stamps[7], 1ull); }
+#endif
+    if (tid == 0) {
+      if (fallback) {                                          // candidates beyond the LDS tiers: the slab-sweep kernel redoes this read-strand
+        const uint32_t f = atomicAdd(a.fb_cnt, 1u);
+        if (f < (uint32_t)a.fb_cap) a.fb_list[f] = (uint32_t)rs; else GS_ADD(a.stats, GS_OVERFLOW_SURV, 1ull);
+      } else {
+        const uint32_t nm = ctrl[C_NMEMB], nk = ctrl[C_NKEEP];
+        a.surv_cnt[rs] = nm;
+        GS_ADD(a.stats, GS_SURVIVORS, (unsigned long long)nm);
+        if (a.prune) GS_ADD(a.stats, GS_PRUNED, (unsigned long long)(nm - nk));
+        const bool heavy = nk > (uint32_t)a.out_cap;
+        if (a.prune) a.out_cnt[rs] = heavy ? 0xFFFFFFFFu : nk;
+        if (heavy) {
+          const uint32_t hs = atomicAdd(a.heavy_cnt, 1u);
+          if (hs < (uint32_t)a.heavy_cap) a.heavy_list[hs] = (uint32_t)rs; else GS_ADD(a.stats, GS_OVERFLOW_SURV, 1ull);
+        }
+      }
+      for (int c = 0; c < C_WORDS; c++) ctrl[c] = 0;
+    }
+    { uint4* t4 = (uint4*)smem; for (int w = tid; w < tab_q; w += nthr) t4[w] = make_uint4(0, 0, 0, 0); }
+    K5_STAMP(5);
+  }
+  for (int d = GM_WAVE / 2; d > 0; d >>= 1) { my_lookups += __shfl_down(my_lookups, d); my_entries += __shfl_down(my_entries, d); }
+  if (lane == 0) { GS_ADD(a.stats, GS_LOOKUPS, my_lookups); GS_ADD(a.stats, GS_ENTRIES, my_entries); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Strip lists: for every list k of a seed, its entries in the first region_overlap bases of a region > 0, in list
+// order: spos[sdir[k] .. sdir[k + 1]).  Derived from dir / pos on the device (one flag pass, a scan over 64-entry
+// groups, one scatter pass); not part of the index files.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool k5_strip(uint32_t p, int rb, uint32_t ovl) { return (p & ((1u << rb) - 1u)) < ovl && (p >> rb) > 0u; }
+
+__global__ void __launch_bounds__(256) k_strip_count(const uint32_t* __restrict__ pos, uint32_t n_pos, int rb, uint32_t ovl, uint32_t* __restrict__ grp_cnt, uint32_t n_groups) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t stride = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (; g < n_groups; g += stride) {
+    const uint64_t i = g * 64 + lane;
+    const bool f = i < n_pos && k5_strip(pos[i], rb, ovl);
+    const unsigned long long b = __ballot(f);
+    if (lane == 0) grp_cnt[g] = (uint32_t)__popcll(b);
+  }
+}
+__global__ void __launch_bounds__(256) k_strip_scatter(const uint32_t* __restrict__ pos, uint32_t n_pos, int rb, uint32_t ovl, const uint32_t* __restrict__ grp_rank,
+                                                       uint32_t n_groups, uint32_t* __restrict__ spos) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t stride = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (; g < n_groups; g += stride) {
+    const uint64_t i = g * 64 + lane;
+    const uint32_t p = i < n_pos ? pos[i] : 0u;
+    const bool f = i < n_pos && k5_strip(p, rb, ovl);
+    const unsigned long long b = __ballot(f);
+    if (f) spos[grp_rank[g] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = p;
+  }
+}
+__global__ void __launch_bounds__(256) k_strip_dir(const uint32_t* __restrict__ dir, const uint32_t* __restrict__ pos, uint32_t n_pos, uint64_t K, int S, int rb, uint32_t ovl,
+                                                   const uint32_t* __restrict__ grp_rank, uint32_t* __restrict__ sdir) {
+  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; k <= K; k += stride) {
+    const uint32_t i = dir[k * (uint64_t)S];                  // first entry of list k (dir[K * S] = n_pos)
+    uint32_t r = grp_rank[i >> 6];
+    for (uint32_t q = i & ~63u; q < i; q++) r += k5_strip(pos[q], rb, ovl) ? 1u : 0u;
+    sdir[k] = r;
+  }
+}
+
+static std::mutex g_strip_mutex;
+int gm_index_derive_strips(GmIndexHost* ix, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_strip_mutex);
+  if (ix->strips_ready) return GM_OK;
+  const int rb = ix->params.region_bits; const uint32_t ovl = (uint32_t)ix->params.region_overlap;
+  for (int sn = 0; sn < ix->n_seeds; sn++) {
+    GmSeedHost& sd = ix->seeds[sn];
+    const uint64_t K = 1ull << sd.kbits;
+    const uint32_t n_groups = (uint32_t)(((uint64_t)sd.n_pos + 63) / 64) + 1u;      // + one empty group: rank of n_pos itself
+    uint32_t *d_cnt = nullptr, *d_rank = nullptr; void* tmp = nullptr; size_t tmp_bytes = 0;
+    GM_HIP(hipMalloc(&d_cnt, (size_t)n_groups * 4)); GM_HIP(hipMalloc(&d_rank, (size_t)n_groups * 4));
+    hipLaunchKernelGGL(k_strip_count, dim3(256 * 16), dim3(256), 0, stream, sd.d_pos, sd.n_pos, rb, ovl, d_cnt, n_groups);
+    hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, d_cnt, d_rank, 0u, (size_t)n_groups, rocprim::plus<uint32_t>(), stream);
+    if (e != hipSuccess) { gm_set_error("exclusive_scan size query: %s", hipGetErrorString(e)); return GM_E_NODEVICE; }
+    GM_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    e = rocprim::exclusive_scan(tmp, tmp_bytes, d_cnt, d_rank, 0u, (size_t)n_groups, rocprim::plus<uint32_t>(), stream);
+    if (e != hipSuccess) { gm_set_error("exclusive_scan: %s", hipGetErrorString(e)); return GM_E_NODEVICE; }
+    uint32_t total = 0;
+    GM_HIP(hipMemcpyAsync(&total, d_rank + (n_groups - 1), 4, hipMemcpyDeviceToHost, stream));
+    GM_HIP(hipStreamSynchronize(stream));
+    sd.n_spos = total;
+    GM_HIP(hipMalloc(&sd.d_spos, ((size_t)total + 64) * 4));
+    GM_HIP(hipMemsetAsync(sd.d_spos, 0xff, ((size_t)total + 64) * 4, stream));
+    GM_HIP(hipMalloc(&sd.d_sdir, (size_t)(K + 1 + 16) * 4));
+    hipLaunchKernelGGL(k_strip_scatter, dim3(256 * 16), dim3(256), 0, stream, sd.d_pos, sd.n_pos, rb, ovl, d_rank, n_groups, sd.d_spos);
+    hipLaunchKernelGGL(k_strip_dir, dim3(256 * 16), dim3(256), 0, stream, sd.d_dir, sd.d_pos, sd.n_pos, K, ix->n_slabs, rb, ovl, d_rank, sd.d_sdir);
+    GM_HIP(hipGetLastError());
+    GM_HIP(hipStreamSynchronize(stream));
+    (void)hipFree(d_cnt); (void)hipFree(d_rank); (void)hipFree(tmp);
+  }
+  ix->strips_ready = true;
+  return GM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch: returns 1 when v5 ran (0: geometry does not fit, the caller takes another kernel; < 0: error)
+// ---------------------------------------------------------------------------------------------
+struct K5Scratch { uint32_t* fb = nullptr; int fb_cap = 0; int cus = 0; };
+static K5Scratch g_k5[16];
+static uint32_t* g_k5_flags = nullptr; static uint32_t g_k5_epoch = 0; static int g_k5_flag_cap = 0, g_k5_flag_grid = 0;
+void gm_lookup5_set_start_flags(uint32_t* flags, int cap, uint32_t epoch) { g_k5_flags = flags; g_k5_flag_cap = cap; g_k5_epoch = epoch; g_k5_flag_grid = 0; }
+int gm_lookup5_start_flag_grid(void) { return g_k5_flag_grid; }
+
+int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words, int max_n_kmers, int NL,
+                      uint64_t* d_out, uint32_t* d_out_cnt, int out_cap, uint32_t* d_surv_cnt, int prune, uint32_t D, int e_max,
+                      uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap, unsigned long long* d_stats, hipStream_t stream,
+                      uint32_t** fb_list, uint32_t** fb_cnt, int* fb_cap_out) {
+  int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  if (!ix.seed[0].sdir || ix.region_bits < 9 || ix.region_bits > 16 || NL <= 0) return 0;
+  K5Scratch& K = g_k5[dev];
+  const bool forced = gm_tune("GM_K1_V5") != nullptr && atoi(gm_tune("GM_K1_V5")) >= 1 && !gm_tune("GM_K5_AUTO");
+  if (!forced) {   // the fixed cost per read-strand (144 KB of table clears, six barriers) pays off from a few thousand list entries per read-strand
+    double entries = 0;
+    for (int sn = 0; sn < ix.n_seeds; sn++) {
+      const double lists = std::max(0, read_len - ix.seed[sn].span + 1 - ix.colour);
+      entries += lists * (double)ix.seed[sn].n_pos / (double)(1ull << (ix.hflag ? 2 * GM_HASH_TABLE_POWER : 2 * ix.seed[sn].weight));
+    }
+    if (entries < 30000.0) return 0;
+  }
+  // LDS: twice (1/8 of seen) | seen | 32 B per list | codes | control words
+  const size_t fixed = (size_t)32 * NL + (size_t)((read_len + 15) & ~15) + C_WORDS * 4;
+  const size_t budget = 160 * 1024 - 512;
+  int lsw = 15;
+  if (const char* e = gm_tune("GM_K5_LSW")) lsw = std::max(8, std::min(15, atoi(e)));
+  while (lsw >= 8 && fixed + (size_t)(4u << lsw) + (size_t)(4u << (lsw - 3)) > budget) lsw--;
+  if (lsw < 8) return 0;
+  int threads = 1024;                                          // waves per workgroup: a power of two
+  if (const char* e = gm_tune("GM_K1_THREADS")) { const int v = std::max(64, std::min(1024, atoi(e))); threads = 64; while (threads * 2 <= v) threads *= 2; }
+  const int ltw = lsw - 3;                                     // twice[] = an eighth of seen[]
+  const int hbits = lsw - 2;                                   // the region table (12 B per slot) takes three quarters of the seen[] area,
+  const int cand_seg = (int)(((4u << lsw) / 4u / 6u / (unsigned)(threads / 64)) & ~3u);   // the candidates (6 B each, one segment per wave) the rest
+  const int cand_cap = cand_seg * (threads / 64);
+  if (cand_seg < 4) return 0;
+  int cand_limit = cand_cap;
+  if (const char* e = gm_tune("GM_K5_CANDLIMIT")) cand_limit = std::max(1, std::min(cand_limit, atoi(e)));
+  if (prune && (D + (uint32_t)std::max(0, e_max) > (1u << ix.region_bits) || D > 0xFFFFu)) return 0;   // the prune rules need bins (= regions) of at least D + e_max positions
+  const size_t lds = fixed + (size_t)(4u << lsw) + (size_t)(4u << ltw);
+  const int fb_cap = std::max(4096, 2 * n_reads);              // every read-strand may fall back (tiny tables in the tests, repeats)
+  if (!K.cus) { if (hipDeviceGetAttribute(&K.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || K.cus < 1) K.cus = 256; }
+  if (fb_cap > K.fb_cap) {
+    if (K.fb) { (void)hipDeviceSynchronize(); (void)hipFree(K.fb); K.fb = nullptr; K.fb_cap = 0; }
+    if (hipMalloc(&K.fb, (size_t)(fb_cap + 4) * 4) != hipSuccess) return 0;
+    K.fb_cap = fb_cap;
+  }
+  uint32_t* const fb_cnt_p = K.fb + K.fb_cap;
+  if (hipMemsetAsync(fb_cnt_p, 0, 4, stream) != hipSuccess) return GM_E_NODEVICE;
+  static size_t configured = 0;
+  if (lds > 48 * 1024 && lds > configured) { if (hipFuncSetAttribute((const void*)k_lookup_v5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0; configured = lds; }
+  int grid = std::min(2 * n_reads, K.cus);
+  if (const char* e = gm_tune("GM_K5_GRID")) grid = std::max(1, std::min(2 * n_reads, atoi(e)));
+  K5Args a;
+  a.reads = d_reads; a.n_reads = n_reads; a.read_len = read_len; a.read_words = read_words; a.max_n_kmers = max_n_kmers; a.NL = NL;
+  a.lsw = lsw; a.ltw = ltw; a.cand_cap = cand_cap; a.hbits = hbits; a.cand_limit = cand_limit;
+  a.out = d_out; a.out_cnt = d_out_cnt; a.out_cap = out_cap; a.surv_cnt = d_surv_cnt; a.prune = prune; a.D = D; a.e_max = e_max;
+  a.heavy_list = d_heavy_list; a.heavy_cnt = d_heavy_cnt; a.heavy_cap = heavy_cap; a.stats = d_stats;
+  a.fb_list = K.fb; a.fb_cnt = fb_cnt_p; a.fb_cap = fb_cap;
+  const bool use_flags = g_k5_flags && grid <= g_k5_flag_cap;
+  g_k5_flag_grid = use_flags ? grid : 0;
+  a.start_flags = use_flags ? g_k5_flags : nullptr; a.start_epoch = g_k5_epoch;
+  hipLaunchKernelGGL(k_lookup_v5, dim3(grid), dim3(threads), lds, stream, ix, a);
+  if (hipGetLastError() != hipSuccess) return GM_E_NODEVICE;
+  *fb_list = K.fb; *fb_cnt = fb_cnt_p; *fb_cap_out = fb_cap;
+  return 1;
+}

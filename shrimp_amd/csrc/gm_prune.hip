@@ -36,10 +36,12 @@ __global__ void __launch_bounds__(1024)
 k_prune(int n_rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict__ surv_cnt, const uint32_t* __restrict__ surv_seg, int scap,
         uint64_t* __restrict__ surv2, uint32_t* __restrict__ surv_cnt2, int scap2, uint32_t D, int e_max, int bin_bits, int hbits,
         int n_slabs, int slab_bits,
-        uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap, unsigned long long* __restrict__ stats) {
+        uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap, unsigned long long* __restrict__ stats,
+        const uint32_t* __restrict__ rs_list, const uint32_t* __restrict__ rs_cnt) {   // list mode: block b prunes read-strand rs_list[b] (b < *rs_cnt)
   extern __shared__ __align__(16) uint32_t sm[];
   __shared__ uint32_t n_keep, too_many;
-  const int rs = blockIdx.x, tid = threadIdx.x;
+  if (rs_cnt && blockIdx.x >= *rs_cnt) return;
+  const int rs = rs_cnt ? (int)rs_list[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
   const uint32_t n = surv_cnt[rs];
   if (n > (uint32_t)scap) { if (tid == 0) surv_cnt2[rs] = 0xFFFFFFFFu; return; }      // already on the heavy list (K1)
   if (n == 0) { if (tid == 0) surv_cnt2[rs] = 0; return; }
@@ -130,7 +132,7 @@ k_prune(int n_rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict_
 int gm_launch_prune(int n_reads, int read_len, int window_len, int e_max, int n_slabs, int slab_bits, const uint64_t* d_surv, const uint32_t* d_surv_cnt,
                     const uint32_t* d_surv_seg, int scap,
                     uint64_t* d_surv2, uint32_t* d_surv_cnt2, int scap2, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
-                    unsigned long long* d_stats, hipStream_t stream) {
+                    unsigned long long* d_stats, hipStream_t stream, const uint32_t* d_rs_list, const uint32_t* d_rs_cnt, int rs_cap) {
   if (n_reads == 0) return GM_OK;
   const uint32_t D = (uint32_t)std::max(window_len, read_len);
   if (e_max > read_len) e_max = read_len;
@@ -143,9 +145,9 @@ int gm_launch_prune(int n_reads, int read_len, int window_len, int e_max, int n_
   static size_t configured = 0;
   if (lds > 48 * 1024 && lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_prune, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
   // latency-bound (hash probes): as many lanes per read-strand as a segment has work for
-  const int pthreads = getenv("GM_PRUNE_THREADS") ? atoi(getenv("GM_PRUNE_THREADS")) : std::min(1024, std::max(128, (1 << hbits) / 8));
-  hipLaunchKernelGGL(k_prune, dim3(n_reads * 2), dim3(pthreads), lds, stream, n_reads * 2, d_surv, d_surv_cnt, d_surv_seg, scap, d_surv2, d_surv_cnt2, scap2,
-                     D, e_max, bin_bits, hbits, segs, slab_bits, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats);
+  const int pthreads = gm_tune("GM_PRUNE_THREADS") ? atoi(gm_tune("GM_PRUNE_THREADS")) : std::min(1024, std::max(128, (1 << hbits) / 8));
+  hipLaunchKernelGGL(k_prune, dim3(d_rs_cnt ? rs_cap : n_reads * 2), dim3(pthreads), lds, stream, n_reads * 2, d_surv, d_surv_cnt, d_surv_seg, scap, d_surv2, d_surv_cnt2, scap2,
+                     D, e_max, bin_bits, hbits, segs, slab_bits, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, d_rs_list, d_rs_cnt);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgmapper_hip.so")
+LIB_PATH = os.environ.get("GM_LIB_PATH") or os.path.join(_HERE, "libgmapper_hip.so")   # GM_LIB_PATH: an experimental build of the same ABI
 
 
 class GmError(RuntimeError):

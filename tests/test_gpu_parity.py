@@ -133,6 +133,14 @@ KERNEL_VARIANTS = [
     {"GM_SLAB_BITS": "18", "GM_K1_V2": "1"},                 # the lane-per-list kernel (also the heavy tier's re-emission)
     {"GM_NO_PRUNE": "1"},                                    # K2 on the unpruned survivors
     {"GM_SCAP": "256", "GM_SCAP2": "64"},                    # small LDS tiers: most read-strands take the heavy tier
+    {"GM_SLAB_BITS": "18", "GM_K1_V5": "1"},                 # k_lookup_v5 forced (wave-per-list streaming, strip lists, region table + fused prune in LDS)
+    {"GM_NO_BUCKETS": "1", "GM_K1_V5": "1"},                 # v5 on a one-slab index
+    {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_LSW": "12"},    # v5 with 2^17 folded counters, a 1 024-slot region table, 16 x 40 candidate records
+    {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_LSW": "9"},     # v5 with tiny tables (64 candidate records): most read-strands fall back to the slab-sweep kernel + K1b in list mode
+    {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_LSW": "11", "GM_K5_CANDLIMIT": "40"},   # v5 mixed: some read-strands in LDS, some fall back
+    {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_NO_PRUNE": "1"},   # v5 without the prune rules (all survivors to K2)
+    {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_SCAP": "256", "GM_SCAP2": "64"},   # v5 survivors beyond K2's LDS tier: heavy tier
+    {"GM_SLAB_BITS": "17", "GM_K1_V5": "1", "GM_K1_THREADS": "128"},               # v5 with two waves per workgroup
 ]
 
 
@@ -149,12 +157,15 @@ def test_kernel_variants_match_reference_golden(gm, name, env):
         s = gm.Session(ix, max_batch_reads=4096)
         got = oa.sam_header(contigs) + s.map_reads(reads)
         st = s.stats
+        kern = gm.lib().gm_last_lookup_kernel().decode()
         s.close(); ix.close()
     finally:
         for k, v in old.items():
             if v is None: os.environ.pop(k, None)
             else: os.environ[k] = v
     assert got == sam, (_first_diff(got, sam), st)
+    want_kern = "k_lookup_v5" if "GM_K1_V5" in env else ("k_lookup_v4" if "GM_K1_V4" in env else None)
+    assert want_kern is None or kern == want_kern, kern
 
 
 @pytest.mark.parametrize("tag", sorted(oa.OPTION_CASES))
@@ -436,7 +447,7 @@ def test_colour_space_sam_matches_reference_golden(gm, name):
 
 
 @pytest.mark.parametrize("env", [{"GM_SLAB_BITS": "18"}, {"GM_SLAB_BITS": "18", "GM_K1_V4": "1"}, {"GM_NO_BUCKETS": "1"}, {"GM_SLAB_BITS": "18", "GM_K1_V2": "1"},
-                                 {"GM_SCAP": "256", "GM_SCAP2": "64"}],
+                                 {"GM_SCAP": "256", "GM_SCAP2": "64"}, {"GM_SLAB_BITS": "18", "GM_K1_V5": "1"}, {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_LSW": "12"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_colour_space_kernel_variants(gm, env):
     """every lookup kernel skips the first colour and reads strand 1 the colour-space way"""

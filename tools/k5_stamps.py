@@ -1,0 +1,26 @@
+"""Phase shares of k_lookup_v5 on the 3 Gbp workload (diagnostic build with -DK5_STAMPS, loaded through GM_LIB_PATH).
+usage (GPU box): GM_LIB_PATH=shrimp_amd/libgm_k5stamps.so python tools/k5_stamps.py [reads]"""
+import os, sys, ctypes as C, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from shrimp_amd import gmapper as gm, synth
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+gname, gseed, _, L, rseed = synth.CONFIGS[os.environ.get("GM_BENCH_WORKLOAD", "cfg3")]
+contigs = synth.make_genome(synth.contig_lengths(gname, 1.0), gseed)
+reads, _ = synth.make_reads(contigs, n, L, rseed)
+ix = gm.Index(contigs); s = gm.Session(ix, max_batch_reads=131072)
+os.environ["GM_RAMP_MIN"] = "131072"
+s.map_reads(reads[:8192])
+lib = gm.lib()
+out = (C.c_ulonglong * 8)()
+has = hasattr(lib, "gm_debug_k5_stamps")
+if has: lib.gm_debug_k5_stamps(out)
+t = time.time(); s.map_reads(reads); dt = time.time() - t
+print("kernel", lib.gm_last_lookup_kernel().decode(), "map %.3fs" % dt, {k: v for k, v in s.stats.items() if k.startswith("ms_") or k in ("survivors", "survivors_pruned", "list_entries")})
+if has:
+    lib.gm_debug_k5_stamps(out)
+    v = [int(x) for x in out]; tot = sum(v) or 1
+    names = ["setup(+clear wait)", "pass A", "pass B", "region table", "rules+output", "bookkeeping+clear"]
+    tot = sum(v[:6]) or 1
+    for nm, x in zip(names, v): print("%-20s %6.2f %%  %8.0f ticks per read-strand" % (nm, 100.0 * x / tot, x / (2.0 * n)))
+    print("candidates per read-strand %.1f, fallbacks %d of %d" % (v[6] / (2.0 * n), v[7], 2 * n))
