@@ -91,7 +91,7 @@ int  gm_index_build(gm_index_t **out, int device, int n_contigs, const uint32_t 
                     int n_seeds, const char *const *seeds, const gm_params_t *params);
 void gm_index_free(gm_index_t *ix);
 /* The reference's on-disk index ("-S prefix" / "-L prefix": <prefix>.genome + <prefix>.seed.<n>, gzip; ref: gmapper/genome.c:15-270,
- * 670-831).  gm_index_save writes files stock gmapper can load; gm_index_load reads files stock gmapper wrote (letter space, no -H)
+ * 670-831).  gm_index_save writes files stock gmapper can load; gm_index_load reads files stock gmapper wrote (letter or colour space, with or without -H: the mode and Hflag words of the files must match params)
  * and uploads them -- the lists are taken as they are, only the per-slab directory is derived on the device. */
 int  gm_index_save(const gm_index_t *ix, const char *prefix);
 int  gm_index_load(gm_index_t **out, int device, const char *prefix, const gm_params_t *params);
@@ -115,8 +115,8 @@ int gm_index_alloc_like(gm_index_t **out, int device, const void *meta, uint64_t
 /* ---------------------------------------------------------------------------------------------
  * S1: vector Smith-Waterman filter (score only).  ref: common/sw-vector.c:388-515
  * Same parameter lists as the reference (penalties passed negative).  State is per calling
- * thread, as in the reference (threadprivate).  genome_ls/initbp/is_rna are accepted for
- * signature compatibility; colour space is not implemented (use_colours must be 0).
+ * thread, as in the reference (threadprivate).  With use_colours the read's first colour is compared with lstocs(genome_ls[j], initbp)
+ * (see the colour-space block below); is_rna is accepted for signature compatibility.
  * ------------------------------------------------------------------------------------------- */
 int sw_vector_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
                     int match, int mismatch, int use_colours, bool reset_stats);
@@ -153,6 +153,7 @@ void sw_full_ls(uint32_t *genome, int goff, int glen, uint32_t *read, int rlen, 
                 struct gm_sw_full_results *sfr, bool revcmpl, struct gm_anchor *anchors, int anchors_cnt,
                 int local_alignment);
 int sw_full_ls_cleanup(void);
+void sw_full_ls_stats(uint64_t *invocs, uint64_t *cells, double *secs);   /* ref: common/sw-full-ls.h:11, called from gmapper.c:745 */
 
 /* ---------------------------------------------------------------------------------------------
  * S1/S2 in colour space.  sw_vector_setup(..., use_colours = 1, ...) makes sw_vector() compare the read's first colour with
@@ -160,8 +161,7 @@ int sw_full_ls_cleanup(void);
  * sw_full_cs: four letter-space translations of the colour read, 3-state affine DP in four layers with crossovers between
  * layers on the NW and N transitions, traceback with crossover marks (lower-case in qralign), ref: common/sw-full-cs.c:249-1236.
  * Global mode (local_alignment == 0) and one anchor box, as gmapper calls it (ref: mapping.c:375-379); crossover_score
- * (per-position penalties from read qualities) must be NULL.  The colour-space read pipeline around these two kernels
- * (CS index, post_sw, CS SAM tags) is not built yet.
+ * (per-position penalties from read qualities) must be NULL at this seam; the read pipeline (gm_map_reads_cs*) takes them from the QVs itself.
  * ------------------------------------------------------------------------------------------- */
 int sw_full_cs_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
                      int match, int mismatch, int global_xover_penalty, bool reset_stats, int anchor_width, int indel_taboo_len);
@@ -169,6 +169,19 @@ void sw_full_cs(uint32_t *genome_ls, int goff, int glen, uint32_t *read, int rle
                 struct gm_sw_full_results *sfr, bool revcmpl, bool is_rna, struct gm_anchor *anchors, int anchors_cnt,
                 int local_alignment, int *crossover_score);
 int sw_full_cs_cleanup(void);
+void sw_full_cs_stats(uint64_t *invocs, uint64_t *cells, double *secs);   /* ref: common/sw-full-cs.h:9, called from gmapper.c:742 */
+
+/* ---------------------------------------------------------------------------------------------
+ * S3: post_sw, the colour-space posterior of one alignment (16-state forward-backward over the aligned columns, doubles through libm in
+ * the reference's operation order -- a host routine here as in the reference).  ref: common/sw-post.h:6-9, sw-post.c:364-758; called by
+ * hit_run_post_sw (gmapper/mapping.c:1609-1625).  post_sw re-calls sfr->qralign in place, recounts matches / mismatches / crossovers,
+ * mallocs sfr->qual (base qualities, PHRED+33) and fills sfr->posterior.  State is per calling thread.  Returns follow the reference (1).
+ * ------------------------------------------------------------------------------------------- */
+int  post_sw_setup(int max_len, double pr_snp, double pr_xover, double pr_del_open, double pr_del_extend, double pr_ins_open, double pr_ins_extend,
+                   bool use_read_qvs, bool use_sanger_qvs, int qual_vector_offset, int qual_delta, bool reset_stats);
+void post_sw(uint32_t *read, int initbp, char *qual, struct gm_sw_full_results *sfr);
+int  post_sw_cleanup(void);
+int  post_sw_stats(uint64_t *invocs, uint64_t *cells, double *secs);
 /* batch form of the colour-space vector filter: as gm_sw_vector_batch plus the letter-space genome and one initial base per read */
 int gm_sw_vector_batch_cs(int n, const uint32_t *genome_cs, const uint32_t *genome_ls, uint64_t genome_words, const int64_t *g_off,
                           const int *glen, const uint32_t *reads, int read_words, const int *rlen, const int *initbp, int *scores);

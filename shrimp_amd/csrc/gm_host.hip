@@ -521,12 +521,21 @@ static inline char rc_char(char c) { switch (c) { case 'A': return 'T'; case 'C'
 // order in doubles through the same libm calls, so posterior (-> Z0/Z1, MAPQ, AS) carries the same bits; what is hoisted out of
 // the reference's inner loops (node priors, exp() of the previous column, log() of a sum shared by four states) is computed from
 // identical operands, once instead of four or sixteen times.
-struct CsPostConsts { double let_m, let_x, col_m[2], col_x[2]; };   // log(1 - e), log(e / 3) for the letter and the two colour error rates
-static CsPostConsts cs_post_consts(const gm_session* s) {
-  CsPostConsts c; const double ce[2] = {s->P.pr_xover, .75};
-  c.let_m = log(1 - s->pr_mismatch); c.let_x = log(s->pr_mismatch / 3.0);
+struct CsPostConsts {
+  double let_m, let_x, col_m[2], col_x[2];            // log(1 - e), log(e / 3) for the letter and the two colour error rates
+  double pr_del_open, pr_del_extend, pr_ins_open, pr_ins_extend;
+  bool sanger = true; int qoff = 0;                   // read QVs: PHRED (Sanger) or Solexa-style odds (ref: sw-post.c:489-491); offset of the first colour's QV in the string
+};
+static CsPostConsts cs_post_consts_from(double pr_snp, double pr_xover, double pr_del_open, double pr_del_extend, double pr_ins_open, double pr_ins_extend,
+                                        bool sanger, int qoff) {
+  CsPostConsts c; const double ce[2] = {pr_xover, .75};
+  c.let_m = log(1 - pr_snp); c.let_x = log(pr_snp / 3.0);
   for (int k = 0; k < 2; k++) { c.col_m[k] = log(1 - ce[k]); c.col_x[k] = log(ce[k] / 3.0); }
+  c.pr_del_open = pr_del_open; c.pr_del_extend = pr_del_extend; c.pr_ins_open = pr_ins_open; c.pr_ins_extend = pr_ins_extend; c.sanger = sanger; c.qoff = qoff;
   return c;
+}
+static CsPostConsts cs_post_consts(const gm_session* s) {
+  return cs_post_consts_from(s->pr_mismatch, s->P.pr_xover, s->pr_del_open, s->pr_del_extend, s->pr_ins_open, s->pr_ins_extend, true, 0);
 }
 // exp() of 16 state values of one column.  The 16 arguments take few distinct values (a state's prior has four possible values, the
 // transition terms depend on one letter only), and exp is a pure function: computing it once per distinct bit pattern gives the very same
@@ -541,8 +550,8 @@ static inline void exp_neg16(const double* in, double* out) {
   }
 }
 
-static void cs_post_sw(const gm_session* s, const CsPostConsts& K, const uint32_t* rw, int init_bp, int read_start, FHit& h,
-                       const char* qual = nullptr, int qual_delta = 33) {   // qual: the read's QV string (csfastq) or null
+static void cs_post_sw(const CsPostConsts& K, const uint32_t* rw, int init_bp, int read_start, FHit& h,
+                       const char* qual = nullptr, int qual_delta = 33, bool base_quals = false) {   // qual: the read's QV string (csfastq) or null; base_quals: h.qual even without it
   struct Col { double prior[16], fw[16], bw[16], fs, bs; int col, base_call; };
   std::string& db = h.db; std::string& qr = h.qr;
   static thread_local std::vector<Col> colbuf;
@@ -555,7 +564,7 @@ static void cs_post_sw(const gm_session* s, const CsPostConsts& K, const uint32_
       const int c = colour(j);
       if (c == 15) { start_run = 15; min_qv = 0; j = read_start; break; }
       start_run ^= c;
-      if (qual) min_qv = std::min(min_qv, (int)qual[j]);
+      if (qual) min_qv = std::min(min_qv, (int)qual[K.qoff + j]);
     }
     for (size_t i = 0; i < db.size(); i++) {
       if (qr[i] == '-') continue;
@@ -567,8 +576,9 @@ static void cs_post_sw(const gm_session* s, const CsPostConsts& K, const uint32_
       if ((len == 0 && start_run == 15) || cc == 15) { c.col = 0; which = 1; } else { c.col = cc ^ (len == 0 ? start_run : 0); which = 0; }
       double col_m = K.col_m[which], col_x = K.col_x[which];
       if (qual && which == 0) {                         // the colour's own error rate, ref: sw-post.c:486-491 (use_sanger_qvs = true)
-        const int qv = (len == 0 ? std::min(min_qv, (int)qual[j]) : (int)qual[j]) - qual_delta;
+        const int qv = (len == 0 ? std::min(min_qv, (int)qual[K.qoff + j]) : (int)qual[K.qoff + j]) - qual_delta;
         double e = qv <= 0 ? .99999999 : (qv >= 250 ? 1E-25 : pow(10.0, -(double)qv / 10.0));
+        if (!K.sanger) e /= (1 + e);
         if (e > .75) e = .75;
         col_m = log(1 - e); col_x = log(e / 3.0);
       }
@@ -628,7 +638,7 @@ static void cs_post_sw(const gm_session* s, const CsPostConsts& K, const uint32_
       { double a[16], ev[16]; for (int st = 0; st < 16; st++) a[st] = c.fw[st] + c.bw[st] + c.fs + c.bs - total; exp_neg16(a, ev);
         for (int st = 0; st < 16; st++) post[st & 3] += ev[st]; }
       int crt = 0; for (int b = 1; b < 4; b++) if (post[b] > post[crt]) crt = b;
-      if (qual) {                                       // get_base_qualities, ref: sw-post.c:568-586: of the letter sw_full_cs had called
+      if (qual || base_quals) {                         // get_base_qualities, ref: sw-post.c:568-586: of the letter sw_full_cs had called
         int t = c.base_call >= 0 ? qv_from_pr_corr(post[c.base_call]) : 0;
         if (t > 40) t = 40;
         h.qual.push_back((char)(33 + t));
@@ -641,8 +651,8 @@ static void cs_post_sw(const gm_session* s, const CsPostConsts& K, const uint32_
   {  // get_posterior, ref: sw-post.c:589-612
     double res = exp(-total);
     for (size_t i = 0; i < db.size(); i++) {
-      if (db[i] == '-') { res *= s->pr_ins_extend; if (i == 0 || db[i - 1] != '-') res *= s->pr_ins_open; }
-      else if (qr[i] == '-') { res *= s->pr_del_extend; if (i == 0 || qr[i - 1] != '-') res *= s->pr_del_open; }
+      if (db[i] == '-') { res *= K.pr_ins_extend; if (i == 0 || db[i - 1] != '-') res *= K.pr_ins_open; }
+      else if (qr[i] == '-') { res *= K.pr_del_extend; if (i == 0 || qr[i - 1] != '-') res *= K.pr_del_open; }
     }
     h.posterior = res;
   }
@@ -679,7 +689,7 @@ struct Finalizer {
       const double a = s->score_alpha, b = s->score_beta;
       if (P.colour_space) {
         cs_alignment_strings(h.ops, h.ops + ops_half, std::min(r->n_ops, ops_half), h.db, h.qr);
-        cs_post_sw(s, csk, reads + (size_t)r->read_idx * read_words, (int)initbp[r->read_idx], r->read_start, h,
+        cs_post_sw(csk, reads + (size_t)r->read_idx * read_words, (int)initbp[r->read_idx], r->read_start, h,
                    qual_ptr ? qual_ptr[r->read_idx] : nullptr, qual_delta);
       } else
       h.posterior = pow(2.0, ((double)r->score - (double)r->rmapped * (2.0 * a + b)) / a);
@@ -1375,25 +1385,32 @@ extern "C" int sw_vector(uint32_t* genome, int goff, int glen, uint32_t* read, i
 }
 
 // ---- S2: full SW on caller bitfields ------------------------------------------------------------
-struct SwFullState { bool init = false; GmScoreDev sc; int dblen = 0, qrlen = 0; };
+struct SwFullState { bool init = false; GmScoreDev sc; int dblen = 0, qrlen = 0; uint64_t invocs = 0, cells = 0; double secs = 0; };
 static thread_local SwFullState g_sf;
 static const char LSTRANS[17] = "ACGTUMRWSYKVHDBN";   // base_translate, ref: common/fasta.c:689-690
 
 extern "C" int sw_full_ls_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
                                 int match, int mismatch, bool reset_stats, int anchor_width) {
-  (void)reset_stats;
   if (gm_device_count() < 1) { gm_set_error("no HIP device"); return GM_E_NODEVICE; }
   gm_params_t P; gm_params_default(&P);
   P.match_score = match; P.mismatch_score = mismatch; P.a_gap_open_score = a_gap_open; P.a_gap_extend_score = a_gap_ext;
   P.b_gap_open_score = b_gap_open; P.b_gap_extend_score = b_gap_ext; P.anchor_width = anchor_width;
   g_sf.sc = make_score(P); g_sf.dblen = dblen; g_sf.qrlen = qrlen; g_sf.init = true;
+  if (reset_stats) { g_sf.invocs = g_sf.cells = 0; g_sf.secs = 0; }
   return 0;
 }
 extern "C" int sw_full_ls_cleanup(void) { g_sf.init = false; return 0; }
+// invocations, cells (window x read, the upper bound of the band the reference counts, ref: sw-full-ls.c:237) and seconds spent inside sw_full_ls on this thread
+extern "C" void sw_full_ls_stats(uint64_t* invocs, uint64_t* cells, double* secs) {
+  if (invocs) *invocs = g_sf.invocs; if (cells) *cells = g_sf.cells; if (secs) *secs = g_sf.secs;
+}
+struct SeamTimer { double* acc; std::chrono::steady_clock::time_point t0; explicit SeamTimer(double* a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+                   ~SeamTimer() { *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } };
 
 extern "C" void sw_full_ls(uint32_t* genome, int goff, int glen, uint32_t* read, int rlen, int threshscore, int maxscore,
                            struct gm_sw_full_results* sfr, bool revcmpl, struct gm_anchor* anchors, int anchors_cnt, int local_alignment) {
   if (!g_sf.init) abort();   // ref: sw-full-ls.c:649-650
+  SeamTimer tm(&g_sf.secs); g_sf.invocs++; g_sf.cells += (uint64_t)std::max(glen, 0) * (uint64_t)std::max(rlen, 0);
   if ((anchors != nullptr && anchors_cnt != 1) || glen > g_sf.dblen || rlen > g_sf.qrlen || glen < 1 || rlen < 1) {
     gm_set_error("sw_full_ls: one anchor box (gmapper's call, ref: mapping.c:391-394) or none (the threshold band) is implemented");
     sfr->score = 0; sfr->dbalign = strdup(""); sfr->qralign = strdup(""); return;
@@ -1456,23 +1473,27 @@ extern "C" int gm_sw_vector_batch_cs(int n, const uint32_t* genome_cs, const uin
 }
 
 // ---- S2 in colour space: sw_full_cs on caller bitfields (ref: common/sw-full-cs.c:1084-1236) --------------
-struct SwFullCsState { bool init = false; int p[9]; int dblen = 0, qrlen = 0; };
+struct SwFullCsState { bool init = false; int p[9]; int dblen = 0, qrlen = 0; uint64_t invocs = 0, cells = 0; double secs = 0; };
 static thread_local SwFullCsState g_sc;
 extern "C" int sw_full_cs_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
                                 int match, int mismatch, int global_xover_penalty, bool reset_stats, int anchor_width, int indel_taboo_len) {
-  (void)reset_stats;
+  if (reset_stats) { g_sc.invocs = g_sc.cells = 0; g_sc.secs = 0; }
   if (gm_device_count() < 1) { gm_set_error("no HIP device"); return GM_E_NODEVICE; }
   const int p[9] = {match, mismatch, global_xover_penalty, -a_gap_open, -a_gap_ext, -b_gap_open, -b_gap_ext, anchor_width, indel_taboo_len};
   memcpy(g_sc.p, p, sizeof p); g_sc.dblen = dblen; g_sc.qrlen = qrlen; g_sc.init = true;
   return 0;
 }
 extern "C" int sw_full_cs_cleanup(void) { g_sc.init = false; return 0; }
+extern "C" void sw_full_cs_stats(uint64_t* invocs, uint64_t* cells, double* secs) {   // ref: sw-full-cs.c:1127-1140 (cells: window x read x 4 layers here)
+  if (invocs) *invocs = g_sc.invocs; if (cells) *cells = g_sc.cells; if (secs) *secs = g_sc.secs;
+}
 
 extern "C" void sw_full_cs(uint32_t* genome_ls, int goff, int glen, uint32_t* read, int rlen, int initbp, int threshscore,
                            struct gm_sw_full_results* sfr, bool revcmpl, bool is_rna, struct gm_anchor* anchors, int anchors_cnt,
                            int local_alignment, int* crossover_score) {
   (void)is_rna;
   if (!g_sc.init) abort();   // ref: sw-full-cs.c:1155-1156
+  SeamTimer tm(&g_sc.secs); g_sc.invocs++; g_sc.cells += 4ull * (uint64_t)std::max(glen, 0) * (uint64_t)std::max(rlen, 0);
   auto fail = [&](const char* why) { gm_set_error("sw_full_cs: %s", why); sfr->score = 0; sfr->dbalign = nullptr; sfr->qralign = nullptr; };
   if (local_alignment || crossover_score || anchors == nullptr || anchors_cnt != 1 || glen > g_sc.dblen || rlen > g_sc.qrlen || glen < 1 || rlen < 1 ||
       initbp < 0 || initbp > 3 || g_sc.p[7] < 0) {
@@ -1526,3 +1547,37 @@ extern "C" void sw_full_cs(uint32_t* genome_ls, int goff, int glen, uint32_t* re
   sfr->dbalign = strdup(db.c_str()); sfr->qralign = strdup(q.c_str());
 }
 
+
+// ---- S3: post_sw on a caller's sw_full_results (ref: common/sw-post.c:364-758, sw-post.h:6-9) ------------------------------------------
+// The colour-space posterior of one alignment, host doubles through libm in the reference's operation order (cs_post_sw above, the routine the
+// read pipeline uses).  State per calling thread, like the reference's threadprivate statics.
+struct PostSwState { bool init = false; CsPostConsts K; bool use_read_qvs = false; int qual_delta = 33, max_len = 0; uint64_t invocs = 0, cells = 0; double secs = 0; };
+static thread_local PostSwState g_ps;
+extern "C" int post_sw_setup(int max_len, double pr_snp, double pr_xover, double pr_del_open, double pr_del_extend, double pr_ins_open, double pr_ins_extend,
+                             bool use_read_qvs, bool use_sanger_qvs, int qual_vector_offset, int qual_delta, bool reset_stats) {
+  g_ps.K = cs_post_consts_from(pr_snp, pr_xover, pr_del_open, pr_del_extend, pr_ins_open, pr_ins_extend, use_sanger_qvs, use_read_qvs ? qual_vector_offset : 0);
+  g_ps.use_read_qvs = use_read_qvs; g_ps.qual_delta = qual_delta; g_ps.max_len = max_len; g_ps.init = true;
+  if (reset_stats) { g_ps.invocs = g_ps.cells = 0; g_ps.secs = 0; }
+  return 1;                                                  // the reference returns 1 (sw-post.c:441)
+}
+extern "C" int post_sw_cleanup(void) { g_ps.init = false; return 1; }
+extern "C" int post_sw_stats(uint64_t* invocs, uint64_t* cells, double* secs) {
+  if (invocs) *invocs = g_ps.invocs; if (cells) *cells = g_ps.cells; if (secs) *secs = g_ps.secs;
+  return 1;
+}
+// read: the colour read as the reference's 4-bit bitfield; qual: its QV string (used when post_sw_setup got use_read_qvs); sfr: the result of
+// sw_full_cs -- qralign is re-called in place, matches / mismatches / crossovers are recounted, qual (malloc) and posterior are filled.
+extern "C" void post_sw(uint32_t* read, int initbp, char* qual, struct gm_sw_full_results* sfr) {
+  if (!g_ps.init) abort();                                   // ref: sw-post.c:657-658
+  if (!sfr || !sfr->dbalign || !sfr->qralign) abort();
+  SeamTimer tm(&g_ps.secs); g_ps.invocs++;
+  FHit h; h.db = sfr->dbalign; h.qr = sfr->qralign;
+  cs_post_sw(g_ps.K, read, initbp, sfr->read_start, h, g_ps.use_read_qvs ? qual : nullptr, g_ps.qual_delta, true);
+  size_t len = 0; for (char c : h.qr) len += c != '-';
+  g_ps.cells += 16 * (uint64_t)len;
+  memcpy(sfr->qralign, h.qr.data(), h.qr.size());
+  sfr->matches = h.cs_match; sfr->mismatches = h.cs_mismatch; sfr->crossovers = h.cs_xover;
+  sfr->qual = (char*)malloc(h.qr.size() + 1);
+  if (sfr->qual) { memcpy(sfr->qual, h.qual.data(), h.qual.size()); sfr->qual[h.qual.size()] = 0; }
+  sfr->posterior = h.posterior;
+}

@@ -78,8 +78,9 @@ class SwFullResults(C.Structure):   # struct gm_sw_full_results == the reference
 EXPORTS = ["gm_last_error", "gm_device_count", "gm_params_default", "gm_params_default_cs", "gm_index_build", "gm_index_free", "gm_index_list_cutoff",
            "gm_index_save", "gm_index_load", "gm_index_bytes", "gm_index_n_slabs", "gm_index_has_buckets", "gm_index_get_list", "gm_index_device_array", "gm_index_meta", "gm_index_alloc_like",
            "sw_vector_setup", "sw_vector", "sw_vector_stats", "sw_vector_cleanup", "gm_sw_vector_batch",
-           "sw_full_ls_setup", "sw_full_ls", "sw_full_ls_cleanup",
-           "sw_full_cs_setup", "sw_full_cs", "sw_full_cs_cleanup", "gm_sw_vector_batch_cs",
+           "sw_full_ls_setup", "sw_full_ls", "sw_full_ls_cleanup", "sw_full_ls_stats",
+           "sw_full_cs_setup", "sw_full_cs", "sw_full_cs_cleanup", "sw_full_cs_stats", "gm_sw_vector_batch_cs",
+           "post_sw_setup", "post_sw", "post_sw_cleanup", "post_sw_stats",
            "gm_session_create", "gm_session_free", "gm_map_reads", "gm_map_reads_fastq", "gm_map_reads_cs", "gm_map_reads_cs_fastq", "gm_map_reads_device", "gm_free", "gm_debug_tophits",
            "gm_pair_opts_default", "gm_map_pairs", "gm_map_pairs_fastq",
            "gm_last_lookup_timing", "gm_last_lookup_kernel"]
@@ -447,7 +448,7 @@ def sw_full_ls(genome_words, goff, glen, read_words, rlen, anchor, revcmpl=False
     return {n: getattr(s, n) for n, _ in SwFullResults._fields_[:9]}, db, qr
 
 
-# ---- colour space S1/S2 (the CS read pipeline around them is not built yet) ----
+# ---- colour space S1/S2/S3 at the kernel seams (the read pipeline is Session.map_reads_cs*) ----
 def sw_vector_batch_cs(genome_cs, genome_ls, g_off, glen, reads_words, rlen, initbp):
     """colour-space vector filter: genome_cs / genome_ls = colour and letter bitfields of the same contig; one initial base per read"""
     L = lib()
@@ -482,3 +483,13 @@ def sw_full_cs(genome_ls, goff, glen, read_words, rlen, initbp, thresh, anchor, 
     if s.qralign: L.gm_free(s.qralign)
     f = {n: getattr(s, n) for n in ("score", "read_start", "rmapped", "genome_start", "gmapped", "matches", "mismatches", "insertions", "deletions", "crossovers")}
     return f, db, qr
+
+
+def seam_stats(which):
+    """(invocations, cells, seconds) of this thread's sw_vector / sw_full_ls / sw_full_cs / post_sw calls (ref: the *_stats functions gmapper.c:734-745 reads)."""
+    L = lib()
+    inv, cells, secs = C.c_uint64(0), C.c_uint64(0), C.c_double(0)
+    fn = getattr(L, {"sw_vector": "sw_vector_stats", "sw_full_ls": "sw_full_ls_stats", "sw_full_cs": "sw_full_cs_stats", "post_sw": "post_sw_stats"}[which])
+    fn.restype = None if which != "post_sw" else C.c_int
+    fn(C.byref(inv), C.byref(cells), C.byref(secs))
+    return inv.value, cells.value, secs.value

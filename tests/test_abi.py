@@ -22,7 +22,7 @@ def declared_functions():
     names = set()
     for m in re.finditer(r"\b([a-z_][a-z0-9_]*)\s*\(", src):
         n = m.group(1)
-        if n.startswith(("gm_", "sw_")) and not n.endswith("_t"):
+        if n.startswith(("gm_", "sw_", "post_sw")) and not n.endswith("_t"):
             names.add(n)
     return sorted(names)
 
@@ -64,3 +64,31 @@ def test_sw_vector_setup_range_check(gm):
     """match * qrlen >= 32768 is rejected (the reference exit(1)s, sw-vector.c:393-398) before any device use."""
     rc = gm.lib().sw_vector_setup(1400, 4000, -33, -7, -33, -3, 10, -15, 0, True)
     assert rc == -4
+
+
+def test_reference_objects_link_against_the_library(gm, tmp_path):
+    """INTEGRATION.md section A, literally: the reference's own objects (gmapper/*.o and common/*.o as oracle/Makefile.ref compiles them from
+    /root/reference) minus sw-vector.o, sw-full-ls.o, sw-full-cs.o and sw-post.o link against libgmapper_hip.so without an unresolved symbol --
+    the library exports the C++-linkage names those objects reference (ref: common/util.h:8-10 has extern "C" commented out).  Link only:
+    nothing runs here (no GPU), and nothing of the reference travels in source form."""
+    objdir = os.path.join(ROOT, "oracle", "_ref", "obj")
+    if not os.path.isdir(os.path.join(objdir, "gmapper")):
+        if not os.path.isdir("/root/reference/gmapper"):
+            pytest.skip("reference objects not built and /root/reference absent (GPU box)")
+        subprocess.run(["make", "-f", os.path.join("oracle", "Makefile.ref"), "-j8"], cwd=ROOT, check=True, capture_output=True)
+    import glob
+    dropped = {"sw-vector.o", "sw-full-ls.o", "sw-full-cs.o", "sw-post.o"}
+    objs = sorted(glob.glob(os.path.join(objdir, "gmapper", "*.o"))) + [o for o in sorted(glob.glob(os.path.join(objdir, "common", "*.o"))) if os.path.basename(o) not in dropped]
+    assert len(objs) == 5 + 10, objs
+    exe = str(tmp_path / "gmapper-seams")
+    r = subprocess.run(["g++", "-fopenmp", "-o", exe, *objs, "-L" + os.path.dirname(gm.LIB_PATH), "-lgmapper_hip", "-Wl,-rpath," + os.path.dirname(gm.LIB_PATH),
+                        "-Wl,-rpath-link,/opt/rocm/lib", "-lm", "-lz", "-lstdc++", "-lrt"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # the symbols the dropped objects used to define are now undefined in the program and defined (mangled, as the objects spell them) by the library
+    und = subprocess.run(["nm", "-u", exe], capture_output=True, text=True, check=True).stdout
+    lib = subprocess.run(["nm", "-D", "--defined-only", gm.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for sym in ("_Z9sw_vectorPjiiS_iS_ib", "_Z15sw_vector_setupiiiiiiiiib", "_Z10sw_full_lsPjiiS_iiiP15sw_full_resultsbP6anchorii", "_Z16sw_full_ls_statsPmS_Pd",
+                "_Z10sw_full_csPjiiS_iiiP15sw_full_resultsbbP6anchoriiPi", "_Z16sw_full_cs_statsPmS_Pd", "_Z13post_sw_setupiddddddbbiib", "_Z7post_swPjiPcP15sw_full_results",
+                "_Z13post_sw_statsPmS_Pd", "_Z15post_sw_cleanupv"):
+        assert sym in und, sym
+        assert sym in lib, sym

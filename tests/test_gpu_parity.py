@@ -37,12 +37,17 @@ def test_sw_vector_known_answers(gm):
     """S1: every vector-SW known answer produced by the reference's own sw_vector()."""
     gm.sw_vector_setup(1400, 1000, -33, -7, -33, -3, 10, -15, 0, True)
     recs = [r for r in oa.load_kat() if r[0] == "V"]
-    n = 0
+    assert len(recs) >= 1500
+    # every record, in ONE launch of the batch entry: the records' genome bitfields are laid end to end (each starts on a word boundary)
+    words, goffs, glens, rlens, reads, want = [], [], [], [], [], []
+    base = 0; rw_max = max(len(r[5]) for r in recs)
     for _, goff, glen, rlen, g, r, score in recs:
-        got = gm.sw_vector_batch(g, [goff], [glen], r[None, :], [rlen])[0]
-        assert got == score, (goff, glen, rlen, got, score)
-        n += 1
-        if n >= 400: break
+        words.append(g); goffs.append(base * 8 + goff); glens.append(glen); rlens.append(rlen); want.append(score)
+        reads.append(np.concatenate([r, np.zeros(rw_max - len(r), dtype=np.uint32)]))
+        base += len(g)
+    got = gm.sw_vector_batch(np.concatenate(words), goffs, glens, np.stack(reads), rlens)
+    bad = np.nonzero(np.asarray(got) != np.asarray(want))[0]
+    assert bad.size == 0, (bad[:10], [got[i] for i in bad[:10]], [want[i] for i in bad[:10]])
     # and the single-call form with the reference's parameter list
     _, goff, glen, rlen, g, r, score = recs[0]
     assert gm.sw_vector(g, goff, glen, r, rlen) == score
@@ -102,8 +107,9 @@ def test_sw_full_ls_known_answers(gm):
         assert got == exp, (n, goff, glen, rlen, ax, ay, alen, aw, rv, got, exp)
         assert db == edb and qr == eqr
         n += 1
-        if n >= 300: break
-    assert n >= 300
+    assert n >= 2990                                   # every record of the reference's own sw_full_ls (global mode)
+    inv, cells, secs = gm.seam_stats("sw_full_ls")      # ref: sw_full_ls_stats, gmapper.c:745
+    assert inv == n and cells > 0 and secs > 0
 
 
 @pytest.mark.parametrize("name", GOLDEN)
@@ -612,7 +618,6 @@ def test_sw_full_ls_local_mode_known_answers(gm):
         got = [f[k] for k in ("score", "read_start", "rmapped", "genome_start", "gmapped", "matches", "mismatches", "insertions", "deletions")]
         assert got == want and db == edb and qr == eqr, (goff, glen, rlen, no_anchor, got, want)
         n += 1
-        if n >= 500: break
     assert n >= 500
 
 
@@ -667,3 +672,96 @@ def test_longest_default_read_length_vs_oracle(gm, oracle_lib):
         s.map_reads(np.zeros((2, 1001), dtype=np.uint8))          # beyond longest_read_len: refused, as the reference skips such reads
     s.close(); ix.close()
     assert got == want, _first_diff(got, want)
+
+
+def test_device_resident_path_matches_the_host_buffer_path(gm):
+    """gm_map_reads_device (reads already in HBM, the path bench.py times) against gm_map_reads on the same reads: SAM bytes with emit_sam = 1,
+    the same alignment statistics with emit_sam = 0."""
+    import torch
+    from shrimp_amd import synth
+    contigs, reads, sam = oa.load_golden("cfg2s_100bp_2Mbp")
+    ix = gm.Index(contigs); s = gm.Session(ix, max_batch_reads=2048)
+    want = s.map_reads(reads); st_host = dict(s.stats)
+    dev = torch.from_numpy(synth.pack_reads(reads).view(np.int32)).to("cuda:0")
+    got = s.map_device(dev.data_ptr(), reads.shape[0], reads.shape[1], emit_sam=True)
+    st_dev = dict(s.stats)
+    n0 = s.map_device(dev.data_ptr(), reads.shape[0], reads.shape[1], emit_sam=False, return_bytes=False)
+    st_nosam = dict(s.stats)
+    s.close(); ix.close()
+    assert got == want and oa.sam_header(contigs) + got == sam
+    keys = ("reads", "reads_matched", "lookups", "list_entries", "survivors", "windows", "vec_calls", "full_calls")
+    assert [st_dev[k] for k in keys] == [st_host[k] for k in keys] == [st_nosam[k] for k in keys]
+    assert n0 == 0 and st_nosam["sam_records"] == st_host["sam_records"]
+
+
+def _write_fasta(path, names, seqs):
+    T = np.frombuffer(b"ACGTUMRWSYKVHDBN", dtype=np.uint8)
+    with open(path, "wb") as f:
+        for nm, sq in zip(names, seqs):
+            f.write(b">" + nm + b"\n")
+            t = T[sq]
+            for k in range(0, len(t), 70):
+                f.write(t[k:k + 70].tobytes() + b"\n")
+
+
+@pytest.mark.parametrize("mode", ["ls", "cs"])
+def test_reference_program_on_the_library_seams(gm, mode, tmp_path):
+    """Drop-in at S1-S3, literally: the reference's own gmapper program, linked in the build container from its unmodified objects minus
+    sw-vector.o / sw-full-ls.o / sw-full-cs.o / sw-post.o against libgmapper_hip.so (oracle/Makefile.ref `seams`), maps the
+    first reads of a golden here on the GPU: its SAM must be the golden's (which stock gmapper produced).  Exercises sw_vector_setup / sw_vector /
+    sw_full_ls (ls) and the colour forms + sw_full_cs + post_sw (cs) through the C++-linkage names the reference's objects call."""
+    import subprocess
+    exe = os.path.join(oa.ROOT, "oracle", "_ref", "gmapper-seams-" + mode)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/gmapper-seams-* is built where /root/reference exists (make -f oracle/Makefile.ref seams)")
+    from shrimp_amd import synth
+    name, n = ("cfg1_36bp_1Mbp", 150) if mode == "ls" else ("cfg4s_50col_2Mbp", 60)
+    contigs, reads, sam = oa.load_golden(name)
+    g = str(tmp_path / "g.fa"); r = str(tmp_path / ("r.fa" if mode == "ls" else "r.csfasta"))
+    _write_fasta(g, [b"contig%d" % (i + 1) for i in range(len(contigs))], contigs)
+    if mode == "ls": _write_fasta(r, [b"r%d" % i for i in range(n)], list(reads[:n]))
+    else: synth.write_csfasta_reads(r, reads[:n])
+    p = subprocess.run([exe, "-N", "1", r, g], capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = [l for l in p.stdout.split(b"\n") if l and not l.startswith(b"@")]
+    first = {b"r%d" % i for i in range(n)}
+    want = [l for l in sam.split(b"\n") if l and not l.startswith(b"@") and l.split(b"\t")[0] in first]
+    assert len(want) >= n // 2
+    assert got == want, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want)))
+
+
+def test_full_size_genome_vs_oracle(gm, oracle_lib):
+    """BASELINE configs[2..4] at full genome size: the 24-contig 3.0 Gbp genome (global 32-bit coordinates beyond 2^31, six slabs, the lookup kernel
+    the benchmark really runs), 20 000 letter-space reads, 2 000 2x150 bp pairs and 5 000 50-colour reads against the CPU oracle."""
+    from shrimp_amd import synth
+    contigs = synth.make_genome(synth.contig_lengths("cfg3", 1.0), 3)
+    offs = np.cumsum([0] + [len(c) for c in contigs])
+    assert offs[-1] > 2**31 and offs[-1] < 2**32
+    high = {b"contig%d" % (i + 1) for i in range(len(contigs)) if offs[i] >= 2**31}
+    reads, _ = synth.make_reads(contigs, 20000, 100, 31)
+    pr, _ = synth.make_pairs(contigs, 2000, 150, 35)
+    m1, m2 = pr[0::2], pr[1::2]
+    o = oa.Session(contigs)
+    want = o.map_sam(reads, nthreads=16)
+    o.set_pairing("opp-in", 100, 600)
+    want_p = o.map_pairs_sam(m1, m2, nthreads=16)
+    o.close()
+    ix = gm.Index(contigs); s = gm.Session(ix)
+    assert ix.n_slabs == 6
+    got = s.map_reads(reads)
+    kern = gm.lib().gm_last_lookup_kernel().decode()
+    got_p = s.map_pairs(m1, m2, mode="opp-in", min_insert=100, max_insert=600)
+    s.close(); ix.close()
+    assert kern == "k_lookup_v4", kern
+    assert got == want, _first_diff(got, want)
+    assert sum(1 for l in got.split(b"\n") if l and l.split(b"\t")[2] in high) > 1000       # hits at global positions >= 2^31
+    assert got_p == want_p, _first_diff(got_p, want_p)
+    cs, _ = synth.make_cs_reads(contigs, 5000, 50, 37)
+    o = oa.Session(contigs, opts="colour=1")
+    want_c = o.map_sam(cs, nthreads=16); o.close()
+    p = gm.default_params_cs()
+    ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p)
+    got_c = s.map_reads_cs(cs)
+    s.close(); ix.close()
+    assert got_c == want_c, _first_diff(got_c, want_c)
+    assert sum(1 for l in got_c.split(b"\n") if l and l.split(b"\t")[2] in high) > 200
