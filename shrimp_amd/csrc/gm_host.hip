@@ -303,6 +303,7 @@ struct gm_session {
   hipStream_t stream_c = nullptr;                 // host -> device copies of the next sub-batch (never queued behind kernels)
   hipEvent_t ev[12];
   hipEvent_t pev[2][10];                           // per buffer set: stage boundaries, front done, copies done
+  hipEvent_t pkev[2][4];                           // paired mode: begin / end of K1 for mate set 0 and 1 of buffer pair k
   unsigned long long* d_pstats[2] = {nullptr, nullptr};   // per buffer set: counters of one sub-batch
   uint32_t* h_pin = nullptr;                      // pinned words the front writes (heavy count per set); from word 16 on: K1's start flags
   uint32_t flag_epoch = 0, front_epoch[2] = {0, 0}; int front_flag_grid[2] = {0, 0};
@@ -436,6 +437,7 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   GM_HIP(hipStreamCreateWithFlags(&s->stream_c, hipStreamNonBlocking));
   for (auto& e : s->ev) GM_HIP(hipEventCreate(&e));
   for (auto& row : s->pev) for (auto& e : row) GM_HIP(hipEventCreate(&e));
+  for (auto& row : s->pkev) for (auto& e : row) GM_HIP(hipEventCreate(&e));
   GM_HIP(hipMalloc(&s->d_stats, (size_t)GS_STRIPES * GS_STRIDE * 8));
   for (auto& d : s->d_pstats) GM_HIP(hipMalloc(&d, (size_t)GS_STRIPES * GS_STRIDE * 8));
   GM_HIP(hipHostMalloc((void**)&s->h_pin, (16 + 1024) * 4, hipHostMallocDefault));
@@ -460,6 +462,7 @@ extern "C" void gm_session_free(gm_session_t* s) {
   if (s->h_pin) (void)hipHostFree(s->h_pin);
   for (auto& e : s->ev) (void)hipEventDestroy(e);
   for (auto& row : s->pev) for (auto& e : row) (void)hipEventDestroy(e);
+  for (auto& row : s->pkev) for (auto& e : row) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(s->stream);
   if (s->stream_b) (void)hipStreamDestroy(s->stream_b);
   if (s->stream_c) (void)hipStreamDestroy(s->stream_c);
@@ -1083,7 +1086,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     std::thread th;
   };
   std::vector<std::unique_ptr<Job>> jobs;
-  int nthreads = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+  int nthreads = (int)std::min<unsigned>(32, std::max(1u, std::thread::hardware_concurrency()));   // a multi-rank job divides the cores itself: GM_HOST_THREADS (bench.py: cores / ranks of this node)
   if (const char* e = getenv("GM_HOST_THREADS")) nthreads = std::max(1, atoi(e));
   const int ops_stride = D.ops_stride;
   // The SAM text is assembled as the jobs finish, in input order (each job appends after its predecessor), so that the copy -- and the

@@ -321,6 +321,29 @@ class Session:
         self.stats = st.as_dict()
         return out
 
+    def map_cs_packed(self, packed: np.ndarray, initbp: np.ndarray, n: int, n_colours: int, return_bytes: bool = True):
+        """Colour-space reads already packed (pack_reads of the colours, one primer byte per read): the form a timed loop uses.
+        With return_bytes=False the SAM text stays in the library's buffer and its length is returned."""
+        L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
+        _check(L.gm_map_reads_cs(self.h, n, n_colours, packed.ctypes.data_as(C.POINTER(C.c_uint32)), initbp.ctypes.data_as(C.POINTER(C.c_uint8)), None,
+                                 C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_reads_cs")
+        out = sl.value
+        if return_bytes: out = C.string_at(sam, sl.value) if sam.value else b""
+        if sam.value: L.gm_free(sam)
+        self.stats = st.as_dict()
+        return out
+
+    def map_pairs_packed(self, p1: np.ndarray, p2: np.ndarray, n: int, len1: int, len2: int, opts: "PairOpts", return_bytes: bool = True):
+        """Paired mode on packed mates (pack_reads of each mate set)."""
+        L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
+        _check(L.gm_map_pairs(self.h, n, len1, p1.ctypes.data_as(C.POINTER(C.c_uint32)), len2, p2.ctypes.data_as(C.POINTER(C.c_uint32)),
+                              None, None, C.byref(opts), C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_pairs")
+        out = sl.value
+        if return_bytes: out = C.string_at(sam, sl.value) if sam.value else b""
+        if sam.value: L.gm_free(sam)
+        self.stats = st.as_dict()
+        return out
+
     def map_packed(self, packed: np.ndarray, n: int, read_len: int, names=None) -> bytes:
         L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
         nm = None
