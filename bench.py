@@ -48,6 +48,40 @@ def reduce_max_time(dt: float, world: int, dist=None, device=None) -> float:
     return float(tt.item())
 
 
+def host_threads_for(local_world: int) -> int:
+    """host threads per rank for the finalisation (selection, MAPQ, SAM text): this rank's share of the cores the job may run on"""
+    try: n_cores = len(os.sched_getaffinity(0))
+    except Exception: n_cores = os.cpu_count() or 1
+    return max(1, min(32, n_cores // max(1, local_world)))
+
+
+def selftest_ranks(steps: int = 3, units: int = 1000):
+    """The N > 1 logic of main() without a GPU (gloo): per-rank seeds, barrier-bracketed timing, MAX over ranks, rank-0-only JSON.
+    A step is a sleep that grows with the rank, so that the slowest rank decides.  Used by tests/test_dist_gloo.py."""
+    import torch, torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world > 1: dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_pool = 2
+    seeds = [shard_seed(3, rank, n_pool, b) for b in range(n_pool)]
+    per_step = 0.02 * (rank + 1)
+    if world > 1: dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps): time.sleep(per_step)
+    if world > 1: dist.barrier()
+    dt = reduce_max_time(time.perf_counter() - t0, world, dist, torch.device("cpu"))
+    allseeds = [None] * world; allstep = [None] * world
+    if world > 1:
+        dist.all_gather_object(allseeds, seeds); dist.all_gather_object(allstep, per_step)
+    else:
+        allseeds, allstep = [seeds], [per_step]
+    if rank == 0:
+        print(json.dumps({"selftest": True, "value": units * steps * world / dt, "n_gpus": world, "steps": steps, "ms_per_step": 1e3 * dt / steps, "scaling": "weak",
+                          "seeds": allseeds, "rank_step_s": allstep, "units_per_rank_step": units, "host_threads_per_rank": host_threads_for(local_world)}))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,9 +111,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # host threads per rank for the finalisation (selection, MAPQ, SAM text): this rank's share of the host cores
-    try: n_cores = len(os.sched_getaffinity(0))
-    except Exception: n_cores = os.cpu_count() or 1
-    host_threads = max(1, min(32, n_cores // max(1, local_world)))
+    host_threads = host_threads_for(local_world)
     os.environ.setdefault("GM_HOST_THREADS", str(host_threads))
 
     kind, gname, gseed, L, rseed, R_def, metric, unit, descr = WORKLOADS[args.workload]

@@ -29,22 +29,37 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def broadcast_index(index, rank: int, device, src: int = 0, chunk_bytes: int = 1 << 30):
+def device_view(ptr: int, nbytes: int, device):
+    """uint8 tensor over `nbytes` of device memory at `ptr` (no copy): what RCCL broadcasts from / into"""
+    import torch
+    return torch.as_tensor(_DevArray(ptr, nbytes), device=device)
+
+
+def host_view(ptr: int, nbytes: int, device=None):
+    """the same over host memory (the gloo tests drive broadcast_index through this view)"""
+    import ctypes, numpy as np, torch
+    return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(ptr)))
+
+
+def broadcast_index(index, rank: int, device, src: int = 0, chunk_bytes: int = 1 << 30, alloc_like=None, view=device_view):
     """Replicate the index built on `src` to every rank: metadata by object broadcast, then each
     resident array (packed genome, per-seed directory, per-seed positions) by dist.broadcast straight
     from/into HBM.  xGMI is point-to-point, so one ring broadcast of the 39 GB hg-sized index is per-link
-    bound (~0.3 s); it happens once.  Returns the local Index."""
-    import torch
+    bound (~0.3 s); it happens once.  Returns the local Index.
+    `index` needs meta() and device_arrays(); `alloc_like(meta, device)` makes the receiving side (default: gmapper.Index.alloc_like);
+    `view(ptr, nbytes, device)` turns one array into a tensor (device_view for HBM; host_view in the CPU tests)."""
     import torch.distributed as dist
-    from . import gmapper as gm
     meta = [index.meta() if rank == src else None]
     dist.broadcast_object_list(meta, src=src)
     if rank != src:
-        index = gm.Index.alloc_like(meta[0], device=device.index if hasattr(device, "index") else int(device))
+        if alloc_like is None:
+            from . import gmapper as gm
+            alloc_like = gm.Index.alloc_like
+        index = alloc_like(meta[0], device=device.index if hasattr(device, "index") else device)
     for ptr, nb in index.device_arrays():
         if not nb or not ptr:
             continue
-        t = torch.as_tensor(_DevArray(ptr, nb), device=device)
+        t = view(ptr, nb, device)
         for o in range(0, nb, chunk_bytes):
             dist.broadcast(t[o:o + chunk_bytes], src=src)
     return index

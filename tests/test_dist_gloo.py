@@ -16,17 +16,33 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+class _HostIndex:
+    """stand-in for gmapper.Index with its arrays in host memory: the same two methods parallel.broadcast_index uses"""
+    def __init__(self, arrays, meta_blob):
+        self.arrays = arrays; self.blob = meta_blob
+    def meta(self): return self.blob
+    def device_arrays(self): return [(a.ctypes.data, a.nbytes) for a in self.arrays] + [(0, 0)]       # a kind that is not resident: skipped
+    @classmethod
+    def alloc_like(cls, meta, device=None):
+        import pickle
+        shapes = pickle.loads(meta)
+        return cls([np.zeros(n, dtype=np.uint8) for n in shapes], meta)
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     contigs, reads, _ = oa.load_golden("stress_60bp")
-    # start-up broadcast: rank 0 owns the "index arrays", everyone else receives them
-    meta = [{"n": int(sum(len(c) for c in contigs))} if rank == 0 else None]
-    dist.broadcast_object_list(meta, src=0)
-    arr = torch.from_numpy(np.concatenate(contigs).copy()) if rank == 0 else torch.zeros(meta[0]["n"], dtype=torch.uint8)
-    for o in range(0, arr.numel(), 1 << 16):
-        dist.broadcast(arr[o:o + (1 << 16)], src=0)
-    assert int(arr.sum()) == int(np.concatenate(contigs).sum())
+    # start-up broadcast through parallel.broadcast_index itself (host view instead of the HBM view): rank 0 owns the arrays, the others receive them
+    import pickle
+    if rank == 0:
+        arrays = [np.concatenate(contigs).copy(), np.arange(100003, dtype=np.uint32).view(np.uint8).copy(), np.zeros(0, dtype=np.uint8)]
+        ix = _HostIndex(arrays, pickle.dumps([a.nbytes for a in arrays]))
+    else:
+        ix = None
+    ix = parallel.broadcast_index(ix, rank, None, src=0, chunk_bytes=1 << 16, alloc_like=_HostIndex.alloc_like, view=parallel.host_view)
+    assert int(ix.arrays[0].astype(np.int64).sum()) == int(np.concatenate(contigs).astype(np.int64).sum())
+    assert (ix.arrays[1].view(np.uint32) == np.arange(100003, dtype=np.uint32)).all()
     lo, hi = parallel.shard_bounds(len(reads), world)[rank]
     s = oa.Session(contigs)
     local = s.map_sam(reads[lo:hi], nthreads=2)
@@ -50,3 +66,38 @@ def test_world2_sharded_equals_unsharded():
     for p in procs: p.join(180)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get() is True
+
+
+def _bench_rank_worker(rank, world, port, q):
+    """bench.py's rank logic (seeds per rank, barrier-bracketed timing, all_reduce MAX, rank-0-only JSON) without a GPU"""
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "LOCAL_WORLD_SIZE": str(world)})
+    import io, contextlib, json, sys
+    sys.path.insert(0, oa.ROOT)
+    import bench
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.selftest_ranks(steps=3)
+    q.put((rank, buf.getvalue()))
+
+
+def test_world2_bench_rank_logic():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    outs = dict(q.get() for _ in range(2))
+    for p in procs: p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    import json
+    assert outs[1] == ""                                    # only rank 0 prints
+    lines = [l for l in outs[0].split("\n") if l]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
+    assert d["seeds"][0] != d["seeds"][1] and len(set(sum(d["seeds"], []))) == 4          # every (rank, pool slot) draws its own reads
+    # the job's time is the slowest rank's (rank 1 sleeps twice as long per step): value = all ranks' units over that time
+    assert abs(d["ms_per_step"] - 1e3 * d["rank_step_s"][1]) < 0.5 * 1e3 * d["rank_step_s"][1]
+    assert d["ms_per_step"] >= 1e3 * d["rank_step_s"][0]
+    assert abs(d["value"] - 2 * d["units_per_rank_step"] / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]
+    assert d["host_threads_per_rank"] >= 1
