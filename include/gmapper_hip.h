@@ -209,6 +209,14 @@ typedef struct gm_map_stats {
   double   ms_lookup, ms_anchors, ms_pass1, ms_select, ms_pass2, ms_host;   /* device time per stage (events) */
 } gm_map_stats_t;
 
+/* A22: the read loop's text -> bitfield step inside the library.  gm_sequence_to_bitfield == fasta_sequence_to_bitfield with the reference's code
+ * tables (ref: common/fasta.c:609-673, :151-200; fasta.h:26-42): letters A C G T U M R W S Y K V H D B N -> 0..15 (X and '.' -> 15, either case);
+ * in colour space the first character is the primer letter (returned in *initbp), then colours 0-3 ('4', 'N', '.', 'X' -> 15).  Host code, no device.
+ * gm_map_reads_text takes the reads as lines of one length and keeps the characters for the fields the reference prints from the file's text
+ * (SEQ of unaligned reads and clipped ends, ref: gmapper/output.c:326-351; CS:Z, :451,727). */
+int gm_sequence_to_bitfield(int colour_space, const char *seq, int seq_len, uint32_t *words, int *initbp);
+int gm_map_reads_text(gm_session_t *s, int n_reads, int read_len, const char *seqs, const char *names, const char *quals, int qual_delta,
+                      char **sam, size_t *sam_len, gm_map_stats_t *stats);
 /* host-buffer form: reads are uploaded, SAM text is returned in a malloc()ed buffer (*sam, *sam_len) */
 int gm_map_reads(gm_session_t *s, int n_reads, int read_len, const uint32_t *reads_packed,
                  const char *names, char **sam, size_t *sam_len, gm_map_stats_t *stats);

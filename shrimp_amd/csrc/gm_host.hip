@@ -517,6 +517,9 @@ static void dedup_pass(std::vector<FHit*>& v, Cmp cmp) {     // ref: mapping.c:1
 }
 
 static const char CODE2SEQ[17] = "ACGTNNNNNNNNNNNN";   // SEQ letter of an aligned read base (ref: output.c:485-533: non-ACGTN -> N)
+static inline char seq_from_text(char c) {          // ref: gmapper/output.c:326-351
+  switch (c) { case 'R': case 'Y': case 'S': case 'W': case 'K': case 'M': case 'B': case 'D': case 'H': case 'V': return 'N'; default: return c >= 'a' ? (char)(c - 32) : c; }
+}
 static inline char rc_char(char c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'N'; } }
 
 // ---- colour space: post_sw (ref: common/sw-post.c:639-758) for reads without quality values -----------------------------------
@@ -679,6 +682,7 @@ struct Finalizer {
   const gm_session* s; int read_len, read_words; const uint32_t* reads;   // host copy of the packed reads of this sub-batch
   const char* const* name_ptr; const int* name_len; long name_base;
   const uint8_t* initbp = nullptr; int ops_half = 0; CsPostConsts csk = CsPostConsts();
+  const char* const* seq_ptr = nullptr;                                                // text input: the read as it stood in the file (fields the reference prints from re->seq)
   const char* const* qual_ptr = nullptr; int qual_delta = 33;                          // FASTQ input: QUAL string of every read of this sub-batch   // colour space: primer letters of this sub-batch, ops_stride / 2
 
   // hit_run_post_sw for one pass-2 result (ref: mapping.c:1609-1625)
@@ -730,7 +734,8 @@ struct Finalizer {
     else { nl = (size_t)snprintf(nbuf, sizeof nbuf, "r%ld", name_base + rd); nm = nbuf; }
     const size_t need = 64 + nl + 8 * (size_t)read_len + 320;
     // colour space: the read as csfasta text, primer letter + colours ('.' for a skipped cycle), for the CS:Z tag (ref: output.c:451,730)
-    auto put_csfasta = [&](char* p) { *p++ = "ACGT"[initbp[rd] & 3]; for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = (c < 4) ? (char)('0' + c) : '.'; } return p; };
+    auto put_csfasta = [&](char* p) { if (seq_ptr) return put_str(p, seq_ptr[rd], (size_t)read_len + 1);     // verbatim, as the reference prints re->seq
+      *p++ = "ACGT"[initbp[rd] & 3]; for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = (c < 4) ? (char)('0' + c) : '.'; } return p; };
     if (p2.empty()) {
       if (P.sam_unaligned) {                                                       // ref: output.c:411-466
         size_t o = out.size(); out.resize(o + need); char* p = &out[o];
@@ -740,7 +745,8 @@ struct Finalizer {
           if (qual_ptr) p = put_str(p, qual_ptr[rd], (size_t)read_len); else *p++ = '*';
           p = put_str(p, "\tCS:Z:", 6); p = put_csfasta(p); *p++ = '\n'; out.resize(p - out.data()); return 1;
         }
-        for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = (c < 4) ? "ACGT"[c] : 'N'; }
+        if (seq_ptr) for (int i = 0; i < read_len; i++) *p++ = seq_from_text(seq_ptr[rd][i]);
+        else for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = (c < 4) ? "ACGT"[c] : 'N'; }
         if (qual_ptr) { *p++ = '\t'; p = put_str(p, qual_ptr[rd], (size_t)read_len); *p++ = '\n'; }      // ref: output.c:419-421 (verbatim)
         else p = put_str(p, "\t*\n", 3);
         out.resize(p - out.data());
@@ -814,8 +820,11 @@ struct Finalizer {
         continue;
       }
       // SEQ: read bases in input orientation (aligned part from qralign == the read's own letters), revcomp on '-'
-      if (!rev) for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = CODE2SEQ[c]; }
-      else for (int i = read_len - 1; i >= 0; i--) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = rc_char(CODE2SEQ[c]); }
+      // (text input: the clipped ends -- local mode only -- keep the file's letters, ref: output.c:326-351,482-533; on the reverse strand the reference's
+      // reverse() knows no 'X' / 'U' and exits there, those print as N here)
+      auto seq_at = [&](int i) -> char { const int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; return (seq_ptr && (i < read_start - 1 || i >= read_end)) ? seq_from_text(seq_ptr[rd][i]) : CODE2SEQ[c]; };
+      if (!rev) for (int i = 0; i < read_len; i++) *p++ = seq_at(i);
+      else for (int i = read_len - 1; i >= 0; i--) { const char c = seq_at(i); *p++ = c == '.' ? '.' : rc_char(c); }
       if (qual_ptr) {                                                              // ref: output.c:539-570
         *p++ = '\t';
         const char* q = qual_ptr[rd]; const int dq = 33 - qual_delta;
@@ -1053,7 +1062,7 @@ static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int
 
 static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* reads_host, const void* reads_dev,
                     const char* names, int emit_sam, char** sam, size_t* sam_len, gm_map_stats_t* stats, const uint8_t* initbp_host = nullptr,
-                    const char* quals = nullptr, int qual_delta = 33) {
+                    const char* quals = nullptr, int qual_delta = 33, const char* seq_text = nullptr) {
   if (!s || n_reads < 0 || read_len < 1) { gm_set_error("gm_map_reads: bad arguments"); return GM_E_ARG; }
   if ((s->P.colour_space != 0) != (initbp_host != nullptr)) {
     gm_set_error(s->P.colour_space ? "colour-space session: use gm_map_reads_cs (colours + primer letters)" : "gm_map_reads_cs needs a colour-space session"); return GM_E_ARG; }
@@ -1066,7 +1075,15 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   s->last_lookup_ms = 0; s->last_lookup_bytes = 0; s->last_lookup_launches = 0;
   // names
   std::vector<const char*> nptr; std::vector<int> nlen;
-  std::vector<const char*> qptr; std::vector<int8_t> xbuf;
+  std::vector<const char*> qptr; std::vector<int8_t> xbuf; std::vector<const char*> sptr;
+  if (seq_text) {                                            // one line per read: read_len letters, or primer + read_len colours
+    const char* p = seq_text; const int want = read_len + (s->P.colour_space ? 1 : 0);
+    for (int i = 0; i < n_reads; i++) {
+      const char* e = strchr(p, '\n'); if (!e) e = p + strlen(p);
+      if ((int)(e - p) != want) { gm_set_error("read %d: %d characters, expected %d", i, (int)(e - p), want); return GM_E_ARG; }
+      sptr.push_back(p); p = *e ? e + 1 : e;
+    }
+  }
   if (quals) {
     const char* p = quals;
     for (int i = 0; i < n_reads; i++) {
@@ -1101,6 +1118,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     Finalizer F{s, read_len, read_words, J->hreads, names ? nptr.data() + J->base : nullptr, names ? nlen.data() + J->base : nullptr, (long)J->base};
     if (s->P.colour_space) { F.initbp = initbp_host + J->base; F.ops_half = ops_stride / 2; F.csk = cs_post_consts(s); }
     if (quals) { F.qual_ptr = qptr.data() + J->base; F.qual_delta = qual_delta; }
+    if (seq_text) F.seq_ptr = sptr.data() + J->base;
     auto worker = [&]() {
       std::vector<FHit> fh; std::vector<FHit*> p2;
       for (;;) {
@@ -1290,6 +1308,53 @@ extern "C" int gm_map_reads_cs(gm_session_t* s, int n_reads, int n_colours, cons
 extern "C" int gm_map_reads_device(gm_session_t* s, int n_reads, int read_len, const void* reads_dev, int emit_sam, char** sam, size_t* sam_len, gm_map_stats_t* stats) {
   return map_impl(s, n_reads, read_len, nullptr, reads_dev, nullptr, emit_sam, sam, sam_len, stats);
 }
+// ---- A22: text -> 4-bit codes (ref: common/fasta.c:609-673; tables :151-200, fasta.h:26-42) --------------------------------------------------
+// Host code (no device needed).  Letter space: A C G T U M R W S Y K V H D B N = 0..15, X and '.' = 15, either case.  Colour space: the first
+// character is the primer letter (A/C/G/T, either case; anything else: the reference drops the read), then colours 0-3, and 4 / N / n / . / X / x = 15.
+extern "C" int gm_sequence_to_bitfield(int colour_space, const char* seq, int seq_len, uint32_t* words, int* initbp) {
+  if (!seq || seq_len < 1 || !words) { gm_set_error("gm_sequence_to_bitfield: bad arguments"); return GM_E_ARG; }
+  static const signed char LS[128] = {
+    -1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1, -1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,15,-1, -1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,
+    -1, 0,14, 1,13,-1,-1, 2,12,-1,-1,10,-1, 5,15,-1, -1,-1, 6, 8, 3, 4,11, 7,15, 9,-1,-1,-1,-1,-1,-1,  -1, 0,14, 1,13,-1,-1, 2,12,-1,-1,10,-1, 5,15,-1, -1,-1, 6, 8, 3, 4,11, 7,15, 9,-1,-1,-1,-1,-1,-1};
+  int i = 0, idx = 0;
+  if (colour_space) {
+    int b;
+    switch (seq[0]) { case 'A': case 'a': b = 0; break; case 'C': case 'c': b = 1; break; case 'G': case 'g': b = 2; break; case 'T': case 't': b = 3; break;
+                      default: gm_set_error("colour-space read does not start with a primer letter (ref: fasta.c:626-634)"); return GM_E_ARG; }
+    if (initbp) *initbp = b;
+    i = 1;
+  }
+  const int n = seq_len - i;
+  memset(words, 0, (size_t)((n + 7) / 8) * 4);
+  for (; i < seq_len; i++, idx++) {
+    const unsigned char ch = (unsigned char)seq[i]; int a = -1;
+    if (colour_space) { if (ch >= '0' && ch <= '3') a = ch - '0'; else if (ch == '4' || ch == 'N' || ch == 'n' || ch == '.' || ch == 'X' || ch == 'x') a = 15; }
+    else if (ch < 128) a = LS[ch];
+    if (a < 0) { gm_set_error("invalid character 0x%x in a read (did you mix up letter space and colour space? ref: fasta.c:639-650)", ch); return GM_E_ARG; }
+    words[idx >> 3] |= (uint32_t)a << ((idx & 7) * 4);
+  }
+  return GM_OK;
+}
+
+// Text entry point: n reads of one length as lines ('\n' separated): letters, or in a colour-space session primer + colours.  The library packs them
+// (gm_sequence_to_bitfield) and keeps the characters for what the reference prints from the file's text: SEQ of unaligned reads and of clipped ends,
+// the CS:Z tag.  quals (optional): FASTQ QUAL lines and their offset.
+extern "C" int gm_map_reads_text(gm_session_t* s, int n_reads, int read_len, const char* seqs, const char* names, const char* quals, int qual_delta,
+                                 char** sam, size_t* sam_len, gm_map_stats_t* stats) {
+  if (!s || !seqs || n_reads < 0 || read_len < 1) { gm_set_error("gm_map_reads_text: bad arguments"); return GM_E_ARG; }
+  const int cs = s->P.colour_space ? 1 : 0, line = read_len + cs, rwords = (read_len + 7) / 8;
+  std::vector<uint32_t> packed((size_t)n_reads * rwords); std::vector<uint8_t> ibp(cs ? n_reads : 0);
+  const char* p = seqs;
+  for (int i = 0; i < n_reads; i++) {
+    const char* e = strchr(p, '\n'); if (!e) e = p + strlen(p);
+    if ((int)(e - p) != line) { gm_set_error("read %d: %d characters, expected %d", i, (int)(e - p), line); return GM_E_ARG; }
+    int b = 0; const int rc = gm_sequence_to_bitfield(cs, p, line, packed.data() + (size_t)i * rwords, &b); if (rc) return rc;
+    if (cs) ibp[i] = (uint8_t)b;
+    p = *e ? e + 1 : e;
+  }
+  return map_impl(s, n_reads, read_len, packed.data(), nullptr, names, 1, sam, sam_len, stats, cs ? ibp.data() : nullptr, quals, qual_delta, seqs);
+}
+
 extern "C" int gm_last_lookup_timing(gm_session_t* s, double* ms, uint64_t* alg_bytes, int* launches) {
   if (!s) return GM_E_ARG;
   if (ms) *ms = s->last_lookup_ms; if (alg_bytes) *alg_bytes = s->last_lookup_bytes; if (launches) *launches = s->last_lookup_launches;

@@ -81,7 +81,7 @@ EXPORTS = ["gm_last_error", "gm_device_count", "gm_params_default", "gm_params_d
            "sw_full_ls_setup", "sw_full_ls", "sw_full_ls_cleanup", "sw_full_ls_stats",
            "sw_full_cs_setup", "sw_full_cs", "sw_full_cs_cleanup", "sw_full_cs_stats", "gm_sw_vector_batch_cs",
            "post_sw_setup", "post_sw", "post_sw_cleanup", "post_sw_stats",
-           "gm_session_create", "gm_session_free", "gm_map_reads", "gm_map_reads_fastq", "gm_map_reads_cs", "gm_map_reads_cs_fastq", "gm_map_reads_device", "gm_free", "gm_debug_tophits",
+           "gm_session_create", "gm_session_free", "gm_sequence_to_bitfield", "gm_map_reads_text", "gm_map_reads", "gm_map_reads_fastq", "gm_map_reads_cs", "gm_map_reads_cs_fastq", "gm_map_reads_device", "gm_free", "gm_debug_tophits",
            "gm_pair_opts_default", "gm_map_pairs", "gm_map_pairs_fastq",
            "gm_last_lookup_timing", "gm_last_lookup_kernel"]
 
@@ -344,6 +344,18 @@ class Session:
         self.stats = st.as_dict()
         return out
 
+    def map_reads_text(self, seqs, names=None, quals=None, qual_delta: int = 64) -> bytes:
+        """Reads as text lines of one length (letters; or primer + colours in a colour-space session), packed inside the library."""
+        L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
+        seqs = [x if isinstance(x, bytes) else x.encode() for x in seqs]
+        n = len(seqs); read_len = len(seqs[0]) - (1 if self.params.colour_space else 0) if n else 1
+        join = lambda v: None if v is None else b"\n".join(x if isinstance(x, bytes) else x.encode() for x in v)
+        _check(L.gm_map_reads_text(self.h, n, read_len, b"\n".join(seqs), join(names), join(quals), int(qual_delta), C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_reads_text")
+        out = C.string_at(sam, sl.value) if sam.value else b""
+        if sam.value: L.gm_free(sam)
+        self.stats = st.as_dict()
+        return out
+
     def map_packed(self, packed: np.ndarray, n: int, read_len: int, names=None) -> bytes:
         L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
         nm = None
@@ -516,3 +528,12 @@ def seam_stats(which):
     fn.restype = None if which != "post_sw" else C.c_int
     fn(C.byref(inv), C.byref(cells), C.byref(secs))
     return inv.value, cells.value, secs.value
+
+
+def sequence_to_bitfield(text, colour_space: bool = False):
+    """fasta_sequence_to_bitfield (ref: common/fasta.c:609-673) through the library: returns (uint32 words, primer letter code or None)."""
+    t = text if isinstance(text, bytes) else text.encode()
+    n = len(t) - (1 if colour_space else 0)
+    words = np.zeros(max(1, (n + 7) // 8), dtype=np.uint32); b = C.c_int(0)
+    _check(lib().gm_sequence_to_bitfield(int(colour_space), t, len(t), words.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(b)), "gm_sequence_to_bitfield")
+    return words, (b.value if colour_space else None)

@@ -765,3 +765,22 @@ def test_full_size_genome_vs_oracle(gm, oracle_lib):
     s.close(); ix.close()
     assert got_c == want_c, _first_diff(got_c, want_c)
     assert sum(1 for l in got_c.split(b"\n") if l and l.split(b"\t")[2] in high) > 200
+
+
+@pytest.mark.parametrize("mode", ["ls", "cs"])
+def test_text_input_matches_reference_golden(gm, mode):
+    """A22: reads handed over as the file's characters (gm_map_reads_text packs them with gm_sequence_to_bitfield): lower case, X / . / U, ambiguity codes;
+    csfasta with '.', '4', 'N' and a lower-case primer -- against the reference's SAM with --sam-unaligned, which prints SEQ of unaligned reads and CS:Z
+    from the file's text (ref: gmapper/output.c:326-351,451,727)."""
+    import gzip
+    d = os.path.join(oa.ROOT, "tests", "golden")
+    with gzip.open(os.path.join(d, "text_%s_reads.txt.gz" % mode), "rb") as f: lines = [l for l in f.read().split(b"\n") if l]
+    with gzip.open(os.path.join(d, "text_%s_unal.sam.gz" % mode), "rb") as f: sam = f.read()
+    contigs, _, _ = oa.load_golden("stress_100bp_unal" if mode == "ls" else "stress_cs_60col_unal")
+    p = gm.default_params() if mode == "ls" else gm.default_params_cs()
+    p.sam_unaligned = 1
+    ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p, max_batch_reads=512)
+    got = oa.sam_header(contigs) + s.map_reads_text(lines)
+    s.close(); ix.close()
+    assert got == sam, _first_diff(got, sam)
+    assert any(ch in l.split(b"\t")[9] for l in sam.split(b"\n") if l and not l.startswith(b"@") for ch in (b"X", b"U", b".")) or mode == "cs"

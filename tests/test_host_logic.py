@@ -37,3 +37,20 @@ def test_shard_bounds_cover_input_in_whole_chunks():
         assert all(lo % 1000 == 0 for lo, hi in b if lo < n)
     b = parallel.shard_bounds(10_000, 3, chunk=1001, paired=True)
     assert all(lo % 2 == 0 for lo, _ in b)                # mates stay together
+
+
+def test_sequence_to_bitfield_follows_the_reference_tables():
+    """gm_sequence_to_bitfield == fasta_sequence_to_bitfield (ref: common/fasta.c:609-673) with the tables of fasta.c:151-200 / fasta.h:26-42; host code,
+    works without a GPU."""
+    import numpy as np
+    from shrimp_amd import gmapper as gm, synth
+    text = b"ACGTUMRWSYKVHDBNacgtumrwsykvhdbnXx." + b"ACGTACGTAC"
+    want = np.array(list(range(16)) * 2 + [15, 15, 15] + [0, 1, 2, 3, 0, 1, 2, 3, 0, 1], dtype=np.uint8)
+    words, ib = gm.sequence_to_bitfield(text)
+    assert ib is None and (words == synth.pack_reads(want[None, :])[0]).all()
+    words, ib = gm.sequence_to_bitfield(b"t0123.4NnXx3210", colour_space=True)
+    assert ib == 3 and (words == synth.pack_reads(np.array([[0, 1, 2, 3, 15, 15, 15, 15, 15, 15, 3, 2, 1, 0]], dtype=np.uint8))[0]).all()
+    import pytest
+    with pytest.raises(gm.GmError): gm.sequence_to_bitfield(b"ACGT0")                       # a colour in a letter-space read (the reference exits, fasta.c:639-650)
+    with pytest.raises(gm.GmError): gm.sequence_to_bitfield(b"N0123", colour_space=True)    # no primer letter (the reference drops the read, :626-634)
+    with pytest.raises(gm.GmError): gm.sequence_to_bitfield(b"TACGT", colour_space=True)    # letters in a colour-space read

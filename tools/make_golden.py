@@ -380,5 +380,51 @@ def main():
     paired_fastq_case()
 
 
+def text_cases():
+    """Text input: reads as the file's characters -- lower case, X / x / . for N, U, ambiguity codes; csfasta with '.', '4', 'N' for a skipped
+    cycle and a lower-case primer -- through the reference with --sam-unaligned: what it prints verbatim from the file's text (SEQ of unaligned reads,
+    CS:Z) and what it normalises.  Fixtures: the read lines themselves + the reference's SAM.  (With --local the reference exits on a reverse-strand
+    clip that holds X or U -- "error in getting reverse complement", gmapper/output.c:213-216 -- so there is no golden for that.)"""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    def run(exe, extra, reads_path, genome_path):
+        p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", exe), "-N", "2", *extra, reads_path, genome_path], capture_output=True, check=True)
+        return b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+    z = np.load(os.path.join(OUT, "stress_100bp_unal.npz")); contigs = [z["contig%d" % i] for i in range(len(z.files) - 1)]; reads = z["reads"][:400]
+    LET = b"ACGTUMRWSYKVHDBN"; lines = []
+    for r in reads:
+        t = bytearray(LET[c] for c in r)
+        for i, c in enumerate(r):
+            if c == 15: t[i] = b"NnXx."[rng.integers(0, 5)]
+            elif rng.random() < 0.15: t[i] = t[i] + 32
+        lines.append(bytes(t))
+    for k in range(0, 400, 9):                        # reads that cannot map: SEQ shows their text (X . U kept, ambiguity codes -> N)
+        t = bytearray(lines[k])
+        for q in rng.integers(0, 100, 25): t[q] = b"XUx.uRYK"[rng.integers(0, 8)]
+        lines[k] = bytes(t)
+    with tempfile.TemporaryDirectory() as d:
+        g = os.path.join(d, "g.fa"); r = os.path.join(d, "r.fa")
+        write_fa_codes(g, [b"contig%d" % (i + 1) for i in range(len(contigs))], contigs)
+        with open(r, "wb") as f:
+            for i, t in enumerate(lines): f.write(b">r%d\n" % i + t + b"\n")
+        sam = run("gmapper-ls", ["--sam-unaligned"], r, g)
+    with gzip.open(os.path.join(OUT, "text_ls_reads.txt.gz"), "wb", compresslevel=9) as f: f.write(b"\n".join(lines) + b"\n")
+    with gzip.open(os.path.join(OUT, "text_ls_unal.sam.gz"), "wb", compresslevel=9) as f: f.write(sam)
+    z = np.load(os.path.join(OUT, "stress_cs_60col_unal.npz")); contigs = [z["contig%d" % i] for i in range(len(z.files) - 1)]; reads = z["reads"][:300]
+    lines = []
+    for r in reads:
+        t = bytearray(b"ACGT"[r[0]:r[0] + 1])
+        for c in r[1:]: t += (b"0123"[c:c + 1] if c < 4 else b".4Nn"[rng.integers(0, 4):][:1])
+        if rng.random() < 0.2: t[0] = t[0] + 32
+        lines.append(bytes(t))
+    with tempfile.TemporaryDirectory() as d:
+        g = os.path.join(d, "g.fa"); r = os.path.join(d, "r.csfasta")
+        write_fa_codes(g, [b"contig%d" % (i + 1) for i in range(len(contigs))], contigs)
+        with open(r, "wb") as f:
+            for i, t in enumerate(lines): f.write(b">r%d\n" % i + t + b"\n")
+        sam = run("gmapper-cs", ["--sam-unaligned"], r, g)
+    with gzip.open(os.path.join(OUT, "text_cs_reads.txt.gz"), "wb", compresslevel=9) as f: f.write(b"\n".join(lines) + b"\n")
+    with gzip.open(os.path.join(OUT, "text_cs_unal.sam.gz"), "wb", compresslevel=9) as f: f.write(sam)
+
+
 if __name__ == "__main__":
     main()
