@@ -443,7 +443,7 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   GM_HIP(hipHostMalloc((void**)&s->h_pin, (16 + 1024) * 4, hipHostMallocDefault));
   memset(s->h_pin, 0, (16 + 1024) * 4);
   // k_lookup_v5 streams large indexes with the help of per-list strip lists, derived once per index (not stored in the index files)
-  if (gm_tune("GM_K1_V5") && ix->params.region_bits >= 9 && ix->params.region_bits <= 16) {
+  if ((ix->n_slabs > 1 || gm_tune("GM_K1_V5")) && !gm_tune("GM_NO_V5") && ix->params.region_bits >= 9 && ix->params.region_bits <= 16) {
     const int rc = gm_index_derive_strips(const_cast<gm_index*>(ix), s->stream);
     if (rc) { gm_session_free(s); return rc; }
   }

@@ -1123,10 +1123,10 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     configured = lds;
   }
   const bool bkt = ix.seed[0].bkt != nullptr && ix.n_slabs == 1 && NL <= 512 && !getenv("GM_NO_BUCKETS");
-  if (!bkt && NL < 65536 && !getenv("GM_K1_V2") && !getenv("GM_K1_V3") && !getenv("GM_K1_V4") && getenv("GM_K1_V5")) {
+  if (!bkt && NL < 65536 && !getenv("GM_K1_V2") && !getenv("GM_K1_V3") && !getenv("GM_K1_V4") && !getenv("GM_NO_V5")) {
     // k_lookup_v5 (gm_lookup5.hip): wave-per-list streaming, candidates and the exact rule in LDS, K1b's prune rules fused when the caller allows.
-    // Opt-in (GM_K1_V5=1): measured in round 2 it needs 24 % fewer VALU instructions than v4 + K1b but 152 KB of LDS, which keeps pass 1 / pass 2 of
-    // the other stream off its CUs -- end to end it is slower than v4 inside the two-stream pipeline.
+    // It takes the read-strands with many list entries (gm_lookup5_launch declines the others: 50-colour reads, small genomes) -- round 2: 24 %
+    // fewer VALU instructions than v4 + K1b, 2.09 M reads/s against 1.90 M on the 3 Gbp workload.
     const bool want_fuse = fuse && fuse->scap2 > 0;
     const uint32_t D = (uint32_t)std::max(want_fuse ? fuse->window_len : 0, read_len);
     const int e_max = want_fuse ? std::min(fuse->e_max, read_len) : -1;

@@ -40,7 +40,7 @@ typedef __attribute__((address_space(3))) uint32_t k5_lds_u32;
 #define K5_LDS_OR(off, m) __hip_atomic_fetch_or(K5_LDS(off), (m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
 #define K5_Q 6            // list chunks in flight per wave
-enum { C_NLISTS = 0, C_NCAND, C_OVERFLOW, C_NMEMB, C_NKEEP, C_WUP = 8, C_WDN = 24, C_PFX = 40, C_WORDS = 60 };   // C_WUP / C_WDN: candidates per wave segment (from the bottom / from the top); C_PFX: exclusive prefix of their sums (17 words)
+enum { C_NLISTS = 0, C_NCAND, C_OVERFLOW, C_NMEMB, C_NKEEP, C_WORDS = 8 };
 
 // Diagnostic build (-DK5_STAMPS): thread 0 of every workgroup adds the cycles between the phase boundaries of each read-strand to k5_stamps[]
 // (setup, pass A, pass B, region table, rules + output, clears); gm_debug_k5_stamps() reads and resets them.  No stamp executes in the normal build.
@@ -76,54 +76,7 @@ __device__ __forceinline__ uint32_t k5_lane_times(int lane, uint32_t W) {
   return ((uint32_t)lane << sh) + ((uint32_t)lane & add3);
 }
 
-// Region table over the candidates (exact stage): open addressing, three parallel arrays of 2^hbits words.
-//   htag[h] = (region + 1) << 8 | flags     A: marked once, B: marked twice or more (the reference's count >= 2), C / D / E: 1 / 2 / >= 3 candidates inside
-//   hmin[h] = 0x10000 - smallest offset of a candidate inside the region (0: none), hmax[h] = largest offset + 1 (0: none)
-// Only single-shot atomics (one CAS to claim a slot, then OR / MAX): a read that really maps puts ~250 candidates into one region, and a
-// compare-and-swap retry loop on that slot serialises them (measured: 19 k cycles per read-strand for the insert phase alone).
-#define K5_FA 1u
-#define K5_FB 2u
-#define K5_FC 4u
-#define K5_FD 8u
-#define K5_FE 16u
-__device__ __forceinline__ uint32_t k5_hash(uint32_t r1, int hshift) { return (r1 * 2654435761u) >> hshift; }
-__device__ __forceinline__ uint32_t k5_step(uint32_t r1) { return ((r1 * 0x9E3779B1u) >> 15) | 1u; }      // odd: the probe sequence h, h + step, ... visits every slot (double hashing: no primary clustering)
-
-// returns the slot of region r (claiming one if needed) after OR-ing `first` into a fresh slot / `again` bookkeeping into an existing one; 0xFFFFFFFF: table full
-__device__ __forceinline__ uint32_t k5_insert(uint32_t* htag, uint32_t hmask, int hshift, uint32_t r, bool own) {
-  const uint32_t r1 = r + 1u, t = r1 << 8, first = own ? (K5_FA | K5_FC) : K5_FA;
-  uint32_t h = k5_hash(r1, hshift); const uint32_t step = k5_step(r1);
-  for (uint32_t n = 0; n <= hmask; n++) {
-    const uint32_t prev = atomicCAS(&htag[h], 0u, t | first);
-    if (prev == 0u) return h;
-    if ((prev >> 8) == r1) {
-      uint32_t old = prev;
-      if ((old & first) != first) old = atomicOr(&htag[h], first);     // (the claimer's flags are there already)
-      uint32_t need = ((old & K5_FA) ? K5_FB : 0u) | ((own && (old & K5_FC)) ? K5_FD : 0u) | ((own && (old & K5_FD)) ? K5_FE : 0u);
-      need &= ~old;
-      if (need) {
-        const uint32_t old2 = atomicOr(&htag[h], need);
-        if (own && (need & K5_FD) && (old2 & K5_FD) && !(old2 & K5_FE)) atomicOr(&htag[h], K5_FE);
-      }
-      return h;
-    }
-    h = (h + step) & hmask;
-  }
-  return 0xFFFFFFFFu;
-}
-// slot of region r, or 0xFFFFFFFF
-__device__ __forceinline__ uint32_t k5_find(const uint32_t* htag, uint32_t hmask, int hshift, uint32_t r, uint32_t& tagword) {
-  const uint32_t r1 = r + 1u;
-  uint32_t h = k5_hash(r1, hshift); const uint32_t step = k5_step(r1);
-  for (uint32_t n = 0; n <= hmask; n++) {
-    const uint32_t cur = htag[h];
-    if (cur == 0u) break;
-    if ((cur >> 8) == r1) { tagword = cur; return h; }
-    h = (h + step) & hmask;
-  }
-  tagword = 0u;
-  return 0xFFFFFFFFu;
-}
+#include "gm_region_table.h"
 
 __global__ void __launch_bounds__(1024)
 k_lookup_v5(GmIndexDev ix, K5Args a) {
@@ -291,17 +244,23 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
           gen(sd[q]); issue(sd[q], sv[q]);
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the dummy loads of the exhausted generator
+      // (the dummy loads of the exhausted generator stay in flight: nothing reads their registers)
     }
+    // Pass B streams the same lists again: its first K5_Q loads go out here, before the barrier, so that the wait for the slowest wave, the clear of
+    // the region table and the strip loop hide the fill of its load pipeline (~2 us per pass otherwise).
+    Step sdB[K5_Q]; k5_u32x4 svB[K5_Q];
+    gen_reset();
+#pragma unroll
+    for (int q = 0; q < K5_Q; q++) { gen(sdB[q]); issue(sdB[q], svB[q]); }
     __syncthreads();
     K5_STAMP(1);
     // ================= pass B: candidates (into the dead seen[] area) =================
     { uint4* h4 = (uint4*)htag; for (int w = tid; w < hclr_q; w += nthr) h4[w] = make_uint4(0, 0, 0, 0); }
     {
-      // Candidates go to per-wave segments of the candidate arrays (seg words each): the main loop fills its wave's segment from the bottom with
-      // a wave-uniform counter (no atomic, no LDS round trip per step), the strip loop below -- whose threads are not wave-uniform -- from the top.
+      // Candidates are appended to one dense array (positions + y/seed) through a counter in LDS: one atomic per wave and step.  (Per-wave segments
+      // with a wave-uniform counter -- no atomic at all -- were measured and dropped: pass B gained 2 %, the two exact stages lost 20 % to the
+      // segment -> slot mapping and to half-empty iterations.)
       // a strip entry whose own region stays below 2 is a candidate when the region before reaches 2
-      const uint32_t seg = (uint32_t)a.cand_cap / (uint32_t)nwv, cbase = (uint32_t)wv * seg;
       for (int j0 = tid >> 2; j0 < nl; j0 += nthr >> 2) {
         const uint4 sr = *(const uint4*)&srec[4 * j0];
         const uint32_t* sp = spos0 + (((uint64_t)sr.y << 32) | sr.x);
@@ -316,26 +275,18 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
           const bool c2 = nv > 2 && !has2(v.z) && has2(v.z - (1u << rb));
           const bool c3 = nv > 3 && !has2(v.w) && has2(v.w - (1u << rb));
           if (c0 | c1 | c2 | c3) {
-            const uint32_t cn = (uint32_t)c0 + (uint32_t)c1 + (uint32_t)c2 + (uint32_t)c3;
-            const uint32_t d = atomicAdd(&ctrl[C_WDN + wv], cn);
-            if (d + cn <= seg) {
-              uint32_t idx = cbase + seg - 1u - d;
+            uint32_t idx = atomicAdd(&ctrl[C_NCAND], (uint32_t)c0 + (uint32_t)c1 + (uint32_t)c2 + (uint32_t)c3);
+            if (idx + 4u <= (uint32_t)a.cand_cap) {
               const uint16_t y16 = (uint16_t)(((ysn >> 12) & 0xFFF0u) | (ysn & 0xFu));
-              if (c0) { candp[idx] = v.x; candy[idx--] = y16; }
-              if (c1) { candp[idx] = v.y; candy[idx--] = y16; }
-              if (c2) { candp[idx] = v.z; candy[idx--] = y16; }
-              if (c3) { candp[idx] = v.w; candy[idx--] = y16; }
+              if (c0) { candp[idx] = v.x; candy[idx++] = y16; }
+              if (c1) { candp[idx] = v.y; candy[idx++] = y16; }
+              if (c2) { candp[idx] = v.z; candy[idx++] = y16; }
+              if (c3) { candp[idx] = v.w; candy[idx++] = y16; }
             }
           }
         }
       }
-      const uint32_t wdn = __builtin_amdgcn_readfirstlane(ctrl[C_WDN + wv]);     // this wave's strip candidates are all in (same wave, program order)
-      const uint32_t wlim = wdn <= seg ? seg - wdn : 0u;
-      uint32_t wup = 0;
-      gen_reset();
-      Step sd[K5_Q]; k5_u32x4 sv[K5_Q];
-#pragma unroll
-      for (int q = 0; q < K5_Q; q++) { gen(sd[q]); issue(sd[q], sv[q]); }
+      Step (&sd)[K5_Q] = sdB; k5_u32x4 (&sv)[K5_Q] = svB;
       bool more = true;
       while (more) {
 #pragma unroll
@@ -362,10 +313,12 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
           const uint32_t c0 = (uint32_t)__popcll(b0), c1 = (uint32_t)__popcll(b1), c2 = (uint32_t)__popcll(b2), c3 = (uint32_t)__popcll(b3);
           const uint32_t tot = c0 + c1 + c2 + c3;
           if (tot) {
-            if (wup + tot <= wlim) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&ctrl[C_NCAND], tot);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base + tot <= (uint32_t)a.cand_cap) {
               const unsigned long long lt = (1ull << lane) - 1ull;
               const uint16_t y16 = (uint16_t)(((s.ysn >> 12) & 0xFFF0u) | (s.ysn & 0xFu));
-              uint32_t base = cbase + wup;
               if (h0) { const uint32_t ci = base + (uint32_t)__popcll(b0 & lt); candp[ci] = sv[q].x; candy[ci] = y16; }
               base += c0;
               if (h1) { const uint32_t ci = base + (uint32_t)__popcll(b1 & lt); candp[ci] = sv[q].y; candy[ci] = y16; }
@@ -374,38 +327,19 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
               base += c2;
               if (h3) { const uint32_t ci = base + (uint32_t)__popcll(b3 & lt); candp[ci] = sv[q].w; candy[ci] = y16; }
             }
-            wup += tot;                                        // beyond wlim: nothing is written, the read-strand falls back
           }
           gen(sd[q]); issue(sd[q], sv[q]);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) {
-        const bool over = wup > wlim || wdn > seg;
-        ctrl[C_WUP + wv] = over ? 0u : wup;
-        if (over) { ctrl[C_WDN + wv] = 0u; ctrl[C_OVERFLOW] = 1u; } else atomicAdd(&ctrl[C_NCAND], wup + wdn);
-      }
     }
     __syncthreads();
     K5_STAMP(2);
     const uint32_t nc = ctrl[C_NCAND];
-    bool fallback = nc > (uint32_t)a.cand_limit || ctrl[C_OVERFLOW] != 0u;
-    const uint32_t seg = (uint32_t)a.cand_cap / (uint32_t)nwv;
-    // dense candidate index d (0 .. nc) -> slot in the per-wave segments: segment = number of prefix sums <= d, then bottom part first, top part after
-    auto slot_of = [&](const uint32_t d) -> uint32_t {         // (the 16 prefix words in four 16-byte reads: one LDS round trip, not sixteen)
-      const uint4 p0 = *(const uint4*)&ctrl[C_PFX], p1 = *(const uint4*)&ctrl[C_PFX + 4], p2 = *(const uint4*)&ctrl[C_PFX + 8], p3 = *(const uint4*)&ctrl[C_PFX + 12];
-      const uint32_t sg = (uint32_t)(d >= p0.y) + (uint32_t)(d >= p0.z) + (uint32_t)(d >= p0.w) + (uint32_t)(d >= p1.x) + (uint32_t)(d >= p1.y) + (uint32_t)(d >= p1.z) +
-                          (uint32_t)(d >= p1.w) + (uint32_t)(d >= p2.x) + (uint32_t)(d >= p2.y) + (uint32_t)(d >= p2.z) + (uint32_t)(d >= p2.w) + (uint32_t)(d >= p3.x) +
-                          (uint32_t)(d >= p3.y) + (uint32_t)(d >= p3.z) + (uint32_t)(d >= p3.w);
-      const uint32_t j = d - ctrl[C_PFX + sg], up = ctrl[C_WUP + sg];
-      return sg * seg + (j < up ? j : seg - 1u - (j - up));
-    };
+    bool fallback = nc > (uint32_t)a.cand_limit;
     // ================= exact stage 1: region table over the candidates =================
-    if (tid == 0) { uint32_t run = 0; for (int k = 0; k < 16; k++) { ctrl[C_PFX + k] = k < nwv ? run : 0xFFFFFFFFu; if (k < nwv) run += ctrl[C_WUP + k] + ctrl[C_WDN + k]; } }
-    __syncthreads();
     if (!fallback) {
-      for (uint32_t d = tid; d < nc; d += nthr) {
-        const uint32_t i = slot_of(d);
+      for (uint32_t i = tid; i < nc; i += nthr) {
         const uint32_t p = candp[i], r = p >> rb, off = p & rmask;
         const uint32_t h = k5_insert(htag, hmask, hshift, r, true);
         bool ok = h != 0xFFFFFFFFu;
@@ -420,11 +354,10 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
     // ================= exact stage 2: the reference's rule (ref: mapping.c:733-742), prune rules (gm_prune.hip), output =================
     if (!fallback) {
       unsigned long long* out = (unsigned long long*)a.out + (size_t)rs * a.out_cap;
-      for (uint32_t d0 = 0; d0 < nc; d0 += nthr) {
-        const uint32_t d = d0 + tid;
-        bool memb = false, keep = false; uint32_t p = 0, i = 0;
-        if (d < nc) {
-          i = slot_of(d);
+      for (uint32_t i0 = 0; i0 < nc; i0 += nthr) {
+        const uint32_t i = i0 + tid;
+        bool memb = false, keep = false; uint32_t p = 0;
+        if (i < nc) {
           p = candp[i];
           const uint32_t r = p >> rb, off = p & rmask;
           uint32_t town, tlf = 0, trt = 0;
@@ -477,6 +410,7 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
       }
     }
     __syncthreads();
+    if (!fallback && a.prune && ctrl[C_NKEEP] > (uint32_t)a.out_cap) fallback = true;   // more kept than K2's LDS tier takes: k_prune's finer bins get the last word before the heavy tier
     K5_STAMP(4);
 #ifdef K5_STAMPS
     if (tid == 0) { atomicAdd(&k5_stamps[6], (unsigned long long)nc); if (fallback) atomicAdd(&k5_stamps[7], 1ull); }
@@ -599,15 +533,14 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
   if (!ix.seed[0].sdir || ix.region_bits < 9 || ix.region_bits > 16 || NL <= 0) return 0;
   K5Scratch& K = g_k5[dev];
-  const bool forced = gm_tune("GM_K1_V5") != nullptr && atoi(gm_tune("GM_K1_V5")) >= 1 && !gm_tune("GM_K5_AUTO");
-  if (!forced) {   // the fixed cost per read-strand (144 KB of table clears, six barriers) pays off from a few thousand list entries per read-strand
-    double entries = 0;
-    for (int sn = 0; sn < ix.n_seeds; sn++) {
-      const double lists = std::max(0, read_len - ix.seed[sn].span + 1 - ix.colour);
-      entries += lists * (double)ix.seed[sn].n_pos / (double)(1ull << (ix.hflag ? 2 * GM_HASH_TABLE_POWER : 2 * ix.seed[sn].weight));
-    }
-    if (entries < 30000.0) return 0;
+  const bool forced = gm_tune("GM_K1_V5") != nullptr;
+  double entries = 0;                                          // expected list entries per read-strand
+  for (int sn = 0; sn < ix.n_seeds; sn++) {
+    const double lists = std::max(0, read_len - ix.seed[sn].span + 1 - ix.colour);
+    entries += lists * (double)ix.seed[sn].n_pos / (double)(1ull << (ix.hflag ? 2 * GM_HASH_TABLE_POWER : 2 * ix.seed[sn].weight));
   }
+  // the fixed cost per read-strand (144 KB of table clears, six barriers) pays off from a few ten thousand list entries per read-strand
+  if (!forced && entries < 30000.0) return 0;
   // LDS: twice (1/8 of seen) | seen | 32 B per list | codes | control words
   const size_t fixed = (size_t)32 * NL + (size_t)((read_len + 15) & ~15) + C_WORDS * 4;
   const size_t budget = 160 * 1024 - 512;
@@ -619,10 +552,18 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   if (const char* e = gm_tune("GM_K1_THREADS")) { const int v = std::max(64, std::min(1024, atoi(e))); threads = 64; while (threads * 2 <= v) threads *= 2; }
   const int ltw = lsw - 3;                                     // twice[] = an eighth of seen[]
   const int hbits = lsw - 2;                                   // the region table (12 B per slot) takes three quarters of the seen[] area,
-  const int cand_seg = (int)(((4u << lsw) / 4u / 6u / (unsigned)(threads / 64)) & ~3u);   // the candidates (6 B each, one segment per wave) the rest
-  const int cand_cap = cand_seg * (threads / 64);
-  if (cand_seg < 4) return 0;
-  int cand_limit = cand_cap;
+  const int cand_cap = (int)(((4u << lsw) / 4u / 6u) & ~15u);   // the candidates (6 B each) the rest
+  if (cand_cap < 16) return 0;
+  int cand_limit = cand_cap - 8;
+  if (!forced) {
+    // Expected candidates per read-strand: the reference's survivors (entries sharing a region; ~2x the independence estimate with the strip and the
+    // echoes of a real hit) + later arrivals on a shared seen[] bit + first arrivals that meet a set twice[] bit.  Read-strands beyond the candidate
+    // array fall back to the slab-sweep kernel: when that would be the rule (2 x 150 bp reads on 3 Gbp: ~9 k), k_lookup_v4 is the better kernel.
+    const double lam = entries * (double)((1u << ix.region_bits) + ix.region_overlap) / std::max(1.0, (double)ix.total_len);
+    const double memb = 2.0 * entries * std::min(1.0, lam), late = 0.5 * entries * std::min(1.0, entries / (double)(32ull << lsw));
+    const double first = entries * std::min(1.0, (late + 0.5 * memb) / (double)(32ull << (lsw - 3)));
+    if (memb + late + first > 0.85 * cand_cap) return 0;
+  }
   if (const char* e = gm_tune("GM_K5_CANDLIMIT")) cand_limit = std::max(1, std::min(cand_limit, atoi(e)));
   if (prune && (D + (uint32_t)std::max(0, e_max) > (1u << ix.region_bits) || D > 0xFFFFu)) return 0;   // the prune rules need bins (= regions) of at least D + e_max positions
   const size_t lds = fixed + (size_t)(4u << lsw) + (size_t)(4u << ltw);

@@ -31,6 +31,12 @@
 #include "gm_common.h"
 #include <algorithm>
 #include "gm_internal.h"
+#include "gm_region_table.h"
+
+__device__ void prune_one(uint32_t* sm, uint32_t* n_keep_p, uint32_t* too_many_p, int rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict__ surv_cnt,
+                          const uint32_t* __restrict__ surv_seg, int scap, uint64_t* __restrict__ surv2, uint32_t* __restrict__ surv_cnt2, int scap2, uint32_t D, int e_max,
+                          int bin_bits, int hbits, int n_slabs, int slab_bits, uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap,
+                          unsigned long long* __restrict__ stats);
 
 __global__ void __launch_bounds__(1024)
 k_prune(int n_rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict__ surv_cnt, const uint32_t* __restrict__ surv_seg, int scap,
@@ -40,8 +46,23 @@ k_prune(int n_rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict_
         const uint32_t* __restrict__ rs_list, const uint32_t* __restrict__ rs_cnt) {   // list mode: block b prunes read-strand rs_list[b] (b < *rs_cnt)
   extern __shared__ __align__(16) uint32_t sm[];
   __shared__ uint32_t n_keep, too_many;
-  if (rs_cnt && blockIdx.x >= *rs_cnt) return;
-  const int rs = rs_cnt ? (int)rs_list[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
+  // list mode: a bounded grid walks the list (a grid as long as the list's capacity -- hundreds of thousands of workgroups that exit at once -- kept
+  // the persistent K1 grid of the next sub-batch and pass 1 of this one from sharing the CUs: the two-stream pipeline ran in stage order)
+  if (rs_cnt) {
+    const uint32_t cnt = *rs_cnt;
+    for (uint32_t b = blockIdx.x; b < cnt; b += gridDim.x) { prune_one(sm, &n_keep, &too_many, (int)rs_list[b], surv, surv_cnt, surv_seg, scap, surv2, surv_cnt2, scap2, D, e_max, bin_bits, hbits,
+                                                                       n_slabs, slab_bits, heavy_list, heavy_cnt, heavy_cap, stats); __syncthreads(); }
+    return;
+  }
+  prune_one(sm, &n_keep, &too_many, (int)blockIdx.x, surv, surv_cnt, surv_seg, scap, surv2, surv_cnt2, scap2, D, e_max, bin_bits, hbits, n_slabs, slab_bits, heavy_list, heavy_cnt, heavy_cap, stats);
+}
+
+__device__ void prune_one(uint32_t* sm, uint32_t* n_keep_p, uint32_t* too_many_p, int rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict__ surv_cnt,
+                          const uint32_t* __restrict__ surv_seg, int scap, uint64_t* __restrict__ surv2, uint32_t* __restrict__ surv_cnt2, int scap2, uint32_t D, int e_max,
+                          int bin_bits, int hbits, int n_slabs, int slab_bits, uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap,
+                          unsigned long long* __restrict__ stats) {
+  uint32_t& n_keep = *n_keep_p; uint32_t& too_many = *too_many_p;
+  const int tid = threadIdx.x;
   const uint32_t n = surv_cnt[rs];
   if (n > (uint32_t)scap) { if (tid == 0) surv_cnt2[rs] = 0xFFFFFFFFu; return; }      // already on the heavy list (K1)
   if (n == 0) { if (tid == 0) surv_cnt2[rs] = 0; return; }
@@ -129,6 +150,100 @@ k_prune(int n_rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// k_prune_v2: the same two rules with bins of 2^bb >= D + e_max positions (the 2 048-base regions by default) in the region table of
+// gm_region_table.h.  What changes against k_prune:
+//  * only single-shot LDS atomics (slot claim by one CAS, counts as flag bits, min / max by atomicMax): k_prune's compare-and-swap loop on the
+//    packed (count, min, max) word serialises the ~250 survivors of a read that really maps, which all fall into one or two bins;
+//  * survivors of one region come in twos by construction (that is why they survived), so the table holds about half as many keys as survivors:
+//    4 096 slots x 12 B = 48 KB, three workgroups per CU instead of two;
+//  * a survivor at least D + e_max away from both ends of its bin never needs the neighbour bins (no neighbour-bin survivor is within D of it or
+//    of anything within e_max of it): 83 % of them at 2 048-base bins skip two look-ups of mostly absent keys.
+// Bigger bins only make the rules more conservative where they are not exact (three or more survivors in a bin: kept; rule 2 sees more
+// bystanders).  Read-strands with more survivors than the table takes go to k_prune (list mode).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512)
+k_prune_v2(int n_rs, const uint64_t* __restrict__ surv, const uint32_t* __restrict__ surv_cnt, int scap, uint64_t* __restrict__ surv2, uint32_t* __restrict__ surv_cnt2,
+           int scap2, uint32_t D, int e_max, int bb, int hbits, uint32_t n_max, uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap,
+           unsigned long long* __restrict__ stats, uint32_t* __restrict__ ov_list, uint32_t* __restrict__ ov_cnt, int ov_cap) {
+  extern __shared__ __align__(16) uint32_t sm[];
+  __shared__ uint32_t n_keep, full;
+  const int rs = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+  const uint32_t n = surv_cnt[rs];
+  if (n > (uint32_t)scap) { if (tid == 0) surv_cnt2[rs] = 0xFFFFFFFFu; return; }      // already on the heavy list (K1)
+  if (n == 0) { if (tid == 0) surv_cnt2[rs] = 0; return; }
+  if (n > n_max) {                                                                   // more than the table takes: k_prune does this one
+    if (tid == 0) { const uint32_t f = atomicAdd(ov_cnt, 1u); if (f < (uint32_t)ov_cap) ov_list[f] = (uint32_t)rs; else GS_ADD(stats, GS_OVERFLOW_SURV, 1ull); }
+    return;
+  }
+  const uint32_t H = 1u << hbits, hmask = H - 1u; const int hshift = 32 - hbits;
+  uint32_t* htag = sm; uint32_t* hmin = sm + H; uint32_t* hmax = hmin + H;
+  { uint4* t4 = (uint4*)sm; for (uint32_t w = tid; w < (3u * H) >> 2; w += nthr) t4[w] = make_uint4(0, 0, 0, 0); }
+  if (tid == 0) { n_keep = 0; full = 0; }
+  __syncthreads();
+  const uint64_t* in = surv + (size_t)rs * scap;
+  uint64_t* out = surv2 + (size_t)rs * scap2;
+  const uint32_t bmask = (1u << bb) - 1u;
+  for (uint32_t i = tid; i < n; i += nthr) {
+    const uint32_t x = (uint32_t)(in[i] >> 32), r = x >> bb, off = x & bmask;
+    const uint32_t h = k5_insert(htag, hmask, hshift, r, true);
+    if (h == 0xFFFFFFFFu) full = 1u; else { atomicMax(&hmin[h], 0x10000u - off); atomicMax(&hmax[h], off + 1u); }
+  }
+  __syncthreads();
+  const uint32_t edge = D + (uint32_t)max(e_max, 0);
+  if (!full)
+    for (uint32_t i0 = 0; i0 < n; i0 += nthr) {
+      const uint32_t i = i0 + tid;
+      bool keep = false; uint64_t ent = 0;
+      if (i < n) {
+        ent = in[i];
+        const uint32_t x = (uint32_t)(ent >> 32), r = x >> bb, off = x & bmask;
+        uint32_t town, tlf = 0, trt = 0, hlf = 0xFFFFFFFFu, hrt = 0xFFFFFFFFu;
+        const uint32_t hown = k5_find(htag, hmask, hshift, r, town);
+        if (off < edge && r > 0) hlf = k5_find(htag, hmask, hshift, r - 1u, tlf);
+        if (off + edge >= (1u << bb)) hrt = k5_find(htag, hmask, hshift, r + 1u, trt);
+        const uint32_t co = (town & K5_FE) ? 3u : ((town & K5_FD) ? 2u : 1u);
+        const uint32_t omin = 0x10000u - hmin[hown], omax = hmax[hown] - 1u, rbase = r << bb;
+        const bool cl = (tlf & K5_FC) != 0u, cr = (trt & K5_FC) != 0u;
+        // (1) isolation: two entries in the bin: the other one is max - min away; three or more: keep
+        keep = co >= 3u || (co == 2u && omax - omin <= D);
+        uint32_t lmin = 0, lmax = 0, rmin = 0, rmax = 0;
+        if (cl) { lmin = 0x10000u - hmin[hlf]; lmax = hmax[hlf] - 1u; }
+        if (cr) { rmin = 0x10000u - hmin[hrt]; rmax = hmax[hrt] - 1u; }
+        if (!keep && cl) keep = x - (rbase - (1u << bb) + lmax) <= D;
+        if (!keep && cr) keep = (rbase + (1u << bb) + rmin) - x <= D;
+        // (2) tight cluster: everything in the three bins (which cover x -+ (D + e_max)) spans at most e_max positions
+        if (keep && e_max >= 0) {
+          uint32_t gmin = rbase + omin, gmax = rbase + omax;
+          if (cl) gmin = rbase - (1u << bb) + lmin;
+          if (cr) gmax = rbase + (1u << bb) + rmax;
+          if (gmax - gmin <= (uint32_t)e_max) keep = false;
+        }
+      }
+      const unsigned long long bk = __ballot(keep);
+      if (bk) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&n_keep, (uint32_t)__popcll(bk));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (keep) { const uint32_t sl = base + (uint32_t)__popcll(bk & ((1ull << lane) - 1ull)); if (sl < (uint32_t)scap2) out[sl] = ent; }
+      }
+    }
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t k = n_keep;
+    if (full || k > (uint32_t)scap2) {
+      // table full (cannot happen with n <= n_max < slots), or more kept than K2's LDS tier takes: region-sized bins keep a few more than k_prune's
+      // 256-base bins do (three survivors in one region are all kept), so k_prune gets the last word before the heavy tier -- a read-strand on the
+      // heavy list stalls the two-stream pipeline for its whole sub-batch
+      const uint32_t f = atomicAdd(ov_cnt, 1u); if (f < (uint32_t)ov_cap) ov_list[f] = (uint32_t)rs; else GS_ADD(stats, GS_OVERFLOW_SURV, 1ull);
+    } else {
+      surv_cnt2[rs] = k;
+      GS_ADD(stats, GS_PRUNED, (unsigned long long)(n - k));
+    }
+  }
+}
+
 int gm_launch_prune(int n_reads, int read_len, int window_len, int e_max, int n_slabs, int slab_bits, const uint64_t* d_surv, const uint32_t* d_surv_cnt,
                     const uint32_t* d_surv_seg, int scap,
                     uint64_t* d_surv2, uint32_t* d_surv_cnt2, int scap2, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
@@ -136,6 +251,28 @@ int gm_launch_prune(int n_reads, int read_len, int window_len, int e_max, int n_
   if (n_reads == 0) return GM_OK;
   const uint32_t D = (uint32_t)std::max(window_len, read_len);
   if (e_max > read_len) e_max = read_len;
+  if (!d_rs_cnt && !gm_tune("GM_PRUNE_V1") && D + (uint32_t)std::max(0, e_max) <= 65535u) {
+    // k_prune_v2 for every read-strand; the few with more survivors than its table takes are listed and done by k_prune below (list mode)
+    int dev = 0; GM_HIP(hipGetDevice(&dev));
+    static uint32_t* ov[16] = {nullptr}; static int ov_cap[16] = {0};
+    if (dev >= 0 && dev < 16) {
+      const int need = std::max(4096, 2 * n_reads);
+      if (need > ov_cap[dev]) { if (ov[dev]) { GM_HIP(hipDeviceSynchronize()); (void)hipFree(ov[dev]); } GM_HIP(hipMalloc(&ov[dev], (size_t)(need + 4) * 4)); ov_cap[dev] = need; }
+      uint32_t* ovc = ov[dev] + ov_cap[dev];
+      GM_HIP(hipMemsetAsync(ovc, 0, 4, stream));
+      int bb = 11; while ((1u << bb) < D + (uint32_t)std::max(0, e_max)) bb++;
+      int hb = 12; if (const char* e = gm_tune("GM_PRUNE_HBITS")) hb = std::max(6, std::min(13, atoi(e)));
+      const uint32_t n_max = (3u << hb) / 4u;
+      const size_t lds2 = (size_t)12 << hb;
+      static size_t configured2 = 0;
+      if (lds2 > 48 * 1024 && lds2 > configured2) { GM_HIP(hipFuncSetAttribute((const void*)k_prune_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); configured2 = lds2; }
+      hipLaunchKernelGGL(k_prune_v2, dim3(n_reads * 2), dim3(512), lds2, stream, n_reads * 2, d_surv, d_surv_cnt, scap, d_surv2, d_surv_cnt2, scap2, D, e_max, bb, hb, n_max,
+                         d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, ov[dev], ovc, ov_cap[dev]);
+      GM_HIP(hipGetLastError());
+      return gm_launch_prune(n_reads, read_len, window_len, e_max, n_slabs, slab_bits, d_surv, d_surv_cnt, d_surv_seg, scap, d_surv2, d_surv_cnt2, scap2,
+                             d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, stream, ov[dev], ovc, ov_cap[dev]);
+    }
+  }
   int bin_bits = 1; while ((1u << bin_bits) < D + (uint32_t)std::max(0, e_max)) bin_bits++;
   if (bin_bits > 12) { gm_set_error("prune: D = %u does not fit the 12-bit bin offsets", D); return GM_E_ARG; }
   // table for one slab's segment: twice the expected share of the survivor capacity (segments beyond half the table go to the heavy tier)
@@ -146,7 +283,7 @@ int gm_launch_prune(int n_reads, int read_len, int window_len, int e_max, int n_
   if (lds > 48 * 1024 && lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_prune, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
   // latency-bound (hash probes): as many lanes per read-strand as a segment has work for
   const int pthreads = gm_tune("GM_PRUNE_THREADS") ? atoi(gm_tune("GM_PRUNE_THREADS")) : std::min(1024, std::max(128, (1 << hbits) / 8));
-  hipLaunchKernelGGL(k_prune, dim3(d_rs_cnt ? rs_cap : n_reads * 2), dim3(pthreads), lds, stream, n_reads * 2, d_surv, d_surv_cnt, d_surv_seg, scap, d_surv2, d_surv_cnt2, scap2,
+  hipLaunchKernelGGL(k_prune, dim3(d_rs_cnt ? std::min(rs_cap, 1024) : n_reads * 2), dim3(pthreads), lds, stream, n_reads * 2, d_surv, d_surv_cnt, d_surv_seg, scap, d_surv2, d_surv_cnt2, scap2,
                      D, e_max, bin_bits, hbits, segs, slab_bits, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, d_rs_list, d_rs_cnt);
   GM_HIP(hipGetLastError());
   return GM_OK;

@@ -138,6 +138,8 @@ KERNEL_VARIANTS = [
     {"GM_SLAB_BITS": "18", "GM_K1_V4": "1", "GM_SCAP": "256", "GM_SCAP2": "64"},   # v4 survivors beyond the LDS tiers: heavy tier (re-emission by the lane-per-list kernel)
     {"GM_SLAB_BITS": "18", "GM_K1_V2": "1"},                 # the lane-per-list kernel (also the heavy tier's re-emission)
     {"GM_NO_PRUNE": "1"},                                    # K2 on the unpruned survivors
+    {"GM_PRUNE_V1": "1"},                                    # the first prune kernel (256-base bins, compare-and-swap updates) for every read-strand
+    {"GM_PRUNE_HBITS": "6"},                                 # k_prune_v2 with a 64-slot table: most read-strands overflow it and go to k_prune in list mode
     {"GM_SCAP": "256", "GM_SCAP2": "64"},                    # small LDS tiers: most read-strands take the heavy tier
     {"GM_SLAB_BITS": "18", "GM_K1_V5": "1"},                 # k_lookup_v5 forced (wave-per-list streaming, strip lists, region table + fused prune in LDS)
     {"GM_NO_BUCKETS": "1", "GM_K1_V5": "1"},                 # v5 on a one-slab index
@@ -752,7 +754,7 @@ def test_full_size_genome_vs_oracle(gm, oracle_lib):
     kern = gm.lib().gm_last_lookup_kernel().decode()
     got_p = s.map_pairs(m1, m2, mode="opp-in", min_insert=100, max_insert=600)
     s.close(); ix.close()
-    assert kern == "k_lookup_v4", kern
+    assert kern == "k_lookup_v5", kern
     assert got == want, _first_diff(got, want)
     assert sum(1 for l in got.split(b"\n") if l and l.split(b"\t")[2] in high) > 1000       # hits at global positions >= 2^31
     assert got_p == want_p, _first_diff(got_p, want_p)
