@@ -40,7 +40,7 @@ typedef __attribute__((address_space(3))) uint32_t k5_lds_u32;
 #define K5_LDS_OR(off, m) __hip_atomic_fetch_or(K5_LDS(off), (m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
 #define K5_Q 6            // list chunks in flight per wave
-enum { C_NLISTS = 0, C_NCAND, C_OVERFLOW, C_NMEMB, C_NKEEP, C_WORDS = 8 };
+enum { C_NCAND = 0, C_OVERFLOW, C_NMEMB, C_NKEEP, C_NLISTS /* two words: read-strands alternate */, C_SINK = 6, C_WORDS = 8 };
 
 // Diagnostic build (-DK5_STAMPS): thread 0 of every workgroup adds the cycles between the phase boundaries of each read-strand to k5_stamps[]
 // (setup, pass A, pass B, region table, rules + output, clears); gm_debug_k5_stamps() reads and resets them.  No stamp executes in the normal build.
@@ -104,7 +104,7 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
   uint32_t* rec = twice + (1u << a.ltw);
   uint32_t* srec = rec + 4 * a.NL;
   uint8_t* codes = (uint8_t*)(srec + 4 * a.NL);
-  uint32_t* ctrl = (uint32_t*)(codes + ((a.read_len + 15) & ~15));
+  uint32_t* ctrl = (uint32_t*)(codes + 2 * ((a.read_len + 15) & ~15));           // two code buffers (this read-strand's and the next one's)
   const uint32_t smask4 = wmask << 2, tmask4 = tmask << 2, swb = 4u << lsw;
   const int sh_a = rb - 2, sh_b = rb + lsw;
   const uint32_t hmask = (1u << a.hbits) - 1u; const int hshift = 32 - a.hbits;
@@ -127,7 +127,54 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
 #ifdef K5_STAMPS
   unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
-  for (int rs = blockIdx.x; rs < 2 * a.n_reads; rs += gridDim.x) {
+  // Set-up of a read-strand (k-mers -> map indexes -> directory entries) one read-strand ahead: while the passes of read-strand n run, the
+  // directory words of read-strand n + 1 are already on their way (two dependent HBM round trips and a 19-step loop per k-mer off the critical
+  // path).  One k-mer per thread (NL <= threads); longer reads take the plain path.
+  const bool ahead = a.NL <= nthr;
+  uint8_t* cbuf[2] = {codes, codes + ((a.read_len + 15) & ~15)};
+  uint32_t pf_b = 0, pf_e = 0, pf_sb = 0, pf_se = 0, pf_mi = 0; bool pf_ok = false;
+  auto fill_codes = [&](const int r, uint8_t* cb) {
+    if (r >= 2 * a.n_reads) return;
+    const uint32_t* rw = a.reads + (size_t)(r >> 1) * a.read_words;
+    for (int i = tid; i < a.read_len; i += nthr) cb[i] = (uint8_t)gm_read_code(rw, a.read_len, r & 1, ix.colour, i);
+  };
+  auto kmer_ahead = [&](const int r, const uint8_t* cb) {      // the four directory words of this thread's k-mer of read-strand r: loads issued, used at the next top
+    pf_ok = false;
+    int sn = 0, i = 0; uint32_t mapidx = 0;
+    if (r < 2 * a.n_reads && tid < a.NL) {
+      sn = tid / a.max_n_kmers; i = tid - sn * a.max_n_kmers;
+      const int span = ix.seed[sn].span;
+      if (i >= ix.colour && i + span <= a.read_len) { mapidx = gm_mapidx(ix, ix.seed[sn].mask, span, cb + i); pf_ok = true; }
+    }
+    // (unconditional loads and, at the next top, an unconditional use: conditional ones leave the compiler's counter model with "maybe pending" loads
+    // and it then waits for vmcnt(0) inside the streaming loops)
+    const uint32_t* dir = ix.seed[sn].dir + (size_t)mapidx * (uint32_t)S;
+    pf_b = dir[0]; pf_e = dir[S]; pf_sb = ix.seed[sn].sdir[mapidx]; pf_se = ix.seed[sn].sdir[mapidx + 1]; pf_mi = ((uint32_t)i << 16) | (uint32_t)sn;
+  };
+  if (ahead) { fill_codes(blockIdx.x, cbuf[0]); __syncthreads(); kmer_ahead(blockIdx.x, cbuf[0]); }
+  int it = 0;
+  for (int rs = blockIdx.x; rs < 2 * a.n_reads; rs += gridDim.x, it++) {
+    // (the list counter alternates between two words: with the set-up ahead there is no barrier between thread 0's reset at the end of a
+    // read-strand and the first additions of the next one; the other word was reset a whole read-strand earlier)
+    uint32_t* const cnl = &ctrl[C_NLISTS + (it & 1)];
+    if (ahead) {
+      fill_codes(rs + (int)gridDim.x, cbuf[(it + 1) & 1]);
+      const uint32_t b = pf_b, e = pf_e, sb = pf_sb, se = pf_se;
+      if ((b ^ e ^ sb ^ se) == 0x9E3779B9u && e - b == 0x7F4A7C15u) ctrl[C_SINK] = 1u;        // never true for list bounds: pins the use of all four words here
+      if (pf_ok) {
+        my_lookups++;
+        if (e != b && e - b <= ix.list_cutoff) {               // ref: mapping.c:497 (longer lists are skipped, not deleted)
+          const uint32_t sn = pf_mi & 0xFFFFu;
+          my_entries += (e - b);
+          const uint32_t j = atomicAdd(cnl, 1u);
+          const uint64_t ptr = (uint64_t)((ix.seed[sn].pos + b) - pos0), sptr = (uint64_t)((ix.seed[sn].spos + sb) - spos0);
+          *(uint4*)&rec[4 * j] = make_uint4((uint32_t)ptr, (uint32_t)(ptr >> 32), e - b, pf_mi);
+          *(uint4*)&srec[4 * j] = make_uint4((uint32_t)sptr, (uint32_t)(sptr >> 32), se - sb, 0u);
+        }
+      }
+      __syncthreads();                                         // rec[] of this read-strand and the codes of the next one are in; the tables are clear
+      kmer_ahead(rs + (int)gridDim.x, cbuf[(it + 1) & 1]);
+    } else {
     const int rd = rs >> 1, st = rs & 1;
     const uint32_t* rw = a.reads + (size_t)rd * a.read_words;
     for (int i = tid; i < a.read_len; i += nthr) codes[i] = (uint8_t)gm_read_code(rw, a.read_len, st, ix.colour, i);
@@ -144,14 +191,16 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
       if (e == b || e - b > ix.list_cutoff) continue;          // ref: mapping.c:497 (longer lists are skipped, not deleted)
       const uint32_t sb = ix.seed[sn].sdir[mapidx], se = ix.seed[sn].sdir[mapidx + 1];
       my_entries += (e - b);
-      const uint32_t j = atomicAdd(&ctrl[C_NLISTS], 1u);
+      const uint32_t j = atomicAdd(cnl, 1u);
       const uint64_t ptr = (uint64_t)((ix.seed[sn].pos + b) - pos0), sptr = (uint64_t)((ix.seed[sn].spos + sb) - spos0);
       *(uint4*)&rec[4 * j] = make_uint4((uint32_t)ptr, (uint32_t)(ptr >> 32), e - b, ((uint32_t)i << 16) | (uint32_t)sn);
       *(uint4*)&srec[4 * j] = make_uint4((uint32_t)sptr, (uint32_t)(sptr >> 32), se - sb, 0u);
     }
     __syncthreads();
+    }
+    __syncthreads();
     K5_STAMP(0);
-    const int nl = (int)ctrl[C_NLISTS];
+    const int nl = (int)*cnl;
 
     // One chunk of a list: n <= 256 entries from src, W = ceil(n / 64) per lane.  Wave-uniform (SGPRs).
     struct Step { uint32_t n, ysn; const uint32_t* src; };
@@ -217,11 +266,12 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
       Step sd[K5_Q]; k5_u32x4 sv[K5_Q];
 #pragma unroll
       for (int q = 0; q < K5_Q; q++) { gen(sd[q]); issue(sd[q], sv[q]); }
-      bool more = true;
-      while (more) {
+      // No exit from the middle of a round: a step with n == 0 (generator exhausted) is a no-op, so the loop tests sd[0] once per round.  (An
+      // exit per step merges, in the structurized loop, the counter states behind each of the K5_Q loads at the loop header, and the compiler
+      // then waits for vmcnt(0) at every step: one memory round trip per step instead of a K5_Q-deep pipeline.)
+      while (sd[0].n) {
 #pragma unroll
         for (int q = 0; q < K5_Q; q++) {
-          if (!sd[q].n) { more = false; break; }
           K5_WAIT_OLDEST(sv[q]);
           // Marks only have to cover every real entry (pass B and the region table apply the exact rule): the last active lane also
           // marks the up-to-3 words it read past the chunk.
@@ -287,12 +337,10 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
         }
       }
       Step (&sd)[K5_Q] = sdB; k5_u32x4 (&sv)[K5_Q] = svB;
-      bool more = true;
-      while (more) {
+      while (sd[0].n) {                                                 // (no exit inside a round, as in pass A)
 #pragma unroll
         for (int q = 0; q < K5_Q; q++) {
           const Step& s = sd[q];
-          if (!s.n) { more = false; break; }
           K5_WAIT_OLDEST(sv[q]);
           const uint32_t W = (s.n + 63u) >> 6;
           const uint32_t e0 = k5_lane_times(lane, W);
@@ -431,7 +479,8 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
           if (hs < (uint32_t)a.heavy_cap) a.heavy_list[hs] = (uint32_t)rs; else GS_ADD(a.stats, GS_OVERFLOW_SURV, 1ull);
         }
       }
-      for (int c = 0; c < C_WORDS; c++) ctrl[c] = 0;
+      for (int c = 0; c < C_NLISTS; c++) ctrl[c] = 0;
+      *cnl = 0;
     }
     { uint4* t4 = (uint4*)smem; for (int w = tid; w < tab_q; w += nthr) t4[w] = make_uint4(0, 0, 0, 0); }
     K5_STAMP(5);
@@ -542,7 +591,7 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   // the fixed cost per read-strand (144 KB of table clears, six barriers) pays off from a few ten thousand list entries per read-strand
   if (!forced && entries < 30000.0) return 0;
   // LDS: twice (1/8 of seen) | seen | 32 B per list | codes | control words
-  const size_t fixed = (size_t)32 * NL + (size_t)((read_len + 15) & ~15) + C_WORDS * 4;
+  const size_t fixed = (size_t)32 * NL + 2 * (size_t)((read_len + 15) & ~15) + C_WORDS * 4;
   const size_t budget = 160 * 1024 - 512;
   int lsw = 15;
   if (const char* e = gm_tune("GM_K5_LSW")) lsw = std::max(8, std::min(15, atoi(e)));
