@@ -39,8 +39,10 @@ typedef __attribute__((address_space(3))) uint32_t k5_lds_u32;
 #define K5_LDS(off) ((k5_lds_u32*)(uintptr_t)(uint32_t)(off))
 #define K5_LDS_OR(off, m) __hip_atomic_fetch_or(K5_LDS(off), (m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
-#define K5_Q 6            // list chunks in flight per wave
-enum { C_NCAND = 0, C_OVERFLOW, C_NMEMB, C_NKEEP, C_NLISTS /* two words: read-strands alternate */, C_SINK = 6, C_WORDS = 8 };
+#ifndef K5_Q
+#define K5_Q 6            // list chunks in flight per wave (8 and 10 measured: no gain)
+#endif
+enum { C_NCAND = 0, C_OVERFLOW, C_NMEMB, C_NKEEP, C_NSTRIP, C_NEDGE, C_NLISTS /* two words: read-strands alternate */, C_SINK = 8, C_WORDS = 12 };
 
 // Diagnostic build (-DK5_STAMPS): thread 0 of every workgroup adds the cycles between the phase boundaries of each read-strand to k5_stamps[]
 // (setup, pass A, pass B, region table, rules + output, clears); gm_debug_k5_stamps() reads and resets them.  No stamp executes in the normal build.
@@ -386,15 +388,29 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
     const uint32_t nc = ctrl[C_NCAND];
     bool fallback = nc > (uint32_t)a.cand_limit;
     // ================= exact stage 1: region table over the candidates =================
+    // A wave pays the longest chain of LDS round trips among its lanes, so the rare cases are taken out of the main loops and worked off
+    // densely afterwards: the overlap-strip marks here (2 % of the candidates, but some lane of most waves), the neighbour-region look-ups of
+    // stage 2 below.  Their lists (region numbers, then candidate indexes) live in rec[] / srec[], dead since pass B.
+    uint32_t* const elist = rec; const uint32_t ecap = 8u * (uint32_t)a.NL;
     if (!fallback) {
       for (uint32_t i = tid; i < nc; i += nthr) {
         const uint32_t p = candp[i], r = p >> rb, off = p & rmask;
         const uint32_t h = k5_insert(htag, hmask, hshift, r, true);
-        bool ok = h != 0xFFFFFFFFu;
-        if (ok) { atomicMax(&hmin[h], 0x10000u - off); atomicMax(&hmax[h], off + 1u); }
-        if (off < ovl && r > 0) ok = (k5_insert(htag, hmask, hshift, r - 1u, false) != 0xFFFFFFFFu) && ok;   // ref: mapping.c:521-533
-        if (!ok) ctrl[C_OVERFLOW] = 1u;
+        if (h != 0xFFFFFFFFu) {
+          atomicMax(&hmin[h], 0x10000u - off); atomicMax(&hmax[h], off + 1u);
+          candp[i] = (h << 16) | off;                          // slot and offset: stage 2 reads the region back from the tag (no second probe sequence)
+          if (off < ovl && r > 0) {                            // the overlap strip also counts for the region before (ref: mapping.c:521-533)
+            const uint32_t j = atomicAdd(&ctrl[C_NSTRIP], 1u);
+            if (j < ecap) elist[j] = r - 1u; else ctrl[C_OVERFLOW] = 1u;
+          }
+        } else ctrl[C_OVERFLOW] = 1u;
       }
+    }
+    __syncthreads();
+    if (!fallback) {
+      const uint32_t ns = min(ctrl[C_NSTRIP], ecap);
+      for (uint32_t j = tid; j < ns; j += nthr)
+        if (k5_insert(htag, hmask, hshift, elist[j], false) == 0xFFFFFFFFu) ctrl[C_OVERFLOW] = 1u;
     }
     __syncthreads();
     K5_STAMP(3);
@@ -402,24 +418,64 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
     // ================= exact stage 2: the reference's rule (ref: mapping.c:733-742), prune rules (gm_prune.hip), output =================
     if (!fallback) {
       unsigned long long* out = (unsigned long long*)a.out + (size_t)rs * a.out_cap;
+      // The neighbour regions only matter near the region's ends: a candidate at least D + e_max away from both has no neighbour-region
+      // candidate within D of it or of anything within e_max of it, so both rules see the same with the neighbours left out (83 % of the
+      // members at 2 048-base regions; each look-up of an absent region is a full probe sequence).
+      const uint32_t edge = a.D + (uint32_t)max(a.e_max, 0);
+      auto emit = [&](const bool memb, const bool keep, const uint32_t p, const uint32_t i) {      // (called by whole waves)
+        const unsigned long long bm = __ballot(memb), bk = __ballot(keep);
+        if (bm) {
+          uint32_t base = 0;
+          if (lane == 0) { atomicAdd(&ctrl[C_NMEMB], (uint32_t)__popcll(bm)); if (bk) base = atomicAdd(&ctrl[C_NKEEP], (uint32_t)__popcll(bk)); }
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (keep) {
+            const uint32_t slot = base + (uint32_t)__popcll(bk & ((1ull << lane) - 1ull));
+            const uint32_t y16 = candy[i];
+            if (slot < (uint32_t)a.out_cap) out[slot] = ((unsigned long long)p << 32) | ((unsigned long long)(y16 >> 4) << 16) | (y16 & 15u);
+          }
+        }
+      };
+      // (2a) every candidate: its region's tag; members away from the region's ends are decided here, the rest goes to the list
       for (uint32_t i0 = 0; i0 < nc; i0 += nthr) {
         const uint32_t i = i0 + tid;
         bool memb = false, keep = false; uint32_t p = 0;
         if (i < nc) {
-          p = candp[i];
-          const uint32_t r = p >> rb, off = p & rmask;
-          uint32_t town, tlf = 0, trt = 0;
-          const uint32_t hown = k5_find(htag, hmask, hshift, r, town);
+          const uint32_t w = candp[i], h = w >> 16, off = w & 0xFFFFu, town = htag[h], r = (town >> 8) - 1u;
+          p = (r << rb) | off;
+          const bool is_m = (town & K5_FB) != 0u;
+          const bool nb = is_m ? (a.prune && ((off < edge && r > 0) || off + edge >= (1u << rb))) : (off < ovl && r > 0);
+          if (nb) {
+            const uint32_t j = atomicAdd(&ctrl[C_NEDGE], 1u);
+            if (j < ecap) elist[j] = i; else ctrl[C_OVERFLOW] = 1u;
+          } else if (is_m) {
+            memb = true; keep = true;
+            if (a.prune) {
+              const uint32_t co = (town & K5_FE) ? 3u : ((town & K5_FD) ? 2u : 1u);
+              const uint32_t span = (hmax[h] - 1u) - (0x10000u - hmin[h]);
+              keep = co >= 3u || (co == 2u && span <= a.D);                         // (1) isolation
+              if (keep && a.e_max >= 0 && span <= (uint32_t)a.e_max) keep = false;    // (2) tight cluster
+            }
+          }
+        }
+        emit(memb, keep, p, i);
+      }
+      __syncthreads();
+      // (2b) the listed candidates, with the regions before / behind theirs
+      const uint32_t ne = min(ctrl[C_NEDGE], ecap);
+      for (uint32_t j0 = 0; j0 < ne; j0 += nthr) {
+        const uint32_t j = j0 + tid;
+        bool memb = false, keep = false; uint32_t p = 0, i = 0;
+        if (j < ne) {
+          i = elist[j];
+          const uint32_t w = candp[i], hown = w >> 16, off = w & 0xFFFFu, town = htag[hown], r = (town >> 8) - 1u;
+          p = (r << rb) | off;
+          uint32_t tlf = 0, trt = 0;
           memb = (town & K5_FB) != 0u;
           uint32_t hlf = 0xFFFFFFFFu; bool have_lf = false;
           if (!memb && off < ovl && r > 0) { hlf = k5_find(htag, hmask, hshift, r - 1u, tlf); have_lf = true; memb = (tlf & K5_FB) != 0u; }
           if (memb) {
             keep = true;
             if (a.prune) {
-              // The neighbour regions only matter near the region's ends: a candidate at least D + e_max away from both has no neighbour-region
-              // candidate within D of it or of anything within e_max of it, so both rules see the same with the neighbours left out (83 % of the
-              // members at 2 048-base regions; each look-up of an absent region is a full probe sequence, and the wave pays its longest).
-              const uint32_t edge = a.D + (uint32_t)max(a.e_max, 0);
               uint32_t hrt = 0xFFFFFFFFu; trt = 0;
               if (off < edge) { if (!have_lf && r > 0) hlf = k5_find(htag, hmask, hshift, r - 1u, tlf); } else tlf = 0;
               if (off + edge >= (1u << rb)) hrt = k5_find(htag, hmask, hshift, r + 1u, trt);
@@ -444,20 +500,11 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
             }
           }
         }
-        const unsigned long long bm = __ballot(memb), bk = __ballot(keep);
-        if (bm) {
-          uint32_t base = 0;
-          if (lane == 0) { atomicAdd(&ctrl[C_NMEMB], (uint32_t)__popcll(bm)); if (bk) base = atomicAdd(&ctrl[C_NKEEP], (uint32_t)__popcll(bk)); }
-          base = __builtin_amdgcn_readfirstlane(base);
-          if (keep) {
-            const uint32_t slot = base + (uint32_t)__popcll(bk & ((1ull << lane) - 1ull));
-            const uint32_t y16 = candy[i];
-            if (slot < (uint32_t)a.out_cap) out[slot] = ((unsigned long long)p << 32) | ((unsigned long long)(y16 >> 4) << 16) | (y16 & 15u);
-          }
-        }
+        emit(memb, keep, p, i);
       }
     }
     __syncthreads();
+    if (ctrl[C_OVERFLOW] != 0u) fallback = true;                    // (the list of stage 2 ran over)
     if (!fallback && a.prune && ctrl[C_NKEEP] > (uint32_t)a.out_cap) fallback = true;   // more kept than K2's LDS tier takes: k_prune's finer bins get the last word before the heavy tier
     K5_STAMP(4);
 #ifdef K5_STAMPS
