@@ -45,12 +45,13 @@ typedef __attribute__((address_space(3))) uint32_t k5_lds_u32;
 enum { C_NCAND = 0, C_OVERFLOW, C_NMEMB, C_NKEEP, C_NSTRIP, C_NEDGE, C_NLISTS /* two words: read-strands alternate */, C_SINK = 8, C_WORDS = 12 };
 
 // Diagnostic build (-DK5_STAMPS): thread 0 of every workgroup adds the cycles between the phase boundaries of each read-strand to k5_stamps[]
-// (setup, pass A, pass B, region table, rules + output, clears); gm_debug_k5_stamps() reads and resets them.  No stamp executes in the normal build.
+// (0-5: setup, pass A, pass B, region table, rules + output, clears; 6, 7: candidates, fallbacks; 8-11: parts of set-up / the exact stages, taken out of
+// the phase they sit in); gm_debug_k5_stamps() reads and resets all 16.  No stamp executes in the normal build.
 #ifdef K5_STAMPS
-__device__ unsigned long long k5_stamps[8];
+__device__ unsigned long long k5_stamps[16];
 #define K5_STAMP(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&k5_stamps[i], t_ - t_prev); t_prev = t_; } } while (0)
 extern "C" int gm_debug_k5_stamps(unsigned long long* out) {
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(k5_stamps), sizeof z) != hipSuccess) return GM_E_NODEVICE;
   if (hipMemcpyToSymbol(HIP_SYMBOL(k5_stamps), z, sizeof z) != hipSuccess) return GM_E_NODEVICE;
   return GM_OK;
@@ -133,49 +134,83 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
   // directory words of read-strand n + 1 are already on their way (two dependent HBM round trips and a 19-step loop per k-mer off the critical
   // path).  One k-mer per thread (NL <= threads); longer reads take the plain path.
   const bool ahead = a.NL <= nthr;
-  uint8_t* cbuf[2] = {codes, codes + ((a.read_len + 15) & ~15)};
-  uint32_t pf_b = 0, pf_e = 0, pf_sb = 0, pf_se = 0, pf_mi = 0; bool pf_ok = false;
+  const uint32_t cpad = (uint32_t)((a.read_len + 15) & ~15);     // (code buffer b = codes + b * cpad: pointer arithmetic keeps the LDS address space, a pointer array does not)
+  uint32_t pf_b = 0, pf_e = 0, pf_sb = 0, pf_se = 0; bool pf_ok = false;
   auto fill_codes = [&](const int r, uint8_t* cb) {
     if (r >= 2 * a.n_reads) return;
     const uint32_t* rw = a.reads + (size_t)(r >> 1) * a.read_words;
     for (int i = tid; i < a.read_len; i += nthr) cb[i] = (uint8_t)gm_read_code(rw, a.read_len, r & 1, ix.colour, i);
   };
+  // A thread keeps the same k-mer slot (seed, offset in the read) for every read-strand: its seed's span and mask stay in registers, the seed's
+  // pointers in a small LDS table.  (ix.seed[sn] with a run-time sn is a chain of loads from the kernel-argument segment -- a memory round trip
+  // per field and use: 4 k cycles per read-strand before.)
+  uint32_t* stab = ctrl + C_WORDS;                             // per seed: dir, sdir (pointers), pos - pos0, spos - spos0 (elements)
+  if (tid < ix.n_seeds) {
+    const GmSeedDev& sd = ix.seed[tid];
+    const uint64_t d = (uint64_t)(uintptr_t)sd.dir, sdp = (uint64_t)(uintptr_t)sd.sdir, po = (uint64_t)(sd.pos - pos0), so = (uint64_t)(sd.spos - spos0);
+    *(uint4*)&stab[8 * tid] = make_uint4((uint32_t)d, (uint32_t)(d >> 32), (uint32_t)sdp, (uint32_t)(sdp >> 32));
+    *(uint4*)&stab[8 * tid + 4] = make_uint4((uint32_t)po, (uint32_t)(po >> 32), (uint32_t)so, (uint32_t)(so >> 32));
+  }
+  int k_sn = 0, k_i = 0, k_span = 0; uint64_t k_mask = 0; bool k_ok = false;
+  // (the k-mer slots are spread over all the waves -- every stride-th thread has one: the scattered directory loads of a wave full of k-mers
+  // take 64 cache lines per instruction, and a few late waves hold up the barrier behind pass A)
+  const int k_stride = max(1, nthr / max(1, a.NL)), k_slot = tid / k_stride;
+  if (ahead && tid % k_stride == 0 && k_slot < a.NL) {
+    k_sn = k_slot / a.max_n_kmers; k_i = k_slot - k_sn * a.max_n_kmers;
+    k_span = ix.seed[k_sn].span; k_mask = ix.seed[k_sn].mask;
+    k_ok = k_i >= ix.colour && k_i + k_span <= a.read_len;
+    if (!k_ok) { k_span = 0; k_mask = 0; }
+  }
   auto kmer_ahead = [&](const int r, const uint8_t* cb) {      // the four directory words of this thread's k-mer of read-strand r: loads issued, used at the next top
-    pf_ok = false;
-    int sn = 0, i = 0; uint32_t mapidx = 0;
-    if (r < 2 * a.n_reads && tid < a.NL) {
-      sn = tid / a.max_n_kmers; i = tid - sn * a.max_n_kmers;
-      const int span = ix.seed[sn].span;
-      if (i >= ix.colour && i + span <= a.read_len) { mapidx = gm_mapidx(ix, ix.seed[sn].mask, span, cb + i); pf_ok = true; }
-    }
+    pf_ok = k_ok && r < 2 * a.n_reads;
+    uint32_t mapidx = 0;
+    if (!ix.hflag) {
+      // KMER_TO_MAPIDX (ref: gmapper.h:349-368) without a branch per base: eight code bytes per LDS round trip, the mask bit selects
+      for (int t0 = 0; t0 < ix.max_seed_span; t0 += 8) {
+        uint32_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int x = k_i + k_span - 1 - t0 - u; c[u] = cb[min(max(x, 0), a.read_len - 1)]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) mapidx = ((k_mask >> (t0 + u)) & 1ull) ? ((mapidx << 2) | (c[u] & 3u)) : mapidx;
+      }
+    } else if (pf_ok) mapidx = gm_mapidx(ix, k_mask, k_span, cb + k_i);
+    if (!pf_ok) mapidx = 0;
     // (unconditional loads and, at the next top, an unconditional use: conditional ones leave the compiler's counter model with "maybe pending" loads
     // and it then waits for vmcnt(0) inside the streaming loops)
-    const uint32_t* dir = ix.seed[sn].dir + (size_t)mapidx * (uint32_t)S;
-    pf_b = dir[0]; pf_e = dir[S]; pf_sb = ix.seed[sn].sdir[mapidx]; pf_se = ix.seed[sn].sdir[mapidx + 1]; pf_mi = ((uint32_t)i << 16) | (uint32_t)sn;
+    const uint4 sp = *(const uint4*)&stab[8 * k_sn];
+    // (pointers rebuilt from integers must name the global address space: a flat load also counts as an LDS operation, and every LDS wait
+    // behind it would wait for the memory round trip)
+    typedef const uint32_t __attribute__((address_space(1)))* k5_gptr;
+    const k5_gptr dir = (k5_gptr)(((uint64_t)sp.y << 32) | sp.x) + (size_t)mapidx * (uint32_t)S;
+    const k5_gptr sdir = (k5_gptr)(((uint64_t)sp.w << 32) | sp.z) + mapidx;
+    pf_b = dir[0]; pf_e = dir[S]; pf_sb = sdir[0]; pf_se = sdir[1];
   };
-  if (ahead) { fill_codes(blockIdx.x, cbuf[0]); __syncthreads(); kmer_ahead(blockIdx.x, cbuf[0]); }
+  __syncthreads();
+  if (ahead) { fill_codes(blockIdx.x, codes); __syncthreads(); kmer_ahead(blockIdx.x, codes); }
   int it = 0;
   for (int rs = blockIdx.x; rs < 2 * a.n_reads; rs += gridDim.x, it++) {
     // (the list counter alternates between two words: with the set-up ahead there is no barrier between thread 0's reset at the end of a
     // read-strand and the first additions of the next one; the other word was reset a whole read-strand earlier)
     uint32_t* const cnl = &ctrl[C_NLISTS + (it & 1)];
     if (ahead) {
-      fill_codes(rs + (int)gridDim.x, cbuf[(it + 1) & 1]);
+      fill_codes(rs + (int)gridDim.x, codes + (uint32_t)((it + 1) & 1) * cpad);
       const uint32_t b = pf_b, e = pf_e, sb = pf_sb, se = pf_se;
       if ((b ^ e ^ sb ^ se) == 0x9E3779B9u && e - b == 0x7F4A7C15u) ctrl[C_SINK] = 1u;        // never true for list bounds: pins the use of all four words here
       if (pf_ok) {
         my_lookups++;
         if (e != b && e - b <= ix.list_cutoff) {               // ref: mapping.c:497 (longer lists are skipped, not deleted)
-          const uint32_t sn = pf_mi & 0xFFFFu;
+          const uint4 so = *(const uint4*)&stab[8 * k_sn + 4];
           my_entries += (e - b);
           const uint32_t j = atomicAdd(cnl, 1u);
-          const uint64_t ptr = (uint64_t)((ix.seed[sn].pos + b) - pos0), sptr = (uint64_t)((ix.seed[sn].spos + sb) - spos0);
-          *(uint4*)&rec[4 * j] = make_uint4((uint32_t)ptr, (uint32_t)(ptr >> 32), e - b, pf_mi);
+          const uint64_t ptr = (((uint64_t)so.y << 32) | so.x) + b, sptr = (((uint64_t)so.w << 32) | so.z) + sb;
+          *(uint4*)&rec[4 * j] = make_uint4((uint32_t)ptr, (uint32_t)(ptr >> 32), e - b, ((uint32_t)k_i << 16) | (uint32_t)k_sn);
           *(uint4*)&srec[4 * j] = make_uint4((uint32_t)sptr, (uint32_t)(sptr >> 32), se - sb, 0u);
         }
       }
       __syncthreads();                                         // rec[] of this read-strand and the codes of the next one are in; the tables are clear
-      kmer_ahead(rs + (int)gridDim.x, cbuf[(it + 1) & 1]);
+      K5_STAMP(8);
+      kmer_ahead(rs + (int)gridDim.x, codes + (uint32_t)((it + 1) & 1) * cpad);
+      K5_STAMP(9);
     } else {
     const int rd = rs >> 1, st = rs & 1;
     const uint32_t* rw = a.reads + (size_t)rd * a.read_words;
@@ -200,7 +235,8 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
     }
     __syncthreads();
     }
-    __syncthreads();
+    // (no barrier behind the k-mers ahead: they read the next read-strand's codes and the seed table only, and their scattered loads -- 64 cache
+    // lines per instruction -- queue up in the address unit; the waves go on to pass A as they get through)
     K5_STAMP(0);
     const int nl = (int)*cnl;
 
@@ -407,6 +443,7 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
       }
     }
     __syncthreads();
+    K5_STAMP(10);
     if (!fallback) {
       const uint32_t ns = min(ctrl[C_NSTRIP], ecap);
       for (uint32_t j = tid; j < ns; j += nthr)
@@ -460,6 +497,7 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
         emit(memb, keep, p, i);
       }
       __syncthreads();
+      K5_STAMP(11);
       // (2b) the listed candidates, with the regions before / behind theirs
       const uint32_t ne = min(ctrl[C_NEDGE], ecap);
       for (uint32_t j0 = 0; j0 < ne; j0 += nthr) {
@@ -638,7 +676,7 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   // the fixed cost per read-strand (144 KB of table clears, six barriers) pays off from a few ten thousand list entries per read-strand
   if (!forced && entries < 30000.0) return 0;
   // LDS: twice (1/8 of seen) | seen | 32 B per list | codes | control words
-  const size_t fixed = (size_t)32 * NL + 2 * (size_t)((read_len + 15) & ~15) + C_WORDS * 4;
+  const size_t fixed = (size_t)32 * NL + 2 * (size_t)((read_len + 15) & ~15) + C_WORDS * 4 + GM_MAX_SEEDS * 32;   // (+ the seed table)
   const size_t budget = 160 * 1024 - 512;
   int lsw = 15;
   if (const char* e = gm_tune("GM_K5_LSW")) lsw = std::max(8, std::min(15, atoi(e)));

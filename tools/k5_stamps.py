@@ -12,7 +12,7 @@ ix = gm.Index(contigs); s = gm.Session(ix, max_batch_reads=131072)
 os.environ["GM_RAMP_MIN"] = "131072"
 s.map_reads(reads[:8192])
 lib = gm.lib()
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 has = hasattr(lib, "gm_debug_k5_stamps")
 if has: lib.gm_debug_k5_stamps(out)
 t = time.time(); s.map_reads(reads); dt = time.time() - t
@@ -23,4 +23,5 @@ if has:
     names = ["setup(+clear wait)", "pass A", "pass B", "region table", "rules+output", "bookkeeping+clear"]
     tot = sum(v[:6]) or 1
     for nm, x in zip(names, v): print("%-20s %6.2f %%  %8.0f ticks per read-strand" % (nm, 100.0 * x / tot, x / (2.0 * n)))
+    for nm, x in zip(["  set-up: to the first barrier", "  set-up: k-mers ahead", "  region table: main loop", "  rules: main loop (2a)"], v[8:12]): print("%-32s %8.0f ticks per read-strand (not in the phase above)" % (nm, x / (2.0 * n)))
     print("candidates per read-strand %.1f, fallbacks %d of %d" % (v[6] / (2.0 * n), v[7], 2 * n))
