@@ -382,36 +382,30 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
           K5_WAIT_OLDEST(sv[q]);
           const uint32_t W = (s.n + 63u) >> 6;
           const uint32_t e0 = k5_lane_times(lane, W);
-          bool h0 = false, h1 = false, h2 = false, h3 = false;
-          if (e0 < s.n) {
-            const uint32_t nv = s.n - e0;                      // >= 1; entries of this lane: min(W, nv)
-            uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-            t0 = *K5_LDS(((sv[q].x >> sh_a) & tmask4) | swb);
-            if (W > 1) t1 = *K5_LDS(((sv[q].y >> sh_a) & tmask4) | swb);
-            if (W > 2) t2 = *K5_LDS(((sv[q].z >> sh_a) & tmask4) | swb);
-            if (W > 3) t3 = *K5_LDS(((sv[q].w >> sh_a) & tmask4) | swb);
-            h0 = (t0 >> ((sv[q].x >> sh_b) & 31u)) & 1u;
-            h1 = nv > 1 && ((t1 >> ((sv[q].y >> sh_b) & 31u)) & 1u);
-            h2 = nv > 2 && ((t2 >> ((sv[q].z >> sh_b) & 31u)) & 1u);
-            h3 = nv > 3 && ((t3 >> ((sv[q].w >> sh_b) & 31u)) & 1u);
-          }
-          const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1), b2 = __ballot(h2), b3 = __ballot(h3);
-          const uint32_t c0 = (uint32_t)__popcll(b0), c1 = (uint32_t)__popcll(b1), c2 = (uint32_t)__popcll(b2), c3 = (uint32_t)__popcll(b3);
-          const uint32_t tot = c0 + c1 + c2 + c3;
-          if (tot) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&ctrl[C_NCAND], tot);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base + tot <= (uint32_t)a.cand_cap) {
-              const unsigned long long lt = (1ull << lane) - 1ull;
+          // the four twice[] words unconditionally (no branch per entry slot; a lane's words past its own entries -- min(W, n - e0) of them --
+          // belong to the next lane / list and are masked), the four answers as one bit mask
+          const uint32_t mine = e0 < s.n ? min(W, s.n - e0) : 0u;
+#ifdef K5_ABL_B
+          const uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = (sv[q].x ^ sv[q].y ^ sv[q].z ^ sv[q].w) == 0x12345678u;
+#else
+          const uint32_t t0 = *K5_LDS(((sv[q].x >> sh_a) & tmask4) | swb), t1 = *K5_LDS(((sv[q].y >> sh_a) & tmask4) | swb);
+          const uint32_t t2 = *K5_LDS(((sv[q].z >> sh_a) & tmask4) | swb), t3 = *K5_LDS(((sv[q].w >> sh_a) & tmask4) | swb);
+#endif
+          const uint32_t hits = (__builtin_amdgcn_ubfe(t0, __builtin_amdgcn_ubfe(sv[q].x, sh_b, 5), 1) | (__builtin_amdgcn_ubfe(t1, __builtin_amdgcn_ubfe(sv[q].y, sh_b, 5), 1) << 1) |
+                                 (__builtin_amdgcn_ubfe(t2, __builtin_amdgcn_ubfe(sv[q].z, sh_b, 5), 1) << 2) | (__builtin_amdgcn_ubfe(t3, __builtin_amdgcn_ubfe(sv[q].w, sh_b, 5), 1) << 3)) &
+                                ((1u << mine) - 1u);
+          const bool h0 = hits & 1u, h1 = hits & 2u, h2 = hits & 4u, h3 = hits & 8u;
+          // one reservation per lane with hits (8 % of the entries are candidates: a dozen lanes per step add to the same LDS word, which the
+          // LDS serialises in as many cycles -- cheaper than four ballots, their counts and a prefix per entry)
+          const uint32_t cnt = (uint32_t)__popc(hits);
+          if (cnt) {
+            uint32_t ci = atomicAdd(&ctrl[C_NCAND], cnt);
+            if (ci + cnt <= (uint32_t)a.cand_cap) {
               const uint16_t y16 = (uint16_t)(((s.ysn >> 12) & 0xFFF0u) | (s.ysn & 0xFu));
-              if (h0) { const uint32_t ci = base + (uint32_t)__popcll(b0 & lt); candp[ci] = sv[q].x; candy[ci] = y16; }
-              base += c0;
-              if (h1) { const uint32_t ci = base + (uint32_t)__popcll(b1 & lt); candp[ci] = sv[q].y; candy[ci] = y16; }
-              base += c1;
-              if (h2) { const uint32_t ci = base + (uint32_t)__popcll(b2 & lt); candp[ci] = sv[q].z; candy[ci] = y16; }
-              base += c2;
-              if (h3) { const uint32_t ci = base + (uint32_t)__popcll(b3 & lt); candp[ci] = sv[q].w; candy[ci] = y16; }
+              if (h0) { candp[ci] = sv[q].x; candy[ci++] = y16; }
+              if (h1) { candp[ci] = sv[q].y; candy[ci++] = y16; }
+              if (h2) { candp[ci] = sv[q].z; candy[ci++] = y16; }
+              if (h3) { candp[ci] = sv[q].w; candy[ci++] = y16; }
             }
           }
           gen(sd[q]); issue(sd[q], sv[q]);
