@@ -267,6 +267,7 @@ struct DevSet {
   uint32_t* d_heavy_list = nullptr; uint32_t* d_heavy_cnt = nullptr;   // read-strands beyond the LDS tier of K2
   int32_t* d_sel = nullptr; int32_t* d_sel_sidx = nullptr; uint32_t* d_sel_cnt = nullptr; uint32_t* d_sel_off = nullptr; uint32_t* d_work = nullptr; uint32_t* d_n_work = nullptr;
   GmFullRes* d_res = nullptr; uint8_t* d_ops = nullptr; uint8_t* d_back = nullptr; size_t back_stride = 0;
+  GmPostRes* d_post = nullptr; double* d_post_fw = nullptr; uint32_t* d_post_info = nullptr;   // colour space: post_sw on the device (gm_post.hip), its per-thread scratch
   // paired mode only: mate range of every window (by sorted position) and the "saved" mark (by hit slot)
   int32_t* d_pmin = nullptr; int32_t* d_pmax = nullptr; uint8_t* d_saved = nullptr; uint32_t* d_saved_list = nullptr;
 };
@@ -275,6 +276,7 @@ struct DevSet {
 // (three slots: one being filled while the host threads still work on the two sub-batches before it).
 struct HostSlot {
   GmFullRes* res = nullptr; uint8_t* ops = nullptr; uint32_t* sel_cnt = nullptr; uint32_t* sel_off = nullptr; uint32_t* reads = nullptr;
+  GmPostRes* post = nullptr; size_t post_cap = 0; bool post_on = false;      // colour space: the device's post_sw results of this sub-batch (post_on: they are there)
   size_t res_cap = 0, ops_cap = 0, n_cap = 0, reads_cap = 0; uint32_t n_work = 0;
 };
 static int slot_reserve(void** p, size_t* cap, size_t bytes) {
@@ -287,7 +289,7 @@ static int slot_reserve(void** p, size_t* cap, size_t bytes) {
   return GM_OK;
 }
 static void slot_free(HostSlot& h) {
-  void* ptrs[] = {h.res, h.ops, h.sel_cnt, h.sel_off, h.reads};
+  void* ptrs[] = {h.res, h.ops, h.sel_cnt, h.sel_off, h.reads, h.post};
   for (void* p : ptrs) if (p) (void)hipHostFree(p);
   h = HostSlot();
 }
@@ -319,8 +321,9 @@ struct gm_session {
 static void free_buffers(DevSet& D) {
   void* ptrs[] = {D.d_xover, D.d_reads, D.d_initbp, D.d_surv, D.d_surv_cnt, D.d_surv_seg, D.d_surv2, D.d_surv_cnt2, D.d_hits, D.d_perm, D.d_hit_cnt, D.d_slots, D.d_heavy_list, D.d_heavy_cnt,
                   D.d_sel, D.d_sel_sidx, D.d_sel_cnt, D.d_sel_off, D.d_work, D.d_n_work, D.d_res, D.d_ops, D.d_back,
-                  D.d_pmin, D.d_pmax, D.d_saved, D.d_saved_list};
+                  D.d_pmin, D.d_pmax, D.d_saved, D.d_saved_list, D.d_post, D.d_post_fw, D.d_post_info};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  D.d_post = nullptr; D.d_post_fw = nullptr; D.d_post_info = nullptr;
   D.d_xover = nullptr; D.d_reads = nullptr; D.d_initbp = nullptr; D.d_surv = nullptr; D.d_surv_cnt = nullptr; D.d_surv_seg = nullptr; D.d_surv2 = nullptr; D.d_surv_cnt2 = nullptr; D.d_hits = nullptr; D.d_perm = nullptr; D.d_hit_cnt = nullptr; D.d_slots = nullptr;
   D.d_heavy_list = nullptr; D.d_heavy_cnt = nullptr; D.d_sel = nullptr; D.d_sel_sidx = nullptr; D.d_sel_cnt = nullptr; D.d_sel_off = nullptr;
   D.d_work = nullptr; D.d_n_work = nullptr; D.d_res = nullptr; D.d_ops = nullptr; D.d_back = nullptr;
@@ -371,6 +374,11 @@ static int alloc_buffers(gm_session* s, DevSet& D, int read_len, bool paired = f
   GM_HIP(hipMalloc(&D.d_n_work, 4));
   GM_HIP(hipMalloc(&D.d_res, rcap * sizeof(GmFullRes)));
   GM_HIP(hipMalloc(&D.d_ops, rcap * D.ops_stride));
+  if (s->P.colour_space && !getenv("GM_POST_SW_HOST")) {     // post_sw on the device (gm_post.hip): one record per result, forward values + column descriptors per thread
+    GM_HIP(hipMalloc(&D.d_post, rcap * sizeof(GmPostRes)));
+    GM_HIP(hipMalloc(&D.d_post_fw, (size_t)GM_POST_THREADS * (size_t)(read_len + 1) * 17 * 8));
+    GM_HIP(hipMalloc(&D.d_post_info, (size_t)GM_POST_THREADS * (size_t)(read_len + 1) * 4));
+  }
   D.p2_grid = (int)std::max<size_t>(256, std::min<size_t>((size_t)s->p2_grid, ((size_t)2 << 30) / D.back_stride));
   GM_HIP(hipMalloc(&D.d_back, (size_t)D.p2_grid * D.back_stride));
   if (paired) {
@@ -682,6 +690,7 @@ struct Finalizer {
   const gm_session* s; int read_len, read_words; const uint32_t* reads;   // host copy of the packed reads of this sub-batch
   const char* const* name_ptr; const int* name_len; long name_base;
   const uint8_t* initbp = nullptr; int ops_half = 0; CsPostConsts csk = CsPostConsts();
+  const GmFullRes* res_base = nullptr; const GmPostRes* post_base = nullptr;           // colour space: post_sw results of the device, parallel to the sub-batch's result records
   const char* const* seq_ptr = nullptr;                                                // text input: the read as it stood in the file (fields the reference prints from re->seq)
   const char* const* qual_ptr = nullptr; int qual_delta = 33;                          // FASTQ input: QUAL string of every read of this sub-batch   // colour space: primer letters of this sub-batch, ops_stride / 2
 
@@ -696,6 +705,10 @@ struct Finalizer {
       const double a = s->score_alpha, b = s->score_beta;
       if (P.colour_space) {
         cs_alignment_strings(h.ops, h.ops + ops_half, std::min(r->n_ops, ops_half), h.db, h.qr);
+        if (post_base && !qual_ptr && post_base[r - res_base].valid == 1) {   // k_post_sw_cs ran: the op record already carries the re-called letters
+          const GmPostRes& pr = post_base[r - res_base];
+          h.posterior = pr.posterior; h.cs_match = pr.cs_match; h.cs_mismatch = pr.cs_mismatch; h.cs_xover = pr.cs_xover; h.qual.clear();
+        } else
         cs_post_sw(csk, reads + (size_t)r->read_idx * read_words, (int)initbp[r->read_idx], r->read_start, h,
                    qual_ptr ? qual_ptr[r->read_idx] : nullptr, qual_delta);
       } else
@@ -1013,6 +1026,16 @@ static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len,
                           -s->P.b_gap_open_score, -s->P.b_gap_extend_score, s->P.anchor_width, s->P.indel_taboo_len};   // sw_full_cs_setup's arguments (ref: gmapper.c:2944-2947)
       rc = gm_launch_pass2_cs(dv, s->sc, cs9, D.d_reads, D.d_initbp, n, read_len, read_words, W, D.d_hits, D.hcap, D.d_sel, D.d_work, D.d_n_work,
                               D.d_res, D.d_ops, D.ops_stride, (uint32_t*)D.d_back, D.back_stride / 4, D.p2_grid, d_stats, q, D.xover_on ? D.d_xover : nullptr);
+      // post_sw of every result on the device, unless the reads carry quality values (per-colour error rates and base qualities: host routine) or
+      // the alignment is local (no mapping qualities at all, ref: gmapper.c:2325-2328)
+      H.post_on = rc == GM_OK && D.d_post && !D.xover_on && !s->P.local_alignment;
+      if (H.post_on) {
+        const CsPostConsts c = cs_post_consts(s);
+        GmCsPostDev K; K.let_m = c.let_m; K.let_x = c.let_x; K.col_m[0] = c.col_m[0]; K.col_m[1] = c.col_m[1]; K.col_x[0] = c.col_x[0]; K.col_x[1] = c.col_x[1];
+        K.pr_del_open = c.pr_del_open; K.pr_del_extend = c.pr_del_extend; K.pr_ins_open = c.pr_ins_open; K.pr_ins_extend = c.pr_ins_extend;
+        rc = gm_launch_post_sw_cs(K, D.d_reads, D.d_initbp, read_len, read_words, D.d_res, D.d_ops, D.ops_stride, D.d_n_work, (uint32_t)rcap, D.d_post, D.d_post_fw, D.d_post_info,
+                                  GM_POST_THREADS, q);
+      }
     } else
     rc = gm_launch_pass2(dv, s->sc, D.d_reads, n, read_len, read_words, W, D.d_hits, D.d_perm, D.hcap, D.d_sel, D.d_sel_cnt, D.d_work, D.d_n_work,
                          D.d_res, D.d_ops, D.ops_stride, D.d_back, D.back_stride, D.p2_grid, d_stats, q);
@@ -1024,7 +1047,10 @@ static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len,
       cap = H.n_cap; rc = slot_reserve((void**)&H.sel_cnt, &cap, (size_t)n * 4); if (rc) return rc;
       cap = H.n_cap; rc = slot_reserve((void**)&H.sel_off, &cap, (size_t)n * 4); H.n_cap = cap; if (rc) return rc; }
     H.n_work = n_work;
+    if (!s->P.colour_space) H.post_on = false;
+    if (H.post_on) { size_t cap = H.post_cap; rc = slot_reserve((void**)&H.post, &cap, (size_t)n_work * sizeof(GmPostRes)); H.post_cap = cap; if (rc) return rc; }
     if (n_work) {
+      if (H.post_on) GM_HIP(hipMemcpyAsync(H.post, D.d_post, (size_t)n_work * sizeof(GmPostRes), hipMemcpyDeviceToHost, q));
       GM_HIP(hipMemcpyAsync(H.res, D.d_res, (size_t)n_work * sizeof(GmFullRes), hipMemcpyDeviceToHost, q));
       GM_HIP(hipMemcpyAsync(H.ops, D.d_ops, (size_t)n_work * D.ops_stride, hipMemcpyDeviceToHost, q));
     }
@@ -1116,7 +1142,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     J->outs.assign(nchunks, std::string()); J->cm.assign(nchunks, 0); J->cr.assign(nchunks, 0);
     std::atomic<int> next(0);
     Finalizer F{s, read_len, read_words, J->hreads, names ? nptr.data() + J->base : nullptr, names ? nlen.data() + J->base : nullptr, (long)J->base};
-    if (s->P.colour_space) { F.initbp = initbp_host + J->base; F.ops_half = ops_stride / 2; F.csk = cs_post_consts(s); }
+    if (s->P.colour_space) { F.initbp = initbp_host + J->base; F.ops_half = ops_stride / 2; F.csk = cs_post_consts(s); if (J->hs->post_on) { F.res_base = J->hs->res; F.post_base = J->hs->post; } }
     if (quals) { F.qual_ptr = qptr.data() + J->base; F.qual_delta = qual_delta; }
     if (seq_text) F.seq_ptr = sptr.data() + J->base;
     auto worker = [&]() {

@@ -114,6 +114,12 @@ int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
                     const int32_t* d_sel_sidx = nullptr, int input_strand = 0, int write_back = 0);
 
 // colour-space pass 2 (sw_full_cs per selected window); ops_stride bytes per result: backtrace bytes, then (genome << 4 | read) codes
+// colour-space post_sw on the device (gm_post.hip): constants = CsPostConsts of gm_host.hip (logs taken on the host), one record per pass-2 result
+struct GmCsPostDev { double let_m, let_x, col_m[2], col_x[2], pr_del_open, pr_del_extend, pr_ins_open, pr_ins_extend; };
+struct GmPostRes { double posterior; int32_t cs_match, cs_mismatch, cs_xover, valid; };
+#define GM_POST_THREADS 32768
+int gm_launch_post_sw_cs(const GmCsPostDev& K, const uint32_t* d_reads, const uint8_t* d_initbp, int read_len, int read_words, const GmFullRes* d_res, uint8_t* d_ops,
+                         int ops_stride, const uint32_t* d_n_work, uint32_t res_cap, GmPostRes* d_post, double* d_fw, uint32_t* d_info, int threads, hipStream_t stream);
 int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs_params9, const uint32_t* d_reads, const uint8_t* d_initbp, int n_reads,
                        int read_len, int read_words, int window_len, const GmHit* d_hits, int hcap, const int32_t* d_sel, const uint32_t* d_work,
                        const uint32_t* d_n_work, GmFullRes* d_res, uint8_t* d_ops, int ops_stride, uint32_t* d_back, size_t back_words, int grid,
