@@ -97,7 +97,7 @@ static void choose_slabs(GmIndexHost* ix) {
   int bits = 12;
   while ((1ull << bits) < ix->total_len) bits++;
   int sb = std::min(bits, 29);
-  if (const char* e = getenv("GM_SLAB_BITS")) sb = std::max(ix->params.region_bits + 2, std::min(31, atoi(e)));
+  if (const char* e = gm_tune("GM_SLAB_BITS")) sb = std::max(ix->params.region_bits + 2, std::min(31, atoi(e)));
   ix->slab_bits = sb;
   ix->n_slabs = (int)((ix->total_len + (1ull << sb) - 1) >> sb);
   if (ix->n_slabs < 1) ix->n_slabs = 1;
@@ -407,10 +407,10 @@ static void choose_caps(gm_session* s, DevSet& D, int read_len) {
   D.hcap = 64;
   // K1b (exact isolation prune) shrinks K2's input; its LDS tier is sized for what typically remains
   // K1b's bounds assume the window-generation threshold: not in -U mode
-  D.scap2 = (s->P.match_mode == 2 && !s->P.ungapped && !getenv("GM_NO_PRUNE")) ? std::max(std::min(D.scap, 256), D.scap / 8) : 0;
-  if (const char* e = getenv("GM_SCAP")) D.scap = std::min(16384, std::max(64, pow2ceil(atoi(e))));
-  if (const char* e = getenv("GM_SCAP2")) { if (D.scap2) D.scap2 = std::min(D.scap, std::max(64, pow2ceil(atoi(e)))); }
-  if (const char* e = getenv("GM_HCAP")) D.hcap = std::min(32768, std::max(4, pow2ceil(atoi(e))));
+  D.scap2 = (s->P.match_mode == 2 && !s->P.ungapped && !gm_tune("GM_NO_PRUNE")) ? std::max(std::min(D.scap, 256), D.scap / 8) : 0;
+  if (const char* e = gm_tune("GM_SCAP")) D.scap = std::min(16384, std::max(64, pow2ceil(atoi(e))));
+  if (const char* e = gm_tune("GM_SCAP2")) { if (D.scap2) D.scap2 = std::min(D.scap, std::max(64, pow2ceil(atoi(e)))); }
+  if (const char* e = gm_tune("GM_HCAP")) D.hcap = std::min(32768, std::max(4, pow2ceil(atoi(e))));
   (void)max_n_kmers;
 }
 
@@ -439,7 +439,7 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   if (s->P.colour_space && s->P.local_alignment) { delete s; gm_set_error("local alignment is implemented for letter space only"); return GM_E_ARG; }
   if ((s->P.colour_space != 0) != (ix->params.colour_space != 0)) { delete s; gm_set_error("session and index disagree on colour space"); return GM_E_ARG; }
   s->max_batch = std::max(64, std::min(max_batch_reads > 0 ? max_batch_reads : 131072, 1 << 20));
-  if (const char* e = getenv("GM_P2_GRID")) s->p2_grid = std::max(64, std::min(65536, atoi(e)));
+  if (const char* e = gm_tune("GM_P2_GRID")) s->p2_grid = std::max(64, std::min(65536, atoi(e)));
   GM_HIP(hipStreamCreate(&s->stream));
   GM_HIP(hipStreamCreateWithFlags(&s->stream_b, hipStreamNonBlocking));
   GM_HIP(hipStreamCreateWithFlags(&s->stream_c, hipStreamNonBlocking));
@@ -1239,7 +1239,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   };
   // Sub-batch sizes: while the two halves overlap, the first sub-batch's front and the last one's back (and its host work) have nothing to
   // run beside, so the sizes ramp up from 8 192 at the start and halve towards the end (results do not depend on the split).
-  int ramp_min = 8192; if (const char* e = getenv("GM_RAMP_MIN")) ramp_min = std::max(64, atoi(e));
+  int ramp_min = 8192; if (const char* e = gm_tune("GM_RAMP_MIN")) ramp_min = std::max(64, atoi(e));
   auto size_at = [&](int base, int eff) {
     const int R = n_reads - base;
     int n = std::min(eff, R);

@@ -125,7 +125,7 @@ int gm_index_from_lists_device(GmIndexHost* ix, int sn, const uint32_t* lens, co
   if (total) GM_HIP(hipMemcpy(sd.d_pos, pos, (size_t)total * 4, hipMemcpyHostToDevice));
   GM_HIP(hipMalloc(&sd.d_dir, (size_t)(KS + 1 + 16) * 4));
   hipLaunchKernelGGL(k_dir_from_lists, dim3(256 * 16), dim3(256), 0, 0, d_start, sd.d_pos, K, ix->n_slabs, ix->slab_bits, sd.d_dir);
-  if (ix->n_slabs == 1 && (double)total / (double)K <= 12.0 && !getenv("GM_NO_BUCKETS")) {
+  if (ix->n_slabs == 1 && (double)total / (double)K <= 12.0 && !gm_tune("GM_NO_BUCKETS")) {
     GM_HIP(hipMalloc(&sd.d_bkt, (size_t)K * 16 * 4));
     hipLaunchKernelGGL(k_build_buckets, dim3(256 * 16), dim3(256), 0, 0, sd.d_dir, sd.d_pos, K, sd.d_bkt);
   }
@@ -200,7 +200,7 @@ int gm_index_build_device(GmIndexHost* ix, hipStream_t stream) {
     GM_HIP(hipMalloc(&sd.d_dir, (size_t)(KS + 1 + 16) * 4));
     hipLaunchKernelGGL(k_build_dir, dim3(grid), dim3(256), 0, stream, keys_b, vals_b, n_valid, ix->n_slabs, ix->slab_bits, KS, sd.d_dir);
     // small genomes (one slab, short lists): add the 64-byte buckets so that a lookup is a single HBM sector
-    if (ix->n_slabs == 1 && (double)n_valid / (double)K <= 12.0 && !getenv("GM_NO_BUCKETS")) {
+    if (ix->n_slabs == 1 && (double)n_valid / (double)K <= 12.0 && !gm_tune("GM_NO_BUCKETS")) {
       GM_HIP(hipMalloc(&sd.d_bkt, (size_t)K * 16 * 4));
       hipLaunchKernelGGL(k_build_buckets, dim3(grid), dim3(256), 0, stream, sd.d_dir, sd.d_pos, K, sd.d_bkt);
     }

@@ -40,12 +40,16 @@ enum { GS_LOOKUPS = 0, GS_ENTRIES, GS_SURVIVORS, GS_ANCHORS, GS_WINDOWS, GS_VEC_
 #define GS_STRIDE 16
 #define GS_ADD(stats, slot, val) atomicAdd(&(stats)[(size_t)(blockIdx.x & (GS_STRIPES - 1)) * GS_STRIDE + (slot)], (unsigned long long)(val))
 
-// Tuning / path-forcing knobs (environment variables): read through one function so that a build can compile them out.
+// Tuning / path-forcing knobs (environment variables GM_K1_*, GM_K4_*, GM_K5_*, GM_SCAP, ... -- the kernel-variant tests force code paths with them) and
+// the ablation bits of the lookup kernels exist only in builds with -DGM_TUNING (the Makefile's default; `make TUNING=0` is the release build: the knobs
+// read as unset and every ablation branch folds away).  GM_HOST_THREADS, GM_OVERLAP and GM_POST_SW_HOST are run-time options of every build.
 #include <cstdlib>
-#ifdef GM_NO_TUNING
-static inline const char* gm_tune(const char*) { return nullptr; }
-#else
+#ifdef GM_TUNING
 static inline const char* gm_tune(const char* name) { return getenv(name); }
+#define GM_ABL(bits) (ablate & (bits))
+#else
+static inline const char* gm_tune(const char*) { return nullptr; }
+#define GM_ABL(bits) (false)
 #endif
 
 // ---- kernel launchers (one per .hip file) -----------------------------------------------------

@@ -146,7 +146,7 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
     const uint32_t rbase = (uint32_t)(B >> rb);           // local region index = region - rbase + 1
     const uint32_t rend = (uint32_t)(E >> rb);
     {   // clear the region counters (16-byte stores)
-      uint4* bm4 = (uint4*)bm; const int n4 = (ablate & 8) ? 0 : (bm_words >> 2);
+      uint4* bm4 = (uint4*)bm; const int n4 = GM_ABL(8) ? 0 : (bm_words >> 2);
       for (int w = tid; w < n4; w += nthr) bm4[w] = make_uint4(0, 0, 0, 0);
       for (int w = (n4 << 2) + tid; w < bm_words; w += nthr) bm[w] = 0;
     }
@@ -183,12 +183,12 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
             for (int u = 0; u < K1_UNROLL; u++)
               if (e + u < h) {
                 const uint32_t reg = p[u] >> rb, rloc = reg - rbase + 1u;
-                if (ablate & 4) { if (p[u] == 0x12345u) bm[0] = 1; continue; }
+                if GM_ABL(4) { if (p[u] == 0x12345u) bm[0] = 1; continue; }
                 k1_mark(bm, rloc);
                 if (((p[u] & rmask) < ovl) && reg > 0) k1_mark(bm, rloc - 1u);
               }
           }
-          if (S > 1 && !(ablate & 2)) {
+          if (S > 1 && !GM_ABL(2)) {
             // entries of the previous slab inside the last region before B count for local region 0
             for (uint32_t q = l; q > lb;) { --q; if ((plist[q] >> rb) + 1u != rbase) break; k1_mark(bm, 0u); }
             // entries of the next slab inside the overlap strip count for this slab's last region
@@ -238,7 +238,7 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
             if (alive & (1u << u)) { if (slot < scap) out[slot] = ((uint64_t)bp[u + 1] << 32) | ((uint64_t)y << 16) | sn; slot++; }
         }
       }
-      if (phase == 1 && !(ablate & 1)) {
+      if (phase == 1 && !GM_ABL(1)) {
         // -- phase 1 (short slices): survival test, re-reading the slice from L1/L2 --
         for (int off = tid; off < NL; off += nthr) {
           const uint32_t l = lo[off], h = hi[off];
@@ -547,7 +547,7 @@ k_lookup_v3(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
       uint32_t r0, nv, d1, dn;
       region_slots(act, j, w, pv, rl, r0, nv, d1, dn);
       if (!act) return;
-      if (ablate & 4) { if ((pv[0] ^ pv[1] ^ pv[2] ^ pv[3]) == 0x12345u) bm[0] = 1; return; }
+      if GM_ABL(4) { if ((pv[0] ^ pv[1] ^ pv[2] ^ pv[3]) == 0x12345u) bm[0] = 1; return; }
       uint32_t old[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) old[u] = atomicOr(&bm[rl[u] >> 4], 1u << ((rl[u] & 15u) * 2u));
@@ -628,7 +628,7 @@ k_lookup_v3(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
     auto load_window = [&](const int j, const uint32_t w) -> k1_u32x4 {
       return *(const k1_u32x4*)(pos0 + (long long)(((uint64_t)rec[3 * j + 1] << 32) | rec[3 * j]) + w);
     };
-    for (int phase = 0; phase < ((ablate & 1) ? 1 : 2); phase++) {   // mark, then test
+    for (int phase = 0; phase < (GM_ABL(1) ? 1 : 2); phase++) {   // mark, then test
       for (int t0 = 0; t0 < nwin; t0 += K1Q * ng) {        // K1Q windows per lane group in flight
         int jq[K1Q]; uint32_t wq[K1Q], pq[K1Q][4]; bool aq[K1Q];
 #pragma unroll
@@ -636,7 +636,7 @@ k_lookup_v3(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
           jq[q] = 0; wq[q] = 0;
           k1_u32x4 v = {0, 0, 0, 0};
           aq[q] = locate(t0 + q * ng + g, phase == 0, jq[q], wq[q]);
-          if (aq[q] && !(ablate & 16)) v = load_window(jq[q], wq[q]);
+          if (aq[q] && !GM_ABL(16)) v = load_window(jq[q], wq[q]);
           pq[q][0] = v.x; pq[q][1] = v.y; pq[q][2] = v.z; pq[q][3] = v.w;
         }
 #pragma unroll
@@ -812,7 +812,7 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
       w.p[0] = v.x; w.p[1] = w.nv > 1 ? v.y : 0xFFFFFFFFu; w.p[2] = w.nv > 2 ? v.z : 0xFFFFFFFFu; w.p[3] = w.nv > 3 ? v.w : 0xFFFFFFFFu;
     };
     // ---- pass A: folded counts ----
-    if (!(ablate & 8)) {
+    if (!GM_ABL(8)) {
       Win cur[K4Q], nxt[K4Q];
 #pragma unroll
       for (int q = 0; q < K4Q; q++) fetch(q * ng + g, cur[q]);
@@ -822,7 +822,7 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
 #pragma unroll
         for (int q = 0; q < K4Q; q++) {
           const Win& w = cur[q];
-          if (ablate & 2) { if ((w.p[0] ^ w.p[1] ^ w.p[2] ^ w.p[3]) == 0x12345u) tab[0] = 1; continue; }   // loads only
+          if GM_ABL(2) { if ((w.p[0] ^ w.p[1] ^ w.p[2] ^ w.p[3]) == 0x12345u) tab[0] = 1; continue; }   // loads only
           // Folded counts only have to be >= the true ones (the exact rule is applied in pass C), so this pass takes two short cuts: an empty lane
           // (0xFFFFFFFF) counts into the folded counter of its pseudo-region instead of a spare word, and a strip entry of region 0 marks
           // counter (0 - 1) & tmask.  Both can only add candidates.
@@ -847,7 +847,7 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
     }
     __syncthreads();
     // ---- pass B: candidates = entries whose folded counter reached 2, binned by position ----
-    if (!(ablate & 1)) {
+    if (!GM_ABL(1)) {
       Win cur[K4Q], nxt[K4Q];
 #pragma unroll
       for (int q = 0; q < K4Q; q++) fetch(q * ng + g, cur[q]);
@@ -871,7 +871,7 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
             if (k1_has2(tab, ((pu >> rb) - 1u) & tmask)) hit |= 1u << u;
           }
           hit &= (1u << w.nv) - 1u;                                // empty lanes (their pseudo-region's counter may have reached 2) are no entries
-          if (hit && (ablate & 16)) { if (hit == 0x55u) tab[1] = 1; hit = 0; }
+          if (hit && GM_ABL(16)) { if (hit == 0x55u) tab[1] = 1; hit = 0; }
           if (hit) {
             const uint32_t ysn = rec[4 * w.j + 3];
             while (hit) {
@@ -906,7 +906,7 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
       continue;
     }
     // ---- pass C: exact counts per slab over the candidates (local counter = region - first region of the slab + 1) ----
-    if (ablate & 4) continue;
+    if GM_ABL(4) continue;
     __threadfence_block();
     { uint4* t4 = (uint4*)tab; for (int w = tid; w < (tab_words >> 2); w += nthr) t4[w] = make_uint4(0, 0, 0, 0); }
     __syncthreads();
@@ -1009,7 +1009,7 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
       if (surv_seg && tid == 0 && (((s + 1) % per_slab) == 0 || s + 1 == SC)) surv_seg[(size_t)rs * (S + 1) + s / per_slab + 1] = n_surv;   // survivors come out slab by slab
       __syncthreads();
     }
-    tab_clean = !ablate;
+    tab_clean = !GM_ABL(~0);
     if (tid == 0) {
       if (surv_seg) surv_seg[(size_t)rs * (S + 1)] = 0;
       surv_cnt[rs] = n_surv;
@@ -1056,25 +1056,25 @@ static bool k4_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
       const double lists = std::max(0, read_len - ix.seed[sn].span + 1 - ix.colour);
       entries += lists * (double)ix.seed[sn].n_pos / (double)(1ull << (ix.hflag ? 2 * GM_HASH_TABLE_POWER : 2 * ix.seed[sn].weight));
     }
-    if (entries < 30000.0 && !getenv("GM_K1_V4")) return false;
+    if (entries < 30000.0 && !gm_tune("GM_K1_V4")) return false;
   }
-  int tab_bits = 19; if (const char* e = getenv("GM_K4_TABBITS")) tab_bits = std::max(6, std::min(19, atoi(e)));
+  int tab_bits = 19; if (const char* e = gm_tune("GM_K4_TABBITS")) tab_bits = std::max(6, std::min(19, atoi(e)));
   // pass C keeps the exact counters of one bin of 2^cbits positions (+2) in the table's LDS; bins nest inside the index slabs
   const int cbits = std::min(ix.slab_bits, tab_bits + ix.region_bits - 1);
   if (cbits < ix.region_bits + 1) return false;
   const int SC = (int)((ix.total_len + (1ull << cbits) - 1) >> cbits);
   if (SC < 1 || SC > 4096) return false;
-  int wcap = 4096; if (const char* e = getenv("GM_K4_WCAP")) wcap = std::max(2, std::min(4096, atoi(e) & ~1));   // windows with a direct window -> list entry (the rest: binary search)
+  int wcap = 4096; if (const char* e = gm_tune("GM_K4_WCAP")) wcap = std::max(2, std::min(4096, atoi(e) & ~1));   // windows with a direct window -> list entry (the rest: binary search)
   const int fb_cap = 4096;
-  int bin_cap = 4096; if (const char* e = getenv("GM_K4_BINCAP")) { const int v = std::max(16, std::min(1 << 20, atoi(e))); bin_cap = 16; while (bin_cap < v) bin_cap <<= 1; }
+  int bin_cap = 4096; if (const char* e = gm_tune("GM_K4_BINCAP")) { const int v = std::max(16, std::min(1 << 20, atoi(e))); bin_cap = 16; while (bin_cap < v) bin_cap <<= 1; }
   const int code_words = (read_len + 3) / 4;
   size_t lds = (size_t)(((((code_words + 3) & ~3) + 4 * NL + NL + 1 + SC + (wcap + 1) / 2 + 3) & ~3) + (1 << (tab_bits - 4)) + 4) * 4;
   if (const char* e = gm_tune("GM_K4_LDS_PAD")) lds += (size_t)std::max(0, atoi(e));   // experiment: what the LDS footprint does to the co-residency with pass 1 / pass 2
   if (lds > 160 * 1024 - 64) return false;
-  int wgs_per_cu = 1; if (const char* e = getenv("GM_K4_WGS")) wgs_per_cu = std::max(1, std::min(8, atoi(e)));
+  int wgs_per_cu = 1; if (const char* e = gm_tune("GM_K4_WGS")) wgs_per_cu = std::max(1, std::min(8, atoi(e)));
   if (!K.cus) { if (hipDeviceGetAttribute(&K.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || K.cus < 1) K.cus = 256; }
   int grid = std::min(2 * n_reads, K.cus * wgs_per_cu);
-  if (const char* e = getenv("GM_K4_GRID")) grid = std::max(1, std::min(2 * n_reads, atoi(e)));
+  if (const char* e = gm_tune("GM_K4_GRID")) grid = std::max(1, std::min(2 * n_reads, atoi(e)));
   const size_t need = (size_t)std::max(grid, K.cus) * SC * bin_cap;
   if (need > K.words) {
     if (K.scratch) (void)hipFree(K.scratch);
@@ -1088,12 +1088,12 @@ static bool k4_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   if (lds > 48 * 1024 && lds > configured4) { if (hipFuncSetAttribute((const void*)k_lookup_v4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false; configured4 = lds; }
   if (lds_generic > 48 * 1024 && lds_generic > configured_g) {
     if (hipFuncSetAttribute((const void*)k_lookup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_generic) != hipSuccess) return false; configured_g = lds_generic; }
-  int k4_threads = 1024; if (const char* e = getenv("GM_K1_THREADS")) k4_threads = std::max(64, std::min(1024, atoi(e) & ~63));
+  int k4_threads = 1024; if (const char* e = gm_tune("GM_K1_THREADS")) k4_threads = std::max(64, std::min(1024, atoi(e) & ~63));
   const bool use_flags = g_k4_flags && grid <= g_k4_flag_cap;
   g_k4_flag_grid = use_flags ? grid : 0;
   hipLaunchKernelGGL(k_lookup_v4, dim3(grid), dim3(k4_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words, max_n_kmers, NL, tab_bits, cbits, SC, wcap,
                      d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, d_surv_seg, K.scratch, bin_cap, K.fb, K.fb + fb_cap, fb_cap,
-                     getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0, use_flags ? g_k4_flags : nullptr, g_k4_epoch);
+                     gm_tune("GM_K1_ABLATE") ? atoi(gm_tune("GM_K1_ABLATE")) : 0, use_flags ? g_k4_flags : nullptr, g_k4_epoch);
   // read-strands whose candidates overflowed their bins: the slab-sweep kernel in list mode (blocks beyond the list's end return at once)
   hipLaunchKernelGGL(k_lookup<false>, dim3(fb_cap), dim3(K1_THREADS), lds_generic, stream, ix, d_reads, n_reads, read_len, read_words,
                      max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
@@ -1122,8 +1122,8 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     GM_HIP(hipFuncSetAttribute((const void*)k_lookup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = lds;
   }
-  const bool bkt = ix.seed[0].bkt != nullptr && ix.n_slabs == 1 && NL <= 512 && !getenv("GM_NO_BUCKETS");
-  if (!bkt && NL < 65536 && !getenv("GM_K1_V2") && !getenv("GM_K1_V3") && !getenv("GM_K1_V4") && !getenv("GM_NO_V5")) {
+  const bool bkt = ix.seed[0].bkt != nullptr && ix.n_slabs == 1 && NL <= 512 && !gm_tune("GM_NO_BUCKETS");
+  if (!bkt && NL < 65536 && !gm_tune("GM_K1_V2") && !gm_tune("GM_K1_V3") && !gm_tune("GM_K1_V4") && !gm_tune("GM_NO_V5")) {
     // k_lookup_v5 (gm_lookup5.hip): wave-per-list streaming, candidates and the exact rule in LDS, K1b's prune rules fused when the caller allows.
     // It takes the read-strands with many list entries (gm_lookup5_launch declines the others: 50-colour reads, small genomes) -- round 2: 24 %
     // fewer VALU instructions than v4 + K1b, 2.09 M reads/s against 1.90 M on the 3 Gbp workload.
@@ -1164,11 +1164,11 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     const size_t lds_b = (size_t)((((read_len + 3) / 4) + 3) & ~3) * 4 + (size_t)bm_words * 4;
     hipLaunchKernelGGL(k_lookup_bkt, dim3(n_reads * 2), dim3((NL + 63) & ~63), lds_b, stream, ix, d_reads, n_reads, read_len, read_words,
                        max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, d_surv_seg);
-  } else if (ix.n_slabs > 1 && NL < 65536 && !getenv("GM_K1_V2") && !getenv("GM_K1_V3") && k4_launch(ix, d_reads, n_reads, read_len, read_words, max_n_kmers, NL, d_surv, d_surv_cnt, scap,
+  } else if (ix.n_slabs > 1 && NL < 65536 && !gm_tune("GM_K1_V2") && !gm_tune("GM_K1_V3") && k4_launch(ix, d_reads, n_reads, read_len, read_words, max_n_kmers, NL, d_surv, d_surv_cnt, scap,
                                                                                                    d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, stream, d_surv_seg, lds, bm_words)) {
     // k_lookup_v4 ran (hashed pre-count + exact count on the candidates); read-strands it could not hold were redone in list mode
     g_k1_name = "k_lookup_v4";
-  } else if (ix.list_cutoff < 65536u && !getenv("GM_K1_V2") &&
+  } else if (ix.list_cutoff < 65536u && !gm_tune("GM_K1_V2") &&
              (size_t)((((read_len + 3) / 4) + 3 * NL + ix.n_slabs * NL + (ix.n_slabs + 1) / 2 + (NL * (ix.n_slabs + 1) + 1) / 2 + 3) & ~3) * 4 + (size_t)bm_words * 4 <= 160 * 1024) {
     // (long reads on many slabs: the per-slab window maps outgrow the LDS and the lane-per-list kernel below takes over)
     g_k1_name = "k_lookup_v3";
@@ -1176,19 +1176,19 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     static size_t configured3 = 0;
     if (lds3 > 48 * 1024 && lds3 > configured3) { GM_HIP(hipFuncSetAttribute((const void*)k_lookup_v3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); configured3 = lds3; }
     int k1_threads = 768;
-    if (const char* e = getenv("GM_K1_THREADS")) k1_threads = std::max(64, std::min(768, atoi(e) & ~63));
+    if (const char* e = gm_tune("GM_K1_THREADS")) k1_threads = std::max(64, std::min(768, atoi(e) & ~63));
     hipLaunchKernelGGL(k_lookup_v3, dim3(n_reads * 2), dim3(k1_threads), lds3, stream, ix, d_reads, n_reads, read_len, read_words,
                        max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats,
-                       getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0, d_surv_seg);
+                       gm_tune("GM_K1_ABLATE") ? atoi(gm_tune("GM_K1_ABLATE")) : 0, d_surv_seg);
   } else {
     g_k1_name = "k_lookup";
     // one list per lane when the read-strand's lists fit a workgroup: every list slice is in flight at once
     int k1_threads = std::min(1024, (NL + 63) & ~63);
-    if (const char* e = getenv("GM_K1_THREADS")) k1_threads = std::max(64, std::min(1024, atoi(e) & ~63));
+    if (const char* e = gm_tune("GM_K1_THREADS")) k1_threads = std::max(64, std::min(1024, atoi(e) & ~63));
     hipLaunchKernelGGL(k_lookup<false>, dim3(n_reads * 2), dim3(k1_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words,
                        max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
                        (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_stats,
-                       getenv("GM_K1_ABLATE") ? atoi(getenv("GM_K1_ABLATE")) : 0, d_surv_seg);
+                       gm_tune("GM_K1_ABLATE") ? atoi(gm_tune("GM_K1_ABLATE")) : 0, d_surv_seg);
   }
   GM_HIP(hipGetLastError());
   return GM_OK;

@@ -571,7 +571,7 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
     // When pass 1 computed it for this very window the re-score is the same number: local SW with direction-free gap costs is
     // invariant under reversing + complementing both sequences (N and IUPAC codes map one-to-one), which is all reverse_hit does.
     int sv;
-    if ((h.flags & 1u) && !(ablate & 4)) sv = h.score_vector;
+    if ((h.flags & 1u) && !GM_ABL(4)) sv = h.score_vector;
     else { sv = sw_vector_wave(db, w_len, qr, read_len, sc, (int16_t*)carry, lane); vcalls++; vcells += (unsigned long long)w_len * read_len; }
     GmFullRes R;
     R.read_idx = rd; R.st = 0; R.gen_st = (int16_t)gen_st; R.cn = (uint32_t)cn; R.g_off = (uint32_t)g_off; R.w_len = w_len;
@@ -580,7 +580,7 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
     R.n_match = R.n_mismatch = R.n_ins = R.n_del = 0; R.n_ops = 0; R.ops_off = (uint32_t)(wi * (uint32_t)ops_stride);
     R.sort_idx = sel_sidx ? sel_sidx[(size_t)rd * SEL_MAX + k] : 0; R.hit_slot = (uint32_t)slot;
     if (write_back && lane == 0) hits[slot].score_vector = sv;          // hit_run_full_sw keeps the re-scored value in the hit (ref: mapping.c:386-388)
-    if (sv >= thresh && !(ablate & 1)) {
+    if (sv >= thresh && !GM_ABL(1)) {
       fcalls++;
       // rectangle = anchor_join(1 anchor) + anchor_widen(anchor_width), ref: sw-full-ls.c:176-178, anchors.c:9-61
       long long nw = ax + ay, sw = ax - ay, ne = sw + 2 * (h.awidth - 1), se = nw + 2 * (h.alen - 1);
@@ -603,7 +603,7 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
       R.score = fo.score;
       if (fo.score > 0) {
         // do_backtrace, ref: sw-full-ls.c:413-516 -- lane 0 walks; ops are emitted reversed then flipped
-        if (lane == 0 && !(ablate & 2)) {
+        if (lane == 0 && !GM_ABL(2)) {
           int i = fo.max_i, j = fo.max_j;
           // from-state: 0 nw, 1 n, 2 w  (ref :420-427: nw, then w if strictly greater, then n if strictly greater)
           int state = 0, fs = fo.e_nw;
@@ -816,14 +816,14 @@ int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
                     uint8_t* d_back, size_t back_stride, int grid, unsigned long long* d_stats, hipStream_t stream,
                     const int32_t* d_sel_sidx, int input_strand, int write_back) {
   if (n_reads == 0) return GM_OK;
-  const int p2_ablate = getenv("GM_P2_ABLATE") ? atoi(getenv("GM_P2_ABLATE")) : 0;
+  const int p2_ablate = gm_tune("GM_P2_ABLATE") ? atoi(gm_tune("GM_P2_ABLATE")) : 0;
   size_t lds = ((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 12 + 64;
   const size_t back_bytes = (size_t)read_len * window_len;
 #define GM_P2_LAUNCH(BL, LOC) hipLaunchKernelGGL((k_pass2<BL, LOC>), dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words, \
     d_hits, d_perm, hcap, d_sel, d_sel_sidx, input_strand, write_back, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats, p2_ablate)
   // Back pointers in LDS (14 KB per wave at 100 bp) cap the CU at ten waves; in a per-wave global scratch (L2-resident) the CU runs at full
   // occupancy: measured 109 -> 37 ms per 1 M reads on the 3 Gbp workload.  The LDS form stays for comparison (GM_P2_BACK_LDS=1).
-  if (back_bytes <= 40 * 1024 && getenv("GM_P2_BACK_LDS")) {
+  if (back_bytes <= 40 * 1024 && gm_tune("GM_P2_BACK_LDS")) {
     lds += back_bytes + 16;
     if (sc.local) GM_P2_LAUNCH(true, true); else GM_P2_LAUNCH(true, false);
   } else {
