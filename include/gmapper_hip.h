@@ -261,7 +261,8 @@ typedef struct gm_pair_opts {
   int pair_mode;                               /* ref: gmapper.h:140 */
   int min_insert_size, max_insert_size;        /* ref: gmapper-defaults.h:28-29  0 / 1000 */
   double insert_size_mean, insert_size_stddev; /* ref: gmapper-defaults.h:30-31  200 / 100 */
-  int half_paired;                             /* ref: gmapper.h:181 true; 0 (mate-pair region counts, mapping.c:545-608) is refused: not implemented */
+  int half_paired;                             /* ref: gmapper.h:181 true; 0 = --no-half-paired: each mate's list entries are filtered by the other mate's region
+                                                  counts (mapping.c:545-608,733-742, use_mp_region_counts = 1) and no unpaired rescue runs (gmapper.c:2657-2683) */
 } gm_pair_opts_t;
 void gm_pair_opts_default(gm_pair_opts_t *o);
 int gm_map_pairs(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_packed, int len2, const uint32_t *mates2_packed,

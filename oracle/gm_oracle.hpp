@@ -105,6 +105,7 @@ struct Params {
   int min_insert_size = 0, max_insert_size = 1000;
   double insert_size_mean = 200, insert_size_stddev = 100;
   bool half_paired = true;
+  int mp_match_mode = 4;            // the paired option set's match mode (gmapper-defaults.h: DEF_MATCH_MODE_PAIRED); with half_paired it picks use_mp_region_counts
   // colour space (gmapper/gmapper.h:55-57,119; gmapper-defaults.h:52-58): set by set_colour_space()
   bool colour = false;
   int crossover_score = -20, indel_taboo_len = 0;
@@ -1067,10 +1068,12 @@ struct Read {
   std::vector<Hit> hits[2];
   bool paired = false, first_in_pair = false; Read* mate_pair = nullptr;
   int delta_g_off_min[2] = {0, 0}, delta_g_off_max[2] = {0, 0};
+  int delta_region_min[2] = {0, 0}, delta_region_max[2] = {0, 0};   // mate-pair region counts (mapping.c:2422-2430)
   std::vector<Hit> final_unpaired_hits; bool mapped = false;
 };
 
-struct Stats { uint64_t vec_calls = 0, vec_cells = 0, vec_bypassed = 0, full_calls = 0, full_cells = 0, reads_matched = 0, dup_pruned = 0; };
+struct Stats { uint64_t vec_calls = 0, vec_cells = 0, vec_bypassed = 0, full_calls = 0, full_cells = 0, reads_matched = 0, dup_pruned = 0;
+               uint64_t pair_anchors = 0, pair_windows = 0; };   // paired mode: collapsed anchors / windows of both mates (stage check of the mate-pair region counts)
 
 struct ThreadState {               // the reference's threadprivate state
   std::vector<uint16_t> region_map[2][2];       // region_map[number_in_pair][st]
@@ -1214,8 +1217,20 @@ struct Mapper {
   };
 
   // advance_index_in_genomemap (mapping.c:646-805), unpaired branch (use_mp_region_counts == 0)
-  void advance_index(const ThreadState& T, int nip, int st, uint32_t* idx, uint32_t max_idx, const uint32_t* map) const {
+  void advance_index(const ThreadState& T, int nip, int st, uint32_t* idx, uint32_t max_idx, const uint32_t* map, int mp_mode = 0) const {
     const uint16_t* rm = T.region_map[nip][st].data();
+    auto mp_ok = [&](int region) {                                           // mapping.c:733-742
+      const int count_main = (rm[region] & 0x1) ? 2 : 1, count_mp = (rm[region] >> 1) & 0x3;
+      return (mp_mode == 1 && count_main >= 2 && count_mp >= 2) || (mp_mode == 2 && (count_main >= 2 || count_mp >= 2)) ||
+             (mp_mode == 3 && count_mp >= 1 && count_main + count_mp >= 3);
+    };
+    while (mp_mode && *idx < max_idx) {
+      int region = (int)(map[*idx] >> P.region_bits);
+      if (mp_ok(region)) break;
+      if (region > 0 && (map[*idx] & ((1u << P.region_bits) - 1)) < (uint32_t)P.region_overlap && mp_ok(region - 1)) break;
+      (*idx)++;
+    }
+    if (mp_mode) return;
     while (*idx < max_idx) {
       int region = (int)(map[*idx] >> P.region_bits);
       if (rm[region] & 0x1) break;
@@ -1233,6 +1248,7 @@ struct Mapper {
     // unpaired: use_region_counts = (match_mode == 2) (gmapper.c:2615); paired default (mode 4, half-paired): true, no mp counts (:2652-2660)
     bool use_region_counts = re.paired ? true : (P.match_mode == 2);
     const int nip = (re.first_in_pair || !re.paired) ? 0 : 1;
+    const int mp_mode = re.paired ? mp_region_mode() : 0;
     re.anchors[st].clear();
     if (re.mapidx[st].empty()) return;
     HeapUU h; h.a.resize((size_t)ns * re.max_n_kmers + 1);
@@ -1244,7 +1260,7 @@ struct Mapper {
         uint32_t mi = re.mapidx[st][off];
         uint32_t len = I->list_len(sn, mi); const uint32_t* l = I->list(sn, mi);
         if (len > P.list_cutoff) idx[off] = len;
-        if (use_region_counts) advance_index(T, nip, st, &idx[off], len, l);
+        if (use_region_counts) advance_index(T, nip, st, &idx[off], len, l, mp_mode);
         if (idx[off] < len) { h.insert({l[idx[off]], off}); idx[off]++; }
       }
     std::vector<Anchor>& A = re.anchors[st];
@@ -1263,7 +1279,7 @@ struct Mapper {
       }
       uint32_t mi = re.mapidx[st][off];
       uint32_t len = I->list_len(sn, mi); const uint32_t* l = I->list(sn, mi);
-      if (use_region_counts) advance_index(T, nip, st, &idx[off], len, l);
+      if (use_region_counts) advance_index(T, nip, st, &idx[off], len, l, mp_mode);
       if (idx[off] < len) { h.replace_min({l[idx[off]], off}); idx[off]++; }
       else h.extract_min();
     }
@@ -1656,6 +1672,43 @@ struct Mapper {
     } else {
       re2.delta_g_off_min[0] = -b; re2.delta_g_off_max[0] = -a; re2.delta_g_off_min[1] = -d; re2.delta_g_off_max[1] = -c;
     }
+    const int R = 1 << P.region_bits;                                        // mapping.c:2422-2430
+    for (Read* re : {&re1, &re2}) for (int st = 0; st < 2; st++) {
+      const int mn = re->delta_g_off_min[st], mx = re->delta_g_off_max[st];
+      re->delta_region_min[st] = mn >= 0 ? mn / R : -1 - (-mn - 1) / R;
+      re->delta_region_max[st] = mx > 0 ? 1 + (mx - 1) / R : -(-mx / R);
+    }
+  }
+
+  // use_mp_region_counts of the paired option set (gmapper.c:2657-2662): 1 = match mode 4 without half-paired, 2 / 3 = match mode 3 with / without
+  int mp_region_mode() const { return P.mp_match_mode == 4 ? (P.half_paired ? 0 : 1) : (P.mp_match_mode == 3 ? (P.half_paired ? 2 : 3) : 0); }
+
+  // read_get_mp_region_counts (mapping.c:545-608): for every region the read's list entries mark, the best count of the mate's regions (other
+  // strand) within the insert-size range: 0 none, 1 marked once, 2 marked twice or more
+  void read_get_mp_region_counts(ThreadState& T, Read& re, int st) const {
+    const int nip = re.first_in_pair ? 0 : 1;
+    uint16_t* rm = T.region_map[nip][st].data();
+    const uint16_t* mp = T.region_map[1 - nip][1 - st].data();
+    const int n_regions = (int)T.region_map[nip][st].size();
+    auto set_cnt = [&](int region) {
+      if ((rm[region] & 0x6) != 0x6) return;                                 // RG_VALID_MP_CNT
+      int first = std::max(0, region + re.delta_region_min[st]), last = std::min(n_regions - 1, region + re.delta_region_max[st]), mx = 0;
+      for (int k = first; k <= last && mx < 2; k++) if ((mp[k] >> 3) == T.region_map_id) mx = (mp[k] & 0x1) ? 2 : 1;
+      rm[region] = (uint16_t)((rm[region] & ~0x6) | (mx << 1));             // RG_SET_MP_CNT
+    };
+    int ns = (int)P.seeds.size();
+    for (int sn = 0; sn < ns; sn++)
+      for (int i = 0; re.min_kmer_pos + i + P.seeds[sn].span - 1 < re.read_len; i++) {
+        uint32_t mi = re.mapidx[st][sn * re.max_n_kmers + i];
+        uint32_t len = I->list_len(sn, mi);
+        if (len > P.list_cutoff) continue;
+        const uint32_t* l = I->list(sn, mi);
+        for (uint32_t j = 0; j < len; j++) {
+          int region = (int)(l[j] >> P.region_bits);
+          set_cnt(region);
+          if (region > 0 && (l[j] & ((1u << P.region_bits) - 1)) < (uint32_t)P.region_overlap) set_cnt(region - 1);
+        }
+      }
   }
 
   // readpair_pair_up_hits (mapping.c:266-325)
@@ -2046,6 +2099,7 @@ struct Mapper {
     T.region_map_id++; T.region_map_id &= ((1 << region_map_id_bits) - 1);
     read_get_region_counts(T, re1, 0); read_get_region_counts(T, re1, 1);
     read_get_region_counts(T, re2, 0); read_get_region_counts(T, re2, 1);
+    if (mp_region_mode()) { read_get_mp_region_counts(T, re1, 0); read_get_mp_region_counts(T, re1, 1); read_get_mp_region_counts(T, re2, 0); read_get_mp_region_counts(T, re2, 1); }   // mapping.c:2531-2538
     read_get_anchor_list(T, re1, 0); read_get_anchor_list(T, re1, 1);
     read_get_anchor_list(T, re2, 0); read_get_anchor_list(T, re2, 1);
     for (Read* re : {&re1, &re2}) {
@@ -2053,6 +2107,7 @@ struct Mapper {
       for (size_t i = 0; i < re->hits[0].size(); i++) re->hits[0][i].sort_idx = (int)i;
       for (size_t i = 0; i < re->hits[1].size(); i++) re->hits[1][i].sort_idx = (int)(re->hits[0].size() + i);
     }
+    for (Read* re : {&re1, &re2}) for (int st = 0; st < 2; st++) { T.stats.pair_anchors += re->anchors[st].size(); T.stats.pair_windows += re->hits[st].size(); }
     readpair_pair_up_hits(re1, re2);
     read_pass1(T, re1, 0, true); read_pass1(T, re1, 1, true);
     read_pass1(T, re2, 0, true); read_pass1(T, re2, 1, true);

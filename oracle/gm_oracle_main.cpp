@@ -36,6 +36,7 @@ struct Session {
   Mapper M; Genome G; Index I;
 };
 
+static uint64_t g_last_pair_counts[2] = {0, 0};   // anchors, windows of the last paired call
 static void map_all(const Session& S, std::vector<Read>& reads, int nthreads, std::string& out, Stats* stats_out) {
   const int chunk = 64;   // finer than the reference's 1000-read chunks so that a bounded sample still fills every core
   int nchunks = (int)((reads.size() + chunk - 1) / chunk);
@@ -64,6 +65,8 @@ static void map_all(const Session& S, std::vector<Read>& reads, int nthreads, st
     st[omp_get_thread_num()].full_cells = T.sww.local_retries;      // reported in the stats' 7th slot
   }
   for (auto& o : outs) out += o;
+  g_last_pair_counts[0] = g_last_pair_counts[1] = 0;
+  for (auto& s : st) { g_last_pair_counts[0] += s.pair_anchors; g_last_pair_counts[1] += s.pair_windows; }
   if (stats_out) {
     for (auto& s : st) {
       stats_out->vec_calls += s.vec_calls; stats_out->vec_cells += s.vec_cells; stats_out->vec_bypassed += s.vec_bypassed;
@@ -208,6 +211,8 @@ static void apply_opts(Params& P, const char* opts) {
     else if (k == "report") P.num_outputs = (int)d; else if (k == "anchor-width") P.anchor_width = (int)d;
     else if (k == "cutoff") P.list_cutoff = (uint32_t)d; else if (k == "strata") P.strata = d != 0;
     else if (k == "max-alignments") P.max_alignments = (int)d;
+    else if (k == "mp-match-mode") P.mp_match_mode = (int)d;     // 4 (default) / 3: the paired option set's match mode; 0 switches the mate-pair region counts off (sensitivity checks)
+    else if (k == "half-paired") P.half_paired = d != 0;        // --no-half-paired: mate-pair region counts, no unpaired rescue (gmapper.c:2657-2683)
     else if (k == "local") { P.Gflag = d == 0; if (!P.Gflag) P.compute_mapping_qualities = false; }   // --local (gmapper.c:2303-2305,2325-2328)
     else if (k == "ungapped") { if (d != 0) { P.gapless = true; P.anchor_width = 0; P.a_gap_open_score = -255; P.b_gap_open_score = -255; P.hash_filter_calls = false; } }   // -U (gmapper.c:2057-2062)
     else if (k == "hash-spaced-kmers") P.Hflag = d != 0;     // -H
@@ -309,8 +314,8 @@ char* gmo_map_pairs_sam(void* s, int n, int L1, const uint8_t* codes1, int L2, c
     char nm[40];
     if (p1) next_name(p1, reads[2 * i].name); else { snprintf(nm, sizeof nm, "p%d/1", i); reads[2 * i].name = nm; }
     if (p2) next_name(p2, reads[2 * i + 1].name); else { snprintf(nm, sizeof nm, "p%d/2", i); reads[2 * i + 1].name = nm; }
-    reads[2 * i].seq = code_seq(codes1 + (size_t)i * L1, L1);
-    reads[2 * i + 1].seq = code_seq(codes2 + (size_t)i * L2, L2);
+    reads[2 * i].seq = S->M.P.colour ? code_seq_cs(codes1 + (size_t)i * L1, L1) : code_seq(codes1 + (size_t)i * L1, L1);
+    reads[2 * i + 1].seq = S->M.P.colour ? code_seq_cs(codes2 + (size_t)i * L2, L2) : code_seq(codes2 + (size_t)i * L2, L2);
   }
   std::string out;
   map_all(*S, reads, nthreads > 0 ? nthreads : 1, out, nullptr);
@@ -343,6 +348,7 @@ char* gmo_map_pairs_sam_q(void* s, int n, int L1, const uint8_t* codes1, int L2,
   return r;
 }
 void gmo_free(void* p) { free(p); }
+void gmo_last_pair_counts(uint64_t* out2) { out2[0] = g_last_pair_counts[0]; out2[1] = g_last_pair_counts[1]; }
 
 // Stage dump for one batch, for GPU-vs-oracle stage parity: for every read the pass-1 survivors
 // (top-K heap array order) as rows of 12 ints:

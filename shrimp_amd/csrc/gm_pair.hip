@@ -187,3 +187,120 @@ int gm_launch_mark_saved(uint8_t* d_saved, const uint32_t* d_list, int n, hipStr
   GM_HIP(hipGetLastError());
   return GM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Mate-pair region counts (ref: mapping.c:545-608 read_get_mp_region_counts, :733-742 the test in advance_index_in_genomemap with
+// use_mp_region_counts == 1: match mode 4 without half-paired, gmapper.c:2657-2662).  A list entry of mate A, strand st, whose region X
+// (or X - 1 from the overlap strip) was marked twice stays only if mate B, strand 1 - st, marked some region in [X + dmin, X + dmax] twice.
+// K1 has already applied the "marked twice" part, and the regions a read-strand marked twice are exactly the regions its SURVIVORS mark twice
+// (every entry that marks such a region is a survivor), so both maps are rebuilt from the survivor lists: one workgroup per (pair, st) puts the
+// regions of A[st] and of B[1 - st] into two LDS region tables (gm_region_table.h, flags A / B = once / twice), then drops from both lists the
+// entries that fail the test -- the relation is symmetric (A[st] looks at B[1 - st] and the other way round) -- and compacts them in place.
+// A read-strand beyond the LDS tier (count > scap: heavy tier) or a table that runs full leaves both lists as they are: a superset of the
+// reference's anchors (the filter only removes entries that cannot pair up); such items are counted in GS_MP_UNFILTERED.
+// ---------------------------------------------------------------------------------------------
+#include "gm_region_table.h"
+#define MPF_THREADS 1024
+#define MPF_HBITS 14
+#define MPF_PER_THREAD 16          // survivors per thread held in registers during the compaction: scap <= 16 384
+struct MpDelta { int amin[2], amax[2], bmin[2], bmax[2]; };   // region deltas of mate 1 / mate 2 per strand (ref: mapping.c:2422-2430)
+
+__global__ void __launch_bounds__(MPF_THREADS)
+k_mp_filter(int n_pairs, int rb, uint32_t ovl, uint64_t* __restrict__ surv1, uint32_t* __restrict__ cnt1, int scap1,
+            uint64_t* __restrict__ surv2, uint32_t* __restrict__ cnt2, int scap2, MpDelta dl, uint32_t* __restrict__ seg1, uint32_t* __restrict__ seg2, int n_slabs,
+            unsigned long long* __restrict__ unfiltered) {
+  extern __shared__ __align__(16) uint32_t mpf_lds[];
+  uint32_t* tagA = mpf_lds; uint32_t* tagB = tagA + (1u << MPF_HBITS);
+  __shared__ uint32_t sh_fail, sh_keep[2], sh_wave[MPF_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t hmask = (1u << MPF_HBITS) - 1u; const int hshift = 32 - MPF_HBITS;
+  const uint32_t rmask = (1u << rb) - 1u;
+  for (int w = blockIdx.x; w < 2 * n_pairs; w += gridDim.x) {
+    const int p = w >> 1, st = w & 1;
+    const int rsA = 2 * p + st, rsB = 2 * p + (1 - st);
+    const uint32_t nA = cnt1[rsA], nB = cnt2[rsB];
+    __syncthreads();                                           // (the tables and the counters of the previous item are done with)
+    if (nA > (uint32_t)scap1 || nB > (uint32_t)scap2 || nA > MPF_THREADS * MPF_PER_THREAD || nB > MPF_THREADS * MPF_PER_THREAD) {
+      if (tid == 0 && (nA || nB)) GS_ADD(unfiltered, GS_MP_UNFILTERED, 1ull);
+      continue;
+    }
+    if (nA == 0 && nB == 0) continue;
+    uint64_t* sA = surv1 + (size_t)rsA * scap1; uint64_t* sB = surv2 + (size_t)rsB * scap2;
+    for (uint32_t i = tid; i < (2u << MPF_HBITS); i += MPF_THREADS) mpf_lds[i] = 0;
+    if (tid == 0) { sh_fail = 0; sh_keep[0] = sh_keep[1] = 0; }
+    __syncthreads();
+    // the two region maps
+    for (int side = 0; side < 2; side++) {
+      const uint64_t* s = side ? sB : sA; const uint32_t n = side ? nB : nA; uint32_t* tag = side ? tagB : tagA;
+      for (uint32_t i = tid; i < n; i += MPF_THREADS) {
+        const uint32_t pos = (uint32_t)(s[i] >> 32), r = pos >> rb;
+        bool ok = k5_insert(tag, hmask, hshift, r, false) != 0xFFFFFFFFu;
+        if ((pos & rmask) < ovl && r > 0) ok = (k5_insert(tag, hmask, hshift, r - 1u, false) != 0xFFFFFFFFu) && ok;   // ref: mapping.c:521-533
+        if (!ok) sh_fail = 1u;
+      }
+    }
+    __syncthreads();
+    if (sh_fail) { if (tid == 0) GS_ADD(unfiltered, GS_MP_UNFILTERED, 1ull); continue; }
+    // the test, then the compaction of each list in place (its survivors wait in registers across the barrier)
+    for (int side = 0; side < 2; side++) {
+      uint64_t* s = side ? sB : sA; const uint32_t n = side ? nB : nA;
+      const uint32_t* own = side ? tagB : tagA; const uint32_t* mate = side ? tagA : tagB;
+      const int dmin = side ? dl.bmin[1 - st] : dl.amin[st], dmax = side ? dl.bmax[1 - st] : dl.amax[st];
+      auto has2 = [&](const uint32_t* tag, long long r) -> bool {
+        if (r < 0 || r > 0xFFFFFFFFll >> rb) return false;
+        uint32_t t; k5_find(tag, hmask, hshift, (uint32_t)r, t);
+        return (t & K5_FB) != 0u;
+      };
+      auto mp_ok = [&](long long X) -> bool {                  // count_main >= 2 && count_mp >= 2 (ref: mapping.c:733-742, use_mp_region_counts == 1)
+        if (!has2(own, X)) return false;
+        for (long long k = X + dmin; k <= X + dmax; k++) if (has2(mate, k)) return true;
+        return false;
+      };
+      uint64_t keep_v[MPF_PER_THREAD]; uint32_t nk = 0;
+#pragma unroll
+      for (int u = 0; u < MPF_PER_THREAD; u++) {
+        const uint32_t i = (uint32_t)tid * MPF_PER_THREAD + (uint32_t)u;          // a contiguous piece per thread: the compaction keeps the order
+        keep_v[u] = ~0ull;
+        if (i < n) {
+          const uint64_t key = s[i]; const uint32_t pos = (uint32_t)(key >> 32), r = pos >> rb;
+          if (mp_ok((long long)r) || ((pos & rmask) < ovl && r > 0 && mp_ok((long long)r - 1))) { keep_v[u] = key; nk++; }
+        }
+      }
+      // exclusive prefix of nk over the workgroup
+      uint32_t incl = nk;
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+      if (lane == 63) sh_wave[wv] = incl;
+      __syncthreads();                                         // (also: every thread has read its part of the list)
+      uint32_t base = 0, total = 0;
+      for (int k = 0; k < MPF_THREADS / 64; k++) { const uint32_t c = sh_wave[k]; if (k < wv) base += c; total += c; }
+      uint32_t o = base + incl - nk;
+#pragma unroll
+      for (int u = 0; u < MPF_PER_THREAD; u++) if (keep_v[u] != ~0ull) s[o++] = keep_v[u];
+      if (tid == 0) { if (side) cnt2[rsB] = total; else cnt1[rsA] = total; }
+      // K1's per-slab segment ends (K1b prunes slab by slab when a read-strand does not fit its table) no longer hold: one segment with everything --
+      // K1b then keeps what lies beyond the first slab as it is (its border guard), a superset of what its rules keep, still exact
+      { uint32_t* sg = side ? seg2 : seg1; const int rs = side ? rsB : rsA;
+        if (sg && tid <= n_slabs) sg[(size_t)rs * (n_slabs + 1) + tid] = tid == 0 ? 0u : total; }
+      __syncthreads();                                         // sh_wave is reused by the other side
+    }
+  }
+}
+
+int gm_launch_mp_filter(int n_pairs, int region_bits, int region_overlap, uint64_t* d_surv1, uint32_t* d_cnt1, int scap1, uint64_t* d_surv2, uint32_t* d_cnt2, int scap2,
+                        const int* dmin1, const int* dmax1, const int* dmin2, const int* dmax2, uint32_t* d_seg1, uint32_t* d_seg2, int n_slabs,
+                        unsigned long long* d_unfiltered, hipStream_t stream) {
+  if (n_pairs == 0) return GM_OK;
+  MpDelta dl;
+  const int R = 1 << region_bits;
+  auto rmin = [&](int v) { return v >= 0 ? v / R : -1 - (-v - 1) / R; };          // ref: mapping.c:2422-2430
+  auto rmax = [&](int v) { return v > 0 ? 1 + (v - 1) / R : -(-v / R); };
+  for (int st = 0; st < 2; st++) { dl.amin[st] = rmin(dmin1[st]); dl.amax[st] = rmax(dmax1[st]); dl.bmin[st] = rmin(dmin2[st]); dl.bmax[st] = rmax(dmax2[st]); }
+  const size_t lds = (size_t)(2u << MPF_HBITS) * 4;
+  static bool configured = false;
+  if (!configured) { GM_HIP(hipFuncSetAttribute((const void*)k_mp_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = true; }
+  const int grid = std::min(2 * n_pairs, 1024);
+  hipLaunchKernelGGL(k_mp_filter, dim3(grid), dim3(MPF_THREADS), lds, stream, n_pairs, region_bits, (uint32_t)region_overlap, d_surv1, d_cnt1, scap1, d_surv2, d_cnt2, scap2,
+                     dl, d_seg1, d_seg2, n_slabs, d_unfiltered);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}

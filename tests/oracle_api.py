@@ -94,6 +94,10 @@ class Session:
         s = C.string_at(p); self.L.gmo_free(p)
         return s
 
+    def last_pair_counts(self):
+        """(collapsed anchors, windows) over both mates and strands of the last paired call"""
+        o = (C.c_uint64 * 2)(); self.L.gmo_last_pair_counts(o); return int(o[0]), int(o[1])
+
     def set(self, hash_filter_calls=True, sam_unaligned=False):
         self.L.gmo_session_set(self.h, int(hash_filter_calls), int(sam_unaligned))
 

@@ -787,3 +787,27 @@ def test_text_input_matches_reference_golden(gm, mode):
     s.close(); ix.close()
     assert got == sam, _first_diff(got, sam)
     assert any(ch in l.split(b"\t")[9] for l in sam.split(b"\n") if l and not l.startswith(b"@") for ch in (b"X", b"U", b".")) or mode == "cs"
+
+
+@pytest.mark.parametrize("base,tag", [("stress_pairs_2x100", "no_half_paired"), ("cfg5s_2x150_1Mbp", "cfg5_no_half_paired")])
+def test_no_half_paired_mate_pair_region_counts(gm, oracle_lib, base, tag):
+    """A7: gm_pair_opts_t.half_paired = 0 -- k_mp_filter applies the other mate's region counts to each mate's list entries (mapping.c:545-608,733-742)
+    and the unpaired rescue is off.  SAM == the reference's `--no-half-paired` run; the stage check is the window count, which the filter changes
+    (and K1b does not): it equals the oracle's with the filter, and differs from the default paired run's."""
+    g = oa.load_golden_pairs(base)
+    want = oa.load_option_sam(base, tag)
+    o = oa.Session(g["contigs"], g["contig_names"], opts="half-paired=0")
+    o.set_pairing(g["mode"], *g["ins"])
+    o.map_pairs_sam(g["m1"], g["m2"], g["names1"], g["names2"], nthreads=4)
+    _, want_windows = o.last_pair_counts(); o.close()
+    ix = gm.Index(g["contigs"], names=g["contig_names"])
+    s = gm.Session(ix, max_batch_reads=4096)
+    opts = gm.PairOpts.default(g["mode"], g["ins"][0], g["ins"][1]); opts.half_paired = 0
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs(g["m1"], g["m2"], g["names1"], g["names2"], opts=opts)
+    st = s.stats
+    s.map_pairs(g["m1"], g["m2"], g["names1"], g["names2"], mode=g["mode"], min_insert=g["ins"][0], max_insert=g["ins"][1])
+    st_default = s.stats
+    s.close(); ix.close()
+    assert got == want, (_first_diff(got, want), st)
+    assert st["windows"] < st_default["windows"], (st["windows"], st_default["windows"])
+    if base.startswith("cfg5s"): assert st["windows"] == want_windows, (st["windows"], want_windows)     # (no read-strand beyond the LDS tiers on the uniform genome)

@@ -227,3 +227,25 @@ def test_oracle_paired_fastq_matches_reference(oracle_lib):
     got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_sam_q(g["m1"], g["m2"], q1, q2, delta, g["names1"], g["names2"], nthreads=4)
     s.close()
     assert got == sam
+
+
+NO_HALF_PAIRED = [("stress_pairs_2x100", "no_half_paired"), ("cfg5s_2x150_1Mbp", "cfg5_no_half_paired")]
+
+
+@pytest.mark.parametrize("base,tag", NO_HALF_PAIRED)
+def test_oracle_no_half_paired_matches_reference(oracle_lib, base, tag):
+    """--no-half-paired: mate-pair region counts in the anchor lists (mapping.c:545-608, use_mp_region_counts = 1) and no unpaired rescue.
+    The SAM equals the reference's; that the filter itself is restated (it rarely changes the SAM: it removes anchors that cannot pair up)
+    shows in the stage counts -- fewer collapsed anchors and windows than with the filter switched off."""
+    g = oa.load_golden_pairs(base)
+    want = oa.load_option_sam(base, tag)
+    counts = {}
+    for opts in ("half-paired=0", "half-paired=0;mp-match-mode=0"):
+        s = oa.Session(g["contigs"], g["contig_names"], opts=opts)
+        s.set_pairing(g["mode"], *g["ins"])
+        got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_sam(g["m1"], g["m2"], g["names1"], g["names2"], nthreads=4)
+        counts[opts] = s.last_pair_counts()
+        s.close()
+        if opts == "half-paired=0": assert got == want
+    a, b = counts["half-paired=0"], counts["half-paired=0;mp-match-mode=0"]
+    assert a[0] < b[0] and a[1] < b[1], (a, b)

@@ -155,6 +155,9 @@ OPTION_CASES = {
     "pairs_hashed": ("stress_pairs_2x100", ["-H", "-o", "3"]),
     "pairs_local": ("stress_pairs_2x100", ["--local"]),
     "pairs_ungapped": ("stress_pairs_2x100", ["--local", "-U"]),
+    # --no-half-paired: mate-pair region counts in the anchor lists (use_mp_region_counts = 1), no unpaired rescue
+    "no_half_paired": ("stress_pairs_2x100", ["--no-half-paired"]),
+    "cfg5_no_half_paired": ("cfg5s_2x150_1Mbp", ["--no-half-paired"]),
 }
 
 
