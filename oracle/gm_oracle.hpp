@@ -1895,10 +1895,10 @@ struct Mapper {
     return res;
   }
   static double get_pr_missed(const Read& re) { return re.read_len < 40 ? 1e-10 : (re.read_len < 60 ? 1e-14 : 1e-16); }   // mapping.h:28-37
-  double pr_random_mapping_given_score(const Read& re, int score) const {      // mapping.h:39-61 (letter space)
+  double pr_random_mapping_given_score(const Read& re, int score) const {      // mapping.h:39-61
     int read_len = re.read_len;
     if (score > read_len * P.match_score) return 1e-200;
-    unsigned a = (unsigned)(read_len * P.match_score - score), b = (unsigned)abs(P.mismatch_score - P.match_score);
+    unsigned a = (unsigned)(read_len * P.match_score - score), b = (unsigned)abs(P.colour ? P.crossover_score : P.mismatch_score - P.match_score);   // colour space: crossovers
     int n_mismatches = (a == 0) ? 0 : (int)((a - 1) / b + 1);                   // ceil_div (util.h:213-219)
     double lnck = 0.0; for (int i = 0; i < n_mismatches; i++) lnck += log(read_len - i) - log(i + 1);   // log_nchoosek (util.c:1306-1313)
     double tmp = -lnck - n_mismatches * log(3) + read_len * log(4);
@@ -1985,11 +1985,13 @@ struct Mapper {
       if (i > 0 && (re.name[i - 1] == ':' || re.name[i - 1] == '/')) i--;
       qname = re.name.substr(0, i); }
     std::string seq(re.read_len, 'N');
-    for (int i = 0; i < re.read_len; i++) {
-      char c = re.seq[i];
-      switch (c) { case 'R': case 'Y': case 'S': case 'W': case 'K': case 'M': case 'B': case 'D': case 'H': case 'V': seq[i] = 'N'; break;
-                   default: if (c >= 'a') c -= 32; seq[i] = c; break; }
-    }
+    if (!P.colour) {
+      for (int i = 0; i < re.read_len; i++) {
+        char c = re.seq[i];
+        switch (c) { case 'R': case 'Y': case 'S': case 'W': case 'K': case 'M': case 'B': case 'D': case 'H': case 'V': seq[i] = 'N'; break;
+                     default: if (c >= 'a') c -= 32; seq[i] = c; break; }
+      }
+    } else seq = "*";                                                          // output.c:353-355
     const bool paired_alignment = (rh != nullptr && rh_mp != nullptr && !improper);
     const bool query_unmapped = (rh == nullptr), mate_unmapped = (rh_mp == nullptr);
     bool reverse_strand = false, reverse_strand_mp = false;
@@ -2009,7 +2011,9 @@ struct Mapper {
     };
     if (query_unmapped) {                                                     // output.c:411-466 (half_paired => only this case)
       out += qname; snprintf(buf, sizeof buf, "\t%i\t*\t0\t0\t*\t%s\t%u\t0\t", flags(), mrnm, (unsigned)mpos); out += buf;
-      out += seq; out += "\t"; out += P.Qflag ? re.qual : std::string("*"); out += "\n";     // output.c:419-421
+      out += seq; out += "\t"; out += (P.Qflag && !P.colour) ? re.qual : std::string("*");    // output.c:419-421
+      if (P.colour) { out += "\tCQ:Z:"; out += P.Qflag ? re.qual : std::string("*"); out += "\tCS:Z:"; out += re.seq; }   // output.c:441-451
+      out += "\n";
       return;
     }
     const SwFullResults& s = rh->sfr;
@@ -2017,12 +2021,18 @@ struct Mapper {
     int read_start = s.read_start + 1, read_end = read_start + s.rmapped - 1, genome_length = (int)G->len[rh->cn];
     std::vector<std::pair<int, char>> cigar;
     make_cigar(read_start, read_end, re.read_len, s.qralign, s.dbalign, &cigar);
-    int j = read_start - 1;
+    int j = P.colour ? 0 : read_start - 1;                                       // output.c:485-493: colour space prints the aligned part only
+    if (P.colour) seq.assign(read_end - read_start + 1, 'N');
     for (size_t i = 0; i < s.qralign.size(); i++) {
       char c = s.qralign[i];
       if (c != '-') { if (c >= 'a') c -= 32; if (c != 'A' && c != 'G' && c != 'C' && c != 'T' && c != 'N') c = 'N'; seq[j++] = c; }
     }
-    seq.resize(j + (re.read_len - read_end));
+    std::string cs_qual = "*";
+    if (!P.colour) seq.resize(j + (re.read_len - read_end));
+    else {                                                                      // output.c:572-621: hard clips, post_sw's base qualities with QVs
+      for (auto& c : cigar) if (c.second == 'S') c.second = 'H';
+      if (P.Qflag && P.compute_mapping_qualities) { cs_qual = s.qual; if (rh->gen_st == 1) for (int i = 0; i < s.rmapped / 2; i++) std::swap(cs_qual[i], cs_qual[s.rmapped - i - 1]); }
+    }
     int genome_start;
     if (!reverse_strand) genome_start = s.genome_start + 1;
     else {
@@ -2048,7 +2058,8 @@ struct Mapper {
     for (auto& c : cigar) { snprintf(buf, sizeof buf, "%d%c", c.first, c.second); out += buf; }
     snprintf(buf, sizeof buf, "\t%s\t%u\t%i\t", mrnm, (unsigned)mpos, isize); out += buf;
     out += seq; out += "\t";
-    if (P.Qflag) {                               // output.c:539-570
+    if (P.colour) out += cs_qual;
+    else if (P.Qflag) {                          // output.c:539-570
       std::string qual = re.qual;
       if (reverse_strand) std::reverse(qual.begin(), qual.end());
       if (P.qual_delta != 33) for (auto& c : qual) c = (char)(c - P.qual_delta + 33);
@@ -2064,7 +2075,13 @@ struct Mapper {
                  double_to_neglog(s.pr_top_random_at_location), double_to_neglog(s.pr_missed_mp));
       out += buf;
     }
-    snprintf(buf, sizeof buf, "\tNM:i:%d\n", s.mismatches + s.deletions + s.insertions); out += buf;
+    snprintf(buf, sizeof buf, "\tNM:i:%d", s.mismatches + s.deletions + s.insertions); out += buf;
+    if (P.colour) {                             // output.c:717-730
+      if (P.Qflag) { out += "\tCQ:Z:"; out += re.qual; }
+      out += "\tCS:Z:"; out += re.seq;
+      snprintf(buf, sizeof buf, "\tCM:i:%d\tXX:Z:", s.crossovers); out += buf; out += s.qralign;
+    }
+    out += "\n";
   }
 
   // readpair_output (output.c:1070-1291), default flags (no single-best-mapping)

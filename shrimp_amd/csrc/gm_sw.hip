@@ -1090,7 +1090,8 @@ k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__
            int read_words, const GmHit* __restrict__ hits, int hcap, const int32_t* __restrict__ sel,
            const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work_p, GmFullRes* __restrict__ res, uint8_t* __restrict__ ops, int ops_stride,
            uint32_t* __restrict__ back_pool, size_t back_words, int max_w, unsigned long long* __restrict__ stats,
-           const int8_t* __restrict__ xover) {         // [n_reads][read_len] crossover scores from the QVs, or null
+           const int8_t* __restrict__ xover,           // [n_reads][read_len] crossover scores from the QVs, or null
+           const int32_t* __restrict__ sel_sidx) {     // paired mode: the windows' positions in their reads' lists (ref: mapping.c:2545-2552), or null
   extern __shared__ __align__(16) uint8_t sm[];
   const int lane = threadIdx.x;
   const int qstride = (read_len + 15) & ~15;
@@ -1143,7 +1144,7 @@ k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__
     R.score_vector = h.score_vector; R.score_max = score_max; R.matches = h.matches; R.score_window_gen = h.score_window_gen;
     R.score = 0; R.read_start = 0; R.rmapped = 0; R.genome_start = 0; R.gmapped = 0;
     R.n_match = R.n_mismatch = R.n_ins = R.n_del = 0; R.n_ops = 0; R.ops_off = (uint32_t)(wi * (uint32_t)ops_stride);
-    R.sort_idx = 0; R.hit_slot = (uint32_t)slot; R.n_xover = 0;
+    R.sort_idx = sel_sidx ? sel_sidx[(size_t)rd * SEL_MAX + k] : 0; R.hit_slot = (uint32_t)slot; R.n_xover = 0;
     long long nw = ax + ay, sw = ax - ay, ne = sw + 2 * (h.awidth - 1), se = nw + 2 * (h.alen - 1);      // anchor_join + anchor_widen, ref: anchors.c:9-61
     if ((nw + sw) % 2 != 0) nw--;
     long long rx = (nw + sw) / 2, ry = nw - rx;
@@ -1203,7 +1204,7 @@ k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__
 int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs_params9, const uint32_t* d_reads, const uint8_t* d_initbp, int n_reads,
                        int read_len, int read_words, int window_len, const GmHit* d_hits, int hcap, const int32_t* d_sel, const uint32_t* d_work,
                        const uint32_t* d_n_work, GmFullRes* d_res, uint8_t* d_ops, int ops_stride, uint32_t* d_back, size_t back_words, int grid,
-                       unsigned long long* d_stats, hipStream_t stream, const int8_t* d_xover) {
+                       unsigned long long* d_stats, hipStream_t stream, const int8_t* d_xover, const int32_t* d_sel_sidx) {
   if (n_reads == 0) return GM_OK;
   GmCsDev P; P.match = cs_params9[0]; P.mismatch = cs_params9[1]; P.xover = cs_params9[2]; P.a_go = cs_params9[3]; P.a_ge = cs_params9[4];
   P.b_go = cs_params9[5]; P.b_ge = cs_params9[6]; P.anchor_width = cs_params9[7]; P.taboo = cs_params9[8];
@@ -1212,7 +1213,7 @@ int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs
   static size_t configured = 0;
   if (lds > 48 * 1024 && lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
   hipLaunchKernelGGL(k_pass2_cs, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, P, d_reads, d_initbp, n_reads, read_len, read_words, d_hits, hcap, d_sel,
-                     d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_words, window_len, d_stats, d_xover);
+                     d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_words, window_len, d_stats, d_xover, d_sel_sidx);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

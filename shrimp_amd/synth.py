@@ -159,6 +159,18 @@ def make_cs_reads(contigs: list[np.ndarray], n_reads: int, n_colours: int, seed:
     return out, {"cn": cn.astype(np.int32), "pos": pos, "strand": strand}
 
 
+def cs_from_letters(codes: np.ndarray, seed: int, p_col: float = 0.03) -> np.ndarray:
+    """Letter-space reads as sequenced -> colour-space reads behind a 'T' primer (colour = XOR of adjacent 2-bit codes) with per-colour
+    substitutions: codes[n, 1 + L], column 0 the primer letter code (3 = T).  Used for colour-space pairs (mates from make_pairs)."""
+    rng = np.random.default_rng(seed + 4_000_004)
+    b = np.asarray(codes, dtype=np.uint8) & 3
+    prev = np.concatenate([np.full((b.shape[0], 1), 3, np.uint8), b[:, :-1]], axis=1)
+    col = (prev ^ b) & 3
+    err = rng.random(col.shape) < p_col
+    col = np.where(err, (col + rng.integers(1, 4, col.shape)) & 3, col).astype(np.uint8)
+    return np.concatenate([np.full((b.shape[0], 1), 3, np.uint8), col], axis=1)
+
+
 def write_csfasta_reads(path: str, reads: np.ndarray) -> None:
     """codes[n, 1 + colours] -> csfasta (primer letter, then colours 0-3 or '.')"""
     n, L = reads.shape
