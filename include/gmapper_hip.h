@@ -268,9 +268,9 @@ void gm_pair_opts_default(gm_pair_opts_t *o);
 int gm_map_pairs(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_packed, int len2, const uint32_t *mates2_packed,
                  const char *names1, const char *names2, const gm_pair_opts_t *opts,
                  char **sam, size_t *sam_len, gm_map_stats_t *stats);
-/* Colour-space pairs (gmapper-cs -p opp-in; ref: handle_readpair mapping.c:2502-2636 with the colour-space branches of read_pass1_per_strand :1297-1319,
+/* Colour-space pairs (gmapper-cs -p <mode>; ref: handle_readpair mapping.c:2502-2636 with the colour-space branches of read_pass1_per_strand :1297-1319,
  * hit_run_full_sw :375-379 and hit_output output.c:353-355,441-451,485-537,572-580,717-730): mates as packed colours and one primer-letter byte per read, as
- * gm_map_reads_cs takes them.  Pair modes that reverse a mate (opp-out, col-fw, col-bw) and quality values are refused: not implemented. */
+ * gm_map_reads_cs takes them, in all four pair modes (a mate the mode reverses keeps its colours and swaps its strand labels).  Quality values are refused: not implemented. */
 int gm_map_pairs_cs(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_packed, const uint8_t *initbp1, int len2, const uint32_t *mates2_packed,
                     const uint8_t *initbp2, const char *names1, const char *names2, const gm_pair_opts_t *opts,
                     char **sam, size_t *sam_len, gm_map_stats_t *stats);

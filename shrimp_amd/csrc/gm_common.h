@@ -46,6 +46,8 @@ struct GmIndexDev {
   const uint32_t* genome_cs;          // colour space only: colour p = lstocs(letter p-1, letter p), 'T' before a contig's first letter (ref: fasta.c:586-606)
   int colour;                         // 1 in colour space (== min_kmer_pos, ref: gmapper.c:477-480)
   int hflag;                          // -H: lists are keyed by kmer_to_mapidx_hash, 4^12 of them per seed (ref: gmapper.h:323-336)
+  int cs_flip;                        // colour space, a mate the pair mode reverses (read_reverse, ref: gmapper.c:174-185): the read keeps its colours, its strand LABELS
+                                      // swap -- strand label st stands for strand st ^ cs_flip of the read as sequenced, which is then the read's input strand
   uint64_t total_len;                 // sum of contig lengths (< 2^32)
   int n_contigs;
   const uint32_t* contig_off;         // [n_contigs+1] global offsets (ref: contig_offsets[])

@@ -139,7 +139,7 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
   auto fill_codes = [&](const int r, uint8_t* cb) {
     if (r >= 2 * a.n_reads) return;
     const uint32_t* rw = a.reads + (size_t)(r >> 1) * a.read_words;
-    for (int i = tid; i < a.read_len; i += nthr) cb[i] = (uint8_t)gm_read_code(rw, a.read_len, r & 1, ix.colour, i);
+    for (int i = tid; i < a.read_len; i += nthr) cb[i] = (uint8_t)gm_read_code(rw, a.read_len, (r & 1) ^ ix.cs_flip, ix.colour, i);
   };
   // A thread keeps the same k-mer slot (seed, offset in the read) for every read-strand: its seed's span and mask stay in registers, the seed's
   // pointers in a small LDS table.  (ix.seed[sn] with a run-time sn is a chain of loads from the kernel-argument segment -- a memory round trip
@@ -214,7 +214,7 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
     } else {
     const int rd = rs >> 1, st = rs & 1;
     const uint32_t* rw = a.reads + (size_t)rd * a.read_words;
-    for (int i = tid; i < a.read_len; i += nthr) codes[i] = (uint8_t)gm_read_code(rw, a.read_len, st, ix.colour, i);
+    for (int i = tid; i < a.read_len; i += nthr) codes[i] = (uint8_t)gm_read_code(rw, a.read_len, st ^ ix.cs_flip, ix.colour, i);
     __syncthreads();                                           // also: the tables and the control words are clear
     // ---- map indexes, list bounds, strip-list bounds (ref: mapping.c:53-66, KMER_TO_MAPIDX gmapper.h:349-368) ----
     for (int off = tid; off < a.NL; off += nthr) {

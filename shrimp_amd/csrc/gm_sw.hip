@@ -284,7 +284,7 @@ k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
     // ref :1295 -- a window keeps a positive score from an earlier pass (paired mode runs pass 1 twice); unpaired: always <= 0 here
     if (h->score_vector > 0) continue;
     const uint64_t g0 = (uint64_t)ix.contig_off[cn] + goff;
-    if (CS) load_window_cs(ix, cn, goff, w_len, st != 0, ib, db, db0, lane);
+    if (CS) load_window_cs(ix, cn, goff, w_len, st != ix.cs_flip, ib, db, db0, lane);      // the hit is turned onto the read's input strand (label cs_flip)
     else load_window(ix.genome, g0, w_len, false, db, lane);
     __syncthreads();
     int score = -1; bool computed = false;
@@ -574,7 +574,7 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
     if ((h.flags & 1u) && !GM_ABL(4)) sv = h.score_vector;
     else { sv = sw_vector_wave(db, w_len, qr, read_len, sc, (int16_t*)carry, lane); vcalls++; vcells += (unsigned long long)w_len * read_len; }
     GmFullRes R;
-    R.read_idx = rd; R.st = 0; R.gen_st = (int16_t)gen_st; R.cn = (uint32_t)cn; R.g_off = (uint32_t)g_off; R.w_len = w_len;
+    R.read_idx = rd; R.st = (int16_t)ix.cs_flip; R.gen_st = (int16_t)gen_st; R.cn = (uint32_t)cn; R.g_off = (uint32_t)g_off; R.w_len = w_len;
     R.score_vector = sv; R.score_max = score_max; R.matches = h.matches; R.score_window_gen = h.score_window_gen;
     R.score = 0; R.read_start = 0; R.rmapped = 0; R.genome_start = 0; R.gmapped = 0;
     R.n_match = R.n_mismatch = R.n_ins = R.n_del = 0; R.n_ops = 0; R.ops_off = (uint32_t)(wi * (uint32_t)ops_stride);
@@ -1129,7 +1129,7 @@ k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__
     const int cn = h.cn, w_len = h.w_len;
     const long long clen = (long long)ix.contig_off[cn + 1] - ix.contig_off[cn];
     long long g_off = h.g_off; long long ax = h.ax, ay = h.ay; int gen_st = 0;
-    if (st != 0) {                                      // reverse_hit, ref: mapping.c:254-263; anchor_reverse anchors.h:30-34
+    if (st != ix.cs_flip) {                             // reverse_hit onto the input strand (label cs_flip), ref: mapping.c:254-263; anchor_reverse anchors.h:30-34
       g_off = clen - g_off - w_len;
       ax = -ax + (w_len - 1) - (h.alen - 1) - (h.awidth - 1);
       ay = -ay + (read_len - 1) - (h.alen - 1) + (h.awidth - 1);
@@ -1140,7 +1140,7 @@ k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__
     const int score_max = (read_len < w_len ? read_len : w_len) * sc.match;
     const int thresh = thr_of(sc.full_thr_frac, sc.full_abs, score_max);
     GmFullRes R;
-    R.read_idx = rd; R.st = 0; R.gen_st = (int16_t)gen_st; R.cn = (uint32_t)cn; R.g_off = (uint32_t)g_off; R.w_len = w_len;
+    R.read_idx = rd; R.st = (int16_t)ix.cs_flip; R.gen_st = (int16_t)gen_st; R.cn = (uint32_t)cn; R.g_off = (uint32_t)g_off; R.w_len = w_len;
     R.score_vector = h.score_vector; R.score_max = score_max; R.matches = h.matches; R.score_window_gen = h.score_window_gen;
     R.score = 0; R.read_start = 0; R.rmapped = 0; R.genome_start = 0; R.gmapped = 0;
     R.n_match = R.n_mismatch = R.n_ins = R.n_del = 0; R.n_ops = 0; R.ops_off = (uint32_t)(wi * (uint32_t)ops_stride);

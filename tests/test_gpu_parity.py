@@ -813,18 +813,18 @@ def test_no_half_paired_mate_pair_region_counts(gm, oracle_lib, base, tag):
     if base.startswith("cfg5s"): assert st["windows"] == want_windows, (st["windows"], want_windows)     # (no read-strand beyond the LDS tiers on the uniform genome)
 
 
-def test_colour_space_pairs_match_reference_golden(gm):
+@pytest.mark.parametrize("mode", ["opp-in", "opp-out", "col-fw", "col-bw"])
+def test_colour_space_pairs_match_reference_golden(gm, mode):
     """paired colour space (gm_map_pairs_cs, pair mode opp-in): K1 / pair-up / CS filter / sw_full_cs at half the threshold / post_sw / readpair_pass2 / the unpaired
-    rescue / CS SAM fields -- byte-identical to gmapper-cs -p opp-in -I 100,600 --sam-unaligned (paired, half-paired and unaligned records)"""
-    import gzip
-    g = oa.load_golden_pairs("cs_pairs_50col_opp-in")
-    with gzip.open(os.path.join(oa.ROOT, "tests", "golden", "cs_pairs_50col_opp-in.sam.gz"), "rb") as f: want = f.read()
+    rescue / CS SAM fields -- byte-identical to gmapper-cs -p <mode> -I 100,600 --sam-unaligned (paired, half-paired and unaligned records); in opp-out, col-fw and
+    col-bw a mate is reversed: it keeps its colours and swaps its strand labels (GmIndexDev::cs_flip)"""
+    g = oa.load_golden_pairs("cs_pairs_50col_" + mode)
+    want = g["sam"]
     p = gm.default_params_cs(); p.sam_unaligned = 1
     ix = gm.Index(g["contigs"], names=g["contig_names"], params=p)
     s = gm.Session(ix, params=p, max_batch_reads=4096)
     got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_cs(g["m1"], g["m2"], g["names1"], g["names2"], mode=g["mode"],
                                                                            min_insert=g["ins"][0], max_insert=g["ins"][1])
     st = s.stats
-    with pytest.raises(RuntimeError): s.map_pairs_cs(g["m1"][:4], g["m2"][:4], mode="col-fw")     # a pair mode that reverses a mate: refused
     s.close(); ix.close()
     assert got == want, (_first_diff(got, want), st)

@@ -251,11 +251,11 @@ def test_oracle_no_half_paired_matches_reference(oracle_lib, base, tag):
     assert a[0] < b[0] and a[1] < b[1], (a, b)
 
 
-def test_oracle_colour_space_pairs_match_reference(oracle_lib):
-    """gmapper-cs -p opp-in -I 100,600 --sam-unaligned: paired, half-paired and unaligned records with the colour-space fields"""
-    import gzip, os
-    g = oa.load_golden_pairs("cs_pairs_50col_opp-in")
-    with gzip.open(os.path.join(oa.ROOT, "tests", "golden", "cs_pairs_50col_opp-in.sam.gz"), "rb") as f: want = f.read()
+@pytest.mark.parametrize("mode", ["opp-in", "opp-out", "col-fw", "col-bw"])
+def test_oracle_colour_space_pairs_match_reference(oracle_lib, mode):
+    """gmapper-cs -p <mode> -I 100,600 --sam-unaligned: paired, half-paired and unaligned records with the colour-space fields; three of the modes reverse a mate"""
+    g = oa.load_golden_pairs("cs_pairs_50col_" + mode)
+    want = g["sam"]
     s = oa.Session(g["contigs"], g["contig_names"], opts="colour=1"); s.set(True, True)
     s.set_pairing(g["mode"], *g["ins"])
     got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_sam(g["m1"], g["m2"], g["names1"], g["names2"], nthreads=4)

@@ -273,31 +273,39 @@ def cs_cases():
 
 
 def cs_pair_case():
-    """colour-space pairs through the reference's gmapper-cs -p opp-in (mates adjacent in one csfasta file)"""
+    """colour-space pairs through the reference's gmapper-cs -p <mode> (mates adjacent in one csfasta file): opp-in with unmappable mates and skipped
+    cycles; the three modes that reverse a mate (read_reverse swaps the strands of a colour read) on 300 pairs each"""
     contigs = synth.make_genome([600_000, 400_000], 55)
-    reads, _ = synth.make_pairs(contigs, 800, 50, 15, ins_mean=250, ins_sd=30)
-    m1 = synth.cs_from_letters(reads[0::2], 1); m2 = synth.cs_from_letters(reads[1::2], 2)
-    rng = np.random.default_rng(17)                                   # some mates that map nowhere: half-paired records, unaligned pairs
-    for i in range(len(m1)):
-        if i % 20 == 7: m2[i, 1:] = rng.integers(0, 4, m2.shape[1] - 1)
-        if i % 50 == 3: m1[i, 1:] = rng.integers(0, 4, m1.shape[1] - 1); m2[i, 1:] = rng.integers(0, 4, m2.shape[1] - 1)
-        if i % 33 == 5: m1[i, 10] = 15                                  # a skipped cycle ('.')
-    n = len(m1); names1 = [b"p%d/1" % i for i in range(n)]; names2 = [b"p%d/2" % i for i in range(n)]
-    name = "cs_pairs_50col_opp-in"; mode = "opp-in"; ins = (100, 600); cn = [b"contig1", b"contig2"]
-    with tempfile.TemporaryDirectory() as d:
-        g = os.path.join(d, "g.fa"); r = os.path.join(d, "r.csfasta")
-        write_fa_codes(g, cn, contigs)
-        with open(r, "wb") as f:
-            for i in range(n):
-                for nm, row in ((names1[i], m1[i]), (names2[i], m2[i])):
-                    f.write(b">" + nm + b"\n" + b"ACGT"[row[0]:row[0] + 1] + bytes(b"0123"[c] if c < 4 else ord(".") for c in row[1:]) + b"\n")
-        p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "gmapper-cs"), "-N", "4", "-p", mode, "-I", "%d,%d" % ins, "--sam-unaligned", r, g], capture_output=True, check=True)
-        body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), **{"contig%d" % i: c for i, c in enumerate(contigs)}, mates1=m1, mates2=m2,
-                        names1=np.array(names1), names2=np.array(names2), contig_names=np.array(cn), mode=np.array(mode), ins=np.array(ins))
-    with gzip.open(os.path.join(OUT, name + ".sam.gz"), "wb", compresslevel=9) as f:
-        f.write(body)
-    print("%s: %d colour-space pairs -> %d SAM records" % (name, n, sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@"))))
+    cn = [b"contig1", b"contig2"]; ins = (100, 600)
+    rcl = lambda x: synth.COMPLEMENT[x[:, ::-1]]
+    for mode, npairs, seed in (("opp-in", 800, 15), ("opp-out", 300, 21), ("col-fw", 300, 22), ("col-bw", 300, 23)):
+        reads, _ = synth.make_pairs(contigs, npairs, 50, seed, ins_mean=250, ins_sd=30)
+        a, b = reads[0::2].copy(), reads[1::2].copy()               # make_pairs yields opp-in mates: the other orientations are derived from them
+        if mode == "opp-out": a, b = rcl(a), rcl(b)
+        elif mode == "col-fw": b = rcl(b)
+        elif mode == "col-bw": a = rcl(a)
+        m1 = synth.cs_from_letters(a, 1); m2 = synth.cs_from_letters(b, 2)
+        rng = np.random.default_rng(17)                               # some mates that map nowhere: half-paired records, unaligned pairs
+        for i in range(len(m1)):
+            if i % 20 == 7: m2[i, 1:] = rng.integers(0, 4, m2.shape[1] - 1)
+            if i % 50 == 3: m1[i, 1:] = rng.integers(0, 4, m1.shape[1] - 1); m2[i, 1:] = rng.integers(0, 4, m2.shape[1] - 1)
+            if i % 33 == 5: m1[i, 10] = 15                              # a skipped cycle ('.')
+        n = len(m1); names1 = [b"p%d/1" % i for i in range(n)]; names2 = [b"p%d/2" % i for i in range(n)]
+        name = "cs_pairs_50col_" + mode
+        with tempfile.TemporaryDirectory() as d:
+            g = os.path.join(d, "g.fa"); r = os.path.join(d, "r.csfasta")
+            write_fa_codes(g, cn, contigs)
+            with open(r, "wb") as f:
+                for i in range(n):
+                    for nm, row in ((names1[i], m1[i]), (names2[i], m2[i])):
+                        f.write(b">" + nm + b"\n" + b"ACGT"[row[0]:row[0] + 1] + bytes(b"0123"[c] if c < 4 else ord(".") for c in row[1:]) + b"\n")
+            p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "gmapper-cs"), "-N", "4", "-p", mode, "-I", "%d,%d" % ins, "--sam-unaligned", r, g], capture_output=True, check=True)
+            body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **{"contig%d" % i: c for i, c in enumerate(contigs)}, mates1=m1, mates2=m2,
+                            names1=np.array(names1), names2=np.array(names2), contig_names=np.array(cn), mode=np.array(mode), ins=np.array(ins))
+        with gzip.open(os.path.join(OUT, name + ".sam.gz"), "wb", compresslevel=9) as f:
+            f.write(body)
+        print("%s: %d colour-space pairs -> %d SAM records" % (name, n, sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@"))))
 
 
 def fastq_cases():
