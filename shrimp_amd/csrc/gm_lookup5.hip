@@ -667,8 +667,9 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
     const double lists = std::max(0, read_len - ix.seed[sn].span + 1 - ix.colour);
     entries += lists * (double)ix.seed[sn].n_pos / (double)(1ull << (ix.hflag ? 2 * GM_HASH_TABLE_POWER : 2 * ix.seed[sn].weight));
   }
-  // the fixed cost per read-strand (144 KB of table clears, six barriers) pays off from a few ten thousand list entries per read-strand
-  if (!forced && entries < 30000.0) return 0;
+  // the fixed cost per read-strand (144 KB of table clears, the barriers) pays off from several thousand list entries per read-strand: 50-colour reads on
+  // 3 Gbp (17 k entries) take 74 ms per 500 k reads here against 124 ms in the slab-sweep kernel
+  if (!forced && entries < 8000.0) return 0;
   // LDS: twice (1/8 of seen) | seen | 32 B per list | codes | control words
   const size_t fixed = (size_t)32 * NL + 2 * (size_t)((read_len + 15) & ~15) + C_WORDS * 4 + GM_MAX_SEEDS * 32;   // (+ the seed table)
   const size_t budget = 160 * 1024 - 512;
