@@ -440,7 +440,11 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   if ((s->P.colour_space != 0) != (ix->params.colour_space != 0)) { delete s; gm_set_error("session and index disagree on colour space"); return GM_E_ARG; }
   s->max_batch = std::max(64, std::min(max_batch_reads > 0 ? max_batch_reads : 131072, 1 << 20));
   if (const char* e = gm_tune("GM_P2_GRID")) s->p2_grid = std::max(64, std::min(65536, atoi(e)));
-  GM_HIP(hipStreamCreate(&s->stream));
+  // The front stream gets the higher queue priority: K1's fall-back kernels (a few workgroups that each want most of a CU's LDS) otherwise wait for milliseconds
+  // behind the back stream's thousands of small pass-1 workgroups, which refill every CU the moment the persistent K1 grid has left it.
+  { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (getenv("GM_STREAM_PRIO_OFF") || hi == lo) { GM_HIP(hipStreamCreate(&s->stream)); }
+    else GM_HIP(hipStreamCreateWithPriority(&s->stream, hipStreamDefault, hi)); }
   GM_HIP(hipStreamCreateWithFlags(&s->stream_b, hipStreamNonBlocking));
   GM_HIP(hipStreamCreateWithFlags(&s->stream_c, hipStreamNonBlocking));
   for (auto& e : s->ev) GM_HIP(hipEventCreate(&e));

@@ -74,7 +74,8 @@ int gm_lookup5_start_flag_grid(void);
 int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words, int max_n_kmers, int NL,
                       uint64_t* d_out, uint32_t* d_out_cnt, int out_cap, uint32_t* d_surv_cnt, int prune, uint32_t D, int e_max,
                       uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap, unsigned long long* d_stats, hipStream_t stream,
-                      uint32_t** fb_list, uint32_t** fb_cnt, int* fb_cap_out);
+                      uint32_t** fb_list, uint32_t** fb_cnt, int* fb_cap_out,
+                      uint64_t* d_raw = nullptr, int raw_cap = 0, uint32_t* d_surv_seg = nullptr, uint32_t** pl_list = nullptr, uint32_t** pl_cnt = nullptr);
 int gm_launch_lookup_redo(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
                           int n_heavy, const uint32_t* d_redo_list, const uint64_t* d_redo_off, uint64_t* d_out,
                           unsigned long long* d_stats, hipStream_t stream);

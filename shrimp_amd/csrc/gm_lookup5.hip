@@ -42,7 +42,7 @@ typedef __attribute__((address_space(3))) uint32_t k5_lds_u32;
 #ifndef K5_Q
 #define K5_Q 6            // list chunks in flight per wave (8 and 10 measured: no gain)
 #endif
-enum { C_NCAND = 0, C_OVERFLOW, C_NMEMB, C_NKEEP, C_NSTRIP, C_NEDGE, C_NLISTS /* two words: read-strands alternate */, C_SINK = 8, C_WORDS = 12 };
+enum { C_NCAND = 0, C_OVERFLOW, C_NMEMB, C_NKEEP, C_NSTRIP, C_NEDGE, C_NLISTS /* two words: read-strands alternate */, C_SINK = 8, C_NRAW = 9, C_WORDS = 12 };
 
 // Diagnostic build (-DK5_STAMPS): thread 0 of every workgroup adds the cycles between the phase boundaries of each read-strand to k5_stamps[]
 // (0-5: setup, pass A, pass B, region table, rules + output, clears; 6, 7: candidates, fallbacks; 8-11: parts of set-up / the exact stages, taken out of
@@ -71,6 +71,9 @@ struct K5Args {
   unsigned long long* stats;
   uint32_t* fb_list; uint32_t* fb_cnt; int fb_cap;
   uint32_t* start_flags; uint32_t start_epoch;
+  // fused prune only: a read-strand that keeps more than out_cap survivors under the region-sized bins writes ALL its members to its raw row and goes to pl_list --
+  // k_prune (256-base bins) prunes it from there; without this the lane-per-list kernel had to produce the members again
+  uint64_t* raw_out; int raw_cap; uint32_t* surv_seg; int n_slabs; uint32_t* pl_list; uint32_t* pl_cnt; int pl_cap;
 };
 
 // lane * W for a wave-uniform W in 1..4 without the quarter-rate 32-bit multiply
@@ -537,7 +540,43 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
     }
     __syncthreads();
     if (ctrl[C_OVERFLOW] != 0u) fallback = true;                    // (the list of stage 2 ran over)
-    if (!fallback && a.prune && ctrl[C_NKEEP] > (uint32_t)a.out_cap) fallback = true;   // more kept than K2's LDS tier takes: k_prune's finer bins get the last word before the heavy tier
+    // More kept than K2's LDS tier takes (1 read-strand in 8 000 on the benchmark genome): k_prune's finer bins get the last word before the heavy tier.  The members are
+    // all here, so they go to the read-strand's raw row as K1 without the fused rules would have left them, and only k_prune runs for it (list pl_list).  (Sending these
+    // read-strands back through the lane-per-list kernel cost 1-6 ms per launch: its few large-LDS workgroups queue behind the other stream's pass-1 workgroups.)
+    bool prune_only = false;
+    if (!fallback && a.prune && ctrl[C_NKEEP] > (uint32_t)a.out_cap) {
+      if (a.raw_out && ctrl[C_NMEMB] <= (uint32_t)a.raw_cap) {
+        prune_only = true;
+        unsigned long long* raw = (unsigned long long*)a.raw_out + (size_t)rs * a.raw_cap;
+        // slab by slab, as the sweep kernels leave them (K1b prunes a long row per slab segment: surv_seg)
+        for (int sl = 0; sl < a.n_slabs; sl++) {
+        for (uint32_t i0 = 0; i0 < nc; i0 += nthr) {
+          const uint32_t i = i0 + tid;
+          bool memb = false; uint32_t p = 0;
+          if (i < nc) {
+            const uint32_t w = candp[i], h = w >> 16, off = w & 0xFFFFu, town = htag[h], r = (town >> 8) - 1u;
+            p = (r << rb) | off;
+            if ((int)(p >> ix.slab_bits) == sl || (sl == a.n_slabs - 1 && (int)(p >> ix.slab_bits) >= a.n_slabs)) {
+              memb = (town & K5_FB) != 0u;
+              if (!memb && off < ovl && r > 0) { uint32_t tlf; k5_find(htag, hmask, hshift, r - 1u, tlf); memb = (tlf & K5_FB) != 0u; }
+            }
+          }
+          const unsigned long long bm = __ballot(memb);
+          if (bm) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&ctrl[C_NRAW], (uint32_t)__popcll(bm));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (memb) {
+              const uint32_t slot = base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull)), y16 = candy[i];
+              if (slot < (uint32_t)a.raw_cap) raw[slot] = ((unsigned long long)p << 32) | ((unsigned long long)(y16 >> 4) << 16) | (y16 & 15u);
+            }
+          }
+        }
+        __syncthreads();
+        if (tid == 0 && a.surv_seg) { if (sl == 0) a.surv_seg[(size_t)rs * (a.n_slabs + 1)] = 0u; a.surv_seg[(size_t)rs * (a.n_slabs + 1) + sl + 1] = ctrl[C_NRAW]; }
+        }
+      } else fallback = true;
+    }
     K5_STAMP(4);
 #ifdef K5_STAMPS
     if (tid == 0) { atomicAdd(&k5_stamps[6], (unsigned long long)nc); if (fallback) atomicAdd(&k5_stamps[7], 1ull); }
@@ -546,6 +585,12 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
       if (fallback) {                                          // candidates beyond the LDS tiers: the slab-sweep kernel redoes this read-strand
         const uint32_t f = atomicAdd(a.fb_cnt, 1u);
         if (f < (uint32_t)a.fb_cap) a.fb_list[f] = (uint32_t)rs; else GS_ADD(a.stats, GS_OVERFLOW_SURV, 1ull);
+      } else if (prune_only) {                                 // members in the raw row, segment ends written above
+        const uint32_t nm = ctrl[C_NRAW];
+        a.surv_cnt[rs] = nm;
+        GS_ADD(a.stats, GS_SURVIVORS, (unsigned long long)nm);
+        const uint32_t f = atomicAdd(a.pl_cnt, 1u);
+        if (f < (uint32_t)a.pl_cap) a.pl_list[f] = (uint32_t)rs; else GS_ADD(a.stats, GS_OVERFLOW_SURV, 1ull);
       } else {
         const uint32_t nm = ctrl[C_NMEMB], nk = ctrl[C_NKEEP];
         a.surv_cnt[rs] = nm;
@@ -559,7 +604,7 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
         }
       }
       for (int c = 0; c < C_NLISTS; c++) ctrl[c] = 0;
-      *cnl = 0;
+      *cnl = 0; ctrl[C_NRAW] = 0;
     }
     { uint4* t4 = (uint4*)smem; for (int w = tid; w < tab_q; w += nthr) t4[w] = make_uint4(0, 0, 0, 0); }
     K5_STAMP(5);
@@ -648,7 +693,7 @@ int gm_index_derive_strips(GmIndexHost* ix, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 // launch: returns 1 when v5 ran (0: geometry does not fit, the caller takes another kernel; < 0: error)
 // ---------------------------------------------------------------------------------------------
-struct K5Scratch { uint32_t* fb = nullptr; int fb_cap = 0; int cus = 0; };
+struct K5Scratch { uint32_t* fb = nullptr; uint32_t* pl = nullptr; int fb_cap = 0; int cus = 0; };   // fb: read-strands for the lane-per-list kernel + K1b; pl: for K1b only
 static K5Scratch g_k5[16];
 static uint32_t* g_k5_flags = nullptr; static uint32_t g_k5_epoch = 0; static int g_k5_flag_cap = 0, g_k5_flag_grid = 0;
 void gm_lookup5_set_start_flags(uint32_t* flags, int cap, uint32_t epoch) { g_k5_flags = flags; g_k5_flag_cap = cap; g_k5_epoch = epoch; g_k5_flag_grid = 0; }
@@ -657,7 +702,8 @@ int gm_lookup5_start_flag_grid(void) { return g_k5_flag_grid; }
 int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words, int max_n_kmers, int NL,
                       uint64_t* d_out, uint32_t* d_out_cnt, int out_cap, uint32_t* d_surv_cnt, int prune, uint32_t D, int e_max,
                       uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap, unsigned long long* d_stats, hipStream_t stream,
-                      uint32_t** fb_list, uint32_t** fb_cnt, int* fb_cap_out) {
+                      uint32_t** fb_list, uint32_t** fb_cnt, int* fb_cap_out,
+                      uint64_t* d_raw, int raw_cap, uint32_t* d_surv_seg, uint32_t** pl_list, uint32_t** pl_cnt) {
   int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
   if (!ix.seed[0].sdir || ix.region_bits < 9 || ix.region_bits > 16 || NL <= 0) return 0;
   K5Scratch& K = g_k5[dev];
@@ -699,12 +745,13 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   const int fb_cap = std::max(4096, 2 * n_reads);              // every read-strand may fall back (tiny tables in the tests, repeats)
   if (!K.cus) { if (hipDeviceGetAttribute(&K.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || K.cus < 1) K.cus = 256; }
   if (fb_cap > K.fb_cap) {
-    if (K.fb) { (void)hipDeviceSynchronize(); (void)hipFree(K.fb); K.fb = nullptr; K.fb_cap = 0; }
+    if (K.fb) { (void)hipDeviceSynchronize(); (void)hipFree(K.fb); (void)hipFree(K.pl); K.fb = nullptr; K.pl = nullptr; K.fb_cap = 0; }
     if (hipMalloc(&K.fb, (size_t)(fb_cap + 4) * 4) != hipSuccess) return 0;
+    if (hipMalloc(&K.pl, (size_t)(fb_cap + 4) * 4) != hipSuccess) return 0;
     K.fb_cap = fb_cap;
   }
-  uint32_t* const fb_cnt_p = K.fb + K.fb_cap;
-  if (hipMemsetAsync(fb_cnt_p, 0, 4, stream) != hipSuccess) return GM_E_NODEVICE;
+  uint32_t* const fb_cnt_p = K.fb + K.fb_cap; uint32_t* const pl_cnt_p = K.pl + K.fb_cap;
+  if (hipMemsetAsync(fb_cnt_p, 0, 4, stream) != hipSuccess || hipMemsetAsync(pl_cnt_p, 0, 4, stream) != hipSuccess) return GM_E_NODEVICE;
   static size_t configured = 0;
   if (lds > 48 * 1024 && lds > configured) { if (hipFuncSetAttribute((const void*)k_lookup_v5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0; configured = lds; }
   int grid = std::min(2 * n_reads, K.cus);
@@ -715,11 +762,12 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   a.out = d_out; a.out_cnt = d_out_cnt; a.out_cap = out_cap; a.surv_cnt = d_surv_cnt; a.prune = prune; a.D = D; a.e_max = e_max;
   a.heavy_list = d_heavy_list; a.heavy_cnt = d_heavy_cnt; a.heavy_cap = heavy_cap; a.stats = d_stats;
   a.fb_list = K.fb; a.fb_cnt = fb_cnt_p; a.fb_cap = fb_cap;
+  a.raw_out = prune ? d_raw : nullptr; a.raw_cap = raw_cap; a.surv_seg = d_surv_seg; a.n_slabs = ix.n_slabs; a.pl_list = K.pl; a.pl_cnt = pl_cnt_p; a.pl_cap = fb_cap;
   const bool use_flags = g_k5_flags && grid <= g_k5_flag_cap;
   g_k5_flag_grid = use_flags ? grid : 0;
   a.start_flags = use_flags ? g_k5_flags : nullptr; a.start_epoch = g_k5_epoch;
   hipLaunchKernelGGL(k_lookup_v5, dim3(grid), dim3(threads), lds, stream, ix, a);
   if (hipGetLastError() != hipSuccess) return GM_E_NODEVICE;
-  *fb_list = K.fb; *fb_cnt = fb_cnt_p; *fb_cap_out = fb_cap;
+  *fb_list = K.fb; *fb_cnt = fb_cnt_p; *fb_cap_out = fb_cap; if (pl_list) *pl_list = K.pl; if (pl_cnt) *pl_cnt = pl_cnt_p;
   return 1;
 }
