@@ -247,6 +247,7 @@ void* gmo_session_create_opts(int n_contigs, const uint8_t* const* codes, const 
   return S;
 }
 void gmo_session_destroy(void* s) { delete (Session*)s; }
+void gmo_session_set_half_paired(void* s, int on) { ((Session*)s)->M.P.half_paired = on != 0; }   // --no-half-paired on an existing session (no index change)
 unsigned gmo_session_cutoff(void* s) { return ((Session*)s)->M.P.list_cutoff; }
 // the chunk-parallel index builder against the sequential restatement of load_genome (genome.c:1012-1182)
 int gmo_index_selfcheck(void* s, int nthreads) {

@@ -37,6 +37,8 @@ def load():
     L.gmo_session_destroy.argtypes = [C.c_void_p]
     L.gmo_session_cutoff.argtypes = [C.c_void_p]; L.gmo_session_cutoff.restype = C.c_uint
     L.gmo_session_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.gmo_session_set_half_paired.argtypes = [C.c_void_p, C.c_int]
+    L.gmo_last_pair_counts.argtypes = [C.POINTER(C.c_uint64)]
     L.gmo_map_sam.argtypes = [C.c_void_p, C.c_int, C.c_int, u8p, C.c_char_p, C.c_int, C.POINTER(C.c_uint64)]; L.gmo_map_sam.restype = C.c_void_p
     L.gmo_session_set_pairing.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.gmo_map_pairs_sam.argtypes = [C.c_void_p, C.c_int, C.c_int, u8p, C.c_int, u8p, C.c_char_p, C.c_char_p, C.c_int]; L.gmo_map_pairs_sam.restype = C.c_void_p
@@ -93,6 +95,9 @@ class Session:
                                        b"\n".join(quals1), b"\n".join(quals2), qual_delta, nthreads)
         s = C.string_at(p); self.L.gmo_free(p)
         return s
+
+    def set_half_paired(self, on):
+        self.L.gmo_session_set_half_paired(self.h, int(bool(on)))
 
     def last_pair_counts(self):
         """(collapsed anchors, windows) over both mates and strands of the last paired call"""

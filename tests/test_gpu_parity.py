@@ -748,17 +748,22 @@ def test_full_size_genome_vs_oracle(gm, oracle_lib):
     want = o.map_sam(reads, nthreads=16)
     o.set_pairing("opp-in", 100, 600)
     want_p = o.map_pairs_sam(m1, m2, nthreads=16)
+    o.set_half_paired(False)
+    want_n = o.map_pairs_sam(m1[:500], m2[:500], nthreads=16)                               # --no-half-paired: mate-pair region counts at full size
     o.close()
     ix = gm.Index(contigs); s = gm.Session(ix)
     assert ix.n_slabs == 6
     got = s.map_reads(reads)
     kern = gm.lib().gm_last_lookup_kernel().decode()
     got_p = s.map_pairs(m1, m2, mode="opp-in", min_insert=100, max_insert=600)
+    onh = gm.PairOpts.default("opp-in", 100, 600); onh.half_paired = 0
+    got_n = s.map_pairs(m1[:500], m2[:500], opts=onh)
     s.close(); ix.close()
     assert kern == "k_lookup_v5", kern
     assert got == want, _first_diff(got, want)
     assert sum(1 for l in got.split(b"\n") if l and l.split(b"\t")[2] in high) > 1000       # hits at global positions >= 2^31
     assert got_p == want_p, _first_diff(got_p, want_p)
+    assert got_n == want_n, _first_diff(got_n, want_n)
     cs, _ = synth.make_cs_reads(contigs, 5000, 50, 37)
     o = oa.Session(contigs, opts="colour=1")
     want_c = o.map_sam(cs, nthreads=16); o.close()
