@@ -43,6 +43,18 @@ struct K2Ws {            // per-wave workspace
 
 // LDS tier: a plain barrier.  Heavy tier: the arrays live in global memory and are written by one
 // lane and read by the others, so the barrier also releases/acquires at agent scope (L1 invalidate).
+#ifdef K2_STAMPS
+__device__ unsigned long long k2_stamps[8];
+#define K2_STAMP(i) do { if (lane == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&k2_stamps[i], t_ - t_prev); t_prev = t_; } } while (0)
+extern "C" int gm_debug_k2_stamps(unsigned long long* out) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(k2_stamps), sizeof z) != hipSuccess) return GM_E_NODEVICE;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(k2_stamps), z, sizeof z) != hipSuccess) return GM_E_NODEVICE;
+  return GM_OK;
+}
+#else
+#define K2_STAMP(i) do { } while (0)
+#endif
 template <bool BIG> __device__ __forceinline__ void k2_sync() { if (BIG) __threadfence(); __syncthreads(); }
 
 template <bool BIG, typename T> __device__ void k2_bitonic(T* key, int npad, int lane) {
@@ -191,32 +203,51 @@ __device__ int k2_collapse_par(const GmIndexDev& ix, K2Ws<false>& ws, uint32_t* 
   }
   k2_sync<false>();
   k2_bitonic<false, uint32_t>(ck, npad, lane);
-  for (int r = lane; r < n; r += GM_WAVE) {
-    const uint32_t c = ck[r]; const int t = (int)(c & 0xFFFF);
-    const uint64_t k = ws.key[t]; const uint32_t au = ws.aux[t];
-    const long long x = (long long)(k >> 32); const int y = (int)(au & 0x7FFF); const int cn = (int)(au >> 16);
-    bool head = true;
-    if (r > 0) {
-      const uint32_t cp = ck[r - 1];
-      if ((cp >> 16) == (c >> 16)) {
+  // Runs of one (class, contig, diagonal) are contiguous now.  A run's head takes the extent of all its members and their number -- a read that really maps
+  // puts ~250 colinear k-mer hits into ONE run, and walking it from its head (one lane, two dependent LDS reads per member) was two thirds of this kernel's time.
+  // So: every member finds its head by a running maximum over the head positions (wave scan, chunk by chunk) and adds itself with two LDS atomics: extent by
+  // atomicMax into the head's ck word (length << 16 | t, the class bits are dead by then), count by atomicAdd into the low word of the head's key (which only
+  // the head itself had read).  Maximum and count do not depend on the order, so the result is the serial loop's.
+  int carry_head = -1; uint32_t carry_c = 0xFFFFFFFFu;
+  for (int c0 = 0; c0 < n; c0 += GM_WAVE) {
+    const int r = c0 + lane; const bool valid = r < n;
+    uint32_t c = 0xFFFFFFFFu; int t = 0; long long x = 0; int y = 0, cn = 0, span = 0; bool head = false;
+    if (valid) {
+      c = ck[r]; t = (int)(c & 0xFFFF);
+      const uint64_t k = ws.key[t]; const uint32_t au = ws.aux[t];
+      x = (long long)(k >> 32); y = (int)(au & 0x7FFF); cn = (int)(au >> 16); span = ix.seed[(int)(k & 0xFFFF)].span;
+    }
+    uint32_t cp = (uint32_t)__shfl_up((int)c, 1); if (lane == 0) cp = carry_c;       // the class word of the entry before (its ck slot may already hold a head's extent)
+    if (valid) {
+      head = true;
+      if (r > 0 && (cp >> 16) == (c >> 16)) {
         const int tp = (int)(cp & 0xFFFF);
         const long long xp = (long long)(ws.key[tp] >> 32); const uint32_t aup = ws.aux[tp];
         head = !((int)(aup >> 16) == cn && (xp - (long long)(aup & 0x7FFF)) == (x - y));
       }
     }
-    if (!head) { atomicOr(&ws.aux[t], 0x8000u); continue; }
-    long long end = x + ix.seed[(int)(k & 0xFFFF)].span; uint32_t w = 1;
-    for (int r2 = r + 1; r2 < n; r2++) {
-      const uint32_t c2 = ck[r2];
-      if ((c2 >> 16) != (c >> 16)) break;
-      const int t2 = (int)(c2 & 0xFFFF);
-      const uint64_t k2 = ws.key[t2]; const uint32_t au2 = ws.aux[t2];
-      const long long x2 = (long long)(k2 >> 32);
-      if (!((int)(au2 >> 16) == cn && (x2 - (long long)(au2 & 0x7FFF)) == (x - y))) break;
-      end = max(end, x2 + ix.seed[(int)(k2 & 0xFFFF)].span); w++;
+    carry_c = (uint32_t)__shfl((int)c, GM_WAVE - 1);
+    int hidx = (valid && head) ? r : -1;
+    for (int d = 1; d < GM_WAVE; d <<= 1) { const int o = __shfl_up(hidx, d); if (lane >= d) hidx = max(hidx, o); }
+    hidx = max(hidx, carry_head);
+    carry_head = __shfl(hidx, GM_WAVE - 1);
+    k2_sync<false>();                                            // every lane has read the words the heads now take over
+    if (valid && head) { ck[r] = ((uint32_t)span << 16) | (uint32_t)t; ((uint32_t*)&ws.key[t])[0] = 1u; }
+    k2_sync<false>();
+    if (valid && !head) {
+      const int th = (int)(ck[hidx] & 0xFFFF);
+      const long long xh = (long long)(ws.key[th] >> 32);
+      atomicMax(&ck[hidx], ((uint32_t)(x + span - xh) << 16) | (uint32_t)th);
+      atomicAdd(&((uint32_t*)&ws.key[th])[0], 1u);
+      atomicOr(&ws.aux[t], 0x8000u);
     }
-    // members keep their sort key (x, y, seed: read above by other lanes); the head's own low word is only read by itself
-    ws.key[t] = ((uint64_t)x << 32) | ((uint64_t)(uint32_t)(end - x) << 16) | min(w, 0xFFFFu);
+  }
+  k2_sync<false>();
+  for (int r = lane; r < n; r += GM_WAVE) {                       // heads: x | extent | members (min(w, 0xFFFF), ref: anchors.h uw_join)
+    const uint32_t c = ck[r]; const int t = (int)(c & 0xFFFF);
+    if (ws.aux[t] & 0x8000u) continue;
+    const uint64_t k = ws.key[t];
+    ws.key[t] = (k & 0xFFFFFFFF00000000ull) | ((uint64_t)(c >> 16) << 16) | (uint64_t)min((uint32_t)k, 0xFFFFu);
   }
   k2_sync<false>();
   // stable compaction of the heads, in canonical (= creation) order
@@ -322,6 +353,9 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
   extern __shared__ __align__(16) uint8_t smem_raw[];
   __shared__ int sh_na;
   const int lane = threadIdx.x;
+#ifdef K2_STAMPS
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
   int rs, n;
   K2Ws<BIG> ws;
   uint8_t* base = smem_raw;
@@ -357,6 +391,7 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
       k2_sync<BIG>();
       k2_bitonic<BIG, uint64_t>(ws.key, npad, lane);
     }
+    K2_STAMP(0);
     for (int t = lane; t < n; t += GM_WAVE) {
       const uint64_t k = ws.key[t];
       const uint32_t x = (uint32_t)(k >> 32);
@@ -399,14 +434,18 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
   int na = 0, nh = 0;
   bool need_exact = BIG;
   load_sorted();
+  K2_STAMP(1);
   if (!BIG) {
     // ---- fast path: order-free collapse + windows in canonical order, with sensitivity detection ----
     na = k2_collapse_par(ix, *(K2Ws<false>*)&ws, scratch32, n, npad, read_len, lane);
+    K2_STAMP(2);
     bool sens = false;
     nh = k2_windows<BIG, true>(ix, sc, ws, na, read_len, window_len, H, scratch32, hcap, lane, &sens);
     k2_sync<BIG>();
+    K2_STAMP(3);
     need_exact = sens;
     if (!need_exact) need_exact = sort_windows(min(nh, hcap), true);
+    K2_STAMP(4);
   }
   if (need_exact) {
     // ---- exact path: reference pop order (heap replay when a position carries two read offsets) ----
