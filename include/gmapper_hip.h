@@ -244,7 +244,8 @@ int gm_map_reads_cs(gm_session_t *s, int n_reads, int n_colours, const uint32_t 
  * error rates in post_sw (sw-post.c:486-491), the SAM QUAL column (post_sw's base qualities) and the CQ:Z tag (output.c:613-621,724-727). */
 int gm_map_reads_cs_fastq(gm_session_t *s, int n_reads, int n_colours, const uint32_t *colours_packed, const uint8_t *initbp,
                           const char *names, const char *quals, int qual_delta, char **sam, size_t *sam_len, gm_map_stats_t *stats);
-void gm_free(void *p);
+void gm_free(void *p);          /* every *sam the library hands out; a large text buffer is parked for the next call instead of being unmapped */
+void gm_release_cache(void);    /* drops the parked buffer */
 
 /* ---------------------------------------------------------------------------------------------
  * Paired mode.  Replaces handle_readpair() (ref: gmapper/mapping.c:2502-2636) with the binary's

@@ -392,6 +392,24 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
       k2_bitonic<BIG, uint64_t>(ws.key, npad, lane);
     }
     K2_STAMP(0);
+    if (!BIG && ix.n_contigs <= GM_WAVE) {
+      // up to 64 contigs: lane l keeps contig_off[l], the binary search gathers from the lanes (six uniform steps, no memory round trip per step;
+      // every lane takes part in every gather, the ones past n search for position 0)
+      const uint32_t my_off = lane < ix.n_contigs ? ix.contig_off[lane] : 0xFFFFFFFFu;
+      for (int t0 = 0; t0 < n; t0 += GM_WAVE) {
+        const int t = t0 + lane;
+        const uint64_t k = t < n ? ws.key[t] : 0ull;
+        const uint32_t x = (uint32_t)(k >> 32);
+        int lo = 0, hi = ix.n_contigs;
+        for (int it = 0; it < 6; it++) {
+          const int m = (lo + hi) >> 1;
+          const uint32_t v = (uint32_t)__shfl((int)my_off, m);
+          const bool open = hi - lo > 1, le = v <= x;
+          lo = (open && le) ? m : lo; hi = (open && !le) ? m : hi;
+        }
+        if (t < n) ws.aux[t] = (uint32_t)((k >> 16) & 0x7FFF) | ((uint32_t)lo << 16);
+      }
+    } else
     for (int t = lane; t < n; t += GM_WAVE) {
       const uint64_t k = ws.key[t];
       const uint32_t x = (uint32_t)(k >> 32);

@@ -28,7 +28,27 @@ void gm_set_error(const char* fmt, ...) {
 }
 extern "C" const char* gm_last_error(void) { return g_err; }
 extern "C" int gm_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
-extern "C" void gm_free(void* p) { free(p); }
+// The SAM text of a large call is hundreds of megabytes: allocating it afresh for every call (page faults on first touch) and unmapping it in gm_free cost 20+ ms per
+// 1 M reads that nothing overlaps.  One freed text buffer of >= 16 MB is therefore parked here and handed to the next call (gm_release_cache() drops it).
+static struct { std::mutex m; char* p = nullptr; size_t cap = 0; char* live = nullptr; size_t live_cap = 0; } g_outcache;
+static char* outcache_take(size_t want, size_t* cap) {
+  std::lock_guard<std::mutex> g(g_outcache.m);
+  if (g_outcache.p && g_outcache.cap >= want) { char* r = g_outcache.p; *cap = g_outcache.cap; g_outcache.p = nullptr; g_outcache.cap = 0; return r; }
+  return nullptr;
+}
+static void outcache_track(char* p, size_t cap) { std::lock_guard<std::mutex> g(g_outcache.m); g_outcache.live = p; g_outcache.live_cap = cap; }
+extern "C" void gm_release_cache(void) { std::lock_guard<std::mutex> g(g_outcache.m); free(g_outcache.p); g_outcache.p = nullptr; g_outcache.cap = 0; }
+extern "C" void gm_free(void* p) {
+  if (!p) return;
+  { std::lock_guard<std::mutex> g(g_outcache.m);
+    if (p == g_outcache.live && g_outcache.live_cap >= ((size_t)16 << 20)) {
+      g_outcache.live = nullptr;
+      if (g_outcache.p && g_outcache.cap >= g_outcache.live_cap) { /* a larger one is parked already */ }
+      else { free(g_outcache.p); g_outcache.p = (char*)p; g_outcache.cap = g_outcache.live_cap; return; }
+    } else if (p == g_outcache.live) g_outcache.live = nullptr;
+  }
+  free(p);
+}
 
 extern "C" void gm_params_default(gm_params_t* p) {
   memset(p, 0, sizeof *p);
@@ -1176,7 +1196,8 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
         // first guess: this job's bytes per read for all reads, then geometric growth (large blocks move by remapping)
         size_t want = std::max(ob.len + sz + 1, ob.cap + ob.cap / 2);
         if (!ob.cap) want = std::max(want, (size_t)((double)sz / std::max(1, n) * 1.02 * n_reads) + 4096);
-        char* np = (char*)realloc(ob.p, want);
+        size_t ccap = 0; char* np = ob.p ? nullptr : outcache_take(want, &ccap);   // the buffer of the last call, if it was given back and is large enough
+        if (np) want = ccap; else np = (char*)realloc(ob.p, want);
         if (!np) ob.failed = true; else { ob.p = np; ob.cap = want; }
       }
       if (!ob.failed) {
@@ -1305,8 +1326,10 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   if (stats) { stats->reads = n_reads; stats->reads_matched = matched; stats->sam_records = records; }
   if (emit_sam && sam) {
     if (ob.failed) return GM_E_NOMEM;
-    char* r = (char*)realloc(ob.p, ob.len + 1); if (!r) return GM_E_NOMEM;
+    char* r = ob.p;                                            // (not shrunk: gm_free parks a large buffer for the next call)
+    if (!r || ob.cap < ob.len + 1) { r = (char*)realloc(ob.p, ob.len + 1); if (!r) return GM_E_NOMEM; ob.cap = ob.len + 1; }
     ob.p = nullptr;
+    outcache_track(r, ob.cap);
     r[ob.len] = 0; *sam = r; if (sam_len) *sam_len = ob.len;
   } else { if (sam) *sam = nullptr; if (sam_len) *sam_len = 0; }
   return GM_OK;
