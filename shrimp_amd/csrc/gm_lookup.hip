@@ -710,8 +710,7 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
             int NL, int tab_bits, int cbits, int SC, int wcap, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
             uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap, unsigned long long* __restrict__ stats,
             uint32_t* __restrict__ surv_seg, uint64_t* __restrict__ scratch, int bin_cap, uint32_t* __restrict__ fb_list, uint32_t* __restrict__ fb_cnt,
-            int fb_cap, int ablate, uint32_t* __restrict__ start_flags, uint32_t start_epoch,
-            const uint32_t* __restrict__ in_list, const uint32_t* __restrict__ in_cnt, int in_cap) {      // list mode (k_lookup_v5's fall-back): the read-strands to do, or null
+            int fb_cap, int ablate, uint32_t* __restrict__ start_flags, uint32_t start_epoch) {
   // resident: tell the host (pinned memory), which holds the other stream's pass-1 launch back until every workgroup of this grid has a CU
   if (start_flags && threadIdx.x == 0) __hip_atomic_store(&start_flags[blockIdx.x], start_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __builtin_amdgcn_s_setprio(3);                            // memory-latency-bound: issue first when ready; VALU-bound kernels of the other stream fill the gaps
@@ -739,9 +738,7 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
   unsigned long long my_lookups = 0, my_entries = 0;
   bool tab_clean = false;                                   // uniform over the workgroup
 
-  const int n_items = in_list ? (int)min(*in_cnt, (uint32_t)in_cap) : 2 * n_reads;
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const int rs = in_list ? (int)in_list[item] : item;
+  for (int rs = blockIdx.x; rs < 2 * n_reads; rs += gridDim.x) {
     const int rd = rs >> 1, st = rs & 1;
     uint64_t* out = surv + (size_t)rs * scap_all;
     const uint32_t scap = (uint32_t)scap_all;
@@ -1048,8 +1045,7 @@ struct K4Scratch { uint64_t* scratch = nullptr; size_t words = 0; uint32_t* fb =
 static K4Scratch g_k4[16];
 static bool k4_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words, int max_n_kmers, int NL,
                       uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
-                      unsigned long long* d_stats, hipStream_t stream, uint32_t* d_surv_seg, size_t lds_generic, int bm_words,
-                      const uint32_t* in_list = nullptr, const uint32_t* in_cnt = nullptr, int in_cap = 0) {      // list mode: only these read-strands (k_lookup_v5's fall-back)
+                      unsigned long long* d_stats, hipStream_t stream, uint32_t* d_surv_seg, size_t lds_generic, int bm_words) {
   int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
   K4Scratch& K = g_k4[dev];
   const int S = ix.n_slabs;
@@ -1060,7 +1056,7 @@ static bool k4_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
       const double lists = std::max(0, read_len - ix.seed[sn].span + 1 - ix.colour);
       entries += lists * (double)ix.seed[sn].n_pos / (double)(1ull << (ix.hflag ? 2 * GM_HASH_TABLE_POWER : 2 * ix.seed[sn].weight));
     }
-    if (entries < 30000.0 && !gm_tune("GM_K1_V4") && !in_list) return false;
+    if (entries < 30000.0 && !gm_tune("GM_K1_V4")) return false;
   }
   int tab_bits = 19; if (const char* e = gm_tune("GM_K4_TABBITS")) tab_bits = std::max(6, std::min(19, atoi(e)));
   // pass C keeps the exact counters of one bin of 2^cbits positions (+2) in the table's LDS; bins nest inside the index slabs
@@ -1093,11 +1089,11 @@ static bool k4_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   if (lds_generic > 48 * 1024 && lds_generic > configured_g) {
     if (hipFuncSetAttribute((const void*)k_lookup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_generic) != hipSuccess) return false; configured_g = lds_generic; }
   int k4_threads = 1024; if (const char* e = gm_tune("GM_K1_THREADS")) k4_threads = std::max(64, std::min(1024, atoi(e) & ~63));
-  const bool use_flags = !in_list && g_k4_flags && grid <= g_k4_flag_cap;
-  if (!in_list) g_k4_flag_grid = use_flags ? grid : 0;
+  const bool use_flags = g_k4_flags && grid <= g_k4_flag_cap;
+  g_k4_flag_grid = use_flags ? grid : 0;
   hipLaunchKernelGGL(k_lookup_v4, dim3(grid), dim3(k4_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words, max_n_kmers, NL, tab_bits, cbits, SC, wcap,
                      d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, d_surv_seg, K.scratch, bin_cap, K.fb, K.fb + fb_cap, fb_cap,
-                     gm_tune("GM_K1_ABLATE") ? atoi(gm_tune("GM_K1_ABLATE")) : 0, use_flags ? g_k4_flags : nullptr, g_k4_epoch, in_list, in_cnt, in_cap);
+                     gm_tune("GM_K1_ABLATE") ? atoi(gm_tune("GM_K1_ABLATE")) : 0, use_flags ? g_k4_flags : nullptr, g_k4_epoch);
   // read-strands whose candidates overflowed their bins: the slab-sweep kernel in list mode (blocks beyond the list's end return at once)
   hipLaunchKernelGGL(k_lookup<false>, dim3(fb_cap), dim3(K1_THREADS), lds_generic, stream, ix, d_reads, n_reads, read_len, read_words,
                      max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
@@ -1150,25 +1146,16 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     if (r < 0) return r;
     if (r == 1) {
       g_k1_name = "k_lookup_v5";
-      // Read-strands whose candidates did not fit the LDS tiers (1 in 8 000 on the benchmark genome: the ones with the most list entries), then K1b for those.
-      // They go through k_lookup_v4 in list mode -- its candidate bins live in global memory -- spread over the CUs: the lane-per-list kernel took 1-6 ms for
-      // a few dozen of them (one workgroup each, slab by slab), 32 ms of every 1 M reads.  Where v4's geometry does not fit: that kernel.
-      {
-      const bool v4fb = ix.n_slabs > 1 && !gm_tune("GM_K5_FB_GENERIC") &&
-                        k4_launch(ix, d_reads, n_reads, read_len, read_words, max_n_kmers, NL, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, stream,
-                                  d_surv_seg, lds, bm_words, fbl, fbc, fbcap);
-      if (!v4fb)
+      // read-strands whose candidates did not fit the LDS tiers (none on the benchmark genome): the slab-sweep kernel in list mode (blocks beyond the list's end
+      // return at once), then K1b for those.  (k_lookup_v4 in list mode was tried for them: no faster, and its 134 KB workgroups wait longer for a CU.)
       hipLaunchKernelGGL(k_lookup<false>, dim3(fbcap), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
                          max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
                          (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)fbl, (const uint32_t*)fbc, d_stats, 0, d_surv_seg);
       GM_HIP(hipGetLastError());
-      }
       if (fused) {
-        {
         const int rc = gm_launch_prune(n_reads, read_len, fuse->window_len, fuse->e_max, ix.n_slabs, ix.slab_bits, d_surv, d_surv_cnt, d_surv_seg, scap,
                                        fuse->d_surv2, fuse->d_surv_cnt2, fuse->scap2, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, stream, fbl, fbc, fbcap);
         if (rc) return rc;
-        }
         if (pll) {   // read-strands whose members v5 left in their raw rows (more kept than K2's tier under region-sized bins): K1b only
           const int rc2 = gm_launch_prune(n_reads, read_len, fuse->window_len, fuse->e_max, ix.n_slabs, ix.slab_bits, d_surv, d_surv_cnt, d_surv_seg, scap,
                                           fuse->d_surv2, fuse->d_surv_cnt2, fuse->scap2, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, stream, pll, plc, fbcap);
