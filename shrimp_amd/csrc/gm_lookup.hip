@@ -51,8 +51,8 @@ __device__ __forceinline__ bool k1_has2(const uint32_t* bm, uint32_t rloc) {
 
 // dynamic LDS layout: codes[read_len pad 4] | kS[NL] | lbeg[NL] | lend[NL] | lo[NL] | hi[NL] | pre[NL+1] | bitmap[bm_words]
 template <bool BKT>
-__global__ void __launch_bounds__(1024)
-k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
+__device__ __forceinline__ void
+k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
          int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
          uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap,
          const uint32_t* __restrict__ redo_list, const uint64_t* __restrict__ redo_off,
@@ -65,11 +65,10 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
   // normal mode: block b = read-strand b, output slot surv[b*scap_all .. +scap_all).
   // redo mode (redo_list != 0): block b re-runs heavy read-strand redo_list[b] into surv[redo_off[b] .. redo_off[b+1])
   const bool redo = (redo_list != nullptr);
-  if (fb_cnt && blockIdx.x >= *fb_cnt) return;
-  const int rs = redo ? (int)redo_list[blockIdx.x] : (fb_cnt ? (int)fb_list[blockIdx.x] : (int)blockIdx.x);
+  const int rs = redo ? (int)redo_list[item] : (fb_cnt ? (int)fb_list[item] : item);
   const int rd = rs >> 1, st = rs & 1;
-  uint64_t* out = redo ? (surv + redo_off[blockIdx.x]) : (surv + (size_t)rs * scap_all);
-  const uint32_t scap = redo ? (uint32_t)(redo_off[blockIdx.x + 1] - redo_off[blockIdx.x]) : (uint32_t)scap_all;
+  uint64_t* out = redo ? (surv + redo_off[item]) : (surv + (size_t)rs * scap_all);
+  const uint32_t scap = redo ? (uint32_t)(redo_off[item + 1] - redo_off[item]) : (uint32_t)scap_all;
   uint8_t* codes = (uint8_t*)smem;
   const int code_words = (read_len + 3) / 4;
   uint32_t* kS = smem + code_words;
@@ -314,6 +313,27 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
   if (fb_cnt) return;                    // the work counters were taken by the first run
   for (int d = GM_WAVE / 2; d > 0; d >>= 1) { my_lookups += __shfl_down(my_lookups, d); my_entries += __shfl_down(my_entries, d); }
   if ((tid & (GM_WAVE - 1)) == 0) { GS_ADD(stats, GS_LOOKUPS, my_lookups); GS_ADD(stats, GS_ENTRIES, my_entries); }
+}
+
+// One block per read-strand; in list mode (fb_list) a bounded grid walks the list -- one block per possible entry meant hundreds of thousands of empty
+// workgroups per launch, each of which still had to be given its LDS before it could return (1 ms per launch with an empty list).
+template <bool BKT>
+__global__ void __launch_bounds__(1024)
+k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
+         int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
+         uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap,
+         const uint32_t* __restrict__ redo_list, const uint64_t* __restrict__ redo_off,
+         const uint32_t* __restrict__ fb_list, const uint32_t* __restrict__ fb_cnt,
+         unsigned long long* __restrict__ stats, int ablate, uint32_t* __restrict__ surv_seg) {
+  if (fb_cnt) {
+    const int n_items = (int)*fb_cnt;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+      k_lookup_body<BKT>(item, ix, reads, n_reads, read_len, read_words, max_n_kmers, NL, bm_words, surv, surv_cnt, scap_all, heavy_list, heavy_cnt, heavy_cap,
+                         redo_list, redo_off, fb_list, fb_cnt, stats, ablate, surv_seg);
+      __syncthreads();
+    }
+  } else k_lookup_body<BKT>((int)blockIdx.x, ix, reads, n_reads, read_len, read_words, max_n_kmers, NL, bm_words, surv, surv_cnt, scap_all, heavy_list, heavy_cnt, heavy_cap,
+                            redo_list, redo_off, fb_list, fb_cnt, stats, ablate, surv_seg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1095,7 +1115,7 @@ static bool k4_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
                      d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, d_surv_seg, K.scratch, bin_cap, K.fb, K.fb + fb_cap, fb_cap,
                      gm_tune("GM_K1_ABLATE") ? atoi(gm_tune("GM_K1_ABLATE")) : 0, use_flags ? g_k4_flags : nullptr, g_k4_epoch);
   // read-strands whose candidates overflowed their bins: the slab-sweep kernel in list mode (blocks beyond the list's end return at once)
-  hipLaunchKernelGGL(k_lookup<false>, dim3(fb_cap), dim3(K1_THREADS), lds_generic, stream, ix, d_reads, n_reads, read_len, read_words,
+  hipLaunchKernelGGL(k_lookup<false>, dim3(std::min(fb_cap, 1024)), dim3(K1_THREADS), lds_generic, stream, ix, d_reads, n_reads, read_len, read_words,
                      max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
                      (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)K.fb, (const uint32_t*)(K.fb + fb_cap), d_stats, 0, d_surv_seg);
   return true;
@@ -1148,7 +1168,7 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
       g_k1_name = "k_lookup_v5";
       // read-strands whose candidates did not fit the LDS tiers (none on the benchmark genome): the slab-sweep kernel in list mode (blocks beyond the list's end
       // return at once), then K1b for those.  (k_lookup_v4 in list mode was tried for them: no faster, and its 134 KB workgroups wait longer for a CU.)
-      hipLaunchKernelGGL(k_lookup<false>, dim3(fbcap), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+      hipLaunchKernelGGL(k_lookup<false>, dim3(std::min(fbcap, 1024)), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
                          max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
                          (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)fbl, (const uint32_t*)fbc, d_stats, 0, d_surv_seg);
       GM_HIP(hipGetLastError());
