@@ -281,6 +281,42 @@ int gm_map_pairs_fastq(gm_session_t *s, int n_pairs, int len1, const uint32_t *m
                        const char *names1, const char *names2, const char *quals1, const char *quals2, int qual_delta,
                        const gm_pair_opts_t *opts, char **sam, size_t *sam_len, gm_map_stats_t *stats);
 
+/* ---------------------------------------------------------------------------------------------
+ * Merging.  Replaces the mergesam program (ref: mergesam/mergesam.c main :308-816, sam_reader.c pp_ll_combine_and_check :417-716,
+ * render.c :210-277; SPLITTING_AND_MERGING:100-148): SAM texts of several gmapper runs -- the same reads against different contig groups,
+ * different reads against the same genome, or both -- become one SAM text in the order of the reads text, with the mapping qualities
+ * recomputed from the Z0-Z6 fields gmapper writes unless --all-contigs was given.  Host code (text in, text out).
+ *
+ * reads_text is the reads file (FASTA or FASTQ; for pairs the file gmapper read, mates adjacent): only the names are used, and a record
+ * belongs to the first read, from the last matched one on, whose name starts with its QNAME (ref: sam_reader.c:947).  Every SAM text
+ * must list its records in that order (gmapper's output does).  The fields mirror mergesam's options of the same names; the
+ * reference's --un / --al files are `output` 1 / 2 (FASTA / FASTQ text of the unaligned / aligned reads instead of SAM).
+ * command_line, when given, is what follows "CL:" in the @PG line mergesam adds for itself (NULL: no such line). */
+#define GM_MERGE_OUT_SAM              0
+#define GM_MERGE_OUT_UNALIGNED_READS  1
+#define GM_MERGE_OUT_ALIGNED_READS    2
+typedef struct gm_merge_options {
+  int max_outputs;            /* -o/--report (10) */
+  int max_alignments;         /* --max-alignments (0 = all) */
+  int strata;                 /* --strata */
+  int half_paired;            /* --half-paired (1) / --no-half-paired (0) */
+  int sam_unaligned;          /* --sam-unaligned */
+  int single_best;            /* --single-best-mapping (forces max_outputs = 1) */
+  int all_contigs;            /* --all-contigs: last merge of these reads, the Z fields are dropped */
+  int no_mapping_qualities;   /* --no-mapping-qualities (MAPQ 255 unless leave_mapq) */
+  int leave_mapq;             /* --leave-mapq-untouched */
+  int no_improper_mappings;   /* --no-improper-mappings */
+  int min_mapq;               /* --min-mapq (with all_contigs) */
+  int fastq;                  /* reads text: 0 FASTA, 1 FASTQ, -1 detect from the first character (mergesam's default) */
+  int threads;                /* -N */
+  int output;                 /* GM_MERGE_OUT_* */
+  int header_given;           /* --sam-header: the caller supplies the header; only the first sorted line and the @PG line are written */
+  const char *command_line;
+} gm_merge_options_t;
+void gm_merge_options_default(gm_merge_options_t *o);
+int gm_merge_sam(const gm_merge_options_t *opts, const char *reads_text, size_t reads_len, int n_files, const char *const *sam_text,
+                 const size_t *sam_len, char **out, size_t *out_len);     /* *out: gm_free */
+
 /* per-read top-K candidate rows after pass 1 (heap array order), for stage parity tests:
  * 12 x int64 per row: read st cn g_off w_len score_vector pct_score_vector matches ax ay alen awidth */
 int gm_debug_tophits(gm_session_t *s, int n_reads, int read_len, const uint32_t *reads_packed,

@@ -61,6 +61,35 @@ class PairOpts(C.Structure):    # gm_pair_opts_t
         return o
 
 
+class MergeOptions(C.Structure):   # gm_merge_options_t (mergesam's options of the same names, ref: mergesam/mergesam.c:216-243)
+    _fields_ = [(n, C.c_int) for n in ("max_outputs", "max_alignments", "strata", "half_paired", "sam_unaligned", "single_best", "all_contigs",
+                                       "no_mapping_qualities", "leave_mapq", "no_improper_mappings", "min_mapq", "fastq", "threads", "output",
+                                       "header_given")] + [("command_line", C.c_char_p)]
+
+
+MERGE_OUT = {"sam": 0, "un": 1, "al": 2}
+
+
+def merge_sam(reads_text: bytes, sam_texts, command_line=None, output="sam", **options) -> bytes:
+    """mergesam (ref: mergesam/mergesam.c): SAM texts of several runs -> one, in the order of the reads text, mapping qualities recomputed from
+    the Z fields.  options: the fields of gm_merge_options_t (max_outputs, strata, single_best, all_contigs, sam_unaligned, ...)."""
+    L = lib(); o = MergeOptions(); L.gm_merge_options_default(C.byref(o))
+    for k, v in options.items():
+        if not hasattr(o, k):
+            raise TypeError("merge_sam: unknown option %r" % k)
+        setattr(o, k, int(v))
+    o.output = MERGE_OUT[output] if isinstance(output, str) else int(output)
+    if command_line is not None:
+        o.command_line = command_line if isinstance(command_line, bytes) else command_line.encode()
+    texts = [bytes(t) for t in sam_texts]
+    arr = (C.c_char_p * len(texts))(*texts); lens = (C.c_size_t * len(texts))(*[len(t) for t in texts])
+    out = C.c_void_p(); ol = C.c_size_t()
+    _check(L.gm_merge_sam(C.byref(o), reads_text, len(reads_text), len(texts), arr, lens, C.byref(out), C.byref(ol)), "gm_merge_sam")
+    res = C.string_at(out, ol.value) if out.value else b""
+    if out.value: L.gm_free(out)
+    return res
+
+
 class Anchor(C.Structure):      # struct gm_anchor == the reference's struct anchor (gmapper-definitions.h:66-74)
     _fields_ = [("x", C.c_longlong), ("y", C.c_longlong), ("length", C.c_int), ("width", C.c_int),
                 ("weight", C.c_int), ("cn", C.c_int), ("score", C.c_int)]
@@ -75,7 +104,7 @@ class SwFullResults(C.Structure):   # struct gm_sw_full_results == the reference
 
 
 # every entry point include/gmapper_hip.h declares
-EXPORTS = ["gm_release_cache", "gm_map_pairs_cs", "gm_last_error", "gm_device_count", "gm_params_default", "gm_params_default_cs", "gm_index_build", "gm_index_free", "gm_index_list_cutoff",
+EXPORTS = ["gm_merge_options_default", "gm_merge_sam", "gm_release_cache", "gm_map_pairs_cs", "gm_last_error", "gm_device_count", "gm_params_default", "gm_params_default_cs", "gm_index_build", "gm_index_free", "gm_index_list_cutoff",
            "gm_index_save", "gm_index_load", "gm_index_bytes", "gm_index_n_slabs", "gm_index_has_buckets", "gm_index_get_list", "gm_index_device_array", "gm_index_meta", "gm_index_alloc_like",
            "sw_vector_setup", "sw_vector", "sw_vector_stats", "sw_vector_cleanup", "gm_sw_vector_batch",
            "sw_full_ls_setup", "sw_full_ls", "sw_full_ls_cleanup", "sw_full_ls_stats",
@@ -137,6 +166,8 @@ def lib():
                                      C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_map_pairs.argtypes = [vp, C.c_int, C.c_int, u32p, C.c_int, u32p, C.c_char_p, C.c_char_p, C.POINTER(PairOpts),
                                C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
+    L.gm_merge_options_default.argtypes = [C.POINTER(MergeOptions)]
+    L.gm_merge_sam.argtypes = [C.POINTER(MergeOptions), C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.gm_map_pairs_cs.argtypes = [vp, C.c_int, C.c_int, u32p, C.POINTER(C.c_uint8), C.c_int, u32p, C.POINTER(C.c_uint8), C.c_char_p, C.c_char_p, C.POINTER(PairOpts),
                                   C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_debug_tophits.argtypes = [vp, C.c_int, C.c_int, u32p, C.POINTER(C.c_longlong), C.c_long, C.POINTER(C.c_long)]

@@ -833,3 +833,39 @@ def test_colour_space_pairs_match_reference_golden(gm, mode):
     st = s.stats
     s.close(); ix.close()
     assert got == want, (_first_diff(got, want), st)
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_genome_shards_mapped_here_then_merged_match_mergesam(gm, paired):
+    """SURVEY 8(f)3 end to end: the contig groups of tests/golden/merge mapped by the library (byte-identical to the reference's per-shard SAM files),
+    the two texts merged by gm_merge_sam: the reference's mergesam output on the reference's shard files."""
+    import gzip, json
+    M = os.path.join(os.path.dirname(__file__), "golden", "merge")
+    case = "pairs_db2" if paired else "ls_db2"
+    c = json.load(open(os.path.join(M, "cases.json")))[case]
+    rd = lambda n: gzip.open(os.path.join(M, n), "rb").read()
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "stress_60bp.npz"))
+    contigs = [z["contig%d" % i] for i in range(4)]; names = [b"contig%d" % (i + 1) for i in range(4)]
+    if paired:
+        g = oa.load_golden_pairs("stress_pairs_2x100"); NP = 500
+    else:
+        reads = z["reads"][:1400]
+    texts = []
+    for k, (lo, hi) in enumerate(((0, 1), (1, 4))):
+        ix = gm.Index(contigs[lo:hi], names=names[lo:hi]); s = gm.Session(ix, max_batch_reads=4096)
+        if paired: body = s.map_pairs(g["m1"][:NP], g["m2"][:NP], list(g["names1"][:NP]), list(g["names2"][:NP]), mode="opp-in", min_insert=100, max_insert=600)
+        else: body = s.map_reads(reads)
+        s.close(); ix.close()
+        want = rd("%s.in%d.sam.gz" % (case, k))
+        pg = [l for l in want.split(b"\n") if l.startswith(b"@PG")]
+        assert body == b"".join(l + b"\n" for l in want.split(b"\n") if l and not l.startswith(b"@")), _first_diff(body, want)
+        texts.append(oa.sam_header(contigs[lo:hi], names[lo:hi]) + pg[0] + b"\n" + body)      # the shard's @PG line as the reference's run wrote it
+    reads_text = rd(case + ".reads.gz")
+    for st in ("default", "single_best_all", "strata", "all_contigs"):
+        d = c["sets"][st]
+        kw = {"--strata": {"strata": 1}, "--single-best-mapping": {"single_best": 1}, "--all-contigs": {"all_contigs": 1}}
+        opts = {}
+        for a in d["args"]: opts.update(kw[a])
+        got = gm.merge_sam(reads_text, texts, command_line=d["command_line"], threads=4, **opts)
+        want = rd("%s@%s.out.gz" % (case, st))
+        assert got == want, (st, _first_diff(got, want))
