@@ -71,3 +71,27 @@ def gather_ordered(local: bytes, rank: int, world: int, dst: int = 0):
     parts = [None] * world if rank == dst else None
     dist.gather_object(local, parts, dst=dst)
     return b"".join(parts) if rank == dst else None
+
+
+def contig_groups(contig_len, world: int) -> list[list[int]]:
+    """Genome-sharded mode (the reference's SPLIT-DB workflow, SPLITTING_AND_MERGING:25-60, for a genome whose index does not fit one device): contigs
+    dealt to `world` groups, longest first onto the lightest group, each group in genome order.  Deterministic, so every rank computes the same deal."""
+    order = sorted(range(len(contig_len)), key=lambda i: (-int(contig_len[i]), i))
+    load = [0] * world; groups = [[] for _ in range(world)]
+    for i in order:
+        g = min(range(world), key=lambda k: (load[k], k))
+        groups[g].append(i); load[g] += int(contig_len[i])
+    return [sorted(g) for g in groups]
+
+
+def merge_genome_shards(local_sam: bytes, reads_text: bytes, rank: int, world: int, dst: int = 0, **merge_options):
+    """Every rank mapped ALL reads against its own contig group (local_sam: header + records, Z fields present); rank `dst` gathers the texts (one
+    gather_object, the only exchange of the scheme) and merges them with the mapping qualities recomputed across groups (gm_merge_sam, ref:
+    mergesam/mergesam.c).  Other ranks get None.  Give all_contigs=1 when no further merge follows (SPLITTING_AND_MERGING:100-148)."""
+    import torch.distributed as dist
+    from . import gmapper
+    parts = [None] * world if rank == dst else None
+    dist.gather_object(local_sam, parts, dst=dst)
+    if rank != dst:
+        return None
+    return gmapper.merge_sam(reads_text, parts, **merge_options)

@@ -101,3 +101,32 @@ def test_world2_bench_rank_logic():
     assert d["ms_per_step"] >= 1e3 * d["rank_step_s"][0]
     assert abs(d["value"] - 2 * d["units_per_rank_step"] / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]
     assert d["host_threads_per_rank"] >= 1
+
+
+def _genome_shard_worker(rank, world, port, q):
+    import gzip, json, torch.distributed as dist
+    from shrimp_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    M = os.path.join(os.path.dirname(__file__), "golden", "merge")
+    rd = lambda n: gzip.open(os.path.join(M, n), "rb").read()
+    c = json.load(open(os.path.join(M, "cases.json")))["ls_db2"]
+    # rank r holds what the device path produces for contig group r (byte-identical to these files: tests/test_gpu_parity.py checks that on the GPU)
+    local = rd("ls_db2.in%d.sam.gz" % rank)
+    d = c["sets"]["single_best_all"]
+    out = parallel.merge_genome_shards(local, rd("ls_db2.reads.gz"), rank, world, command_line=d["command_line"], single_best=1, all_contigs=1, threads=2)
+    q.put((rank, None if out is None else out == rd("ls_db2@single_best_all.out.gz")))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_world2_genome_sharded_merge():
+    """genome-sharded scheme: one contig group per rank, one gather, the merge on rank 0 -- equal to the reference's mergesam on the same shard files"""
+    from shrimp_amd import parallel
+    assert parallel.contig_groups([160212, 120000, 70, 74200], 2) == [[0, 2], [1, 3]]
+    assert parallel.contig_groups([5, 5, 5], 4) == [[0], [1], [2], []]
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    ps = [ctx.Process(target=_genome_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps: p.start()
+    res = dict(q.get(timeout=180) for _ in ps)
+    for p in ps: p.join(60)
+    assert res == {0: True, 1: None}
