@@ -217,6 +217,12 @@ typedef struct gm_map_stats {
 int gm_sequence_to_bitfield(int colour_space, const char *seq, int seq_len, uint32_t *words, int *initbp);
 int gm_map_reads_text(gm_session_t *s, int n_reads, int read_len, const char *seqs, const char *names, const char *quals, int qual_delta,
                       char **sam, size_t *sam_len, gm_map_stats_t *stats);
+/* File input: the reads file as the reference's reader takes it -- FASTA or FASTQ (fastq: 0 / 1, -1 detects from the first character),
+ * plain or gzip, '#' comment lines, sequences over several lines, names cut at the first blank, any mix of read lengths, primer + colours in a
+ * colour-space session (ref: common/fasta.c:61-150 fasta_open, :315-552 fasta_get_next_read_with_range).  Reads longer than longest_read_len are
+ * dropped without a record and reading stops at a malformed entry, as in the reference (gmapper.c:495-521, fasta.c:362-372).  Records come back in
+ * the file's order. */
+int gm_map_reads_file(gm_session_t *s, const char *path, int fastq, int qual_delta, char **sam, size_t *sam_len, gm_map_stats_t *stats);
 /* host-buffer form: reads are uploaded, SAM text is returned in a malloc()ed buffer (*sam, *sam_len) */
 int gm_map_reads(gm_session_t *s, int n_reads, int read_len, const uint32_t *reads_packed,
                  const char *names, char **sam, size_t *sam_len, gm_map_stats_t *stats);

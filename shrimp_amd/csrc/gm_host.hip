@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +19,7 @@
 #include <mutex>
 #include <condition_variable>
 #include <functional>
+#include <zlib.h>
 #include "gm_common.h"
 #include "gm_internal.h"
 
@@ -1112,7 +1114,7 @@ static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int
 
 static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* reads_host, const void* reads_dev,
                     const char* names, int emit_sam, char** sam, size_t* sam_len, gm_map_stats_t* stats, const uint8_t* initbp_host = nullptr,
-                    const char* quals = nullptr, int qual_delta = 33, const char* seq_text = nullptr) {
+                    const char* quals = nullptr, int qual_delta = 33, const char* seq_text = nullptr, uint32_t* per_read_bytes = nullptr) {
   if (!s || n_reads < 0 || read_len < 1) { gm_set_error("gm_map_reads: bad arguments"); return GM_E_ARG; }
   if ((s->P.colour_space != 0) != (initbp_host != nullptr)) {
     gm_set_error(s->P.colour_space ? "colour-space session: use gm_map_reads_cs (colours + primer letters)" : "gm_map_reads_cs needs a colour-space session"); return GM_E_ARG; }
@@ -1176,7 +1178,9 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
         std::string& o = J->outs[c]; if (emit_sam) o.reserve((size_t)chunk * (read_len + 120));
         for (int rd = c * chunk; rd < std::min(n, (c + 1) * chunk); rd++) {
           const uint32_t cnt = J->hs->sel_cnt[rd], off = J->hs->sel_off[rd];
+          const size_t before = o.size();
           int k = F.finalize_read(rd, cnt ? &J->hs->res[off] : nullptr, J->hs->ops, ops_stride, (int)cnt, o, fh, p2);
+          if (per_read_bytes) per_read_bytes[J->base + rd] = (uint32_t)(o.size() - before);
           if (!p2.empty()) J->cm[c]++;
           J->cr[c] += k;
           if (!emit_sam) o.clear();
@@ -1406,6 +1410,136 @@ extern "C" int gm_map_reads_text(gm_session_t* s, int n_reads, int read_len, con
     p = *e ? e + 1 : e;
   }
   return map_impl(s, n_reads, read_len, packed.data(), nullptr, names, 1, sam, sam_len, stats, cs ? ibp.data() : nullptr, quals, qual_delta, seqs);
+}
+
+// File entry point: the reference's reads reader -- FASTA / FASTQ, plain or gzip (zlib's gz* layer reads both, as fasta_open does), '#'
+// comment lines, sequences over several lines, names cut at the first blank, reads of any mix of lengths (ref: common/fasta.c:61-150 fasta_open,
+// :242-283 extract_name, :315-552 fasta_get_next_read_with_range; gmapper.c:462-521 for the reads that are dropped).  The device pipeline takes batches of
+// one length, so the reads are grouped by length, every group goes through map_impl, and the records return to the file's order.
+struct FileRead { std::string name, seq, qual; };
+static int read_reads_file(const char* path, int colour_space, int fastq, std::vector<FileRead>& out, bool* is_fastq) {
+  gzFile fp = gzopen(path, "r");
+  if (!fp) { gm_set_error("cannot open '%s' for reading", path); return GM_E_ARG; }
+  gzbuffer(fp, 1 << 20);
+  if (fastq < 0) {                                                 // ref: fasta.c:99-127
+    int c = gzgetc(fp);
+    while (c == '#' || c == ';') { while (c != -1 && c != '\n') c = gzgetc(fp); if (gzeof(fp)) break; if (c == -1) break; c = gzgetc(fp); }
+    fastq = 0;
+    if (!gzeof(fp) && c != -1) {
+      if (c == '@') fastq = 1; else if (c == '>') fastq = 0;
+      else { gzclose(fp); gm_set_error("unrecognized character [%c] in input file [%s]", (char)c, path); return GM_E_ARG; }
+      gzungetc(c, fp);
+    }
+  }
+  *is_fastq = fastq != 0;
+  const char mark = fastq ? '@' : '>';
+  std::string line, pending; bool have_pending = false, eof = false;
+  std::vector<char> buf(1 << 16);
+  auto getline = [&](std::string& l) -> bool {                     // one line without its '\n'; `complete` is false for a last line that lacks it
+    l.clear();
+    for (;;) {
+      if (!gzgets(fp, buf.data(), (int)buf.size())) { eof = true; return !l.empty(); }
+      const size_t n = strlen(buf.data());
+      if (n && buf[n - 1] == '\n') { l.append(buf.data(), n - 1); return true; }
+      l.append(buf.data(), n);
+    }
+  };
+  for (;;) {
+    // ---- name line ----
+    bool got = false;
+    for (;;) {
+      if (have_pending) { line.swap(pending); have_pending = false; } else if (!getline(line)) break;
+      if (line.empty()) { got = false; break; }
+      if (line[0] == '#') continue;
+      if (line[0] != mark) { got = false; line.clear(); break; }    // "Expecting ..." -- the reference stops reading here
+      got = true; break;
+    }
+    if (!got || line.size() <= 1) break;
+    FileRead R;
+    { size_t b = 1, e = line.find('\t', 1); if (e == std::string::npos) e = line.size();
+      while (b < e && isspace((unsigned char)line[b])) b++; while (e > b && isspace((unsigned char)line[e - 1])) e--;      // strtrim
+      size_t k = b; while (k < e && line[k] != ' ' && line[k] != '\t') k++;
+      R.name.assign(line, b, k - b); }
+    // ---- sequence ----
+    bool plus = false; std::string plus_line;
+    for (;;) {
+      if (!getline(line)) break;
+      if (fastq && !line.empty() && line[0] == '+') { plus = true; break; }
+      if (!fastq && !line.empty() && line[0] == '>') { pending = line; have_pending = true; break; }
+      if (!line.empty() && line[0] == '#') continue;
+      R.seq += line;
+    }
+    if (R.seq.empty()) break;
+    if (fastq) {
+      if (!plus) break;
+      const size_t want = R.seq.size() - (colour_space ? 1 : 0);
+      for (;;) {
+        if (!getline(line)) break;
+        R.qual += line;
+        if (R.qual.size() >= want) break;
+      }
+      if (R.qual.size() != want) {
+        if (R.qual.size() > want) { gzclose(fp); gm_set_error("read \"%s\": the quality string is longer than the sequence (ref: fasta.c:478-482)", R.name.c_str()); return GM_E_ARG; }
+        break;
+      }
+      for (char& c : R.qual) c = std::max(c, '!');
+    }
+    out.push_back(std::move(R));
+    if (eof && !have_pending) break;
+  }
+  gzclose(fp);
+  return GM_OK;
+}
+
+extern "C" int gm_map_reads_file(gm_session_t* s, const char* path, int fastq, int qual_delta, char** sam, size_t* sam_len, gm_map_stats_t* stats) {
+  if (!s || !path || !sam || !sam_len) { gm_set_error("gm_map_reads_file: bad arguments"); return GM_E_ARG; }
+  *sam = nullptr; *sam_len = 0;
+  const int cs = s->P.colour_space ? 1 : 0;
+  std::vector<FileRead> reads; bool is_fastq = false;
+  int rc = read_reads_file(path, cs, fastq, reads, &is_fastq); if (rc) return rc;
+  if (is_fastq) for (const FileRead& R : reads) for (char c : R.qual) {            // ref: gmapper.c:462-472
+    const int qv = (int)c - qual_delta;
+    if (qv < -10 || qv > 50) { gm_set_error("the quality offset might be set incorrectly: PHRED+%d gives a quality value of %d (read \"%s\")", qual_delta, qv, R.name.c_str()); return GM_E_ARG; }
+  }
+  // groups of one length, in order of first appearance; a read longer than longest_read_len is dropped without a record (ref: gmapper.c:495-521)
+  std::vector<int> lens; std::vector<std::vector<uint32_t>> members;
+  std::vector<int> group_of(reads.size(), -1);
+  for (uint32_t i = 0; i < reads.size(); i++) {
+    const int L = (int)reads[i].seq.size() - cs;
+    if (L < 1 || L > s->P.longest_read_len) continue;
+    size_t g = 0; for (; g < lens.size(); g++) if (lens[g] == L) break;
+    if (g == lens.size()) { lens.push_back(L); members.emplace_back(); }
+    members[g].push_back(i); group_of[i] = (int)g;
+  }
+  gm_map_stats_t total; memset(&total, 0, sizeof total);
+  std::vector<char*> gsam(lens.size(), nullptr); std::vector<size_t> glen(lens.size(), 0); std::vector<std::vector<uint32_t>> gbytes(lens.size());
+  auto cleanup = [&]() { for (char* p : gsam) free(p); };
+  for (size_t g = 0; g < lens.size(); g++) {
+    std::string seqs, names, quals;
+    for (uint32_t i : members[g]) { seqs += reads[i].seq; seqs += '\n'; names += reads[i].name; names += '\n'; if (is_fastq) { quals += reads[i].qual; quals += '\n'; } }
+    const int n = (int)members[g].size(), L = lens[g], rwords = (L + 7) / 8, line = L + cs;
+    std::vector<uint32_t> packed((size_t)n * rwords); std::vector<uint8_t> ibp(cs ? n : 0);
+    const char* p = seqs.data();
+    for (int i = 0; i < n; i++, p += line + 1) { int b = 0; rc = gm_sequence_to_bitfield(cs, p, line, packed.data() + (size_t)i * rwords, &b); if (rc) { cleanup(); return rc; } if (cs) ibp[i] = (uint8_t)b; }
+    gbytes[g].assign(n, 0);
+    gm_map_stats_t st;
+    rc = map_impl(s, n, L, packed.data(), nullptr, names.c_str(), 1, &gsam[g], &glen[g], &st, cs ? ibp.data() : nullptr, is_fastq ? quals.c_str() : nullptr, qual_delta,
+                  seqs.c_str(), gbytes[g].data());
+    if (rc) { cleanup(); return rc; }
+    { std::lock_guard<std::mutex> lk(g_outcache.m); if (gsam[g] == g_outcache.live) g_outcache.live = nullptr; }      // this buffer is freed here, not by the caller
+    { uint64_t* a = (uint64_t*)&total; const uint64_t* b = (const uint64_t*)&st;                 // the counters: every field up to the stage times
+      const size_t nu = offsetof(gm_map_stats_t, ms_lookup) / sizeof(uint64_t); for (size_t k = 0; k < nu; k++) a[k] += b[k]; }
+    total.ms_lookup += st.ms_lookup; total.ms_anchors += st.ms_anchors; total.ms_pass1 += st.ms_pass1; total.ms_select += st.ms_select; total.ms_pass2 += st.ms_pass2; total.ms_host += st.ms_host;
+  }
+  size_t tot = 0; for (size_t g = 0; g < lens.size(); g++) tot += glen[g];
+  char* outp = (char*)malloc(tot + 1); if (!outp) { cleanup(); gm_set_error("gm_map_reads_file: out of memory"); return GM_E_NOMEM; }
+  { std::vector<size_t> cur(lens.size(), 0), nxt(lens.size(), 0); size_t w = 0;
+    for (uint32_t i = 0; i < reads.size(); i++) { const int g = group_of[i]; if (g < 0) continue; const uint32_t b = gbytes[g][nxt[g]++]; memcpy(outp + w, gsam[g] + cur[g], b); cur[g] += b; w += b; }
+    outp[w] = 0; *sam_len = w; }
+  cleanup();
+  *sam = outp;
+  if (stats) *stats = total;
+  return GM_OK;
 }
 
 extern "C" int gm_last_lookup_timing(gm_session_t* s, double* ms, uint64_t* alg_bytes, int* launches) {

@@ -869,3 +869,25 @@ def test_genome_shards_mapped_here_then_merged_match_mergesam(gm, paired):
         got = gm.merge_sam(reads_text, texts, command_line=d["command_line"], threads=4, **opts)
         want = rd("%s@%s.out.gz" % (case, st))
         assert got == want, (st, _first_diff(got, want))
+
+
+@pytest.mark.parametrize("case", ["ls_fa_gz", "ls_fq", "cs_fa_gz"])
+def test_reads_files_match_reference_golden(gm, case, tmp_path):
+    """gm_map_reads_file on the very files the reference read -- gzip, '#' comments, folded sequences, descriptions, five read lengths mixed,
+    folded FASTQ, a read beyond --longest-read (dropped), csfasta -- records in the file's order, byte-identical to the reference's SAM."""
+    import gzip, shutil
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    src, want_name, base = {"ls_fa_gz": ("file_ls_mixed.fa.gz", "file_ls_mixed.sam.gz", "stress_60bp"), "ls_fq": ("file_ls_mixed.fq.gz", "file_ls_mixed_fq.sam.gz", "stress_60bp"),
+                            "cs_fa_gz": ("file_cs_mixed.csfasta.gz", "file_cs_mixed.sam.gz", "stress_cs_60col_unal")}[case]
+    z = np.load(os.path.join(G, base + ".npz")); contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig")))]
+    want = gzip.open(os.path.join(G, want_name), "rb").read()
+    path = os.path.join(G, src)
+    if case == "ls_fq":                                       # the reference read this one as plain text
+        path = str(tmp_path / "r.fq"); open(path, "wb").write(gzip.open(os.path.join(G, src), "rb").read())
+    p = gm.default_params_cs() if case.startswith("cs") else gm.default_params()
+    p.sam_unaligned = 1
+    ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+    got = oa.sam_header(contigs) + s.map_reads_file(path, qual_delta=33 if case == "ls_fq" else None)
+    st = s.stats
+    s.close(); ix.close()
+    assert got == want, (_first_diff(got, want), st)

@@ -465,5 +465,63 @@ def text_cases():
     with gzip.open(os.path.join(OUT, "text_cs_unal.sam.gz"), "wb", compresslevel=9) as f: f.write(sam)
 
 
+def file_cases():
+    """File input: reads files as users have them -- gzip, '#' comments, sequences folded over lines, descriptions after the name, reads of
+    several lengths mixed, FASTQ with folded sequences, a read longer than --longest-read -- through the reference with --sam-unaligned.  Fixtures:
+    the files themselves (data the reference read) + the reference's SAM."""
+    rng = np.random.Generator(np.random.PCG64(4242))
+    sg = stress_genome()
+    def run(exe, extra, reads_path, genome_path):
+        p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", exe), "-N", "2", "--sam-unaligned", *extra, reads_path, genome_path], capture_output=True, check=True)
+        return b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+    LET = b"ACGTUMRWSYKVHDBN"
+    sets = [stress_reads(sg, 150, L, seed=300 + L) for L in (36, 50, 75, 100, 130)]
+    recs = [(L, r) for rs in sets for L, r in ((rs.shape[1], x) for x in rs)]
+    order = rng.permutation(len(recs))
+    with tempfile.TemporaryDirectory() as d:
+        g = os.path.join(d, "g.fa"); write_fa_codes(g, [b"contig%d" % (i + 1) for i in range(len(sg))], sg)
+        # (1) FASTA, gzip, folded lines, comments, descriptions
+        fa = bytearray(b"# reads of five lengths\n; second comment line\n")
+        for n, k in enumerate(order):
+            L, r = recs[k]; t = bytes(LET[c] for c in r)
+            fa += b">read_%d  len=%d some description\twith a tab\n" % (n, L)
+            w = int(rng.integers(20, 80))
+            for o in range(0, L, w): fa += t[o:o + w] + b"\n"
+            if n % 37 == 0: fa += b"# a comment between reads\n"
+        fa += b">too_long\n" + bytes(LET[c] for c in rng.integers(0, 4, 1100)) + b"\n>after_long\n" + bytes(LET[c] for c in recs[0][1]) + b"\n"
+        with gzip.open(os.path.join(d, "r.fa.gz"), "wb") as f: f.write(bytes(fa))
+        sam = run("gmapper-ls", [], os.path.join(d, "r.fa.gz"), g)
+        with gzip.open(os.path.join(OUT, "file_ls_mixed.fa.gz"), "wb", compresslevel=9) as f: f.write(bytes(fa))
+        with gzip.open(os.path.join(OUT, "file_ls_mixed.sam.gz"), "wb", compresslevel=9) as f: f.write(sam)
+        print("file_ls_mixed:", sum(1 for l in sam.split(b"\n") if l and not l.startswith(b"@")), "records")
+        # (2) FASTQ (PHRED+33), plain, sequence and qualities folded, three lengths
+        fq = bytearray()
+        for n, k in enumerate(order[:300]):
+            L, r = recs[k]; t = bytes(LET[c] for c in r); q = bytes((rng.integers(2, 40, L) + 33).astype(np.uint8))
+            fq += b"@fq%d extra\n" % n
+            if n % 3 == 0: fq += t[:L // 2] + b"\n" + t[L // 2:] + b"\n+fq%d\n" % n + q[:L // 3] + b"\n" + q[L // 3:] + b"\n"
+            else: fq += t + b"\n+\n" + q + b"\n"
+        open(os.path.join(d, "r.fq"), "wb").write(bytes(fq))
+        sam = run("gmapper-ls", ["--qv-offset", "33"], os.path.join(d, "r.fq"), g)
+        with gzip.open(os.path.join(OUT, "file_ls_mixed.fq.gz"), "wb", compresslevel=9) as f: f.write(bytes(fq))
+        with gzip.open(os.path.join(OUT, "file_ls_mixed_fq.sam.gz"), "wb", compresslevel=9) as f: f.write(sam)
+        print("file_ls_mixed_fq:", sum(1 for l in sam.split(b"\n") if l and not l.startswith(b"@")), "records")
+        # (3) csfasta, two lengths (reads of the committed colour-space cases, cut)
+        z = np.load(os.path.join(OUT, "stress_cs_60col_unal.npz")); cc = [z["contig%d" % i] for i in range(len(z.files) - 1)]; cr = z["reads"][:400]
+        gc = os.path.join(d, "gc.fa"); write_fa_codes(gc, [b"contig%d" % (i + 1) for i in range(len(cc))], cc)
+        cf = bytearray(b"# csfasta\n")
+        for n, r in enumerate(cr):
+            L = 60 if n % 2 else 45
+            cf += b">c%d_F3\n" % n + b"ACGT"[r[0]:r[0] + 1] + bytes(b"0123"[c] if c < 4 else ord(".") for c in r[1:1 + L]) + b"\n"
+        with gzip.open(os.path.join(d, "r.csfasta.gz"), "wb") as f: f.write(bytes(cf))
+        sam = run("gmapper-cs", [], os.path.join(d, "r.csfasta.gz"), gc)
+        with gzip.open(os.path.join(OUT, "file_cs_mixed.csfasta.gz"), "wb", compresslevel=9) as f: f.write(bytes(cf))
+        with gzip.open(os.path.join(OUT, "file_cs_mixed.sam.gz"), "wb", compresslevel=9) as f: f.write(sam)
+        print("file_cs_mixed:", sum(1 for l in sam.split(b"\n") if l and not l.startswith(b"@")), "records")
+
+
 if __name__ == "__main__":
-    main()
+    if "--file-only" in sys.argv:
+        os.makedirs(OUT, exist_ok=True); file_cases()
+    else:
+        main()
