@@ -71,6 +71,12 @@ typedef struct gm_params {
                                                   hash_filter_calls 0; requires local_alignment (gmapper.c:2330-2333).  0 */
   int hash_seeds;                              /* -H (Hflag): lists are keyed by kmer_to_mapidx_hash -- 4^12 lists per seed whatever its weight, so seeds
                                                   heavier than 14 are allowed (ref: gmapper.h:309-336, seeds.c:83-102,132-136).  An index property.  0 */
+  int output_format;                           /* 0: SAM (-E, the binary's default); 1: --shrimp-format, one line per mapping -- readname contigname strand
+                                                  contigstart contigend readstart readend readlength score editstring (ref: common/output.c:280-352 output_normal,
+                                                  :36-115 alignment_edit_string); 2: -P/--pretty, each line followed by the aligned G: / R: (/ T:) rows
+                                                  (ref: common/output.c:118-262 output_pretty).  Unaligned reads print nothing in 1 / 2; in paired mode every mate has its
+                                                  own line under its own name, and the unmapped mate of a half-paired mapping prints ">name" (gmapper/output.c:292-294).  0 */
+  int print_read_seq;                          /* -R: the read's sequence as a last column of the SHRiMP-format line (ref: gmapper.h Rflag, output.c:310-313)  0 */
 } gm_params_t;
 
 void gm_params_default(gm_params_t *p);        /* letter-space defaults of the reference binary (gmapper-ls) */

@@ -61,7 +61,7 @@ extern "C" void gm_params_default(gm_params_t* p) {
   p->match_mode = 2; p->num_outputs = 10; p->num_tmp_outputs = 30; p->anchor_width = 8;
   p->region_bits = 11; p->region_overlap = 50; p->list_cutoff = 0; p->hash_filter_calls = 1; p->tiebreak_rev = 1;
   p->sam_unaligned = 0; p->longest_read_len = 1000; p->strata = 0; p->max_alignments = 0;
-  p->colour_space = 0; p->crossover_score = -20; p->indel_taboo_len = 0; p->pr_xover = 0.03; p->local_alignment = 0; p->ungapped = 0; p->hash_seeds = 0;
+  p->colour_space = 0; p->crossover_score = -20; p->indel_taboo_len = 0; p->pr_xover = 0.03; p->local_alignment = 0; p->ungapped = 0; p->hash_seeds = 0; p->output_format = 0; p->print_read_seq = 0;
 }
 // the gmapper-cs binary's defaults (ref: gmapper.c:1748-1755, gmapper-defaults.h:52-58,64-66)
 extern "C" void gm_params_default_cs(gm_params_t* p) {
@@ -336,6 +336,7 @@ struct gm_session {
   HostSlot slot[3];
   uint32_t* d_pairs = nullptr; uint32_t* d_pair_cnt = nullptr; int pairs_cap = 0;   // paired mode: selected (mate 1, mate 2) window pairs
   unsigned long long* d_stats = nullptr;
+  std::vector<uint32_t> h_genome;                 // host copy of the packed genome: only for the SHRiMP / pretty output formats, which print genome letters (fetched on first use)
   // last lookup timing
   double last_lookup_ms = 0; uint64_t last_lookup_bytes = 0; int last_lookup_launches = 0;
 };
@@ -719,6 +720,86 @@ struct Finalizer {
   const GmFullRes* res_base = nullptr; const GmPostRes* post_base = nullptr;           // colour space: post_sw results of the device, parallel to the sub-batch's result records
   const char* const* seq_ptr = nullptr;                                                // text input: the read as it stood in the file (fields the reference prints from re->seq)
   const char* const* qual_ptr = nullptr; int qual_delta = 33;                          // FASTQ input: QUAL string of every read of this sub-batch   // colour space: primer letters of this sub-batch, ops_stride / 2
+  const uint32_t* hgen = nullptr;                                                      // SHRiMP / pretty output: the packed genome on the host
+
+  // dbalign / qralign of a letter-space result from its op record ('M' both, 'I' genome only, 'D' read only), the genome and the read: what sw_full_ls
+  // hands to the output routines (ref: sw-full-ls.c pretty_print).  A reverse-strand result aligned the read to the reverse complement of the contig.
+  void ls_alignment_strings(const GmFullRes& r, const uint8_t* ops, int nops, const uint32_t* rw, std::string& db, std::string& qr) const {
+    static const char L[17] = "ACGTUMRWSYKVHDBN";
+    const gm_index* ix = s->ix; const uint64_t base = ix->contig_off[r.cn]; const int glen = (int)(ix->contig_off[r.cn + 1] - ix->contig_off[r.cn]);
+    auto gcode = [&](int j) -> int {
+      const uint64_t p = base + (uint64_t)(r.gen_st ? glen - 1 - j : j); int c = (int)((hgen[p >> 3] >> ((p & 7) * 4)) & 0xf);
+      if (r.gen_st) c = (int)((0xFBCDE56879A00123ull >> (c * 4)) & 0xf);                    // complement_base, ref: util.h:125-151
+      return c; };
+    db.clear(); qr.clear();
+    int gi = r.genome_start, ri = r.read_start;
+    for (int k = 0; k < nops; k++) {
+      const char op = (char)ops[k];
+      if (op == 'M') { db.push_back(L[gcode(gi++)]); qr.push_back(L[(rw[ri >> 3] >> ((ri & 7) * 4)) & 0xf]); ri++; }
+      else if (op == 'I') { db.push_back(L[gcode(gi++)]); qr.push_back('-'); }
+      else { db.push_back('-'); qr.push_back(L[(rw[ri >> 3] >> ((ri & 7) * 4)) & 0xf]); ri++; }
+    }
+  }
+  // ref: common/output.c:36-115
+  static void edit_string(const std::string& db, const std::string& qr, std::string& o) {
+    const int len = (int)db.size(); int consec = 0; bool refgap = false; char nb[16];
+    for (int i = 0; i <= len; i++) {
+      if (i != len && db[i] == qr[i] && db[i] != '-') { consec++; continue; }
+      if (refgap && (consec != 0 || (i == len ? '\0' : db[i]) != '-')) { o += ')'; refgap = false; }
+      if (consec != 0) { o.append(nb, snprintf(nb, sizeof nb, "%d", consec)); consec = 0; }
+      if (i == len) break;
+      if (db[i] == '-') { if (islower((unsigned char)qr[i])) o += 'x'; if (!refgap) o += '('; o += (char)toupper((unsigned char)qr[i]); refgap = true; continue; }
+      if (qr[i] == '-') o += '-';
+      else if (db[i] == toupper((unsigned char)qr[i])) { o += 'x'; consec++; }
+      else if (islower((unsigned char)qr[i])) { o += 'x'; o += (char)toupper((unsigned char)qr[i]); }
+      else o += qr[i];
+    }
+  }
+  // one mapping in the SHRiMP format, with the pretty rows when asked (ref: gmapper/output.c:270-296; common/output.c:280-352 output_normal, :118-262 output_pretty)
+  void emit_shrimp(const FHit& h, const char* nm, size_t nl, int rd, const uint32_t* rw, const std::string& db, const std::string& qr, std::string& out) const {
+    const gm_params_t& P = s->P; const gm_index* ix = s->ix; const GmFullRes& r = *h.r;
+    const bool rev = r.gen_st == 1, cs = P.colour_space != 0;
+    const uint32_t glen = (uint32_t)(ix->contig_off[r.cn + 1] - ix->contig_off[r.cn]);
+    const uint32_t gs = (uint32_t)r.genome_start, ge = gs + (uint32_t)r.gmapped - 1;
+    const uint32_t igs = rev ? glen - ge - 1 : gs, ige = rev ? glen - gs - 1 : ge;
+    char b[160];
+    out += '>'; out.append(nm, nl); out += '\t'; out += ix->names[r.cn]; out += '\t'; out += rev ? '-' : '+';
+    out.append(b, snprintf(b, sizeof b, "\t%u\t%u\t%d\t%d\t%d\t%d\t", igs + 1, ige + 1, r.read_start + 1, r.read_start + r.rmapped, read_len, h.score_full));
+    edit_string(db, qr, out); out += '\t';
+    std::string rstr;                                                                   // readtostr, ref: common/output.c:17-34
+    auto read_text = [&]() { static const char LS[17] = "ACGTUMRWSYKVHDBN", CS[17] = "0123!@#$%^&*?~;."; rstr.clear(); if (cs) rstr += LS[initbp[rd] & 15];
+      for (int i = 0; i < read_len; i++) { const int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; rstr += cs ? CS[c] : LS[c]; } };
+    if (P.print_read_seq) { read_text(); out += rstr; }
+    out += '\n';
+    if (P.output_format != 2) return;
+    static const char LS[17] = "ACGTUMRWSYKVHDBN";
+    const uint64_t base = ix->contig_off[r.cn];
+    auto fwd_letter = [&](uint32_t j) { const uint64_t p = base + j; return LS[(hgen[p >> 3] >> ((p & 7) * 4)) & 0xf]; };   // (the reference reads the forward contig here on either strand)
+    const uint32_t read_start = (uint32_t)r.read_start, read_end = (uint32_t)(r.read_start + r.rmapped - 1);
+    std::string gpre, gpost, lspre, lspost, mpre;
+    for (uint32_t j = 0; j < read_start; j++) { gpre += (gs + j > read_start) ? fwd_letter(gs - read_start + j) : '-'; lspre += '-'; mpre += ' '; }
+    if (read_end < (uint32_t)read_len - 1) for (uint32_t j = 0; j < (uint32_t)read_len - read_end - 1; j++) { gpost += (ge + 1 + j < glen) ? fwd_letter(ge + 1 + j) : '-'; lspost += '-'; }
+    out.append(b, snprintf(b, sizeof b, "G: %10lld    ", (long long)(rev ? ige + 1 : igs + 1))); out += gpre; out += db; out += gpost;
+    out.append(b, snprintf(b, sizeof b, "    %-10lld\n", (long long)(rev ? igs + 1 : ige + 1)));
+    out.append(b, snprintf(b, sizeof b, "%16s ", "")); out += mpre;
+    for (size_t j = 0; j < db.size(); j++) {
+      if (db[j] == qr[j] && db[j] != '-') out += '|';
+      else if (db[j] == toupper((unsigned char)qr[j])) out += 'X';
+      else if (islower((unsigned char)qr[j])) out += 'x';
+      else out += ' ';
+    }
+    out += '\n';
+    if (cs) { out.append(b, snprintf(b, sizeof b, "T: %10s    ", "")); out += lspre; out += qr; out += lspost; out += '\n'; }
+    else { out.append(b, snprintf(b, sizeof b, "R: %10u    ", read_start + 1)); out += lspre; out += qr; out += lspost; out.append(b, snprintf(b, sizeof b, "    %-10u\n", read_end + 1)); }
+    if (cs) {
+      out.append(b, snprintf(b, sizeof b, "R: %10u   ", read_start + 1));
+      read_text(); size_t k = 0; out += rstr[k++];
+      for (uint32_t j = 0; j < read_start; j++) out += rstr[k++];
+      for (size_t j = 0; k < rstr.size();) { if (j < qr.size() && qr[j] == '-') out += '-'; else out += rstr[k++]; if (j < qr.size()) j++; }
+      out.append(b, snprintf(b, sizeof b, "    %-10u\n", read_end + 1));
+    }
+    out += '\n';
+  }
 
   // hit_run_post_sw for one pass-2 result (ref: mapping.c:1609-1625)
   void post_sw(FHit& h, const GmFullRes* r, const uint8_t* ops) const {
@@ -797,6 +878,14 @@ struct Finalizer {
       double z1 = 0.0;
       for (auto* h : p2) z1 += h->posterior;
       for (auto* h : p2) { h->z0 = h->posterior; h->z1 = z1; h->mqv = qv_from_pr_corr(h->posterior / z1); if (h->mqv < 4) h->mqv = 0; }
+    }
+    if (P.output_format) {                                                         // --shrimp-format / --pretty, ref: gmapper/output.c:270-296
+      std::string db, qr;
+      for (auto* h : p2) {
+        if (P.colour_space) emit_shrimp(*h, nm, nl, rd, rw, h->db, h->qr, out);
+        else { ls_alignment_strings(*h->r, h->ops, std::min(h->r->n_ops, ops_stride), rw, db, qr); emit_shrimp(*h, nm, nl, rd, rw, db, qr, out); }
+      }
+      return (int)p2.size();
     }
     for (auto* h : p2) {
       const GmFullRes& r = *h->r;
@@ -1124,6 +1213,10 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   if (stats) memset(stats, 0, sizeof *stats);
   if (D.cur_len != read_len) { choose_caps(s, D, read_len); int rc = alloc_buffers(s, D, read_len); if (rc) return rc; }
   const int read_words = (read_len + 7) / 8;
+  if (s->P.output_format && s->h_genome.empty()) {                // the SHRiMP / pretty formats print genome letters: one download per session
+    s->h_genome.resize(s->ix->genome_words);
+    GM_HIP(hipMemcpy(s->h_genome.data(), s->ix->d_genome, s->ix->genome_words * 4, hipMemcpyDeviceToHost));
+  }
   s->last_lookup_ms = 0; s->last_lookup_bytes = 0; s->last_lookup_launches = 0;
   // names
   std::vector<const char*> nptr; std::vector<int> nlen;
@@ -1171,6 +1264,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     if (s->P.colour_space) { F.initbp = initbp_host + J->base; F.ops_half = ops_stride / 2; F.csk = cs_post_consts(s); if (J->hs->post_on) { F.res_base = J->hs->res; F.post_base = J->hs->post; } }
     if (quals) { F.qual_ptr = qptr.data() + J->base; F.qual_delta = qual_delta; }
     if (seq_text) F.seq_ptr = sptr.data() + J->base;
+    if (s->P.output_format) F.hgen = s->h_genome.data();
     auto worker = [&]() {
       std::vector<FHit> fh; std::vector<FHit*> p2;
       for (;;) {

@@ -891,3 +891,35 @@ def test_reads_files_match_reference_golden(gm, case, tmp_path):
     st = s.stats
     s.close(); ix.close()
     assert got == want, (_first_diff(got, want), st)
+
+
+FORMATS = {"fmt_shrimp": ("stress_60bp", dict(output_format=1)), "fmt_pretty_R": ("stress_60bp", dict(output_format=2, print_read_seq=1)),
+           "fmt_local_pretty": ("stress_100bp_unal", dict(output_format=2, local_alignment=1)),
+           "fmt_cs_shrimp_R": ("stress_cs_60col_unal", dict(output_format=1, print_read_seq=1)), "fmt_cs_pretty": ("stress_cs_60col_unal", dict(output_format=2)),
+           "fmt_pairs_shrimp_R": ("stress_pairs_2x100", dict(output_format=1, print_read_seq=1)), "fmt_pairs_pretty": ("pairfix_opp-out", dict(output_format=2)),
+           "fmt_pairs_colbw": ("pairfix_col-bw", dict(output_format=1)), "fmt_cs_pairs_pretty_R": ("cs_pairs_50col_col-bw", dict(output_format=2, print_read_seq=1)),
+           "fmt_cs_pairs_shrimp": ("cs_pairs_50col_opp-in", dict(output_format=1))}
+
+
+@pytest.mark.parametrize("tag", sorted(FORMATS))
+def test_output_formats_match_reference_golden(gm, tag):
+    """--shrimp-format and -P/--pretty (with -R), letter and colour space, global and local alignments: the reference's whole output"""
+    import gzip
+    base, fields = FORMATS[tag]
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(G, base + ".npz")); contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
+    want = gzip.open(os.path.join(G, "%s@%s.txt.gz" % (base, tag)), "rb").read()
+    cs = "cs" in base
+    p = gm.default_params_cs() if cs else gm.default_params()
+    for k, v in fields.items(): setattr(p, k, v)
+    if "mates1" in z.files:
+        g = oa.load_golden_pairs(base)
+        ix = gm.Index(g["contigs"], names=g["contig_names"], params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+        body = (s.map_pairs_cs if cs else s.map_pairs)(g["m1"], g["m2"], g["names1"], g["names2"], mode=g["mode"], min_insert=g["ins"][0], max_insert=g["ins"][1])
+    else:
+        ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+        body = s.map_reads_cs(z["reads"]) if cs else s.map_reads(z["reads"])
+    s.close(); ix.close()
+    head = b"#FORMAT: readname contigname strand contigstart contigend readstart readend readlength score editstring" + (b" readsequence" if fields.get("print_read_seq") else b"") + b"\n"
+    got = head + body
+    assert got == want, _first_diff(got, want)

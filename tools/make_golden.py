@@ -520,8 +520,51 @@ def file_cases():
         print("file_cs_mixed:", sum(1 for l in sam.split(b"\n") if l and not l.startswith(b"@")), "records")
 
 
+FORMAT_CASES = {
+    # tag: (base golden, program, options): the reference's SHRiMP-format / pretty output, whole (its #FORMAT line included)
+    "fmt_shrimp": ("stress_60bp", "gmapper-ls", ["--shrimp-format"]),
+    "fmt_pretty_R": ("stress_60bp", "gmapper-ls", ["-P", "-R"]),
+    "fmt_local_pretty": ("stress_100bp_unal", "gmapper-ls", ["--local", "-P"]),
+    "fmt_cs_shrimp_R": ("stress_cs_60col_unal", "gmapper-cs", ["--shrimp-format", "-R"]),
+    "fmt_cs_pretty": ("stress_cs_60col_unal", "gmapper-cs", ["-P"]),
+    # pairs: one line per mate under the mate's own name, ">name" for the unmapped mate of a half-paired mapping
+    "fmt_pairs_shrimp_R": ("stress_pairs_2x100", "gmapper-ls", ["--shrimp-format", "-R"]),
+    "fmt_pairs_pretty": ("pairfix_opp-out", "gmapper-ls", ["-P"]),
+    "fmt_pairs_colbw": ("pairfix_col-bw", "gmapper-ls", ["--shrimp-format"]),
+    "fmt_cs_pairs_pretty_R": ("cs_pairs_50col_col-bw", "gmapper-cs", ["-P", "-R"]),
+    "fmt_cs_pairs_shrimp": ("cs_pairs_50col_opp-in", "gmapper-cs", ["--shrimp-format"]),
+}
+
+
+def format_cases():
+    for tag, (base, exe, extra) in FORMAT_CASES.items():
+        z = np.load(os.path.join(OUT, base + ".npz"))
+        contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
+        with tempfile.TemporaryDirectory() as d:
+            g = os.path.join(d, "g.fa"); r = os.path.join(d, "r.fa")
+            write_fa_codes(g, [b"contig%d" % (i + 1) for i in range(len(contigs))], contigs)
+            if "mates1" in z.files:
+                write_fa_codes(g, [bytes(x) for x in z["contig_names"]], contigs)
+                names = [bytes(n) for pair in zip(z["names1"], z["names2"]) for n in pair]
+                seqs = [q for pair in zip(list(z["mates1"]), list(z["mates2"])) for q in pair]
+                if exe == "gmapper-cs":
+                    tab = np.full(16, ord("."), dtype=np.uint8); tab[:4] = np.frombuffer(b"0123", dtype=np.uint8)
+                    with open(r, "wb") as f:
+                        for nm, q in zip(names, seqs): f.write(b">" + nm + b"\n" + b"ACGT"[q[0]:q[0] + 1] + tab[q[1:]].tobytes() + b"\n")
+                else: write_fa_codes(r, names, seqs)
+                extra = ["-p", str(z["mode"]), "-I", "%d,%d" % tuple(int(x) for x in z["ins"]), *extra]
+            elif exe == "gmapper-cs": synth.write_csfasta_reads(r, z["reads"])
+            else: write_fa_codes(r, [b"r%d" % i for i in range(len(z["reads"]))], list(z["reads"]))
+            p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", exe), "-N", "4", *extra, r, g], capture_output=True, check=True)
+        with gzip.open(os.path.join(OUT, "%s@%s.txt.gz" % (base, tag)), "wb", compresslevel=9) as f:
+            f.write(p.stdout)
+        print("%s@%s: %d mappings" % (base, tag, p.stdout.count(b"\n>")))
+
+
 if __name__ == "__main__":
-    if "--file-only" in sys.argv:
+    if "--format-only" in sys.argv:
+        os.makedirs(OUT, exist_ok=True); format_cases()
+    elif "--file-only" in sys.argv:
         os.makedirs(OUT, exist_ok=True); file_cases()
     else:
         main()
