@@ -76,14 +76,16 @@ struct K5Args {
   uint64_t* raw_out; int raw_cap; uint32_t* surv_seg; int n_slabs; uint32_t* pl_list; uint32_t* pl_cnt; int pl_cap;
 };
 
-// lane * W for a wave-uniform W in 1..4 without the quarter-rate 32-bit multiply
+// lane * W for a wave-uniform W in 1..4 (the 24-bit multiply is a full-rate instruction)
 __device__ __forceinline__ uint32_t k5_lane_times(int lane, uint32_t W) {
-  const uint32_t sh = W >> 2 ? 2u : (W >> 1), add3 = W == 3u ? 0xFFFFFFFFu : 0u;
-  return ((uint32_t)lane << sh) + ((uint32_t)lane & add3);
+  uint32_t r; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(lane), "s"(W)); return r;     // (the compiler turns __umul24 by a uniform factor into the quarter-rate v_mul_lo_u32)
 }
 
 #include "gm_region_table.h"
 
+// LSWC: log2(words) of seen[] as a compile-time constant (the production size, 15), or 0 for the size in K5Args (small-table test variants, long reads):
+// with constants the table masks are immediates and the base of seen[] folds into the LDS instructions' offset field.
+template <int LSWC>
 __global__ void __launch_bounds__(1024)
 k_lookup_v5(GmIndexDev ix, K5Args a) {
   if (a.start_flags && threadIdx.x == 0) __hip_atomic_store(&a.start_flags[blockIdx.x], a.start_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -91,31 +93,32 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
   extern __shared__ __align__(16) uint32_t smem[];
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & (GM_WAVE - 1);
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
-  const int S = ix.n_slabs, rb = ix.region_bits, lsw = a.lsw;
+  const int S = ix.n_slabs, rb = ix.region_bits, lsw = LSWC ? LSWC : a.lsw, ltw = lsw - 3, hbits = lsw - 2;
+  const int cand_cap = LSWC ? (int)(((4u << LSWC) / 4u / 6u) & ~15u) : a.cand_cap;
   const uint32_t rmask = (1u << rb) - 1u, ovl = (uint32_t)ix.region_overlap;
-  const uint32_t wmask = (1u << lsw) - 1u, tmask = (1u << a.ltw) - 1u;
-  // LDS: seen (later: candidates | region table) | twice | rec[NL] (4 words) | srec[NL] (4 words) | codes | ctrl
-  // Byte offsets into the tables come straight from the position: seen word of p at (p >> (rb - 2)) & smask4, its twice word at
-  // ((p >> (rb - 2)) & tmask4) | swb (twice[] starts at swb = the size of seen[], a power of two above tmask4), bit (p >> (rb + lsw)) & 31.
+  const uint32_t wmask = (1u << lsw) - 1u, tmask = (1u << ltw) - 1u;
+  // LDS: twice | seen (later: candidates | region table) | rec[NL] (4 words) | srec[NL] (4 words) | codes | ctrl
+  // Byte offsets into the tables come straight from the position: twice word of p at (p >> (rb - 2)) & tmask4 (twice[] starts at 0: no base to add), its
+  // seen word at swb + ((p >> (rb - 2)) & smask4) (swb = the size of twice[]: an instruction offset when the sizes are compile-time), bit (p >> (rb + lsw)) & 31.
   if ((uint32_t)(uintptr_t)(k5_lds_u32*)smem != 0u) __builtin_trap();      // no static LDS in this kernel: the dynamic segment starts at 0
-  uint32_t* seen = smem;
-  uint32_t* twice = smem + (1u << lsw);
+  uint32_t* twice = smem;
+  uint32_t* seen = smem + (1u << ltw);
   // after pass A the seen[] area is re-used: htag | hmin | hmax (2^hbits = 2^(lsw - 2) words each: three quarters of it) | candidate positions
   // (cand_cap words) | candidate y / seed (u16); cand_cap = the last quarter / 6 bytes, cut into one segment per wave
   uint32_t* htag = seen;
-  uint32_t* hmin = htag + (1u << a.hbits);
-  uint32_t* hmax = hmin + (1u << a.hbits);
-  uint32_t* candp = hmax + (1u << a.hbits);
-  uint16_t* candy = (uint16_t*)(candp + a.cand_cap);
-  uint32_t* rec = twice + (1u << a.ltw);
+  uint32_t* hmin = htag + (1u << hbits);
+  uint32_t* hmax = hmin + (1u << hbits);
+  uint32_t* candp = hmax + (1u << hbits);
+  uint16_t* candy = (uint16_t*)(candp + cand_cap);
+  uint32_t* rec = seen + (1u << lsw);
   uint32_t* srec = rec + 4 * a.NL;
   uint8_t* codes = (uint8_t*)(srec + 4 * a.NL);
   uint32_t* ctrl = (uint32_t*)(codes + 2 * ((a.read_len + 15) & ~15));           // two code buffers (this read-strand's and the next one's)
-  const uint32_t smask4 = wmask << 2, tmask4 = tmask << 2, swb = 4u << lsw;
+  const uint32_t smask4 = wmask << 2, tmask4 = tmask << 2, swb = 4u << ltw;
   const int sh_a = rb - 2, sh_b = rb + lsw;
-  const uint32_t hmask = (1u << a.hbits) - 1u; const int hshift = 32 - a.hbits;
-  const int hclr_q = (int)(3u << a.hbits) >> 2;                         // uint4 words of the region table (cleared during pass B)
-  const int tab_q = (int)(((1u << a.ltw) + (1u << lsw)) >> 2);             // uint4 words of twice + seen
+  const uint32_t hmask = (1u << hbits) - 1u; const int hshift = 32 - hbits;
+  const int hclr_q = (int)(3u << hbits) >> 2;                         // uint4 words of the region table (cleared during pass B)
+  const int tab_q = (int)(((1u << ltw) + (1u << lsw)) >> 2);             // uint4 words of twice + seen
   const uint32_t* __restrict__ pos0 = ix.seed[0].pos;
   const uint32_t* __restrict__ spos0 = ix.seed[0].spos;
   unsigned long long my_lookups = 0, my_entries = 0;
@@ -125,10 +128,10 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
 
   auto mark = [&](const uint32_t p) {                          // one mark of region p >> rb (strip loop; the main loop has its own batched form)
     const uint32_t av = p >> sh_a, m = 1u << ((p >> sh_b) & 31u);
-    const uint32_t old = K5_LDS_OR(av & smask4, m);
-    if (old & m) K5_LDS_OR((av & tmask4) | swb, m);
+    const uint32_t old = K5_LDS_OR(swb + (av & smask4), m);
+    if (old & m) K5_LDS_OR(av & tmask4, m);
   };
-  auto has2 = [&](const uint32_t p) -> bool { return (*K5_LDS(((p >> sh_a) & tmask4) | swb) >> ((p >> sh_b) & 31u)) & 1u; };
+  auto has2 = [&](const uint32_t p) -> bool { return (*K5_LDS((p >> sh_a) & tmask4) >> ((p >> sh_b) & 31u)) & 1u; };
 
 #ifdef K5_STAMPS
   unsigned long long t_prev = __builtin_amdgcn_s_memtime();
@@ -263,7 +266,7 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
     // (next list / tail pad).  (Hand-issued inline-asm loads with a manual s_waitcnt vmcnt(K5_Q - 1) returned stale registers now and then on
     // gfx950 -- tools/probes/vmcnt_order.hip -- so the loads are left to the compiler, which places the counted waits itself.)
     auto issue = [&](const Step& s, k5_u32x4& v) {
-      const uint32_t W = (s.n + 63u) >> 6, x = k5_lane_times(lane, W), lim = s.n ? s.n - 1u : 0u;
+      const uint32_t W = (s.n + 63u) >> 6, x = k5_lane_times(lane, W), lim = max(s.n, 1u) - 1u;      // (lim on the scalar side)
       const uint32_t e = (x < lim ? x : lim) << 2;
 #ifdef K5_ASM_LOADS
       asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(v) : "v"(e), "s"(s.src) : "memory");
@@ -281,9 +284,9 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
 #define K5_WAIT_OLDEST(v) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(K5_Q - 1) : "memory")
 #endif
 #ifdef K5_TWICE_BRANCH
-#define K5_TWICE(av, t) do { if (t) K5_LDS_OR(((av) & tmask4) | swb, (t)); } while (0)
+#define K5_TWICE(av, t) do { if (t) K5_LDS_OR((av) & tmask4, (t)); } while (0)
 #else
-#define K5_TWICE(av, t) K5_LDS_OR(((av) & tmask4) | swb, (t))
+#define K5_TWICE(av, t) K5_LDS_OR((av) & tmask4, (t))
 #endif
 
     // ================= pass A: marks =================
@@ -323,10 +326,10 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
             const uint32_t a0 = sv[q].x >> sh_a, a1 = sv[q].y >> sh_a, a2 = sv[q].z >> sh_a, a3 = sv[q].w >> sh_a;
             const uint32_t m0 = 1u << ((sv[q].x >> sh_b) & 31u), m1 = 1u << ((sv[q].y >> sh_b) & 31u), m2 = 1u << ((sv[q].z >> sh_b) & 31u), m3 = 1u << ((sv[q].w >> sh_b) & 31u);
             uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-            o0 = K5_LDS_OR(a0 & smask4, m0);
-            if (W > 1) o1 = K5_LDS_OR(a1 & smask4, m1);
-            if (W > 2) o2 = K5_LDS_OR(a2 & smask4, m2);
-            if (W > 3) o3 = K5_LDS_OR(a3 & smask4, m3);
+            o0 = K5_LDS_OR(swb + (a0 & smask4), m0);
+            if (W > 1) o1 = K5_LDS_OR(swb + (a1 & smask4), m1);
+            if (W > 2) o2 = K5_LDS_OR(swb + (a2 & smask4), m2);
+            if (W > 3) o3 = K5_LDS_OR(swb + (a3 & smask4), m3);
             K5_TWICE(a0, o0 & m0);
             if (W > 1) K5_TWICE(a1, o1 & m1);
             if (W > 2) K5_TWICE(a2, o2 & m2);
@@ -367,7 +370,7 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
           const bool c3 = nv > 3 && !has2(v.w) && has2(v.w - (1u << rb));
           if (c0 | c1 | c2 | c3) {
             uint32_t idx = atomicAdd(&ctrl[C_NCAND], (uint32_t)c0 + (uint32_t)c1 + (uint32_t)c2 + (uint32_t)c3);
-            if (idx + 4u <= (uint32_t)a.cand_cap) {
+            if (idx + 4u <= (uint32_t)cand_cap) {
               const uint16_t y16 = (uint16_t)(((ysn >> 12) & 0xFFF0u) | (ysn & 0xFu));
               if (c0) { candp[idx] = v.x; candy[idx++] = y16; }
               if (c1) { candp[idx] = v.y; candy[idx++] = y16; }
@@ -387,28 +390,31 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
           const uint32_t e0 = k5_lane_times(lane, W);
           // the four twice[] words unconditionally (no branch per entry slot; a lane's words past its own entries -- min(W, n - e0) of them --
           // belong to the next lane / list and are masked), the four answers as one bit mask
-          const uint32_t mine = e0 < s.n ? min(W, s.n - e0) : 0u;
+          const uint32_t mine = min(W, __builtin_elementwise_sub_sat(s.n, e0));
 #ifdef K5_ABL_B
           const uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = (sv[q].x ^ sv[q].y ^ sv[q].z ^ sv[q].w) == 0x12345678u;
 #else
-          const uint32_t t0 = *K5_LDS(((sv[q].x >> sh_a) & tmask4) | swb), t1 = *K5_LDS(((sv[q].y >> sh_a) & tmask4) | swb);
-          const uint32_t t2 = *K5_LDS(((sv[q].z >> sh_a) & tmask4) | swb), t3 = *K5_LDS(((sv[q].w >> sh_a) & tmask4) | swb);
+          const uint32_t t0 = *K5_LDS((sv[q].x >> sh_a) & tmask4), t1 = *K5_LDS((sv[q].y >> sh_a) & tmask4);
+          const uint32_t t2 = *K5_LDS((sv[q].z >> sh_a) & tmask4), t3 = *K5_LDS((sv[q].w >> sh_a) & tmask4);
 #endif
           const uint32_t hits = (__builtin_amdgcn_ubfe(t0, __builtin_amdgcn_ubfe(sv[q].x, sh_b, 5), 1) | (__builtin_amdgcn_ubfe(t1, __builtin_amdgcn_ubfe(sv[q].y, sh_b, 5), 1) << 1) |
                                  (__builtin_amdgcn_ubfe(t2, __builtin_amdgcn_ubfe(sv[q].z, sh_b, 5), 1) << 2) | (__builtin_amdgcn_ubfe(t3, __builtin_amdgcn_ubfe(sv[q].w, sh_b, 5), 1) << 3)) &
                                 ((1u << mine) - 1u);
-          const bool h0 = hits & 1u, h1 = hits & 2u, h2 = hits & 4u, h3 = hits & 8u;
           // one reservation per lane with hits (8 % of the entries are candidates: a dozen lanes per step add to the same LDS word, which the
           // LDS serialises in as many cycles -- cheaper than four ballots, their counts and a prefix per entry)
           const uint32_t cnt = (uint32_t)__popc(hits);
           if (cnt) {
-            uint32_t ci = atomicAdd(&ctrl[C_NCAND], cnt);
-            if (ci + cnt <= (uint32_t)a.cand_cap) {
-              const uint16_t y16 = (uint16_t)(((s.ysn >> 12) & 0xFFF0u) | (s.ysn & 0xFu));
-              if (h0) { candp[ci] = sv[q].x; candy[ci++] = y16; }
-              if (h1) { candp[ci] = sv[q].y; candy[ci++] = y16; }
-              if (h2) { candp[ci] = sv[q].z; candy[ci++] = y16; }
-              if (h3) { candp[ci] = sv[q].w; candy[ci++] = y16; }
+            const uint32_t ci = atomicAdd(&ctrl[C_NCAND], cnt);
+            if (ci + cnt <= (uint32_t)cand_cap) {
+              // slot k of a lane goes to ci + (hits below k): no running index (and no register copy) between the four predicated store pairs,
+              // the list's y / seed word in one register for all of them
+              uint32_t y16 = ((s.ysn >> 12) & 0xFFF0u) | (s.ysn & 0xFu);
+              asm volatile("" : "+v"(y16));
+              const uint32_t c1 = ci + (hits & 1u), c2 = ci + (uint32_t)__popc(hits & 3u), c3 = ci + (uint32_t)__popc(hits & 7u);
+              if (hits & 1u) { candp[ci] = sv[q].x; candy[ci] = (uint16_t)y16; }
+              if (hits & 2u) { candp[c1] = sv[q].y; candy[c1] = (uint16_t)y16; }
+              if (hits & 4u) { candp[c2] = sv[q].z; candy[c2] = (uint16_t)y16; }
+              if (hits & 8u) { candp[c3] = sv[q].w; candy[c3] = (uint16_t)y16; }
             }
           }
           gen(sd[q]); issue(sd[q], sv[q]);
@@ -753,7 +759,11 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   uint32_t* const fb_cnt_p = K.fb + K.fb_cap; uint32_t* const pl_cnt_p = K.pl + K.fb_cap;
   if (hipMemsetAsync(fb_cnt_p, 0, 4, stream) != hipSuccess || hipMemsetAsync(pl_cnt_p, 0, 4, stream) != hipSuccess) return GM_E_NODEVICE;
   static size_t configured = 0;
-  if (lds > 48 * 1024 && lds > configured) { if (hipFuncSetAttribute((const void*)k_lookup_v5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0; configured = lds; }
+  if (lds > 48 * 1024 && lds > configured) {
+    if (hipFuncSetAttribute((const void*)k_lookup_v5<15>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_lookup_v5<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
+    configured = lds;
+  }
   int grid = std::min(2 * n_reads, K.cus);
   if (const char* e = gm_tune("GM_K5_GRID")) grid = std::max(1, std::min(2 * n_reads, atoi(e)));
   K5Args a;
@@ -766,7 +776,8 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   const bool use_flags = g_k5_flags && grid <= g_k5_flag_cap;
   g_k5_flag_grid = use_flags ? grid : 0;
   a.start_flags = use_flags ? g_k5_flags : nullptr; a.start_epoch = g_k5_epoch;
-  hipLaunchKernelGGL(k_lookup_v5, dim3(grid), dim3(threads), lds, stream, ix, a);
+  if (lsw == 15) hipLaunchKernelGGL(k_lookup_v5<15>, dim3(grid), dim3(threads), lds, stream, ix, a);
+  else hipLaunchKernelGGL(k_lookup_v5<0>, dim3(grid), dim3(threads), lds, stream, ix, a);
   if (hipGetLastError() != hipSuccess) return GM_E_NODEVICE;
   *fb_list = K.fb; *fb_cnt = fb_cnt_p; *fb_cap_out = fb_cap; if (pl_list) *pl_list = K.pl; if (pl_cnt) *pl_cnt = pl_cnt_p;
   return 1;
