@@ -392,13 +392,16 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
           // belong to the next lane / list and are masked), the four answers as one bit mask
           const uint32_t mine = min(W, __builtin_elementwise_sub_sat(s.n, e0));
 #ifdef K5_ABL_B
-          const uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = (sv[q].x ^ sv[q].y ^ sv[q].z ^ sv[q].w) == 0x12345678u;
+          const uint32_t t0 = 0, t1 = 0, t2 = 0, b3 = ((sv[q].x ^ sv[q].y ^ sv[q].z ^ sv[q].w) == 0x12345678u) << 3;
 #else
           const uint32_t t0 = *K5_LDS((sv[q].x >> sh_a) & tmask4), t1 = *K5_LDS((sv[q].y >> sh_a) & tmask4);
-          const uint32_t t2 = *K5_LDS((sv[q].z >> sh_a) & tmask4), t3 = *K5_LDS((sv[q].w >> sh_a) & tmask4);
+          const uint32_t t2 = *K5_LDS((sv[q].z >> sh_a) & tmask4);
+          // (the fourth slot only in steps of more than 192 entries -- one wave-uniform branch; lists of the default seeds on 3 Gbp hold ~180)
+          uint32_t b3 = 0;
+          if (W > 3u) b3 = __builtin_amdgcn_ubfe(*K5_LDS((sv[q].w >> sh_a) & tmask4), __builtin_amdgcn_ubfe(sv[q].w, sh_b, 5), 1) << 3;
 #endif
           const uint32_t hits = (__builtin_amdgcn_ubfe(t0, __builtin_amdgcn_ubfe(sv[q].x, sh_b, 5), 1) | (__builtin_amdgcn_ubfe(t1, __builtin_amdgcn_ubfe(sv[q].y, sh_b, 5), 1) << 1) |
-                                 (__builtin_amdgcn_ubfe(t2, __builtin_amdgcn_ubfe(sv[q].z, sh_b, 5), 1) << 2) | (__builtin_amdgcn_ubfe(t3, __builtin_amdgcn_ubfe(sv[q].w, sh_b, 5), 1) << 3)) &
+                                 (__builtin_amdgcn_ubfe(t2, __builtin_amdgcn_ubfe(sv[q].z, sh_b, 5), 1) << 2) | b3) &
                                 ((1u << mine) - 1u);
           // one reservation per lane with hits (8 % of the entries are candidates: a dozen lanes per step add to the same LDS word, which the
           // LDS serialises in as many cycles -- cheaper than four ballots, their counts and a prefix per entry)
