@@ -283,10 +283,15 @@ int gm_map_pairs(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_
                  char **sam, size_t *sam_len, gm_map_stats_t *stats);
 /* Colour-space pairs (gmapper-cs -p <mode>; ref: handle_readpair mapping.c:2502-2636 with the colour-space branches of read_pass1_per_strand :1297-1319,
  * hit_run_full_sw :375-379 and hit_output output.c:353-355,441-451,485-537,572-580,717-730): mates as packed colours and one primer-letter byte per read, as
- * gm_map_reads_cs takes them, in all four pair modes (a mate the mode reverses keeps its colours and swaps its strand labels).  Quality values are refused: not implemented. */
+ * gm_map_reads_cs takes them, in all four pair modes (a mate the mode reverses keeps its colours and swaps its strand labels). */
 int gm_map_pairs_cs(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_packed, const uint8_t *initbp1, int len2, const uint32_t *mates2_packed,
                     const uint8_t *initbp2, const char *names1, const char *names2, const gm_pair_opts_t *opts,
                     char **sam, size_t *sam_len, gm_map_stats_t *stats);
+/* csfastq pairs: as gm_map_pairs_cs, plus one QV character per colour and mate ('\n' separated strings, offset qual_delta), used as gm_map_reads_cs_fastq uses them
+ * (per-position crossover scores in sw_full_cs, per-colour error rates in post_sw, QUAL = post_sw's base qualities, CQ:Z). */
+int gm_map_pairs_cs_fastq(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_packed, const uint8_t *initbp1, int len2, const uint32_t *mates2_packed,
+                          const uint8_t *initbp2, const char *names1, const char *names2, const char *quals1, const char *quals2, int qual_delta,
+                          const gm_pair_opts_t *opts, char **sam, size_t *sam_len, gm_map_stats_t *stats);
 /* FASTQ pairs: as gm_map_pairs, plus the mates' QUAL strings ('\n' separated) and the file's quality offset; the QUAL column is printed as
  * gm_map_reads_fastq prints it (mates keep their input orientation: read_reverse() leaves seq and qual alone, ref: gmapper.c:174-185). */
 int gm_map_pairs_fastq(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_packed, int len2, const uint32_t *mates2_packed,

@@ -104,7 +104,7 @@ class SwFullResults(C.Structure):   # struct gm_sw_full_results == the reference
 
 
 # every entry point include/gmapper_hip.h declares
-EXPORTS = ["gm_map_reads_file", "gm_merge_options_default", "gm_merge_sam", "gm_release_cache", "gm_map_pairs_cs", "gm_last_error", "gm_device_count", "gm_params_default", "gm_params_default_cs", "gm_index_build", "gm_index_free", "gm_index_list_cutoff",
+EXPORTS = ["gm_map_pairs_cs_fastq", "gm_map_reads_file", "gm_merge_options_default", "gm_merge_sam", "gm_release_cache", "gm_map_pairs_cs", "gm_last_error", "gm_device_count", "gm_params_default", "gm_params_default_cs", "gm_index_build", "gm_index_free", "gm_index_list_cutoff",
            "gm_index_save", "gm_index_load", "gm_index_bytes", "gm_index_n_slabs", "gm_index_has_buckets", "gm_index_get_list", "gm_index_device_array", "gm_index_meta", "gm_index_alloc_like",
            "sw_vector_setup", "sw_vector", "sw_vector_stats", "sw_vector_cleanup", "gm_sw_vector_batch",
            "sw_full_ls_setup", "sw_full_ls", "sw_full_ls_cleanup", "sw_full_ls_stats",
@@ -166,6 +166,8 @@ def lib():
                                      C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_map_pairs.argtypes = [vp, C.c_int, C.c_int, u32p, C.c_int, u32p, C.c_char_p, C.c_char_p, C.POINTER(PairOpts),
                                C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
+    L.gm_map_pairs_cs_fastq.argtypes = [vp, C.c_int, C.c_int, u32p, C.POINTER(C.c_uint8), C.c_int, u32p, C.POINTER(C.c_uint8), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int,
+                                        C.POINTER(PairOpts), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_map_reads_file.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_merge_options_default.argtypes = [C.POINTER(MergeOptions)]
     L.gm_merge_sam.argtypes = [C.POINTER(MergeOptions), C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
@@ -366,7 +368,7 @@ class Session:
         return out
 
     def map_pairs_cs(self, mates1: np.ndarray, mates2: np.ndarray, names1=None, names2=None, mode="opp-in", min_insert=0, max_insert=1000,
-                     opts: "PairOpts | None" = None) -> bytes:
+                     opts: "PairOpts | None" = None, quals1=None, quals2=None, qual_delta=33) -> bytes:
         """Colour-space pairs (gmapper-cs -p opp-in): mates as for map_reads_cs ([n, 1 + colours], column 0 the primer letter code)."""
         from .synth import pack_reads
         L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
@@ -378,8 +380,14 @@ class Session:
         join = lambda names: None if names is None else b"\n".join(x if isinstance(x, bytes) else x.encode() for x in names)
         o = opts if opts is not None else PairOpts.default(mode, min_insert, max_insert)
         u32p, u8p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
-        _check(L.gm_map_pairs_cs(self.h, m1.shape[0], m1.shape[1] - 1, p1.ctypes.data_as(u32p), ib1.ctypes.data_as(u8p), m2.shape[1] - 1, p2.ctypes.data_as(u32p),
-                                 ib2.ctypes.data_as(u8p), join(names1), join(names2), C.byref(o), C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_pairs_cs")
+        if quals1 is not None:
+            jq = lambda q: b"\n".join(bytes(np.ascontiguousarray(r, dtype=np.uint8)) for r in q)
+            _check(L.gm_map_pairs_cs_fastq(self.h, m1.shape[0], m1.shape[1] - 1, p1.ctypes.data_as(u32p), ib1.ctypes.data_as(u8p), m2.shape[1] - 1, p2.ctypes.data_as(u32p),
+                                           ib2.ctypes.data_as(u8p), join(names1), join(names2), jq(quals1), jq(quals2), int(qual_delta), C.byref(o), C.byref(sam), C.byref(sl),
+                                           C.byref(st)), "gm_map_pairs_cs_fastq")
+        else:
+            _check(L.gm_map_pairs_cs(self.h, m1.shape[0], m1.shape[1] - 1, p1.ctypes.data_as(u32p), ib1.ctypes.data_as(u8p), m2.shape[1] - 1, p2.ctypes.data_as(u32p),
+                                     ib2.ctypes.data_as(u8p), join(names1), join(names2), C.byref(o), C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_pairs_cs")
         out = C.string_at(sam, sl.value) if sam.value else b""
         if sam.value: L.gm_free(sam)
         self.stats = st.as_dict()

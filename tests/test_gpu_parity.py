@@ -923,3 +923,21 @@ def test_output_formats_match_reference_golden(gm, tag):
     head = b"#FORMAT: readname contigname strand contigstart contigend readstart readend readlength score editstring" + (b" readsequence" if fields.get("print_read_seq") else b"") + b"\n"
     got = head + body
     assert got == want, _first_diff(got, want)
+
+
+@pytest.mark.parametrize("mode", ["opp-in", "col-bw"])
+def test_colour_space_fastq_pairs_match_reference_golden(gm, mode):
+    """csfastq pairs (gm_map_pairs_cs_fastq): QV-dependent crossover scores and post_sw error rates for both mates, QUAL = post_sw's base qualities, CQ:Z in every
+    record kind -- the reference's gmapper-cs -p <mode> on a csfastq file, opp-in and a mode that reverses a mate"""
+    import gzip
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    g = oa.load_golden_pairs("cs_pairs_50col_" + mode); zq = np.load(os.path.join(G, "cs_pairs_fq_%s.npz" % mode)); N = int(zq["n_pairs"])
+    want = gzip.open(os.path.join(G, "cs_pairs_fq_%s.sam.gz" % mode), "rb").read()
+    p = gm.default_params_cs(); p.sam_unaligned = 1
+    ix = gm.Index(g["contigs"], names=g["contig_names"], params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_cs(g["m1"][:N], g["m2"][:N], list(g["names1"][:N]), list(g["names2"][:N]), mode=mode,
+                                                                          min_insert=g["ins"][0], max_insert=g["ins"][1], quals1=zq["quals1"], quals2=zq["quals2"],
+                                                                          qual_delta=int(zq["qual_delta"]))
+    st = s.stats
+    s.close(); ix.close()
+    assert got == want, (_first_diff(got, want), st)

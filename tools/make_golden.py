@@ -520,6 +520,36 @@ def file_cases():
         print("file_cs_mixed:", sum(1 for l in sam.split(b"\n") if l and not l.startswith(b"@")), "records")
 
 
+def cs_paired_fastq_cases():
+    """csfastq pairs (PHRED+33) through gmapper-cs -p <mode>: QV-dependent crossover scores and post_sw error rates for both mates, QUAL / CQ:Z in paired, half-paired
+    and unaligned records; opp-in and a mode that reverses a mate (col-bw)"""
+    for mode in ("opp-in", "col-bw"):
+        z = np.load(os.path.join(OUT, "cs_pairs_50col_%s.npz" % mode))
+        contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
+        cn = [bytes(x) for x in z["contig_names"]]
+        N = 300
+        m1, m2 = z["mates1"][:N], z["mates2"][:N]; n1 = [bytes(x) for x in z["names1"]][:N]; n2 = [bytes(x) for x in z["names2"]][:N]
+        rng = np.random.default_rng(31)
+        q1 = (rng.integers(2, 36, size=(N, m1.shape[1] - 1)) + 33).astype(np.uint8); q2 = (rng.integers(2, 36, size=(N, m2.shape[1] - 1)) + 33).astype(np.uint8)
+        tab = np.full(16, ord("."), dtype=np.uint8); tab[:4] = np.frombuffer(b"0123", dtype=np.uint8)
+        with tempfile.TemporaryDirectory() as d:
+            g = os.path.join(d, "g.fa"); r = os.path.join(d, "r.csfastq")
+            write_fa_codes(g, cn, contigs)
+            with open(r, "wb") as f:
+                for i in range(N):
+                    for nm, row, q in ((n1[i], m1[i], q1[i]), (n2[i], m2[i], q2[i])):
+                        f.write(b"@" + nm + b"\n" + b"ACGT"[row[0]:row[0] + 1] + tab[row[1:]].tobytes() + b"\n+\n" + q.tobytes() + b"\n")
+            p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "gmapper-cs"), "-N", "4", "--sam-unaligned", "-p", mode, "-I", "%d,%d" % tuple(int(x) for x in z["ins"]), r, g],
+                               capture_output=True)
+            if p.returncode != 0:
+                print(p.stderr.decode()[-1500:]); raise SystemExit(1)
+            body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+        np.savez_compressed(os.path.join(OUT, "cs_pairs_fq_%s.npz" % mode), quals1=q1, quals2=q2, n_pairs=np.array(N), qual_delta=np.array(33))
+        with gzip.open(os.path.join(OUT, "cs_pairs_fq_%s.sam.gz" % mode), "wb", compresslevel=9) as f:
+            f.write(body)
+        print("cs_pairs_fq_%s: %d SAM records" % (mode, sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@"))))
+
+
 FORMAT_CASES = {
     # tag: (base golden, program, options): the reference's SHRiMP-format / pretty output, whole (its #FORMAT line included)
     "fmt_shrimp": ("stress_60bp", "gmapper-ls", ["--shrimp-format"]),
@@ -562,7 +592,9 @@ def format_cases():
 
 
 if __name__ == "__main__":
-    if "--format-only" in sys.argv:
+    if "--cs-pairs-fq-only" in sys.argv:
+        os.makedirs(OUT, exist_ok=True); cs_paired_fastq_cases()
+    elif "--format-only" in sys.argv:
         os.makedirs(OUT, exist_ok=True); format_cases()
     elif "--file-only" in sys.argv:
         os.makedirs(OUT, exist_ok=True); file_cases()
