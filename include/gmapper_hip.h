@@ -287,6 +287,10 @@ int gm_map_pairs(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_
 int gm_map_pairs_cs(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_packed, const uint8_t *initbp1, int len2, const uint32_t *mates2_packed,
                     const uint8_t *initbp2, const char *names1, const char *names2, const gm_pair_opts_t *opts,
                     char **sam, size_t *sam_len, gm_map_stats_t *stats);
+/* Paired reads from files: `path2` NULL = one file with the mates adjacent, else mate 1 from path1 and mate 2 from path2 (gmapper's -1 / -2; ref: gmapper.c:363-620).
+ * Formats and rules as gm_map_reads_file; pairs of any mix of lengths; a pair with a mate beyond longest_read_len is dropped whole.  Letter or colour space by the session. */
+int gm_map_pairs_file(gm_session_t *s, const char *path1, const char *path2, int fastq, int qual_delta, const gm_pair_opts_t *opts,
+                      char **sam, size_t *sam_len, gm_map_stats_t *stats);
 /* csfastq pairs: as gm_map_pairs_cs, plus one QV character per colour and mate ('\n' separated strings, offset qual_delta), used as gm_map_reads_cs_fastq uses them
  * (per-position crossover scores in sw_full_cs, per-colour error rates in post_sw, QUAL = post_sw's base qualities, CQ:Z). */
 int gm_map_pairs_cs_fastq(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_packed, const uint8_t *initbp1, int len2, const uint32_t *mates2_packed,

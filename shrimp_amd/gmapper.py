@@ -104,7 +104,7 @@ class SwFullResults(C.Structure):   # struct gm_sw_full_results == the reference
 
 
 # every entry point include/gmapper_hip.h declares
-EXPORTS = ["gm_map_pairs_cs_fastq", "gm_map_reads_file", "gm_merge_options_default", "gm_merge_sam", "gm_release_cache", "gm_map_pairs_cs", "gm_last_error", "gm_device_count", "gm_params_default", "gm_params_default_cs", "gm_index_build", "gm_index_free", "gm_index_list_cutoff",
+EXPORTS = ["gm_map_pairs_file", "gm_map_pairs_cs_fastq", "gm_map_reads_file", "gm_merge_options_default", "gm_merge_sam", "gm_release_cache", "gm_map_pairs_cs", "gm_last_error", "gm_device_count", "gm_params_default", "gm_params_default_cs", "gm_index_build", "gm_index_free", "gm_index_list_cutoff",
            "gm_index_save", "gm_index_load", "gm_index_bytes", "gm_index_n_slabs", "gm_index_has_buckets", "gm_index_get_list", "gm_index_device_array", "gm_index_meta", "gm_index_alloc_like",
            "sw_vector_setup", "sw_vector", "sw_vector_stats", "sw_vector_cleanup", "gm_sw_vector_batch",
            "sw_full_ls_setup", "sw_full_ls", "sw_full_ls_cleanup", "sw_full_ls_stats",
@@ -168,6 +168,7 @@ def lib():
                                C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_map_pairs_cs_fastq.argtypes = [vp, C.c_int, C.c_int, u32p, C.POINTER(C.c_uint8), C.c_int, u32p, C.POINTER(C.c_uint8), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int,
                                         C.POINTER(PairOpts), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
+    L.gm_map_pairs_file.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(PairOpts), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_map_reads_file.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(MapStats)]
     L.gm_merge_options_default.argtypes = [C.POINTER(MergeOptions)]
     L.gm_merge_sam.argtypes = [C.POINTER(MergeOptions), C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
@@ -362,6 +363,18 @@ class Session:
         L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
         qd = qual_delta if qual_delta is not None else (33 if self.params.colour_space else 64)      # gmapper-defaults.h:41-42
         _check(L.gm_map_reads_file(self.h, os.fsencode(path), int(fastq), int(qd), C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_reads_file")
+        out = C.string_at(sam, sl.value) if sam.value else b""
+        if sam.value: L.gm_free(sam)
+        self.stats = st.as_dict()
+        return out
+
+    def map_pairs_file(self, path1, path2=None, fastq=-1, qual_delta=None, mode="opp-in", min_insert=0, max_insert=1000, opts: "PairOpts | None" = None) -> bytes:
+        """Pairs from one file (mates adjacent) or two (-1 / -2): FASTA / FASTQ, plain or gzip, any mix of lengths (gm_map_pairs_file)."""
+        L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
+        qd = qual_delta if qual_delta is not None else (33 if self.params.colour_space else 64)
+        o = opts if opts is not None else PairOpts.default(mode, min_insert, max_insert)
+        _check(L.gm_map_pairs_file(self.h, os.fsencode(path1), None if path2 is None else os.fsencode(path2), int(fastq), int(qd), C.byref(o),
+                                   C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_pairs_file")
         out = C.string_at(sam, sl.value) if sam.value else b""
         if sam.value: L.gm_free(sam)
         self.stats = st.as_dict()

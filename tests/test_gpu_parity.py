@@ -941,3 +941,25 @@ def test_colour_space_fastq_pairs_match_reference_golden(gm, mode):
     st = s.stats
     s.close(); ix.close()
     assert got == want, (_first_diff(got, want), st)
+
+
+@pytest.mark.parametrize("case", ["two_fastq_gz", "interleaved_fasta"])
+def test_pair_files_match_reference_golden(gm, case, tmp_path):
+    """gm_map_pairs_file: `gmapper -1 a.fq.gz -2 b.fq.gz` (PHRED+33, mates cut to a mix of lengths) and one FASTA file with the mates adjacent -- the files the
+    reference read, records in file order"""
+    import gzip
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    g = oa.load_golden_pairs("stress_pairs_2x100")
+    p = gm.default_params(); p.sam_unaligned = 1
+    ix = gm.Index(g["contigs"], names=g["contig_names"], params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+    if case == "two_fastq_gz":
+        want = gzip.open(os.path.join(G, "file_pairs_12.sam.gz"), "rb").read()
+        body = s.map_pairs_file(os.path.join(G, "file_pairs_1.fq.gz"), os.path.join(G, "file_pairs_2.fq.gz"), qual_delta=33, mode=g["mode"], min_insert=g["ins"][0], max_insert=g["ins"][1])
+    else:
+        want = gzip.open(os.path.join(G, "file_pairs_il.sam.gz"), "rb").read()
+        path = str(tmp_path / "il.fa"); open(path, "wb").write(gzip.open(os.path.join(G, "file_pairs_il.fa.gz"), "rb").read())
+        body = s.map_pairs_file(path, mode=g["mode"], min_insert=g["ins"][0], max_insert=g["ins"][1])
+    st = s.stats
+    s.close(); ix.close()
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + body
+    assert got == want, (_first_diff(got, want), st)

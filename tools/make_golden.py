@@ -550,6 +550,36 @@ def cs_paired_fastq_cases():
         print("cs_pairs_fq_%s: %d SAM records" % (mode, sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@"))))
 
 
+def pair_file_cases():
+    """paired file input: (1) gmapper -1 a.fq.gz -2 b.fq.gz, PHRED+33, mates cut to a mix of lengths; (2) one FASTA file with the mates adjacent (folded lines,
+    comments).  Fixtures: the files themselves + the reference's SAM."""
+    z = np.load(os.path.join(OUT, "stress_pairs_2x100.npz"))
+    contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
+    cn = [bytes(x) for x in z["contig_names"]]
+    N = 360; m1, m2 = z["mates1"][:N], z["mates2"][:N]
+    rng = np.random.default_rng(77); T = np.frombuffer(b"ACGTUMRWSYKVHDBN", dtype=np.uint8)
+    l1 = rng.choice([100, 80, 64], size=N); l2 = rng.choice([100, 60], size=N)
+    ins = tuple(int(x) for x in z["ins"])
+    with tempfile.TemporaryDirectory() as d:
+        g = os.path.join(d, "g.fa"); write_fa_codes(g, cn, contigs)
+        a = bytearray(); b = bytearray(); il = bytearray(b"# pairs, mates adjacent\n")
+        for i in range(N):
+            s1 = T[m1[i][:l1[i]]].tobytes(); s2 = T[m2[i][100 - l2[i]:]].tobytes()     # mate 2 keeps its 3' part, so that the pair still spans the insert
+            q1 = bytes((rng.integers(2, 40, l1[i]) + 33).astype(np.uint8)); q2 = bytes((rng.integers(2, 40, l2[i]) + 33).astype(np.uint8))
+            a += b"@q%d/1 first mate\n" % i + s1 + b"\n+\n" + q1 + b"\n"; b += b"@q%d/2\n" % i + s2 + b"\n+\n" + q2 + b"\n"
+            il += b">q%d/1\n" % i + s1[:50] + b"\n" + s1[50:] + b"\n>q%d/2 desc\n" % i + s2 + b"\n"
+        with gzip.open(os.path.join(d, "a.fq.gz"), "wb") as f: f.write(bytes(a))
+        with gzip.open(os.path.join(d, "b.fq.gz"), "wb") as f: f.write(bytes(b))
+        open(os.path.join(d, "il.fa"), "wb").write(bytes(il))
+        run = lambda args: b"".join(l + b"\n" for l in subprocess.run([REF, "-N", "4", "--sam-unaligned", "-p", str(z["mode"]), "-I", "%d,%d" % ins, *args, g],
+                                                                        capture_output=True, check=True).stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+        sam12 = run(["--qv-offset", "33", "-1", os.path.join(d, "a.fq.gz"), "-2", os.path.join(d, "b.fq.gz")])
+        samil = run([os.path.join(d, "il.fa")])
+    for nm, data in (("file_pairs_1.fq.gz", bytes(a)), ("file_pairs_2.fq.gz", bytes(b)), ("file_pairs_il.fa.gz", bytes(il)), ("file_pairs_12.sam.gz", sam12), ("file_pairs_il.sam.gz", samil)):
+        with gzip.open(os.path.join(OUT, nm), "wb", compresslevel=9) as f: f.write(data)
+    print("file_pairs_12:", sum(1 for l in sam12.split(b"\n") if l and not l.startswith(b"@")), "records; file_pairs_il:", sum(1 for l in samil.split(b"\n") if l and not l.startswith(b"@")))
+
+
 FORMAT_CASES = {
     # tag: (base golden, program, options): the reference's SHRiMP-format / pretty output, whole (its #FORMAT line included)
     "fmt_shrimp": ("stress_60bp", "gmapper-ls", ["--shrimp-format"]),
@@ -592,7 +622,9 @@ def format_cases():
 
 
 if __name__ == "__main__":
-    if "--cs-pairs-fq-only" in sys.argv:
+    if "--pair-file-only" in sys.argv:
+        os.makedirs(OUT, exist_ok=True); pair_file_cases()
+    elif "--cs-pairs-fq-only" in sys.argv:
         os.makedirs(OUT, exist_ok=True); cs_paired_fastq_cases()
     elif "--format-only" in sys.argv:
         os.makedirs(OUT, exist_ok=True); format_cases()
