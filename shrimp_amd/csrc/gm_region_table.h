@@ -14,8 +14,11 @@
 #define K5_FC 4u
 #define K5_FD 8u
 #define K5_FE 16u
-__device__ __forceinline__ uint32_t k5_hash(uint32_t r1, int hshift) { return (r1 * 2654435761u) >> hshift; }
-__device__ __forceinline__ uint32_t k5_step(uint32_t r1) { return ((r1 * 0x9E3779B1u) >> 15) | 1u; }      // odd: the probe sequence h, h + step, ... visits every slot (double hashing: no primary clustering)
+// (region + 1 < 2^24 -- positions are 32 bits, regions hold at least 2^9 of them -- so both products are 24 x 24 bits: v_mul_u32_u24 is a full-rate instruction, the 32-bit
+// v_mul_lo_u32 takes four times as long, and an insert or a find needs two of them)
+__device__ __forceinline__ uint32_t k5_mul24(uint32_t a, uint32_t c) { uint32_t r; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(c)); return r; }
+__device__ __forceinline__ uint32_t k5_hash(uint32_t r1, int hshift) { return k5_mul24(r1, 0x9E3779u) >> hshift; }
+__device__ __forceinline__ uint32_t k5_step(uint32_t r1) { return (k5_mul24(r1, 0x7FEB35u) >> 7) | 1u; }      // odd: the probe sequence h, h + step, ... visits every slot (double hashing: no primary clustering)
 
 // returns the slot of region r (claiming one if needed) after OR-ing `first` into a fresh slot / `again` bookkeeping into an existing one; 0xFFFFFFFF: table full
 __device__ __forceinline__ uint32_t k5_insert(uint32_t* htag, uint32_t hmask, int hshift, uint32_t r, bool own) {
