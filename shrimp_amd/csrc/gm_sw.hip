@@ -422,27 +422,35 @@ __device__ FullOut full_sw_wave(const uint8_t* db, int glen, const uint8_t* qr, 
   FullOut out; out.score = 0; out.max_i = 0; out.max_j = 0; out.e_nw = out.e_n = out.e_w = 0;
   const int n_stripes = (rlen + 63) >> 6;
   int* cNW = carry; int* cN = carry + glen; int* cW = carry + 2 * glen;   // last row of the previous stripe, per column
+  int cw_lo = 1, cw_hi = 0;                                    // columns of the carry rows the previous stripe wrote (the others read as out-of-band cells)
   for (int s = 0; s < n_stripes; s++) {
     const int r = s * 64 + lane;
     const bool row_ok = r < rlen;
     const int q = row_ok ? qr[r] : 0x7F;
     int x_min = 0, x_max = -1;
     if (row_ok) band_range(rx, ry, rl, rw, glen, r, &x_min, &x_max);
-    const int rows = min(64, rlen - s * 64);
-    const int steps = glen + rows - 1;
+    // Only the steps at which some lane stands inside the band: the band is a strip along the diagonal (the anchor box widened by anchor_width), so
+    // column t - lane is inside it for t in [min(x_min + lane), max(x_max + lane)] -- ~150 of the glen + rows - 1 ~ 200 steps of a 100 bp read.  Before
+    // and after, every lane holds the constants of an out-of-band cell: nothing to compute.
+    int t_lo = INT_MAX, t_hi = -1;
+    if (row_ok && x_max >= x_min) { t_lo = x_min + lane; t_hi = x_max + lane; }
+    for (int dd = 32; dd > 0; dd >>= 1) { t_lo = min(t_lo, __shfl_xor(t_lo, dd)); t_hi = max(t_hi, __shfl_xor(t_hi, dd)); }
     // own previous cell (r, c-1) and the two cells of row r-1 needed next: (r-1, c) arrives by shift
     int pw_nw = o_nw, pw_n = o_n, pw_w = o_w;                  // cell_w  = (r, c-1); column -1 is out of band
     int d_nw = o_nw, d_n = o_n, d_w = o_w;                     // cell_nw = (r-1, c-1)
     int cur_nw = o_nw, cur_n = o_n, cur_w = o_w;               // this lane's latest cell, shifted to lane+1 next step
-    if (s == 0 && lane == 0) { d_nw = 0; d_n = -b_go; d_w = -a_go; }   // virtual row -1, column -1
+    if (lane == 0) {
+      if (s == 0) { d_nw = 0; d_n = -b_go; d_w = -a_go; }      // virtual row -1 (every column of it, -1 included)
+      else if (t_hi >= 0 && t_lo >= 1 && t_lo - 1 >= cw_lo && t_lo - 1 <= cw_hi) { d_nw = cNW[t_lo - 1]; d_n = cN[t_lo - 1]; d_w = cW[t_lo - 1]; }   // (r-1, t_lo-1) of the previous stripe's last row
+    }
     const bool more = (s + 1 < n_stripes);
     const bool last_row_lane = row_ok && (r == rlen - 1);
-    for (int t = 0; t < steps; t++) {
+    for (int t = t_lo; t <= t_hi; t++) {
       const int c = t - lane;
       // lane 0's upper neighbour at column t: virtual row (stripe 0) or carry from the previous stripe
       int in_nw, in_n, in_w;
       if (s == 0) { in_nw = 0; in_n = -b_go; in_w = -a_go; }
-      else { const int cc = min(t, glen - 1); in_nw = cNW[cc]; in_n = cN[cc]; in_w = cW[cc]; if (t >= glen) { in_nw = o_nw; in_n = o_n; in_w = o_w; } }
+      else { in_nw = o_nw; in_n = o_n; in_w = o_w; if (t >= cw_lo && t <= cw_hi) { in_nw = cNW[t]; in_n = cN[t]; in_w = cW[t]; } }
       const int u_nw = shr1_i(cur_nw, in_nw), u_n = shr1_i(cur_n, in_n), u_w = shr1_i(cur_w, in_w);   // cell_n = (r-1, c)
       const bool inband = row_ok && c >= x_min && c <= x_max;
       int n_nw = o_nw, n_n = o_n, n_w = o_w;
@@ -491,6 +499,8 @@ __device__ FullOut full_sw_wave(const uint8_t* db, int glen, const uint8_t* qr, 
       cur_nw = n_nw; cur_n = n_n; cur_w = n_w;
       (void)pw_n;
     }
+    cw_lo = 1; cw_hi = 0;
+    if (more && t_hi >= 0) { cw_lo = max(0, t_lo - 63); cw_hi = min(glen - 1, t_hi - 63); }
     if (more) __syncthreads();
   }
   // broadcast the result: from the last row's lane, or (local) from the lane whose row comes first among those with the largest score
@@ -871,18 +881,27 @@ k_sw_vector_batch_cs(GmScoreDev sc, int n, const uint32_t* __restrict__ genome_c
 }
 
 struct GmCsDev { int match, mismatch, xover, a_go, a_ge, b_go, b_ge, anchor_width, taboo; };
+#ifdef GM_BAND_DEBUG
+__device__ unsigned long long g_band_dbg[8];
+extern "C" int gm_debug_band(unsigned long long* out) { unsigned long long z[8] = {0}; if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_band_dbg), sizeof z) != hipSuccess) return -1; return hipMemcpyToSymbol(HIP_SYMBOL(g_band_dbg), z, sizeof z) == hipSuccess ? 0 : -1; }
+#endif
 
 // sw_full_cs (ref: common/sw-full-cs.c:249-623): lane = read row, column t - lane at step t, twelve running values per cell
 // (4 layers x {nw, n, w}); what row r needs from row r - 1 arrives by DPP shifts.  back[cell] = three words of four codes
 // (dir << 2 | layer) for the nw / n / w states of the four layers.  Out-of-band cells are -INT_MAX/2 as init_cell(.., 0, ..) leaves them.
 struct CsBest { int score, i, j, k, e_nw, e_n, e_w; };
 // xrow: per-position crossover scores of this read (from its QVs, ref: gmapper.c:532-544) or null = the global one everywhere
-__device__ CsBest full_sw_cs_wave(const uint8_t* db, int glen, const uint8_t* qr4, int qstride, int rlen, const GmCsDev& P, bool revcmpl,
-                                  long long rx, long long ry, int rl, int rw, uint32_t* back, int* carry, int lane, const int8_t* xrow = nullptr) {
+// REV / TABOO as template constants: the tie rules of a reverse-strand window and the indel-taboo tests sit inside every one of the 36 state updates of
+// a step; as run-time values they became a uniform branch (with its register copies) each -- two thirds of the step's scalar instructions.
+template <bool REV, bool TABOO>
+__device__ CsBest full_sw_cs_wave_t(const uint8_t* db, int glen, const uint8_t* qr4, int qstride, int rlen, const GmCsDev& P,
+                                    long long rx, long long ry, int rl, int rw, uint32_t* back, int* carry, int lane, const int8_t* xrow = nullptr) {
+  constexpr bool revcmpl = REV;
   CsBest best; best.score = 0; best.i = best.j = best.k = 0; best.e_nw = best.e_n = best.e_w = 0;
   const int xg = P.xover;                                 // global_xover_penalty: the virtual row above the matrix (ref: sw-full-cs.c:270)
   int xo = xg;
   const int n_stripes = (rlen + 63) >> 6;
+  int cw_lo = 1, cw_hi = 0;                              // columns of the carry rows the previous stripe wrote
   for (int s = 0; s < n_stripes; s++) {
     const int r = s * 64 + lane;
     const bool row_ok = r < rlen;
@@ -892,28 +911,42 @@ __device__ CsBest full_sw_cs_wave(const uint8_t* db, int glen, const uint8_t* qr
     for (int k = 0; k < 4; k++) q[k] = row_ok ? qr4[k * qstride + r] : 0x7F;
     int x_min = 0, x_max = -1;
     if (row_ok) band_range(rx, ry, rl, rw, glen, r, &x_min, &x_max);
-    const bool notaboo = r < rlen - P.taboo;
-    const int rows = min(64, rlen - s * 64);
-    const int steps = glen + rows - 1;
+    const bool notaboo = TABOO ? r < rlen - P.taboo : true;
+    // only the steps at which some lane stands inside the band (see full_sw_wave)
+    int t_lo = INT_MAX, t_hi = -1;
+    if (row_ok && x_max >= x_min) { t_lo = x_min + lane; t_hi = x_max + lane; }
+    for (int dd = 32; dd > 0; dd >>= 1) { t_lo = min(t_lo, __shfl_xor(t_lo, dd)); t_hi = max(t_hi, __shfl_xor(t_hi, dd)); }
+#ifdef GM_BAND_DEBUG
+    if (lane == 0) { atomicAdd(&g_band_dbg[0], (unsigned long long)(glen + min(64, rlen - s * 64) - 1)); atomicAdd(&g_band_dbg[1], (unsigned long long)max(0, t_hi - t_lo + 1)); atomicAdd(&g_band_dbg[2], 1ull);
+                     atomicAdd(&g_band_dbg[3], (unsigned long long)rw); atomicAdd(&g_band_dbg[4], (unsigned long long)rl); }
+#endif
     int pw[12], d[12], cur[12];                      // (r, c-1), (r-1, c-1), this lane's latest cell; index = layer * 3 + {0 nw, 1 n, 2 w}
 #pragma unroll
     for (int x = 0; x < 12; x++) { pw[x] = FS_NEG; d[x] = FS_NEG; cur[x] = FS_NEG; }
-    if (s == 0 && lane == 0) {                       // virtual row -1, column -1: init_cell(.., 1, xover), ref :201-215
+    if (lane == 0) {
+      if (s == 0) {                                  // virtual row -1 (every column of it, -1 included): init_cell(.., 1, xover), ref :201-215
 #pragma unroll
-      for (int k = 0; k < 4; k++) { const int x = k ? xg : 0; d[k * 3] = x; d[k * 3 + 1] = -P.b_go + x; d[k * 3 + 2] = -P.a_go + x; }
+        for (int k = 0; k < 4; k++) { const int x = k ? xg : 0; d[k * 3] = x; d[k * 3 + 1] = -P.b_go + x; d[k * 3 + 2] = -P.a_go + x; }
+      } else if (t_hi >= 0 && t_lo >= 1 && t_lo - 1 >= cw_lo && t_lo - 1 <= cw_hi) {   // (r-1, t_lo-1) of the previous stripe's last row
+#pragma unroll
+        for (int x = 0; x < 12; x++) d[x] = carry[x * glen + t_lo - 1];
+      }
     }
     const bool more = (s + 1 < n_stripes);
     const bool last_row_lane = row_ok && (r == rlen - 1);
-    for (int t = 0; t < steps; t++) {
+    for (int t = t_lo; t <= t_hi; t++) {
       const int c = t - lane;
-      int u[12];
+      int u[12], inv[12];
+      // lane 0's upper neighbour: the virtual row (stripe 0: constants, no memory access at all), or the previous stripe's last row -- one wave-uniform
+      // branch around the twelve loads (per-value conditions cost a masked load and a wait each, every step, also in the single-stripe case)
 #pragma unroll
-      for (int x = 0; x < 12; x++) {
-        int in;
-        if (s == 0) { const int k = x / 3, st = x % 3; const int xv = k ? xg : 0; in = (st == 0 ? 0 : (st == 1 ? -P.b_go : -P.a_go)) + xv; }
-        else in = (t < glen) ? carry[x * glen + t] : FS_NEG;
-        u[x] = shr1_i(cur[x], in);                    // cell (r-1, c)
+      for (int x = 0; x < 12; x++) { const int k = x / 3, st = x % 3; const int xv = k ? xg : 0; inv[x] = s == 0 ? (st == 0 ? 0 : (st == 1 ? -P.b_go : -P.a_go)) + xv : FS_NEG; }
+      if (__builtin_amdgcn_readfirstlane((int)(s > 0 && t >= cw_lo && t <= cw_hi))) {
+#pragma unroll
+        for (int x = 0; x < 12; x++) inv[x] = carry[x * glen + t];
       }
+#pragma unroll
+      for (int x = 0; x < 12; x++) u[x] = shr1_i(cur[x], inv[x]);   // cell (r-1, c)
       const bool inband = row_ok && c >= x_min && c <= x_max;
       int nv[12];
 #pragma unroll
@@ -994,12 +1027,20 @@ __device__ CsBest full_sw_cs_wave(const uint8_t* db, int glen, const uint8_t* qr
 #pragma unroll
       for (int x = 0; x < 12; x++) { d[x] = u[x]; pw[x] = nv[x]; cur[x] = nv[x]; }
     }
+    cw_lo = 1; cw_hi = 0;
+    if (more && t_hi >= 0) { cw_lo = max(0, t_lo - 63); cw_hi = min(glen - 1, t_hi - 63); }
     if (more) __syncthreads();
   }
   const int src = (rlen - 1) & 63;
   best.score = __shfl(best.score, src); best.i = __shfl(best.i, src); best.j = __shfl(best.j, src); best.k = __shfl(best.k, src);
   best.e_nw = __shfl(best.e_nw, src); best.e_n = __shfl(best.e_n, src); best.e_w = __shfl(best.e_w, src);
   return best;
+}
+template <bool TABOO>
+__device__ CsBest full_sw_cs_wave(const uint8_t* db, int glen, const uint8_t* qr4, int qstride, int rlen, const GmCsDev& P, bool revcmpl,
+                                  long long rx, long long ry, int rl, int rw, uint32_t* back, int* carry, int lane, const int8_t* xrow = nullptr) {
+  return revcmpl ? full_sw_cs_wave_t<true, TABOO>(db, glen, qr4, qstride, rlen, P, rx, ry, rl, rw, back, carry, lane, xrow)
+                 : full_sw_cs_wave_t<false, TABOO>(db, glen, qr4, qstride, rlen, P, rx, ry, rl, rw, back, carry, lane, xrow);
 }
 
 // out[0..11] = score read_start rmapped genome_start gmapped matches mismatches insertions deletions crossovers n_ops 0;
@@ -1035,7 +1076,7 @@ k_sw_full_cs_single(GmCsDev P, const uint32_t* __restrict__ genome_ls, long long
   if ((se - nw) % 2 != 0) se++;
   int rl = (int)((se - nw) / 2 + 1);
   rx -= P.anchor_width / 2; ry += P.anchor_width / 2; rw += P.anchor_width;
-  const CsBest fo = full_sw_cs_wave(db, glen, qr4, qstride, rlen, P, revcmpl != 0, rx, ry, rl, rw, back, carry, lane);
+  const CsBest fo = full_sw_cs_wave<true>(db, glen, qr4, qstride, rlen, P, revcmpl != 0, rx, ry, rl, rw, back, carry, lane);
   __syncthreads();
   __threadfence();
   if (lane == 0) {
@@ -1085,7 +1126,8 @@ k_sw_full_cs_single(GmCsDev P, const uint32_t* __restrict__ genome_ls, long long
 // the two 4-bit codes it prints (ops[ops_stride/2 ..): genome letter << 4 | read letter), enough to rebuild dbalign / qralign
 // (ref :945-1060) without the genome.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(GM_WAVE)
+template <bool TABOO>                               // indel_taboo_len > 0 (a session constant): the taboo tests compiled in
+__global__ void __launch_bounds__(GM_WAVE, 2)       // two waves per SIMD: at most 256 registers (the straight-line variants would take 286 and halve the occupancy)
 k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__ reads, const uint8_t* __restrict__ initbp, int n_reads, int read_len,
            int read_words, const GmHit* __restrict__ hits, int hcap, const int32_t* __restrict__ sel,
            const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work_p, GmFullRes* __restrict__ res, uint8_t* __restrict__ ops, int ops_stride,
@@ -1154,7 +1196,7 @@ k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__
     int rl = (int)((se - nw) / 2 + 1);
     rx -= P.anchor_width / 2; ry += P.anchor_width / 2; rw += P.anchor_width;
     fcalls++; fcells += (unsigned long long)w_len * read_len;
-    const CsBest fo = full_sw_cs_wave(db, w_len, qr4, qstride, read_len, P, (gen_st != 0) && sc.tiebreak_rev, rx, ry, rl, rw, back, carry, lane,
+    const CsBest fo = full_sw_cs_wave<TABOO>(db, w_len, qr4, qstride, read_len, P, (gen_st != 0) && sc.tiebreak_rev, rx, ry, rl, rw, back, carry, lane,
                                       xover ? xover + (size_t)rd * read_len : nullptr);
     __syncthreads();
     __threadfence();
@@ -1211,8 +1253,14 @@ int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs
   const size_t lds = 5 * (size_t)((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 48 + 64;
   if (lds > 160 * 1024) { gm_set_error("colour-space pass 2: window of %d does not fit LDS", window_len); return GM_E_ARG; }
   static size_t configured = 0;
-  if (lds > 48 * 1024 && lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
-  hipLaunchKernelGGL(k_pass2_cs, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, P, d_reads, d_initbp, n_reads, read_len, read_words, d_hits, hcap, d_sel,
+  if (lds > 48 * 1024 && lds > configured) {
+    GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
+  if (P.taboo > 0)
+  hipLaunchKernelGGL(k_pass2_cs<true>, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, P, d_reads, d_initbp, n_reads, read_len, read_words, d_hits, hcap, d_sel,
+                     d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_words, window_len, d_stats, d_xover, d_sel_sidx);
+  else
+  hipLaunchKernelGGL(k_pass2_cs<false>, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, P, d_reads, d_initbp, n_reads, read_len, read_words, d_hits, hcap, d_sel,
                      d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_words, window_len, d_stats, d_xover, d_sel_sidx);
   GM_HIP(hipGetLastError());
   return GM_OK;
