@@ -67,7 +67,9 @@ __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen,
     const uint32_t q = pk(r0 < rlen ? qr[r0] : SW_QR_SENT, r0 + 1 < rlen ? qr[r0 + 1] : SW_QR_SENT);
     const int rows = min(128, rlen - s * 128);
     const int steps = glen + rows - 1;
-    uint32_t Hprev = 0, Aprev = pk(-sc.a_go, -sc.a_go), Bprev = pk(-sc.b_go, -sc.b_go);
+    // Tprev: what the row below takes for its gap-along-the-read state, max(B - b_ext, H - b_open - b_ext) of this lane's rows at the column they just
+    // left -- formed here, so that one value travels down a row per step instead of B and H both (two instructions less per step)
+    uint32_t Hprev = 0, Aprev = pk(-sc.a_go, -sc.a_go), Tprev = pk(-sc.b_go - sc.b_ge, -sc.b_go - sc.b_ge);
     uint32_t Gprev = pk(SW_DB_SENT, SW_DB_SENT);
     uint32_t upH_prev = 0;                     // H(r-1, c-1) for the step to come
     const bool more = !SINGLE && (s + 1 < n_stripes);
@@ -78,21 +80,20 @@ __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen,
         const int c = t + lane;
         dbv = (c < glen) ? (uint32_t)db[c] : SW_DB_SENT;
         if (CS && s == 0) db0v = (c < glen) ? (uint32_t)db0[c] : SW_DB_SENT;
-        if (!SINGLE && s > 0) { chv = (c < glen) ? (uint32_t)(uint16_t)carryH[c] : 0u; cbv = (c < glen) ? (uint32_t)(uint16_t)carryB[c] : (uint32_t)(uint16_t)(-sc.b_go); }
+        if (!SINGLE && s > 0) { chv = (c < glen) ? (uint32_t)(uint16_t)carryH[c] : 0u; cbv = (c < glen) ? (uint32_t)(uint16_t)carryB[c] : (uint32_t)(uint16_t)(-sc.b_go - sc.b_ge); }
       }
       const int sl = t & 63;
       // lane 0's neighbour (row 128s - 1) comes from the carry arrays / the initial row
       const uint32_t in_g = (uint32_t)__builtin_amdgcn_readlane((int)dbv, sl) << 16;
       const uint32_t in_h = (!SINGLE && s > 0) ? ((uint32_t)__builtin_amdgcn_readlane((int)chv, sl) << 16) : 0u;
-      const uint32_t in_b = (!SINGLE && s > 0) ? ((uint32_t)__builtin_amdgcn_readlane((int)cbv, sl) << 16) : ((uint32_t)(uint16_t)(-sc.b_go) << 16);
+      const uint32_t in_b = (!SINGLE && s > 0) ? ((uint32_t)__builtin_amdgcn_readlane((int)cbv, sl) << 16) : ((uint32_t)(uint16_t)(-sc.b_go - sc.b_ge) << 16);   // (carryB holds T)
       const uint32_t G = up_of(Gprev, wave_shr1(Gprev, in_g));
       const uint32_t upH = up_of(Hprev, SINGLE ? wave_shr1_z(Hprev) : wave_shr1(Hprev, in_h));
-      // SINGLE: row -1's B may be anything <= 0 -- a B value that is not positive never changes an H (H >= 0), and starting from 0 instead of
-      // -b_open the B column stays <= 0 until an H - b_open - b_ext term takes over, which is the same term as in the exact recurrence.
-      const uint32_t upB = up_of(Bprev, SINGLE ? wave_shr1_z(Bprev) : wave_shr1(Bprev, in_b));
-      // a: gap along the genome (from the left), b: gap along the read (from above)
+      // SINGLE: row -1's b may be anything <= 0 -- a b value that is not positive never changes an H (H >= 0), and starting from 0 instead of
+      // -b_open - b_ext the column of b stays <= 0 until an H - b_open - b_ext term takes over, which is the same term as in the exact recurrence.
+      // a: gap along the genome (from the left), b: gap along the read (from above) = the T of the row above at this column
+      const uint32_t b = up_of(Tprev, SINGLE ? wave_shr1_z(Tprev) : wave_shr1(Tprev, in_b));
       const uint32_t a = pk_max(pk_sub(Aprev, v_a_ext), pk_sub(Hprev, v_a_oe));
-      const uint32_t b = pk_max(pk_sub(upB, v_b_ext), pk_sub(upH, v_b_oe));
       uint32_t Gc = G;
       if (CS && s == 0) {                      // row 0 lives in the low half of lane 0
         const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)db0v, sl);
@@ -104,9 +105,9 @@ __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen,
       v_score = pk_max(v_score, h);
       if (more && lane == 63) {                // row 128s+127 feeds the next stripe
         const int c = t - 127;
-        if (c >= 0 && c < glen) { carryH[c] = (int16_t)(h >> 16); carryB[c] = (int16_t)(b >> 16); }
+        if (c >= 0 && c < glen) { carryH[c] = (int16_t)(h >> 16); carryB[c] = (int16_t)(pk_max(pk_sub(b, v_b_ext), pk_sub(h, v_b_oe)) >> 16); }
       }
-      upH_prev = upH; Hprev = h; Aprev = a; Bprev = b; Gprev = G;
+      upH_prev = upH; Hprev = h; Aprev = a; Tprev = pk_max(pk_sub(b, v_b_ext), pk_sub(h, v_b_oe)); Gprev = G;
     }
     if (more) __syncthreads();
   }
