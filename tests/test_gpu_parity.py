@@ -963,3 +963,31 @@ def test_pair_files_match_reference_golden(gm, case, tmp_path):
     s.close(); ix.close()
     got = oa.sam_header(g["contigs"], g["contig_names"]) + body
     assert got == want, (_first_diff(got, want), st)
+
+
+def test_csfastq_files_match_reference_golden(gm, tmp_path):
+    """file input in colour space with quality values: the csfastq file of the cfg4s_50col_fq golden through gm_map_reads_file, and the csfastq pairs of
+    cs_pairs_fq_opp-in (mates adjacent in one file) through gm_map_pairs_file -- the goldens of the packed-array entry points"""
+    import gzip
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    tab = np.full(16, ord("."), dtype=np.uint8); tab[:4] = np.frombuffer(b"0123", dtype=np.uint8)
+    rec = lambda nm, row, q: b"@" + nm + b"\n" + b"ACGT"[row[0]:row[0] + 1] + tab[row[1:]].tobytes() + b"\n+\n" + bytes(q) + b"\n"
+    # unpaired
+    z = np.load(os.path.join(G, "cfg4s_50col_2Mbp.npz")); zq = np.load(os.path.join(G, "cfg4s_50col_fq.npz")); n = int(zq["n_reads"])
+    contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
+    path = str(tmp_path / "r.csfastq"); open(path, "wb").write(b"".join(rec(b"r%d" % i, z["reads"][i], zq["quals"][i]) for i in range(n)))
+    want = gzip.open(os.path.join(G, "cfg4s_50col_fq.sam.gz"), "rb").read()
+    p = gm.default_params_cs(); p.sam_unaligned = 1
+    ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+    got = oa.sam_header(contigs) + s.map_reads_file(path, qual_delta=33)
+    s.close(); ix.close()
+    assert got == want, _first_diff(got, want)
+    # pairs
+    g = oa.load_golden_pairs("cs_pairs_50col_opp-in"); zq = np.load(os.path.join(G, "cs_pairs_fq_opp-in.npz")); N = int(zq["n_pairs"])
+    path = str(tmp_path / "p.csfastq")
+    open(path, "wb").write(b"".join(rec(bytes(g["names1"][i]), g["m1"][i], zq["quals1"][i]) + rec(bytes(g["names2"][i]), g["m2"][i], zq["quals2"][i]) for i in range(N)))
+    want = gzip.open(os.path.join(G, "cs_pairs_fq_opp-in.sam.gz"), "rb").read()
+    ix = gm.Index(g["contigs"], names=g["contig_names"], params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_file(path, qual_delta=33, mode="opp-in", min_insert=g["ins"][0], max_insert=g["ins"][1])
+    s.close(); ix.close()
+    assert got == want, _first_diff(got, want)
