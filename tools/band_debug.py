@@ -1,3 +1,7 @@
+"""How many anti-diagonal steps of sw_full_cs the band leaves out (diagnostic build of gm_sw.hip with -DGM_BAND_DEBUG, linked like tools/build_k5_stamps.sh
+links its object, loaded through GM_LIB_PATH).  Result at the end of round 2: none -- the reference's band keeps a corner block above and below the anchor box
+(anchor_get_x_range, anchors.c:64-95), so the first row reaches column 0 and the last one the window's end; in letter space (two stripes of a 100 bp read) ~150 of 203.
+usage (GPU box): GM_LIB_PATH=shrimp_amd/libgm_banddbg.so python tools/band_debug.py"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.getcwd())
 import numpy as np
