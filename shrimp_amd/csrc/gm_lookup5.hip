@@ -209,7 +209,8 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
           my_entries += (e - b);
           const uint32_t j = atomicAdd(cnl, 1u);
           const uint64_t ptr = (((uint64_t)so.y << 32) | so.x) + b, sptr = (((uint64_t)so.w << 32) | so.z) + sb;
-          *(uint4*)&rec[4 * j] = make_uint4((uint32_t)ptr, (uint32_t)(ptr >> 32), e - b, ((uint32_t)k_i << 16) | (uint32_t)k_sn);
+          const uint64_t la = (uint64_t)(uintptr_t)(pos0 + ptr);     // the list's address itself: the step generator only adds the chunk offset
+          *(uint4*)&rec[4 * j] = make_uint4((uint32_t)la, (uint32_t)(la >> 32), e - b, ((uint32_t)k_i << 16) | (uint32_t)k_sn);
           *(uint4*)&srec[4 * j] = make_uint4((uint32_t)sptr, (uint32_t)(sptr >> 32), se - sb, 0u);
         }
       }
@@ -236,7 +237,8 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
       my_entries += (e - b);
       const uint32_t j = atomicAdd(cnl, 1u);
       const uint64_t ptr = (uint64_t)((ix.seed[sn].pos + b) - pos0), sptr = (uint64_t)((ix.seed[sn].spos + sb) - spos0);
-      *(uint4*)&rec[4 * j] = make_uint4((uint32_t)ptr, (uint32_t)(ptr >> 32), e - b, ((uint32_t)i << 16) | (uint32_t)sn);
+      const uint64_t la = (uint64_t)(uintptr_t)(pos0 + ptr);
+      *(uint4*)&rec[4 * j] = make_uint4((uint32_t)la, (uint32_t)(la >> 32), e - b, ((uint32_t)i << 16) | (uint32_t)sn);
       *(uint4*)&srec[4 * j] = make_uint4((uint32_t)sptr, (uint32_t)(sptr >> 32), se - sb, 0u);
     }
     __syncthreads();
@@ -256,7 +258,8 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
       if (gj < nl) {
         const uint32_t len = __builtin_amdgcn_readfirstlane(gr.z);
         const uint64_t o = ((uint64_t)__builtin_amdgcn_readfirstlane(gr.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(gr.x);
-        s.n = min(256u, len - gc); s.src = pos0 + o + gc; s.ysn = __builtin_amdgcn_readfirstlane(gr.w);
+        s.n = min(256u, len - gc); s.ysn = __builtin_amdgcn_readfirstlane(gr.w);
+        s.src = (const uint32_t*)(const uint32_t __attribute__((address_space(1)))*)(uintptr_t)o + gc;   // (rebuilt from integers: it has to name the global address space, else the loads become flat loads)
         gc += 256u;
         if (gc >= len) { gj += nwv; gc = 0; if (gj < nl) gr = *(const uint4*)&rec[4 * gj]; }
       }
