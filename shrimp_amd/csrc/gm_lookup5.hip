@@ -327,15 +327,18 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
             // all seen[] updates of the step first, then the twice[] updates (old & m is 0 or m: the update is unconditional, a no-op for
             // first marks -- cheaper than a branch per entry): one LDS round trip per step, not per entry
             const uint32_t a0 = sv[q].x >> sh_a, a1 = sv[q].y >> sh_a, a2 = sv[q].z >> sh_a, a3 = sv[q].w >> sh_a;
-            const uint32_t m0 = 1u << ((sv[q].x >> sh_b) & 31u), m1 = 1u << ((sv[q].y >> sh_b) & 31u), m2 = 1u << ((sv[q].z >> sh_b) & 31u), m3 = 1u << ((sv[q].w >> sh_b) & 31u);
-            uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-            o0 = K5_LDS_OR(swb + (a0 & smask4), m0);
-            if (W > 1) o1 = K5_LDS_OR(swb + (a1 & smask4), m1);
-            if (W > 2) o2 = K5_LDS_OR(swb + (a2 & smask4), m2);
+            // slots 1 and 2 without a branch: a slot beyond W ORs a zero mask (a no-op that returns the word) -- two scalar selects and two ANDs instead of
+            // a compare, a select and a branch per slot and table (the scalar unit, one per CU, is the busier one in this loop); the fourth slot is rare
+            const uint32_t k1 = W > 1u ? 0xFFFFFFFFu : 0u, k2 = W > 2u ? 0xFFFFFFFFu : 0u;
+            const uint32_t m0 = 1u << ((sv[q].x >> sh_b) & 31u), m1 = (1u << ((sv[q].y >> sh_b) & 31u)) & k1, m2 = (1u << ((sv[q].z >> sh_b) & 31u)) & k2, m3 = 1u << ((sv[q].w >> sh_b) & 31u);
+            uint32_t o3 = 0;
+            const uint32_t o0 = K5_LDS_OR(swb + (a0 & smask4), m0);
+            const uint32_t o1 = K5_LDS_OR(swb + (a1 & smask4), m1);
+            const uint32_t o2 = K5_LDS_OR(swb + (a2 & smask4), m2);
             if (W > 3) o3 = K5_LDS_OR(swb + (a3 & smask4), m3);
             K5_TWICE(a0, o0 & m0);
-            if (W > 1) K5_TWICE(a1, o1 & m1);
-            if (W > 2) K5_TWICE(a2, o2 & m2);
+            K5_TWICE(a1, o1 & m1);
+            K5_TWICE(a2, o2 & m2);
             if (W > 3) K5_TWICE(a3, o3 & m3);
           }
           gen(sd[q]); issue(sd[q], sv[q]);
