@@ -42,6 +42,7 @@ typedef __attribute__((address_space(3))) uint32_t k5_lds_u32;
 #ifndef K5_Q
 #define K5_Q 6            // list chunks in flight per wave (8 and 10 measured: no gain)
 #endif
+#define K5_XREC 64                                      // chunk records beyond one per list (a list of more than 256 positions takes one record per 256)
 enum { C_NCAND = 0, C_OVERFLOW, C_NMEMB, C_NKEEP, C_NSTRIP, C_NEDGE, C_NLISTS /* two words: read-strands alternate */, C_SINK = 8, C_NRAW = 9, C_WORDS = 12 };
 
 // Diagnostic build (-DK5_STAMPS): thread 0 of every workgroup adds the cycles between the phase boundaries of each read-strand to k5_stamps[]
@@ -111,8 +112,9 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
   uint32_t* candp = hmax + (1u << hbits);
   uint16_t* candy = (uint16_t*)(candp + cand_cap);
   uint32_t* rec = seen + (1u << lsw);
-  uint32_t* srec = rec + 4 * a.NL;
-  uint8_t* codes = (uint8_t*)(srec + 4 * a.NL);
+  const int RC = a.NL + K5_XREC;                                 // records: one per chunk of at most 256 positions
+  uint32_t* srec = rec + 4 * RC;
+  uint8_t* codes = (uint8_t*)(srec + 4 * RC);
   uint32_t* ctrl = (uint32_t*)(codes + 2 * ((a.read_len + 15) & ~15));           // two code buffers (this read-strand's and the next one's)
   const uint32_t smask4 = wmask << 2, tmask4 = tmask << 2, swb = 4u << ltw;
   const int sh_a = rb - 2, sh_b = rb + lsw;
@@ -167,6 +169,19 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
     k_ok = k_i >= ix.colour && k_i + k_span <= a.read_len;
     if (!k_ok) { k_span = 0; k_mask = 0; }
   }
+  // One record per chunk of at most 256 positions (the list's address + the chunk's, its length, y / seed), so that the step generator of the two passes is
+  // "next record": a list longer than 256 takes several; its strip list rides on the first one.  Records beyond the array are dropped, the read-strand then
+  // falls back (rec_over below).  `cnl` is this read-strand's counter word.
+  uint32_t* cnl_w = nullptr;
+  auto put_records = [&](const uint64_t la, const uint32_t len, const uint32_t ysn, const uint64_t sptr, const uint32_t slen) {
+    const uint32_t nch = (len + 255u) >> 8;
+    const uint32_t j = atomicAdd(cnl_w, nch);
+    for (uint32_t c = 0; c < nch && j + c < (uint32_t)RC; c++) {
+      const uint64_t ca = la + ((uint64_t)c << 10);
+      *(uint4*)&rec[4 * (j + c)] = make_uint4((uint32_t)ca, (uint32_t)(ca >> 32), min(256u, len - (c << 8)), ysn);
+      *(uint4*)&srec[4 * (j + c)] = c ? make_uint4(0u, 0u, 0u, 0u) : make_uint4((uint32_t)sptr, (uint32_t)(sptr >> 32), slen, 0u);
+    }
+  };
   auto kmer_ahead = [&](const int r, const uint8_t* cb) {      // the four directory words of this thread's k-mer of read-strand r: loads issued, used at the next top
     pf_ok = k_ok && r < 2 * a.n_reads;
     uint32_t mapidx = 0;
@@ -198,6 +213,7 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
     // (the list counter alternates between two words: with the set-up ahead there is no barrier between thread 0's reset at the end of a
     // read-strand and the first additions of the next one; the other word was reset a whole read-strand earlier)
     uint32_t* const cnl = &ctrl[C_NLISTS + (it & 1)];
+    cnl_w = cnl;
     if (ahead) {
       fill_codes(rs + (int)gridDim.x, codes + (uint32_t)((it + 1) & 1) * cpad);
       const uint32_t b = pf_b, e = pf_e, sb = pf_sb, se = pf_se;
@@ -207,11 +223,8 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
         if (e != b && e - b <= ix.list_cutoff) {               // ref: mapping.c:497 (longer lists are skipped, not deleted)
           const uint4 so = *(const uint4*)&stab[8 * k_sn + 4];
           my_entries += (e - b);
-          const uint32_t j = atomicAdd(cnl, 1u);
           const uint64_t ptr = (((uint64_t)so.y << 32) | so.x) + b, sptr = (((uint64_t)so.w << 32) | so.z) + sb;
-          const uint64_t la = (uint64_t)(uintptr_t)(pos0 + ptr);     // the list's address itself: the step generator only adds the chunk offset
-          *(uint4*)&rec[4 * j] = make_uint4((uint32_t)la, (uint32_t)(la >> 32), e - b, ((uint32_t)k_i << 16) | (uint32_t)k_sn);
-          *(uint4*)&srec[4 * j] = make_uint4((uint32_t)sptr, (uint32_t)(sptr >> 32), se - sb, 0u);
+          put_records((uint64_t)(uintptr_t)(pos0 + ptr), e - b, ((uint32_t)k_i << 16) | (uint32_t)k_sn, sptr, se - sb);
         }
       }
       __syncthreads();                                         // rec[] of this read-strand and the codes of the next one are in; the tables are clear
@@ -235,33 +248,29 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
       if (e == b || e - b > ix.list_cutoff) continue;          // ref: mapping.c:497 (longer lists are skipped, not deleted)
       const uint32_t sb = ix.seed[sn].sdir[mapidx], se = ix.seed[sn].sdir[mapidx + 1];
       my_entries += (e - b);
-      const uint32_t j = atomicAdd(cnl, 1u);
-      const uint64_t ptr = (uint64_t)((ix.seed[sn].pos + b) - pos0), sptr = (uint64_t)((ix.seed[sn].spos + sb) - spos0);
-      const uint64_t la = (uint64_t)(uintptr_t)(pos0 + ptr);
-      *(uint4*)&rec[4 * j] = make_uint4((uint32_t)la, (uint32_t)(la >> 32), e - b, ((uint32_t)i << 16) | (uint32_t)sn);
-      *(uint4*)&srec[4 * j] = make_uint4((uint32_t)sptr, (uint32_t)(sptr >> 32), se - sb, 0u);
+      const uint64_t sptr = (uint64_t)((ix.seed[sn].spos + sb) - spos0);
+      put_records((uint64_t)(uintptr_t)(ix.seed[sn].pos + b), e - b, ((uint32_t)i << 16) | (uint32_t)sn, sptr, se - sb);
     }
     __syncthreads();
     }
     // (no barrier behind the k-mers ahead: they read the next read-strand's codes and the seed table only, and their scattered loads -- 64 cache
     // lines per instruction -- queue up in the address unit; the waves go on to pass A as they get through)
     K5_STAMP(0);
-    const int nl = (int)*cnl;
+    const int nl_raw = (int)*cnl, nl = min(nl_raw, RC);
+    const bool rec_over = nl_raw > RC;                          // more chunks than records: the read-strand is redone by the fall-back kernels
 
     // One chunk of a list: n <= 256 entries from src, W = ceil(n / 64) per lane.  Wave-uniform (SGPRs).
     struct Step { uint32_t n, ysn; const uint32_t* src; };
-    int gj = wv; uint32_t gc = 0;                              // generator: list, entries of it already handed out
-    uint4 gr = make_uint4(0, 0, 0, 0);                         // descriptor of list gj, read one step ahead of its use (an LDS round trip off the critical path)
-    auto gen_reset = [&]() { gj = wv; gc = 0; if (gj < nl) gr = *(const uint4*)&rec[4 * gj]; };
-    auto gen = [&](Step& s) {                                  // (every list in rec[] has at least one entry: no loop)
+    int gj = wv;                                               // generator: the next record of this wave (records wv, wv + nwv, ...)
+    uint4 gr = make_uint4(0, 0, 0, 0);                         // that record, read one step ahead of its use (an LDS round trip off the critical path)
+    auto gen_reset = [&]() { gj = wv; if (gj < nl) gr = *(const uint4*)&rec[4 * gj]; };
+    auto gen = [&](Step& s) {
       s.n = 0; s.ysn = 0; s.src = pos0;
       if (gj < nl) {
-        const uint32_t len = __builtin_amdgcn_readfirstlane(gr.z);
         const uint64_t o = ((uint64_t)__builtin_amdgcn_readfirstlane(gr.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(gr.x);
-        s.n = min(256u, len - gc); s.ysn = __builtin_amdgcn_readfirstlane(gr.w);
-        s.src = (const uint32_t*)(const uint32_t __attribute__((address_space(1)))*)(uintptr_t)o + gc;   // (rebuilt from integers: it has to name the global address space, else the loads become flat loads)
-        gc += 256u;
-        if (gc >= len) { gj += nwv; gc = 0; if (gj < nl) gr = *(const uint4*)&rec[4 * gj]; }
+        s.n = __builtin_amdgcn_readfirstlane(gr.z); s.ysn = __builtin_amdgcn_readfirstlane(gr.w);
+        s.src = (const uint32_t*)(const uint32_t __attribute__((address_space(1)))*)(uintptr_t)o;   // (rebuilt from integers: it has to name the global address space, else the loads become flat loads)
+        gj += nwv; if (gj < nl) gr = *(const uint4*)&rec[4 * gj];
       }
     };
     // EVERY step issues exactly one dwordx4 per lane -- lanes past the chunk re-read its last entry, an exhausted generator reads the first
@@ -439,7 +448,7 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
     // A wave pays the longest chain of LDS round trips among its lanes, so the rare cases are taken out of the main loops and worked off
     // densely afterwards: the overlap-strip marks here (2 % of the candidates, but some lane of most waves), the neighbour-region look-ups of
     // stage 2 below.  Their lists (region numbers, then candidate indexes) live in rec[] / srec[], dead since pass B.
-    uint32_t* const elist = rec; const uint32_t ecap = 8u * (uint32_t)a.NL;
+    uint32_t* const elist = rec; const uint32_t ecap = 8u * (uint32_t)RC;
     if (!fallback) {
       for (uint32_t i = tid; i < nc; i += nthr) {
         const uint32_t p = candp[i], r = p >> rb, off = p & rmask;
@@ -463,7 +472,7 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
     }
     __syncthreads();
     K5_STAMP(3);
-    fallback = fallback || ctrl[C_OVERFLOW] != 0u;
+    fallback = fallback || rec_over || ctrl[C_OVERFLOW] != 0u;
     // ================= exact stage 2: the reference's rule (ref: mapping.c:733-742), prune rules (gm_prune.hip), output =================
     if (!fallback) {
       unsigned long long* out = (unsigned long long*)a.out + (size_t)rs * a.out_cap;
@@ -732,7 +741,7 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   // 3 Gbp (17 k entries) take 74 ms per 500 k reads here against 124 ms in the slab-sweep kernel
   if (!forced && entries < 8000.0) return 0;
   // LDS: twice (1/8 of seen) | seen | 32 B per list | codes | control words
-  const size_t fixed = (size_t)32 * NL + 2 * (size_t)((read_len + 15) & ~15) + C_WORDS * 4 + GM_MAX_SEEDS * 32;   // (+ the seed table)
+  const size_t fixed = (size_t)32 * (NL + K5_XREC) + 2 * (size_t)((read_len + 15) & ~15) + C_WORDS * 4 + GM_MAX_SEEDS * 32;   // (chunk records, + the seed table)
   const size_t budget = 160 * 1024 - 512;
   int lsw = 15;
   if (const char* e = gm_tune("GM_K5_LSW")) lsw = std::max(8, std::min(15, atoi(e)));
