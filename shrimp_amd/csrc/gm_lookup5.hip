@@ -160,10 +160,12 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
     *(uint4*)&stab[8 * tid + 4] = make_uint4((uint32_t)po, (uint32_t)(po >> 32), (uint32_t)so, (uint32_t)(so >> 32));
   }
   int k_sn = 0, k_i = 0, k_span = 0; uint64_t k_mask = 0; bool k_ok = false;
-  // (the k-mer slots are spread over all the waves -- every stride-th thread has one: the scattered directory loads of a wave full of k-mers
-  // take 64 cache lines per instruction, and a few late waves hold up the barrier behind pass A)
-  const int k_stride = max(1, nthr / max(1, a.NL)), k_slot = tid / k_stride;
-  if (ahead && tid % k_stride == 0 && k_slot < a.NL) {
+  // The k-mer slots sit on the first threads: ceil(NL / 64) waves ("set-up waves", 4 of 16 at 100 bp) work out the map indexes of the next read-strand, the
+  // other waves skip that arithmetic (their directory loads are dummies) and go straight to pass A, where they take one list each ahead of the rota
+  // (see the step generator) -- the set-up costs a quarter of the vector instructions it took when every stride-th thread of all the waves held a slot.
+  const int k_stride = 1, k_slot = tid;
+  const int nsw = ahead ? min(nwv, (a.NL + GM_WAVE - 1) / GM_WAVE) : nwv;      // set-up waves
+  if (ahead && k_slot < a.NL) {
     k_sn = k_slot / a.max_n_kmers; k_i = k_slot - k_sn * a.max_n_kmers;
     k_span = ix.seed[k_sn].span; k_mask = ix.seed[k_sn].mask;
     k_ok = k_i >= ix.colour && k_i + k_span <= a.read_len;
@@ -185,7 +187,8 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
   auto kmer_ahead = [&](const int r, const uint8_t* cb) {      // the four directory words of this thread's k-mer of read-strand r: loads issued, used at the next top
     pf_ok = k_ok && r < 2 * a.n_reads;
     uint32_t mapidx = 0;
-    if (!ix.hflag) {
+    if (wv >= nsw) {}                                        // (no slot in this wave: wave-uniform)
+    else if (!ix.hflag) {
       // KMER_TO_MAPIDX (ref: gmapper.h:349-368) without a branch per base: eight code bytes per LDS round trip, the mask bit selects
       for (int t0 = 0; t0 < ix.max_seed_span; t0 += 8) {
         uint32_t c[8];
@@ -261,16 +264,19 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
 
     // One chunk of a list: n <= 256 entries from src, W = ceil(n / 64) per lane.  Wave-uniform (SGPRs).
     struct Step { uint32_t n, ysn; const uint32_t* src; };
-    int gj = wv;                                               // generator: the next record of this wave (records wv, wv + nwv, ...)
+    // generator: the next record of this wave.  The waves without k-mer slots reach pass A earlier than the set-up waves: each of them takes one record of
+    // the first `xh` ahead of the rota (record wv - nsw), then every wave strides through the rest (xh + wv, xh + wv + nwv, ...).
+    const int xh = min(nl, nwv - nsw);
+    int gj = wv, gnext = wv;
     uint4 gr = make_uint4(0, 0, 0, 0);                         // that record, read one step ahead of its use (an LDS round trip off the critical path)
-    auto gen_reset = [&]() { gj = wv; if (gj < nl) gr = *(const uint4*)&rec[4 * gj]; };
+    auto gen_reset = [&]() { gnext = xh + wv; gj = (wv >= nsw && wv - nsw < xh) ? wv - nsw : gnext; if (gj == gnext) gnext += nwv; if (gj < nl) gr = *(const uint4*)&rec[4 * gj]; };
     auto gen = [&](Step& s) {
       s.n = 0; s.ysn = 0; s.src = pos0;
       if (gj < nl) {
         const uint64_t o = ((uint64_t)__builtin_amdgcn_readfirstlane(gr.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(gr.x);
         s.n = __builtin_amdgcn_readfirstlane(gr.z); s.ysn = __builtin_amdgcn_readfirstlane(gr.w);
         s.src = (const uint32_t*)(const uint32_t __attribute__((address_space(1)))*)(uintptr_t)o;   // (rebuilt from integers: it has to name the global address space, else the loads become flat loads)
-        gj += nwv; if (gj < nl) gr = *(const uint4*)&rec[4 * gj];
+        gj = gnext; gnext += nwv; if (gj < nl) gr = *(const uint4*)&rec[4 * gj];
       }
     };
     // EVERY step issues exactly one dwordx4 per lane -- lanes past the chunk re-read its last entry, an exhausted generator reads the first
