@@ -73,21 +73,24 @@ __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen,
     uint32_t Gprev = pk(SW_DB_SENT, SW_DB_SENT);
     uint32_t upH_prev = 0;                     // H(r-1, c-1) for the step to come
     const bool more = !SINGLE && (s + 1 < n_stripes);
-    uint32_t dbv = 0, chv = 0, cbv = 0, db0v = 0;
-#pragma unroll 2
-    for (int t = 0; t < steps; t++) {
+    uint32_t dbr = 0, chv = 0, cbv = 0, db0v = 0;
+    // The genome letter that enters at lane 0: the staging register of the next 64 columns (letter << 16) is rotated by one lane per step, so that lane 0
+    // always holds the letter of the column it is about to start, and the shift of G takes it from there as the value its lane 0 keeps -- two DPP moves per
+    // step instead of a lane read, a scalar shift, a move into a vector register and the DPP move.
+    auto step = [&](const int t) {
       if ((t & 63) == 0) {                     // refill the per-lane staging of the next 64 columns
         const int c = t + lane;
-        dbv = (c < glen) ? (uint32_t)db[c] : SW_DB_SENT;
+        dbr = ((c < glen) ? (uint32_t)db[c] : SW_DB_SENT) << 16;
         if (CS && s == 0) db0v = (c < glen) ? (uint32_t)db0[c] : SW_DB_SENT;
         if (!SINGLE && s > 0) { chv = (c < glen) ? (uint32_t)(uint16_t)carryH[c] : 0u; cbv = (c < glen) ? (uint32_t)(uint16_t)carryB[c] : (uint32_t)(uint16_t)(-sc.b_go - sc.b_ge); }
       }
       const int sl = t & 63;
       // lane 0's neighbour (row 128s - 1) comes from the carry arrays / the initial row
-      const uint32_t in_g = (uint32_t)__builtin_amdgcn_readlane((int)dbv, sl) << 16;
       const uint32_t in_h = (!SINGLE && s > 0) ? ((uint32_t)__builtin_amdgcn_readlane((int)chv, sl) << 16) : 0u;
       const uint32_t in_b = (!SINGLE && s > 0) ? ((uint32_t)__builtin_amdgcn_readlane((int)cbv, sl) << 16) : ((uint32_t)(uint16_t)(-sc.b_go - sc.b_ge) << 16);   // (carryB holds T)
-      const uint32_t G = up_of(Gprev, wave_shr1(Gprev, in_g));
+      const uint32_t dbn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dbr, 0x134, 0xf, 0xf, true);      // wave_rol:1 -- lane l takes lane l + 1's letter
+      const uint32_t G = up_of(Gprev, (uint32_t)__builtin_amdgcn_update_dpp((int)dbr, (int)Gprev, 0x138, 0xf, 0xf, false));   // wave_shr:1, lane 0 keeps dbr's
+      dbr = dbn;
       const uint32_t upH = up_of(Hprev, SINGLE ? wave_shr1_z(Hprev) : wave_shr1(Hprev, in_h));
       // SINGLE: row -1's b may be anything <= 0 -- a b value that is not positive never changes an H (H >= 0), and starting from 0 instead of
       // -b_open - b_ext the column of b stays <= 0 until an H - b_open - b_ext term takes over, which is the same term as in the exact recurrence.
@@ -108,7 +111,10 @@ __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen,
         if (c >= 0 && c < glen) { carryH[c] = (int16_t)(h >> 16); carryB[c] = (int16_t)(pk_max(pk_sub(b, v_b_ext), pk_sub(h, v_b_oe)) >> 16); }
       }
       upH_prev = upH; Hprev = h; Aprev = a; Tprev = pk_max(pk_sub(b, v_b_ext), pk_sub(h, v_b_oe)); Gprev = G;
-    }
+    };
+    int t = 0;
+    for (; t + 1 < steps; t += 2) { step(t); step(t + 1); }      // two steps per round (the second never starts a staging block: blocks begin at even t)
+    if (t < steps) step(t);
     if (more) __syncthreads();
   }
   int best = max((int)(int16_t)(v_score & 0xFFFF), (int)(int16_t)(v_score >> 16));
