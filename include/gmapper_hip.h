@@ -134,6 +134,11 @@ int sw_vector_cleanup(void);
  * g_off[i] indexes into `genome` (one shared bitfield), reads[i*read_words .. ) holds read i. */
 int gm_sw_vector_batch(int n, const uint32_t *genome, uint64_t genome_words, const int64_t *g_off, const int *glen,
                        const uint32_t *reads, int read_words, const int *rlen, int *scores);
+/* the same with pass 1's early stop (unpaired reads, ref: mapping.c:1332-1335 only compares the score with the threshold): a window whose remaining
+ * cells can no longer lift any alignment to `threshold` stops there; stopped[i] = 1 and scores[i] = the best score up to that point, which like the
+ * final one is below `threshold`.  stopped[i] = 0: scores[i] is the value gm_sw_vector_batch returns.  Letter space, reads up to 128 bases stop early. */
+int gm_sw_vector_batch_bounded(int n, const uint32_t *genome, uint64_t genome_words, const int64_t *g_off, const int *glen,
+                               const uint32_t *reads, int read_words, const int *rlen, int threshold, int *scores, uint8_t *stopped);
 
 /* ---------------------------------------------------------------------------------------------
  * S2: full Smith-Waterman with traceback, letter space.  ref: common/sw-full-ls.c:568-683

@@ -1112,7 +1112,7 @@ static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len,
     }
     GM_HIP(hipEventRecord(s->pev[k][3], q));
     rc = gm_launch_pass1(dv, s->sc, D.d_reads, n, read_len, read_words, W, overlap_abs, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, D.d_slots, d_stats, q,
-                         nullptr, nullptr, D.d_initbp);
+                         nullptr, nullptr, D.d_initbp, true);
     if (rc) return rc;
     GM_HIP(hipEventRecord(s->pev[k][4], q));
     rc = gm_launch_select(s->sc, n, read_len, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, D.d_sel, D.d_sel_cnt, D.d_sel_off, D.d_work, D.d_n_work, q);
@@ -1696,8 +1696,8 @@ extern "C" void sw_vector_stats(uint64_t* invocs, uint64_t* cells, double* secs)
   if (invocs) *invocs = g_sv.invocs; if (cells) *cells = g_sv.cells; if (secs) *secs = g_sv.secs;
 }
 
-extern "C" int gm_sw_vector_batch(int n, const uint32_t* genome, uint64_t genome_words, const int64_t* g_off, const int* glen,
-                                  const uint32_t* reads, int read_words, const int* rlen, int* scores) {
+static int sw_vector_batch_impl(int n, const uint32_t* genome, uint64_t genome_words, const int64_t* g_off, const int* glen,
+                                const uint32_t* reads, int read_words, const int* rlen, int* scores, int early_thr, uint8_t* stopped) {
   if (!g_sv.init) { gm_set_error("sw_vector called before sw_vector_setup"); return GM_E_NOTSETUP; }
   if (n <= 0) return GM_OK;
   int max_g = 0, max_r = 0;
@@ -1712,11 +1712,25 @@ extern "C" int gm_sw_vector_batch(int n, const uint32_t* genome, uint64_t genome
   GM_HIP(hipMemcpy(dgo, g_off, (size_t)n * 8, hipMemcpyHostToDevice));
   GM_HIP(hipMemcpy(dgl, glen, (size_t)n * 4, hipMemcpyHostToDevice));
   GM_HIP(hipMemcpy(drl, rlen, (size_t)n * 4, hipMemcpyHostToDevice));
-  int rc = gm_launch_sw_vector_batch(g_sv.sc, n, dg, dgo, dgl, dr, read_words, drl, max_g, max_r, ds, 0);
-  if (rc == GM_OK) { GM_HIP(hipDeviceSynchronize()); GM_HIP(hipMemcpy(scores, ds, (size_t)n * 4, hipMemcpyDeviceToHost)); }
-  (void)hipFree(dg); (void)hipFree(dr); (void)hipFree(dgo); (void)hipFree(dgl); (void)hipFree(drl); (void)hipFree(ds);
+  uint8_t* dst = nullptr;
+  if (stopped) GM_HIP(hipMalloc(&dst, (size_t)n));
+  int rc = gm_launch_sw_vector_batch(g_sv.sc, n, dg, dgo, dgl, dr, read_words, drl, max_g, max_r, ds, 0, early_thr, dst);
+  if (rc == GM_OK) {
+    GM_HIP(hipDeviceSynchronize()); GM_HIP(hipMemcpy(scores, ds, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (stopped) GM_HIP(hipMemcpy(stopped, dst, (size_t)n, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(dg); (void)hipFree(dr); (void)hipFree(dgo); (void)hipFree(dgl); (void)hipFree(drl); (void)hipFree(ds); if (dst) (void)hipFree(dst);
   for (int i = 0; i < n; i++) { g_sv.invocs++; g_sv.cells += (uint64_t)glen[i] * rlen[i]; }
   return rc;
+}
+extern "C" int gm_sw_vector_batch(int n, const uint32_t* genome, uint64_t genome_words, const int64_t* g_off, const int* glen,
+                                  const uint32_t* reads, int read_words, const int* rlen, int* scores) {
+  return sw_vector_batch_impl(n, genome, genome_words, g_off, glen, reads, read_words, rlen, scores, 0, nullptr);
+}
+extern "C" int gm_sw_vector_batch_bounded(int n, const uint32_t* genome, uint64_t genome_words, const int64_t* g_off, const int* glen,
+                                          const uint32_t* reads, int read_words, const int* rlen, int threshold, int* scores, uint8_t* stopped) {
+  if (threshold <= 0 || !stopped) { gm_set_error("gm_sw_vector_batch_bounded: threshold > 0 and a stopped[] array are required"); return GM_E_ARG; }
+  return sw_vector_batch_impl(n, genome, genome_words, g_off, glen, reads, read_words, rlen, scores, threshold, stopped);
 }
 
 extern "C" int sw_vector(uint32_t* genome, int goff, int glen, uint32_t* read, int rlen, uint32_t* genome_ls, int initbp, bool is_rna) {

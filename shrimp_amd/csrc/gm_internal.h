@@ -104,7 +104,8 @@ int gm_launch_pass1(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
                     int window_len, int window_overlap_abs, GmHit* d_hits, const uint16_t* d_perm, const uint32_t* d_hit_cnt, int hcap,
                     unsigned long long* d_slots, unsigned long long* d_stats, hipStream_t stream,
                     const int32_t* d_pair_min = nullptr, const uint8_t* d_saved = nullptr,   // paired mode: only_paired / saved windows
-                    const uint8_t* d_initbp = nullptr);                                        // colour space: primer letter per read
+                    const uint8_t* d_initbp = nullptr,                                         // colour space: primer letter per read
+                    bool early_stop = false);       // unpaired reads: a window may stop once it cannot reach the threshold (its score is then a lower bound below it)
 
 // K4a top-K selection (ref: read_get_vector_hits), one thread per read; K4b pass 2, one wave per selected hit
 #define GM_SEL_MAX 64
@@ -148,7 +149,8 @@ int gm_launch_mark_saved(uint8_t* d_saved, const uint32_t* d_list, int n, hipStr
 
 // S1 batch kernel on caller-provided bitfields
 int gm_launch_sw_vector_batch(const GmScoreDev& sc, int n, const uint32_t* d_genome, const long long* d_goff, const int* d_glen,
-                              const uint32_t* d_reads, int read_words, const int* d_rlen, int max_g, int max_r, int* d_scores, hipStream_t stream);
+                              const uint32_t* d_reads, int read_words, const int* d_rlen, int max_g, int max_r, int* d_scores, hipStream_t stream,
+                              int early_thr = 0, uint8_t* d_stopped = nullptr);   // > 0: pass 1's early stop against this threshold, stopped[i] = 1 where it fired
 
 // S2 single alignment on caller-provided bitfields
 int gm_launch_sw_full_single(const GmScoreDev& sc, const uint32_t* d_genome, long long goff, int glen, const uint32_t* d_read, int rlen,

@@ -51,9 +51,14 @@ __device__ __forceinline__ uint32_t up_of(uint32_t own, uint32_t shifted) { retu
 // CS: colour space -- read row 0 (the first colour) is compared with db0[c] = lstocs(genome_ls[c], initbp) instead of the colour
 // genome (ref: common/sw-vector.c:112-146); the colour codes still flow on to row 1.
 // SINGLE: rlen <= 128, one stripe -- no carry rows, lane 0's H neighbour is the zero row (the usual case: reads up to 128 bases).
+// early_thr > 0 (pass 1 of unpaired reads only, where a window below the threshold is dropped and its score never read again): once the genome has
+// run out (step t >= glen, the 41 % of the steps in which the anti-diagonal drains), the sweep stops as soon as NO alignment can reach early_thr any more.
+// Every alignment that ends on a later anti-diagonal either passes through a cell of the last two anti-diagonals -- and gains at most match per remaining
+// row / column after it: H(r, c) + match * min(rows - 1 - r, glen - 1 - c) -- or starts after them, which the same expression with H = 0 covers.  The value
+// returned is then the maximum so far (< early_thr, like the final one) and *bounded is set; the caller keeps the two apart (f1 cache).
 template <bool CS, bool SINGLE>
 __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc,
-                                int16_t* carry, int lane) {
+                                int16_t* carry, int lane, const int early_thr = 0, bool* bounded = nullptr) {
   const uint32_t v_match = pk(sc.match, sc.match);
   const uint32_t v_delta = pk(sc.mismatch - sc.match, sc.mismatch - sc.match);
   const uint32_t v_a_ext = pk(sc.a_ge, sc.a_ge), v_a_oe = pk(sc.a_go + sc.a_ge, sc.a_go + sc.a_ge);
@@ -113,8 +118,30 @@ __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen,
       upH_prev = upH; Hprev = h; Aprev = a; Tprev = pk_max(pk_sub(b, v_b_ext), pk_sub(h, v_b_oe)); Gprev = G;
     };
     int t = 0;
-    for (; t + 1 < steps; t += 2) { step(t); step(t + 1); }      // two steps per round (the second never starts a staging block: blocks begin at even t)
-    if (t < steps) step(t);
+    bool cut = false;
+    if (SINGLE && early_thr > 0) {
+      const uint32_t v_row = pk(2 * lane, 2 * lane + 1);
+      const uint32_t v_rleft = pk(max(rows - 1 - 2 * lane, 0), max(rows - 2 - 2 * lane, 0));
+      const uint32_t v_thr1 = pk(early_thr - 1, early_thr - 1);
+      for (int j = 0; j < 9; j++) {
+        const int frac = (j == 0 ? 23 : j == 1 ? 33 : j == 2 ? 44 : j == 3 ? 56 : j == 4 ? 72 : j == 5 ? 92 : j == 6 ? 118 : j == 7 ? 154 : 192);     // of 256: where along the drain the test is made
+        const int tc = (glen + ((rows * frac) >> 8) + 1) & ~1;
+        if (tc + 8 >= steps) break;
+        for (; t + 1 < tc; t += 2) { step(t); step(t + 1); }
+        // steps 0 .. t - 1 are done: Hprev holds anti-diagonal t - 1 (row r at column t - 1 - r: r - (t - glen) columns after it), upH_prev anti-diagonal t - 2 one row down
+        const int kk = t - glen;
+        const uint32_t left = pk_min_u16(as_u(__builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, v_row), __builtin_bit_cast(u16x2, pk(kk, kk))))), v_rleft);
+        const uint32_t pot = as_u(__builtin_bit_cast(s16x2, __builtin_bit_cast(u16x2, left) * __builtin_bit_cast(u16x2, v_match)));
+        const uint32_t top = pk_max(v_score, pk_add(pk_max(Hprev, pk_add(upH_prev, v_match)), pot));
+        const uint32_t over = as_u(__builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, top), __builtin_bit_cast(u16x2, v_thr1))));
+        if (!__any(over != 0u)) { cut = true; break; }
+      }
+    }
+    if (!cut) {
+      for (; t + 1 < steps; t += 2) { step(t); step(t + 1); }      // two steps per round (the second never starts a staging block: blocks begin at even t)
+      if (t < steps) step(t);
+    }
+    if (bounded) *bounded = cut;
     if (more) __syncthreads();
   }
   int best = max((int)(int16_t)(v_score & 0xFFFF), (int)(int16_t)(v_score >> 16));
@@ -123,8 +150,9 @@ __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen,
 }
 template <bool CS>
 __device__ __forceinline__ int sw_vector_wave_t(const uint8_t* db, const uint8_t* db0, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc,
-                                                int16_t* carry, int lane) {
-  return rlen <= 128 ? sw_vector_wave_s<CS, true>(db, db0, glen, qr, rlen, sc, carry, lane) : sw_vector_wave_s<CS, false>(db, db0, glen, qr, rlen, sc, carry, lane);
+                                                int16_t* carry, int lane, const int early_thr = 0, bool* bounded = nullptr) {
+  if (bounded) *bounded = false;
+  return rlen <= 128 ? sw_vector_wave_s<CS, true>(db, db0, glen, qr, rlen, sc, carry, lane, early_thr, bounded) : sw_vector_wave_s<CS, false>(db, db0, glen, qr, rlen, sc, carry, lane);
 }
 __device__ int sw_vector_wave(const uint8_t* db, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc, int16_t* carry, int lane) {
   return sw_vector_wave_t<false>(db, nullptr, glen, qr, rlen, sc, carry, lane);
@@ -255,7 +283,7 @@ __global__ void __launch_bounds__(GM_WAVE)
 k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words,
         int window_len, int overlap_abs, GmHit* __restrict__ hits, const uint16_t* __restrict__ perm,
         const uint32_t* __restrict__ hit_cnt, int hcap, unsigned long long* __restrict__ slots, unsigned long long* __restrict__ stats,
-        const int32_t* __restrict__ pair_min, const uint8_t* __restrict__ saved, const uint8_t* __restrict__ initbp) {
+        const int32_t* __restrict__ pair_min, const uint8_t* __restrict__ saved, const uint8_t* __restrict__ initbp, const int early) {
   extern __shared__ __align__(16) uint8_t sm[];
   const int lane = threadIdx.x;
   const int rs = blockIdx.x, rd = rs >> 1, st = rs & 1;
@@ -294,7 +322,7 @@ k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
     if (CS) load_window_cs(ix, cn, goff, w_len, st != ix.cs_flip, ib, db, db0, lane);      // the hit is turned onto the read's input strand (label cs_flip)
     else load_window(ix.genome, g0, w_len, false, db, lane);
     __syncthreads();
-    int score = -1; bool computed = false;
+    int score = -1; bool computed = false, was_cut = false;
     uint32_t slot = 0;
     if (sc.hash_filter_calls) {                                                          // f1_run look-up, ref: f1-wrapper.h:103-114
       slot = window_hash_slot(db, w_len, lane);
@@ -306,7 +334,26 @@ k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
         const unsigned long long bal = __ballot(hit);
         if (bal) { found = c0 + __builtin_ctzll(bal); break; }
       }
-      if (found >= 0) { score = (int)(__hip_atomic_load(&SL[found], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32); bypass++; }
+      if (found >= 0) {
+        const unsigned long long e = __hip_atomic_load(&SL[found], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        score = (int)((e >> 32) & 0x7FFFu); bypass++;
+        if ((e >> 47) & 1u) {
+          // the entry holds a lower bound of a score below ITS window's threshold (early stop); a window with a lower threshold (shorter than the
+          // read) needs the value itself: score the entry's window in full and put it right
+          const GmHit* ha = &H[(int)(e >> 48)];
+          const int a_len = ha->w_len;
+          const int a_max = (read_len < a_len ? read_len : a_len) * sc.match, b_max = (read_len < w_len ? read_len : w_len) * sc.match;
+          if (thr_of(sc.vect_thr_frac, sc.vect_abs, b_max) < thr_of(sc.vect_thr_frac, sc.vect_abs, a_max)) {
+            __syncthreads();
+            if (CS) load_window_cs(ix, ha->cn, ha->g_off, a_len, st != ix.cs_flip, ib, db, db0, lane);
+            else load_window(ix.genome, (uint64_t)ix.contig_off[ha->cn] + ha->g_off, a_len, false, db, lane);
+            __syncthreads();
+            score = sw_vector_wave_t<CS>(db, db0, a_len, qr, read_len, sc, carry, lane);
+            if (lane == 0) __hip_atomic_store(&SL[found], (e & 0xFFFF0000FFFFFFFFull) | ((unsigned long long)(uint32_t)score << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+          }
+        }
+      }
     }
     if (score < 0) {
       if (!CS && sc.gapless) {                                                           // -U: f1_run's ungapped branch, ref: f1-wrapper.h:122-125, mapping.c:1321-1328
@@ -314,11 +361,14 @@ k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
                                 (long long)goff + h->ax, h->ay, sc, lane);
         calls++; cells += (unsigned long long)read_len;
       } else {
-        score = sw_vector_wave_t<CS>(db, db0, w_len, qr, read_len, sc, carry, lane); computed = true;
+        const int score_max_w = (read_len < w_len ? read_len : w_len) * sc.match;
+        score = sw_vector_wave_t<CS>(db, db0, w_len, qr, read_len, sc, carry, lane, early ? thr_of(sc.vect_thr_frac, sc.vect_abs, score_max_w) : 0, &was_cut); computed = true;
         calls++; cells += (unsigned long long)w_len * read_len;
       }
       if (sc.hash_filter_calls) {
-        if (lane == 0) __hip_atomic_store(&SL[n_comp], (unsigned long long)slot | ((unsigned long long)(uint32_t)score << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (cache slot | score, 15 bits | early stop | hit index)
+        if (lane == 0) __hip_atomic_store(&SL[n_comp], (unsigned long long)slot | ((unsigned long long)(uint32_t)score << 32) | ((unsigned long long)(was_cut ? 1u : 0u) << 47) | ((unsigned long long)(uint32_t)hi << 48),
+                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         n_comp++; __syncthreads();
       }
     }
@@ -695,7 +745,8 @@ __global__ void __launch_bounds__(1024) k_scan_counts(int n, const uint32_t* __r
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(GM_WAVE)
 k_sw_vector_batch(GmScoreDev sc, int n, const uint32_t* __restrict__ genome, const long long* __restrict__ goff, const int* __restrict__ glen,
-                  const uint32_t* __restrict__ reads, int read_words, const int* __restrict__ rlen, int max_g, int max_r, int* __restrict__ scores) {
+                  const uint32_t* __restrict__ reads, int read_words, const int* __restrict__ rlen, int max_g, int max_r, int* __restrict__ scores,
+                  int early_thr, uint8_t* __restrict__ stopped) {
   extern __shared__ __align__(16) uint8_t sm[];
   const int lane = threadIdx.x;
   uint8_t* qr = sm;
@@ -706,8 +757,9 @@ k_sw_vector_batch(GmScoreDev sc, int n, const uint32_t* __restrict__ genome, con
     load_read(reads + (size_t)i * read_words, rlen[i], false, qr, lane);
     load_window(genome, (uint64_t)goff[i], glen[i], false, db, lane);
     __syncthreads();
-    const int s = sw_vector_wave(db, glen[i], qr, rlen[i], sc, carry, lane);
-    if (lane == 0) scores[i] = s;
+    bool cut = false;
+    const int s = early_thr > 0 ? sw_vector_wave_t<false>(db, nullptr, glen[i], qr, rlen[i], sc, carry, lane, early_thr, &cut) : sw_vector_wave(db, glen[i], qr, rlen[i], sc, carry, lane);
+    if (lane == 0) { scores[i] = s; if (stopped) stopped[i] = cut ? 1 : 0; }
   }
 }
 
@@ -792,17 +844,21 @@ int gm_launch_sw_full_single(const GmScoreDev& sc, const uint32_t* d_genome, lon
 int gm_launch_pass1(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
                     int window_len, int window_overlap_abs, GmHit* d_hits, const uint16_t* d_perm, const uint32_t* d_hit_cnt, int hcap,
                     unsigned long long* d_slots, unsigned long long* d_stats, hipStream_t stream, const int32_t* d_pair_min, const uint8_t* d_saved,
-                    const uint8_t* d_initbp) {
+                    const uint8_t* d_initbp, bool early_stop) {
   if (n_reads == 0) return GM_OK;
+  // the early stop of a window that cannot reach the threshold (sw_vector_wave_s): only where a score below the threshold is never read again (unpaired
+  // reads: the caller says so), with a scoring scheme in which a cell gains at most `match`, and within the 16-bit range of the test
+  const int early = (early_stop && !d_pair_min && !sc.gapless && sc.match > 0 && sc.mismatch <= sc.match && sc.match * (2 * 128 + 2) < 32000 && hcap <= 65536 &&
+                     !(gm_tune("GM_P1_EARLY") && atoi(gm_tune("GM_P1_EARLY")) == 0)) ? 1 : 0;
   if (ix.colour) {
     if (!d_initbp) { gm_set_error("pass 1 in colour space needs the primer letters"); return GM_E_ARG; }
     const size_t lds = ((read_len + 15) & ~15) + 2 * (size_t)((window_len + 15) & ~15) + (size_t)window_len * 4 + 64;
     hipLaunchKernelGGL(k_pass1<true>, dim3(n_reads * 2), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
-                       window_len, window_overlap_abs, d_hits, d_perm, d_hit_cnt, hcap, d_slots, d_stats, d_pair_min, d_saved, d_initbp);
+                       window_len, window_overlap_abs, d_hits, d_perm, d_hit_cnt, hcap, d_slots, d_stats, d_pair_min, d_saved, d_initbp, early);
   } else {
     const size_t lds = ((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 4 + 64;
     hipLaunchKernelGGL(k_pass1<false>, dim3(n_reads * 2), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
-                       window_len, window_overlap_abs, d_hits, d_perm, d_hit_cnt, hcap, d_slots, d_stats, d_pair_min, d_saved, (const uint8_t*)nullptr);
+                       window_len, window_overlap_abs, d_hits, d_perm, d_hit_cnt, hcap, d_slots, d_stats, d_pair_min, d_saved, (const uint8_t*)nullptr, early);
   }
   GM_HIP(hipGetLastError());
   return GM_OK;
@@ -852,11 +908,13 @@ int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
 }
 
 int gm_launch_sw_vector_batch(const GmScoreDev& sc, int n, const uint32_t* d_genome, const long long* d_goff, const int* d_glen,
-                              const uint32_t* d_reads, int read_words, const int* d_rlen, int max_g, int max_r, int* d_scores, hipStream_t stream) {
+                              const uint32_t* d_reads, int read_words, const int* d_rlen, int max_g, int max_r, int* d_scores, hipStream_t stream,
+                              int early_thr, uint8_t* d_stopped) {
   if (n == 0) return GM_OK;
   const size_t lds = ((max_r + 15) & ~15) + ((max_g + 15) & ~15) + (size_t)max_g * 4 + 64;
   const int grid = std::min(n, 256 * 16);
-  hipLaunchKernelGGL(k_sw_vector_batch, dim3(grid), dim3(GM_WAVE), lds, stream, sc, n, d_genome, d_goff, d_glen, d_reads, read_words, d_rlen, max_g, max_r, d_scores);
+  hipLaunchKernelGGL(k_sw_vector_batch, dim3(grid), dim3(GM_WAVE), lds, stream, sc, n, d_genome, d_goff, d_glen, d_reads, read_words, d_rlen, max_g, max_r, d_scores,
+                     early_thr, d_stopped);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

@@ -106,7 +106,7 @@ class SwFullResults(C.Structure):   # struct gm_sw_full_results == the reference
 # every entry point include/gmapper_hip.h declares
 EXPORTS = ["gm_map_pairs_file", "gm_map_pairs_cs_fastq", "gm_map_reads_file", "gm_merge_options_default", "gm_merge_sam", "gm_release_cache", "gm_map_pairs_cs", "gm_last_error", "gm_device_count", "gm_params_default", "gm_params_default_cs", "gm_index_build", "gm_index_free", "gm_index_list_cutoff",
            "gm_index_save", "gm_index_load", "gm_index_bytes", "gm_index_n_slabs", "gm_index_has_buckets", "gm_index_get_list", "gm_index_device_array", "gm_index_meta", "gm_index_alloc_like",
-           "sw_vector_setup", "sw_vector", "sw_vector_stats", "sw_vector_cleanup", "gm_sw_vector_batch",
+           "sw_vector_setup", "sw_vector", "sw_vector_stats", "sw_vector_cleanup", "gm_sw_vector_batch", "gm_sw_vector_batch_bounded",
            "sw_full_ls_setup", "sw_full_ls", "sw_full_ls_cleanup", "sw_full_ls_stats",
            "sw_full_cs_setup", "sw_full_cs", "sw_full_cs_cleanup", "sw_full_cs_stats", "gm_sw_vector_batch_cs",
            "post_sw_setup", "post_sw", "post_sw_cleanup", "post_sw_stats",
@@ -146,6 +146,8 @@ def lib():
     L.sw_vector_setup.argtypes = [C.c_int] * 9 + [C.c_bool]
     L.sw_vector.argtypes = [u32p, C.c_int, C.c_int, u32p, C.c_int, u32p, C.c_int, C.c_bool]
     L.gm_sw_vector_batch.argtypes = [C.c_int, u32p, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int), u32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.gm_sw_vector_batch_bounded.argtypes = [C.c_int, u32p, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int), u32p, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
+                                             C.POINTER(C.c_uint8)]
     L.sw_full_ls_setup.argtypes = [C.c_int] * 8 + [C.c_bool, C.c_int]
     L.sw_full_ls.argtypes = [u32p, C.c_int, C.c_int, u32p, C.c_int, C.c_int, C.c_int, C.POINTER(SwFullResults), C.c_bool, C.POINTER(Anchor), C.c_int, C.c_int]
     L.sw_full_ls.restype = None
@@ -540,6 +542,22 @@ def sw_vector_batch(genome_words: np.ndarray, g_off, glen, reads_words: np.ndarr
                                 reads_words.ctypes.data_as(C.POINTER(C.c_uint32)), reads_words.shape[1],
                                 rlen.ctypes.data_as(C.POINTER(C.c_int)), out.ctypes.data_as(C.POINTER(C.c_int))), "gm_sw_vector_batch")
     return out
+
+
+def sw_vector_batch_bounded(genome_words: np.ndarray, g_off, glen, reads_words: np.ndarray, rlen, threshold: int):
+    """gm_sw_vector_batch with pass 1's early stop against `threshold`: (scores, stopped); where stopped, the score is a lower bound below the threshold"""
+    L = lib()
+    genome_words = np.ascontiguousarray(genome_words, dtype=np.uint32)
+    reads_words = np.ascontiguousarray(reads_words, dtype=np.uint32)
+    n = reads_words.shape[0]
+    g_off = np.ascontiguousarray(g_off, dtype=np.int64); glen = np.ascontiguousarray(glen, dtype=np.int32); rlen = np.ascontiguousarray(rlen, dtype=np.int32)
+    out = np.zeros(n, dtype=np.int32); stopped = np.zeros(n, dtype=np.uint8)
+    _check(L.gm_sw_vector_batch_bounded(n, genome_words.ctypes.data_as(C.POINTER(C.c_uint32)), genome_words.size,
+                                        g_off.ctypes.data_as(C.POINTER(C.c_int64)), glen.ctypes.data_as(C.POINTER(C.c_int)),
+                                        reads_words.ctypes.data_as(C.POINTER(C.c_uint32)), reads_words.shape[1],
+                                        rlen.ctypes.data_as(C.POINTER(C.c_int)), int(threshold), out.ctypes.data_as(C.POINTER(C.c_int)),
+                                        stopped.ctypes.data_as(C.POINTER(C.c_uint8))), "gm_sw_vector_batch_bounded")
+    return out, stopped
 
 
 def sw_vector(genome_words, goff, glen, read_words, rlen, genome_ls=None, initbp=-1) -> int:

@@ -76,6 +76,46 @@ def test_sw_vector_batch_random_vs_oracle(gm, oracle_lib):
     assert (got == want).all(), np.nonzero(got != want)[0][:10]
 
 
+def test_sw_vector_early_stop_is_exact_about_the_threshold(gm):
+    """pass 1's early stop (unpaired reads): a window stops only when no alignment can reach the threshold any more -- the full score of every stopped
+    window is below the threshold, its returned value is a lower bound of it, and a window that did not stop returns the full score"""
+    from shrimp_amd import synth
+    rng = np.random.default_rng(17)
+    n, L = 6000, 100
+    G = rng.integers(0, 4, size=300_000, dtype=np.uint8)
+    G[rng.integers(0, G.size, 300)] = 15
+    starts = rng.integers(0, G.size - 400, size=n)
+    reads = np.stack([G[s + 20:s + 20 + L].copy() for s in starts])
+    # a third true hits (6 % substitutions), a third half-reads (the other half random: scores around the threshold), a third chance windows with two seed-like runs
+    reads = np.where(rng.random(reads.shape) < 0.06, rng.integers(0, 4, size=reads.shape), reads).astype(np.uint8)
+    third = n // 3
+    for i in range(third, 2 * third):
+        cut = int(rng.integers(30, 70)); side = int(rng.integers(0, 2))
+        if side: reads[i, cut:] = rng.integers(0, 4, size=L - cut)
+        else: reads[i, :cut] = rng.integers(0, 4, size=cut)
+    for i in range(2 * third, n):
+        keep = np.zeros(L, dtype=bool)
+        for _ in range(2):
+            a = int(rng.integers(0, L - 14)); keep[a:a + 14] = True
+        reads[i] = np.where(keep, reads[i], rng.integers(0, 4, size=L))
+    gw = synth.pack_nibbles(G); rw = synth.pack_reads(reads)
+    glen = np.full(n, 140, dtype=np.int32); glen[::7] = 90; glen[3::11] = 250
+    rlen = np.full(n, L, dtype=np.int32)
+    gm.sw_vector_setup(1400, 1000, -33, -7, -33, -3, 10, -15, 0, True)
+    full = gm.sw_vector_batch(gw, starts, glen, rw, rlen)
+    n_stopped = 0
+    for thr in (470, 300, 700):
+        got, stopped = gm.sw_vector_batch_bounded(gw, starts, glen, rw, rlen, thr)
+        st = stopped.astype(bool)
+        assert (got[~st] == full[~st]).all()
+        assert (full[st] < thr).all(), np.nonzero(st & (full >= thr))[0][:10]
+        assert (got[st] <= full[st]).all() and (got[st] >= 0).all()
+        assert ((full >= thr) <= ~st).all()
+        n_stopped += int(st.sum())
+        if thr == 470: assert st.sum() > n // 4 and (full >= thr).sum() > n // 4      # both outcomes are well represented
+    assert n_stopped > 0
+
+
 def test_sw_vector_long_reads_multi_stripe(gm, oracle_lib):
     """reads longer than 128 rows exercise the stripe carry"""
     import ctypes as C
@@ -149,6 +189,7 @@ KERNEL_VARIANTS = [
     {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_NO_PRUNE": "1"},   # v5 without the prune rules (all survivors to K2)
     {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_SCAP": "256", "GM_SCAP2": "64"},   # v5 survivors beyond K2's LDS tier: heavy tier
     {"GM_SLAB_BITS": "17", "GM_K1_V5": "1", "GM_K1_THREADS": "128"},               # v5 with two waves per workgroup
+    {"GM_P1_EARLY": "0"},                                    # pass 1 without the early stop of windows that cannot reach the threshold
 ]
 
 
@@ -456,7 +497,8 @@ def test_colour_space_sam_matches_reference_golden(gm, name):
 
 @pytest.mark.parametrize("env", [{"GM_SLAB_BITS": "18"}, {"GM_SLAB_BITS": "18", "GM_K1_V4": "1"}, {"GM_NO_BUCKETS": "1"}, {"GM_SLAB_BITS": "18", "GM_K1_V2": "1"},
                                  {"GM_SCAP": "256", "GM_SCAP2": "64"}, {"GM_SLAB_BITS": "18", "GM_K1_V5": "1"}, {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_LSW": "12"},
-                                 {"GM_POST_SW_HOST": "1"}],      # post_sw by the host routine instead of k_post_sw_cs
+                                 {"GM_POST_SW_HOST": "1"},       # post_sw by the host routine instead of k_post_sw_cs
+                                 {"GM_P1_EARLY": "0"}],          # pass 1 without the early stop
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_colour_space_kernel_variants(gm, env):
     """every lookup kernel skips the first colour and reads strand 1 the colour-space way"""
