@@ -71,6 +71,54 @@ template <bool BIG, typename T> __device__ void k2_bitonic(T* key, int npad, int
     }
 }
 
+// The same network on up to 256 keys held in registers (R = 1, 2, 4 per lane, key i = lane * R + j): partners less than R apart sit in the same lane,
+// the others come by a lane exchange -- one round trip per stage instead of an LDS read, a write and a barrier.  Equal keys are identical values
+// (a survivor key is unique, pads are all ~0), so the result is the sorted array whatever the network does with them.
+template <typename T> __device__ __forceinline__ T k2_xor_lane(T v, int dl) { return (T)__shfl_xor(v, dl); }
+template <> __device__ __forceinline__ uint64_t k2_xor_lane<uint64_t>(uint64_t v, int dl) {
+  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, dl), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), dl);
+  return ((uint64_t)hi << 32) | lo;
+}
+template <typename T, int R> __device__ __forceinline__ void k2_bitonic_regs(T* key, int lane) {
+  T v[R];
+#pragma unroll
+  for (int j = 0; j < R; j++) v[j] = key[lane * R + j];
+#pragma unroll
+  for (int k = 2; k <= 64 * R; k <<= 1) {
+#pragma unroll
+    for (int d = k >> 1; d > 0; d >>= 1) {
+      if (d < R) {
+#pragma unroll
+        for (int j = 0; j < R; j++) if ((j & d) == 0) {
+          const bool up = (((lane * R + j) & k) == 0);
+          const T a = v[j], b = v[j | d];
+          const bool sw = (a > b) == up;
+          v[j] = sw ? b : a; v[j | d] = sw ? a : b;
+        }
+      } else {
+        const int dl = d / R;
+        const bool lower = (lane & dl) == 0;
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+          const bool up = (((lane * R + j) & k) == 0);
+          const T o = k2_xor_lane<T>(v[j], dl);
+          const bool less = v[j] < o;
+          v[j] = ((up == lower) == less) ? v[j] : o;         // the lower index keeps the smaller key where the run ascends
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < R; j++) key[lane * R + j] = v[j];
+}
+// keys in LDS, written and fenced by the caller; sorted and fenced on return
+template <bool BIG, typename T> __device__ void k2_sort(T* key, int npad, int lane) {
+  if (!BIG && npad <= 256) {
+    if (npad == 64) k2_bitonic_regs<T, 1>(key, lane); else if (npad == 128) k2_bitonic_regs<T, 2>(key, lane); else k2_bitonic_regs<T, 4>(key, lane);
+    __syncthreads();
+  } else k2_bitonic<BIG, T>(key, npad, lane);
+}
+
 // anchor_join of two anchors (ref: common/anchors.c:9-52) in window-relative coordinates
 struct K2Box { long long x, y; int length, width; };
 __device__ __forceinline__ K2Box k2_join2(long long x0, long long y0, int l0, int w0, long long x1, long long y1, int l1, int w1) {
@@ -202,7 +250,7 @@ __device__ int k2_collapse_par(const GmIndexDev& ix, K2Ws<false>& ws, uint32_t* 
     ck[t] = c;
   }
   k2_sync<false>();
-  k2_bitonic<false, uint32_t>(ck, npad, lane);
+  k2_sort<false, uint32_t>(ck, npad, lane);
   // Runs of one (class, contig, diagonal) are contiguous now.  A run's head takes the extent of all its members and their number -- a read that really maps
   // puts ~250 colinear k-mer hits into ONE run, and walking it from its head (one lane, two dependent LDS reads per member) was two thirds of this kernel's time.
   // So: every member finds its head by a running maximum over the head positions (wave scan, chunk by chunk) and adds itself with two LDS atomics: extent by
@@ -389,7 +437,7 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
       const uint64_t* sv = surv + (size_t)rs * scap;
       for (int t = lane; t < npad; t += GM_WAVE) ws.key[t] = (t < n) ? sv[t] : ~0ull;
       k2_sync<BIG>();
-      k2_bitonic<BIG, uint64_t>(ws.key, npad, lane);
+      k2_sort<BIG, uint64_t>(ws.key, npad, lane);
     }
     K2_STAMP(0);
     if (!BIG && ix.n_contigs <= GM_WAVE) {
@@ -439,7 +487,7 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
         ws.key[t] = k;
       }
       k2_sync<BIG>();
-      k2_bitonic<BIG, uint64_t>(ws.key, hp, lane);
+      k2_sort<BIG, uint64_t>(ws.key, hp, lane);
       for (int t = lane; t < nhc; t += GM_WAVE) {
         P[t] = (uint16_t)(ws.key[t] & 0xFFFF);
         if (detect && t > 0 && (ws.key[t] >> 16) == (ws.key[t - 1] >> 16) &&
