@@ -1714,6 +1714,9 @@ static int sw_vector_batch_impl(int n, const uint32_t* genome, uint64_t genome_w
   GM_HIP(hipMemcpy(drl, rlen, (size_t)n * 4, hipMemcpyHostToDevice));
   uint8_t* dst = nullptr;
   if (stopped) GM_HIP(hipMalloc(&dst, (size_t)n));
+  // (the early stop needs a scheme in which a cell gains at most `match` and gaps cost: otherwise every window runs to its end)
+  const GmScoreDev& sv = g_sv.sc;
+  if (!(sv.match > 0 && sv.mismatch <= sv.match && sv.a_go >= 0 && sv.a_ge >= 0 && sv.b_go >= 0 && sv.b_ge >= 0 && sv.match * (2 * 128 + 2) < 32000)) early_thr = 0;
   int rc = gm_launch_sw_vector_batch(g_sv.sc, n, dg, dgo, dgl, dr, read_words, drl, max_g, max_r, ds, 0, early_thr, dst);
   if (rc == GM_OK) {
     GM_HIP(hipDeviceSynchronize()); GM_HIP(hipMemcpy(scores, ds, (size_t)n * 4, hipMemcpyDeviceToHost));

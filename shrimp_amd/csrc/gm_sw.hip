@@ -847,8 +847,9 @@ int gm_launch_pass1(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
                     const uint8_t* d_initbp, bool early_stop) {
   if (n_reads == 0) return GM_OK;
   // the early stop of a window that cannot reach the threshold (sw_vector_wave_s): only where a score below the threshold is never read again (unpaired
-  // reads: the caller says so), with a scoring scheme in which a cell gains at most `match`, and within the 16-bit range of the test
-  const int early = (early_stop && !d_pair_min && !sc.gapless && sc.match > 0 && sc.mismatch <= sc.match && sc.match * (2 * 128 + 2) < 32000 && hcap <= 65536 &&
+  // reads: the caller says so), with a scoring scheme in which a cell gains at most `match` and a gap never gains, and within the 16-bit range of the test
+  const int early = (early_stop && !d_pair_min && !sc.gapless && sc.match > 0 && sc.mismatch <= sc.match && sc.a_go >= 0 && sc.a_ge >= 0 && sc.b_go >= 0 && sc.b_ge >= 0 &&
+                     sc.match * (2 * 128 + 2) < 32000 && hcap <= 65536 &&
                      !(gm_tune("GM_P1_EARLY") && atoi(gm_tune("GM_P1_EARLY")) == 0)) ? 1 : 0;
   if (ix.colour) {
     if (!d_initbp) { gm_set_error("pass 1 in colour space needs the primer letters"); return GM_E_ARG; }
