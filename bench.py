@@ -191,7 +191,9 @@ def main():
                    "parallelism": "read-sharded x%d, index replicated (1 RCCL broadcast at start-up)" % world,
                    "inputs": "reads resident in HBM" if kind == "ls" else "packed reads in host buffers, uploaded every step",
                    "sam_emitted": not args.no_sam, "scale": args.scale, "host_threads_per_rank": int(os.environ["GM_HOST_THREADS"]),
-                   "sub_batch_pipeline": "stage order" if os.environ.get("GM_OVERLAP") == "0" else "two streams (lookup of sub-batch i+1 beside SW of sub-batch i)"},
+                   "sub_batch_pipeline": "stage order" if os.environ.get("GM_OVERLAP") == "0" else "two streams (lookup of sub-batch i+1 beside SW of sub-batch i)",
+                   "vector_sw_filter": ("every window swept to its end" if (kind == "pairs" or os.environ.get("GM_P1_EARLY") == "0") else
+                                        "a window stops once no alignment can reach the vector threshold (exact bound, same SAM; DESIGN.md section 4, K3)")},
     }
     if rank == 0:
         U = R * args.steps
