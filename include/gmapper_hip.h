@@ -7,6 +7,7 @@
  *
  * Seams replaced:
  *   S1  sw_vector_setup / sw_vector / sw_vector_stats      ref: common/sw-vector.h:1-6, common/sw-vector.c:388-515
+ *       sw_gapless_setup / sw_gapless / sw_gapless_stats   ref: common/sw-gapless.h:11-14, common/sw-gapless.c:29-117
  *   S2  sw_full_ls_setup / sw_full_ls                       ref: common/sw-full-ls.h, common/sw-full-ls.c:568-683
  *   S4  handle_read (per-read pipeline -> SAM text)        ref: gmapper/mapping.h:23, gmapper/mapping.c:1773-1868
  *   S5  load_genome (index build) + its globals            ref: gmapper/genome.h:23-32, gmapper/genome.c:1012-1182
@@ -139,6 +140,17 @@ int gm_sw_vector_batch(int n, const uint32_t *genome, uint64_t genome_words, con
  * final one is below `threshold`.  stopped[i] = 0: scores[i] is the value gm_sw_vector_batch returns.  Letter space, reads up to 128 bases stop early. */
 int gm_sw_vector_batch_bounded(int n, const uint32_t *genome, uint64_t genome_words, const int64_t *g_off, const int *glen,
                                const uint32_t *reads, int read_words, const int *rlen, int threshold, int *scores, uint8_t *stopped);
+
+/* S1, ungapped form (-U / gapless_sw): the best ungapped segment on the diagonal of `genome` (glen positions from its first word) through
+ * (g_idx, r_idx).  ref: common/sw-gapless.h:11-14, sw-gapless.c:29-117; f1_setup / f1_run call these instead of sw_vector when gapless_sw is set
+ * (f1-wrapper.h:66-68,122-125).  Colour space: genome = colours, genome_ls = the letters, and a diagonal that starts at the read's first colour
+ * compares it with lstocs(genome_ls[g], init_bp) (:84-94).  sw_gapless_stats: invocations, cells (+= rlen per call, :111), time inside (here ns). */
+int  sw_gapless_setup(int match, int mismatch, bool reset_stats);
+int  sw_gapless(uint32_t *genome, int glen, uint32_t *read, int rlen, int g_idx, int r_idx, uint32_t *genome_ls, int init_bp, bool is_rna);
+void sw_gapless_stats(uint64_t *invocs, uint64_t *cells, uint64_t *ticks);
+/* batch form: call i's bitfield starts at word genome_woff[i] of `genome` (and of `genome_ls`, which is NULL in letter space; initbp may then be NULL) */
+int gm_sw_gapless_batch(int n, const uint32_t *genome, const uint32_t *genome_ls, uint64_t genome_words, const int64_t *genome_woff, const int *glen,
+                        const uint32_t *reads, int read_words, const int *rlen, const int *g_idx, const int *r_idx, const int *initbp, int *scores);
 
 /* ---------------------------------------------------------------------------------------------
  * S2: full Smith-Waterman with traceback, letter space.  ref: common/sw-full-ls.c:568-683

@@ -4,7 +4,7 @@
 // reference Itanium-mangled symbols: _Z9sw_vectorPjiiS_iS_ib and friends.  libgmapper_hip.so exports the seams with C linkage (include/gmapper_hip.h);
 // this file adds the mangled twins, each a one-line forward, so that the reference's unmodified objects link against the library once
 // common/sw-vector.o, sw-full-ls.o, sw-full-cs.o and sw-post.o are dropped from the link line (tests/test_abi.py links them).
-// Declarations follow common/sw-vector.h:3-6, sw-full-ls.h:9-13, sw-full-cs.h:7-11, sw-post.h:8-12; the two structs are only named here (their
+// Declarations follow common/sw-vector.h:3-6, sw-gapless.h:11-14, sw-full-ls.h:9-13, sw-full-cs.h:7-11, sw-post.h:8-12; the two structs are only named here (their
 // layouts are gm_sw_full_results / gm_anchor in the public header, field for field the reference's).
 #include <stdint.h>
 struct sw_full_results;
@@ -15,6 +15,9 @@ int  gmc_sw_vector_setup(int, int, int, int, int, int, int, int, int, bool) __as
 int  gmc_sw_vector_cleanup(void) __asm__("sw_vector_cleanup");
 void gmc_sw_vector_stats(uint64_t*, uint64_t*, double*) __asm__("sw_vector_stats");
 int  gmc_sw_vector(uint32_t*, int, int, uint32_t*, int, uint32_t*, int, bool) __asm__("sw_vector");
+int  gmc_sw_gapless_setup(int, int, bool) __asm__("sw_gapless_setup");
+void gmc_sw_gapless_stats(uint64_t*, uint64_t*, uint64_t*) __asm__("sw_gapless_stats");
+int  gmc_sw_gapless(uint32_t*, int, uint32_t*, int, int, int, uint32_t*, int, bool) __asm__("sw_gapless");
 int  gmc_sw_full_ls_setup(int, int, int, int, int, int, int, int, bool, int) __asm__("sw_full_ls_setup");
 int  gmc_sw_full_ls_cleanup(void) __asm__("sw_full_ls_cleanup");
 void gmc_sw_full_ls_stats(uint64_t*, uint64_t*, double*) __asm__("sw_full_ls_stats");
@@ -34,6 +37,9 @@ GM_EXPORT int sw_vector_setup(int a, int b, int c, int d, int e, int f, int g, i
 GM_EXPORT int sw_vector_cleanup(void) { return gmc_sw_vector_cleanup(); }
 GM_EXPORT void sw_vector_stats(uint64_t* a, uint64_t* b, double* c) { gmc_sw_vector_stats(a, b, c); }
 GM_EXPORT int sw_vector(uint32_t* a, int b, int c, uint32_t* d, int e, uint32_t* f, int g, bool h) { return gmc_sw_vector(a, b, c, d, e, f, g, h); }
+GM_EXPORT int sw_gapless_setup(int a, int b, bool c) { return gmc_sw_gapless_setup(a, b, c); }
+GM_EXPORT void sw_gapless_stats(uint64_t* a, uint64_t* b, uint64_t* c) { gmc_sw_gapless_stats(a, b, c); }
+GM_EXPORT int sw_gapless(uint32_t* a, int b, uint32_t* c, int d, int e, int f, uint32_t* g, int h, bool i) { return gmc_sw_gapless(a, b, c, d, e, f, g, h, i); }
 GM_EXPORT int sw_full_ls_setup(int a, int b, int c, int d, int e, int f, int g, int h, bool i, int j) { return gmc_sw_full_ls_setup(a, b, c, d, e, f, g, h, i, j); }
 GM_EXPORT int sw_full_ls_cleanup(void) { return gmc_sw_full_ls_cleanup(); }
 GM_EXPORT void sw_full_ls_stats(uint64_t* a, uint64_t* b, double* c) { gmc_sw_full_ls_stats(a, b, c); }

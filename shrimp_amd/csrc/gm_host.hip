@@ -1750,6 +1750,57 @@ extern "C" int sw_vector(uint32_t* genome, int goff, int glen, uint32_t* read, i
   return rc == GM_OK ? score : rc;
 }
 
+// ---- S1, ungapped: sw_gapless on caller bitfields (ref: common/sw-gapless.h:11-14, sw-gapless.c:29-117) -----------------------------
+// What f1_setup / f1_run call when gapless_sw is set (ref: f1-wrapper.h:66-68,122-125).  State per calling thread, like the reference's threadprivate statics.
+struct SwGaplessState { bool init = false; int match = 0, mismatch = 0; uint64_t invocs = 0, cells = 0, ticks = 0; };
+static thread_local SwGaplessState g_sg;
+extern "C" int sw_gapless_setup(int match, int mismatch, bool reset_stats) {
+  if (gm_device_count() < 1) { gm_set_error("no HIP device"); return GM_E_NODEVICE; }
+  g_sg.match = match; g_sg.mismatch = mismatch; g_sg.init = true;
+  if (reset_stats) g_sg.invocs = g_sg.cells = g_sg.ticks = 0;
+  return 0;
+}
+extern "C" void sw_gapless_stats(uint64_t* invocs, uint64_t* cells, uint64_t* ticks) {      // (ticks: nanoseconds spent inside sw_gapless on this thread; the reference counts rdtsc ticks)
+  if (invocs) *invocs = g_sg.invocs; if (cells) *cells = g_sg.cells; if (ticks) *ticks = g_sg.ticks;
+}
+// n independent calls; call i's genome bitfield starts at word genome_woff[i] of `genome` (and of `genome_ls`, colour space only: then `genome` holds colours,
+// `genome_ls` the letters of the same contig and initbp[i] the read's primer letter) and holds glen[i] positions
+extern "C" int gm_sw_gapless_batch(int n, const uint32_t* genome, const uint32_t* genome_ls, uint64_t genome_words, const int64_t* genome_woff, const int* glen,
+                                   const uint32_t* reads, int read_words, const int* rlen, const int* g_idx, const int* r_idx, const int* initbp, int* scores) {
+  if (!g_sg.init) { gm_set_error("sw_gapless called before sw_gapless_setup"); return GM_E_NOTSETUP; }
+  if (n <= 0) return GM_OK;
+  if (genome_ls && !initbp) { gm_set_error("gm_sw_gapless_batch: colour space needs initbp"); return GM_E_ARG; }
+  int max_r = 0;
+  for (int i = 0; i < n; i++) {
+    if (glen[i] < 1 || rlen[i] < 1 || g_idx[i] < 0 || r_idx[i] < 0 || g_idx[i] >= glen[i] || r_idx[i] >= rlen[i] || genome_woff[i] < 0 ||
+        (uint64_t)genome_woff[i] + ((uint64_t)glen[i] + 7) / 8 > genome_words || (rlen[i] + 7) / 8 > read_words) { gm_set_error("gm_sw_gapless_batch: call %d out of range", i); return GM_E_ARG; }
+    max_r = std::max(max_r, rlen[i]);
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  uint32_t *dg = nullptr, *dgl = nullptr, *dr = nullptr; long long* dwo = nullptr; int *dn = nullptr, *drl = nullptr, *dgi = nullptr, *dri = nullptr, *dib = nullptr, *ds = nullptr;
+  GM_HIP(hipMalloc(&dg, (genome_words + 8) * 4)); GM_HIP(hipMemset(dg, 0, (genome_words + 8) * 4)); GM_HIP(hipMemcpy(dg, genome, genome_words * 4, hipMemcpyHostToDevice));
+  if (genome_ls) { GM_HIP(hipMalloc(&dgl, (genome_words + 8) * 4)); GM_HIP(hipMemset(dgl, 0, (genome_words + 8) * 4)); GM_HIP(hipMemcpy(dgl, genome_ls, genome_words * 4, hipMemcpyHostToDevice)); }
+  GM_HIP(hipMalloc(&dr, (size_t)n * read_words * 4 + 32)); GM_HIP(hipMemcpy(dr, reads, (size_t)n * read_words * 4, hipMemcpyHostToDevice));
+  GM_HIP(hipMalloc(&dwo, (size_t)n * 8)); GM_HIP(hipMemcpy(dwo, genome_woff, (size_t)n * 8, hipMemcpyHostToDevice));
+  int** const dst[5] = {&dn, &drl, &dgi, &dri, &dib}; const int* const src[5] = {glen, rlen, g_idx, r_idx, initbp};
+  for (int k = 0; k < 5; k++) { if (!src[k]) continue; GM_HIP(hipMalloc(dst[k], (size_t)n * 4)); GM_HIP(hipMemcpy(*dst[k], src[k], (size_t)n * 4, hipMemcpyHostToDevice)); }
+  GM_HIP(hipMalloc(&ds, (size_t)n * 4));
+  int rc = gm_launch_sw_gapless_batch(n, g_sg.match, g_sg.mismatch, dg, dgl, dwo, dn, dr, read_words, drl, dgi, dri, dib, max_r, ds, 0);
+  if (rc == GM_OK) { GM_HIP(hipDeviceSynchronize()); GM_HIP(hipMemcpy(scores, ds, (size_t)n * 4, hipMemcpyDeviceToHost)); }
+  (void)hipFree(dg); if (dgl) (void)hipFree(dgl); (void)hipFree(dr); (void)hipFree(dwo); (void)hipFree(dn); (void)hipFree(drl); (void)hipFree(dgi); (void)hipFree(dri);
+  if (dib) (void)hipFree(dib); (void)hipFree(ds);
+  for (int i = 0; i < n; i++) { g_sg.invocs++; g_sg.cells += (uint64_t)rlen[i]; }              // ref: sw-gapless.c:111 (cells += rlen)
+  g_sg.ticks += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
+}
+extern "C" int sw_gapless(uint32_t* genome, int glen, uint32_t* read, int rlen, int g_idx, int r_idx, uint32_t* genome_ls, int init_bp, bool is_rna) {
+  (void)is_rna;
+  if (!g_sg.init) abort();   // ref: sw-gapless.c:66-67
+  int64_t wo = 0; int score = 0;
+  int rc = gm_sw_gapless_batch(1, genome, genome_ls, ((uint64_t)glen + 7) / 8, &wo, &glen, read, (rlen + 7) / 8, &rlen, &g_idx, &r_idx, genome_ls ? &init_bp : nullptr, &score);
+  return rc == GM_OK ? score : rc;
+}
+
 // ---- S2: full SW on caller bitfields ------------------------------------------------------------
 struct SwFullState { bool init = false; GmScoreDev sc; int dblen = 0, qrlen = 0; uint64_t invocs = 0, cells = 0; double secs = 0; };
 static thread_local SwFullState g_sf;

@@ -158,6 +158,9 @@ int gm_launch_sw_full_single(const GmScoreDev& sc, const uint32_t* d_genome, lon
                              hipStream_t stream, int has_anchor = 1, int thresh = 0, int maxscore = 0, int local = 0);   // no anchor: the threshold band; local: Gflag off
 
 // colour space S1/S2 (gm_sw.hip): cs_params9 = match mismatch xover a_go a_ge b_go b_ge anchor_width indel_taboo_len (penalties positive)
+int gm_launch_sw_gapless_batch(int n, int match, int mismatch, const uint32_t* d_genome, const uint32_t* d_genome_ls, const long long* d_woff, const int* d_glen,
+                               const uint32_t* d_reads, int read_words, const int* d_rlen, const int* d_gidx, const int* d_ridx, const int* d_initbp, int max_r,
+                               int* d_scores, hipStream_t stream);
 int gm_launch_sw_vector_batch_cs(const GmScoreDev& sc, int n, const uint32_t* d_genome_cs, const uint32_t* d_genome_ls, const long long* d_goff,
                                  const int* d_glen, const uint32_t* d_reads, int read_words, const int* d_rlen, const int* d_initbp, int max_g, int max_r,
                                  int* d_scores, hipStream_t stream);

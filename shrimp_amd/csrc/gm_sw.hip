@@ -1332,6 +1332,71 @@ int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs
   return GM_OK;
 }
 
+// S1's ungapped filter at the seam (ref: common/sw-gapless.c:57-117): call i scores the diagonal of its own genome bitfield (window i starts at word
+// woff[i]) through (g_idx, r_idx); with genome_ls the read's first colour is forced against lstocs(letter, init_bp) (:84-94).  One wave per call: the wave
+// routine above on a bitfield that starts at the call's first word; the forced first colour enters as the running score's start value.
+__global__ void __launch_bounds__(GM_WAVE)
+k_sw_gapless_batch(int n, int match, int mismatch, const uint32_t* __restrict__ genome, const uint32_t* __restrict__ genome_ls, const long long* __restrict__ woff,
+                   const int* __restrict__ glen, const uint32_t* __restrict__ reads, int read_words, const int* __restrict__ rlen, const int* __restrict__ g_idx,
+                   const int* __restrict__ r_idx, const int* __restrict__ initbp, int max_r, int* __restrict__ scores) {
+  extern __shared__ __align__(16) uint8_t gl_smem[];
+  uint8_t* qr = gl_smem;
+  const int lane = threadIdx.x;
+  GmScoreDev sc; sc.match = match; sc.mismatch = mismatch;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const uint32_t* g = genome + woff[i]; const uint32_t* rw = reads + (size_t)i * read_words;
+    const int rl = rlen[i], gn = glen[i];
+    __syncthreads();
+    for (int k = lane; k < rl; k += GM_WAVE) qr[k] = (uint8_t)((rw[k >> 3] >> ((k & 7) * 4)) & 0xf);
+    __syncthreads();
+    long long gi = g_idx[i]; int ri = r_idx[i];
+    int head = 0, skip = 0;
+    if (genome_ls && gi >= ri) {                       // r_left == 0: the first colour is compared with the letter at g_left and the primer
+      const long long gl0 = gi - ri;
+      const uint32_t* gls = genome_ls + woff[i];
+      const int letter = (int)((gls[gl0 >> 3] >> ((gl0 & 7) * 4)) & 0xf);
+      head = (cs_lstocs(letter, initbp[i]) == (int)qr[0]) ? match : 0;
+      skip = 1;
+    }
+    // the rest of the diagonal: positions (g_left + skip + k, r_left + skip + k); a start value `head` >= 0 is a first cell of that score
+    int best;
+    if (!skip) best = sw_gapless_wave(g, 0ull, (long long)gn, qr, rl, gi, ri, sc, lane);
+    else {
+      // shift the diagonal by one cell and prepend the start value: max-subarray with an initial running score
+      const long long g_left = gi - ri + 1; const int r_left = 1;
+      const long long room = (long long)gn - g_left;
+      const int m = (int)(room < (long long)(rl - r_left) ? room : (long long)(rl - r_left));
+      int carry_sum = head, carry_min = 0; best = head;
+      for (int k0 = 0; k0 < m; k0 += GM_WAVE) {
+        const int k = k0 + lane; int sv = 0;
+        if (k < m) { const uint64_t p = (uint64_t)g_left + (uint64_t)k; const uint32_t gc = (g[p >> 3] >> ((p & 7) * 4)) & 0xf; sv = (gc == (uint32_t)qr[r_left + k]) ? match : mismatch; }
+        int ps = sv;
+        for (int d = 1; d < GM_WAVE; d <<= 1) { const int o = __shfl_up(ps, d); if (lane >= d) ps += o; }
+        ps += carry_sum;
+        int pm = ps;
+        for (int d = 1; d < GM_WAVE; d <<= 1) { const int o = __shfl_up(pm, d); if (lane >= d) pm = min(pm, o); }
+        int excl = __shfl_up(pm, 1); if (lane == 0) excl = INT_MAX;
+        excl = min(excl, carry_min);
+        if (k < m) best = max(best, ps - excl);
+        carry_sum = __shfl(ps, GM_WAVE - 1);
+        carry_min = min(carry_min, __shfl(pm, GM_WAVE - 1));
+      }
+      for (int d = 32; d > 0; d >>= 1) best = max(best, __shfl_xor(best, d));
+    }
+    if (lane == 0) scores[i] = best;
+  }
+}
+int gm_launch_sw_gapless_batch(int n, int match, int mismatch, const uint32_t* d_genome, const uint32_t* d_genome_ls, const long long* d_woff, const int* d_glen,
+                               const uint32_t* d_reads, int read_words, const int* d_rlen, const int* d_gidx, const int* d_ridx, const int* d_initbp, int max_r,
+                               int* d_scores, hipStream_t stream) {
+  if (n == 0) return GM_OK;
+  const size_t lds = ((size_t)max_r + 15) & ~(size_t)15;
+  hipLaunchKernelGGL(k_sw_gapless_batch, dim3(std::min(n, 256 * 16)), dim3(GM_WAVE), lds, stream, n, match, mismatch, d_genome, d_genome_ls, d_woff, d_glen, d_reads,
+                     read_words, d_rlen, d_gidx, d_ridx, d_initbp, max_r, d_scores);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
 int gm_launch_sw_vector_batch_cs(const GmScoreDev& sc, int n, const uint32_t* d_genome_cs, const uint32_t* d_genome_ls, const long long* d_goff,
                                  const int* d_glen, const uint32_t* d_reads, int read_words, const int* d_rlen, const int* d_initbp, int max_g, int max_r,
                                  int* d_scores, hipStream_t stream) {

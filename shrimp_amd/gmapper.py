@@ -107,6 +107,7 @@ class SwFullResults(C.Structure):   # struct gm_sw_full_results == the reference
 EXPORTS = ["gm_map_pairs_file", "gm_map_pairs_cs_fastq", "gm_map_reads_file", "gm_merge_options_default", "gm_merge_sam", "gm_release_cache", "gm_map_pairs_cs", "gm_last_error", "gm_device_count", "gm_params_default", "gm_params_default_cs", "gm_index_build", "gm_index_free", "gm_index_list_cutoff",
            "gm_index_save", "gm_index_load", "gm_index_bytes", "gm_index_n_slabs", "gm_index_has_buckets", "gm_index_get_list", "gm_index_device_array", "gm_index_meta", "gm_index_alloc_like",
            "sw_vector_setup", "sw_vector", "sw_vector_stats", "sw_vector_cleanup", "gm_sw_vector_batch", "gm_sw_vector_batch_bounded",
+           "sw_gapless_setup", "sw_gapless", "sw_gapless_stats", "gm_sw_gapless_batch",
            "sw_full_ls_setup", "sw_full_ls", "sw_full_ls_cleanup", "sw_full_ls_stats",
            "sw_full_cs_setup", "sw_full_cs", "sw_full_cs_cleanup", "sw_full_cs_stats", "gm_sw_vector_batch_cs",
            "post_sw_setup", "post_sw", "post_sw_cleanup", "post_sw_stats",
@@ -148,6 +149,10 @@ def lib():
     L.gm_sw_vector_batch.argtypes = [C.c_int, u32p, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int), u32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.gm_sw_vector_batch_bounded.argtypes = [C.c_int, u32p, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int), u32p, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
                                              C.POINTER(C.c_uint8)]
+    L.sw_gapless_setup.argtypes = [C.c_int, C.c_int, C.c_bool]
+    L.sw_gapless.argtypes = [u32p, C.c_int, u32p, C.c_int, C.c_int, C.c_int, u32p, C.c_int, C.c_bool]
+    L.gm_sw_gapless_batch.argtypes = [C.c_int, u32p, u32p, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int), u32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.sw_full_ls_setup.argtypes = [C.c_int] * 8 + [C.c_bool, C.c_int]
     L.sw_full_ls.argtypes = [u32p, C.c_int, C.c_int, u32p, C.c_int, C.c_int, C.c_int, C.POINTER(SwFullResults), C.c_bool, C.POINTER(Anchor), C.c_int, C.c_int]
     L.sw_full_ls.restype = None
@@ -568,6 +573,33 @@ def sw_vector(genome_words, goff, glen, read_words, rlen, genome_ls=None, initbp
     return lib().sw_vector(g.ctypes.data_as(C.POINTER(C.c_uint32)), goff, glen, r.ctypes.data_as(C.POINTER(C.c_uint32)), rlen, gl, initbp, False)
 
 
+def sw_gapless_setup(match, mismatch, reset_stats=True):
+    _check(lib().sw_gapless_setup(match, mismatch, reset_stats), "sw_gapless_setup")
+
+
+def sw_gapless_batch(genome_words, genome_woff, glen, reads_words, rlen, g_idx, r_idx, genome_ls=None, initbp=None) -> np.ndarray:
+    """n calls of the ungapped filter (ref: sw-gapless.c:57-117): call i's bitfield starts at word genome_woff[i]; colour space: genome_ls + initbp"""
+    L = lib()
+    g = np.ascontiguousarray(genome_words, dtype=np.uint32); r = np.ascontiguousarray(reads_words, dtype=np.uint32)
+    n = r.shape[0]
+    u32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32)); ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    wo = np.ascontiguousarray(genome_woff, dtype=np.int64); out = np.zeros(n, dtype=np.int32)
+    gn, rl, gi, ri = (np.ascontiguousarray(a, dtype=np.int32) for a in (glen, rlen, g_idx, r_idx))
+    gl = np.ascontiguousarray(genome_ls, dtype=np.uint32) if genome_ls is not None else None
+    ib = np.ascontiguousarray(initbp, dtype=np.int32) if initbp is not None else None
+    _check(L.gm_sw_gapless_batch(n, u32(g), u32(gl) if gl is not None else None, g.size if gl is None else min(g.size, gl.size), wo.ctypes.data_as(C.POINTER(C.c_int64)), ip(gn),
+                                 u32(r), r.shape[1], ip(rl), ip(gi), ip(ri), ip(ib) if ib is not None else None, ip(out)), "gm_sw_gapless_batch")
+    return out
+
+
+def sw_gapless(genome_words, glen, read_words, rlen, g_idx, r_idx, genome_ls=None, init_bp=-1) -> int:
+    g = np.ascontiguousarray(genome_words, dtype=np.uint32); r = np.ascontiguousarray(read_words, dtype=np.uint32)
+    gl = None
+    if genome_ls is not None:
+        gla = np.ascontiguousarray(genome_ls, dtype=np.uint32); gl = gla.ctypes.data_as(C.POINTER(C.c_uint32))
+    return lib().sw_gapless(g.ctypes.data_as(C.POINTER(C.c_uint32)), glen, r.ctypes.data_as(C.POINTER(C.c_uint32)), rlen, g_idx, r_idx, gl, init_bp, False)
+
+
 def sw_full_ls_setup(dblen, qrlen, a_gap_open, a_gap_ext, b_gap_open, b_gap_ext, match, mismatch, reset_stats=True, anchor_width=8):
     _check(lib().sw_full_ls_setup(dblen, qrlen, a_gap_open, a_gap_ext, b_gap_open, b_gap_ext, match, mismatch, reset_stats, anchor_width), "sw_full_ls_setup")
 
@@ -626,6 +658,11 @@ def sw_full_cs(genome_ls, goff, glen, read_words, rlen, initbp, thresh, anchor, 
 def seam_stats(which):
     """(invocations, cells, seconds) of this thread's sw_vector / sw_full_ls / sw_full_cs / post_sw calls (ref: the *_stats functions gmapper.c:734-745 reads)."""
     L = lib()
+    if which == "sw_gapless":                                 # (invocations, cells, ns): three integers, as sw-gapless.h:12 declares them
+        inv, cells, ticks = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        L.sw_gapless_stats.restype = None
+        L.sw_gapless_stats(C.byref(inv), C.byref(cells), C.byref(ticks))
+        return inv.value, cells.value, ticks.value
     inv, cells, secs = C.c_uint64(0), C.c_uint64(0), C.c_double(0)
     fn = getattr(L, {"sw_vector": "sw_vector_stats", "sw_full_ls": "sw_full_ls_stats", "sw_full_cs": "sw_full_cs_stats", "post_sw": "post_sw_stats"}[which])
     fn.restype = None if which != "post_sw" else C.c_int

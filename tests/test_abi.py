@@ -68,7 +68,7 @@ def test_sw_vector_setup_range_check(gm):
 
 def test_reference_objects_link_against_the_library(gm, tmp_path):
     """INTEGRATION.md section A, literally: the reference's own objects (gmapper/*.o and common/*.o as oracle/Makefile.ref compiles them from
-    /root/reference) minus sw-vector.o, sw-full-ls.o, sw-full-cs.o and sw-post.o link against libgmapper_hip.so without an unresolved symbol --
+    /root/reference) minus sw-vector.o, sw-gapless.o, sw-full-ls.o, sw-full-cs.o and sw-post.o link against libgmapper_hip.so without an unresolved symbol --
     the library exports the C++-linkage names those objects reference (ref: common/util.h:8-10 has extern "C" commented out).  Link only:
     nothing runs here (no GPU), and nothing of the reference travels in source form."""
     objdir = os.path.join(ROOT, "oracle", "_ref", "obj")
@@ -77,9 +77,9 @@ def test_reference_objects_link_against_the_library(gm, tmp_path):
             pytest.skip("reference objects not built and /root/reference absent (GPU box)")
         subprocess.run(["make", "-f", os.path.join("oracle", "Makefile.ref"), "-j8"], cwd=ROOT, check=True, capture_output=True)
     import glob
-    dropped = {"sw-vector.o", "sw-full-ls.o", "sw-full-cs.o", "sw-post.o"}
+    dropped = {"sw-vector.o", "sw-gapless.o", "sw-full-ls.o", "sw-full-cs.o", "sw-post.o"}
     objs = sorted(glob.glob(os.path.join(objdir, "gmapper", "*.o"))) + [o for o in sorted(glob.glob(os.path.join(objdir, "common", "*.o"))) if os.path.basename(o) not in dropped]
-    assert len(objs) == 5 + 10, objs
+    assert len(objs) == 5 + 9, objs
     exe = str(tmp_path / "gmapper-seams")
     r = subprocess.run(["g++", "-fopenmp", "-o", exe, *objs, "-L" + os.path.dirname(gm.LIB_PATH), "-lgmapper_hip", "-Wl,-rpath," + os.path.dirname(gm.LIB_PATH),
                         "-Wl,-rpath-link,/opt/rocm/lib", "-lm", "-lz", "-lstdc++", "-lrt"], capture_output=True, text=True)
@@ -87,8 +87,29 @@ def test_reference_objects_link_against_the_library(gm, tmp_path):
     # the symbols the dropped objects used to define are now undefined in the program and defined (mangled, as the objects spell them) by the library
     und = subprocess.run(["nm", "-u", exe], capture_output=True, text=True, check=True).stdout
     lib = subprocess.run(["nm", "-D", "--defined-only", gm.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    for sym in ("_Z9sw_vectorPjiiS_iS_ib", "_Z15sw_vector_setupiiiiiiiiib", "_Z10sw_full_lsPjiiS_iiiP15sw_full_resultsbP6anchorii", "_Z16sw_full_ls_statsPmS_Pd",
+    for sym in ("_Z9sw_vectorPjiiS_iS_ib", "_Z15sw_vector_setupiiiiiiiiib", "_Z10sw_gaplessPjiS_iiiS_ib", "_Z16sw_gapless_setupiib", "_Z16sw_gapless_statsPmS_S_", "_Z10sw_full_lsPjiiS_iiiP15sw_full_resultsbP6anchorii", "_Z16sw_full_ls_statsPmS_Pd",
                 "_Z10sw_full_csPjiiS_iiiP15sw_full_resultsbbP6anchoriiPi", "_Z16sw_full_cs_statsPmS_Pd", "_Z13post_sw_setupiddddddbbiib", "_Z7post_swPjiPcP15sw_full_results",
                 "_Z13post_sw_statsPmS_Pd", "_Z15post_sw_cleanupv"):
         assert sym in und, sym
         assert sym in lib, sym
+
+
+def test_seam_driver_links_by_the_mangled_names(gm, tmp_path):
+    """tests/seam_driver.cpp (the program the GPU parity test runs over every known-answer record) declares the seams with C++ linkage, as the reference's
+    headers do: it must link against the library, resolving the Itanium-mangled names to the library's exports.  Link only (no GPU here)."""
+    exe = str(tmp_path / "seam_driver")
+    libdir = os.path.dirname(gm.LIB_PATH)
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "seam_driver.cpp"), "-L" + libdir, "-lgmapper_hip", "-Wl,-rpath," + libdir,
+                        "-Wl,-rpath-link,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    und = subprocess.run(["nm", "-u", exe], capture_output=True, text=True, check=True).stdout
+    lib = subprocess.run(["nm", "-D", "--defined-only", gm.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for sym in ("_Z9sw_vectorPjiiS_iS_ib", "_Z10sw_gaplessPjiS_iiiS_ib", "_Z10sw_full_lsPjiiS_iiiP15sw_full_resultsbP6anchorii",
+                "_Z10sw_full_csPjiiS_iiiP15sw_full_resultsbbP6anchoriiPi", "_Z7post_swPjiPcP15sw_full_results", "_Z13post_sw_setupiddddddbbiib"):
+        assert sym in und and sym in lib, sym
+
+
+def test_nothing_built_from_the_reference_travels_to_the_gpu_box():
+    """oracle/_ref/ (the reference compiled by oracle/Makefile.ref) is kept out of history AND out of the gpurun snapshot"""
+    assert "oracle/_ref/" in open(os.path.join(ROOT, ".gitignore")).read().split()
+    assert "oracle/_ref/" in open(os.path.join(ROOT, ".gpurunignore")).read().split()

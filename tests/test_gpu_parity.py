@@ -749,30 +749,84 @@ def _write_fasta(path, names, seqs):
                 f.write(t[k:k + 70].tobytes() + b"\n")
 
 
-@pytest.mark.parametrize("mode", ["ls", "cs"])
-def test_reference_program_on_the_library_seams(gm, mode, tmp_path):
-    """Drop-in at S1-S3, literally: the reference's own gmapper program, linked in the build container from its unmodified objects minus
-    sw-vector.o / sw-full-ls.o / sw-full-cs.o / sw-post.o against libgmapper_hip.so (oracle/Makefile.ref `seams`), maps the
-    first reads of a golden here on the GPU: its SAM must be the golden's (which stock gmapper produced).  Exercises sw_vector_setup / sw_vector /
-    sw_full_ls (ls) and the colour forms + sw_full_cs + post_sw (cs) through the C++-linkage names the reference's objects call."""
+def _seam_driver(tmp_path):
+    """tests/seam_driver.cpp compiled here (g++) against libgmapper_hip.so: it calls the seams by the reference's C++-linkage (mangled) names"""
     import subprocess
-    exe = os.path.join(oa.ROOT, "oracle", "_ref", "gmapper-seams-" + mode)
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/gmapper-seams-* is built where /root/reference exists (make -f oracle/Makefile.ref seams)")
-    from shrimp_amd import synth
-    name, n = ("cfg1_36bp_1Mbp", 150) if mode == "ls" else ("cfg4s_50col_2Mbp", 60)
-    contigs, reads, sam = oa.load_golden(name)
-    g = str(tmp_path / "g.fa"); r = str(tmp_path / ("r.fa" if mode == "ls" else "r.csfasta"))
-    _write_fasta(g, [b"contig%d" % (i + 1) for i in range(len(contigs))], contigs)
-    if mode == "ls": _write_fasta(r, [b"r%d" % i for i in range(n)], list(reads[:n]))
-    else: synth.write_csfasta_reads(r, reads[:n])
-    p = subprocess.run([exe, "-N", "1", r, g], capture_output=True, timeout=900)
+    from shrimp_amd import gmapper
+    exe = str(tmp_path / "seam_driver")
+    libdir = os.path.dirname(gmapper.LIB_PATH)
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(oa.ROOT, "tests", "seam_driver.cpp"), "-L" + libdir, "-lgmapper_hip", "-Wl,-rpath," + libdir,
+                        "-Wl,-rpath-link,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return exe
+
+
+def _hexw(a): return ",".join("%x" % int(x) for x in a)
+
+
+def test_mangled_seams_on_every_known_answer(gm, tmp_path):
+    """Drop-in at S1-S3 through the names the reference's objects reference (_Z9sw_vectorPjiiS_iS_ib, _Z10sw_gaplessPjiS_iiiS_ib, _Z10sw_full_lsPji...,
+    _Z10sw_full_csPji..., _Z7post_swPjiPcP15sw_full_results; ref: sw-vector.h:3-6, sw-gapless.h:11-14, sw-full-ls.h:9-13, sw-full-cs.h:7-11, sw-post.h:8-12):
+    a C++ program of our own (tests/seam_driver.cpp), linked against the library, replays EVERY known-answer record the reference's functions produced --
+    1 500 sw_vector + 700 colour-space sw_vector, 2 400 sw_gapless (letter and colour space), 2 990 sw_full_ls, 1 400 sw_full_cs and 1 833 post_sw
+    (with and without quality values; posterior compared to the last bit, %a) -- on the GPU."""
+    import gzip, subprocess
+    exe = _seam_driver(tmp_path)
+    req, want = [], []
+    req += ["setup_v 0 -15", "setup_f_ls"]
+    nV = nF = 0
+    for rec in oa.load_kat():
+        if rec[0] == "V":
+            _, goff, glen, rlen, g, r, score = rec
+            req.append("V %d %d %d %s %s" % (goff, glen, rlen, _hexw(g), _hexw(r))); want.append("V %d" % score); nV += 1
+        else:
+            _, goff, glen, rlen, ax, ay, alen, aw, rv, g, r, exp, edb, eqr = rec
+            req.append("F %d %d %d %d %d %d %d %d %s %s" % (goff, glen, rlen, ax, ay, alen, aw, rv, _hexw(g), _hexw(r)))
+            want.append("F " + " ".join(str(x) for x in exp) + " %s %s" % (edb, eqr)); nF += 1
+    req += ["setup_v 1 -10", "setup_f_cs"]
+    cs = oa.load_kat_cs(); srecs = [r for r in cs if r[0] == "S"]
+    for r in cs:
+        if r[0] == "C":
+            _, goff, glen, rlen, initbp, gcs, gls, rd, score = r
+            req.append("C %d %d %d %d %s %s %s" % (goff, glen, rlen, initbp, _hexw(gcs), _hexw(gls), _hexw(rd))); want.append("C %d" % score)
+    def s_args(r):
+        _, (goff, glen, rlen, initbp, ax, ay, alen, awidth, rv, thresh), gls, rd, w, db, qr = r
+        return "%d %d %d %d %d %d %d %d %d %d %s %s" % (goff, glen, rlen, initbp, ax, ay, alen, awidth, rv, thresh, _hexw(gls), _hexw(rd))
+    for r in srecs:
+        w, db, qr = r[4], r[5], r[6]
+        req.append("S " + s_args(r))
+        want.append("S " + " ".join(str(x) for x in w) + " %s %s" % ((db or b"-").decode(), (qr or b"-").decode()) if w[0] != 0 else None)      # score 0: nothing else is defined
+    with gzip.open(os.path.join(oa.ROOT, "tests", "golden", "sw_kat_post.txt.gz"), "rt") as f: post = [l.split() for l in f if l.strip()]
+    K = [t for t in post if t[0] == "K"][0][1:]
+    nP = 0
+    for useq in (0, 1):
+        req.append("setup_p %d %s" % (useq, " ".join(K)))
+        for t in post:
+            if t[0] != "P" or int(t[2]) != useq: continue
+            req.append("P %s %s" % (t[3], s_args(srecs[int(t[1])]))); want.append("P " + " ".join(t[4:])); nP += 1
+    nG = 0
+    with gzip.open(os.path.join(oa.ROOT, "tests", "golden", "sw_kat_gapless.txt.gz"), "rt") as f: gl = [l.split() for l in f if l.startswith("G ")]
+    for half, mm in ((0, -15), (1, -24)):
+        req.append("setup_g 10 %d" % mm)
+        for t in gl:
+            if (t[5] != "-1") != bool(half): continue
+            req.append(" ".join(t[:-1])); want.append("G " + t[-1]); nG += 1
+    req.append("stats")
+    assert nV >= 1500 and nF >= 2990 and len(srecs) >= 1400 and nP >= 1800 and nG >= 2400
+    p = subprocess.run([exe], input=("\n".join(req) + "\n").encode(), capture_output=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-2000:]
-    got = [l for l in p.stdout.split(b"\n") if l and not l.startswith(b"@")]
-    first = {b"r%d" % i for i in range(n)}
-    want = [l for l in sam.split(b"\n") if l and not l.startswith(b"@") and l.split(b"\t")[0] in first]
-    assert len(want) >= n // 2
-    assert got == want, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want)))
+    got = p.stdout.decode().split("\n")
+    assert got[-1] == "" and len(got) == len(want) + 2, (len(got), len(want))
+    bad = []
+    for i, w in enumerate(want):
+        if w is None:
+            if not got[i].startswith("S 0 "): bad.append((i, got[i][:200], "S 0 ..."))
+        elif got[i] != w: bad.append((i, got[i][:300], w[:300]))
+    assert not bad, (len(bad), bad[:5])
+    st = [int(x) for x in got[len(want)].split()[1:]]
+    # the *_stats entries (ref: gmapper.c:734-745 reads them): every set-up above resets its counters, so each shows the calls since its last set-up
+    nq = sum(1 for t in post if t[0] == "P" and t[2] == "1")
+    assert st == [700, nG // 2, nF, len(srecs) + nP, nq], st
 
 
 def test_full_size_genome_vs_oracle(gm, oracle_lib):

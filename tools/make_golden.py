@@ -226,6 +226,19 @@ def cs_kat_cases():
     print("sw_kat_cs:", kat.count(b"\nC ") + 1, "colour-space vector,", kat.count(b"\nS "), "sw_full_cs")
 
 
+def post_kat_cases():
+    """the reference's own post_sw() on its own sw_full_cs results of sw_kat_cs.txt.gz (oracle/ref_kat_post.cpp), and its own sw_gapless() (oracle/ref_kat_gapless.cpp)"""
+    src = gzip.open(os.path.join(OUT, "sw_kat_cs.txt.gz"), "rb").read()
+    kat = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_kat_post")], input=src, capture_output=True, check=True).stdout
+    with gzip.open(os.path.join(OUT, "sw_kat_post.txt.gz"), "wb", compresslevel=9) as f:
+        f.write(kat)
+    print("sw_kat_post:", kat.count(b"\nP "), "post_sw answers")
+    kat = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_kat_gapless"), "1200"], capture_output=True, check=True).stdout
+    with gzip.open(os.path.join(OUT, "sw_kat_gapless.txt.gz"), "wb", compresslevel=9) as f:
+        f.write(kat)
+    print("sw_kat_gapless:", kat.count(b"\nG ") + 1, "sw_gapless answers")
+
+
 def run_cs_case(name, contigs, reads, extra=()):
     """colour-space reads (codes[n, 1 + colours]) through the reference's gmapper-cs"""
     with tempfile.TemporaryDirectory() as d:
@@ -391,6 +404,8 @@ def main():
         cs_kat_cases(); return
     if "--local-kat-only" in sys.argv:
         local_kat_cases(); return
+    if "--post-kat-only" in sys.argv:
+        post_kat_cases(); return
     if "--index-only" in sys.argv:
         index_cases(); return
     if "--options-only" in sys.argv:
@@ -412,6 +427,7 @@ def main():
     option_cases()
     index_cases()
     cs_kat_cases()
+    post_kat_cases()
     local_kat_cases()
     cs_cases()
     fastq_cases()
