@@ -11,8 +11,11 @@ Workloads:
   cfg4           50-colour SOLiD reads (one indel, 4 % colour errors) vs the 3.0 Gbp genome (BASELINE configs[3]): sw_full_cs + post_sw path
   cfg5           2 x 150 bp opp-in pairs, -I 100,600, vs the 3.0 Gbp genome (BASELINE configs[4]): paired-mode path; unit = pairs/s
   (cfg4 / cfg5 go through the host-buffer entry points: packed reads are uploaded every step, 26 / 152 bytes per unit.)
-N > 1: launched by torch.distributed.run, one rank per GPU; rank 0 builds the index, its arrays are broadcast once over RCCL (no per-step
-collective); every rank maps its own read shard (weak scaling: R units per rank per step).  Prints ONE JSON line on rank 0.
+N > 1: one rank per GPU (torch.distributed, backend nccl = RCCL); rank 0 builds the index, its arrays are broadcast once over RCCL (no per-step
+collective); every rank maps its own read shard (weak scaling: R units per rank per step).  Prints ONE JSON line on rank 0.  The ranks come either from
+the caller (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: WORLD_SIZE must then equal --gpus) or from this script: a plain
+`python bench.py --gpus N` starts them itself as a CHILD torch.distributed.run (launch_ranks; the parent never touches the GPU and exits with the child's code).
+The default N = 1 line also carries `other_workloads`: cfg4 and cfg5, three steps each, with their own roofline and parity-sample fields.
 """
 import argparse, json, os, sys, time
 
@@ -55,6 +58,21 @@ def host_threads_for(local_world: int) -> int:
     return max(1, min(32, n_cores // max(1, local_world)))
 
 
+def launch_ranks(n: int, argv, capture: bool = False, timeout=None):
+    """Start `n` ranks of this script on this node: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port P bench.py argv`
+    as a child process (never an exec: the caller may not have initialised HIP, and must not be replaced once it has).  Returns the child's exit code
+    (with capture: (code, stdout, stderr)).  The reference's analogue is the OpenMP chunk loop of launch_scan_threads (ref: gmapper/gmapper.c:322-345,588-607)."""
+    import socket, subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("OMP_NUM_THREADS", "1")
+    if capture:
+        p = subprocess.run(cmd, env=env, capture_output=True, timeout=timeout)
+        return p.returncode, p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
+    return subprocess.run(cmd, env=env, timeout=timeout).returncode
+
+
 def selftest_ranks(steps: int = 3, units: int = 1000):
     """The N > 1 logic of main() without a GPU (gloo): per-rank seeds, barrier-bracketed timing, MAX over ranks, rank-0-only JSON.
     A step is a sleep that grows with the rank, so that the slowest rank decides.  Used by tests/test_dist_gloo.py."""
@@ -70,16 +88,102 @@ def selftest_ranks(steps: int = 3, units: int = 1000):
     for _ in range(steps): time.sleep(per_step)
     if world > 1: dist.barrier()
     dt = reduce_max_time(time.perf_counter() - t0, world, dist, torch.device("cpu"))
-    allseeds = [None] * world; allstep = [None] * world
+    allseeds = [None] * world; allstep = [None] * world; allthr = [None] * world
     if world > 1:
-        dist.all_gather_object(allseeds, seeds); dist.all_gather_object(allstep, per_step)
+        dist.all_gather_object(allseeds, seeds); dist.all_gather_object(allstep, per_step); dist.all_gather_object(allthr, host_threads_for(local_world))
     else:
-        allseeds, allstep = [seeds], [per_step]
+        allseeds, allstep, allthr = [seeds], [per_step], [host_threads_for(local_world)]
     if rank == 0:
         print(json.dumps({"selftest": True, "value": units * steps * world / dt, "n_gpus": world, "steps": steps, "ms_per_step": 1e3 * dt / steps, "scaling": "weak",
-                          "seeds": allseeds, "rank_step_s": allstep, "units_per_rank_step": units, "host_threads_per_rank": host_threads_for(local_world)}))
+                          "seeds": allseeds, "rank_step_s": allstep, "units_per_rank_step": units, "host_threads_per_rank": host_threads_for(local_world),
+                          "host_threads": allthr}))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
+
+
+def make_pools(synth, contigs, kind, R, L, rseed, rank, n_pool, dev):
+    """n_pool distinct synthetic batches for this rank (letter space: packed and resident in HBM; colour space / pairs: packed host buffers)"""
+    import torch
+    pools = []
+    for b in range(n_pool):
+        sd = shard_seed(rseed, rank, n_pool, b)
+        if kind == "ls":
+            reads, _ = synth.make_reads(contigs, R, L, sd)
+            pools.append(torch.from_numpy(synth.pack_reads(reads).view(np.int32)).to(dev))          # resident in HBM
+        elif kind == "cs":
+            reads, _ = synth.make_cs_reads(contigs, R, L, sd)
+            pools.append((np.ascontiguousarray(synth.pack_reads(np.ascontiguousarray(reads[:, 1:]))), np.ascontiguousarray(reads[:, 0])))
+        else:
+            reads, _ = synth.make_pairs(contigs, R, L, sd)
+            pools.append((np.ascontiguousarray(synth.pack_reads(np.ascontiguousarray(reads[0::2]))), np.ascontiguousarray(synth.pack_reads(np.ascontiguousarray(reads[1::2])))))
+    return pools
+
+
+def make_sample(synth, contigs, kind, n, L, rseed):
+    if kind == "ls": return synth.make_reads(contigs, n, L, rseed + 104729)[0]
+    if kind == "cs": return synth.make_cs_reads(contigs, n, L, rseed + 104729)[0]
+    return synth.make_pairs(contigs, n, L, rseed + 104729)[0]
+
+
+def timed_steps(gm, sess, kind, pools, R, L, steps, warmup, world, dist, dev, emit_sam=True):
+    """W untimed steps, then EXACTLY `steps` timed ones between barrier + synchronize on both sides; the job's time is the slowest rank's.
+    Returns (seconds, K1 event milliseconds, K1 algorithmic bytes, K1 launches, summed stats)."""
+    import torch
+    popts = gm.PairOpts.default("opp-in", 100, 600)
+    n_pool = len(pools)
+
+    def step(i):
+        p = pools[i % n_pool]
+        if kind == "ls": sess.map_device(p.data_ptr(), R, L, emit_sam=emit_sam, return_bytes=False)
+        elif kind == "cs": sess.map_cs_packed(p[0], p[1], R, L, return_bytes=False)
+        else: sess.map_pairs_packed(p[0], p[1], R, L, L, popts, return_bytes=False)
+        return sess.stats
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    lk_ms = 0.0; lk_bytes = 0; lk_launch = 0
+    agg = {}
+    t0 = time.perf_counter()
+    for i in range(steps):
+        st = step(warmup + i)
+        ms, nb, nl = sess.lookup_timing()                    # K1's own HIP events on its stream (paired mode: both mate sets of every sub-batch)
+        lk_ms += ms; lk_bytes += (nb or st["list_bytes"]); lk_launch += nl
+        for k, v in st.items():
+            agg[k] = agg.get(k, 0) + v
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = reduce_max_time(time.perf_counter() - t0, world, dist, dev)
+    return dt, lk_ms, lk_bytes, lk_launch, agg
+
+
+def roofline_of(gm, lk_ms, lk_bytes, lk_launch, units):
+    """dominant kernel = seed lookup (K1): algorithmic bytes (12 B per lookup + 4 B per list entry) / its own HIP-event time"""
+    ach = (lk_bytes / 1e9) / (lk_ms / 1e3) if lk_ms > 0 else 0.0
+    kname = gm.lib().gm_last_lookup_kernel().decode()       # k_lookup_bkt (one slab, short lists), k_lookup_v4 (folded count), k_lookup_v3 (slab sweep), k_lookup_v5
+    return {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+            "traffic": None,       # HBM bytes are not measurable inside this run; see traffic_from_profile
+            "kernel": kname, "launches": lk_launch, "avg_launch_ms": lk_ms / max(1, lk_launch), "alg_bytes_per_launch": lk_bytes / max(1, lk_launch),
+            "alg_bytes_per_unit": lk_bytes / max(1, units)}
+
+
+def oracle_sample(oa, o, kind, sample, ncores):
+    """the CPU restatement on a bounded sample: (seconds, SAM text)"""
+    t0 = time.perf_counter()
+    if kind == "pairs":
+        o.set_pairing("opp-in", 100, 600); sam = o.map_pairs_sam(sample[0::2], sample[1::2], nthreads=ncores)
+    else:
+        sam = o.map_sam(sample, nthreads=ncores)
+    return time.perf_counter() - t0, sam
+
+
+def product_sample(sess, kind, sample):
+    if kind == "ls": return sess.map_reads(sample)
+    if kind == "cs": return sess.map_reads_cs(sample)
+    return sess.map_pairs(sample[0::2], sample[1::2], mode="opp-in", min_insert=100, max_insert=600)
 
 
 def main():
@@ -93,19 +197,47 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="units in the CPU-baseline sample; 0 = the workload's default (10-30 s of CPU work)")
     ap.add_argument("--no-sam", action="store_true", help="skip SAM text emission on the host (alignment records only; letter-space unpaired only)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the cfg4 / cfg5 entries of the default line")
+    ap.add_argument("--selftest-ranks", action="store_true", help="rank logic only (gloo, sleeps instead of GPU steps): what tests/test_dist_gloo.py drives through launch_ranks")
     args = ap.parse_args()
 
+    have_ranks = "WORLD_SIZE" in os.environ
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not have_ranks and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks as a child job.  This process has not touched the GPU (device_count() does not initialise HIP).
+        if not args.selftest_ranks:
+            import torch
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, have))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: the launcher's rank count and --gpus must agree (n_gpus in the JSON is the number of ranks that ran)" % (args.gpus, world))
+    if args.selftest_ranks:
+        return selftest_ranks()
+
+    # The library measured: the release build (make release: no tuning knobs compiled in) when it is there -- unless the caller asks for a build (GM_LIB_PATH) or sets
+    # one of the kernel-variant knobs, which only the tuning build reads.
+    rel = os.path.join(ROOT, "shrimp_amd", "libgmapper_hip_release.so")
+    knobs = [k for k in os.environ if k.startswith("GM_") and k not in ("GM_HOST_THREADS", "GM_SUBBATCH", "GM_BENCH_WORKLOAD", "GM_CPU_THREADS", "GM_LIB_PATH")]
+    if "GM_LIB_PATH" not in os.environ and not knobs and os.path.exists(rel):
+        os.environ["GM_LIB_PATH"] = rel
     import torch
     import torch.distributed as dist
     from shrimp_amd import gmapper as gm, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if local >= torch.cuda.device_count():
+        raise SystemExit("rank %d: local rank %d has no GPU (%d visible)" % (rank, local, torch.cuda.device_count()))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("only %d of %d ranks came up" % (dist.get_world_size(), args.gpus))
     if gm.lib().gm_device_count() < 1:
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local)
@@ -113,6 +245,7 @@ def main():
     # host threads per rank for the finalisation (selection, MAPQ, SAM text): this rank's share of the host cores
     host_threads = host_threads_for(local_world)
     os.environ.setdefault("GM_HOST_THREADS", str(host_threads))
+    host_threads = int(os.environ["GM_HOST_THREADS"])
 
     kind, gname, gseed, L, rseed, R_def, metric, unit, descr = WORKLOADS[args.workload]
     R = args.reads_per_step or R_def
@@ -121,22 +254,9 @@ def main():
     contigs = synth.make_genome(synth.contig_lengths(gname, args.scale), gseed)
     t_gen = time.time() - t0
     n_pool = min(2, args.steps + args.warmup)            # distinct batches, cycled
-    pools = []
-    for b in range(n_pool):
-        sd = shard_seed(rseed, rank, n_pool, b)
-        if kind == "ls":
-            reads, _ = synth.make_reads(contigs, R, L, sd)
-            pools.append(torch.from_numpy(synth.pack_reads(reads).view(np.int32)).to(dev))          # resident in HBM
-        elif kind == "cs":
-            reads, _ = synth.make_cs_reads(contigs, R, L, sd)
-            pools.append((np.ascontiguousarray(synth.pack_reads(np.ascontiguousarray(reads[:, 1:]))), np.ascontiguousarray(reads[:, 0])))
-        else:
-            reads, _ = synth.make_pairs(contigs, R, L, sd)
-            pools.append((np.ascontiguousarray(synth.pack_reads(np.ascontiguousarray(reads[0::2]))), np.ascontiguousarray(synth.pack_reads(np.ascontiguousarray(reads[1::2])))))
+    pools = make_pools(synth, contigs, kind, R, L, rseed, rank, n_pool, dev)
     n_sample = args.cpu_sample or {"ls": 200_000, "cs": 50_000, "pairs": 20_000}[kind]
-    if kind == "ls": sample, _ = synth.make_reads(contigs, n_sample, L, rseed + 104729)
-    elif kind == "cs": sample, _ = synth.make_cs_reads(contigs, n_sample, L, rseed + 104729)
-    else: sample, _ = synth.make_pairs(contigs, n_sample, L, rseed + 104729)
+    sample = make_sample(synth, contigs, kind, n_sample, L, rseed)
 
     # ---- index: built on rank 0's GPU, broadcast once ----
     params = gm.default_params_cs() if kind == "cs" else gm.default_params()
@@ -151,36 +271,16 @@ def main():
         ix = parallel.broadcast_index(ix, rank, dev, src=0)      # the single collective of the whole job
         torch.cuda.synchronize(); dist.barrier()
         t_bcast = time.time() - t0
-    sess = gm.Session(ix, params=params, max_batch_reads=int(os.environ.get("GM_SUBBATCH", "131072" if kind != "pairs" else "65536")))
-    popts = gm.PairOpts.default("opp-in", 100, 600)
+    sub_batch = lambda k: int(os.environ.get("GM_SUBBATCH", "131072" if k != "pairs" else "65536"))
+    sess = gm.Session(ix, params=params, max_batch_reads=sub_batch(kind))
 
-    def step(i):
-        p = pools[i % n_pool]
-        if kind == "ls": sess.map_device(p.data_ptr(), R, L, emit_sam=not args.no_sam, return_bytes=False)
-        elif kind == "cs": sess.map_cs_packed(p[0], p[1], R, L, return_bytes=False)
-        else: sess.map_pairs_packed(p[0], p[1], R, L, L, popts, return_bytes=False)
-        return sess.stats
-
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    lk_ms = 0.0; lk_bytes = 0; lk_launch = 0
-    agg = {}
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        st = step(args.warmup + i)
-        ms, nb, nl = sess.lookup_timing()                    # K1's own HIP events on its stream (paired mode: both mate sets of every sub-batch)
-        lk_ms += ms; lk_bytes += (nb or st["list_bytes"]); lk_launch += nl
-        for k, v in st.items():
-            agg[k] = agg.get(k, 0) + v
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = reduce_max_time(time.perf_counter() - t0, world, dist, dev)
+    dt, lk_ms, lk_bytes, lk_launch, agg = timed_steps(gm, sess, kind, pools, R, L, args.steps, args.warmup, world, dist, dev, emit_sam=not args.no_sam)
     total_units = R * args.steps * world
     value = total_units / dt
+    threads_all = [host_threads]
+    if world > 1:
+        threads_all = [None] * world
+        dist.all_gather_object(threads_all, host_threads)
 
     out = {
         "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -190,20 +290,16 @@ def main():
                    "genome_bp": int(sum(len(c) for c in contigs)),
                    "parallelism": "read-sharded x%d, index replicated (1 RCCL broadcast at start-up)" % world,
                    "inputs": "reads resident in HBM" if kind == "ls" else "packed reads in host buffers, uploaded every step",
-                   "sam_emitted": not args.no_sam, "scale": args.scale, "host_threads_per_rank": int(os.environ["GM_HOST_THREADS"]),
+                   "library": os.path.basename(gm.LIB_PATH) + ("" if not knobs else " (tuning knobs set: %s)" % ",".join(sorted(knobs))),
+                   "sam_emitted": not args.no_sam, "scale": args.scale, "host_threads_per_rank": host_threads, "host_threads": threads_all,
                    "sub_batch_pipeline": "stage order" if os.environ.get("GM_OVERLAP") == "0" else "two streams (lookup of sub-batch i+1 beside SW of sub-batch i)",
                    "vector_sw_filter": ("every window swept to its end" if (kind == "pairs" or os.environ.get("GM_P1_EARLY") == "0") else
                                         "a window stops once no alignment can reach the vector threshold (exact bound, same SAM; DESIGN.md section 4, K3)")},
     }
     if rank == 0:
         U = R * args.steps
-        # dominant kernel = seed lookup (K1): algorithmic bytes (12 B per lookup + 4 B per list entry) / its own HIP-event time
-        ach = (lk_bytes / 1e9) / (lk_ms / 1e3) if lk_ms > 0 else 0.0
-        kname = gm.lib().gm_last_lookup_kernel().decode()       # k_lookup_bkt (one slab, short lists), k_lookup_v4 (folded count), k_lookup_v3 (slab sweep), k_lookup_v5
-        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                           "traffic": None,       # HBM bytes are not measurable inside this run; see traffic_from_profile
-                           "kernel": kname, "launches": lk_launch, "avg_launch_ms": lk_ms / max(1, lk_launch), "alg_bytes_per_launch": lk_bytes / max(1, lk_launch),
-                           "alg_bytes_per_unit": lk_bytes / max(1, U)}
+        out["roofline"] = roofline_of(gm, lk_ms, lk_bytes, lk_launch, U)
+        kname = out["roofline"]["kernel"]
         try:      # a stored figure from separate rocprofv3 --pmc passes (profiles/traffic.json), NOT something this run measured
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             t = tj.get("%s/%s/131072" % (args.workload, kname))
@@ -216,40 +312,70 @@ def main():
                            "survivors_pruned": agg["survivors_pruned"] / U, "vec_sw_calls": agg["vec_calls"] / U, "full_sw_calls": agg["full_calls"] / U,
                            "mapped_frac": agg["reads_matched"] / U, "exact_order_frac": agg["exact_order_reads"] / (2 * U)}
         out["setup_s"] = {"genome_gen": t_gen, "index_build": t_index, "index_bcast": t_bcast, "index_bytes": ix.nbytes}
+        o_ls = None
         if not args.no_cpu_baseline and world == 1:
-            # the CPU restatement (oracle, "port") on this box's host cores over a bounded sample of the same workload
+            # the CPU restatement (oracle, "port") on this box's host cores over a bounded sample of the same workload -- on as many threads as the GPU run's
+            # host side used (this process's CPU affinity share), so that the two numbers sit on the same cores
             from tests import oracle_api as oa
-            ncores = int(os.environ.get("GM_CPU_THREADS", min(os.cpu_count() or 1, 16)))     # the GPU box gives one GPU job a 16-core share of the host
+            ncores = int(os.environ.get("GM_CPU_THREADS", host_threads))
             oa.load().gmo_set_threads(ncores)
             t0 = time.time(); o = oa.Session(contigs, opts="colour=1" if kind == "cs" else None); t_oidx = time.time() - t0
-            t0 = time.perf_counter()
-            if kind == "pairs":
-                o.set_pairing("opp-in", 100, 600); sam = o.map_pairs_sam(sample[0::2], sample[1::2], nthreads=ncores)
-            else:
-                sam = o.map_sam(sample, nthreads=ncores)
-            cdt = time.perf_counter() - t0
-            o.close()
-            out["cpu_baseline"] = {"value": n_sample / cdt, "unit": unit, "cores": ncores, "kind": "port",
+            cdt, sam = oracle_sample(oa, o, kind, sample, ncores)
+            if kind == "cs": o.close()
+            else: o_ls = o                                   # the letter-space oracle index also serves the cfg5 entry below
+            out["cpu_baseline"] = {"value": n_sample / cdt, "unit": unit, "cores": ncores, "gpu_run_host_threads": host_threads, "kind": "port",
                                    "sample": "%d %s of the same workload (same genome, same error model), oracle/gm_oracle.hpp with OpenMP over reads; "
                                              "index build %.1fs not included" % (n_sample, "pairs" if kind == "pairs" else "reads", t_oidx)}
-            # the reference binary itself cannot travel; its speed relative to the port was measured in the build container
+            # the reference binary itself does not travel; its speed relative to the port was measured in the build container
             try:
-                rb = json.load(open(os.path.join(ROOT, "profiles", "r02_ref_baseline.json")))
-                c = rb["cases"].get("cfg2" if kind == "ls" and L == 100 else ("cfg1" if kind == "ls" else ""))
+                rb = json.load(open(os.path.join(ROOT, "profiles", "r03_ref_baseline.json")))
+                key = ("cfg3_group" if gname == "cfg3" else "cfg2") if (kind == "ls" and L == 100) else ("cfg1" if kind == "ls" else "")
+                c = rb["cases"].get(key) or (rb["cases"].get("cfg2") if key == "cfg3_group" else None)
                 if c:
                     out["cpu_baseline"]["ref_ratio"] = c["ref_over_oracle"]
-                    out["cpu_baseline"]["ref_ratio_source"] = "reference gmapper-ls -N %d vs the port, %d x %d bp reads vs %d bp, %s (profiles/r02_ref_baseline.json)" % (
-                        rb["threads"], c["reads"], c["read_len"], c["genome_bp"], rb["host"])
+                    out["cpu_baseline"]["ref_ratio_measured_at"] = "%d bp genome, %d x %d bp reads, %d threads" % (c["genome_bp"], c["reads"], c["read_len"], rb["threads"])
+                    out["cpu_baseline"]["ref_ratio_source"] = c.get("what", "reference gmapper-ls vs the port on the same reads") + "; " + rb["host"] + " (profiles/r03_ref_baseline.json)"
                     out["cpu_baseline"]["reference_equivalent"] = out["cpu_baseline"]["value"] * c["ref_over_oracle"]
                 else:
                     out["cpu_baseline"]["ref_ratio"] = None
             except Exception:
                 out["cpu_baseline"]["ref_ratio"] = None
             # parity spot check on the sample while we are here
-            if kind == "ls": got = sess.map_reads(sample)
-            elif kind == "cs": got = sess.map_reads_cs(sample)
-            else: got = sess.map_pairs(sample[0::2], sample[1::2], mode="opp-in", min_insert=100, max_insert=600)
-            out["cpu_baseline"]["sample_sam_identical"] = bool(got == sam)
+            out["cpu_baseline"]["sample_sam_identical"] = bool(product_sample(sess, kind, sample) == sam)
+        # ---- the other single-GPU configurations, three steps each, so that their numbers are measured by whoever runs the default line ----
+        if world == 1 and args.workload == "cfg3" and args.scale == 1.0 and not args.no_other_workloads and not args.no_sam:
+            others = {}
+            for wname in ("cfg5", "cfg4"):
+                k2, _, _, L2, rs2, R2, m2, u2, d2 = WORKLOADS[wname]
+                try:
+                    p2 = gm.default_params_cs() if k2 == "cs" else params
+                    t0 = time.time()
+                    ix2 = gm.Index(contigs, device=local, params=p2) if k2 == "cs" else ix
+                    t_ix2 = time.time() - t0
+                    s2 = gm.Session(ix2, params=p2, max_batch_reads=sub_batch(k2))
+                    pools2 = make_pools(synth, contigs, k2, R2, L2, rs2, 0, 2, dev)
+                    dt2, ms2, by2, nl2, agg2 = timed_steps(gm, s2, k2, pools2, R2, L2, 3, 1, 1, dist, dev)
+                    e = {"metric": m2, "unit": u2, "workload": d2, "value": R2 * 3 / dt2, "steps": 3, "warmup": 1, "ms_per_step": 1e3 * dt2 / 3,
+                         "roofline": {k: v for k, v in roofline_of(gm, ms2, by2, nl2, R2 * 3).items() if k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches", "alg_bytes_per_unit")},
+                         "stages_ms_per_step": {k: agg2[k] / 3 for k in agg2 if k.startswith("ms_")}}
+                    if k2 == "cs": e["index_build_s"] = t_ix2
+                    if not args.no_cpu_baseline:
+                        from tests import oracle_api as oa
+                        ns2 = {"cs": 20_000, "pairs": 5_000}[k2]
+                        smp2 = make_sample(synth, contigs, k2, ns2, L2, rs2)
+                        o2 = oa.Session(contigs, opts="colour=1") if k2 == "cs" else (o_ls or oa.Session(contigs))
+                        cdt2, sam2 = oracle_sample(oa, o2, k2, smp2, ncores)
+                        if o2 is not o_ls: o2.close()
+                        e["cpu_port_value"] = ns2 / cdt2; e["cpu_cores"] = ncores; e["sample_units"] = ns2
+                        e["sample_sam_identical"] = bool(product_sample(s2, k2, smp2) == sam2)
+                    s2.close()
+                    if ix2 is not ix: ix2.close()
+                    del pools2
+                    others[wname] = e
+                except Exception as ex:                      # the headline must not be lost to a problem in a side entry: say what happened instead
+                    others[wname] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            out["other_workloads"] = others
+        if o_ls is not None: o_ls.close()
         print(json.dumps(out))
     sess.close()
     if world > 1:

@@ -558,7 +558,7 @@ int gm_launch_anchors(const GmIndexDev& ix, const GmScoreDev& sc, int n_reads, i
   if (n_reads == 0) return GM_OK;
   const size_t lds = k2_lds_bytes(false, scap, NL, read_len);
   if (lds > 64 * 1024) {
-    static size_t configured = 0;
+    static GmLdsLimit lim_configured; size_t& configured = lim_configured.cur();
     if (lds > 160 * 1024) { gm_set_error("anchor kernel LDS %zu too large", lds); return GM_E_ARG; }
     if (lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_anchors<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
   }

@@ -508,6 +508,7 @@ extern "C" void gm_session_free(gm_session_t* s) {
 struct FHit {            // one pass-2 candidate on the host (read_hit + sw_full_results subset)
   const GmFullRes* r; const uint8_t* ops;
   int score_full, pass2_key; double pct_score_full; double posterior; int mqv; double z0, z1;
+  bool dev_post = false;          // colour space: posterior and re-called letters came from k_post_sw_cs (the host routine can still redo them)
   double z2, z3, pr_top_random, insert_size_denom, pr_missed_mp;   // paired mode (ref: sw-full-common.h:30-44)
   std::string db, qr, qual; int cs_match = 0, cs_mismatch = 0, cs_xover = 0;   // colour space: dbalign / qralign and the counts post_sw leaves (ref: sw-post.c:531-565)
 };
@@ -699,13 +700,14 @@ static void cs_post_sw(const CsPostConsts& K, const uint32_t* rw, int init_bp, i
   }
 }
 // dbalign / qralign of a colour-space alignment from the backtrace bytes and letter codes k_pass2_cs wrote (pretty_print, ref: sw-full-cs.c:945-1060)
-static void cs_alignment_strings(const uint8_t* bt, const uint8_t* codes, int n, std::string& db, std::string& qr) {
+// recalled: the read letters and lower-case marks k_post_sw_cs left in the spare bits of the backtrace bytes (gm_post.hip) instead of sw_full_cs's own
+static void cs_alignment_strings(const uint8_t* bt, const uint8_t* codes, int n, std::string& db, std::string& qr, bool recalled = false) {
   static const char L[17] = "ACGTUMRWSYKVHDBN";
   db.clear(); qr.clear();
   for (int t = 0; t < n; t++) {
-    const int type = bt[t] & 0x0f; const bool xov = (bt[t] & 0x80) != 0;
+    const int type = bt[t] & 0x0f; const bool xov = recalled ? (bt[t] & 0x40) != 0 : (bt[t] & 0x80) != 0;
     if (type == 1) { db.push_back(L[codes[t] >> 4]); qr.push_back('-'); continue; }
-    char q = L[codes[t] & 15]; if (xov) q = (char)tolower((unsigned char)q);
+    char q = recalled ? L[(bt[t] >> 4) & 3] : L[codes[t] & 15]; if (xov) q = (char)tolower((unsigned char)q);
     if (type >= 2 && type <= 5) { db.push_back('-'); qr.push_back(q); continue; }
     const char d = L[codes[t] >> 4];
     if (q == 'n' || q == 'N') q = xov ? (char)tolower((unsigned char)d) : d;      // an unknown read letter is shown as the genome's
@@ -801,23 +803,51 @@ struct Finalizer {
     out += '\n';
   }
 
+  // Rounding guard for results of the device's post_sw (gm_post.hip): its posterior differs from the host routine's in the last bits (ocml exp / log instead of
+  // glibc's), which matters only where a value is about to be rounded right at a boundary.  Every such conversion below -- rint() for AS, truncation for MAPQ
+  // (with its two cut-offs) and for the Z tags -- checks the distance to the boundary; within guard_tol (1e-7, five orders above the difference) the read's device
+  // results are redone by the host routine (same libm as the reference), so the bytes never hang on the device's last bits.
+  double guard_tol = 1e-7; std::atomic<uint64_t>* redo_ctr = nullptr;
+  bool near_rint(double x) const { const double f = x - floor(x); return fabs(f - 0.5) < guard_tol; }              // rint(): boundary at the half integers
+  bool near_trunc(double x) const { return fabs(x - rint(x)) < guard_tol; }                                          // (int): boundary at the integers
+  bool near_qv(double pr_corr) const {                                                                               // qv_from_pr_corr, ref: common/util.h:267-283
+    const double pr_err = 1 - pr_corr;
+    if (fabs(pr_err - .99999999) < guard_tol * 1e-2 || (pr_err > 0 && fabs(pr_err / 1E-25 - 1.0) < guard_tol)) return true;
+    if (pr_err > .99999999 || pr_err < 1E-25) return false;
+    return near_trunc(-10.0 * log(pr_err) / log(10.0));
+  }
+  void redo_on_host(FHit& h) const {                    // sw_full_cs's own strings, then the host's post_sw (ref: sw-post.c:636-758), then the posterior score
+    const GmFullRes* r = h.r;
+    cs_alignment_strings(h.ops, h.ops + ops_half, std::min(r->n_ops, ops_half), h.db, h.qr);
+    cs_post_sw(csk, reads + (size_t)r->read_idx * read_words, (int)initbp[r->read_idx], r->read_start, h, nullptr, qual_delta);
+    h.dev_post = false;
+    const double a = s->score_alpha, b = s->score_beta;
+    int ps = (int)rint(a * log(h.posterior) / log(2.0) + (double)r->rmapped * (2.0 * a + b));
+    if (ps < 0) ps = 0;
+    h.score_full = ps; h.pct_score_full = (1000 * 100 * ps) / r->score_max;
+    h.pass2_key = s->P.sw_full_threshold < 0 ? h.score_full : (int)h.pct_score_full;
+    if (redo_ctr) redo_ctr->fetch_add(1, std::memory_order_relaxed);
+  }
   // hit_run_post_sw for one pass-2 result (ref: mapping.c:1609-1625)
   void post_sw(FHit& h, const GmFullRes* r, const uint8_t* ops) const {
     const gm_params_t& P = s->P;
-    h.r = r; h.ops = ops + (size_t)r->ops_off; h.mqv = 255; h.z0 = h.z1 = 0; h.posterior = 0;
+    h.r = r; h.ops = ops + (size_t)r->ops_off; h.mqv = 255; h.z0 = h.z1 = 0; h.posterior = 0; h.dev_post = false;
     h.z2 = h.z3 = h.pr_top_random = h.insert_size_denom = h.pr_missed_mp = 0;
     h.score_full = r->score;
     h.pct_score_full = (1000 * 100 * h.score_full) / r->score_max;                 // ref: mapping.c:400-401
     if (h.score_full > 0 && !P.local_alignment) {                  // local mode: mapping qualities are off (ref: gmapper.c:2325-2328, mapping.c:1648)
       const double a = s->score_alpha, b = s->score_beta;
       if (P.colour_space) {
-        cs_alignment_strings(h.ops, h.ops + ops_half, std::min(r->n_ops, ops_half), h.db, h.qr);
-        if (post_base && !qual_ptr && post_base[r - res_base].valid == 1) {   // k_post_sw_cs ran: the op record already carries the re-called letters
+        if (post_base && !qual_ptr && post_base[r - res_base].valid == 1) {   // k_post_sw_cs ran: the op record carries the re-called letters in its spare bits
           const GmPostRes& pr = post_base[r - res_base];
-          h.posterior = pr.posterior; h.cs_match = pr.cs_match; h.cs_mismatch = pr.cs_mismatch; h.cs_xover = pr.cs_xover; h.qual.clear();
-        } else
+          cs_alignment_strings(h.ops, h.ops + ops_half, std::min(r->n_ops, ops_half), h.db, h.qr, true);
+          h.posterior = pr.posterior; h.cs_match = pr.cs_match; h.cs_mismatch = pr.cs_mismatch; h.cs_xover = pr.cs_xover; h.qual.clear(); h.dev_post = true;
+          if (near_rint(a * log(h.posterior) / log(2.0) + (double)r->rmapped * (2.0 * a + b))) { redo_on_host(h); return; }      // AS at a rounding boundary
+        } else {
+        cs_alignment_strings(h.ops, h.ops + ops_half, std::min(r->n_ops, ops_half), h.db, h.qr);
         cs_post_sw(csk, reads + (size_t)r->read_idx * read_words, (int)initbp[r->read_idx], r->read_start, h,
                    qual_ptr ? qual_ptr[r->read_idx] : nullptr, qual_delta);
+        }
       } else
       h.posterior = pow(2.0, ((double)r->score - (double)r->rmapped * (2.0 * a + b)) / a);
       int ps = (int)rint(a * log(h.posterior) / log(2.0) + (double)r->rmapped * (2.0 * a + b));
@@ -875,9 +905,19 @@ struct Finalizer {
       return 0;
     }
     if (!P.local_alignment) {                                                      // compute_unpaired_mqv, ref: output.c:777-793,975
-      double z1 = 0.0;
-      for (auto* h : p2) z1 += h->posterior;
-      for (auto* h : p2) { h->z0 = h->posterior; h->z1 = z1; h->mqv = qv_from_pr_corr(h->posterior / z1); if (h->mqv < 4) h->mqv = 0; }
+      for (int pass = 0; pass < 2; pass++) {
+        double z1 = 0.0;
+        for (auto* h : p2) z1 += h->posterior;
+        for (auto* h : p2) { h->z0 = h->posterior; h->z1 = z1; h->mqv = qv_from_pr_corr(h->posterior / z1); if (h->mqv < 4) h->mqv = 0; }
+        // rounding guard (see post_sw above): MAPQ and the Z0 / Z1 tags of this read's records, when any posterior came from the device
+        bool dev = false, near = false;
+        for (auto* h : p2) dev = dev || h->dev_post;
+        if (pass || !dev) break;
+        near = near_trunc(1000.0 * -log(z1));
+        for (auto* h : p2) near = near || near_qv(h->posterior / z1) || near_trunc(1000.0 * -log(h->z0));
+        if (!near) break;
+        for (auto* h : p2) if (h->dev_post) redo_on_host(*h);
+      }
     }
     if (P.output_format) {                                                         // --shrimp-format / --pretty, ref: gmapper/output.c:270-296
       std::string db, qr;
@@ -1254,6 +1294,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   // The SAM text is assembled as the jobs finish, in input order (each job appends after its predecessor), so that the copy -- and the
   // first touch of the output pages -- overlaps the device work instead of following it.
   struct OutBuf { char* p = nullptr; size_t len = 0, cap = 0; int turn = 0; bool failed = false; std::mutex m; std::condition_variable cv; ~OutBuf() { free(p); } } ob;
+  std::atomic<uint64_t> post_redo(0);
   auto run_job = [&, nthreads, ops_stride](Job* J) {
     auto t0 = std::chrono::steady_clock::now();
     const int n = J->n; const int chunk = std::max(256, std::min(4096, n / (2 * nthreads)));   // small sub-batches (the ramp) still use every thread
@@ -1262,6 +1303,8 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     std::atomic<int> next(0);
     Finalizer F{s, read_len, read_words, J->hreads, names ? nptr.data() + J->base : nullptr, names ? nlen.data() + J->base : nullptr, (long)J->base};
     if (s->P.colour_space) { F.initbp = initbp_host + J->base; F.ops_half = ops_stride / 2; F.csk = cs_post_consts(s); if (J->hs->post_on) { F.res_base = J->hs->res; F.post_base = J->hs->post; } }
+    F.redo_ctr = &post_redo;
+    if (const char* e = gm_tune("GM_POST_GUARD_TOL")) F.guard_tol = atof(e);          // (tests: a huge tolerance sends every result through the redo path)
     if (quals) { F.qual_ptr = qptr.data() + J->base; F.qual_delta = qual_delta; }
     if (seq_text) F.seq_ptr = sptr.data() + J->base;
     if (s->P.output_format) F.hgen = s->h_genome.data();
@@ -1421,7 +1464,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     for (size_t c = 0; c < j->cm.size(); c++) { matched += j->cm[c]; records += j->cr[c]; }
     if (stats) stats->ms_host += j->ms;
   }
-  if (stats) { stats->reads = n_reads; stats->reads_matched = matched; stats->sam_records = records; }
+  if (stats) { stats->reads = n_reads; stats->reads_matched = matched; stats->sam_records = records; stats->post_sw_host_redo = post_redo.load(); }
   if (emit_sam && sam) {
     if (ob.failed) return GM_E_NOMEM;
     char* r = ob.p;                                            // (not shrunk: gm_free parks a large buffer for the next call)

@@ -57,6 +57,11 @@ int gm_index_build_device(GmIndexHost* ix, hipStream_t stream);
 int gm_index_colour_genome_device(GmIndexHost* ix, hipStream_t stream);   // derives d_genome_cs from d_genome
 int gm_index_from_lists_device(GmIndexHost* ix, int sn, const uint32_t* lens, const uint32_t* pos, uint32_t total);
 
+// The dynamic-LDS limit raised for a kernel so far, per device (hipFuncSetAttribute acts on the current device's code object: a process that maps on a
+// second device must raise it there too).  One static instance per kernel at its launch site: `static GmLdsLimit lim; size_t& configured = lim.cur();`
+struct GmLdsLimit { size_t v[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; size_t& cur() { int d = 0; (void)hipGetDevice(&d); return v[(d >= 0 && d < 16) ? d : 0]; } };
+
+
 // K1 seed lookup + region filter: one workgroup per read-strand; read-strands with more than scap
 // survivors are listed in d_heavy_list (count in d_surv_cnt) and re-run by gm_launch_lookup_redo
 void gm_lookup_set_start_flags(uint32_t* flags, int cap, uint32_t epoch);   // pinned words the persistent K1 grid raises when its workgroups are resident

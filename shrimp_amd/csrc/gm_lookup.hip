@@ -1104,7 +1104,7 @@ static bool k4_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   }
   if (!K.fb) { if (hipMalloc(&K.fb, (size_t)(fb_cap + 4) * 4) != hipSuccess) return false; }
   if (hipMemsetAsync(K.fb + fb_cap, 0, 4, stream) != hipSuccess) return false;
-  static size_t configured4 = 0, configured_g = 0;
+  static GmLdsLimit lim_configured4, lim_configured_g; size_t &configured4 = lim_configured4.cur(), &configured_g = lim_configured_g.cur();
   if (lds > 48 * 1024 && lds > configured4) { if (hipFuncSetAttribute((const void*)k_lookup_v4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false; configured4 = lds; }
   if (lds_generic > 48 * 1024 && lds_generic > configured_g) {
     if (hipFuncSetAttribute((const void*)k_lookup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_generic) != hipSuccess) return false; configured_g = lds_generic; }
@@ -1137,7 +1137,7 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
   GM_HIP(hipMemsetAsync(d_heavy_cnt, 0, 4, stream));
   if (fuse && fuse->fused) *fuse->fused = 0;
   if (NL == 0 || n_reads == 0) { GM_HIP(hipMemsetAsync(d_surv_cnt, 0, (size_t)n_reads * 2 * 4, stream)); return GM_OK; }
-  static size_t configured = 0;
+  static GmLdsLimit lim_configured; size_t& configured = lim_configured.cur();
   if (lds > 48 * 1024 && lds > configured) {
     GM_HIP(hipFuncSetAttribute((const void*)k_lookup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = lds;
@@ -1200,7 +1200,7 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     // (long reads on many slabs: the per-slab window maps outgrow the LDS and the lane-per-list kernel below takes over)
     g_k1_name = "k_lookup_v3";
     const size_t lds3 = (size_t)((((read_len + 3) / 4) + 3 * NL + ix.n_slabs * NL + (ix.n_slabs + 1) / 2 + (NL * (ix.n_slabs + 1) + 1) / 2 + 3) & ~3) * 4 + (size_t)bm_words * 4;
-    static size_t configured3 = 0;
+    static GmLdsLimit lim_configured3; size_t& configured3 = lim_configured3.cur();
     if (lds3 > 48 * 1024 && lds3 > configured3) { GM_HIP(hipFuncSetAttribute((const void*)k_lookup_v3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); configured3 = lds3; }
     int k1_threads = 768;
     if (const char* e = gm_tune("GM_K1_THREADS")) k1_threads = std::max(64, std::min(768, atoi(e) & ~63));

@@ -448,8 +448,11 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
     }
     __syncthreads();
     K5_STAMP(2);
-    const uint32_t nc = ctrl[C_NCAND];
-    bool fallback = nc > (uint32_t)a.cand_limit;
+    // Every count the device produced is clamped to the capacity of what it indexes before it bounds a loop: the reservation counter runs past cand_cap when a
+    // read-strand has more candidates than slots (the stores are skipped, the read-strand falls back), so it is never used as it stands.
+    const uint32_t nc_raw = ctrl[C_NCAND];
+    bool fallback = nc_raw > (uint32_t)a.cand_limit;
+    const uint32_t nc = min(nc_raw, (uint32_t)cand_cap);
     // ================= exact stage 1: region table over the candidates =================
     // A wave pays the longest chain of LDS round trips among its lanes, so the rare cases are taken out of the main loops and worked off
     // densely afterwards: the overlap-strip marks here (2 % of the candidates, but some lane of most waves), the neighbour-region look-ups of
@@ -782,7 +785,7 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   }
   uint32_t* const fb_cnt_p = K.fb + K.fb_cap; uint32_t* const pl_cnt_p = K.pl + K.fb_cap;
   if (hipMemsetAsync(fb_cnt_p, 0, 4, stream) != hipSuccess || hipMemsetAsync(pl_cnt_p, 0, 4, stream) != hipSuccess) return GM_E_NODEVICE;
-  static size_t configured = 0;
+  static GmLdsLimit lim_configured; size_t& configured = lim_configured.cur();
   if (lds > 48 * 1024 && lds > configured) {
     if (hipFuncSetAttribute((const void*)k_lookup_v5<15>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_lookup_v5<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;

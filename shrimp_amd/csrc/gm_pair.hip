@@ -296,8 +296,8 @@ int gm_launch_mp_filter(int n_pairs, int region_bits, int region_overlap, uint64
   auto rmax = [&](int v) { return v > 0 ? 1 + (v - 1) / R : -(-v / R); };
   for (int st = 0; st < 2; st++) { dl.amin[st] = rmin(dmin1[st]); dl.amax[st] = rmax(dmax1[st]); dl.bmin[st] = rmin(dmin2[st]); dl.bmax[st] = rmax(dmax2[st]); }
   const size_t lds = (size_t)(2u << MPF_HBITS) * 4;
-  static bool configured = false;
-  if (!configured) { GM_HIP(hipFuncSetAttribute((const void*)k_mp_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = true; }
+  static GmLdsLimit lim_mp; size_t& configured = lim_mp.cur();
+  if (lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_mp_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
   const int grid = std::min(2 * n_pairs, 1024);
   hipLaunchKernelGGL(k_mp_filter, dim3(grid), dim3(MPF_THREADS), lds, stream, n_pairs, region_bits, (uint32_t)region_overlap, d_surv1, d_cnt1, scap1, d_surv2, d_cnt2, scap2,
                      dl, d_seg1, d_seg2, n_slabs, d_unfiltered);

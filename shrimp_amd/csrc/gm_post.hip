@@ -5,14 +5,16 @@
 // The 16-state forward-backward of cs_post_sw (gm_host.hip) in the same operation order, in doubles, with contraction off -- what differs from
 // the host routine is the exp / log implementation (ocml here, glibc there; both within 1 ulp of the true value).  The sums are well conditioned
 // (every column is rescaled by its minimum), so `total` carries an absolute error of ~1e-12 after 50 columns; an output integer (AS, a base
-// quality, MAPQ, the Z tags) differs from the host's only when the value rounded lies that close to a rounding boundary.  All goldens and the
-// bench samples are byte-identical; GM_POST_SW_HOST=1 keeps the host routine (bit-exact by construction), and FASTQ input (per-colour error
-// rates from the QVs, base qualities) always takes it.  One case IS decided by the last bits: a letter call between two (nearly) equal posteriors;
-// the kernel flags those results (valid = 2, record untouched) and the host routine redoes them.
+// quality, MAPQ, the Z tags) could differ from the host's only when the value rounded lies that close to a rounding boundary -- those are caught on the
+// host and redone there (below).  GM_POST_SW_HOST=1 keeps the host routine throughout, and FASTQ input (per-colour error
+// rates from the QVs, base qualities) always takes it.  A letter call between two (nearly) equal posteriors is decided by the last bits too:
+// the kernel flags those results (valid = 2) and the host routine redoes them.
 //
-// What the kernel leaves: GmPostRes per result (posterior, the match / mismatch / crossover counts), and the re-called letters written INTO the
-// result's op record -- letter code in the low nibble of codes[t], lower-case flag in bit 7 of bt[t] -- so that the host's cs_alignment_strings
-// yields the final qralign directly.
+// What the kernel leaves: GmPostRes per result (posterior, the match / mismatch / crossover counts), and the re-called letters written into the spare
+// bits of the result's backtrace bytes -- letter in bits 4-5 of bt[t], lower-case flag in bit 6; the type nibble, sw_full_cs's crossover mark (bit 7) and
+// the letter codes stay as they were -- so that the host's cs_alignment_strings yields the final qralign directly AND the host routine can still redo
+// any result from sw_full_cs's own record.  The host does that whenever a value it is about to round (AS, MAPQ, the Z tags) lies within 1e-7 of its
+// rounding boundary (Finalizer::post_sw / finalize_read, gm_host.hip): there the last bits of exp / log would decide an output byte.
 #include "gm_common.h"
 #include "gm_internal.h"
 
@@ -115,8 +117,7 @@ k_post_sw_cs(GmCsPostDev K, const uint32_t* __restrict__ reads, const uint8_t* _
             if (lower) out.cs_xover++;
             const int d = codes[t] >> 4;
             if (!(type >= 2 && type <= 5)) { if (d == crt) out.cs_match++; else out.cs_mismatch++; }
-            codes[t] = (uint8_t)((d << 4) | crt);
-            bt[t] = (uint8_t)((bt[t] & 0x7f) | (lower ? 0x80 : 0));
+            bt[t] = (uint8_t)((bt[t] & 0x8f) | (crt << 4) | (lower ? 0x40 : 0));          // the re-call rides in the spare bits: sw_full_cs's own letters and marks stay
             prev_base = crt; j++;
           } }
         // ---- get_posterior, ref: sw-post.c:589-612 ----
@@ -128,7 +129,7 @@ k_post_sw_cs(GmCsPostDev K, const uint32_t* __restrict__ reads, const uint8_t* _
             prev_ins = ins; prev_del = del;
           }
           out.posterior = r; }
-        if (tie) out.valid = 2;                                   // op record untouched: the host's cs_post_sw takes it from here
+        if (tie) out.valid = 2;                                   // the host's cs_post_sw takes it from here
       }
       if (out.valid == 0) out.valid = 1;
     }

@@ -264,7 +264,7 @@ int gm_launch_prune(int n_reads, int read_len, int window_len, int e_max, int n_
       int hb = 12; if (const char* e = gm_tune("GM_PRUNE_HBITS")) hb = std::max(6, std::min(13, atoi(e)));
       const uint32_t n_max = (3u << hb) / 4u;
       const size_t lds2 = (size_t)12 << hb;
-      static size_t configured2 = 0;
+      static GmLdsLimit lim_configured2; size_t& configured2 = lim_configured2.cur();
       if (lds2 > 48 * 1024 && lds2 > configured2) { GM_HIP(hipFuncSetAttribute((const void*)k_prune_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); configured2 = lds2; }
       hipLaunchKernelGGL(k_prune_v2, dim3(n_reads * 2), dim3(512), lds2, stream, n_reads * 2, d_surv, d_surv_cnt, scap, d_surv2, d_surv_cnt2, scap2, D, e_max, bb, hb, n_max,
                          d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, ov[dev], ovc, ov_cap[dev]);
@@ -279,7 +279,7 @@ int gm_launch_prune(int n_reads, int read_len, int window_len, int e_max, int n_
   const int segs = d_surv_seg ? std::max(1, n_slabs) : 1;
   int hbits = 8; while ((1 << hbits) < 2 * std::max(128, (segs > 1 ? (2 * scap) / segs : scap))) hbits++;
   const size_t lds = (size_t)8 << hbits;
-  static size_t configured = 0;
+  static GmLdsLimit lim_configured; size_t& configured = lim_configured.cur();
   if (lds > 48 * 1024 && lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_prune, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
   // latency-bound (hash probes): as many lanes per read-strand as a segment has work for
   const int pthreads = gm_tune("GM_PRUNE_THREADS") ? atoi(gm_tune("GM_PRUNE_THREADS")) : std::min(1024, std::max(128, (1 << hbits) / 8));

@@ -1318,7 +1318,7 @@ int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs
   P.b_go = cs_params9[5]; P.b_ge = cs_params9[6]; P.anchor_width = cs_params9[7]; P.taboo = cs_params9[8];
   const size_t lds = 5 * (size_t)((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 48 + 64;
   if (lds > 160 * 1024) { gm_set_error("colour-space pass 2: window of %d does not fit LDS", window_len); return GM_E_ARG; }
-  static size_t configured = 0;
+  static GmLdsLimit lim_configured; size_t& configured = lim_configured.cur();
   if (lds > 48 * 1024 && lds > configured) {
     GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
@@ -1415,7 +1415,7 @@ int gm_launch_sw_full_cs_single(const int* cs_params9, const uint32_t* d_genome_
   GmCsDev P; P.match = cs_params9[0]; P.mismatch = cs_params9[1]; P.xover = cs_params9[2]; P.a_go = cs_params9[3]; P.a_ge = cs_params9[4];
   P.b_go = cs_params9[5]; P.b_ge = cs_params9[6]; P.anchor_width = cs_params9[7]; P.taboo = cs_params9[8];
   const size_t lds = 5 * (size_t)((rlen + 15) & ~15) + ((glen + 15) & ~15) + (size_t)glen * 48 + 64;
-  static size_t configured = 0;
+  static GmLdsLimit lim_configured; size_t& configured = lim_configured.cur();
   if (lds > 160 * 1024) { gm_set_error("sw_full_cs: window of %d does not fit LDS", glen); return GM_E_ARG; }
   if (lds > 48 * 1024 && lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_sw_full_cs_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
   hipLaunchKernelGGL(k_sw_full_cs_single, dim3(1), dim3(GM_WAVE), lds, stream, P, d_genome_ls, goff, glen, d_read, rlen, initbp, thresh, ax, ay, alen, awidth,

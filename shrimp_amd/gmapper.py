@@ -39,7 +39,7 @@ class Params(C.Structure):   # gm_params_t (include/gmapper_hip.h)
 class MapStats(C.Structure):   # gm_map_stats_t
     _fields_ = [(n, C.c_uint64) for n in ("reads", "reads_matched", "sam_records", "lookups", "list_entries", "list_bytes",
                                           "survivors", "anchors", "windows", "vec_calls", "vec_cells", "vec_bypassed",
-                                          "full_calls", "full_cells", "exact_order_reads", "retries", "survivors_pruned")] + \
+                                          "full_calls", "full_cells", "exact_order_reads", "retries", "survivors_pruned", "mp_unfiltered", "post_sw_host_redo")] + \
                [(n, C.c_double) for n in ("ms_lookup", "ms_anchors", "ms_pass1", "ms_select", "ms_pass2", "ms_host")]
 
     def as_dict(self):

@@ -130,3 +130,29 @@ def test_world2_genome_sharded_merge():
     res = dict(q.get(timeout=180) for _ in ps)
     for p in ps: p.join(60)
     assert res == {0: True, 1: None}
+
+
+def test_bench_gpus_n_starts_n_ranks():
+    """`python bench.py --gpus 2` (no launcher around it) must itself start two ranks: the launcher function bench.py uses for that (a child
+    torch.distributed.run on 127.0.0.1; the parent never touches the GPU) driven here at world 2 with the rank logic on gloo (--selftest-ranks)."""
+    import json, subprocess, sys
+    sys.path.insert(0, oa.ROOT)
+    import bench
+    env_backup = {k: os.environ.pop(k) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT") if k in os.environ}
+    try:
+        rc, out, err = bench.launch_ranks(2, ["--gpus", "2", "--selftest-ranks"], capture=True, timeout=300)
+        assert rc == 0, err[-2000:]
+        lines = [l for l in out.split("\n") if l.startswith("{")]
+        assert len(lines) == 1, out                          # rank 0 only
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and len(d["host_threads"]) == 2 and len(d["seeds"]) == 2
+        # the plain command line does the same (the parent sees no WORLD_SIZE, --gpus 2 > 1: it launches)
+        p = subprocess.run([sys.executable, os.path.join(oa.ROOT, "bench.py"), "--gpus", "2", "--selftest-ranks"], capture_output=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert json.loads([l for l in p.stdout.decode().split("\n") if l.startswith("{")][0])["n_gpus"] == 2
+        # a launcher whose rank count disagrees with --gpus is an error, not a silent one-GPU run
+        p = subprocess.run([sys.executable, os.path.join(oa.ROOT, "bench.py"), "--gpus", "2", "--selftest-ranks"], capture_output=True, timeout=120,
+                           env=dict(os.environ, WORLD_SIZE="1", RANK="0"))
+        assert p.returncode != 0 and b"WORLD_SIZE=1" in p.stderr
+    finally:
+        os.environ.update(env_backup)

@@ -910,6 +910,8 @@ def test_no_half_paired_mate_pair_region_counts(gm, oracle_lib, base, tag):
     st_default = s.stats
     s.close(); ix.close()
     assert got == want, (_first_diff(got, want), st)
+    # the filter was exact for every (pair, strand) item: none beyond its LDS tiers, none left as a superset (gm_map_stats_t.mp_unfiltered)
+    assert st["mp_unfiltered"] == 0, st["mp_unfiltered"]
     assert st["windows"] < st_default["windows"], (st["windows"], st_default["windows"])
     if base.startswith("cfg5s"): assert st["windows"] == want_windows, (st["windows"], want_windows)     # (no read-strand beyond the LDS tiers on the uniform genome)
 
@@ -1087,3 +1089,76 @@ def test_csfastq_files_match_reference_golden(gm, tmp_path):
     got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_file(path, qual_delta=33, mode="opp-in", min_insert=g["ins"][0], max_insert=g["ins"][1])
     s.close(); ix.close()
     assert got == want, _first_diff(got, want)
+
+
+def test_100mbp_genome_bucket_lookup_vs_oracle(gm, oracle_lib):
+    """BASELINE configs[1] at full genome size: 4 x 25 Mbp (one slab, Poisson(6) lists -> k_lookup_bkt, the 64-byte bucket kernel: length + the first 15 positions
+    per k-mer, longer lists continue in pos[]).  20 000 reads of the workload plus reads placed on lists LONGER than a bucket holds, against the CPU oracle."""
+    from shrimp_amd import synth
+    contigs = synth.make_genome(synth.contig_lengths("cfg2", 1.0), 2)
+    assert sum(len(c) for c in contigs) == 100_000_000
+    reads, _ = synth.make_reads(contigs, 20000, 100, 41)
+    ix = gm.Index(contigs)
+    assert ix.n_slabs == 1 and ix.has_buckets
+    # lists beyond the bucket: scan list lengths of seed 0 until 40 lists of more than 15 entries are found, and cut a read out of the genome at a position of each
+    offs = np.cumsum([0] + [len(c) for c in contigs]); extra = []; longest = 0
+    for mapidx in range(0, 200000):
+        lst = ix.get_list(0, mapidx)
+        if len(lst) > 15:
+            longest = max(longest, len(lst))
+            g = int(lst[len(lst) // 2]); cn = int(np.searchsorted(offs, g, side="right") - 1); o = g - int(offs[cn])
+            if o + 100 <= len(contigs[cn]): extra.append(contigs[cn][o:o + 100].copy())
+            if len(extra) >= 40: break
+    assert len(extra) >= 40 and longest > 15, (len(extra), longest)
+    reads = np.concatenate([reads, np.stack(extra)])
+    o = oa.Session(contigs)
+    want = o.map_sam(reads, nthreads=16); o.close()
+    s = gm.Session(ix)
+    got = s.map_reads(reads)
+    kern = gm.lib().gm_last_lookup_kernel().decode(); st = s.stats
+    s.close(); ix.close()
+    assert kern == "k_lookup_bkt", kern
+    assert 4.0 < st["list_entries"] / st["lookups"] < 9.0, st                # Poisson(6) lists: the bucket kernel's real load
+    assert got == want, _first_diff(got, want)
+    # the reads cut at list positions map (each has at least one lookup that ran past its bucket)
+    mapped = {l.split(b"\t")[0] for l in got.split(b"\n") if l and not l.startswith(b"@")}
+    assert all(b"r%d" % (20000 + i) in mapped for i in range(len(extra)))
+
+
+def test_post_sw_rounding_guard_redoes_on_the_host(gm, monkeypatch):
+    """k_post_sw_cs computes the colour-space posterior with ocml's exp / log; the host redoes every result whose AS / MAPQ / Z0 / Z1 would be rounded within the
+    guard's tolerance of a boundary (Finalizer::post_sw / finalize_read).  Forced here: with a tolerance of 0.49 nearly every device result is sent back through
+    the host routine -- the non-destructive re-call record lets it start from sw_full_cs's own strings -- and the SAM stays the reference's; with the production
+    tolerance the count is reported and the SAM is the reference's too."""
+    contigs, reads, sam = oa.load_golden("cfg4s_50col_2Mbp")
+    p = gm.default_params_cs()
+    ix = gm.Index(contigs, params=p)
+    s = gm.Session(ix, params=p)
+    got0 = oa.sam_header(contigs) + s.map_reads_cs(reads); st0 = s.stats
+    monkeypatch.setenv("GM_POST_GUARD_TOL", "0.49")
+    got1 = oa.sam_header(contigs) + s.map_reads_cs(reads); st1 = s.stats
+    monkeypatch.setenv("GM_POST_GUARD_TOL", "0.01")               # 4 % of the AS values alone
+    got2 = oa.sam_header(contigs) + s.map_reads_cs(reads); st2 = s.stats
+    s.close(); ix.close()
+    assert got0 == sam, _first_diff(got0, sam)
+    assert got1 == sam, _first_diff(got1, sam)
+    assert got2 == sam, _first_diff(got2, sam)
+    assert st1["post_sw_host_redo"] > 0.5 * st1["full_calls"] > 0, st1
+    assert 0 < st2["post_sw_host_redo"] < st1["post_sw_host_redo"], (st2["post_sw_host_redo"], st1["post_sw_host_redo"])
+    assert st0["post_sw_host_redo"] < 0.001 * st0["full_calls"], st0
+
+
+def test_release_build_reproduces_the_reference_goldens():
+    """`make release` (TUNING=0: no tuning / ablation knobs compiled in; the build bench.py measures) against the reference goldens: the golden tests of this
+    file in a child interpreter with GM_LIB_PATH on libgmapper_hip_release.so."""
+    import subprocess, sys
+    rel = os.path.join(oa.ROOT, "shrimp_amd", "libgmapper_hip_release.so")
+    assert os.path.exists(rel), "make -C shrimp_amd/csrc release (or __graft_entry__.build()) has not run"
+    env = dict(os.environ, GM_LIB_PATH=rel)
+    sel = "test_sam_matches_reference_golden or test_paired_sam_matches_reference_golden or test_colour_space_sam_matches_reference_golden or test_sw_vector_known_answers or test_colour_space_pairs_match_reference_golden"
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(oa.ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, env=env, cwd=oa.ROOT, timeout=1500)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    import re
+    m = re.search(r"(\d+) passed", p.stdout)
+    assert m and int(m.group(1)) >= 17, p.stdout[-500:]
