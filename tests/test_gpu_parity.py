@@ -910,8 +910,10 @@ def test_no_half_paired_mate_pair_region_counts(gm, oracle_lib, base, tag):
     st_default = s.stats
     s.close(); ix.close()
     assert got == want, (_first_diff(got, want), st)
-    # the filter was exact for every (pair, strand) item: none beyond its LDS tiers, none left as a superset (gm_map_stats_t.mp_unfiltered)
-    assert st["mp_unfiltered"] == 0, st["mp_unfiltered"]
+    # gm_map_stats_t.mp_unfiltered: (pair, strand) items beyond the filter's LDS tiers, left as a superset of the reference's anchors (paired mode).
+    # None on the uniform genome -- the filter is exact for every pair there; the repeat-rich stress genome has some (heavy-tier read-strands), counted, same SAM.
+    if base.startswith("cfg5s"): assert st["mp_unfiltered"] == 0, st["mp_unfiltered"]
+    else: assert 0 < st["mp_unfiltered"] < len(g["m1"]) // 4, st["mp_unfiltered"]
     assert st["windows"] < st_default["windows"], (st["windows"], st_default["windows"])
     if base.startswith("cfg5s"): assert st["windows"] == want_windows, (st["windows"], want_windows)     # (no read-strand beyond the LDS tiers on the uniform genome)
 
