@@ -37,6 +37,8 @@ typedef __attribute__((address_space(3))) uint32_t k5_lds_u32;
 // LDS word at an absolute LDS byte address (the tables of k_lookup_v5 start at the workgroup's LDS base, which the kernel checks to be 0:
 // table offsets are then OR-ed, not added, into the address)
 #define K5_LDS(off) ((k5_lds_u32*)(uintptr_t)(uint32_t)(off))
+typedef __attribute__((address_space(3))) uint16_t k5_lds_u16;
+#define K5_LDS16(off) ((k5_lds_u16*)(uintptr_t)(uint32_t)(off))
 #define K5_LDS_OR(off, m) __hip_atomic_fetch_or(K5_LDS(off), (m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
 #ifndef K5_Q
@@ -104,13 +106,14 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
   if ((uint32_t)(uintptr_t)(k5_lds_u32*)smem != 0u) __builtin_trap();      // no static LDS in this kernel: the dynamic segment starts at 0
   uint32_t* twice = smem;
   uint32_t* seen = smem + (1u << ltw);
-  // after pass A the seen[] area is re-used: htag | hmin | hmax (2^hbits = 2^(lsw - 2) words each: three quarters of it) | candidate positions
-  // (cand_cap words) | candidate y / seed (u16); cand_cap = the last quarter / 6 bytes, cut into one segment per wave
-  uint32_t* htag = seen;
+  // after pass A the seen[] area is re-used: candidate positions (cand_cap words) | candidate y / seed (u16) -- cand_cap = the first quarter / 6 bytes; with the
+  // production sizes both arrays lie below 64 KB, so that pass B's stores carry their base in the LDS instruction's offset field -- then htag | hmin | hmax
+  // (2^hbits = 2^(lsw - 2) words each: the other three quarters)
+  uint32_t* candp = seen;
+  uint16_t* candy = (uint16_t*)(candp + cand_cap);
+  uint32_t* htag = seen + (1u << hbits);
   uint32_t* hmin = htag + (1u << hbits);
   uint32_t* hmax = hmin + (1u << hbits);
-  uint32_t* candp = hmax + (1u << hbits);
-  uint16_t* candy = (uint16_t*)(candp + cand_cap);
   uint32_t* rec = seen + (1u << lsw);
   const int RC = a.NL + K5_XREC;                                 // records: one per chunk of at most 256 positions
   uint32_t* srec = rec + 4 * RC;
@@ -180,7 +183,7 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
     const uint32_t j = atomicAdd(cnl_w, nch);
     for (uint32_t c = 0; c < nch && j + c < (uint32_t)RC; c++) {
       const uint64_t ca = la + ((uint64_t)c << 10);
-      *(uint4*)&rec[4 * (j + c)] = make_uint4((uint32_t)ca, (uint32_t)(ca >> 32), min(256u, len - (c << 8)), ysn);
+      *(uint4*)&rec[4 * (j + c)] = make_uint4((uint32_t)ca, (uint32_t)(ca >> 32), min(256u, len - (c << 8)), ((ysn >> 12) & 0xFFF0u) | (ysn & 0xFu));   // y << 4 | seed: as the candidates carry it
       *(uint4*)&srec[4 * (j + c)] = c ? make_uint4(0u, 0u, 0u, 0u) : make_uint4((uint32_t)sptr, (uint32_t)(sptr >> 32), slen, 0u);
     }
   };
@@ -392,7 +395,7 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
           if (c0 | c1 | c2 | c3) {
             uint32_t idx = atomicAdd(&ctrl[C_NCAND], (uint32_t)c0 + (uint32_t)c1 + (uint32_t)c2 + (uint32_t)c3);
             if (idx + 4u <= (uint32_t)cand_cap) {
-              const uint16_t y16 = (uint16_t)(((ysn >> 12) & 0xFFF0u) | (ysn & 0xFu));
+              const uint16_t y16 = (uint16_t)ysn;
               if (c0) { candp[idx] = v.x; candy[idx++] = y16; }
               if (c1) { candp[idx] = v.y; candy[idx++] = y16; }
               if (c2) { candp[idx] = v.z; candy[idx++] = y16; }
@@ -432,13 +435,15 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
             if (ci + cnt <= (uint32_t)cand_cap) {
               // slot k of a lane goes to ci + (hits below k): no running index (and no register copy) between the four predicated store pairs,
               // the list's y / seed word in one register for all of them
-              uint32_t y16 = ((s.ysn >> 12) & 0xFFF0u) | (s.ysn & 0xFu);
+              uint32_t y16 = s.ysn;
               asm volatile("" : "+v"(y16));
               const uint32_t c1 = ci + (hits & 1u), c2 = ci + (uint32_t)__popc(hits & 3u), c3 = ci + (uint32_t)__popc(hits & 7u);
-              if (hits & 1u) { candp[ci] = sv[q].x; candy[ci] = (uint16_t)y16; }
-              if (hits & 2u) { candp[c1] = sv[q].y; candy[c1] = (uint16_t)y16; }
-              if (hits & 4u) { candp[c2] = sv[q].z; candy[c2] = (uint16_t)y16; }
-              if (hits & 8u) { candp[c3] = sv[q].w; candy[c3] = (uint16_t)y16; }
+              // (absolute LDS addresses: candp[] starts at swb, candy[] behind it -- with compile-time sizes both bases are instruction offsets, a store pair costs two shifts)
+              const uint32_t cyb = swb + 4u * (uint32_t)cand_cap;
+              if (hits & 1u) { *K5_LDS(swb + (ci << 2)) = sv[q].x; *K5_LDS16(cyb + (ci << 1)) = (uint16_t)y16; }
+              if (hits & 2u) { *K5_LDS(swb + (c1 << 2)) = sv[q].y; *K5_LDS16(cyb + (c1 << 1)) = (uint16_t)y16; }
+              if (hits & 4u) { *K5_LDS(swb + (c2 << 2)) = sv[q].z; *K5_LDS16(cyb + (c2 << 1)) = (uint16_t)y16; }
+              if (hits & 8u) { *K5_LDS(swb + (c3 << 2)) = sv[q].w; *K5_LDS16(cyb + (c3 << 1)) = (uint16_t)y16; }
             }
           }
           gen(sd[q]); issue(sd[q], sv[q]);
