@@ -715,6 +715,256 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
   if (lane == 0) { GS_ADD(stats, GS_FULL_CALLS, fcalls); GS_ADD(stats, GS_VEC_CALLS, vcalls); GS_ADD(stats, GS_VEC_CELLS, vcells); }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K4b, four windows per wave (round 3).  The band of the reference's full SW is a strip of ~10-20 columns along the anchor's diagonal (plus two small
+// corner blocks), so with one read row per lane of a 64-row stripe only a dozen lanes stand inside the band at any step: k_pass2 issues its vector
+// instructions with 48 % of the lanes enabled and a sixth of them computing.  Here a wave takes FOUR selected windows: each group of 16 lanes owns one
+// window, lane l of the group the read row 16 s + l of stripe s, the row above arrives by a DPP shift inside the group (row_shr:1; lane 0 of a group gets
+// the virtual row / the carry of the previous stripe), and a stripe needs band width + 30 steps instead of band width + 126.  Same cell code, same tie
+// rules, same back bytes as full_sw_wave (ref: sw-full-ls.c:154-403); the four group leaders walk their tracebacks side by side.
+// Everything that is wave-uniform in full_sw_wave and differs between windows -- band box, window length, strand flag, "this group has work" -- is a
+// per-lane value here that is uniform inside a group.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int g4_shr1(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x111, 0xf, 0xf, false); }   // row_shr:1; lane 0 of each 16-lane row keeps `first`
+
+template <bool LOCAL>
+__device__ FullOut full_sw_g4(const uint8_t* db, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc, bool revcmpl, bool act,
+                              long long rx, long long ry, int rl, int rw, uint8_t* back, int* carry, int lane) {
+  const int a_go = sc.a_go, a_ge = sc.a_ge, b_go = sc.b_go, b_ge = sc.b_ge;
+  const int o_nw = LOCAL ? 0 : FS_NEG, o_n = LOCAL ? -b_go : FS_NEG, o_w = LOCAL ? -a_go : FS_NEG;   // a cell outside the band
+  FullOut out; out.score = 0; out.max_i = 0; out.max_j = 0; out.e_nw = out.e_n = out.e_w = 0;
+  const int l = lane & 15;
+  const int n_stripes = (rlen + 15) >> 4;
+  int* cNW = carry; int* cN = carry + glen; int* cW = carry + 2 * glen;   // this group's carry rows: last row of the previous stripe, per column
+  int cw_lo = 1, cw_hi = 0;
+  for (int s = 0; s < n_stripes; s++) {
+    const int r = s * 16 + l;
+    const bool row_ok = act && r < rlen;
+    const int q = row_ok ? qr[r] : 0x7F;
+    int x_min = 0, x_max = -1;
+    if (row_ok) band_range(rx, ry, rl, rw, glen, r, &x_min, &x_max);
+    int t_lo = INT_MAX, t_hi = -1;
+    if (row_ok && x_max >= x_min) { t_lo = x_min + l; t_hi = x_max + l; }
+    for (int dd = 8; dd > 0; dd >>= 1) { t_lo = min(t_lo, __shfl_xor(t_lo, dd)); t_hi = max(t_hi, __shfl_xor(t_hi, dd)); }     // over the group
+    int nst = t_hi >= 0 ? t_hi - t_lo + 1 : 0, nmax = nst;
+    for (int dd = 32; dd >= 16; dd >>= 1) nmax = max(nmax, __shfl_xor(nmax, dd));                                             // over the four groups
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
+    int pw_nw = o_nw, pw_w = o_w;
+    int d_nw = o_nw, d_n = o_n, d_w = o_w;
+    int cur_nw = o_nw, cur_n = o_n, cur_w = o_w;
+    if (l == 0) {
+      if (s == 0) { d_nw = 0; d_n = -b_go; d_w = -a_go; }
+      else if (t_hi >= 0 && t_lo >= 1 && t_lo - 1 >= cw_lo && t_lo - 1 <= cw_hi) { d_nw = cNW[t_lo - 1]; d_n = cN[t_lo - 1]; d_w = cW[t_lo - 1]; }
+    }
+    const bool more = (s + 1 < n_stripes);
+    const bool last_row_lane = row_ok && (r == rlen - 1);
+    for (int i = 0; i < nmax; i++) {
+      const bool on = i < nst;                                   // this group still has steps in this stripe
+      const int t = t_lo + i;
+      const int c = t - l;
+      int in_nw, in_n, in_w;
+      if (s == 0) { in_nw = 0; in_n = -b_go; in_w = -a_go; }
+      else { in_nw = o_nw; in_n = o_n; in_w = o_w; if (l == 0 && on && t >= cw_lo && t <= cw_hi) { in_nw = cNW[t]; in_n = cN[t]; in_w = cW[t]; } }
+      const int u_nw = g4_shr1(cur_nw, in_nw), u_n = g4_shr1(cur_n, in_n), u_w = g4_shr1(cur_w, in_w);   // cell_n = (r-1, c)
+      const bool inband = on && row_ok && c >= x_min && c <= x_max;
+      int n_nw = o_nw, n_n = o_n, n_w = o_w;
+      if (inband) {
+        const int ms = (db[c] == q) ? sc.match : sc.mismatch;
+        int tmp, b0, b1, b2, nul = 0;
+        if (!revcmpl) {                                            // ref: sw-full-ls.c:264-278
+          tmp = d_nw + ms; b0 = 0;
+          if (d_n + ms > tmp) { tmp = d_n + ms; b0 = 1; }
+          if (d_w + ms > tmp) { tmp = d_w + ms; b0 = 2; }
+        } else {                                                   // :279-292
+          tmp = d_w + ms; b0 = 2;
+          if (d_n + ms > tmp) { tmp = d_n + ms; b0 = 1; }
+          if (d_nw + ms > tmp) { tmp = d_nw + ms; b0 = 0; }
+        }
+        if (LOCAL && tmp <= 0) { tmp = 0; nul |= 0x10; }
+        n_nw = tmp;
+        if (!revcmpl) {                                            // north :303-320
+          tmp = u_nw - b_go - b_ge; b1 = 0;
+          if (u_n - b_ge > tmp) { tmp = u_n - b_ge; b1 = 1; }
+        } else {
+          tmp = u_n - b_ge; b1 = 1;
+          if (u_nw - b_go - b_ge > tmp) { tmp = u_nw - b_go - b_ge; b1 = 0; }
+        }
+        if (LOCAL && tmp <= 0) { tmp = 0; nul |= 0x20; }
+        n_n = tmp;
+        if (!revcmpl) {                                            // west :330-347
+          tmp = pw_nw - a_go - a_ge; b2 = 0;
+          if (pw_w - a_ge > tmp) { tmp = pw_w - a_ge; b2 = 1; }
+        } else {
+          tmp = pw_w - a_ge; b2 = 1;
+          if (pw_nw - a_go - a_ge > tmp) { tmp = pw_nw - a_go - a_ge; b2 = 0; }
+        }
+        if (LOCAL && tmp <= 0) { tmp = 0; nul |= 0x40; }
+        n_w = tmp;
+        back[(size_t)r * glen + c] = (uint8_t)(0x80 | nul | b0 | (b1 << 2) | (b2 << 3));
+        if (LOCAL || last_row_lane) {                              // :359-368 leftmost strict maximum: of the last read row, or (local) of this lane's rows
+          int m = max(n_n, n_nw); m = max(m, n_w);
+          if (m > out.score) { out.score = m; out.max_i = r; out.max_j = c; out.e_nw = n_nw; out.e_n = n_n; out.e_w = n_w; }
+        }
+      }
+      if (more && l == 15 && on && c >= 0 && c < glen) { cNW[c] = n_nw; cN[c] = n_n; cW[c] = n_w; }
+      d_nw = u_nw; d_n = u_n; d_w = u_w;
+      pw_nw = n_nw; pw_w = n_w;
+      cur_nw = n_nw; cur_n = n_n; cur_w = n_w;
+    }
+    cw_lo = 1; cw_hi = 0;
+    if (more && t_hi >= 0) { cw_lo = max(0, t_lo - 15); cw_hi = min(glen - 1, t_hi - 15); }
+    if (more) __syncthreads();
+  }
+  // the group's result: from the last row's lane, or (local) from the lane whose row comes first among those with the largest score
+  const int gb = lane & 48;
+  int src = (rlen - 1) & 15;
+  if (LOCAL) {
+    int best = out.score;
+    for (int d = 8; d > 0; d >>= 1) best = max(best, __shfl_xor(best, d));
+    int row = (out.score == best) ? out.max_i : INT_MAX;
+    for (int d = 8; d > 0; d >>= 1) row = min(row, __shfl_xor(row, d));
+    src = (best > 0) ? (row & 15) : 0;
+  }
+  out.score = __shfl(out.score, gb | src); out.max_i = __shfl(out.max_i, gb | src); out.max_j = __shfl(out.max_j, gb | src);
+  out.e_nw = __shfl(out.e_nw, gb | src); out.e_n = __shfl(out.e_n, gb | src); out.e_w = __shfl(out.e_w, gb | src);
+  return out;
+}
+
+template <bool LOCAL>
+__global__ void __launch_bounds__(GM_WAVE)
+k_pass2_g4(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words,
+           GmHit* __restrict__ hits, const uint16_t* __restrict__ perm, int hcap,
+           const int32_t* __restrict__ sel, const int32_t* __restrict__ sel_sidx, int input_strand, int write_back,
+           const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work_p,
+           GmFullRes* __restrict__ res, uint8_t* __restrict__ ops, int ops_stride,
+           uint8_t* __restrict__ back_pool, size_t back_stride, int max_w, unsigned long long* __restrict__ stats) {
+  extern __shared__ __align__(16) uint8_t sm[];
+  const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
+  const int rl16 = (read_len + 15) & ~15, mw16 = (max_w + 15) & ~15;
+  uint8_t* qr_all = sm;                                          // four reads, four windows, four sets of carry rows
+  uint8_t* db_all = sm + 4 * rl16;
+  int* carry_all = (int*)(db_all + 4 * mw16);
+  const uint8_t* qr = qr_all + g * rl16; const uint8_t* db = db_all + g * mw16; int* carry = carry_all + g * 3 * max_w;
+  uint8_t* back = back_pool + ((size_t)blockIdx.x * 4 + g) * back_stride;
+  const uint32_t n_work = *n_work_p;
+  unsigned long long vcalls = 0, vcells = 0, fcalls = 0;
+  for (uint32_t base = blockIdx.x * 4u; base < n_work; base += gridDim.x * 4u) {
+    const uint32_t wi = base + (uint32_t)g;
+    const bool has = wi < n_work;
+    const uint32_t wk = has ? work[wi] : 0u;
+    const int rd = (int)(wk >> 6), k = (int)(wk & 63);
+    const int id = has ? sel[(size_t)rd * SEL_MAX + k] : 0;
+    int st = id >> 16; const int hi = id & 0xFFFF;
+    const size_t slot = ((size_t)rd * 2 + st) * hcap + hi;
+    GmHit h; if (has) h = hits[slot]; else { h.g_off = 0; h.ax = h.ay = 0; h.alen = h.awidth = 1; h.score_window_gen = 0; h.score_vector = 0; h.pct_score_vector = 0; h.cn = 0; h.w_len = 1; h.matches = 0; h.flags = 1; }
+    const int cn = h.cn, w_len = h.w_len;
+    const long long clen = (long long)ix.contig_off[cn + 1] - ix.contig_off[cn];
+    long long g_off = h.g_off; long long ax = h.ax, ay = h.ay; int gen_st = 0;
+    if (st != input_strand) {                                   // reverse_hit, ref: mapping.c:254-263,337-339; anchor_reverse anchors.h:30-34
+      g_off = clen - g_off - w_len;
+      ax = -ax + (w_len - 1) - (h.alen - 1) - (h.awidth - 1);
+      ay = -ay + (read_len - 1) - (h.alen - 1) + (h.awidth - 1);
+      gen_st = 1; st = input_strand;
+    }
+    const uint64_t g0 = (uint64_t)ix.contig_off[cn] + h.g_off;
+    __syncthreads();
+    for (int gg = 0; gg < 4; gg++) {                             // the whole wave unpacks each group's read and window (wave-uniform arguments from the group's first lane)
+      if (!__shfl((int)has, gg * 16)) continue;
+      const int rd_g = __shfl(rd, gg * 16), wl_g = __shfl(w_len, gg * 16), gs_g = __shfl(gen_st, gg * 16);
+      const uint64_t g0_g = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(g0 >> 32), gg * 16) << 32) | (uint32_t)__shfl((int)(uint32_t)g0, gg * 16);
+      load_read(reads + (size_t)rd_g * read_words, read_len, input_strand != 0, qr_all + gg * rl16, lane);
+      load_window(ix.genome, g0_g, wl_g, gs_g != 0, db_all + gg * mw16, lane);
+    }
+    __syncthreads();
+    const int score_max = (read_len < w_len ? read_len : w_len) * sc.match;
+    const int thresh = thr_of(sc.full_thr_frac, sc.full_abs, score_max);
+    // re-score only where pass 1 took the value from its cache (see k_pass2)
+    int sv = h.score_vector;
+    const bool need = has && !(h.flags & 1u);
+    for (int gg = 0; gg < 4; gg++) {
+      if (!__shfl((int)need, gg * 16)) continue;
+      __syncthreads();
+      const int v = sw_vector_wave(db_all + gg * mw16, __shfl(w_len, gg * 16), qr_all + gg * rl16, read_len, sc, (int16_t*)carry_all, lane);
+      __syncthreads();
+      if (g == gg) { sv = v; if (l == 0) { vcalls++; vcells += (unsigned long long)w_len * read_len; } }
+    }
+    GmFullRes R;
+    R.read_idx = rd; R.st = (int16_t)ix.cs_flip; R.gen_st = (int16_t)gen_st; R.cn = (uint32_t)cn; R.g_off = (uint32_t)g_off; R.w_len = w_len;
+    R.score_vector = sv; R.score_max = score_max; R.matches = h.matches; R.score_window_gen = h.score_window_gen;
+    R.score = 0; R.read_start = 0; R.rmapped = 0; R.genome_start = 0; R.gmapped = 0;
+    R.n_match = R.n_mismatch = R.n_ins = R.n_del = 0; R.n_ops = 0; R.ops_off = (uint32_t)(wi * (uint32_t)ops_stride);
+    R.sort_idx = (sel_sidx && has) ? sel_sidx[(size_t)rd * SEL_MAX + k] : 0; R.hit_slot = (uint32_t)slot;
+    if (write_back && has && l == 0) hits[slot].score_vector = sv;      // hit_run_full_sw keeps the re-scored value in the hit (ref: mapping.c:386-388)
+    const bool act = has && sv >= thresh;
+    if (act && l == 0) fcalls++;
+    // rectangle = anchor_join(1 anchor) + anchor_widen(anchor_width), ref: sw-full-ls.c:176-178, anchors.c:9-61
+    long long rx, ry; int rw, rl;
+    { long long nw = ax + ay, sw = ax - ay, ne = sw + 2 * (h.awidth - 1), se = nw + 2 * (h.alen - 1);
+      if ((nw + sw) % 2 != 0) nw--;
+      rx = (nw + sw) / 2; ry = nw - rx;
+      if ((ne - sw) % 2 != 0) ne++;
+      rw = (int)((ne - sw) / 2 + 1);
+      if ((se - nw) % 2 != 0) se++;
+      rl = (int)((se - nw) / 2 + 1);
+      rx -= sc.anchor_width / 2; ry += sc.anchor_width / 2; rw += sc.anchor_width; }
+    const bool rvc = (gen_st != 0) && sc.tiebreak_rev;
+    __syncthreads();
+    FullOut fo = full_sw_g4<LOCAL>(db, w_len, qr, read_len, sc, rvc, act, rx, ry, rl, rw, back, carry, lane);
+    __syncthreads();
+    if (LOCAL) {
+      // the filter's best local alignment leaves the anchor band: once more over the band the threshold allows (ref: sw-full-ls.c:395-398)
+      const bool again = act && fo.score != sv;
+      if (__any(again)) {
+        threshold_band(w_len, read_len, sc.match, thresh, &rx, &ry, &rl, &rw);
+        const FullOut f2 = full_sw_g4<LOCAL>(db, w_len, qr, read_len, sc, rvc, again, rx, ry, rl, rw, back, carry, lane);
+        if (again) fo = f2;
+        __syncthreads();
+      }
+    }
+    R.score = act ? fo.score : 0;
+    if (act && fo.score > 0 && l == 0) {
+      // do_backtrace, ref: sw-full-ls.c:413-516 -- the group's first lane walks; ops are emitted reversed then flipped
+      int i = fo.max_i, j = fo.max_j;
+      int state = 0, fs = fo.e_nw;                               // from-state: 0 nw, 1 n, 2 w  (ref :420-427: nw, then w if strictly greater, then n if strictly greater)
+      if (fo.e_w > fs) { state = 2; fs = fo.e_w; }
+      if (fo.e_n > fs) state = 1;
+      uint8_t* o = ops + (size_t)R.ops_off;
+      int no = 0, rstart = 0, gstart = 0, nm = 0, nmm = 0, nin = 0, ndel = 0;
+      while (i >= 0 && j >= 0) {
+        const uint8_t bb = __hip_atomic_load(&back[(size_t)i * w_len + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(bb & 0x80)) break;                // out-of-band cell: back == 0 in the reference
+        if (LOCAL) {                            // a floored state has a null back pointer; a cell outside the band was never computed (stale byte)
+          if ((bb >> (4 + state)) & 1) break;
+          int bx_min, bx_max; band_range(rx, ry, rl, rw, w_len, i, &bx_min, &bx_max);
+          if (j < bx_min || j > bx_max) break;
+        }
+        int nstate;
+        if (state == 1) {                       // FROM_NORTH_*: BACK_DELETION (gap in the genome)
+          if (no < ops_stride) o[no] = 'D'; no++; ndel++; rstart = i; i--;
+          nstate = ((bb >> 2) & 1) ? 1 : 0;
+        } else if (state == 2) {                // FROM_WEST_*: BACK_INSERTION (gap in the read)
+          if (no < ops_stride) o[no] = 'I'; no++; nin++; gstart = j; j--;
+          nstate = ((bb >> 3) & 1) ? 2 : 0;
+        } else {                                // FROM_NORTHWEST_*
+          if (no < ops_stride) o[no] = 'M'; no++;
+          if (db[j] == qr[i]) nm++; else nmm++;
+          rstart = i; gstart = j; i--; j--;
+          nstate = (bb & 3);                    // 0 nw, 1 n, 2 w
+        }
+        state = nstate;
+      }
+      const int nov = min(no, ops_stride);
+      for (int a = 0, b = nov - 1; a < b; a++, b--) { uint8_t tt = o[a]; o[a] = o[b]; o[b] = tt; }
+      R.n_ops = no; R.read_start = rstart; R.genome_start = gstart + (int)g_off;
+      R.gmapped = fo.max_j - gstart + 1; R.rmapped = fo.max_i - rstart + 1;
+      R.n_match = nm; R.n_mismatch = nmm; R.n_ins = nin; R.n_del = ndel;
+    }
+    if (has && l == 0) res[wi] = R;
+  }
+  for (int d = 32; d >= 16; d >>= 1) { fcalls += __shfl_xor(fcalls, d); vcalls += __shfl_xor(vcalls, d); vcells += __shfl_xor(vcells, d); }
+  if (lane == 0) { GS_ADD(stats, GS_FULL_CALLS, fcalls); GS_ADD(stats, GS_VEC_CALLS, vcalls); GS_ADD(stats, GS_VEC_CELLS, vcells); }
+}
+
 // work list = (read << 6 | k) for every selected hit, built by a scan-free atomic append (order fixed up on the host by key)
 __global__ void __launch_bounds__(256) k_build_work(int n_reads, const uint32_t* __restrict__ sel_cnt, const uint32_t* __restrict__ sel_off,
                                                      uint32_t* __restrict__ work) {
@@ -897,6 +1147,16 @@ int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
     d_hits, d_perm, hcap, d_sel, d_sel_sidx, input_strand, write_back, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats, p2_ablate)
   // Back pointers in LDS (14 KB per wave at 100 bp) cap the CU at ten waves; in a per-wave global scratch (L2-resident) the CU runs at full
   // occupancy: measured 109 -> 37 ms per 1 M reads on the 3 Gbp workload.  The LDS form stays for comparison (GM_P2_BACK_LDS=1).
+  // Four windows per wave (k_pass2_g4) unless GM_P2_G4=0 asks for the one-window kernel; its wave owns four consecutive back-pointer scratches
+  const bool g4 = !(gm_tune("GM_P2_G4") && atoi(gm_tune("GM_P2_G4")) == 0) && !gm_tune("GM_P2_BACK_LDS") && grid >= 4;
+  if (g4) {
+    const size_t lds4 = 4 * (size_t)((read_len + 15) & ~15) + 4 * (size_t)((window_len + 15) & ~15) + 4 * (size_t)window_len * 12 + 64;
+    const int grid4 = grid / 4;
+    if (sc.local) hipLaunchKernelGGL((k_pass2_g4<true>), dim3(grid4), dim3(GM_WAVE), lds4, stream, ix, sc, d_reads, n_reads, read_len, read_words, d_hits, d_perm, hcap, d_sel, d_sel_sidx,
+                                     input_strand, write_back, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats);
+    else hipLaunchKernelGGL((k_pass2_g4<false>), dim3(grid4), dim3(GM_WAVE), lds4, stream, ix, sc, d_reads, n_reads, read_len, read_words, d_hits, d_perm, hcap, d_sel, d_sel_sidx,
+                            input_strand, write_back, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats);
+  } else
   if (back_bytes <= 40 * 1024 && gm_tune("GM_P2_BACK_LDS")) {
     lds += back_bytes + 16;
     if (sc.local) GM_P2_LAUNCH(true, true); else GM_P2_LAUNCH(true, false);
