@@ -1569,6 +1569,327 @@ k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__
   if (lane == 0) { GS_ADD(stats, GS_FULL_CALLS, fcalls); GS_ADD(stats, GS_FULL_CELLS, fcells); }
 }
 
+// ---------------------------------------------------------------------------------------------
+// sw_full_cs, four windows per wave (round 3): the scheme of k_pass2_g4 with the colour-space cell -- 16-lane groups, lane = read row 16 s + l, row_shr:1
+// between the rows of a group, one kind of window (forward / reverse tie rules) per pass.  Same state updates, back words and traceback as
+// full_sw_cs_wave_t / k_pass2_cs (ref: sw-full-cs.c:249-623, :633-937).  The carry values lane 0 of a group needs at the next step are read one step ahead.
+// ---------------------------------------------------------------------------------------------
+template <bool REV, bool TABOO>
+__device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4, int qstride, int rlen, const GmCsDev& P, bool act,
+                                int rx, int ry, int rl, int rw, uint32_t* back, int* carry, int lane, const int8_t* xrow) {
+  constexpr bool revcmpl = REV;
+  CsBest best; best.score = 0; best.i = best.j = best.k = 0; best.e_nw = best.e_n = best.e_w = 0;
+  const int l = lane & 15;
+  const int xg = P.xover;
+  int xo = xg;
+  const int n_stripes = (rlen + 15) >> 4;
+  int cw_lo = 1, cw_hi = 0;
+  for (int s = 0; s < n_stripes; s++) {
+    const int r = s * 16 + l;
+    const bool row_ok = act && r < rlen;
+    if (xrow) xo = row_ok ? (int)xrow[r] : xg;           // ref: sw-full-cs.c:312
+    int q[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = row_ok ? qr4[k * qstride + r] : 0x7F;
+    int x_min = 0, x_max = -1;
+    if (row_ok) band_range(rx, ry, rl, rw, glen, r, &x_min, &x_max);
+    const bool notaboo = TABOO ? r < rlen - P.taboo : true;
+    int t_lo = INT_MAX, t_hi = -1;
+    if (row_ok && x_max >= x_min) { t_lo = x_min + l; t_hi = x_max + l; }
+    for (int dd = 8; dd > 0; dd >>= 1) { t_lo = min(t_lo, __shfl_xor(t_lo, dd)); t_hi = max(t_hi, __shfl_xor(t_hi, dd)); }
+    int nst = t_hi >= 0 ? t_hi - t_lo + 1 : 0, nmax = nst;
+    for (int dd = 32; dd >= 16; dd >>= 1) nmax = max(nmax, __shfl_xor(nmax, dd));
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
+    int pw[12], d[12], cur[12], inv[12];
+#pragma unroll
+    for (int x = 0; x < 12; x++) { pw[x] = FS_NEG; d[x] = FS_NEG; cur[x] = FS_NEG; }
+    // lane 0's upper neighbour: the virtual row (stripe 0: constants), or the previous stripe's last row (read one step ahead below)
+#pragma unroll
+    for (int x = 0; x < 12; x++) { const int k = x / 3, st = x % 3; const int xv = k ? xg : 0; inv[x] = s == 0 ? (st == 0 ? 0 : (st == 1 ? -P.b_go : -P.a_go)) + xv : FS_NEG; }
+    if (l == 0) {
+      if (s == 0) {                                  // virtual row -1: init_cell(.., 1, xover), ref :201-215
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int x = k ? xg : 0; d[k * 3] = x; d[k * 3 + 1] = -P.b_go + x; d[k * 3 + 2] = -P.a_go + x; }
+      } else if (t_hi >= 0) {
+        if (t_lo >= 1 && t_lo - 1 >= cw_lo && t_lo - 1 <= cw_hi) {
+#pragma unroll
+          for (int x = 0; x < 12; x++) d[x] = carry[x * glen + t_lo - 1];
+        }
+        if (t_lo >= cw_lo && t_lo <= cw_hi) {
+#pragma unroll
+          for (int x = 0; x < 12; x++) inv[x] = carry[x * glen + t_lo];
+        }
+      }
+    }
+    const bool more = (s + 1 < n_stripes);
+    const bool last_row_lane = row_ok && (r == rlen - 1);
+    for (int i = 0; i < nmax; i++) {
+      const bool on = i < nst;
+      const int t = t_lo + i;
+      const int c = t - l;
+      int u[12];
+#pragma unroll
+      for (int x = 0; x < 12; x++) u[x] = g4_shr1(cur[x], inv[x]);   // cell (r-1, c)
+      if (s > 0) {                                   // next step's carry values for the group's first lane
+#pragma unroll
+        for (int x = 0; x < 12; x++) inv[x] = FS_NEG;
+        if (l == 0 && i + 1 < nst && t + 1 >= cw_lo && t + 1 <= cw_hi) {
+#pragma unroll
+          for (int x = 0; x < 12; x++) inv[x] = carry[x * glen + t + 1];
+        }
+      }
+      const bool inband = on && row_ok && c >= x_min && c <= x_max;
+      int nv[12];
+#pragma unroll
+      for (int x = 0; x < 12; x++) nv[x] = FS_NEG;
+      if (inband) {
+        const int dbc = db[c];
+        uint32_t bw_nw = 0, bw_n = 0, bw_w = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int ms = (dbc == 15 || q[k] == 15) ? 0 : (dbc == q[k] ? P.match : P.mismatch);
+          int tmp, b;
+          // northwest, ref :356-438
+          if (!revcmpl) {
+            tmp = d[k * 3] + ms; b = (6 << 2) | k;
+            if (notaboo && d[k * 3 + 1] + ms > tmp) { tmp = d[k * 3 + 1] + ms; b = (5 << 2) | k; }
+            if (d[k * 3 + 2] + ms > tmp) { tmp = d[k * 3 + 2] + ms; b = (7 << 2) | k; }
+          } else {
+            tmp = d[k * 3 + 2] + ms; b = (7 << 2) | k;
+            if (notaboo && d[k * 3 + 1] + ms > tmp) { tmp = d[k * 3 + 1] + ms; b = (5 << 2) | k; }
+            if (d[k * 3] + ms > tmp) { tmp = d[k * 3] + ms; b = (6 << 2) | k; }
+          }
+#pragma unroll
+          for (int l2 = 0; l2 < 4; l2++) {
+            if (l2 == k) continue;
+            if (!revcmpl) {
+              if (d[l2 * 3] + ms + xo > tmp) { tmp = d[l2 * 3] + ms + xo; b = (6 << 2) | l2; }
+              if (notaboo && d[l2 * 3 + 1] + ms + xo > tmp) { tmp = d[l2 * 3 + 1] + ms + xo; b = (5 << 2) | l2; }
+              if (d[l2 * 3 + 2] + ms + xo > tmp) { tmp = d[l2 * 3 + 2] + ms + xo; b = (7 << 2) | l2; }
+            } else {
+              if (d[l2 * 3 + 2] + ms + xo > tmp) { tmp = d[l2 * 3 + 2] + ms + xo; b = (7 << 2) | l2; }
+              if (notaboo && d[l2 * 3 + 1] + ms + xo > tmp) { tmp = d[l2 * 3 + 1] + ms + xo; b = (5 << 2) | l2; }
+              if (d[l2 * 3] + ms + xo > tmp) { tmp = d[l2 * 3] + ms + xo; b = (6 << 2) | l2; }
+            }
+          }
+          nv[k * 3] = tmp; bw_nw |= (uint32_t)b << (8 * k);
+          // north, ref :447-503
+          if (!revcmpl) {
+            tmp = u[k * 3] - P.b_go - P.b_ge; b = (2 << 2) | k;
+            if (!notaboo || u[k * 3 + 1] - P.b_ge > tmp) { tmp = u[k * 3 + 1] - P.b_ge; b = (1 << 2) | k; }
+          } else {
+            tmp = u[k * 3 + 1] - P.b_ge; b = (1 << 2) | k;
+            if (notaboo && u[k * 3] - P.b_go - P.b_ge > tmp) { tmp = u[k * 3] - P.b_go - P.b_ge; b = (2 << 2) | k; }
+          }
+#pragma unroll
+          for (int l2 = 0; l2 < 4; l2++) {
+            if (l2 == k) continue;
+            if (!revcmpl) {
+              if (notaboo && u[l2 * 3] - P.b_go - P.b_ge + xo > tmp) { tmp = u[l2 * 3] - P.b_go - P.b_ge + xo; b = (2 << 2) | l2; }
+              if (u[l2 * 3 + 1] - P.b_ge + xo > tmp) { tmp = u[l2 * 3 + 1] - P.b_ge + xo; b = (1 << 2) | l2; }
+            } else {
+              if (u[l2 * 3 + 1] - P.b_ge + xo > tmp) { tmp = u[l2 * 3 + 1] - P.b_ge + xo; b = (1 << 2) | l2; }
+              if (notaboo && u[l2 * 3] - P.b_go - P.b_ge + xo > tmp) { tmp = u[l2 * 3] - P.b_go - P.b_ge + xo; b = (2 << 2) | l2; }
+            }
+          }
+          nv[k * 3 + 1] = tmp; bw_n |= (uint32_t)b << (8 * k);
+          // west, ref :512-541 (no crossover on a genomic gap)
+          if (!revcmpl) {
+            tmp = pw[k * 3] - P.a_go - P.a_ge; b = (3 << 2) | k;
+            if (!notaboo || pw[k * 3 + 2] - P.a_ge > tmp) { tmp = pw[k * 3 + 2] - P.a_ge; b = (4 << 2) | k; }
+          } else {
+            tmp = pw[k * 3 + 2] - P.a_ge; b = (4 << 2) | k;
+            if (notaboo && pw[k * 3] - P.a_go - P.a_ge > tmp) { tmp = pw[k * 3] - P.a_go - P.a_ge; b = (3 << 2) | k; }
+          }
+          nv[k * 3 + 2] = tmp; bw_w |= (uint32_t)b << (8 * k);
+          if (last_row_lane) {                         // ref :547-575
+            const int a0 = revcmpl ? nv[k * 3 + 2] : nv[k * 3], a1 = nv[k * 3 + 1], a2 = revcmpl ? nv[k * 3] : nv[k * 3 + 2];
+            const int m = max(a0, max(a1, a2));
+            if (m > best.score) { best.score = m; best.i = r; best.j = c; best.k = k; best.e_nw = nv[k * 3]; best.e_n = nv[k * 3 + 1]; best.e_w = nv[k * 3 + 2]; }
+          }
+        }
+        uint32_t* bp = back + ((size_t)r * glen + c) * 3;
+        bp[0] = bw_nw; bp[1] = bw_n; bp[2] = bw_w;
+      }
+      if (more && l == 15 && on && c >= 0 && c < glen) {
+#pragma unroll
+        for (int x = 0; x < 12; x++) carry[x * glen + c] = nv[x];
+      }
+#pragma unroll
+      for (int x = 0; x < 12; x++) { d[x] = u[x]; pw[x] = nv[x]; cur[x] = nv[x]; }
+    }
+    cw_lo = 1; cw_hi = 0;
+    if (more && t_hi >= 0) { cw_lo = max(0, t_lo - 15); cw_hi = min(glen - 1, t_hi - 15); }
+    if (more) __syncthreads();
+  }
+  const int src = (lane & 48) | ((rlen - 1) & 15);
+  best.score = __shfl(best.score, src); best.i = __shfl(best.i, src); best.j = __shfl(best.j, src); best.k = __shfl(best.k, src);
+  best.e_nw = __shfl(best.e_nw, src); best.e_n = __shfl(best.e_n, src); best.e_w = __shfl(best.e_w, src);
+  return best;
+}
+
+struct P2CsG4 {
+  const uint32_t* reads; const uint8_t* initbp; int read_len, read_words; const GmHit* hits; int hcap; const int32_t* sel; const int32_t* sel_sidx;
+  const uint32_t* work; GmFullRes* res; uint8_t* ops; int ops_stride, max_w; const int8_t* xover;
+  uint8_t* rc_all; uint8_t* qr4_all; uint8_t* db_all; int* carry_all; int qstride, mw16;
+};
+template <bool REV, bool TABOO>
+__device__ __forceinline__ void p2cs_g4_pass(const GmIndexDev& ix, const GmScoreDev& sc, const GmCsDev& P, const P2CsG4& A, const uint32_t wi, const bool has, uint32_t* back,
+                                             const int lane, unsigned long long& fcalls, unsigned long long& fcells) {
+  const int g = lane >> 4, l = lane & 15;
+  const int read_len = A.read_len, qstride = A.qstride, half = A.ops_stride >> 1;
+  const uint8_t* qr4 = A.qr4_all + g * 4 * qstride; const uint8_t* db = A.db_all + g * A.mw16; int* carry = A.carry_all + g * 12 * A.max_w;
+  const uint32_t wk = has ? A.work[wi] : 0u;
+  const int rd = (int)(wk >> 6), k = (int)(wk & 63);
+  const int id = has ? A.sel[(size_t)rd * SEL_MAX + k] : 0;
+  const int st = id >> 16, hi = id & 0xFFFF;
+  const size_t slot = ((size_t)rd * 2 + st) * A.hcap + hi;
+  GmHit h; if (has) h = A.hits[slot]; else { h.g_off = 0; h.ax = h.ay = 0; h.alen = h.awidth = 1; h.score_window_gen = 0; h.score_vector = 0; h.pct_score_vector = 0; h.cn = 0; h.w_len = 1; h.matches = 0; h.flags = 1; }
+  const int cn = h.cn, w_len = h.w_len;
+  const long long clen = (long long)ix.contig_off[cn + 1] - ix.contig_off[cn];
+  long long g_off = h.g_off; long long ax = h.ax, ay = h.ay; int gen_st = 0;
+  if (st != ix.cs_flip) {                               // reverse_hit onto the input strand (label cs_flip), ref: mapping.c:254-263; anchor_reverse anchors.h:30-34
+    g_off = clen - g_off - w_len;
+    ax = -ax + (w_len - 1) - (h.alen - 1) - (h.awidth - 1);
+    ay = -ay + (read_len - 1) - (h.alen - 1) + (h.awidth - 1);
+    gen_st = 1;
+  }
+  const uint64_t g0 = (uint64_t)ix.contig_off[cn] + h.g_off;
+  __syncthreads();
+  for (int gg = 0; gg < 4; gg++) {                       // the whole wave unpacks each group's colours and window
+    if (!__shfl((int)has, gg * 16)) continue;
+    const int rd_g = __shfl(rd, gg * 16), wl_g = __shfl(w_len, gg * 16), gs_g = __shfl(gen_st, gg * 16);
+    const uint64_t g0_g = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(g0 >> 32), gg * 16) << 32) | (uint32_t)__shfl((int)(uint32_t)g0, gg * 16);
+    load_read(A.reads + (size_t)rd_g * A.read_words, read_len, false, A.rc_all + gg * qstride, lane);
+    load_window(ix.genome, g0_g, wl_g, gs_g != 0, A.db_all + gg * A.mw16, lane);
+  }
+  __syncthreads();
+  if (has && l < 4) {                                    // the four letter translations of the group's read, ref: sw-full-cs.c:1182-1197
+    const uint8_t* rc = A.rc_all + g * qstride; uint8_t* q4 = A.qr4_all + g * 4 * qstride;
+    const int ib = (int)A.initbp[rd];
+    int letter = (l + ib) % 4;
+    for (int j = 0; j < read_len; j++) {
+      const int base = rc[j];
+      if (base == 15) { q4[l * qstride + j] = 15; letter = (l + ib) % 4; }
+      else { const int l2 = cs_cstols(letter, base); q4[l * qstride + j] = (uint8_t)l2; letter = l2; }
+    }
+  }
+  const int score_max = (read_len < w_len ? read_len : w_len) * sc.match;
+  const int thresh = thr_of(sc.full_thr_frac, sc.full_abs, score_max);
+  const uint32_t ops_off = (uint32_t)(wi * (uint32_t)A.ops_stride);
+  if (has && l == 0) {
+    GmFullRes R;
+    R.read_idx = rd; R.st = (int16_t)ix.cs_flip; R.gen_st = (int16_t)gen_st; R.cn = (uint32_t)cn; R.g_off = (uint32_t)g_off; R.w_len = w_len;
+    R.score_vector = h.score_vector; R.score_max = score_max; R.matches = h.matches; R.score_window_gen = h.score_window_gen;
+    R.score = 0; R.read_start = 0; R.rmapped = 0; R.genome_start = 0; R.gmapped = 0;
+    R.n_match = R.n_mismatch = R.n_ins = R.n_del = 0; R.n_ops = 0; R.ops_off = ops_off;
+    R.sort_idx = A.sel_sidx ? A.sel_sidx[(size_t)rd * SEL_MAX + k] : 0; R.hit_slot = (uint32_t)slot; R.n_xover = 0;
+    A.res[wi] = R;
+    fcalls++; fcells += (unsigned long long)w_len * read_len;
+  }
+  int rx, ry, rw, rl;
+  { long long nw = ax + ay, sw = ax - ay, ne = sw + 2 * (h.awidth - 1), se = nw + 2 * (h.alen - 1);      // anchor_join + anchor_widen, ref: anchors.c:9-61
+    if ((nw + sw) % 2 != 0) nw--;
+    const long long x0 = (nw + sw) / 2;
+    rx = (int)x0; ry = (int)(nw - x0);
+    if ((ne - sw) % 2 != 0) ne++;
+    rw = (int)((ne - sw) / 2 + 1);
+    if ((se - nw) % 2 != 0) se++;
+    rl = (int)((se - nw) / 2 + 1);
+    rx -= P.anchor_width / 2; ry += P.anchor_width / 2; rw += P.anchor_width; }
+  const int g_off_i = (int)g_off;
+  __syncthreads();
+  const CsBest fo = full_sw_cs_g4<REV, TABOO>(db, w_len, qr4, qstride, read_len, P, has, rx, ry, rl, rw, back, carry, lane, A.xover ? A.xover + (size_t)rd * read_len : nullptr);
+  __syncthreads();
+  __threadfence();
+  if (has && l == 0 && fo.score >= 0 && fo.score >= thresh) {     // ref: sw-full-cs.c:1216; do_backtrace :633-937
+    auto code_at = [&](int ci, int cj, int word, int lay) -> int {
+      int x_min, x_max; band_range(rx, ry, rl, rw, w_len, ci, &x_min, &x_max);
+      if (cj < x_min || cj > x_max) return 0;         // a cell outside the band keeps back == 0 in the reference
+      const uint32_t w = __hip_atomic_load(&back[((size_t)ci * w_len + cj) * 3 + word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return (int)((w >> (8 * lay)) & 0xFFu);
+    };
+    uint8_t* o = A.ops + (size_t)ops_off; uint8_t* oc = o + half;
+    int i = fo.i, j = fo.j, kk = fo.k;
+    int from = code_at(i, j, 0, kk), fromscore = fo.e_nw;
+    if (fo.e_w > fromscore) { from = code_at(i, j, 2, kk); fromscore = fo.e_w; }
+    if (fo.e_n > fromscore) from = code_at(i, j, 1, kk);
+    int no = 0, rstart = 0, gstart = 0, nm = 0, nmm = 0, nin = 0, ndel = 0, nx = 0;
+    while (i >= 0 && j >= 0 && from != 0) {
+      const int dir = from >> 2, lay = from & 3;
+      uint8_t bt, cc;
+      if (dir == 1 || dir == 2) { ndel++; cc = qr4[kk * qstride + i]; rstart = i--; bt = (uint8_t)(2 + kk); }
+      else if (dir == 3 || dir == 4) { nin++; cc = (uint8_t)(db[j] << 4); gstart = j--; bt = 1; }
+      else {
+        const int qv = qr4[kk * qstride + i];
+        if (db[j] == qv || db[j] == 15 || qv == 15) nm++; else nmm++;
+        cc = (uint8_t)((db[j] << 4) | qv);
+        rstart = i--; gstart = j--; bt = (uint8_t)(6 + kk);
+      }
+      if (kk != lay) { bt |= 0x80; nx++; kk = lay; }
+      if (no < half) { o[no] = bt; oc[no] = cc; }
+      no++;
+      if (i < 0 || j < 0) break;                      // the virtual row / left sentinel: back == 0 in the reference
+      const int word = (dir == 1 || dir == 5) ? 1 : ((dir == 4 || dir == 7) ? 2 : 0);
+      from = code_at(i, j, word, kk);
+    }
+    if (kk != 0 && no > 0) { if (no - 1 < half) o[no - 1] |= 0x80; nx++; }     // ref :929-932
+    const int nov = min(no, half);
+    for (int a2 = 0, b2 = nov - 1; a2 < b2; a2++, b2--) { uint8_t tt = o[a2]; o[a2] = o[b2]; o[b2] = tt; tt = oc[a2]; oc[a2] = oc[b2]; oc[b2] = tt; }
+    GmFullRes* Rp = &A.res[wi];
+    Rp->score = fo.score; Rp->n_ops = no; Rp->read_start = rstart; Rp->genome_start = gstart + g_off_i;
+    Rp->gmapped = fo.j - gstart + 1; Rp->rmapped = fo.i - rstart + 1;
+    Rp->n_match = nm; Rp->n_mismatch = nmm; Rp->n_ins = nin; Rp->n_del = ndel; Rp->n_xover = nx;
+  }
+}
+
+template <bool TABOO>
+__global__ void __launch_bounds__(GM_WAVE, 2)
+k_pass2_cs_g4(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__ reads, const uint8_t* __restrict__ initbp, int n_reads, int read_len,
+              int read_words, const GmHit* __restrict__ hits, int hcap, const int32_t* __restrict__ sel,
+              const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work_p, GmFullRes* __restrict__ res, uint8_t* __restrict__ ops, int ops_stride,
+              uint32_t* __restrict__ back_pool, size_t back_words, int max_w, unsigned long long* __restrict__ stats,
+              const int8_t* __restrict__ xover, const int32_t* __restrict__ sel_sidx) {
+  extern __shared__ __align__(16) uint8_t sm[];
+  const int lane = threadIdx.x, g = lane >> 4;
+  P2CsG4 A;
+  A.reads = reads; A.initbp = initbp; A.read_len = read_len; A.read_words = read_words; A.hits = hits; A.hcap = hcap; A.sel = sel; A.sel_sidx = sel_sidx;
+  A.work = work; A.res = res; A.ops = ops; A.ops_stride = ops_stride; A.max_w = max_w; A.xover = xover;
+  A.qstride = (read_len + 15) & ~15; A.mw16 = (max_w + 15) & ~15;
+  A.rc_all = sm; A.qr4_all = sm + 4 * A.qstride; A.db_all = A.qr4_all + 16 * A.qstride; A.carry_all = (int*)(A.db_all + 4 * A.mw16);
+  uint32_t* back = back_pool + ((size_t)blockIdx.x * 4 + g) * back_words;
+  const uint32_t n_work = *n_work_p;
+  unsigned long long fcalls = 0, fcells = 0;
+  // A wave takes 32 consecutive work items at a time, first the forward-strand windows among them four by four, then the reverse-strand ones: a pass holds
+  // windows of one kind (the strand decides the tie rules of all 36 state updates of a cell, ref: sw-full-cs.c:356-541; as a per-lane value both
+  // variants of every update would run).
+  for (uint32_t chunk = blockIdx.x * 32u; chunk < n_work; chunk += gridDim.x * 32u) {
+    bool mine = false, rev = false;
+    if (lane < 32 && chunk + (uint32_t)lane < n_work) {
+      const uint32_t wk = work[chunk + lane];
+      const int id = sel[(size_t)(wk >> 6) * SEL_MAX + (wk & 63)];
+      mine = true; rev = ((id >> 16) != ix.cs_flip) && sc.tiebreak_rev;
+    }
+    const uint32_t m_fw = (uint32_t)__ballot(mine && !rev), m_rv = (uint32_t)__ballot(mine && rev);
+    for (int cls = 0; cls < 2; cls++) {
+      uint32_t m = cls ? m_rv : m_fw;
+      while (m) {
+        uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0; int np = 0;
+        if (m) { p0 = (uint32_t)__builtin_ctz(m); m &= m - 1u; np++; }
+        if (m) { p1 = (uint32_t)__builtin_ctz(m); m &= m - 1u; np++; }
+        if (m) { p2 = (uint32_t)__builtin_ctz(m); m &= m - 1u; np++; }
+        if (m) { p3 = (uint32_t)__builtin_ctz(m); m &= m - 1u; np++; }
+        const bool has = g < np;
+        const uint32_t wi = chunk + (g == 0 ? p0 : (g == 1 ? p1 : (g == 2 ? p2 : p3)));
+        if (cls) p2cs_g4_pass<true, TABOO>(ix, sc, P, A, wi, has, back, lane, fcalls, fcells);
+        else p2cs_g4_pass<false, TABOO>(ix, sc, P, A, wi, has, back, lane, fcalls, fcells);
+      }
+    }
+  }
+  for (int d = 32; d >= 16; d >>= 1) { fcalls += __shfl_xor(fcalls, d); fcells += __shfl_xor(fcells, d); }
+  if (lane == 0) { GS_ADD(stats, GS_FULL_CALLS, fcalls); GS_ADD(stats, GS_FULL_CELLS, fcells); }
+}
+
 int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs_params9, const uint32_t* d_reads, const uint8_t* d_initbp, int n_reads,
                        int read_len, int read_words, int window_len, const GmHit* d_hits, int hcap, const int32_t* d_sel, const uint32_t* d_work,
                        const uint32_t* d_n_work, GmFullRes* d_res, uint8_t* d_ops, int ops_stride, uint32_t* d_back, size_t back_words, int grid,
@@ -1582,6 +1903,24 @@ int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs
   if (lds > 48 * 1024 && lds > configured) {
     GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
+  // four windows per wave (k_pass2_cs_g4) unless GM_P2_G4=0 asks for the one-window kernel; a wave owns four consecutive back-pointer scratches
+  if (!(gm_tune("GM_P2_G4") && atoi(gm_tune("GM_P2_G4")) == 0) && grid >= 4) {
+    const size_t q16 = (size_t)((read_len + 15) & ~15), lds4 = 20 * q16 + 4 * (size_t)((window_len + 15) & ~15) + 4 * (size_t)window_len * 48 + 64;
+    if (lds4 <= 160 * 1024) {
+      static GmLdsLimit lim4; size_t& conf4 = lim4.cur();
+      if (lds4 > 48 * 1024 && lds4 > conf4) {
+        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4)); conf4 = lds4; }
+      if (P.taboo > 0)
+        hipLaunchKernelGGL(k_pass2_cs_g4<true>, dim3(grid / 4), dim3(GM_WAVE), lds4, stream, ix, sc, P, d_reads, d_initbp, n_reads, read_len, read_words, d_hits, hcap, d_sel,
+                           d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_words, window_len, d_stats, d_xover, d_sel_sidx);
+      else
+        hipLaunchKernelGGL(k_pass2_cs_g4<false>, dim3(grid / 4), dim3(GM_WAVE), lds4, stream, ix, sc, P, d_reads, d_initbp, n_reads, read_len, read_words, d_hits, hcap, d_sel,
+                           d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_words, window_len, d_stats, d_xover, d_sel_sidx);
+      GM_HIP(hipGetLastError());
+      return GM_OK;
+    }
+  }
   if (P.taboo > 0)
   hipLaunchKernelGGL(k_pass2_cs<true>, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, P, d_reads, d_initbp, n_reads, read_len, read_words, d_hits, hcap, d_sel,
                      d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_words, window_len, d_stats, d_xover, d_sel_sidx);
