@@ -1096,6 +1096,9 @@ int gm_launch_pass1(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
                     unsigned long long* d_slots, unsigned long long* d_stats, hipStream_t stream, const int32_t* d_pair_min, const uint8_t* d_saved,
                     const uint8_t* d_initbp, bool early_stop) {
   if (n_reads == 0) return GM_OK;
+  // The carry rows of the vector filter exist only for reads of more than 128 bases (two stripes): without them a wave's LDS is 320 B at 100 bp instead of 880 B,
+  // and LDS is what bounds the filter's waves beside the seed lookup (k_lookup_v5 leaves ~5 KB of a CU's 160 KB: 5 waves at 1 KB each, 10 at 512 B).
+  const size_t carry_bytes = read_len > 128 ? (size_t)window_len * 4 : 0;
   // the early stop of a window that cannot reach the threshold (sw_vector_wave_s): only where a score below the threshold is never read again (unpaired
   // reads: the caller says so), with a scoring scheme in which a cell gains at most `match` and a gap never gains, and within the 16-bit range of the test
   const int early = (early_stop && !d_pair_min && !sc.gapless && sc.match > 0 && sc.mismatch <= sc.match && sc.a_go >= 0 && sc.a_ge >= 0 && sc.b_go >= 0 && sc.b_ge >= 0 &&
@@ -1103,11 +1106,11 @@ int gm_launch_pass1(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
                      !(gm_tune("GM_P1_EARLY") && atoi(gm_tune("GM_P1_EARLY")) == 0)) ? 1 : 0;
   if (ix.colour) {
     if (!d_initbp) { gm_set_error("pass 1 in colour space needs the primer letters"); return GM_E_ARG; }
-    const size_t lds = ((read_len + 15) & ~15) + 2 * (size_t)((window_len + 15) & ~15) + (size_t)window_len * 4 + 64;
+    const size_t lds = ((read_len + 15) & ~15) + 2 * (size_t)((window_len + 15) & ~15) + carry_bytes + 64;
     hipLaunchKernelGGL(k_pass1<true>, dim3(n_reads * 2), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
                        window_len, window_overlap_abs, d_hits, d_perm, d_hit_cnt, hcap, d_slots, d_stats, d_pair_min, d_saved, d_initbp, early);
   } else {
-    const size_t lds = ((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 4 + 64;
+    const size_t lds = ((read_len + 15) & ~15) + ((window_len + 15) & ~15) + carry_bytes + 64;
     hipLaunchKernelGGL(k_pass1<false>, dim3(n_reads * 2), dim3(GM_WAVE), lds, stream, ix, sc, d_reads, n_reads, read_len, read_words,
                        window_len, window_overlap_abs, d_hits, d_perm, d_hit_cnt, hcap, d_slots, d_stats, d_pair_min, d_saved, (const uint8_t*)nullptr, early);
   }
