@@ -282,6 +282,7 @@ struct DevSet {
   int cur_len = -1, scap = 0, scap2 = 0, hcap = 0, rcap_per_read = 8, ops_stride = 0, eff_batch = 0;
   int p2_grid = 0;                                           // pass-2 grid for this read length: the session's, capped so that the back-pointer scratch stays within 2 GB
   int8_t* d_xover = nullptr; bool xover_on = false;        // colour space with QVs: per-position crossover scores [B][read_len]
+  uint8_t* d_qv = nullptr; uint8_t* d_post_bq = nullptr;   // ... and the QVs themselves (clamped to 0..250) for post_sw on the device, which leaves the base qualities in d_post_bq [rcap][read_len]
   uint32_t* d_reads = nullptr; uint8_t* d_initbp = nullptr; uint64_t* d_surv = nullptr; uint32_t* d_surv_cnt = nullptr;   // d_initbp: colour space primer letters
   uint32_t* d_surv_seg = nullptr;                                          // [2B][S + 1] survivors after each slab (K1 emits slab by slab)
   uint64_t* d_surv2 = nullptr; uint32_t* d_surv_cnt2 = nullptr;            // survivors after the exact isolation prune (K1b) = input of K2
@@ -298,6 +299,7 @@ struct DevSet {
 // (three slots: one being filled while the host threads still work on the two sub-batches before it).
 struct HostSlot {
   GmFullRes* res = nullptr; uint8_t* ops = nullptr; uint32_t* sel_cnt = nullptr; uint32_t* sel_off = nullptr; uint32_t* reads = nullptr;
+  uint8_t* post_bq = nullptr; size_t post_bq_cap = 0; bool post_bq_on = false;   // base qualities of the device's post_sw (reads with QVs), read_len bytes per result
   GmPostRes* post = nullptr; size_t post_cap = 0; bool post_on = false;      // colour space: the device's post_sw results of this sub-batch (post_on: they are there)
   size_t res_cap = 0, ops_cap = 0, n_cap = 0, reads_cap = 0; uint32_t n_work = 0;
 };
@@ -311,7 +313,7 @@ static int slot_reserve(void** p, size_t* cap, size_t bytes) {
   return GM_OK;
 }
 static void slot_free(HostSlot& h) {
-  void* ptrs[] = {h.res, h.ops, h.sel_cnt, h.sel_off, h.reads, h.post};
+  void* ptrs[] = {h.res, h.ops, h.sel_cnt, h.sel_off, h.reads, h.post, h.post_bq};
   for (void* p : ptrs) if (p) (void)hipHostFree(p);
   h = HostSlot();
 }
@@ -321,6 +323,7 @@ struct gm_session {
   gm_params_t P; GmScoreDev sc;
   double score_alpha = 0, score_beta = 0;
   double pr_mismatch = .01, pr_del_open = 0, pr_del_extend = 0, pr_ins_open = 0, pr_ins_extend = 0;   // post_sw_setup's arguments (ref: gmapper.c:2568-2571,2959-2963)
+  double* d_qtab = nullptr;                       // colour space: log(1 - e(q)), log(e(q) / 3) for q = 0..250 as the host's libm computes them, for post_sw on the device with QVs
   int max_batch = 0, p2_grid = 16384;             // pass-2 waves in flight (GM_P2_GRID); each owns a back-pointer scratch, see DevSet::p2_grid
   hipStream_t stream = nullptr;                   // front of the pipeline (reads in, K1, K1b, K2); the only stream of the paired path
   hipStream_t stream_b = nullptr;                 // back of the pipeline (pass 1, selection, pass 2, results out): runs beside the next sub-batch's front
@@ -344,9 +347,9 @@ struct gm_session {
 static void free_buffers(DevSet& D) {
   void* ptrs[] = {D.d_xover, D.d_reads, D.d_initbp, D.d_surv, D.d_surv_cnt, D.d_surv_seg, D.d_surv2, D.d_surv_cnt2, D.d_hits, D.d_perm, D.d_hit_cnt, D.d_slots, D.d_heavy_list, D.d_heavy_cnt,
                   D.d_sel, D.d_sel_sidx, D.d_sel_cnt, D.d_sel_off, D.d_work, D.d_n_work, D.d_res, D.d_ops, D.d_back,
-                  D.d_pmin, D.d_pmax, D.d_saved, D.d_saved_list, D.d_post, D.d_post_fw, D.d_post_info};
+                  D.d_pmin, D.d_pmax, D.d_saved, D.d_saved_list, D.d_post, D.d_post_fw, D.d_post_info, D.d_qv, D.d_post_bq};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  D.d_post = nullptr; D.d_post_fw = nullptr; D.d_post_info = nullptr;
+  D.d_post = nullptr; D.d_post_fw = nullptr; D.d_post_info = nullptr; D.d_qv = nullptr; D.d_post_bq = nullptr;
   D.d_xover = nullptr; D.d_reads = nullptr; D.d_initbp = nullptr; D.d_surv = nullptr; D.d_surv_cnt = nullptr; D.d_surv_seg = nullptr; D.d_surv2 = nullptr; D.d_surv_cnt2 = nullptr; D.d_hits = nullptr; D.d_perm = nullptr; D.d_hit_cnt = nullptr; D.d_slots = nullptr;
   D.d_heavy_list = nullptr; D.d_heavy_cnt = nullptr; D.d_sel = nullptr; D.d_sel_sidx = nullptr; D.d_sel_cnt = nullptr; D.d_sel_off = nullptr;
   D.d_work = nullptr; D.d_n_work = nullptr; D.d_res = nullptr; D.d_ops = nullptr; D.d_back = nullptr;
@@ -376,7 +379,7 @@ static int alloc_buffers(gm_session* s, DevSet& D, int read_len, bool paired = f
   D.back_stride = (((size_t)read_len * W + 255) / 256) * 256;
   if (s->P.colour_space) { D.ops_stride *= 2; D.back_stride *= 12; }   // backtrace byte + letter codes per column; three words of back pointers per cell
   GM_HIP(hipMalloc(&D.d_reads, (size_t)B * read_words * 4 + 64));
-  if (s->P.colour_space) { GM_HIP(hipMalloc(&D.d_initbp, (size_t)B + 64)); GM_HIP(hipMalloc(&D.d_xover, (size_t)B * read_len + 64)); }
+  if (s->P.colour_space) { GM_HIP(hipMalloc(&D.d_initbp, (size_t)B + 64)); GM_HIP(hipMalloc(&D.d_xover, (size_t)B * read_len + 64)); GM_HIP(hipMalloc(&D.d_qv, (size_t)B * read_len + 64)); }
   GM_HIP(hipMalloc(&D.d_surv, (size_t)rs * D.scap * 8));
   GM_HIP(hipMalloc(&D.d_surv_cnt, (size_t)rs * 4));
   if (D.scap2 > 0) {
@@ -401,6 +404,7 @@ static int alloc_buffers(gm_session* s, DevSet& D, int read_len, bool paired = f
     GM_HIP(hipMalloc(&D.d_post, rcap * sizeof(GmPostRes)));
     GM_HIP(hipMalloc(&D.d_post_fw, (size_t)GM_POST_THREADS * (size_t)(read_len + 1) * 17 * 8));
     GM_HIP(hipMalloc(&D.d_post_info, (size_t)GM_POST_THREADS * (size_t)(read_len + 1) * 4));
+    GM_HIP(hipMalloc(&D.d_post_bq, rcap * (size_t)read_len + 64));
   }
   D.p2_grid = (int)std::max<size_t>(256, std::min<size_t>((size_t)s->p2_grid, ((size_t)2 << 30) / D.back_stride));
   GM_HIP(hipMalloc(&D.d_back, (size_t)D.p2_grid * D.back_stride));
@@ -457,6 +461,18 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   s->pr_ins_open = pow(2.0, (double)s->P.b_gap_open_score / s->score_alpha);
   s->pr_del_extend = pow(2.0, (double)s->P.a_gap_extend_score / s->score_alpha);
   s->pr_ins_extend = pow(2.0, ((double)s->P.b_gap_extend_score - s->score_beta) / s->score_alpha);
+  if (s->P.colour_space && !getenv("GM_POST_SW_HOST")) {
+    // The per-colour error rates post_sw derives from quality values (ref: sw-post.c:486-491, pr_err_from_qv util.h:285-293; Sanger QVs, the binary's default),
+    // tabulated here with the host's libm for every QV the formula distinguishes: the device kernel reads the very doubles the host routine computes.
+    std::vector<double> qt(2 * 251);
+    for (int q = 0; q <= 250; q++) {
+      double e = q <= 0 ? .99999999 : (q >= 250 ? 1E-25 : pow(10.0, -(double)q / 10.0));
+      if (e > .75) e = .75;
+      qt[2 * q] = log(1 - e); qt[2 * q + 1] = log(e / 3.0);
+    }
+    GM_HIP(hipMalloc(&s->d_qtab, qt.size() * 8));
+    GM_HIP(hipMemcpy(s->d_qtab, qt.data(), qt.size() * 8, hipMemcpyHostToDevice));
+  }
   if (s->P.match_mode != 1 && s->P.match_mode != 2) { delete s; gm_set_error("match_mode %d: 1 or 2 (ref: gmapper.c:2624; 3 and 4 are paired-mode settings with mate-pair region counts)", s->P.match_mode); return GM_E_ARG; }
   if (s->P.ungapped && !s->P.local_alignment) { delete s; gm_set_error("ungapped mode needs local alignment (ref: gmapper.c:2330-2333)"); return GM_E_ARG; }
   if (s->P.colour_space && s->P.local_alignment) { delete s; gm_set_error("local alignment is implemented for letter space only"); return GM_E_ARG; }
@@ -490,6 +506,7 @@ extern "C" void gm_session_free(gm_session_t* s) {
   (void)hipSetDevice(s->ix->device);
   free_buffers(s->set[0]); free_buffers(s->set[1]); free_buffers(s->set2[0]); free_buffers(s->set2[1]);
   for (auto& h : s->slot) slot_free(h);
+  if (s->d_qtab) (void)hipFree(s->d_qtab);
   if (s->d_pairs) (void)hipFree(s->d_pairs);
   if (s->d_pair_cnt) (void)hipFree(s->d_pair_cnt);
   (void)hipFree(s->d_stats);
@@ -720,6 +737,7 @@ struct Finalizer {
   const char* const* name_ptr; const int* name_len; long name_base;
   const uint8_t* initbp = nullptr; int ops_half = 0; CsPostConsts csk = CsPostConsts();
   const GmFullRes* res_base = nullptr; const GmPostRes* post_base = nullptr;           // colour space: post_sw results of the device, parallel to the sub-batch's result records
+  const uint8_t* bq_base = nullptr;                                                    // ... and, for reads with QVs, the base qualities it computed (read_len bytes per result)
   const char* const* seq_ptr = nullptr;                                                // text input: the read as it stood in the file (fields the reference prints from re->seq)
   const char* const* qual_ptr = nullptr; int qual_delta = 33;                          // FASTQ input: QUAL string of every read of this sub-batch   // colour space: primer letters of this sub-batch, ops_stride / 2
   const uint32_t* hgen = nullptr;                                                      // SHRiMP / pretty output: the packed genome on the host
@@ -819,7 +837,7 @@ struct Finalizer {
   void redo_on_host(FHit& h) const {                    // sw_full_cs's own strings, then the host's post_sw (ref: sw-post.c:636-758), then the posterior score
     const GmFullRes* r = h.r;
     cs_alignment_strings(h.ops, h.ops + ops_half, std::min(r->n_ops, ops_half), h.db, h.qr);
-    cs_post_sw(csk, reads + (size_t)r->read_idx * read_words, (int)initbp[r->read_idx], r->read_start, h, nullptr, qual_delta);
+    cs_post_sw(csk, reads + (size_t)r->read_idx * read_words, (int)initbp[r->read_idx], r->read_start, h, qual_ptr ? qual_ptr[r->read_idx] : nullptr, qual_delta);
     h.dev_post = false;
     const double a = s->score_alpha, b = s->score_beta;
     int ps = (int)rint(a * log(h.posterior) / log(2.0) + (double)r->rmapped * (2.0 * a + b));
@@ -838,10 +856,14 @@ struct Finalizer {
     if (h.score_full > 0 && !P.local_alignment) {                  // local mode: mapping qualities are off (ref: gmapper.c:2325-2328, mapping.c:1648)
       const double a = s->score_alpha, b = s->score_beta;
       if (P.colour_space) {
-        if (post_base && !qual_ptr && post_base[r - res_base].valid == 1) {   // k_post_sw_cs ran: the op record carries the re-called letters in its spare bits
+        if (post_base && (!qual_ptr || bq_base) && post_base[r - res_base].valid == 1) {   // k_post_sw_cs ran: the op record carries the re-called letters in its spare bits
           const GmPostRes& pr = post_base[r - res_base];
           cs_alignment_strings(h.ops, h.ops + ops_half, std::min(r->n_ops, ops_half), h.db, h.qr, true);
           h.posterior = pr.posterior; h.cs_match = pr.cs_match; h.cs_mismatch = pr.cs_mismatch; h.cs_xover = pr.cs_xover; h.qual.clear(); h.dev_post = true;
+          if (qual_ptr) {                                                // base qualities of the read positions the alignment covers, in alignment order
+            size_t nq = 0; for (char c : h.qr) nq += c != '-';
+            h.qual.assign((const char*)bq_base + (size_t)(r - res_base) * read_len, std::min(nq, (size_t)read_len));
+          }
           if (near_rint(a * log(h.posterior) / log(2.0) + (double)r->rmapped * (2.0 * a + b))) { redo_on_host(h); return; }      // AS at a rounding boundary
         } else {
         cs_alignment_strings(h.ops, h.ops + ops_half, std::min(r->n_ops, ops_half), h.db, h.qr);
@@ -1181,13 +1203,15 @@ static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len,
                           -s->P.b_gap_open_score, -s->P.b_gap_extend_score, s->P.anchor_width, s->P.indel_taboo_len};   // sw_full_cs_setup's arguments (ref: gmapper.c:2944-2947)
       rc = gm_launch_pass2_cs(dv, s->sc, cs9, D.d_reads, D.d_initbp, n, read_len, read_words, W, D.d_hits, D.hcap, D.d_sel, D.d_work, D.d_n_work,
                               D.d_res, D.d_ops, D.ops_stride, (uint32_t*)D.d_back, D.back_stride / 4, D.p2_grid, d_stats, q, D.xover_on ? D.d_xover : nullptr);
-      // post_sw of every result on the device, unless the reads carry quality values (per-colour error rates and base qualities: host routine) or
+      // post_sw of every result on the device (with the reads' quality values where they have them: per-colour error rates from the host's table, base qualities back), unless
       // the alignment is local (no mapping qualities at all, ref: gmapper.c:2325-2328)
-      H.post_on = rc == GM_OK && D.d_post && !D.xover_on && !s->P.local_alignment;
+      H.post_on = rc == GM_OK && D.d_post && !s->P.local_alignment && (!D.xover_on || s->d_qtab);
+      H.post_bq_on = H.post_on && D.xover_on;
       if (H.post_on) {
         const CsPostConsts c = cs_post_consts(s);
         GmCsPostDev K; K.let_m = c.let_m; K.let_x = c.let_x; K.col_m[0] = c.col_m[0]; K.col_m[1] = c.col_m[1]; K.col_x[0] = c.col_x[0]; K.col_x[1] = c.col_x[1];
         K.pr_del_open = c.pr_del_open; K.pr_del_extend = c.pr_del_extend; K.pr_ins_open = c.pr_ins_open; K.pr_ins_extend = c.pr_ins_extend;
+        K.qv = H.post_bq_on ? D.d_qv : nullptr; K.qtab = H.post_bq_on ? s->d_qtab : nullptr; K.bq = H.post_bq_on ? D.d_post_bq : nullptr;
         rc = gm_launch_post_sw_cs(K, D.d_reads, D.d_initbp, read_len, read_words, D.d_res, D.d_ops, D.ops_stride, D.d_n_work, (uint32_t)rcap, D.d_post, D.d_post_fw, D.d_post_info,
                                   GM_POST_THREADS, q);
       }
@@ -1203,9 +1227,12 @@ static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len,
       cap = H.n_cap; rc = slot_reserve((void**)&H.sel_off, &cap, (size_t)n * 4); H.n_cap = cap; if (rc) return rc; }
     H.n_work = n_work;
     if (!s->P.colour_space) H.post_on = false;
+    if (!H.post_on) H.post_bq_on = false;
     if (H.post_on) { size_t cap = H.post_cap; rc = slot_reserve((void**)&H.post, &cap, (size_t)n_work * sizeof(GmPostRes)); H.post_cap = cap; if (rc) return rc; }
+    if (H.post_bq_on) { size_t cap = H.post_bq_cap; rc = slot_reserve((void**)&H.post_bq, &cap, (size_t)n_work * read_len + 64); H.post_bq_cap = cap; if (rc) return rc; }
     if (n_work) {
       if (H.post_on) GM_HIP(hipMemcpyAsync(H.post, D.d_post, (size_t)n_work * sizeof(GmPostRes), hipMemcpyDeviceToHost, q));
+      if (H.post_bq_on) GM_HIP(hipMemcpyAsync(H.post_bq, D.d_post_bq, (size_t)n_work * read_len, hipMemcpyDeviceToHost, q));
       GM_HIP(hipMemcpyAsync(H.res, D.d_res, (size_t)n_work * sizeof(GmFullRes), hipMemcpyDeviceToHost, q));
       GM_HIP(hipMemcpyAsync(H.ops, D.d_ops, (size_t)n_work * D.ops_stride, hipMemcpyDeviceToHost, q));
     }
@@ -1260,7 +1287,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   s->last_lookup_ms = 0; s->last_lookup_bytes = 0; s->last_lookup_launches = 0;
   // names
   std::vector<const char*> nptr; std::vector<int> nlen;
-  std::vector<const char*> qptr; std::vector<int8_t> xbuf; std::vector<const char*> sptr;
+  std::vector<const char*> qptr; std::vector<int8_t> xbuf; std::vector<uint8_t> qvbuf; std::vector<const char*> sptr;
   if (seq_text) {                                            // one line per read: read_len letters, or primer + read_len colours
     const char* p = seq_text; const int want = read_len + (s->P.colour_space ? 1 : 0);
     for (int i = 0; i < n_reads; i++) {
@@ -1302,7 +1329,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     J->outs.assign(nchunks, std::string()); J->cm.assign(nchunks, 0); J->cr.assign(nchunks, 0);
     std::atomic<int> next(0);
     Finalizer F{s, read_len, read_words, J->hreads, names ? nptr.data() + J->base : nullptr, names ? nlen.data() + J->base : nullptr, (long)J->base};
-    if (s->P.colour_space) { F.initbp = initbp_host + J->base; F.ops_half = ops_stride / 2; F.csk = cs_post_consts(s); if (J->hs->post_on) { F.res_base = J->hs->res; F.post_base = J->hs->post; } }
+    if (s->P.colour_space) { F.initbp = initbp_host + J->base; F.ops_half = ops_stride / 2; F.csk = cs_post_consts(s); if (J->hs->post_on) { F.res_base = J->hs->res; F.post_base = J->hs->post; if (J->hs->post_bq_on) F.bq_base = J->hs->post_bq; } }
     F.redo_ctr = &post_redo;
     if (const char* e = gm_tune("GM_POST_GUARD_TOL")) F.guard_tol = atof(e);          // (tests: a huge tolerance sends every result through the redo path)
     if (quals) { F.qual_ptr = qptr.data() + J->base; F.qual_delta = qual_delta; }
@@ -1384,11 +1411,12 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     if (initbp_host) GM_HIP(hipMemcpyAsync(S.d_initbp, initbp_host + base, (size_t)n, hipMemcpyHostToDevice, c));
     S.xover_on = false;
     if (initbp_host && quals) {                              // per-position crossover scores from the QVs, ref: gmapper.c:532-544
-      xbuf.resize((size_t)n * read_len);
+      xbuf.resize((size_t)n * read_len); qvbuf.resize((size_t)n * read_len);
       for (int i = 0; i < n; i++) {
         const char* q = qptr[base + i];
         for (int j = 0; j < read_len; j++) {
           const int qv = (int)q[j] - qual_delta;
+          qvbuf[(size_t)i * read_len + j] = (uint8_t)std::min(250, std::max(0, qv));   // what post_sw's error-rate formula distinguishes (qv <= 0, qv >= 250, ref: util.h:285-293)
           const double pe = qv <= 0 ? .99999999 : (qv >= 250 ? 1E-25 : pow(10.0, -(double)qv / 10.0));   // pr_err_from_qv, ref: util.h:285-293
           int cx = (int)(s->score_alpha * log(pe / 3.0) / log(2.0));
           if (cx > -1) cx = -1; else if (cx < 2 * s->P.crossover_score) cx = 2 * s->P.crossover_score;
@@ -1396,6 +1424,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
         }
       }
       GM_HIP(hipMemcpyAsync(S.d_xover, xbuf.data(), xbuf.size(), hipMemcpyHostToDevice, c));
+      GM_HIP(hipMemcpyAsync(S.d_qv, qvbuf.data(), qvbuf.size(), hipMemcpyHostToDevice, c));
       GM_HIP(hipStreamSynchronize(c));                      // xbuf is reused by the next sub-batch
       S.xover_on = true;
     }

@@ -126,7 +126,10 @@ int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
 
 // colour-space pass 2 (sw_full_cs per selected window); ops_stride bytes per result: backtrace bytes, then (genome << 4 | read) codes
 // colour-space post_sw on the device (gm_post.hip): constants = CsPostConsts of gm_host.hip (logs taken on the host), one record per pass-2 result
-struct GmCsPostDev { double let_m, let_x, col_m[2], col_x[2], pr_del_open, pr_del_extend, pr_ins_open, pr_ins_extend; };
+struct GmCsPostDev { double let_m, let_x, col_m[2], col_x[2], pr_del_open, pr_del_extend, pr_ins_open, pr_ins_extend;
+                     // reads with quality values (csfastq): qv[read][colour] = the colour's QV clamped to 0..250, qtab[2 q] / [2 q + 1] = log(1 - e(q)) / log(e(q) / 3) as the HOST's libm
+                     // computes them (ref: sw-post.c:486-491), bq[result][read position] receives the base qualities (PHRED + 33, ref: :568-586); all null without QVs
+                     const uint8_t* qv; const double* qtab; uint8_t* bq; };
 struct GmPostRes { double posterior; int32_t cs_match, cs_mismatch, cs_xover, valid; };
 #define GM_POST_THREADS 32768
 int gm_launch_post_sw_cs(const GmCsPostDev& K, const uint32_t* d_reads, const uint8_t* d_initbp, int read_len, int read_words, const GmFullRes* d_res, uint8_t* d_ops,

@@ -8,7 +8,10 @@
 // quality, MAPQ, the Z tags) could differ from the host's only when the value rounded lies that close to a rounding boundary -- those are caught on the
 // host and redone there (below).  GM_POST_SW_HOST=1 keeps the host routine throughout, and FASTQ input (per-colour error
 // rates from the QVs, base qualities) always takes it.  A letter call between two (nearly) equal posteriors is decided by the last bits too:
-// the kernel flags those results (valid = 2) and the host routine redoes them.
+// the kernel flags those results (valid = 2) and the host routine redoes them -- as it does a result with a base quality (reads with QVs) whose
+// truncation to an integer falls within 1e-7 of its boundary.
+// Reads with quality values (round 3): the per-colour error rates come from a table the host computed with its own libm (251 entries: the same doubles
+// the host routine uses), so again only exp / log of the recursion differ.
 //
 // What the kernel leaves: GmPostRes per result (posterior, the match / mismatch / crossover counts), and the re-called letters written into the spare
 // bits of the result's backtrace bytes -- letter in bits 4-5 of bt[t], lower-case flag in bit 6; the type nibble, sw_full_cs's crossover mark (bit 7) and
@@ -18,13 +21,16 @@
 #include "gm_common.h"
 #include "gm_internal.h"
 
-// column descriptor: bits 0-2 let + 2 (0: insertion, 1: no state matches, 2-5: A C G T), 3-4 colour, 5 which error rate, 8-10 crt (filled by the backward sweep)
+// column descriptor: bits 0-2 let + 2 (0: insertion, 1: no state matches, 2-5: A C G T), 3-4 colour, 5 which error rate, 8-10 crt (filled by the backward sweep),
+// 12-14 the letter sw_full_cs had called (7: none), 16-23 + bit 24: the colour's quality value (reads with QVs)
 __device__ __forceinline__ double k_prior(const GmCsPostDev& K, uint32_t info, int st) {                    // nodePrior, ref: sw-post.c:111-138
   const int let = (int)(info & 7u) - 2, col = (int)((info >> 3) & 3u), which = (int)((info >> 5) & 1u);
   const int l = (st >> 2) & 3, r = st & 3;
   double val = 0;
   if (let != -2) val = val - ((r == let) ? K.let_m : K.let_x);
-  val = val - (((l ^ r) == col) ? K.col_m[which] : K.col_x[which]);
+  double cm = K.col_m[which], cx = K.col_x[which];
+  if (info & (1u << 24)) { const uint32_t q = (info >> 16) & 0xFFu; cm = K.qtab[2 * q]; cx = K.qtab[2 * q + 1]; }     // the colour's own error rate (reads with QVs)
+  val = val - (((l ^ r) == col) ? cm : cx);
   return val;
 }
 
@@ -47,8 +53,9 @@ k_post_sw_cs(GmCsPostDev K, const uint32_t* __restrict__ reads, const uint8_t* _
       const int init_bp = (int)initbp[R.read_idx];
       auto colour = [&](int j) { return (int)((rw[j >> 3] >> ((j & 7) * 4)) & 0xf); };
       // ---- load_local_vectors, ref: sw-post.c:448-528 ----
-      int start_run = 0, len = 0;
-      { int j; for (j = 0; j < R.read_start; j++) { const int c = colour(j); if (c == 15) { start_run = 15; break; } start_run ^= c; } }
+      int start_run = 0, len = 0, min_qv = 255;
+      const uint8_t* qvr = K.qv ? K.qv + (size_t)R.read_idx * read_len : nullptr;
+      { int j; for (j = 0; j < R.read_start; j++) { const int c = colour(j); if (c == 15) { start_run = 15; min_qv = 0; break; } start_run ^= c; if (qvr) min_qv = min(min_qv, (int)qvr[j]); } }
       { int j = R.read_start;
         for (int t = 0; t < n; t++) {
           const int type = bt[t] & 0x0f; if (type == 1) continue;                     // deletion: no read position
@@ -57,7 +64,13 @@ k_post_sw_cs(GmCsPostDev K, const uint32_t* __restrict__ reads, const uint8_t* _
           const int let = ins ? -2 : (d < 4 ? d : -1);
           const int cc = j < read_len ? colour(j) : 15; int col, which;
           if ((len == 0 && start_run == 15) || cc == 15) { col = 0; which = 1; } else { col = cc ^ (len == 0 ? start_run : 0); which = 0; }
-          infobuf[(size_t)len * T + tid] = (uint32_t)(let + 2) | ((uint32_t)col << 3) | ((uint32_t)which << 5);
+          uint32_t word = (uint32_t)(let + 2) | ((uint32_t)col << 3) | ((uint32_t)which << 5);
+          const int bc = codes[t] & 15; word |= (uint32_t)(bc < 4 ? bc : 7) << 12;
+          if (qvr && which == 0 && j < read_len) {                   // ref: sw-post.c:486-491 (the first column takes the smallest QV of the skipped colours and its own)
+            const int q = len == 0 ? min(min_qv, (int)qvr[j]) : (int)qvr[j];
+            word |= ((uint32_t)q << 16) | (1u << 24);
+          }
+          infobuf[(size_t)len * T + tid] = word;
           len++; j++;
         } }
       if (len > 0) {
@@ -97,6 +110,17 @@ k_post_sw_cs(GmCsPostDev K, const uint32_t* __restrict__ reads, const uint8_t* _
           // same probability -- is decided by the last bits of exp / log: such a result goes to the host routine (0.1 % of the results).
           for (int b = 0; b < 4; b++) if (b != crt && p4[b] >= p4[crt] * (1.0 - 1e-9)) tie = true;
           infobuf[(size_t)i * T + tid] = info | ((uint32_t)crt << 8);
+          if (K.bq) {                                                 // get_base_qualities, ref: sw-post.c:568-586 (qv_from_pr_corr, util.h:267-283; at most 40)
+            const int bc = (int)((info >> 12) & 7u); int tq = 0;
+            if (bc < 4) {
+              const double pr_err = 1 - p4[bc];
+              if (fabs(pr_err - .99999999) < 1e-12 || fabs(pr_err - 1E-25) < 1e-34) tie = true;        // at one of the two cut-offs: the host decides
+              if (pr_err > .99999999) tq = 0; else if (pr_err < 1E-25) tq = 250;
+              else { const double v = -10.0 * log(pr_err) / log(10.0); if (v < 41.5 && fabs(v - rint(v)) < 1e-7) tie = true; tq = (int)v; }   // a truncation at its boundary: the host decides
+            }
+            if (tq > 40) tq = 40;
+            K.bq[(size_t)w * read_len + i] = (uint8_t)(33 + tq);
+          }
           if (i > 0) {
             double e[16], nl[4];
             for (int k = 0; k < 16; k++) { const double a = k_prior(K, info, k) + bw[k]; e[k] = exp(-1 * a); }

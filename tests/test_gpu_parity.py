@@ -634,15 +634,23 @@ def test_fastq_quals_match_reference_golden(gm, tag):
     assert got == sam, _first_diff(got, sam)
 
 
-def test_colour_space_fastq_matches_reference_golden(gm):
+def test_colour_space_fastq_matches_reference_golden(gm, monkeypatch):
     """gm_map_reads_cs_fastq: per-position crossover scores on the device, post_sw with per-colour error rates, QUAL from post_sw,
-    CQ:Z -- byte-identical to gmapper-cs on a csfastq file"""
+    CQ:Z -- byte-identical to gmapper-cs on a csfastq file.  post_sw runs on the device for these reads too (round 3: error rates from the host's table,
+    base qualities back): a huge guard tolerance sends its results through the host redo (the counter shows the device path was the one that ran)."""
     from tests.test_oracle import _cs_fastq_case
     contigs, reads, quals, delta, sam = _cs_fastq_case()
     p = gm.default_params_cs(); p.sam_unaligned = 1
     ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p, max_batch_reads=512)
+    monkeypatch.setenv("GM_POST_GUARD_TOL", "0.49")
+    got_redo = oa.sam_header(contigs) + s.map_reads_cs_fastq(reads, quals, delta)
+    st_redo = s.stats
+    monkeypatch.delenv("GM_POST_GUARD_TOL")
+    assert got_redo == sam, (_first_diff(got_redo, sam), st_redo)
+    assert st_redo["post_sw_host_redo"] > 0.5 * st_redo["full_calls"] > 0, st_redo
     got = oa.sam_header(contigs) + s.map_reads_cs_fastq(reads, quals, delta)
     st = s.stats
+    assert st["post_sw_host_redo"] < 0.01 * st["full_calls"], st
     plain = s.map_reads_cs(reads[:200])                    # the same session without QVs afterwards: global crossover score again
     s.close(); ix.close()
     assert got == sam, (_first_diff(got, sam), st)
