@@ -66,10 +66,12 @@ typedef struct gm_params {
   int indel_taboo_len;                         /* ref: gmapper.h:57  0 */
   double pr_xover;                             /* ref: gmapper.h:119  0.03: fixes score_alpha in colour space (gmapper.c:2557-2563) */
   int local_alignment;                         /* --local, i.e. Gflag off (ref: gmapper.c:2303-2305): sw_full_ls in local mode (soft clips); mapping qualities
-                                                  are then unavailable (gmapper.c:2325-2328): MAPQ 255, no Z0-Z6 tags.  Letter space (unpaired and paired).  0 */
+                                                  are then unavailable (gmapper.c:2325-2328): MAPQ 255, no Z0-Z6 tags.  Letter space (unpaired and paired) and, unpaired, colour space (sw_full_cs with
+                                                  local_alignment, ref: sw-full-cs.c:199-203,315,439-552; no post_sw then, mapping.c:1648; not combined with csfastq quality values).  0 */
   int ungapped;                                /* -U (gapless_sw): pass 1 scores windows with sw_gapless (ref: sw-gapless.c:57-117), every anchor opens a window
                                                   (mapping.c:1095,1154).  As the reference's -U does, also set anchor_width 0, both gap opens -255 and
-                                                  hash_filter_calls 0; requires local_alignment (gmapper.c:2330-2333).  0 */
+                                                  hash_filter_calls 0; requires local_alignment (gmapper.c:2330-2333).  In colour space sw_gapless runs on the contig's colour translation with the
+                                                  read's first colour forced against the primer (sw-gapless.c:84-94).  0 */
   int hash_seeds;                              /* -H (Hflag): lists are keyed by kmer_to_mapidx_hash -- 4^12 lists per seed whatever its weight, so seeds
                                                   heavier than 14 are allowed (ref: gmapper.h:309-336, seeds.c:83-102,132-136).  An index property.  0 */
   int output_format;                           /* 0: SAM (-E, the binary's default); 1: --shrimp-format, one line per mapping -- readname contigname strand

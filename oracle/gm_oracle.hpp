@@ -475,13 +475,23 @@ static inline int sw_vector(const Params& P, const uint32_t* genome, llint goff,
   return score;
 }
 
-// sw_gapless (common/sw-gapless.c:57-117), letter space: best ungapped segment on the diagonal through (g_idx, r_idx) of the contig
-static inline int sw_gapless(const Params& P, const uint32_t* genome, int glen, const uint32_t* read, int rlen, int g_idx, int r_idx) {
+// sw_gapless (common/sw-gapless.c:57-117): best ungapped segment on the diagonal through (g_idx, r_idx) of the contig.  Colour space (genome_ls != null:
+// genome holds colours): a diagonal that starts at the read's first colour compares it with lstocs(letter, primer) first (:84-94); `mismatch` is what
+// sw_gapless_setup got (f1_setup hands over match + crossover in colour space, gmapper.c:2935, f1-wrapper.h:66-68).
+static inline int sw_gapless(const Params& P, const uint32_t* genome, int glen, const uint32_t* read, int rlen, int g_idx, int r_idx,
+                             const uint32_t* genome_ls = nullptr, int init_bp = -1) {
+  const int mismatch = genome_ls ? P.match_score + P.crossover_score : P.mismatch_score;
   int g_left, r_left;
   if (g_idx < r_idx) { g_left = 0; r_left = r_idx - g_idx; } else { g_left = g_idx - r_idx; r_left = 0; }
   int g_right = g_left, r_right = r_left, score = 0, max_score = 0;
+  if (genome_ls != nullptr && r_left == 0) {           // forcefully match the first colour of the read
+    const int real_colour = lstocs((int)EXTRACT(genome_ls, g_right), init_bp);
+    if (real_colour == (int)EXTRACT(read, 0)) score = P.match_score; else { r_left++; g_left++; }
+    r_right++; g_right++;
+    max_score = score;
+  }
   while (g_right < glen && r_right < rlen) {
-    score += (EXTRACT(genome, g_right) == EXTRACT(read, r_right)) ? P.match_score : P.mismatch_score;
+    score += (EXTRACT(genome, g_right) == EXTRACT(read, r_right)) ? P.match_score : mismatch;
     if (score > max_score) max_score = score;
     g_right++; r_right++;
     if (score < 0) score = 0;
@@ -713,14 +723,15 @@ static inline void sw_full_ls(const Params& P, SwFullWorkspace& W, const uint32_
 // Full SW, colour space (common/sw-full-cs.c:249-623 full_sw, :633-937 do_backtrace, :945-1060 pretty_print,
 // :1146-1236 sw_full_cs).  Four letter-space translations of the colour read (start letter (k + initbp) % 4), a
 // 3-state affine DP in four layers; the NW and N transitions may come from another layer at +xover_penalty, the W
-// transition may not; N-vs-anything scores 0.  Global mode (Gflag) only; crossover_score == NULL (no read qualities).
+// transition may not; N-vs-anything scores 0.  Global mode and (round 3) local mode.
 // ---------------------------------------------------------------------------------------------
 struct CsParams { int match = 10, mismatch = -24, xover = -20, a_go = 33, a_ge = 7, b_go = 33, b_ge = 3, anchor_width = 8, indel_taboo_len = 0; };
 typedef SwFullResults SwFullCsResults;
 
 static inline void sw_full_cs(const CsParams& C, const uint32_t* genome_ls, llint goff, int glen, const uint32_t* read, int rlen, int initbp,
                               int threshscore, SwFullCsResults* sfr, bool revcmpl, const Anchor* anchors, int anchors_cnt,
-                              const int* crossover_score = nullptr) {   // per-position crossover scores from the read's QVs (gmapper.c:532-544), or null
+                              const int* crossover_score = nullptr,     // per-position crossover scores from the read's QVs (gmapper.c:532-544), or null
+                              int local_alignment = 0) {                // Gflag off (--local): states floored at 0 / the crossover score with a null back pointer, best cell of the whole band (:199-203,315,439-552)
   const int lena = glen, lenb = rlen;
   struct Lay { int n, w, nw; int8_t bn, bw, bnw; };
   struct Cell { Lay from[4]; };
@@ -755,7 +766,7 @@ static inline void sw_full_cs(const CsParams& C, const uint32_t* genome_ls, llin
     int x_min, x_max;
     anchor_get_x_range(&rectangle, lena, lenb, i, &x_min, &x_max);
     xo = crossover_score ? crossover_score[i] : C.xover;                  // :312
-    init_cell((size_t)(i + 1) * (lena + 1) + (x_min - 1) + 1, 0);         // :319 (global)
+    init_cell((size_t)(i + 1) * (lena + 1) + (x_min - 1) + 1, local_alignment ? 1 : 0);   // :315-322
     const bool notaboo = i < lenb - C.indel_taboo_len;
     for (int j = x_min; j <= x_max; j++) {
       Cell* cnw = &m[(size_t)i * (lena + 1) + j]; Cell* cn = cnw + 1; Cell* cw = cnw + (lena + 1); Cell* cur = cw + 1;
@@ -785,6 +796,8 @@ static inline void sw_full_cs(const CsParams& C, const uint32_t* genome_ls, llin
             if (cnw->from[l].nw + ms + xo > tmp) { tmp = cnw->from[l].nw + ms + xo; tmp2 = FROM_x(l, FROM_NORTHWEST_NORTHWEST); }
           }
         }
+        const int resetval = k ? xo : 0;                                    // :350-353
+        if (tmp <= resetval && local_alignment) { tmp = resetval; tmp2 = 0; }   // :439-442
         cur->from[k].nw = tmp; cur->from[k].bnw = tmp2;
         // ---- north :447-503
         if (!revcmpl) {
@@ -804,6 +817,7 @@ static inline void sw_full_cs(const CsParams& C, const uint32_t* genome_ls, llin
             if (notaboo && cn->from[l].nw - C.b_go - C.b_ge + xo > tmp) { tmp = cn->from[l].nw - C.b_go - C.b_ge + xo; tmp2 = FROM_x(l, FROM_NORTH_NORTHWEST); }
           }
         }
+        if (tmp <= resetval && local_alignment) { tmp = resetval; tmp2 = 0; }   // :503-506
         cur->from[k].n = tmp; cur->from[k].bn = tmp2;
         // ---- west :512-541 (no crossover on a genomic gap)
         if (!revcmpl) {
@@ -813,9 +827,10 @@ static inline void sw_full_cs(const CsParams& C, const uint32_t* genome_ls, llin
           tmp = cw->from[k].w - C.a_ge; tmp2 = FROM_x(k, FROM_WEST_WEST);
           if (notaboo && cw->from[k].nw - C.a_go - C.a_ge > tmp) { tmp = cw->from[k].nw - C.a_go - C.a_ge; tmp2 = FROM_x(k, FROM_WEST_NORTHWEST); }
         }
+        if (tmp <= resetval && local_alignment) { tmp = resetval; tmp2 = 0; }   // :540-543
         cur->from[k].w = tmp; cur->from[k].bw = tmp2;
-        // ---- max on the last read row :547-575
-        if (i == lenb - 1) {
+        // ---- max on the last read row (local: of every row) :547-575
+        if (local_alignment || i == lenb - 1) {
           const Lay& c = cur->from[k];
           if (!revcmpl) {
             if (c.nw > score) { score = c.nw; max_i = i; max_j = j; max_k = k; }
@@ -832,7 +847,7 @@ static inline void sw_full_cs(const CsParams& C, const uint32_t* genome_ls, llin
     if (i + 1 < lenb) {                                                   // :598-606
       int nx_min, nx_max;
       anchor_get_x_range(&rectangle, lena, lenb, i + 1, &nx_min, &nx_max);
-      for (int j = x_max + 1; j <= nx_max; j++) init_cell((size_t)(i + 1) * (lena + 1) + (j + 1), 0);
+      for (int j = x_max + 1; j <= nx_max; j++) init_cell((size_t)(i + 1) * (lena + 1) + (j + 1), local_alignment);
     }
   }
   *sfr = SwFullCsResults();
@@ -1353,7 +1368,7 @@ struct Mapper {
       hv = hash_genome_window(genome, (uint32_t)goff, (uint32_t)wlen) % f1_window_cache_size;
       if (T.f1_tag[hv] == tag) { T.stats.vec_bypassed++; return (int)T.f1_score[hv]; }
     }
-    int score = gapless_call ? sw_gapless(P, genome, gapless_glen, read, rlen, gapless_g_idx, gapless_r_idx) :
+    int score = gapless_call ? sw_gapless(P, genome, gapless_glen, read, rlen, gapless_g_idx, gapless_r_idx, genome_ls, initbp) :
                 genome_ls ? sw_vector_cs(P, P.match_score + P.crossover_score, genome, goff, wlen, read, rlen, genome_ls, initbp)   // gmapper.c:2935
                           : sw_vector(P, genome, goff, wlen, read, rlen);
     T.stats.vec_calls++; T.stats.vec_cells += (uint64_t)wlen * rlen;
@@ -1378,7 +1393,8 @@ struct Mapper {
           if (h.st != re.input_strand) reverse_hit(re, h);
           const uint32_t* gen_cs = (h.gen_st == 0 ? G->cs_fwd[h.cn].data() : G->cs_rc[h.cn].data());
           const uint32_t* gen_ls = (h.gen_st == 0 ? G->fwd[h.cn].data() : G->rc[h.cn].data());
-          h.score_vector = f1_run(T, gen_cs, h.g_off, h.w_len, re.bits[h.st].data(), re.read_len, T.f1_hash_tag, gen_ls, re.initbp[st]);
+          h.score_vector = f1_run(T, gen_cs, h.g_off, h.w_len, re.bits[h.st].data(), re.read_len, T.f1_hash_tag, gen_ls, re.initbp[st],
+                                  P.gapless, (int)G->len[h.cn], (int)(h.g_off + h.anchor.x), (int)h.anchor.y);
         } else
         h.score_vector = f1_run(T, G->fwd[h.cn].data(), h.g_off, h.w_len, re.bits[st].data(), re.read_len, T.f1_hash_tag, nullptr, -1,
                                 P.gapless, (int)G->len[h.cn], (int)(h.g_off + h.anchor.x), (int)h.anchor.y);     // mapping.c:1321-1328
@@ -1437,7 +1453,7 @@ struct Mapper {
       C.anchor_width = P.anchor_width; C.indel_taboo_len = P.indel_taboo_len;
       T.stats.full_calls++;
       sw_full_cs(C, gen, h.g_off, h.w_len, re.bits[h.st].data(), re.read_len, re.initbp[h.st], thresh, &h.sfr, h.gen_st && P.Tflag, &h.anchor, 1,
-                 re.crossover_score.empty() ? nullptr : re.crossover_score.data());
+                 re.crossover_score.empty() ? nullptr : re.crossover_score.data(), P.Gflag ? 0 : 1);
       h.score_full = h.sfr.score;
       h.pct_score_full = (1000 * 100 * h.score_full) / h.score_max;
       return;

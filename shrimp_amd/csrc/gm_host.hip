@@ -475,7 +475,6 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   }
   if (s->P.match_mode != 1 && s->P.match_mode != 2) { delete s; gm_set_error("match_mode %d: 1 or 2 (ref: gmapper.c:2624; 3 and 4 are paired-mode settings with mate-pair region counts)", s->P.match_mode); return GM_E_ARG; }
   if (s->P.ungapped && !s->P.local_alignment) { delete s; gm_set_error("ungapped mode needs local alignment (ref: gmapper.c:2330-2333)"); return GM_E_ARG; }
-  if (s->P.colour_space && s->P.local_alignment) { delete s; gm_set_error("local alignment is implemented for letter space only"); return GM_E_ARG; }
   if ((s->P.colour_space != 0) != (ix->params.colour_space != 0)) { delete s; gm_set_error("session and index disagree on colour space"); return GM_E_ARG; }
   s->max_batch = std::max(64, std::min(max_batch_reads > 0 ? max_batch_reads : 131072, 1 << 20));
   if (const char* e = gm_tune("GM_P2_GRID")) s->p2_grid = std::max(64, std::min(65536, atoi(e)));
@@ -876,6 +875,10 @@ struct Finalizer {
       if (ps < 0) ps = 0;
       h.score_full = ps; h.pct_score_full = (1000 * 100 * ps) / r->score_max;
     }
+    else if (h.score_full > 0 && P.colour_space) {                 // colour space, local mode: no post_sw (mapping.c:1648): sw_full_cs's own strings and counts go out
+      cs_alignment_strings(h.ops, h.ops + ops_half, std::min(r->n_ops, ops_half), h.db, h.qr);
+      h.cs_match = r->n_match; h.cs_mismatch = r->n_mismatch; h.cs_xover = r->n_xover; h.qual.clear();
+    }
     h.pass2_key = P.sw_full_threshold < 0 ? h.score_full : (int)h.pct_score_full;
   }
   // read_pass2's selection over the n pass-2 results of one read (ref: mapping.c:1628-1750): p2 = final hits in output order
@@ -998,8 +1001,10 @@ struct Finalizer {
           if (!rev) p = put_str(p, h->qual.data(), (size_t)nq); else for (int i = nq - 1; i >= 0; i--) *p++ = h->qual[i];
         } else *p++ = '*';
         p = put_str(p, "\tAS:i:", 6); p = put_int(p, h->score_full);
-        p = put_str(p, "\tZ0:i:", 6); p = put_int(p, double_to_neglog(h->z0));
-        p = put_str(p, "\tZ1:i:", 6); p = put_int(p, double_to_neglog(h->z1));
+        if (!P.local_alignment) {                                                    // ref: output.c:691-696
+          p = put_str(p, "\tZ0:i:", 6); p = put_int(p, double_to_neglog(h->z0));
+          p = put_str(p, "\tZ1:i:", 6); p = put_int(p, double_to_neglog(h->z1));
+        }
         p = put_str(p, "\tNM:i:", 6); p = put_int(p, h->cs_mismatch + r.n_del + r.n_ins);
         if (qual_ptr) { p = put_str(p, "\tCQ:Z:", 6); p = put_str(p, qual_ptr[rd], (size_t)read_len); }   // ref: output.c:724-727
         p = put_str(p, "\tCS:Z:", 6); p = put_csfasta(p);

@@ -267,7 +267,13 @@ __device__ void load_window_cs(const GmIndexDev& ix, int cn, uint32_t goff, int 
       const uint64_t pl = cbase + q - 1;
       let = (ix.genome[pl >> 3] >> ((pl & 7) * 4)) & 0xf; let = (uint32_t)(cm >> (let * 4)) & 0xf;
       if (q == clen) col = (uint32_t)cs_lstocs(3, (int)let);
-      else { const uint64_t p = cbase + q; col = (ix.genome_cs[p >> 3] >> ((p & 7) * 4)) & 0xf; }
+      else {
+        // the colour between the complements of forward letters q and q - 1.  For A / C / G / T that is the forward colour q; a 'U' in the contig complements to 'A'
+        // (util.h:125-151), a regular letter, so its colours on the reverse-complement contig are real ones where the forward translation has 15 (fasta.c:586-606)
+        const uint64_t pn = cbase + q;
+        const uint32_t nxt = (uint32_t)(cm >> (((ix.genome[pn >> 3] >> ((pn & 7) * 4)) & 0xf) * 4)) & 0xf;
+        col = (uint32_t)cs_lstocs((int)nxt, (int)let);
+      }
     }
     db[c] = (uint8_t)col; db0[c] = (uint8_t)cs_lstocs((int)let, initbp);
   }
@@ -278,6 +284,48 @@ __device__ __forceinline__ int thr_of(double frac, int absval, int base) { retur
 // ---------------------------------------------------------------------------------------------
 // K3: pass 1.  One wave per read-strand walks its windows in (contig, g_off) order.
 // ---------------------------------------------------------------------------------------------
+// sw_gapless in colour space (ref: common/sw-gapless.c:57-117 with genome_ls != NULL; f1_run's ungapped branch for gmapper-cs -U, mapping.c:1297-1319): the best
+// ungapped segment on the diagonal through (g_idx, r_idx) of the contig's colour translation -- of the reverse-complement contig when the hit was turned onto
+// the read's input strand (rc) -- with the read's first colour forced against lstocs(letter, primer) when the diagonal starts at read position 0.  Colours and
+// letters of the reverse-complement contig come from the forward arrays (see load_window_cs).  sc.mismatch is match + crossover here (gmapper.c:2935).
+__device__ int sw_gapless_cs_wave(const GmIndexDev& ix, int cn, bool rc, const uint8_t* qr, int rlen, long long g_idx, int r_idx, int initbp, const GmScoreDev& sc, int lane) {
+  const uint64_t cbase = ix.contig_off[cn]; const long long clen = (long long)ix.contig_off[cn + 1] - (long long)cbase;
+  const uint64_t cm = 0xFBCDE56879A00123ull;   // complement_base as nibbles (ref: util.h:125-151)
+  auto nib = [&](const uint32_t* a, uint64_t p) -> int { return (int)((a[p >> 3] >> ((p & 7) * 4)) & 0xf); };
+  auto letter_at = [&](long long g) -> int { return rc ? (int)((cm >> (nib(ix.genome, cbase + (uint64_t)(clen - 1 - g)) * 4)) & 0xf) : nib(ix.genome, cbase + (uint64_t)g); };
+  auto colour_at = [&](long long g) -> int {
+    if (!rc) return nib(ix.genome_cs, cbase + (uint64_t)g);
+    if (g == 0) return cs_lstocs(3, letter_at(0));
+    return cs_lstocs(letter_at(g - 1), letter_at(g));          // from the complemented letters themselves (a 'U' complements to 'A': see load_window_cs)
+  };
+  long long g_left; int r_left;
+  if (g_idx < r_idx) { g_left = 0; r_left = (int)(r_idx - g_idx); } else { g_left = g_idx - r_idx; r_left = 0; }
+  int head = 0;
+  if (r_left == 0) {                                   // forcefully match the first colour of the read (:84-94)
+    if (g_left < clen) head = (cs_lstocs(letter_at(g_left), initbp) == (int)qr[0]) ? sc.match : 0;
+    g_left++; r_left = 1;
+  }
+  const long long room = clen - g_left;
+  const int m = (int)(room < (long long)(rlen - r_left) ? room : (long long)(rlen - r_left));
+  int carry_sum = head, carry_min = 0, best = head;
+  for (int k0 = 0; k0 < m; k0 += GM_WAVE) {
+    const int k = k0 + lane; int sv = 0;
+    if (k < m) sv = (colour_at(g_left + k) == (int)qr[r_left + k]) ? sc.match : sc.mismatch;
+    int ps = sv;
+    for (int d = 1; d < GM_WAVE; d <<= 1) { const int o = __shfl_up(ps, d); if (lane >= d) ps += o; }
+    ps += carry_sum;
+    int pm = ps;
+    for (int d = 1; d < GM_WAVE; d <<= 1) { const int o = __shfl_up(pm, d); if (lane >= d) pm = min(pm, o); }
+    int excl = __shfl_up(pm, 1); if (lane == 0) excl = INT_MAX;
+    excl = min(excl, carry_min);
+    if (k < m) best = max(best, ps - excl);
+    carry_sum = __shfl(ps, GM_WAVE - 1);
+    carry_min = min(carry_min, __shfl(pm, GM_WAVE - 1));
+  }
+  for (int d = 32; d > 0; d >>= 1) best = max(best, __shfl_xor(best, d));
+  return best;
+}
+
 template <bool CS>
 __global__ void __launch_bounds__(GM_WAVE)
 k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words,
@@ -359,6 +407,17 @@ k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
       if (!CS && sc.gapless) {                                                           // -U: f1_run's ungapped branch, ref: f1-wrapper.h:122-125, mapping.c:1321-1328
         score = sw_gapless_wave(ix.genome, (uint64_t)ix.contig_off[cn], (long long)ix.contig_off[cn + 1] - ix.contig_off[cn], qr, read_len,
                                 (long long)goff + h->ax, h->ay, sc, lane);
+        calls++; cells += (unsigned long long)read_len;
+      } else if (CS && sc.gapless) {                                                     // the same in colour space: the hit is first turned onto the read's input strand (mapping.c:1302-1303)
+        const bool rcw = st != ix.cs_flip;
+        const long long clen = (long long)ix.contig_off[cn + 1] - ix.contig_off[cn];
+        long long go = goff; long long ax = h->ax, ay = h->ay;
+        if (rcw) {                                                                       // reverse_hit + anchor_reverse, ref: mapping.c:254-263, anchors.h:30-34
+          go = clen - go - w_len;
+          ax = -ax + (w_len - 1) - (h->alen - 1) - (h->awidth - 1);
+          ay = -ay + (read_len - 1) - (h->alen - 1) + (h->awidth - 1);
+        }
+        score = sw_gapless_cs_wave(ix, cn, rcw, qr, read_len, go + ax, (int)ay, ib, sc, lane);
         calls++; cells += (unsigned long long)read_len;
       } else {
         const int score_max_w = (read_len < w_len ? read_len : w_len) * sc.match;
@@ -1577,10 +1636,14 @@ k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__
 // between the rows of a group, one kind of window (forward / reverse tie rules) per pass.  Same state updates, back words and traceback as
 // full_sw_cs_wave_t / k_pass2_cs (ref: sw-full-cs.c:249-623, :633-937).  The carry values lane 0 of a group needs at the next step are read one step ahead.
 // ---------------------------------------------------------------------------------------------
-template <bool REV, bool TABOO>
+// LOCAL (Gflag off, ref: sw-full-cs.c:199-203,315,439-552): a cell outside the band holds (0, -b_open, -a_open) -- plus the crossover score in layers 1-3 -- like the
+// virtual row above the matrix; a state at or below 0 (layer 0) / the crossover score (layers 1-3) takes that value with a null back pointer; the result is the
+// first cell in row-major order with the largest score.  (Local mode takes the global crossover score everywhere: not combined with per-position scores.)
+template <bool REV, bool TABOO, bool LOCAL>
 __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4, int qstride, int rlen, const GmCsDev& P, bool act,
                                 int rx, int ry, int rl, int rw, uint32_t* back, int* carry, int lane, const int8_t* xrow) {
   constexpr bool revcmpl = REV;
+  auto OB = [&](const int x) -> int { const int k = x / 3, st = x % 3; return LOCAL ? (st == 0 ? 0 : (st == 1 ? -P.b_go : -P.a_go)) + (k ? P.xover : 0) : FS_NEG; };   // a cell outside the band
   CsBest best; best.score = 0; best.i = best.j = best.k = 0; best.e_nw = best.e_n = best.e_w = 0;
   const int l = lane & 15;
   const int xg = P.xover;
@@ -1605,10 +1668,10 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
     nmax = __builtin_amdgcn_readfirstlane(nmax);
     int pw[12], d[12], cur[12], inv[12];
 #pragma unroll
-    for (int x = 0; x < 12; x++) { pw[x] = FS_NEG; d[x] = FS_NEG; cur[x] = FS_NEG; }
+    for (int x = 0; x < 12; x++) { pw[x] = OB(x); d[x] = OB(x); cur[x] = OB(x); }
     // lane 0's upper neighbour: the virtual row (stripe 0: constants), or the previous stripe's last row (read one step ahead below)
 #pragma unroll
-    for (int x = 0; x < 12; x++) { const int k = x / 3, st = x % 3; const int xv = k ? xg : 0; inv[x] = s == 0 ? (st == 0 ? 0 : (st == 1 ? -P.b_go : -P.a_go)) + xv : FS_NEG; }
+    for (int x = 0; x < 12; x++) { const int k = x / 3, st = x % 3; const int xv = k ? xg : 0; inv[x] = s == 0 ? (st == 0 ? 0 : (st == 1 ? -P.b_go : -P.a_go)) + xv : OB(x); }
     if (l == 0) {
       if (s == 0) {                                  // virtual row -1: init_cell(.., 1, xover), ref :201-215
 #pragma unroll
@@ -1635,7 +1698,7 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
       for (int x = 0; x < 12; x++) u[x] = g4_shr1(cur[x], inv[x]);   // cell (r-1, c)
       if (s > 0) {                                   // next step's carry values for the group's first lane
 #pragma unroll
-        for (int x = 0; x < 12; x++) inv[x] = FS_NEG;
+        for (int x = 0; x < 12; x++) inv[x] = OB(x);
         if (l == 0 && i + 1 < nst && t + 1 >= cw_lo && t + 1 <= cw_hi) {
 #pragma unroll
           for (int x = 0; x < 12; x++) inv[x] = carry[x * glen + t + 1];
@@ -1644,7 +1707,7 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
       const bool inband = on && row_ok && c >= x_min && c <= x_max;
       int nv[12];
 #pragma unroll
-      for (int x = 0; x < 12; x++) nv[x] = FS_NEG;
+      for (int x = 0; x < 12; x++) nv[x] = OB(x);
       if (inband) {
         const int dbc = db[c];
         uint32_t bw_nw = 0, bw_n = 0, bw_w = 0;
@@ -1675,6 +1738,8 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
               if (d[l2 * 3] + ms + xo > tmp) { tmp = d[l2 * 3] + ms + xo; b = (6 << 2) | l2; }
             }
           }
+          const int resetval = k ? xo : 0;               // :350-353
+          if (LOCAL && tmp <= resetval) { tmp = resetval; b = 0; }
           nv[k * 3] = tmp; bw_nw |= (uint32_t)b << (8 * k);
           // north, ref :447-503
           if (!revcmpl) {
@@ -1695,6 +1760,7 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
               if (notaboo && u[l2 * 3] - P.b_go - P.b_ge + xo > tmp) { tmp = u[l2 * 3] - P.b_go - P.b_ge + xo; b = (2 << 2) | l2; }
             }
           }
+          if (LOCAL && tmp <= resetval) { tmp = resetval; b = 0; }
           nv[k * 3 + 1] = tmp; bw_n |= (uint32_t)b << (8 * k);
           // west, ref :512-541 (no crossover on a genomic gap)
           if (!revcmpl) {
@@ -1704,8 +1770,9 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
             tmp = pw[k * 3 + 2] - P.a_ge; b = (4 << 2) | k;
             if (notaboo && pw[k * 3] - P.a_go - P.a_ge > tmp) { tmp = pw[k * 3] - P.a_go - P.a_ge; b = (3 << 2) | k; }
           }
+          if (LOCAL && tmp <= resetval) { tmp = resetval; b = 0; }
           nv[k * 3 + 2] = tmp; bw_w |= (uint32_t)b << (8 * k);
-          if (last_row_lane) {                         // ref :547-575
+          if (LOCAL || last_row_lane) {                // ref :547-575 (local: every row)
             const int a0 = revcmpl ? nv[k * 3 + 2] : nv[k * 3], a1 = nv[k * 3 + 1], a2 = revcmpl ? nv[k * 3] : nv[k * 3 + 2];
             const int m = max(a0, max(a1, a2));
             if (m > best.score) { best.score = m; best.i = r; best.j = c; best.k = k; best.e_nw = nv[k * 3]; best.e_n = nv[k * 3 + 1]; best.e_w = nv[k * 3 + 2]; }
@@ -1725,7 +1792,14 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
     if (more && t_hi >= 0) { cw_lo = max(0, t_lo - 15); cw_hi = min(glen - 1, t_hi - 15); }
     if (more) __syncthreads();
   }
-  const int src = (lane & 48) | ((rlen - 1) & 15);
+  int src = (lane & 48) | ((rlen - 1) & 15);
+  if (LOCAL) {                                         // the lane whose row comes first among those with the largest score
+    int bs = best.score;
+    for (int dd = 8; dd > 0; dd >>= 1) bs = max(bs, __shfl_xor(bs, dd));
+    int row = (best.score == bs) ? best.i : INT_MAX;
+    for (int dd = 8; dd > 0; dd >>= 1) row = min(row, __shfl_xor(row, dd));
+    src = (lane & 48) | ((bs > 0) ? (row & 15) : 0);
+  }
   best.score = __shfl(best.score, src); best.i = __shfl(best.i, src); best.j = __shfl(best.j, src); best.k = __shfl(best.k, src);
   best.e_nw = __shfl(best.e_nw, src); best.e_n = __shfl(best.e_n, src); best.e_w = __shfl(best.e_w, src);
   return best;
@@ -1736,7 +1810,7 @@ struct P2CsG4 {
   const uint32_t* work; GmFullRes* res; uint8_t* ops; int ops_stride, max_w; const int8_t* xover;
   uint8_t* rc_all; uint8_t* qr4_all; uint8_t* db_all; int* carry_all; int qstride, mw16;
 };
-template <bool REV, bool TABOO>
+template <bool REV, bool TABOO, bool LOCAL>
 __device__ __forceinline__ void p2cs_g4_pass(const GmIndexDev& ix, const GmScoreDev& sc, const GmCsDev& P, const P2CsG4& A, const uint32_t wi, const bool has, uint32_t* back,
                                              const int lane, unsigned long long& fcalls, unsigned long long& fcells) {
   const int g = lane >> 4, l = lane & 15;
@@ -1802,7 +1876,7 @@ __device__ __forceinline__ void p2cs_g4_pass(const GmIndexDev& ix, const GmScore
     rx -= P.anchor_width / 2; ry += P.anchor_width / 2; rw += P.anchor_width; }
   const int g_off_i = (int)g_off;
   __syncthreads();
-  const CsBest fo = full_sw_cs_g4<REV, TABOO>(db, w_len, qr4, qstride, read_len, P, has, rx, ry, rl, rw, back, carry, lane, A.xover ? A.xover + (size_t)rd * read_len : nullptr);
+  const CsBest fo = full_sw_cs_g4<REV, TABOO, LOCAL>(db, w_len, qr4, qstride, read_len, P, has, rx, ry, rl, rw, back, carry, lane, A.xover ? A.xover + (size_t)rd * read_len : nullptr);
   __syncthreads();
   __threadfence();
   if (has && l == 0 && fo.score >= 0 && fo.score >= thresh) {     // ref: sw-full-cs.c:1216; do_backtrace :633-937
@@ -1846,7 +1920,7 @@ __device__ __forceinline__ void p2cs_g4_pass(const GmIndexDev& ix, const GmScore
   }
 }
 
-template <bool TABOO>
+template <bool TABOO, bool LOCAL>
 __global__ void __launch_bounds__(GM_WAVE, 2)
 k_pass2_cs_g4(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__ reads, const uint8_t* __restrict__ initbp, int n_reads, int read_len,
               int read_words, const GmHit* __restrict__ hits, int hcap, const int32_t* __restrict__ sel,
@@ -1884,8 +1958,8 @@ k_pass2_cs_g4(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restric
         if (m) { p3 = (uint32_t)__builtin_ctz(m); m &= m - 1u; np++; }
         const bool has = g < np;
         const uint32_t wi = chunk + (g == 0 ? p0 : (g == 1 ? p1 : (g == 2 ? p2 : p3)));
-        if (cls) p2cs_g4_pass<true, TABOO>(ix, sc, P, A, wi, has, back, lane, fcalls, fcells);
-        else p2cs_g4_pass<false, TABOO>(ix, sc, P, A, wi, has, back, lane, fcalls, fcells);
+        if (cls) p2cs_g4_pass<true, TABOO, LOCAL>(ix, sc, P, A, wi, has, back, lane, fcalls, fcells);
+        else p2cs_g4_pass<false, TABOO, LOCAL>(ix, sc, P, A, wi, has, back, lane, fcalls, fcells);
       }
     }
   }
@@ -1906,23 +1980,28 @@ int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs
   if (lds > 48 * 1024 && lds > configured) {
     GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
-  // four windows per wave (k_pass2_cs_g4) unless GM_P2_G4=0 asks for the one-window kernel; a wave owns four consecutive back-pointer scratches
-  if (!(gm_tune("GM_P2_G4") && atoi(gm_tune("GM_P2_G4")) == 0) && grid >= 4) {
+  // four windows per wave (k_pass2_cs_g4) unless GM_P2_G4=0 asks for the one-window kernel; a wave owns four consecutive back-pointer scratches.
+  // Local alignment (sc.local, ref: sw-full-cs.c:199-203,439-552) exists in the four-window kernel only.
+  const bool want_g4 = !(gm_tune("GM_P2_G4") && atoi(gm_tune("GM_P2_G4")) == 0) && grid >= 4;
+  if (sc.local && d_xover) { gm_set_error("colour space: local alignment is not combined with per-position crossover scores (reads with quality values)"); return GM_E_ARG; }
+  if (want_g4 || sc.local) {
     const size_t q16 = (size_t)((read_len + 15) & ~15), lds4 = 20 * q16 + 4 * (size_t)((window_len + 15) & ~15) + 4 * (size_t)window_len * 48 + 64;
-    if (lds4 <= 160 * 1024) {
+    if (lds4 <= 160 * 1024 && grid >= 4) {
       static GmLdsLimit lim4; size_t& conf4 = lim4.cur();
       if (lds4 > 48 * 1024 && lds4 > conf4) {
-        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
-        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4)); conf4 = lds4; }
-      if (P.taboo > 0)
-        hipLaunchKernelGGL(k_pass2_cs_g4<true>, dim3(grid / 4), dim3(GM_WAVE), lds4, stream, ix, sc, P, d_reads, d_initbp, n_reads, read_len, read_words, d_hits, hcap, d_sel,
-                           d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_words, window_len, d_stats, d_xover, d_sel_sidx);
-      else
-        hipLaunchKernelGGL(k_pass2_cs_g4<false>, dim3(grid / 4), dim3(GM_WAVE), lds4, stream, ix, sc, P, d_reads, d_initbp, n_reads, read_len, read_words, d_hits, hcap, d_sel,
-                           d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_words, window_len, d_stats, d_xover, d_sel_sidx);
+        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4)); conf4 = lds4; }
+#define GM_P2CS_G4(TB, LOC) hipLaunchKernelGGL((k_pass2_cs_g4<TB, LOC>), dim3(grid / 4), dim3(GM_WAVE), lds4, stream, ix, sc, P, d_reads, d_initbp, n_reads, read_len, read_words, d_hits, hcap, d_sel, \
+                           d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_words, window_len, d_stats, d_xover, d_sel_sidx)
+      if (P.taboo > 0) { if (sc.local) GM_P2CS_G4(true, true); else GM_P2CS_G4(true, false); }
+      else { if (sc.local) GM_P2CS_G4(false, true); else GM_P2CS_G4(false, false); }
+#undef GM_P2CS_G4
       GM_HIP(hipGetLastError());
       return GM_OK;
     }
+    if (sc.local) { gm_set_error("colour space: local alignment needs the four-window pass-2 kernel (window of %d does not fit its LDS)", window_len); return GM_E_ARG; }
   }
   if (P.taboo > 0)
   hipLaunchKernelGGL(k_pass2_cs<true>, dim3(grid), dim3(GM_WAVE), lds, stream, ix, sc, P, d_reads, d_initbp, n_reads, read_len, read_words, d_hits, hcap, d_sel,

@@ -223,6 +223,17 @@ OPTION_CASES = {
 }
 
 
+# colour-space option sets (tools/make_golden.py CS_OPTION_CASES: gmapper-cs with these options on a committed colour-space golden's inputs):
+# tag -> (base golden, oracle option string, product gm_params_t fields, sam_unaligned)
+CS_OPTION_CASES = {
+    "cs_local": ("cfg4s_50col_2Mbp", "colour=1;local=1", dict(local_alignment=1), False),
+    "cs_local_unal": ("stress_cs_60col_unal", "colour=1;local=1", dict(local_alignment=1, sam_unaligned=1), True),
+    "cs_ungapped": ("cfg4s_50col_2Mbp", "colour=1;local=1;ungapped=1", dict(local_alignment=1, ungapped=1, anchor_width=0, a_gap_open_score=-255, b_gap_open_score=-255, hash_filter_calls=0), False),
+    "cs_ungapped_unal": ("stress_cs_60col_unal", "colour=1;local=1;ungapped=1;full-threshold=40",
+                         dict(local_alignment=1, ungapped=1, anchor_width=0, a_gap_open_score=-255, b_gap_open_score=-255, hash_filter_calls=0, sw_full_threshold=40.0, sam_unaligned=1), True),
+}
+
+
 def load_option_sam(base, tag):
     with gzip.open(os.path.join(ROOT, "tests", "golden", "%s@%s.sam.gz" % (base, tag)), "rb") as f:
         return f.read()

@@ -1172,3 +1172,19 @@ def test_release_build_reproduces_the_reference_goldens():
     import re
     m = re.search(r"(\d+) passed", p.stdout)
     assert m and int(m.group(1)) >= 17, p.stdout[-500:]
+
+
+@pytest.mark.parametrize("tag", sorted(oa.CS_OPTION_CASES))
+def test_colour_space_local_and_ungapped_match_reference_golden(gm, tag):
+    """gmapper-cs --local and -U on the GPU: the colour-space cell of k_pass2_cs_g4 in local mode (floors at 0 / the crossover score with null back pointers, best cell of
+    the whole band; no post_sw, MAPQ 255, no Z tags) and sw_gapless on the contig's colour translation in pass 1 (forced first colour; reverse-strand hits on the
+    reverse-complement contig's colours) -- byte-identical to the reference's output"""
+    base, _, fields, _ = oa.CS_OPTION_CASES[tag]
+    contigs, reads, _ = oa.load_golden(base)
+    want = oa.load_option_sam(base, tag)
+    p = gm.default_params_cs()
+    for k, v in fields.items(): setattr(p, k, v)
+    ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p, max_batch_reads=1024)
+    got = oa.sam_header(contigs) + s.map_reads_cs(reads)
+    s.close(); ix.close()
+    assert got == want, _first_diff(got, want)

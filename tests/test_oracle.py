@@ -261,3 +261,15 @@ def test_oracle_colour_space_pairs_match_reference(oracle_lib, mode):
     got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_sam(g["m1"], g["m2"], g["names1"], g["names2"], nthreads=4)
     s.close()
     assert got == want
+
+
+@pytest.mark.parametrize("tag", sorted(oa.CS_OPTION_CASES))
+def test_colour_space_local_and_ungapped_match_reference(tag):
+    """gmapper-cs --local (sw_full_cs with local_alignment, ref: sw-full-cs.c:199-203,315,439-552; no post_sw, no mapping qualities) and -U (sw_gapless on colours
+    with the forced first colour, ref: sw-gapless.c:84-94): the restatement against the reference's own output"""
+    base, opts, _, unal = oa.CS_OPTION_CASES[tag]
+    contigs, reads, _ = oa.load_golden(base)
+    want = oa.load_option_sam(base, tag)
+    o = oa.Session(contigs, opts=opts); o.set(sam_unaligned=unal, hash_filter_calls=("ungapped" not in opts))
+    got = oa.sam_header(contigs) + o.map_sam(reads, nthreads=4); o.close()
+    assert got == want

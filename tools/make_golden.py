@@ -161,6 +161,30 @@ OPTION_CASES = {
 }
 
 
+# colour-space option sets (gmapper-cs): inputs of a committed colour-space golden, the reference's SAM body as <base>@<tag>.sam.gz
+CS_OPTION_CASES = {
+    "cs_local":        ("cfg4s_50col_2Mbp", ["--local"]),
+    "cs_local_unal":   ("stress_cs_60col_unal", ["--local", "--sam-unaligned"]),
+    "cs_ungapped":     ("cfg4s_50col_2Mbp", ["--local", "-U"]),
+    "cs_ungapped_unal": ("stress_cs_60col_unal", ["--local", "-U", "--sam-unaligned", "-h", "40%"]),
+}
+
+
+def cs_option_cases():
+    for tag, (base, extra) in CS_OPTION_CASES.items():
+        z = np.load(os.path.join(OUT, base + ".npz"))
+        contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
+        with tempfile.TemporaryDirectory() as d:
+            g = os.path.join(d, "g.fa"); r = os.path.join(d, "r.csfasta")
+            write_fa_codes(g, [b"contig%d" % (i + 1) for i in range(len(contigs))], contigs)
+            synth.write_csfasta_reads(r, z["reads"])
+            p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "gmapper-cs"), "-N", "4", *extra, r, g], capture_output=True, check=True)
+            body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+        with gzip.open(os.path.join(OUT, "%s@%s.sam.gz" % (base, tag)), "wb", compresslevel=9) as f:
+            f.write(body)
+        print("%s@%s: %d SAM records" % (base, tag, sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@"))))
+
+
 def option_cases():
     """non-default options on inputs that are already committed: only the reference's SAM body is stored (<base>@<tag>.sam.gz)"""
     for tag, (base, extra) in OPTION_CASES.items():
@@ -406,6 +430,8 @@ def main():
         local_kat_cases(); return
     if "--post-kat-only" in sys.argv:
         post_kat_cases(); return
+    if "--cs-options-only" in sys.argv:
+        cs_option_cases(); return
     if "--index-only" in sys.argv:
         index_cases(); return
     if "--options-only" in sys.argv:
@@ -425,6 +451,7 @@ def main():
     print("sw_kat:", kat.count(b"\nV ") + 1, "vector,", kat.count(b"\nF "), "full")
     paired_cases()
     option_cases()
+    cs_option_cases()
     index_cases()
     cs_kat_cases()
     post_kat_cases()
