@@ -310,7 +310,8 @@ def main():
         out["stages_ms_per_step"] = {k: agg[k] / args.steps for k in agg if k.startswith("ms_")}
         out["per_unit"] = {"lookups": agg["lookups"] / U, "list_entries": agg["list_entries"] / U, "alg_bytes": agg["list_bytes"] / U, "survivors": agg["survivors"] / U,
                            "survivors_pruned": agg["survivors_pruned"] / U, "vec_sw_calls": agg["vec_calls"] / U, "full_sw_calls": agg["full_calls"] / U,
-                           "mapped_frac": agg["reads_matched"] / U, "exact_order_frac": agg["exact_order_reads"] / (2 * U)}
+                           "mapped_frac": agg["reads_matched"] / U, "exact_order_frac": agg["exact_order_reads"] / (2 * U),
+                           "post_sw_host_redo": agg.get("post_sw_host_redo", 0) / U, "mp_unfiltered": agg.get("mp_unfiltered", 0) / U}
         out["setup_s"] = {"genome_gen": t_gen, "index_build": t_index, "index_bcast": t_bcast, "index_bytes": ix.nbytes}
         o_ls = None
         if not args.no_cpu_baseline and world == 1:
