@@ -127,6 +127,10 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
   const uint32_t* __restrict__ pos0 = ix.seed[0].pos;
   const uint32_t* __restrict__ spos0 = ix.seed[0].spos;
   unsigned long long my_lookups = 0, my_entries = 0;
+  // the prune rules' arguments as opaque scalars, fixed here in uniform control flow (see stage 2a)
+  uint32_t k_prune = __builtin_amdgcn_readfirstlane(a.prune != 0 ? 1u : 0u), k_D = __builtin_amdgcn_readfirstlane(a.D);
+  uint32_t k_emax_on = __builtin_amdgcn_readfirstlane(a.e_max >= 0 ? 1u : 0u), k_emax = __builtin_amdgcn_readfirstlane((uint32_t)max(a.e_max, 0));
+  asm volatile("" : "+s"(k_prune), "+s"(k_D), "+s"(k_emax_on), "+s"(k_emax));
 
   { uint4* t4 = (uint4*)smem; for (int w = tid; w < tab_q; w += nthr) t4[w] = make_uint4(0, 0, 0, 0); }
   if (tid < C_WORDS) ctrl[tid] = 0;                            // thread 0 re-zeroes them at the end of every read-strand
@@ -507,6 +511,44 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
           }
         }
       };
+      // (2a) every candidate: its region's tag; members away from the region's ends are decided here, the rest goes to the list.  Straight-line code: the three
+      // table words of a candidate are read together, the cases are predicates, the list is appended to once per wave (the branchy form of this loop spent more
+      // scalar instructions on its control flow than vector instructions on the work, and reloaded kernel arguments inside it).
+#ifndef K5_2A_BRANCHY
+      {
+        // (the kernel arguments of the rules as opaque scalars: left to itself the compiler re-loads them from the argument segment inside the loop, a memory
+        // round trip per iteration; predicates combined with & and |, not && and ||: no branch per clause)
+        const uint32_t do_prune = k_prune, Dv = k_D, emax_on = k_emax_on, emax = k_emax;
+        const uint32_t rsz = 1u << rb;
+        for (uint32_t i0 = 0; i0 < nc; i0 += nthr) {
+          const uint32_t i = i0 + tid;
+          const uint32_t valid = i < nc ? 1u : 0u;
+          const uint32_t w = candp[valid ? i : 0u], h = w >> 16, off = w & 0xFFFFu;
+          const uint32_t town = htag[h], mn = hmin[h], mx = hmax[h];
+          const uint32_t r = (town >> 8) - 1u, p = (r << rb) | off;
+          const uint32_t is_m = (town >> 1) & 1u /* K5_FB */, r_pos = r > 0u ? 1u : 0u;
+          const uint32_t nb_m = do_prune & (((off < edge ? 1u : 0u) & r_pos) | (off + edge >= rsz ? 1u : 0u)), nb_o = (off < ovl ? 1u : 0u) & r_pos;
+          const uint32_t nbv = valid & (is_m ? nb_m : nb_o);
+          const bool nb = nbv != 0u;
+          const unsigned long long bn = __ballot(nb);
+          if (bn) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&ctrl[C_NEDGE], (uint32_t)__popcll(bn));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (nb) {
+              const uint32_t j = base + (uint32_t)__popcll(bn & ((1ull << lane) - 1ull));
+              if (j < ecap) elist[j] = i; else ctrl[C_OVERFLOW] = 1u;
+            }
+          }
+          const uint32_t fe = (town >> 4) & 1u /* K5_FE */, fd = (town >> 3) & 1u /* K5_FD */;
+          const uint32_t span = (mx - 1u) - (0x10000u - mn);
+          const uint32_t iso = fe | (fd & (span <= Dv ? 1u : 0u));                          // (1) isolation: three or more inside, or two at most D apart
+          const uint32_t tight = emax_on & (span <= emax ? 1u : 0u);                        // (2) tight cluster
+          const uint32_t membv = valid & is_m & (nbv ^ 1u), keepv = membv & ((iso & (tight ^ 1u)) | (do_prune ^ 1u));
+          emit(membv != 0u, keepv != 0u, p, i);
+        }
+      }
+#else
       // (2a) every candidate: its region's tag; members away from the region's ends are decided here, the rest goes to the list
       for (uint32_t i0 = 0; i0 < nc; i0 += nthr) {
         const uint32_t i = i0 + tid;
@@ -531,6 +573,7 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
         }
         emit(memb, keep, p, i);
       }
+#endif
       __syncthreads();
       K5_STAMP(11);
       // (2b) the listed candidates, with the regions before / behind theirs
