@@ -45,7 +45,7 @@ typedef __attribute__((address_space(3))) uint16_t k5_lds_u16;
 #define K5_Q 6            // list chunks in flight per wave (8 and 10 measured: no gain)
 #endif
 #define K5_XREC 64                                      // chunk records beyond one per list (a list of more than 256 positions takes one record per 256)
-enum { C_NCAND = 0, C_OVERFLOW, C_NMEMB, C_NKEEP, C_NSTRIP, C_NEDGE, C_NLISTS /* two words: read-strands alternate */, C_SINK = 8, C_NRAW = 9, C_WORDS = 12 };
+enum { C_NCAND = 0, C_OVERFLOW, C_NMEMB, C_NKEEP, C_NSTRIP, C_NEDGE, C_NLISTS /* two words: read-strands alternate */, C_SINK = 8, C_NRAW = 9, C_NDEFER = 10, C_WORDS = 12 };
 
 // Diagnostic build (-DK5_STAMPS): thread 0 of every workgroup adds the cycles between the phase boundaries of each read-strand to k5_stamps[]
 // (0-5: setup, pass A, pass B, region table, rules + output, clears; 6, 7: candidates, fallbacks; 8-11: parts of set-up / the exact stages, taken out of
@@ -467,24 +467,53 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
     // densely afterwards: the overlap-strip marks here (2 % of the candidates, but some lane of most waves), the neighbour-region look-ups of
     // stage 2 below.  Their lists (region numbers, then candidate indexes) live in rec[] / srec[], dead since pass B.
     uint32_t* const elist = rec; const uint32_t ecap = 8u * (uint32_t)RC;
+    // Stage 1 in two steps.  (a) every candidate tries the FIRST slot of its region's probe sequence, in straight-line code: one compare-and-swap, and when the slot holds the
+    // region already, the flag update -- the same three LDS round trips for every lane.  Two thirds of the candidates are done with that (the table is a third full).
+    // (b) the others -- another region sits in their first slot -- are listed and probed on from the second slot, densely, together with the strip marks: a probing loop
+    // costs a wave the longest sequence among its lanes (five at this load), and it now pays that once per 64 LISTED candidates, not once per 64 candidates.
+    uint32_t* const dlist = elist + 2u * (uint32_t)RC; const uint32_t scap = 2u * (uint32_t)RC, dcap = ecap - scap;
+    auto settle = [&](const uint32_t i, const uint32_t h, const uint32_t off) {      // candidate i sits in slot h
+      atomicMax(&hmin[h], 0x10000u - off); atomicMax(&hmax[h], off + 1u);
+      candp[i] = (h << 16) | off;                              // slot and offset: stage 2 reads the region back from the tag (no second probe sequence)
+    };
+    auto probe_on = [&](const uint32_t i) {                        // step (b) for candidate i, its strip mark included
+      const uint32_t p = candp[i], r = p >> rb, off = p & rmask;
+      const uint32_t h = k5_insert(htag, hmask, hshift, r, true, true);
+      if (h != 0xFFFFFFFFu) {
+        settle(i, h, off);
+        if (off < ovl && r > 0 && k5_insert(htag, hmask, hshift, r - 1u, false) == 0xFFFFFFFFu) ctrl[C_OVERFLOW] = 1u;
+      } else ctrl[C_OVERFLOW] = 1u;
+    };
     if (!fallback) {
-      for (uint32_t i = tid; i < nc; i += nthr) {
-        const uint32_t p = candp[i], r = p >> rb, off = p & rmask;
-        const uint32_t h = k5_insert(htag, hmask, hshift, r, true);
-        if (h != 0xFFFFFFFFu) {
-          atomicMax(&hmin[h], 0x10000u - off); atomicMax(&hmax[h], off + 1u);
-          candp[i] = (h << 16) | off;                          // slot and offset: stage 2 reads the region back from the tag (no second probe sequence)
-          if (off < ovl && r > 0) {                            // the overlap strip also counts for the region before (ref: mapping.c:521-533)
-            const uint32_t j = atomicAdd(&ctrl[C_NSTRIP], 1u);
-            if (j < ecap) elist[j] = r - 1u; else ctrl[C_OVERFLOW] = 1u;
-          }
-        } else ctrl[C_OVERFLOW] = 1u;
+      for (uint32_t i0 = 0; i0 < nc; i0 += nthr) {
+        const uint32_t i = i0 + tid;
+        const bool live = i < nc;
+        const uint32_t p = candp[live ? i : 0u], r = p >> rb, off = p & rmask, r1 = r + 1u;
+        const uint32_t h0 = k5_hash(r1, hshift);
+        uint32_t prev = 0xFFFFFFFFu;
+        if (live) prev = atomicCAS(&htag[h0], 0u, (r1 << 8) | K5_FA | K5_FC);
+        const bool hit = live && (prev == 0u || (prev >> 8) == r1);
+        if (hit) {
+          if (prev != 0u) k5_again(htag, h0, prev, true);
+          settle(i, h0, off);
+        }
+        const bool strip = hit && off < ovl && r > 0, later = live && !hit;      // the overlap strip also counts for the region before (ref: mapping.c:521-533)
+        const unsigned long long bs = __ballot(strip), bd = __ballot(later);
+        if (bs | bd) {
+          uint32_t sb = 0, db = 0;
+          if (lane == 0) { if (bs) sb = atomicAdd(&ctrl[C_NSTRIP], (uint32_t)__popcll(bs)); if (bd) db = atomicAdd(&ctrl[C_NDEFER], (uint32_t)__popcll(bd)); }
+          sb = __builtin_amdgcn_readfirstlane(sb); db = __builtin_amdgcn_readfirstlane(db);
+          const unsigned long long below = (1ull << lane) - 1ull;
+          if (strip) { const uint32_t j = sb + (uint32_t)__popcll(bs & below); if (j < scap) elist[j] = r - 1u; else ctrl[C_OVERFLOW] = 1u; }
+          if (later) { const uint32_t j = db + (uint32_t)__popcll(bd & below); if (j < dcap) dlist[j] = i; else probe_on(i); }      // (a full list: probed on the spot)
+        }
       }
     }
     __syncthreads();
     K5_STAMP(10);
     if (!fallback) {
-      const uint32_t ns = min(ctrl[C_NSTRIP], ecap);
+      const uint32_t ns = min(ctrl[C_NSTRIP], scap), nd = min(ctrl[C_NDEFER], dcap);
+      for (uint32_t j = tid; j < nd; j += nthr) probe_on(dlist[j]);
       for (uint32_t j = tid; j < ns; j += nthr)
         if (k5_insert(htag, hmask, hshift, elist[j], false) == 0xFFFFFFFFu) ctrl[C_OVERFLOW] = 1u;
     }
@@ -685,7 +714,7 @@ k_lookup_v5(GmIndexDev ix, K5Args a) {
         }
       }
       for (int c = 0; c < C_NLISTS; c++) ctrl[c] = 0;
-      *cnl = 0; ctrl[C_NRAW] = 0;
+      *cnl = 0; ctrl[C_NRAW] = 0; ctrl[C_NDEFER] = 0;
     }
     { uint4* t4 = (uint4*)smem; for (int w = tid; w < tab_q; w += nthr) t4[w] = make_uint4(0, 0, 0, 0); }
     K5_STAMP(5);
