@@ -71,7 +71,7 @@ template <bool BIG, typename T> __device__ void k2_bitonic(T* key, int npad, int
     }
 }
 
-// The same network on up to 512 keys held in registers (R = 1, 2, 4, 8 per lane, key i = lane * R + j): partners less than R apart sit in the same lane,
+// The same network on up to 1024 keys held in registers (R = 1, 2, 4, 8, 16 per lane, key i = lane * R + j): partners less than R apart sit in the same lane,
 // the others come by a lane exchange -- one round trip per stage instead of an LDS read, a write and a barrier.  Equal keys are identical values
 // (a survivor key is unique, pads are all ~0), so the result is the sorted array whatever the network does with them.
 template <typename T> __device__ __forceinline__ T k2_xor_lane(T v, int dl) { return (T)__shfl_xor(v, dl); }
@@ -113,9 +113,10 @@ template <typename T, int R> __device__ __forceinline__ void k2_bitonic_regs(T* 
 }
 // keys in LDS, written and fenced by the caller; sorted and fenced on return
 template <bool BIG, typename T> __device__ void k2_sort(T* key, int npad, int lane) {
-  if (!BIG && npad <= 512) {                                    // (512: the read-strand that carries the true hit keeps ~300 survivors on a 3 Gbp genome)
+  if (!BIG && npad <= 1024) {                                   // (the read-strand that carries the true hit keeps ~300 survivors at 100 bp on a 3 Gbp genome, ~700 at 150 bp)
     if (npad == 64) k2_bitonic_regs<T, 1>(key, lane); else if (npad == 128) k2_bitonic_regs<T, 2>(key, lane);
-    else if (npad == 256) k2_bitonic_regs<T, 4>(key, lane); else k2_bitonic_regs<T, 8>(key, lane);
+    else if (npad == 256) k2_bitonic_regs<T, 4>(key, lane); else if (npad == 512) k2_bitonic_regs<T, 8>(key, lane);
+    else k2_bitonic_regs<T, 16>(key, lane);
     __syncthreads();
   } else k2_bitonic<BIG, T>(key, npad, lane);
 }
