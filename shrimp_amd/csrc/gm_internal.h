@@ -76,6 +76,7 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
 int gm_index_derive_strips(GmIndexHost* ix, hipStream_t stream);     // strip lists for k_lookup_v5 (gm_lookup5.hip); idempotent
 void gm_lookup5_set_start_flags(uint32_t* flags, int cap, uint32_t epoch);
 int gm_lookup5_start_flag_grid(void);
+int gm_lookup5_last_rounds(void);
 int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words, int max_n_kmers, int NL,
                       uint64_t* d_out, uint32_t* d_out_cnt, int out_cap, uint32_t* d_surv_cnt, int prune, uint32_t D, int e_max,
                       uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap, unsigned long long* d_stats, hipStream_t stream,

@@ -1165,7 +1165,7 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     gm_lookup5_set_start_flags(nullptr, 0, 0);
     if (r < 0) return r;
     if (r == 1) {
-      g_k1_name = "k_lookup_v5";
+      g_k1_name = gm_lookup5_last_rounds() > 1 ? "k_lookup_v5_rounds" : "k_lookup_v5";
       // read-strands whose candidates did not fit the LDS tiers (none on the benchmark genome): the slab-sweep kernel in list mode (blocks beyond the list's end
       // return at once), then K1b for those.  (k_lookup_v4 in list mode was tried for them: no faster, and its 134 KB workgroups wait longer for a CU.)
       hipLaunchKernelGGL(k_lookup<false>, dim3(std::min(fbcap, 1024)), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,

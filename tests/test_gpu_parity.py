@@ -189,6 +189,10 @@ KERNEL_VARIANTS = [
     {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_NO_PRUNE": "1"},   # v5 without the prune rules (all survivors to K2)
     {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_SCAP": "256", "GM_SCAP2": "64"},   # v5 survivors beyond K2's LDS tier: heavy tier
     {"GM_SLAB_BITS": "17", "GM_K1_V5": "1", "GM_K1_THREADS": "128"},               # v5 with two waves per workgroup
+    {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_ROUNDS": "3"},   # v5 with pass B + exact stages per third of the genome (k_lookup_v5_rounds: what 2 x 150 bp reads on 3 Gbp take)
+    {"GM_NO_BUCKETS": "1", "GM_K1_V5": "1", "GM_K5_ROUNDS": "2"},   # ... per half, one-slab index
+    {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_ROUNDS": "4", "GM_NO_PRUNE": "1"},   # ... four parts, without the prune rules
+    {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_ROUNDS": "3", "GM_SCAP": "256", "GM_SCAP2": "64"},   # ... more kept than K2's LDS tier takes: the whole read-strand falls back
     {"GM_P1_EARLY": "0"},                                    # pass 1 without the early stop of windows that cannot reach the threshold
 ]
 
@@ -213,7 +217,7 @@ def test_kernel_variants_match_reference_golden(gm, name, env):
             if v is None: os.environ.pop(k, None)
             else: os.environ[k] = v
     assert got == sam, (_first_diff(got, sam), st)
-    want_kern = "k_lookup_v5" if "GM_K1_V5" in env else ("k_lookup_v4" if "GM_K1_V4" in env else None)
+    want_kern = ("k_lookup_v5_rounds" if "GM_K5_ROUNDS" in env else "k_lookup_v5") if "GM_K1_V5" in env else ("k_lookup_v4" if "GM_K1_V4" in env else None)
     assert want_kern is None or kern == want_kern, kern
 
 

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from shrimp_amd import gmapper as gm, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
-gname, gseed, _, L, rseed = synth.CONFIGS[os.environ.get("GM_BENCH_WORKLOAD", "cfg3")]
+gname, gseed, _, L, rseed = synth.CONFIGS["cfg3"]
+L = int(os.environ.get("GM_STAMPS_READ_LEN", L))            # 150: the reads of the paired workload (cfg5), mapped unpaired here -- K1 is the same
 contigs = synth.make_genome(synth.contig_lengths(gname, 1.0), gseed)
 reads, _ = synth.make_reads(contigs, n, L, rseed)
 ix = gm.Index(contigs); s = gm.Session(ix, max_batch_reads=131072)
