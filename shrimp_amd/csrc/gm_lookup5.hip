@@ -43,7 +43,7 @@ typedef __attribute__((address_space(3))) uint16_t k5_lds_u16;
 #define K5_LDS_OR(off, m) __hip_atomic_fetch_or(K5_LDS(off), (m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
 #ifndef K5_Q
-#define K5_Q 6            // list chunks in flight per wave (8 and 10 measured: no gain)
+#define K5_Q 4            // list chunks in flight per wave (r03 sweep, ms per 262 144 reads: 1: 87.3, 2: 71.0, 3: 68.6, 4: 65.2, 5: see DESIGN, 6: 69.9, 10: 74.3)
 #endif
 enum { C_NCAND = 0, C_OVERFLOW, C_NMEMB, C_NKEEP, C_NSTRIP, C_NEDGE, C_NLISTS /* two words: read-strands alternate */, C_SINK = 8, C_NRAW = 9, C_NDEFER = 10, C_SPILL = 12 /* K5_MAX_ROUNDS - 1 words */, C_WORDS = 16 };
 #define K5_MAX_ROUNDS 4
