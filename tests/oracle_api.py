@@ -234,6 +234,13 @@ CS_OPTION_CASES = {
 }
 
 
+# colour-space pairs with options (tools/make_golden.py CS_PAIR_OPTION_CASES): tag -> (base pair golden, oracle option string, product gm_params_t fields)
+CS_PAIR_OPTION_CASES = {
+    "cs_pairs_local": ("cs_pairs_50col_opp-in", "colour=1;local=1", dict(local_alignment=1)),
+    "cs_pairs_local_colbw": ("cs_pairs_50col_col-bw", "colour=1;local=1", dict(local_alignment=1)),
+}
+
+
 def load_option_sam(base, tag):
     with gzip.open(os.path.join(ROOT, "tests", "golden", "%s@%s.sam.gz" % (base, tag)), "rb") as f:
         return f.read()

@@ -947,6 +947,24 @@ def test_colour_space_pairs_match_reference_golden(gm, mode):
     assert got == want, (_first_diff(got, want), st)
 
 
+@pytest.mark.parametrize("tag", sorted(oa.CS_PAIR_OPTION_CASES))
+def test_colour_space_pairs_local_match_reference_golden(gm, tag):
+    """gmapper-cs -p <mode> -I 100,600 --sam-unaligned --local: the paired pipeline with sw_full_cs in local mode at half the threshold, sw_full_cs's own strings and
+    counts in the output (no post_sw), no mapping qualities -- byte-identical to the reference (opp-in, and col-bw where a mate is reversed)"""
+    base, _, fields = oa.CS_PAIR_OPTION_CASES[tag]
+    g = oa.load_golden_pairs(base)
+    want = oa.load_option_sam(base, tag)
+    p = gm.default_params_cs(); p.sam_unaligned = 1
+    for k, v in fields.items(): setattr(p, k, v)
+    ix = gm.Index(g["contigs"], names=g["contig_names"], params=p)
+    s = gm.Session(ix, params=p, max_batch_reads=4096)
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_cs(g["m1"], g["m2"], g["names1"], g["names2"], mode=g["mode"],
+                                                                           min_insert=g["ins"][0], max_insert=g["ins"][1])
+    st = s.stats
+    s.close(); ix.close()
+    assert got == want, (_first_diff(got, want), st)
+
+
 @pytest.mark.parametrize("paired", [False, True])
 def test_genome_shards_mapped_here_then_merged_match_mergesam(gm, paired):
     """SURVEY 8(f)3 end to end: the contig groups of tests/golden/merge mapped by the library (byte-identical to the reference's per-shard SAM files),

@@ -263,6 +263,19 @@ def test_oracle_colour_space_pairs_match_reference(oracle_lib, mode):
     assert got == want
 
 
+@pytest.mark.parametrize("tag", sorted(oa.CS_PAIR_OPTION_CASES))
+def test_oracle_colour_space_pairs_local_match_reference(oracle_lib, tag):
+    """gmapper-cs -p <mode> -I 100,600 --sam-unaligned --local: sw_full_cs in local mode at half the threshold for the mates, no post_sw, no mapping qualities"""
+    base, opts, _ = oa.CS_PAIR_OPTION_CASES[tag]
+    g = oa.load_golden_pairs(base)
+    want = oa.load_option_sam(base, tag)
+    s = oa.Session(g["contigs"], g["contig_names"], opts=opts); s.set(True, True)
+    s.set_pairing(g["mode"], *g["ins"])
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_sam(g["m1"], g["m2"], g["names1"], g["names2"], nthreads=4)
+    s.close()
+    assert got == want, next((a, b) for a, b in zip(got.split(b"\n"), want.split(b"\n")) if a != b)
+
+
 @pytest.mark.parametrize("tag", sorted(oa.CS_OPTION_CASES))
 def test_colour_space_local_and_ungapped_match_reference(tag):
     """gmapper-cs --local (sw_full_cs with local_alignment, ref: sw-full-cs.c:199-203,315,439-552; no post_sw, no mapping qualities) and -U (sw_gapless on colours

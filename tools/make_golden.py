@@ -185,6 +185,33 @@ def cs_option_cases():
         print("%s@%s: %d SAM records" % (base, tag, sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@"))))
 
 
+CS_PAIR_OPTION_CASES = {        # tag -> (base colour-space pair golden, extra gmapper-cs options)
+    "cs_pairs_local": ("cs_pairs_50col_opp-in", ["--local"]),
+    "cs_pairs_local_colbw": ("cs_pairs_50col_col-bw", ["--local"]),
+}
+
+
+def cs_pair_option_cases():
+    """non-default options on the committed colour-space pairs (mates adjacent in one csfasta file, as cs_pair_case writes them): only the reference's SAM body is stored"""
+    for tag, (base, extra) in CS_PAIR_OPTION_CASES.items():
+        z = np.load(os.path.join(OUT, base + ".npz"))
+        contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
+        m1, m2 = z["mates1"], z["mates2"]; n = len(m1)
+        with tempfile.TemporaryDirectory() as d:
+            g = os.path.join(d, "g.fa"); r = os.path.join(d, "r.csfasta")
+            write_fa_codes(g, [bytes(x) for x in z["contig_names"]], contigs)
+            with open(r, "wb") as f:
+                for i in range(n):
+                    for nm, row in ((bytes(z["names1"][i]), m1[i]), (bytes(z["names2"][i]), m2[i])):
+                        f.write(b">" + nm + b"\n" + b"ACGT"[row[0]:row[0] + 1] + bytes(b"0123"[c] if c < 4 else ord(".") for c in row[1:]) + b"\n")
+            ins = tuple(int(x) for x in z["ins"])
+            p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "gmapper-cs"), "-N", "4", "-p", str(z["mode"]), "-I", "%d,%d" % ins, "--sam-unaligned", *extra, r, g], capture_output=True, check=True)
+            body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+        with gzip.open(os.path.join(OUT, "%s@%s.sam.gz" % (base, tag)), "wb", compresslevel=9) as f:
+            f.write(body)
+        print("%s@%s: %d SAM records" % (base, tag, sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@"))))
+
+
 def option_cases():
     """non-default options on inputs that are already committed: only the reference's SAM body is stored (<base>@<tag>.sam.gz)"""
     for tag, (base, extra) in OPTION_CASES.items():
@@ -430,6 +457,8 @@ def main():
         local_kat_cases(); return
     if "--post-kat-only" in sys.argv:
         post_kat_cases(); return
+    if "--cs-pair-options-only" in sys.argv:
+        cs_pair_option_cases(); return
     if "--cs-options-only" in sys.argv:
         cs_option_cases(); return
     if "--index-only" in sys.argv:
