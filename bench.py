@@ -375,6 +375,26 @@ def main():
                     others[wname] = e
                 except Exception as ex:                      # the headline must not be lost to a problem in a side entry: say what happened instead
                     others[wname] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            # configs[1] (100 Mbp) has a genome and an index of its own -- small ones: k_lookup_bkt with real Poisson(6) lists
+            try:
+                k2, g2, gs2, L2, rs2, R2, m2, u2, d2 = WORKLOADS["cfg2"]
+                t0 = time.time(); contigs2 = synth.make_genome(synth.contig_lengths(g2, 1.0), gs2); ix2 = gm.Index(contigs2, device=local, params=params); t_ix2 = time.time() - t0
+                s2 = gm.Session(ix2, params=params, max_batch_reads=sub_batch(k2))
+                pools2 = make_pools(synth, contigs2, k2, R2, L2, rs2, 0, 2, dev)
+                dt2, ms2, by2, nl2, agg2 = timed_steps(gm, s2, k2, pools2, R2, L2, 3, 1, 1, dist, dev)
+                e = {"metric": m2, "unit": u2, "workload": d2, "value": R2 * 3 / dt2, "steps": 3, "warmup": 1, "ms_per_step": 1e3 * dt2 / 3,
+                     "roofline": {k: v for k, v in roofline_of(gm, ms2, by2, nl2, R2 * 3).items() if k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches", "alg_bytes_per_unit")},
+                     "stages_ms_per_step": {k: agg2[k] / 3 for k in agg2 if k.startswith("ms_")}, "genome_and_index_s": t_ix2}
+                if not args.no_cpu_baseline:
+                    from tests import oracle_api as oa
+                    smp2 = make_sample(synth, contigs2, k2, 50_000, L2, rs2)
+                    o2 = oa.Session(contigs2); cdt2, sam2 = oracle_sample(oa, o2, k2, smp2, ncores); o2.close()
+                    e["cpu_port_value"] = 50_000 / cdt2; e["cpu_cores"] = ncores; e["sample_units"] = 50_000
+                    e["sample_sam_identical"] = bool(product_sample(s2, k2, smp2) == sam2)
+                s2.close(); ix2.close(); del pools2, contigs2
+                others["cfg2"] = e
+            except Exception as ex:
+                others["cfg2"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
             out["other_workloads"] = others
         if o_ls is not None: o_ls.close()
         print(json.dumps(out))
