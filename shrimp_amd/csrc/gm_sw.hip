@@ -1711,11 +1711,35 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
       if (inband) {
         const int dbc = db[c];
         uint32_t bw_nw = 0, bw_n = 0, bw_w = 0;
+        // Without an indel taboo the reference's scans factor: every candidate of the diagonal move is "a state of some layer (+ a crossover when the layer changes)", tried in
+        // a fixed order with strict comparisons (the first maximum wins), and the own layer comes first -- so the first maximum over the whole list is the first maximum over
+        // the layers' own first maxima.  The per-layer maxima (value and back code) are the same for all four target layers: 8 + 4 compare-selects per cell for them, 3 per
+        // target layer for the choice among layers, instead of 11 (diagonal) and 7 (vertical) per target layer.
+        int Mv[4], Mc[4], Nv[4], Nc[4];
+        if (!TABOO) {
+#pragma unroll
+          for (int l2 = 0; l2 < 4; l2++) {
+            int v, c;
+            if (!revcmpl) { v = d[l2 * 3]; c = 6; if (d[l2 * 3 + 1] > v) { v = d[l2 * 3 + 1]; c = 5; } if (d[l2 * 3 + 2] > v) { v = d[l2 * 3 + 2]; c = 7; } }
+            else { v = d[l2 * 3 + 2]; c = 7; if (d[l2 * 3 + 1] > v) { v = d[l2 * 3 + 1]; c = 5; } if (d[l2 * 3] > v) { v = d[l2 * 3]; c = 6; } }
+            Mv[l2] = v; Mc[l2] = (c << 2) | l2;
+            const int op = u[l2 * 3] - P.b_go - P.b_ge, ex = u[l2 * 3 + 1] - P.b_ge;
+            if (!revcmpl) { v = op; c = 2; if (ex > v) { v = ex; c = 1; } } else { v = ex; c = 1; if (op > v) { v = op; c = 2; } }
+            Nv[l2] = v; Nc[l2] = (c << 2) | l2;
+          }
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const int ms = (dbc == 15 || q[k] == 15) ? 0 : (dbc == q[k] ? P.match : P.mismatch);
           int tmp, b;
           // northwest, ref :356-438
+          if (!TABOO) {
+            tmp = Mv[k]; b = Mc[k];
+#pragma unroll
+            for (int l2 = 0; l2 < 4; l2++) { if (l2 == k) continue; if (Mv[l2] + xo > tmp) { tmp = Mv[l2] + xo; b = Mc[l2]; } }
+            tmp += ms;
+          } else
+          {
           if (!revcmpl) {
             tmp = d[k * 3] + ms; b = (6 << 2) | k;
             if (notaboo && d[k * 3 + 1] + ms > tmp) { tmp = d[k * 3 + 1] + ms; b = (5 << 2) | k; }
@@ -1738,10 +1762,17 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
               if (d[l2 * 3] + ms + xo > tmp) { tmp = d[l2 * 3] + ms + xo; b = (6 << 2) | l2; }
             }
           }
+          }
           const int resetval = k ? xo : 0;               // :350-353
           if (LOCAL && tmp <= resetval) { tmp = resetval; b = 0; }
           nv[k * 3] = tmp; bw_nw |= (uint32_t)b << (8 * k);
           // north, ref :447-503
+          if (!TABOO) {
+            tmp = Nv[k]; b = Nc[k];
+#pragma unroll
+            for (int l2 = 0; l2 < 4; l2++) { if (l2 == k) continue; if (Nv[l2] + xo > tmp) { tmp = Nv[l2] + xo; b = Nc[l2]; } }
+          } else
+          {
           if (!revcmpl) {
             tmp = u[k * 3] - P.b_go - P.b_ge; b = (2 << 2) | k;
             if (!notaboo || u[k * 3 + 1] - P.b_ge > tmp) { tmp = u[k * 3 + 1] - P.b_ge; b = (1 << 2) | k; }
@@ -1759,6 +1790,7 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
               if (u[l2 * 3 + 1] - P.b_ge + xo > tmp) { tmp = u[l2 * 3 + 1] - P.b_ge + xo; b = (1 << 2) | l2; }
               if (notaboo && u[l2 * 3] - P.b_go - P.b_ge + xo > tmp) { tmp = u[l2 * 3] - P.b_go - P.b_ge + xo; b = (2 << 2) | l2; }
             }
+          }
           }
           if (LOCAL && tmp <= resetval) { tmp = resetval; b = 0; }
           nv[k * 3 + 1] = tmp; bw_n |= (uint32_t)b << (8 * k);
