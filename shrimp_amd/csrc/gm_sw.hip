@@ -1666,9 +1666,9 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
     int nst = t_hi >= 0 ? t_hi - t_lo + 1 : 0, nmax = nst;
     for (int dd = 32; dd >= 16; dd >>= 1) nmax = max(nmax, __shfl_xor(nmax, dd));
     nmax = __builtin_amdgcn_readfirstlane(nmax);
-    int pw[12], d[12], cur[12], inv[12];
+    int d[12], cur[12], inv[12];        // (cur: this lane's cell of the step before = the west neighbour of the next one)
 #pragma unroll
-    for (int x = 0; x < 12; x++) { pw[x] = OB(x); d[x] = OB(x); cur[x] = OB(x); }
+    for (int x = 0; x < 12; x++) { d[x] = OB(x); cur[x] = OB(x); }
     // lane 0's upper neighbour: the virtual row (stripe 0: constants), or the previous stripe's last row (read one step ahead below)
 #pragma unroll
     for (int x = 0; x < 12; x++) { const int k = x / 3, st = x % 3; const int xv = k ? xg : 0; inv[x] = s == 0 ? (st == 0 ? 0 : (st == 1 ? -P.b_go : -P.a_go)) + xv : OB(x); }
@@ -1689,11 +1689,12 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
     }
     const bool more = (s + 1 < n_stripes);
     const bool last_row_lane = row_ok && (r == rlen - 1);
-    for (int i = 0; i < nmax; i++) {
+    // One step of the stripe.  d / cur: the cells (r-1, c-1) and (r, c-1) of this lane; the step leaves (r-1, c) and (r, c) in u / nv, which are the next step's d / cur: the
+    // loop below runs two steps per round with the two register sets swapped, so that no values are copied from one set to the other (24 of a step's ~360 instructions).
+    auto step = [&](const int i, const int (&d)[12], const int (&cur)[12], int (&u)[12], int (&nv)[12]) {
       const bool on = i < nst;
       const int t = t_lo + i;
       const int c = t - l;
-      int u[12];
 #pragma unroll
       for (int x = 0; x < 12; x++) u[x] = g4_shr1(cur[x], inv[x]);   // cell (r-1, c)
       if (s > 0) {                                   // next step's carry values for the group's first lane
@@ -1705,11 +1706,10 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
         }
       }
       const bool inband = on && row_ok && c >= x_min && c <= x_max;
-      int nv[12];
-#pragma unroll
-      for (int x = 0; x < 12; x++) nv[x] = OB(x);
-      if (inband) {
-        const int dbc = db[c];
+      // (every lane works the cell out, the band decides afterwards what is kept: straight-line code -- a branch around the cell cost more register copies at its join
+      // than the cell has comparisons)
+      {
+        const int dbc = db[min(max(c, 0), glen - 1)];
         uint32_t bw_nw = 0, bw_n = 0, bw_w = 0;
         // Without an indel taboo the reference's scans factor: every candidate of the diagonal move is "a state of some layer (+ a crossover when the layer changes)", tried in
         // a fixed order with strict comparisons (the first maximum wins), and the own layer comes first -- so the first maximum over the whole list is the first maximum over
@@ -1796,29 +1796,37 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
           nv[k * 3 + 1] = tmp; bw_n |= (uint32_t)b << (8 * k);
           // west, ref :512-541 (no crossover on a genomic gap)
           if (!revcmpl) {
-            tmp = pw[k * 3] - P.a_go - P.a_ge; b = (3 << 2) | k;
-            if (!notaboo || pw[k * 3 + 2] - P.a_ge > tmp) { tmp = pw[k * 3 + 2] - P.a_ge; b = (4 << 2) | k; }
+            tmp = cur[k * 3] - P.a_go - P.a_ge; b = (3 << 2) | k;
+            if (!notaboo || cur[k * 3 + 2] - P.a_ge > tmp) { tmp = cur[k * 3 + 2] - P.a_ge; b = (4 << 2) | k; }
           } else {
-            tmp = pw[k * 3 + 2] - P.a_ge; b = (4 << 2) | k;
-            if (notaboo && pw[k * 3] - P.a_go - P.a_ge > tmp) { tmp = pw[k * 3] - P.a_go - P.a_ge; b = (3 << 2) | k; }
+            tmp = cur[k * 3 + 2] - P.a_ge; b = (4 << 2) | k;
+            if (notaboo && cur[k * 3] - P.a_go - P.a_ge > tmp) { tmp = cur[k * 3] - P.a_go - P.a_ge; b = (3 << 2) | k; }
           }
           if (LOCAL && tmp <= resetval) { tmp = resetval; b = 0; }
           nv[k * 3 + 2] = tmp; bw_w |= (uint32_t)b << (8 * k);
-          if (LOCAL || last_row_lane) {                // ref :547-575 (local: every row)
+          if (inband && (LOCAL || last_row_lane)) {    // ref :547-575 (local: every row)
             const int a0 = revcmpl ? nv[k * 3 + 2] : nv[k * 3], a1 = nv[k * 3 + 1], a2 = revcmpl ? nv[k * 3] : nv[k * 3 + 2];
             const int m = max(a0, max(a1, a2));
             if (m > best.score) { best.score = m; best.i = r; best.j = c; best.k = k; best.e_nw = nv[k * 3]; best.e_n = nv[k * 3 + 1]; best.e_w = nv[k * 3 + 2]; }
           }
         }
-        uint32_t* bp = back + ((size_t)r * glen + c) * 3;
-        bp[0] = bw_nw; bp[1] = bw_n; bp[2] = bw_w;
+        if (inband) {
+          uint32_t* bp = back + ((size_t)r * glen + c) * 3;
+          bp[0] = bw_nw; bp[1] = bw_n; bp[2] = bw_w;
+        }
       }
+#pragma unroll
+      for (int x = 0; x < 12; x++) nv[x] = inband ? nv[x] : OB(x);
       if (more && l == 15 && on && c >= 0 && c < glen) {
 #pragma unroll
         for (int x = 0; x < 12; x++) carry[x * glen + c] = nv[x];
       }
-#pragma unroll
-      for (int x = 0; x < 12; x++) { d[x] = u[x]; pw[x] = nv[x]; cur[x] = nv[x]; }
+    };
+    {
+      int d2[12], cur2[12];
+      int i = 0;
+      for (; i + 1 < nmax; i += 2) { step(i, d, cur, d2, cur2); step(i + 1, d2, cur2, d, cur); }
+      if (i < nmax) step(i, d, cur, d2, cur2);
     }
     cw_lo = 1; cw_hi = 0;
     if (more && t_hi >= 0) { cw_lo = max(0, t_lo - 15); cw_hi = min(glen - 1, t_hi - 15); }
@@ -1837,6 +1845,20 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
   return best;
 }
 
+// Diagnostic build (-DP2CS_STAMPS, tools/p2cs_stamps.py): lane 0 of every wave adds the cycles of a pass's phases to p2cs_stamps[] (0: set-up -- unpack read and window,
+// translations; 1: the cells; 2: traceback; 3: passes).  No stamp executes in the normal build.
+#ifdef P2CS_STAMPS
+__device__ unsigned long long p2cs_stamps[8];
+#define P2CS_STAMP(i) do { if (lane == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&p2cs_stamps[i], t_ - t_prev); t_prev = t_; } } while (0)
+extern "C" int gm_debug_p2cs_stamps(unsigned long long* out) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(p2cs_stamps), sizeof z) != hipSuccess) return GM_E_NODEVICE;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(p2cs_stamps), z, sizeof z) != hipSuccess) return GM_E_NODEVICE;
+  return GM_OK;
+}
+#else
+#define P2CS_STAMP(i) do { } while (0)
+#endif
 struct P2CsG4 {
   const uint32_t* reads; const uint8_t* initbp; int read_len, read_words; const GmHit* hits; int hcap; const int32_t* sel; const int32_t* sel_sidx;
   const uint32_t* work; GmFullRes* res; uint8_t* ops; int ops_stride, max_w; const int8_t* xover;
@@ -1846,6 +1868,9 @@ template <bool REV, bool TABOO, bool LOCAL>
 __device__ __forceinline__ void p2cs_g4_pass(const GmIndexDev& ix, const GmScoreDev& sc, const GmCsDev& P, const P2CsG4& A, const uint32_t wi, const bool has, uint32_t* back,
                                              const int lane, unsigned long long& fcalls, unsigned long long& fcells) {
   const int g = lane >> 4, l = lane & 15;
+#ifdef P2CS_STAMPS
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
   const int read_len = A.read_len, qstride = A.qstride, half = A.ops_stride >> 1;
   const uint8_t* qr4 = A.qr4_all + g * 4 * qstride; const uint8_t* db = A.db_all + g * A.mw16; int* carry = A.carry_all + g * 12 * A.max_w;
   const uint32_t wk = has ? A.work[wi] : 0u;
@@ -1908,9 +1933,11 @@ __device__ __forceinline__ void p2cs_g4_pass(const GmIndexDev& ix, const GmScore
     rx -= P.anchor_width / 2; ry += P.anchor_width / 2; rw += P.anchor_width; }
   const int g_off_i = (int)g_off;
   __syncthreads();
+  P2CS_STAMP(0);
   const CsBest fo = full_sw_cs_g4<REV, TABOO, LOCAL>(db, w_len, qr4, qstride, read_len, P, has, rx, ry, rl, rw, back, carry, lane, A.xover ? A.xover + (size_t)rd * read_len : nullptr);
   __syncthreads();
   __threadfence();
+  P2CS_STAMP(1);
   if (has && l == 0 && fo.score >= 0 && fo.score >= thresh) {     // ref: sw-full-cs.c:1216; do_backtrace :633-937
     auto code_at = [&](int ci, int cj, int word, int lay) -> int {
       int x_min, x_max; band_range(rx, ry, rl, rw, w_len, ci, &x_min, &x_max);
@@ -1950,6 +1977,11 @@ __device__ __forceinline__ void p2cs_g4_pass(const GmIndexDev& ix, const GmScore
     Rp->gmapped = fo.j - gstart + 1; Rp->rmapped = fo.i - rstart + 1;
     Rp->n_match = nm; Rp->n_mismatch = nmm; Rp->n_ins = nin; Rp->n_del = ndel; Rp->n_xover = nx;
   }
+  __builtin_amdgcn_wave_barrier();
+  P2CS_STAMP(2);
+#ifdef P2CS_STAMPS
+  if (lane == 0) atomicAdd(&p2cs_stamps[3], 1ull);
+#endif
 }
 
 template <bool TABOO, bool LOCAL>
