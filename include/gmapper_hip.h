@@ -66,7 +66,7 @@ typedef struct gm_params {
   int indel_taboo_len;                         /* ref: gmapper.h:57  0 */
   double pr_xover;                             /* ref: gmapper.h:119  0.03: fixes score_alpha in colour space (gmapper.c:2557-2563) */
   int local_alignment;                         /* --local, i.e. Gflag off (ref: gmapper.c:2303-2305): sw_full_ls in local mode (soft clips); mapping qualities
-                                                  are then unavailable (gmapper.c:2325-2328): MAPQ 255, no Z0-Z6 tags.  Letter space (unpaired and paired) and, unpaired, colour space (sw_full_cs with
+                                                  are then unavailable (gmapper.c:2325-2328): MAPQ 255, no Z0-Z6 tags.  Letter space and colour space, unpaired and paired (sw_full_cs with
                                                   local_alignment, ref: sw-full-cs.c:199-203,315,439-552; no post_sw then, mapping.c:1648; not combined with csfastq quality values).  0 */
   int ungapped;                                /* -U (gapless_sw): pass 1 scores windows with sw_gapless (ref: sw-gapless.c:57-117), every anchor opens a window
                                                   (mapping.c:1095,1154).  As the reference's -U does, also set anchor_width 0, both gap opens -255 and
@@ -185,7 +185,7 @@ void sw_full_ls_stats(uint64_t *invocs, uint64_t *cells, double *secs);   /* ref
  * lstocs(genome_ls[j], initbp) (ref: common/sw-vector.c:112-146); `mismatch` is then match + crossover (ref: gmapper.c:2935).
  * sw_full_cs: four letter-space translations of the colour read, 3-state affine DP in four layers with crossovers between
  * layers on the NW and N transitions, traceback with crossover marks (lower-case in qralign), ref: common/sw-full-cs.c:249-1236.
- * Global mode (local_alignment == 0) and one anchor box, as gmapper calls it (ref: mapping.c:375-379); crossover_score
+ * Both modes (local_alignment 0 / 1, ref: sw-full-cs.c:199-203,315,439-552) and one anchor box, as gmapper calls it (ref: mapping.c:375-379); crossover_score
  * (per-position penalties from read qualities) must be NULL at this seam; the read pipeline (gm_map_reads_cs*) takes them from the QVs itself.
  * ------------------------------------------------------------------------------------------- */
 int sw_full_cs_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,

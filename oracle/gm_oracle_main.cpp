@@ -178,11 +178,17 @@ int gmo_sw_vector_cs(const uint32_t* genome_cs, int goff, int glen, const uint32
   Params P = default_params();
   return sw_vector_cs(P, 10 + (-20), genome_cs, goff, glen, read, rlen, genome_ls, initbp);
 }
+int gmo_sw_full_cs_mode(const uint32_t* genome_ls, int goff, int glen, const uint32_t* read, int rlen, int initbp, int thresh,
+                        long long ax, long long ay, int alen, int awidth, int revcmpl, int local, int* out, char* dbalign, char* qralign, int cap);
 int gmo_sw_full_cs(const uint32_t* genome_ls, int goff, int glen, const uint32_t* read, int rlen, int initbp, int thresh,
                    long long ax, long long ay, int alen, int awidth, int revcmpl, int* out, char* dbalign, char* qralign, int cap) {
+  return gmo_sw_full_cs_mode(genome_ls, goff, glen, read, rlen, initbp, thresh, ax, ay, alen, awidth, revcmpl, 0, out, dbalign, qralign, cap);
+}
+int gmo_sw_full_cs_mode(const uint32_t* genome_ls, int goff, int glen, const uint32_t* read, int rlen, int initbp, int thresh,
+                        long long ax, long long ay, int alen, int awidth, int revcmpl, int local, int* out, char* dbalign, char* qralign, int cap) {
   CsParams C; SwFullCsResults s;
   Anchor a; a.x = ax; a.y = ay; a.length = alen; a.width = awidth; a.weight = 1;
-  sw_full_cs(C, genome_ls, goff, glen, read, rlen, initbp, thresh, &s, revcmpl != 0, &a, 1);
+  sw_full_cs(C, genome_ls, goff, glen, read, rlen, initbp, thresh, &s, revcmpl != 0, &a, 1, nullptr, local);
   int v[10] = {s.score, s.read_start, s.rmapped, s.genome_start, s.gmapped, s.matches, s.mismatches, s.insertions, s.deletions, s.crossovers};
   memcpy(out, v, sizeof v);
   if ((int)s.dbalign.size() + 1 > cap) return -1;

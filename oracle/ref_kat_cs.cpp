@@ -5,6 +5,7 @@
 //   C goff glen rlen initbp <genome_cs words> <genome_ls words> <read colour words> score
 //   S goff glen rlen initbp ax ay alen awidth revcmpl thresh <genome_ls words> <read colour words>
 //     score read_start rmapped genome_start gmapped matches mismatches insertions deletions crossovers dbalign qralign   ("-" when empty)
+//   L ...  (second argument "local"): the S record's fields for sw_full_cs in local mode -> tests/golden/sw_kat_cs_local.txt.gz
 // Scores are the binary's colour-space defaults (ref: gmapper-defaults.h:52-58): match 10, mismatch -24, crossover -20,
 // gaps -33/-7 (reference) -33/-3 (query); the vector filter's mismatch is match + crossover (ref: gmapper.c:2935).
 #include <cstdio>
@@ -24,6 +25,7 @@ static void dump(const std::vector<uint32_t>& bf) { for (size_t i = 0; i < bf.si
 
 int main(int argc, char** argv) {
   int n = argc > 1 ? atoi(argv[1]) : 1500;
+  const bool local = argc > 2 && !strcmp(argv[2], "local");     // "L" records: the same cases through sw_full_cs(.., local_alignment = true) (ref: sw-full-cs.c:199-203,315,439-552); no C / S records
   std::mt19937_64 rng(20260202);
   sw_vector_setup(1400, 1000, -33, -7, -33, -3, 10, 10 + (-20), 1, true);
   sw_full_cs_setup(1400, 1000, -33, -7, -33, -3, 10, -24, -20, true, 8, 0);
@@ -60,15 +62,15 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < g.size(); i++) { put(gl, (int)i, g[i]); put(gc, (int)i, lstocs(i ? g[i - 1] : BASE_T, g[i], false)); }   // ref: fasta.c:586-607
     for (int i = 0; i < rlen; i++) put(rb, i, rc[i]);
     int sv = sw_vector(gc.data(), goff, glen, rb.data(), rlen, gl.data(), initbp, false);
-    printf("C %d %d %d %d ", goff, glen, rlen, initbp); dump(gc); printf(" "); dump(gl); printf(" "); dump(rb); printf(" %d\n", sv);
+    if (!local) { printf("C %d %d %d %d ", goff, glen, rlen, initbp); dump(gc); printf(" "); dump(gl); printf(" "); dump(rb); printf(" %d\n", sv); }
     struct anchor a; memset(&a, 0, sizeof a);
     a.x = (start - goff) + (int)(rng() % 7) - 3; a.y = 0; a.length = 10 + rng() % (rlen > 16 ? rlen - 10 : 6); a.width = 1 + rng() % 4; a.weight = 2;
     if (rng() % 4 == 0) { a.y = rng() % 10; a.x += a.y; }
     int thresh = (rng() % 3 == 0) ? (int)(0.6 * rlen * 10) : (int)(0.3 * rlen * 10);
     for (int rv = 0; rv < 2; rv++) {
       struct sw_full_results sfr; memset(&sfr, 0, sizeof sfr);
-      sw_full_cs(gl.data(), goff, glen, rb.data(), rlen, initbp, thresh, &sfr, rv != 0, false, &a, 1, 0, NULL);
-      printf("S %d %d %d %d %lld %lld %d %d %d %d ", goff, glen, rlen, initbp, (long long)a.x, (long long)a.y, a.length, a.width, rv, thresh);
+      sw_full_cs(gl.data(), goff, glen, rb.data(), rlen, initbp, thresh, &sfr, rv != 0, false, &a, 1, local ? 1 : 0, NULL);
+      printf("%s %d %d %d %d %lld %lld %d %d %d %d ", local ? "L" : "S", goff, glen, rlen, initbp, (long long)a.x, (long long)a.y, a.length, a.width, rv, thresh);
       dump(gl); printf(" "); dump(rb);
       printf(" %d %d %d %d %d %d %d %d %d %d %s %s\n", sfr.score, sfr.read_start, sfr.rmapped, sfr.genome_start, sfr.gmapped,
              sfr.matches, sfr.mismatches, sfr.insertions, sfr.deletions, sfr.crossovers,

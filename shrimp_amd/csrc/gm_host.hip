@@ -1989,9 +1989,9 @@ extern "C" void sw_full_cs(uint32_t* genome_ls, int goff, int glen, uint32_t* re
   if (!g_sc.init) abort();   // ref: sw-full-cs.c:1155-1156
   SeamTimer tm(&g_sc.secs); g_sc.invocs++; g_sc.cells += 4ull * (uint64_t)std::max(glen, 0) * (uint64_t)std::max(rlen, 0);
   auto fail = [&](const char* why) { gm_set_error("sw_full_cs: %s", why); sfr->score = 0; sfr->dbalign = nullptr; sfr->qralign = nullptr; };
-  if (local_alignment || crossover_score || anchors == nullptr || anchors_cnt != 1 || glen > g_sc.dblen || rlen > g_sc.qrlen || glen < 1 || rlen < 1 ||
+  if (crossover_score || anchors == nullptr || anchors_cnt != 1 || glen > g_sc.dblen || rlen > g_sc.qrlen || glen < 1 || rlen < 1 ||
       initbp < 0 || initbp > 3 || g_sc.p[7] < 0) {
-    fail("only the global mode with one anchor box and the global crossover penalty (gmapper's call, ref: mapping.c:375-379) is implemented"); return;
+    fail("only one anchor box and the global crossover penalty (gmapper's call, ref: mapping.c:375-379) are implemented"); return;
   }
   const uint64_t gw = ((uint64_t)goff + glen + 7) / 8 + 8; const int rwords = (rlen + 7) / 8 + 1;
   const int ops_cap = glen + rlen + 8;
@@ -2005,7 +2005,7 @@ extern "C" void sw_full_cs(uint32_t* genome_ls, int goff, int glen, uint32_t* re
          hipMemset(dr, 0, (size_t)rwords * 4) == hipSuccess && hipMemcpy(dr, read, (size_t)(rwords - 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemset(dback, 0, back_bytes) == hipSuccess &&                                     // out-of-band cells: back == 0 (ref: init_cell)
          gm_launch_sw_full_cs_single(g_sc.p, dg, goff, glen, dr, rlen, initbp, threshscore, anchors[0].x, anchors[0].y, anchors[0].length, anchors[0].width,
-                                     revcmpl ? 1 : 0, dback, dout, dops, ops_cap, 0) == GM_OK &&
+                                     revcmpl ? 1 : 0, dback, dout, dops, ops_cap, 0, local_alignment ? 1 : 0) == GM_OK &&
          hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, dout, 12 * 4, hipMemcpyDeviceToHost) == hipSuccess &&
          hipMemcpy(ops.data(), dops, ops_cap, hipMemcpyDeviceToHost) == hipSuccess;
   }

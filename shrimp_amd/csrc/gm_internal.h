@@ -175,4 +175,4 @@ int gm_launch_sw_vector_batch_cs(const GmScoreDev& sc, int n, const uint32_t* d_
                                  int* d_scores, hipStream_t stream);
 int gm_launch_sw_full_cs_single(const int* cs_params9, const uint32_t* d_genome_ls, long long goff, int glen, const uint32_t* d_read, int rlen, int initbp,
                                 int thresh, long long ax, long long ay, int alen, int awidth, int revcmpl, uint32_t* d_back, int* d_out, uint8_t* d_ops,
-                                int ops_cap, hipStream_t stream);
+                                int ops_cap, hipStream_t stream, int local = 0);

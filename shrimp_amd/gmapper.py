@@ -639,14 +639,14 @@ def sw_full_cs_setup(dblen, qrlen, a_gap_open, a_gap_ext, b_gap_open, b_gap_ext,
            "sw_full_cs_setup")
 
 
-def sw_full_cs(genome_ls, goff, glen, read_words, rlen, initbp, thresh, anchor, revcmpl=False):
-    """anchor = (x, y, length, width); returns (fields dict incl. crossovers, dbalign, qralign)."""
+def sw_full_cs(genome_ls, goff, glen, read_words, rlen, initbp, thresh, anchor, revcmpl=False, local=False):
+    """anchor = (x, y, length, width); local: the reference's local_alignment argument; returns (fields dict incl. crossovers, dbalign, qralign)."""
     L = lib()
     g = np.ascontiguousarray(genome_ls, dtype=np.uint32); r = np.ascontiguousarray(read_words, dtype=np.uint32)
     a = Anchor(anchor[0], anchor[1], anchor[2], anchor[3], 1, 0, 0)
     s = SwFullResults()
     L.sw_full_cs(g.ctypes.data_as(C.POINTER(C.c_uint32)), goff, glen, r.ctypes.data_as(C.POINTER(C.c_uint32)), rlen, initbp, thresh,
-                 C.byref(s), bool(revcmpl), False, C.byref(a), 1, 0, None)
+                 C.byref(s), bool(revcmpl), False, C.byref(a), 1, 1 if local else 0, None)
     db = C.string_at(s.dbalign).decode() if s.dbalign else ""
     qr = C.string_at(s.qralign).decode() if s.qralign else ""
     if s.dbalign: L.gm_free(s.dbalign)

@@ -256,16 +256,16 @@ def load_kat_local():
             yield (tuple(int(x) for x in t[1:12]), parse_words(t[12]), parse_words(t[13]), [int(x) for x in t[14:23]], t[23], t[24])
 
 
-def load_kat_cs():
-    """colour-space known answers produced by the reference's own sw_vector(use_colours) / sw_full_cs (oracle/ref_kat_cs.cpp)"""
+def load_kat_cs(name="sw_kat_cs.txt.gz"):
+    """colour-space known answers produced by the reference's own sw_vector(use_colours) / sw_full_cs (oracle/ref_kat_cs.cpp); sw_kat_cs_local.txt.gz: "L" records, sw_full_cs in local mode"""
     recs = []
     words = lambda t: np.array([int(x, 16) for x in t.split(b",")], dtype=np.uint32)
-    with gzip.open(os.path.join(ROOT, "tests", "golden", "sw_kat_cs.txt.gz"), "rb") as f:
+    with gzip.open(os.path.join(ROOT, "tests", "golden", name), "rb") as f:
         for line in f:
             t = line.split()
             if t[0] == b"C":
                 recs.append(("C", int(t[1]), int(t[2]), int(t[3]), int(t[4]), words(t[5]), words(t[6]), words(t[7]), int(t[8])))
             else:
-                recs.append(("S", [int(x) for x in t[1:11]], words(t[11]), words(t[12]), [int(x) for x in t[13:23]],
+                recs.append((t[0].decode(), [int(x) for x in t[1:11]], words(t[11]), words(t[12]), [int(x) for x in t[13:23]],
                              b"" if t[23] == b"-" else t[23], b"" if t[24] == b"-" else t[24]))
     return recs

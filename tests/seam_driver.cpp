@@ -16,6 +16,7 @@
 //   G glen rlen g_idx r_idx init_bp <genome> <read> <genome_ls | ->   -> G score
 //   F goff glen rlen ax ay alen awidth rv <genome> <read>              -> F score read_start rmapped genome_start gmapped matches mismatches insertions deletions dbalign qralign
 //   S goff glen rlen initbp ax ay alen awidth rv thresh <genome_ls> <read> -> S (the same ten + crossovers) dbalign qralign   ("-" when empty)
+//   L ... (the S request's fields)                                        -> L ...: sw_full_cs with local_alignment = true
 //   P <qual | -> goff glen rlen initbp ax ay alen awidth rv thresh <genome_ls> <read> -> P posterior(%a) matches mismatches crossovers qralign qual   (sw_full_cs, then post_sw)
 //   stats                                                              -> stats <invocations of sw_vector, sw_gapless, sw_full_ls, sw_full_cs, post_sw>
 #include <cstdio>
@@ -97,15 +98,15 @@ int main() {
       printf("F %d %d %d %d %d %d %d %d %d %s %s\n", f.score, f.read_start, f.rmapped, f.genome_start, f.gmapped, f.matches, f.mismatches, f.insertions, f.deletions,
              str(f.dbalign), str(f.qralign));
       free(f.dbalign); free(f.qralign);
-    } else if (op == "S" || op == "P") {
+    } else if (op == "S" || op == "P" || op == "L") {
       std::string q; if (op == "P") in >> q;
       int goff, glen, rlen, ib, rv, thresh; struct anchor a; memset(&a, 0, sizeof a); std::string gl, r;
       in >> goff >> glen >> rlen >> ib >> a.x >> a.y >> a.length >> a.width >> rv >> thresh >> gl >> r; a.weight = 2;
       auto glw = words(gl), rw = words(r);
       struct sw_full_results f; memset(&f, 0, sizeof f);
-      sw_full_cs(glw.data(), goff, glen, rw.data(), rlen, ib, thresh, &f, rv != 0, false, &a, 1, 0, nullptr);
-      if (op == "S") {
-        printf("S %d %d %d %d %d %d %d %d %d %d %s %s\n", f.score, f.read_start, f.rmapped, f.genome_start, f.gmapped, f.matches, f.mismatches, f.insertions, f.deletions,
+      sw_full_cs(glw.data(), goff, glen, rw.data(), rlen, ib, thresh, &f, rv != 0, false, &a, 1, op == "L" ? 1 : 0, nullptr);
+      if (op == "S" || op == "L") {
+        printf("%s %d %d %d %d %d %d %d %d %d %d %s %s\n", op.c_str(), f.score, f.read_start, f.rmapped, f.genome_start, f.gmapped, f.matches, f.mismatches, f.insertions, f.deletions,
                f.crossovers, str(f.dbalign), str(f.qralign));
       } else {
         if (f.score <= 0 || !f.dbalign || !f.dbalign[0]) { printf("P none\n"); }

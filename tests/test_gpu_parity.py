@@ -479,6 +479,17 @@ def test_colour_space_kernels_known_answers(gm):
             assert got == want and gdb.encode() == db and gqr.encode() == qr, (got, want, gdb, db, gqr, qr)
         n += 1
     assert n >= 1400
+    nl = 0
+    for r in oa.load_kat_cs("sw_kat_cs_local.txt.gz"):          # local_alignment = true (ref: sw-full-cs.c:199-203,315,439-552)
+        _, (goff, glen, rlen, initbp, ax, ay, alen, awidth, rv, thresh), gls, rd, want, db, qr = r
+        f, gdb, gqr = gm.sw_full_cs(gls, goff, glen, rd, rlen, initbp, thresh, (ax, ay, alen, awidth), revcmpl=bool(rv), local=True)
+        if want[0] == 0:
+            assert f["score"] == 0, (f, want)
+        else:
+            got = [f[k] for k in ("score", "read_start", "rmapped", "genome_start", "gmapped", "matches", "mismatches", "insertions", "deletions", "crossovers")]
+            assert got == want and gdb.encode() == db and gqr.encode() == qr, (got, want, gdb, db, gqr, qr)
+        nl += 1
+    assert nl >= 800
 
 
 CS_GOLDEN = ["cfg4s_50col_2Mbp", "stress_cs_60col_unal"]
@@ -780,7 +791,7 @@ def test_mangled_seams_on_every_known_answer(gm, tmp_path):
     """Drop-in at S1-S3 through the names the reference's objects reference (_Z9sw_vectorPjiiS_iS_ib, _Z10sw_gaplessPjiS_iiiS_ib, _Z10sw_full_lsPji...,
     _Z10sw_full_csPji..., _Z7post_swPjiPcP15sw_full_results; ref: sw-vector.h:3-6, sw-gapless.h:11-14, sw-full-ls.h:9-13, sw-full-cs.h:7-11, sw-post.h:8-12):
     a C++ program of our own (tests/seam_driver.cpp), linked against the library, replays EVERY known-answer record the reference's functions produced --
-    1 500 sw_vector + 700 colour-space sw_vector, 2 400 sw_gapless (letter and colour space), 2 990 sw_full_ls, 1 400 sw_full_cs and 1 833 post_sw
+    1 500 sw_vector + 700 colour-space sw_vector, 2 400 sw_gapless (letter and colour space), 2 990 sw_full_ls, 1 400 sw_full_cs + 800 in local mode and 1 833 post_sw
     (with and without quality values; posterior compared to the last bit, %a) -- on the GPU."""
     import gzip, subprocess
     exe = _seam_driver(tmp_path)
@@ -808,6 +819,11 @@ def test_mangled_seams_on_every_known_answer(gm, tmp_path):
         w, db, qr = r[4], r[5], r[6]
         req.append("S " + s_args(r))
         want.append("S " + " ".join(str(x) for x in w) + " %s %s" % ((db or b"-").decode(), (qr or b"-").decode()) if w[0] != 0 else None)      # score 0: nothing else is defined
+    lrecs = oa.load_kat_cs("sw_kat_cs_local.txt.gz")                # sw_full_cs with local_alignment = true
+    for r in lrecs:
+        w, db, qr = r[4], r[5], r[6]
+        req.append("L " + s_args(r))
+        want.append("L " + " ".join(str(x) for x in w) + " %s %s" % ((db or b"-").decode(), (qr or b"-").decode()) if w[0] != 0 else None)
     with gzip.open(os.path.join(oa.ROOT, "tests", "golden", "sw_kat_post.txt.gz"), "rt") as f: post = [l.split() for l in f if l.strip()]
     K = [t for t in post if t[0] == "K"][0][1:]
     nP = 0
@@ -832,13 +848,13 @@ def test_mangled_seams_on_every_known_answer(gm, tmp_path):
     bad = []
     for i, w in enumerate(want):
         if w is None:
-            if not got[i].startswith("S 0 "): bad.append((i, got[i][:200], "S 0 ..."))
+            if not (got[i].startswith("S 0 ") or got[i].startswith("L 0 ")): bad.append((i, got[i][:200], "S 0 ... / L 0 ..."))
         elif got[i] != w: bad.append((i, got[i][:300], w[:300]))
     assert not bad, (len(bad), bad[:5])
     st = [int(x) for x in got[len(want)].split()[1:]]
     # the *_stats entries (ref: gmapper.c:734-745 reads them): every set-up above resets its counters, so each shows the calls since its last set-up
     nq = sum(1 for t in post if t[0] == "P" and t[2] == "1")
-    assert st == [700, nG // 2, nF, len(srecs) + nP, nq], st
+    assert st == [700, nG // 2, nF, len(srecs) + len(lrecs) + nP, nq], st
 
 
 def test_full_size_genome_vs_oracle(gm, oracle_lib):

@@ -125,6 +125,23 @@ def test_oracle_colour_space_kernels_match_reference_known_answers(oracle_lib):
     assert nc >= 700 and ns >= 1400
 
 
+def test_oracle_sw_full_cs_local_mode_matches_reference_known_answers(oracle_lib):
+    """sw_full_cs(.., local_alignment = true) (ref: sw-full-cs.c:199-203,315,439-552): 400 random cases x 2 tie-break directions from the reference's own function"""
+    import ctypes as C
+    L = oa.load(); u32p = C.POINTER(C.c_uint32)
+    n = 0
+    for r in oa.load_kat_cs("sw_kat_cs_local.txt.gz"):
+        assert r[0] == "L"
+        _, (goff, glen, rlen, initbp, ax, ay, alen, awidth, rv, thresh), gls, rd, want, db, qr = r
+        out = (C.c_int * 10)(); dba = C.create_string_buffer(4096); qra = C.create_string_buffer(4096)
+        assert L.gmo_sw_full_cs_mode(gls.ctypes.data_as(u32p), goff, glen, rd.ctypes.data_as(u32p), rlen, initbp, thresh, C.c_longlong(ax), C.c_longlong(ay), alen, awidth, rv, 1,
+                                     out, dba, qra, 4096) == 0
+        if want[0] == 0: assert out[0] == 0
+        else: assert list(out) == want and dba.value == db and qra.value == qr, (list(out), want, dba.value, db, qra.value, qr)
+        n += 1
+    assert n >= 800
+
+
 CS_GOLDEN = ["cfg4s_50col_2Mbp", "stress_cs_60col_unal"]
 
 

@@ -275,6 +275,10 @@ def cs_kat_cases():
     with gzip.open(os.path.join(OUT, "sw_kat_cs.txt.gz"), "wb", compresslevel=9) as f:
         f.write(kat)
     print("sw_kat_cs:", kat.count(b"\nC ") + 1, "colour-space vector,", kat.count(b"\nS "), "sw_full_cs")
+    katl = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_kat_cs"), "400", "local"], capture_output=True, check=True).stdout
+    with gzip.open(os.path.join(OUT, "sw_kat_cs_local.txt.gz"), "wb", compresslevel=9) as f:
+        f.write(katl)
+    print("sw_kat_cs_local:", katl.count(b"\nL ") + 1, "sw_full_cs in local mode")
 
 
 def post_kat_cases():
@@ -457,6 +461,8 @@ def main():
         local_kat_cases(); return
     if "--post-kat-only" in sys.argv:
         post_kat_cases(); return
+    if "--cs-kat-only" in sys.argv:
+        cs_kat_cases(); return
     if "--cs-pair-options-only" in sys.argv:
         cs_pair_option_cases(); return
     if "--cs-options-only" in sys.argv:
