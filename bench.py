@@ -293,8 +293,9 @@ def main():
                    "library": os.path.basename(gm.LIB_PATH) + ("" if not knobs else " (tuning knobs set: %s)" % ",".join(sorted(knobs))),
                    "sam_emitted": not args.no_sam, "scale": args.scale, "host_threads_per_rank": host_threads, "host_threads": threads_all,
                    "sub_batch_pipeline": "stage order" if os.environ.get("GM_OVERLAP") == "0" else "two streams (lookup of sub-batch i+1 beside SW of sub-batch i)",
-                   "vector_sw_filter": ("every window swept to its end" if (kind == "pairs" or os.environ.get("GM_P1_EARLY") == "0") else
-                                        "a window stops once no alignment can reach the vector threshold (exact bound, same SAM; DESIGN.md section 4, K3)")},
+                   "vector_sw_filter": ("every window swept to its end" if os.environ.get("GM_P1_EARLY") == "0" else
+                                        ("the mates' own pass (pair sums) sweeps every window; the unpaired pass behind it stops a window once no alignment can reach the vector threshold" if kind == "pairs" else
+                                         "a window stops once no alignment can reach the vector threshold (exact bound, same SAM; DESIGN.md section 4, K3)"))},
     }
     if rank == 0:
         U = R * args.steps

@@ -119,9 +119,19 @@ __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen,
     };
     int t = 0;
     bool cut = false;
-    if (SINGLE && early_thr > 0) {
+    // the most an alignment can still reach that crosses this stripe's last row in one of the columns 0 .. limit - 1, or starts below it
+    auto carry_top = [&](const int limit) -> int {
+      const int rows_left = rlen - (s + 1) * 128;
+      int top = sc.match * min(rows_left, glen);
+      for (int c = lane; c < limit; c += GM_WAVE) top = max(top, (int)carryH[c] + sc.match * min(rows_left, glen - 1 - c));
+      for (int d = 32; d > 0; d >>= 1) top = max(top, __shfl_xor(top, d));
+      return top;
+    };
+    if (early_thr > 0) {
+      // (a stripe of a longer read: the rows of the stripes below count as rows left, and a stop here skips those stripes too)
+      const int rows_below = SINGLE ? 0 : max(rlen - (s + 1) * 128, 0);
       const uint32_t v_row = pk(2 * lane, 2 * lane + 1);
-      const uint32_t v_rleft = pk(max(rows - 1 - 2 * lane, 0), max(rows - 2 - 2 * lane, 0));
+      const uint32_t v_rleft = pk(max(rows - 1 - 2 * lane, 0) + rows_below, max(rows - 2 - 2 * lane, 0) + rows_below);
       const uint32_t v_thr1 = pk(early_thr - 1, early_thr - 1);
       for (int j = 0; j < 9; j++) {
         const int frac = (j == 0 ? 23 : j == 1 ? 33 : j == 2 ? 44 : j == 3 ? 56 : j == 4 ? 72 : j == 5 ? 92 : j == 6 ? 118 : j == 7 ? 154 : 192);     // of 256: where along the drain the test is made
@@ -134,7 +144,12 @@ __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen,
         const uint32_t pot = as_u(__builtin_bit_cast(s16x2, __builtin_bit_cast(u16x2, left) * __builtin_bit_cast(u16x2, v_match)));
         const uint32_t top = pk_max(v_score, pk_add(pk_max(Hprev, pk_add(upH_prev, v_match)), pot));
         const uint32_t over = as_u(__builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, top), __builtin_bit_cast(u16x2, v_thr1))));
-        if (!__any(over != 0u)) { cut = true; break; }
+        if (!__any(over != 0u)) {
+          // (a stripe with stripes below it: an alignment may have LEFT this stripe already, through a cell of its last row that was computed before the
+          // anti-diagonals tested above -- those cells are in the carry row: columns 0 .. t - 128)
+          if (!SINGLE && more && carry_top(min(glen, t - 127)) >= early_thr) continue;
+          cut = true; break;
+        }
       }
     }
     if (!cut) {
@@ -143,6 +158,15 @@ __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen,
     }
     if (bounded) *bounded = cut;
     if (more) __syncthreads();
+    if (!SINGLE && cut) break;
+    if (!SINGLE && more && early_thr > 0) {
+      // Two stripes (reads of more than 128 bases): every alignment that ends in a later stripe crosses this stripe's last row in some cell (R, c) -- or starts behind it,
+      // which H = 0 covers -- and gains at most `match` per row and column left; the gap state that crosses the row is below the cell's H.  If neither the best score so
+      // far nor any H(R, c) + match * min(rows left, columns left) reaches the threshold, the remaining stripes (41 % of a 150-base read's steps) cannot either.
+      int top = max((int)(int16_t)(v_score & 0xFFFF), (int)(int16_t)(v_score >> 16));
+      for (int d = 32; d > 0; d >>= 1) top = max(top, __shfl_xor(top, d));
+      if (max(top, carry_top(glen)) < early_thr) { if (bounded) *bounded = true; break; }
+    }
   }
   int best = max((int)(int16_t)(v_score & 0xFFFF), (int)(int16_t)(v_score >> 16));
   for (int d = 32; d > 0; d >>= 1) best = max(best, __shfl_xor(best, d));
@@ -152,7 +176,7 @@ template <bool CS>
 __device__ __forceinline__ int sw_vector_wave_t(const uint8_t* db, const uint8_t* db0, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc,
                                                 int16_t* carry, int lane, const int early_thr = 0, bool* bounded = nullptr) {
   if (bounded) *bounded = false;
-  return rlen <= 128 ? sw_vector_wave_s<CS, true>(db, db0, glen, qr, rlen, sc, carry, lane, early_thr, bounded) : sw_vector_wave_s<CS, false>(db, db0, glen, qr, rlen, sc, carry, lane);
+  return rlen <= 128 ? sw_vector_wave_s<CS, true>(db, db0, glen, qr, rlen, sc, carry, lane, early_thr, bounded) : sw_vector_wave_s<CS, false>(db, db0, glen, qr, rlen, sc, carry, lane, early_thr, bounded);
 }
 __device__ int sw_vector_wave(const uint8_t* db, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc, int16_t* carry, int lane) {
   return sw_vector_wave_t<false>(db, nullptr, glen, qr, rlen, sc, carry, lane);

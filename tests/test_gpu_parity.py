@@ -116,6 +116,47 @@ def test_sw_vector_early_stop_is_exact_about_the_threshold(gm):
     assert n_stopped > 0
 
 
+@pytest.mark.parametrize("L", [150, 200])
+def test_sw_vector_early_stop_two_stripes_is_exact_about_the_threshold(gm, L):
+    """the same for reads of more than 128 bases (two stripes of 64 lanes x 2 rows; 2 x 150 bp pairs' unpaired pass): a window may stop in the drain of the first stripe
+    (the rows of the second stripe count as rows left, and the alignments that already left through the stripe's last row are bounded from the carry row), between the
+    stripes, or in the drain of the second -- every stopped window's full score is below the threshold, every other window returns the full score"""
+    from shrimp_amd import synth
+    rng = np.random.default_rng(29 + L)
+    n = 4500
+    G = rng.integers(0, 4, size=400_000, dtype=np.uint8)
+    G[rng.integers(0, G.size, 300)] = 15
+    starts = rng.integers(0, G.size - 600, size=n)
+    reads = np.stack([G[s + 25:s + 25 + L].copy() for s in starts])
+    reads = np.where(rng.random(reads.shape) < 0.06, rng.integers(0, 4, size=reads.shape), reads).astype(np.uint8)
+    third = n // 3
+    for i in range(third, 2 * third):          # part of the read random: the true part lies in the first stripe, in the second, or across the seam
+        a = int(rng.integers(0, L - 40)); b = int(rng.integers(a + 30, L))
+        keep = np.zeros(L, dtype=bool); keep[a:b] = True
+        reads[i] = np.where(keep, reads[i], rng.integers(0, 4, size=L))
+    for i in range(2 * third, n):              # chance windows with two seed-like runs, one of them below row 128
+        keep = np.zeros(L, dtype=bool)
+        a = int(rng.integers(0, 100)); keep[a:a + 14] = True
+        a = int(rng.integers(128, L - 14)); keep[a:a + 14] = True
+        reads[i] = np.where(keep, reads[i], rng.integers(0, 4, size=L))
+    gw = synth.pack_nibbles(G); rw = synth.pack_reads(reads)
+    glen = np.full(n, int(L * 1.4), dtype=np.int32); glen[::7] = L - 10; glen[3::11] = 2 * L
+    rlen = np.full(n, L, dtype=np.int32)
+    gm.sw_vector_setup(1400, 1000, -33, -7, -33, -3, 10, -15, 0, True)
+    full = gm.sw_vector_batch(gw, starts, glen, rw, rlen)
+    n_stopped = 0
+    for thr in (int(4.7 * L), 3 * L, 7 * L, 9 * L):
+        got, stopped = gm.sw_vector_batch_bounded(gw, starts, glen, rw, rlen, thr)
+        st = stopped.astype(bool)
+        assert (got[~st] == full[~st]).all()
+        assert (full[st] < thr).all(), np.nonzero(st & (full >= thr))[0][:10]
+        assert (got[st] <= full[st]).all() and (got[st] >= 0).all()
+        assert ((full >= thr) <= ~st).all()
+        n_stopped += int(st.sum())
+        if thr == int(4.7 * L): assert st.sum() > n // 5 and (full >= thr).sum() > n // 5
+    assert n_stopped > 0
+
+
 def test_sw_vector_long_reads_multi_stripe(gm, oracle_lib):
     """reads longer than 128 rows exercise the stripe carry"""
     import ctypes as C
