@@ -112,11 +112,14 @@ template <typename T, int R> __device__ __forceinline__ void k2_bitonic_regs(T* 
   for (int j = 0; j < R; j++) key[lane * R + j] = v[j];
 }
 // keys in LDS, written and fenced by the caller; sorted and fenced on return
-template <bool BIG, typename T> __device__ void k2_sort(T* key, int npad, int lane) {
-  if (!BIG && npad <= 1024) {                                   // (the read-strand that carries the true hit keeps ~300 survivors at 100 bp on a 3 Gbp genome, ~700 at 150 bp)
+// RMAX: keys per lane the register networks go up to (16: 1 024 keys, 114 registers; 32: 2 048 keys, 248 registers -- a kernel of its own, k_anchors<false, 32>, taken only where
+// the LDS tier holds 2 048 survivors: 150-base reads on a 3 Gbp genome keep ~800 per read-strand, a fifth of the read-strands more than 1 024)
+template <bool BIG, typename T, int RMAX = 16> __device__ void k2_sort(T* key, int npad, int lane) {
+  if (!BIG && npad <= 64 * RMAX) {                              // (the read-strand that carries the true hit keeps ~300 survivors at 100 bp on a 3 Gbp genome, ~700 at 150 bp)
     if (npad == 64) k2_bitonic_regs<T, 1>(key, lane); else if (npad == 128) k2_bitonic_regs<T, 2>(key, lane);
     else if (npad == 256) k2_bitonic_regs<T, 4>(key, lane); else if (npad == 512) k2_bitonic_regs<T, 8>(key, lane);
-    else k2_bitonic_regs<T, 16>(key, lane);
+    else if (npad == 1024 || RMAX < 32) k2_bitonic_regs<T, 16>(key, lane);
+    else k2_bitonic_regs<T, RMAX>(key, lane);
     __syncthreads();
   } else k2_bitonic<BIG, T>(key, npad, lane);
 }
@@ -241,6 +244,7 @@ __device__ int k2_collapse_seq(const GmIndexDev& ix, K2Ws<BIG>& ws, int n, int r
 // Within a diagonal class the survivors are visited in position order; an entry opens a new anchor iff
 // its (true diagonal, contig) differs from its class predecessor's (all members of a run are colinear
 // with the run's first entry, so comparing with the predecessor == comparing with the cached anchor).
+template <int RMAX>
 __device__ int k2_collapse_par(const GmIndexDev& ix, K2Ws<false>& ws, uint32_t* ck, int n, int npad, int read_len, int lane) {
   for (int t = lane; t < npad; t += GM_WAVE) {
     uint32_t c = 0xFFFFFFFFu;
@@ -252,7 +256,7 @@ __device__ int k2_collapse_par(const GmIndexDev& ix, K2Ws<false>& ws, uint32_t* 
     ck[t] = c;
   }
   k2_sync<false>();
-  k2_sort<false, uint32_t>(ck, npad, lane);
+  k2_sort<false, uint32_t, RMAX>(ck, npad, lane);
   // Runs of one (class, contig, diagonal) are contiguous now.  A run's head takes the extent of all its members and their number -- a read that really maps
   // puts ~250 colinear k-mer hits into ONE run, and walking it from its head (one lane, two dependent LDS reads per member) was two thirds of this kernel's time.
   // So: every member finds its head by a running maximum over the head positions (wave scan, chunk by chunk) and adds itself with two LDS atomics: extent by
@@ -390,7 +394,7 @@ __device__ int k2_windows(const GmIndexDev& ix, const GmScoreDev& sc, K2Ws<BIG>&
   return nh;
 }
 
-template <bool BIG>
+template <bool BIG, int RMAX = 16>
 __global__ void __launch_bounds__(GM_WAVE)
 k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_len, int max_n_kmers, int NL,
           const uint64_t* __restrict__ surv, const uint32_t* __restrict__ surv_cnt, int scap,
@@ -398,7 +402,9 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
           int n_heavy, const uint32_t* __restrict__ heavy_list, const uint64_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_n,
           uint64_t* __restrict__ big_keys, uint32_t* __restrict__ big_aux, uint32_t* __restrict__ big_nxt, uint32_t* __restrict__ big_ord,
           GmHit* __restrict__ hits, uint16_t* __restrict__ perm, uint32_t* __restrict__ hit_cnt, int hcap,
-          unsigned long long* __restrict__ stats) {
+          unsigned long long* __restrict__ stats,
+          // LDS tier only: this launch takes the read-strands with lmin < survivors <= lcap (its LDS arrays hold lcap); the launch with lmin == 0 also writes the empty and the heavy ones off
+          int lcap, int lmin) {
   typedef typename K2Idx<BIG>::type idx_t;
   extern __shared__ __align__(16) uint8_t smem_raw[];
   __shared__ int sh_na;
@@ -418,12 +424,13 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
   } else {
     rs = blockIdx.x;
     const uint32_t n_all = surv_cnt[rs];
-    if (n_all == 0 || n_all > (uint32_t)scap) { if (lane == 0) hit_cnt[rs] = 0; return; }   // > scap: heavy tier
+    if (n_all == 0 || n_all > (uint32_t)scap) { if (lane == 0 && lmin == 0) hit_cnt[rs] = 0; return; }   // > scap: heavy tier
+    if (n_all <= (uint32_t)lmin || n_all > (uint32_t)lcap) return;                       // another launch's
     n = (int)n_all;
-    ws.key = (uint64_t*)base;                    base += (size_t)scap * 8;
-    ws.aux = (uint32_t*)base;                    base += (size_t)scap * 4;
-    ws.nxt = (idx_t*)base;                       base += (size_t)scap * sizeof(idx_t);
-    ws.ord = (idx_t*)base;                       base += (size_t)scap * sizeof(idx_t);
+    ws.key = (uint64_t*)base;                    base += (size_t)lcap * 8;
+    ws.aux = (uint32_t*)base;                    base += (size_t)lcap * 4;
+    ws.nxt = (idx_t*)base;                       base += (size_t)lcap * sizeof(idx_t);
+    ws.ord = (idx_t*)base;                       base += (size_t)lcap * sizeof(idx_t);
   }
   ws.hk = (uint32_t*)base;                       base += (size_t)NL * 4;
   ws.first = (idx_t*)base;                       base += (size_t)((NL + 1) & ~1) * sizeof(idx_t);
@@ -439,7 +446,7 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
       const uint64_t* sv = surv + (size_t)rs * scap;
       for (int t = lane; t < npad; t += GM_WAVE) ws.key[t] = (t < n) ? sv[t] : ~0ull;
       k2_sync<BIG>();
-      k2_sort<BIG, uint64_t>(ws.key, npad, lane);
+      k2_sort<BIG, uint64_t, RMAX>(ws.key, npad, lane);
     }
     K2_STAMP(0);
     if (!BIG && ix.n_contigs <= GM_WAVE) {
@@ -489,7 +496,7 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
         ws.key[t] = k;
       }
       k2_sync<BIG>();
-      k2_sort<BIG, uint64_t>(ws.key, hp, lane);
+      k2_sort<BIG, uint64_t, RMAX>(ws.key, hp, lane);
       for (int t = lane; t < nhc; t += GM_WAVE) {
         P[t] = (uint16_t)(ws.key[t] & 0xFFFF);
         if (detect && t > 0 && (ws.key[t] >> 16) == (ws.key[t - 1] >> 16) &&
@@ -505,7 +512,7 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
   K2_STAMP(1);
   if (!BIG) {
     // ---- fast path: order-free collapse + windows in canonical order, with sensitivity detection ----
-    na = k2_collapse_par(ix, *(K2Ws<false>*)&ws, scratch32, n, npad, read_len, lane);
+    na = k2_collapse_par<RMAX>(ix, *(K2Ws<false>*)&ws, scratch32, n, npad, read_len, lane);
     K2_STAMP(2);
     bool sens = false;
     nh = k2_windows<BIG, true>(ix, sc, ws, na, read_len, window_len, H, scratch32, hcap, lane, &sens);
@@ -558,16 +565,27 @@ int gm_launch_anchors(const GmIndexDev& ix, const GmScoreDev& sc, int n_reads, i
   const int max_n_kmers = std::max(0, read_len - ix.min_seed_span + 1);
   const int NL = ix.n_seeds * max_n_kmers;
   if (n_reads == 0) return GM_OK;
-  const size_t lds = k2_lds_bytes(false, scap, NL, read_len);
+  // Where the LDS tier holds 2 048 survivors or more (150-base reads on 3 Gbp keep ~800 per read-strand, a fifth of the read-strands more than 1 024), two launches:
+  // the read-strands of up to 1 024 survivors with LDS arrays of 1 024 (16 KB a wave: nine waves per CU instead of four) and the 1 024-key register sort, then the others
+  // with the full arrays and the 2 048-key register sort (a kernel of its own: 248 registers).
+  const bool split = scap >= 2048 && !(gm_tune("GM_K2_WIDE") && atoi(gm_tune("GM_K2_WIDE")) == 0);
+  const size_t lds = k2_lds_bytes(false, scap, NL, read_len), lds_a = k2_lds_bytes(false, split ? 1024 : scap, NL, read_len);
   if (lds > 64 * 1024) {
     static GmLdsLimit lim_configured; size_t& configured = lim_configured.cur();
     if (lds > 160 * 1024) { gm_set_error("anchor kernel LDS %zu too large", lds); return GM_E_ARG; }
-    if (lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_anchors<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
+    if (lds > configured) {
+      GM_HIP(hipFuncSetAttribute((const void*)k_anchors<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      GM_HIP(hipFuncSetAttribute((const void*)k_anchors<false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
   }
-  hipLaunchKernelGGL(k_anchors<false>, dim3(n_reads * 2), dim3(GM_WAVE), lds, stream, ix, sc, n_reads, read_len, window_len, max_n_kmers, NL,
+  hipLaunchKernelGGL(k_anchors<false>, dim3(n_reads * 2), dim3(GM_WAVE), lds_a, stream, ix, sc, n_reads, read_len, window_len, max_n_kmers, NL,
                      d_surv, d_surv_cnt, scap, 0, (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr,
                      (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                     d_hits, d_perm, d_hit_cnt, hcap, d_stats);
+                     d_hits, d_perm, d_hit_cnt, hcap, d_stats, split ? 1024 : scap, 0);
+  if (split)
+  hipLaunchKernelGGL((k_anchors<false, 32>), dim3(n_reads * 2), dim3(GM_WAVE), lds, stream, ix, sc, n_reads, read_len, window_len, max_n_kmers, NL,
+                     d_surv, d_surv_cnt, scap, 0, (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr,
+                     (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                     d_hits, d_perm, d_hit_cnt, hcap, d_stats, scap, 1024);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }
@@ -592,7 +610,7 @@ int gm_launch_anchors_heavy(const GmIndexDev& ix, const GmScoreDev& sc, int n_re
   const size_t lds = k2_lds_bytes(true, 0, NL, read_len);
   hipLaunchKernelGGL(k_anchors<true>, dim3(n_heavy), dim3(GM_WAVE), lds, stream, ix, sc, n_reads, read_len, window_len, max_n_kmers, NL,
                      (const uint64_t*)nullptr, (const uint32_t*)nullptr, 0, n_heavy, d_heavy_list, d_seg_off, d_seg_n,
-                     d_keys_sorted, d_aux, d_nxt, d_ord, d_hits, d_perm, d_hit_cnt, hcap, d_stats);
+                     d_keys_sorted, d_aux, d_nxt, d_ord, d_hits, d_perm, d_hit_cnt, hcap, d_stats, 0, 0);
   GM_HIP(hipGetLastError());
   GM_HIP(hipStreamSynchronize(stream));
   (void)hipFree(tmp);
