@@ -244,8 +244,11 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
     const double first = entries * std::min(1.0, (late + 0.5 * memb) / (double)(32ull << (lsw - 3)));
     // More than one round (pass B and the exact stages per part of the genome) for long reads, as long as the passes over the lists stay cheaper than the separate
     // kernels: up to four.
+    // (The estimate is generous for long reads -- 12.8 k against 9.2 k counted for 150-base reads on 3 Gbp -- and a round costs 10 % of the kernel: two parts there, 4.6 k
+    // candidates each against 5 456 slots, no read-strand of 262 144 fell back; one that does is redone exactly by the fall-back kernels.)
     if (memb + late + first > 0.85 * cand_cap) {
-      rounds = (int)std::ceil((memb + late + first) / (0.85 * cand_cap));
+      rounds = (int)std::ceil((memb + late + first) / (1.25 * cand_cap));
+      rounds = std::max(rounds, 2);
       if (rounds > K5_MAX_ROUNDS || NL > threads || lsw != 15) return 0;
     }
   }
