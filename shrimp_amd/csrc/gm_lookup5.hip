@@ -225,10 +225,21 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   if (fixed0 + 32 * (size_t)xrec + full_tables > budget && fixed0 + 32 * 16 + full_tables <= budget) xrec = (int)((budget - full_tables - fixed0) / 32);
   const size_t fixed = fixed0 + 32 * (size_t)xrec;
   int lsw = 15;
+  int threads = 1024;                                          // waves per workgroup: a power of two
+  // Colour space with few list entries per read-strand (50-colour reads on 3 Gbp: 17 k): the half-size shape -- tables of 2^19 + 2^16 bits (72 KB) and 512 threads.  The kernel
+  // itself is slower that way (89 against 70 ms per 500 k reads), but it leaves half of a CU's LDS and 320 of a SIMD's 512 registers free, and k_pass2_cs_g4 (256 registers,
+  // 15 KB of LDS a wave), which cannot run beside the full shape at all, then runs beside it: the step 132 -> 125 ms.  (Letter space: k_pass2_g4 fits beside the full shape.)
+  bool small_shape = false; (void)small_shape;
+  if (!forced && ix.colour && NL <= 512 && !gm_tune("GM_K5_LSW") && !gm_tune("GM_K1_THREADS") && !(gm_tune("GM_K5_SMALL") && atoi(gm_tune("GM_K5_SMALL")) == 0)) {
+    const double lam = entries * (double)((1u << ix.region_bits) + ix.region_overlap) / std::max(1.0, (double)ix.total_len);
+    const double memb = 2.0 * entries * std::min(1.0, lam), late = 0.5 * entries * std::min(1.0, entries / (double)(32ull << 14));
+    const double first = entries * std::min(1.0, (late + 0.5 * memb) / (double)(32ull << 11));
+    const double cap14 = (double)(((4u << 14) / 4u / 6u) & ~15u);
+    if (memb + late + first <= 0.5 * cap14 && fixed + (size_t)(4u << 14) + (size_t)(4u << 11) <= 96 * 1024) { small_shape = true; lsw = 14; threads = 512; }
+  }
   if (const char* e = gm_tune("GM_K5_LSW")) lsw = std::max(8, std::min(15, atoi(e)));
   while (lsw >= 8 && fixed + (size_t)(4u << lsw) + (size_t)(4u << (lsw - 3)) > budget) lsw--;
   if (lsw < 8) return 0;
-  int threads = 1024;                                          // waves per workgroup: a power of two
   if (const char* e = gm_tune("GM_K1_THREADS")) { const int v = std::max(64, std::min(1024, atoi(e))); threads = 64; while (threads * 2 <= v) threads *= 2; }
   const int ltw = lsw - 3;                                     // twice[] = an eighth of seen[]
   const int hbits = lsw - 2;                                   // the region table (12 B per slot) takes three quarters of the seen[] area,
@@ -272,6 +283,7 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   static GmLdsLimit lim_configured; size_t& configured = lim_configured.cur();
   if (lds > 48 * 1024 && lds > configured) {
     if (hipFuncSetAttribute((const void*)k_lookup_v5<15>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_lookup_v5<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_lookup_v5_rounds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_lookup_v5<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
     configured = lds;
@@ -301,6 +313,7 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   }
   if (rounds > 1) hipLaunchKernelGGL(k_lookup_v5_rounds, dim3(grid), dim3(threads), lds, stream, ix, a);
   else if (lsw == 15) hipLaunchKernelGGL((k_lookup_v5<15>), dim3(grid), dim3(threads), lds, stream, ix, a);
+  else if (lsw == 14) hipLaunchKernelGGL((k_lookup_v5<14>), dim3(grid), dim3(threads), lds, stream, ix, a);
   else hipLaunchKernelGGL((k_lookup_v5<0>), dim3(grid), dim3(threads), lds, stream, ix, a);
   if (hipGetLastError() != hipSuccess) return GM_E_NODEVICE;
   *fb_list = K.fb; *fb_cnt = fb_cnt_p; *fb_cap_out = fb_cap; if (pl_list) *pl_list = K.pl; if (pl_cnt) *pl_cnt = pl_cnt_p;
