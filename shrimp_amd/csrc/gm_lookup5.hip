@@ -219,11 +219,12 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   // LDS: twice (1/8 of seen) | seen | 32 B per list | codes | control words
   // chunk records beyond one per list: 64, or what is left beside full-size tables when the lists alone nearly fill the rest (150 bp reads: 417 lists)
   const size_t budget = 160 * 1024 - 512;
-  const size_t fixed0 = (size_t)32 * NL + 2 * (size_t)((read_len + 15) & ~15) + C_WORDS * 4 + GM_MAX_SEEDS * 32;              // (one record per list, + the seed table)
+  const size_t fixed0 = (size_t)24 * NL + 2 * (size_t)((read_len + 15) & ~15) + C_WORDS * 4 + GM_MAX_SEEDS * 32;              // (one record per list: 16 + 8 bytes, + the seed table)
   const size_t full_tables = (size_t)(4u << 15) + (size_t)(4u << 12);
-  int xrec = 64;
-  if (fixed0 + 32 * (size_t)xrec + full_tables > budget && fixed0 + 32 * 16 + full_tables <= budget) xrec = (int)((budget - full_tables - fixed0) / 32);
-  const size_t fixed = fixed0 + 32 * (size_t)xrec;
+  // (long reads -- two stripes in the vector filter, 450 B of LDS a wave -- keep the extra records few: what the tables leave of a CU's LDS is what pass 1 runs in beside this kernel)
+  int xrec = read_len > 128 ? 16 : 64;
+  if (fixed0 + 24 * (size_t)xrec + full_tables > budget && fixed0 + 24 * 16 + full_tables <= budget) xrec = (int)((budget - full_tables - fixed0) / 24);
+  const size_t fixed = fixed0 + 24 * (size_t)xrec;
   int lsw = 15;
   int threads = 1024;                                          // waves per workgroup: a power of two
   // Colour space with few list entries per read-strand (50-colour reads on 3 Gbp: 17 k): the half-size shape -- tables of 2^19 + 2^16 bits (72 KB) and 512 threads.  The kernel

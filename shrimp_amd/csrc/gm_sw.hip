@@ -67,6 +67,12 @@ __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen,
   uint32_t v_score = 0;
   const int n_stripes = SINGLE ? 1 : ((rlen + 127) >> 7);
   int16_t* carryH = carry; int16_t* carryB = carry + glen;
+  // The last row of a stripe (H and the travelling gap value T, 16 bits each) for the stripe below: windows of up to 256 columns keep it in four registers -- column c in lane
+  // c & 63 of register c >> 6, written from lane 63's value by a lane-select -- and need no LDS for it (a wave of pass 1 then holds 450 B instead of 1.3 KB at 150 bases, which
+  // decides how many of them fit beside the seed lookup's tables); wider windows use the LDS rows.
+  const bool creg = !SINGLE && glen <= 256;
+  uint32_t cr0 = 0, cr1 = 0, cr2 = 0, cr3 = 0;
+  auto cr_at = [&](const int k) -> uint32_t { return k == 0 ? cr0 : (k == 1 ? cr1 : (k == 2 ? cr2 : cr3)); };
   for (int s = 0; s < n_stripes; s++) {
     const int r0 = s * 128 + 2 * lane;
     const uint32_t q = pk(r0 < rlen ? qr[r0] : SW_QR_SENT, r0 + 1 < rlen ? qr[r0 + 1] : SW_QR_SENT);
@@ -87,7 +93,10 @@ __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen,
         const int c = t + lane;
         dbr = ((c < glen) ? (uint32_t)db[c] : SW_DB_SENT) << 16;
         if (CS && s == 0) db0v = (c < glen) ? (uint32_t)db0[c] : SW_DB_SENT;
-        if (!SINGLE && s > 0) { chv = (c < glen) ? (uint32_t)(uint16_t)carryH[c] : 0u; cbv = (c < glen) ? (uint32_t)(uint16_t)carryB[c] : (uint32_t)(uint16_t)(-sc.b_go - sc.b_ge); }
+        if (!SINGLE && s > 0) {
+          if (creg) { const uint32_t w = cr_at(t >> 6); chv = (c < glen) ? (w & 0xFFFFu) : 0u; cbv = (c < glen) ? (w >> 16) : (uint32_t)(uint16_t)(-sc.b_go - sc.b_ge); }
+          else { chv = (c < glen) ? (uint32_t)(uint16_t)carryH[c] : 0u; cbv = (c < glen) ? (uint32_t)(uint16_t)carryB[c] : (uint32_t)(uint16_t)(-sc.b_go - sc.b_ge); }
+        }
       }
       const int sl = t & 63;
       // lane 0's neighbour (row 128s - 1) comes from the carry arrays / the initial row
@@ -111,7 +120,17 @@ __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen,
       uint32_t h = pk_add(pk_mad_i16(pk_min_u16(Gc ^ q, v_one), v_delta, upH_prev), v_match);
       h = pk_max(pk_max(h, 0u), pk_max(a, b));
       v_score = pk_max(v_score, h);
-      if (more && lane == 63) {                // row 128s+127 feeds the next stripe
+      if (more && creg) {                      // row 128s+127 feeds the next stripe: lane 63's upper halves, into lane c & 63 of register c >> 6
+        const int c = t - 127;
+        if (c >= 0 && c < glen) {
+          const uint32_t tn = pk_max(pk_sub(b, v_b_ext), pk_sub(h, v_b_oe));
+          const uint32_t w = ((uint32_t)__builtin_amdgcn_readlane((int)h, 63) >> 16) | ((uint32_t)__builtin_amdgcn_readlane((int)tn, 63) & 0xFFFF0000u);
+          const int k = c >> 6, ln = c & 63;
+          const bool me = lane == ln;
+          if (k == 0) cr0 = me ? w : cr0; else if (k == 1) cr1 = me ? w : cr1; else if (k == 2) cr2 = me ? w : cr2; else cr3 = me ? w : cr3;
+        }
+      } else
+      if (more && lane == 63) {                // ... wider windows: the LDS rows
         const int c = t - 127;
         if (c >= 0 && c < glen) { carryH[c] = (int16_t)(h >> 16); carryB[c] = (int16_t)(pk_max(pk_sub(b, v_b_ext), pk_sub(h, v_b_oe)) >> 16); }
       }
@@ -123,7 +142,7 @@ __device__ int sw_vector_wave_s(const uint8_t* db, const uint8_t* db0, int glen,
     auto carry_top = [&](const int limit) -> int {
       const int rows_left = rlen - (s + 1) * 128;
       int top = sc.match * min(rows_left, glen);
-      for (int c = lane; c < limit; c += GM_WAVE) top = max(top, (int)carryH[c] + sc.match * min(rows_left, glen - 1 - c));
+      for (int c = lane; c < limit; c += GM_WAVE) top = max(top, (creg ? (int)(int16_t)(cr_at(c >> 6) & 0xFFFFu) : (int)carryH[c]) + sc.match * min(rows_left, glen - 1 - c));
       for (int d = 32; d > 0; d >>= 1) top = max(top, __shfl_xor(top, d));
       return top;
     };
@@ -351,7 +370,7 @@ __device__ int sw_gapless_cs_wave(const GmIndexDev& ix, int cn, bool rc, const u
 }
 
 template <bool CS>
-__global__ void __launch_bounds__(GM_WAVE)
+__global__ void __launch_bounds__(GM_WAVE) __attribute__((amdgpu_waves_per_eu(8, 8)))      // 64 registers: two of these waves per SIMD fit beside the seed lookup's four (4 x 96 of 512)
 k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words,
         int window_len, int overlap_abs, GmHit* __restrict__ hits, const uint16_t* __restrict__ perm,
         const uint32_t* __restrict__ hit_cnt, int hcap, unsigned long long* __restrict__ slots, unsigned long long* __restrict__ stats,
@@ -1181,7 +1200,7 @@ int gm_launch_pass1(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
   if (n_reads == 0) return GM_OK;
   // The carry rows of the vector filter exist only for reads of more than 128 bases (two stripes): without them a wave's LDS is 320 B at 100 bp instead of 880 B,
   // and LDS is what bounds the filter's waves beside the seed lookup (k_lookup_v5 leaves ~5 KB of a CU's 160 KB: 5 waves at 1 KB each, 10 at 512 B).
-  const size_t carry_bytes = read_len > 128 ? (size_t)window_len * 4 : 0;
+  const size_t carry_bytes = (read_len > 128 && window_len > 256) ? (size_t)window_len * 4 : 0;      // (windows of up to 256 columns carry the stripe's last row in registers)
   // the early stop of a window that cannot reach the threshold (sw_vector_wave_s): only where a score below the threshold is never read again (unpaired
   // reads: the caller says so), with a scoring scheme in which a cell gains at most `match` and a gap never gains, and within the 16-bit range of the test
   const int early = (early_stop && !d_pair_min && !sc.gapless && sc.match > 0 && sc.mismatch <= sc.match && sc.a_go >= 0 && sc.a_ge >= 0 && sc.b_go >= 0 && sc.b_ge >= 0 &&
