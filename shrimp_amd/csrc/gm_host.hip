@@ -996,7 +996,7 @@ struct Finalizer {
         if (!rev) { for (int i = 0; i < na; i++) if (h->qr[i] != '-') *p++ = up(h->qr[i]); }
         else for (int i = na - 1; i >= 0; i--) if (h->qr[i] != '-') *p++ = rc_char(up(h->qr[i]));
         *p++ = '\t';
-        if (qual_ptr) {                                                             // post_sw's base qualities, ref: output.c:613-621
+        if (qual_ptr && !h->qual.empty()) {                                         // post_sw's base qualities, ref: output.c:613-621 (none in local mode: no post_sw there)
           const int nq = (int)h->qual.size();
           if (!rev) p = put_str(p, h->qual.data(), (size_t)nq); else for (int i = nq - 1; i >= 0; i--) *p++ = h->qual[i];
         } else *p++ = '*';

@@ -1692,12 +1692,13 @@ k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__
 // ---------------------------------------------------------------------------------------------
 // LOCAL (Gflag off, ref: sw-full-cs.c:199-203,315,439-552): a cell outside the band holds (0, -b_open, -a_open) -- plus the crossover score in layers 1-3 -- like the
 // virtual row above the matrix; a state at or below 0 (layer 0) / the crossover score (layers 1-3) takes that value with a null back pointer; the result is the
-// first cell in row-major order with the largest score.  (Local mode takes the global crossover score everywhere: not combined with per-position scores.)
+// first cell in row-major order with the largest score.  (With per-position crossover scores an out-of-band cell carries the score of its own row, as the reference's init_cell leaves it: sw-full-cs.c:312-322.)
 template <bool REV, bool TABOO, bool LOCAL>
 __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4, int qstride, int rlen, const GmCsDev& P, bool act,
                                 int rx, int ry, int rl, int rw, uint32_t* back, int* carry, int lane, const int8_t* xrow) {
   constexpr bool revcmpl = REV;
-  auto OB = [&](const int x) -> int { const int k = x / 3, st = x % 3; return LOCAL ? (st == 0 ? 0 : (st == 1 ? -P.b_go : -P.a_go)) + (k ? P.xover : 0) : FS_NEG; };   // a cell outside the band
+  // a cell outside the band: what the reference's init_cell leaves there -- in local mode with the crossover score of the cell's ROW (per-position scores from quality values, ref: sw-full-cs.c:312-322)
+  auto OBx = [&](const int x, const int xv) -> int { const int k = x / 3, st = x % 3; return LOCAL ? (st == 0 ? 0 : (st == 1 ? -P.b_go : -P.a_go)) + (k ? xv : 0) : FS_NEG; };
   CsBest best; best.score = 0; best.i = best.j = best.k = 0; best.e_nw = best.e_n = best.e_w = 0;
   const int l = lane & 15;
   const int xg = P.xover;
@@ -1708,6 +1709,8 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
     const int r = s * 16 + l;
     const bool row_ok = act && r < rlen;
     if (xrow) xo = row_ok ? (int)xrow[r] : xg;           // ref: sw-full-cs.c:312
+    const int xo_up = (xrow && act && r >= 1 && r - 1 < rlen) ? (int)xrow[r - 1] : xg;      // the row above's
+    auto OB = [&](const int x) -> int { return OBx(x, xo); };
     int q[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) q[k] = row_ok ? qr4[k * qstride + r] : 0x7F;
@@ -1722,10 +1725,10 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
     nmax = __builtin_amdgcn_readfirstlane(nmax);
     int d[12], cur[12], inv[12];        // (cur: this lane's cell of the step before = the west neighbour of the next one)
 #pragma unroll
-    for (int x = 0; x < 12; x++) { d[x] = OB(x); cur[x] = OB(x); }
+    for (int x = 0; x < 12; x++) { d[x] = OBx(x, xo_up); cur[x] = OB(x); }
     // lane 0's upper neighbour: the virtual row (stripe 0: constants), or the previous stripe's last row (read one step ahead below)
 #pragma unroll
-    for (int x = 0; x < 12; x++) { const int k = x / 3, st = x % 3; const int xv = k ? xg : 0; inv[x] = s == 0 ? (st == 0 ? 0 : (st == 1 ? -P.b_go : -P.a_go)) + xv : OB(x); }
+    for (int x = 0; x < 12; x++) { const int k = x / 3, st = x % 3; const int xv = k ? xg : 0; inv[x] = s == 0 ? (st == 0 ? 0 : (st == 1 ? -P.b_go : -P.a_go)) + xv : OBx(x, xo_up); }
     if (l == 0) {
       if (s == 0) {                                  // virtual row -1: init_cell(.., 1, xover), ref :201-215
 #pragma unroll
@@ -1753,7 +1756,7 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
       for (int x = 0; x < 12; x++) u[x] = g4_shr1(cur[x], inv[x]);   // cell (r-1, c)
       if (s > 0) {                                   // next step's carry values for the group's first lane
 #pragma unroll
-        for (int x = 0; x < 12; x++) inv[x] = OB(x);
+        for (int x = 0; x < 12; x++) inv[x] = OBx(x, xo_up);
         if (l == 0 && i + 1 < nst && t + 1 >= cw_lo && t + 1 <= cw_hi) {
 #pragma unroll
           for (int x = 0; x < 12; x++) inv[x] = carry[x * glen + t + 1];
@@ -2101,7 +2104,6 @@ int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs
   // four windows per wave (k_pass2_cs_g4) unless GM_P2_G4=0 asks for the one-window kernel; a wave owns four consecutive back-pointer scratches.
   // Local alignment (sc.local, ref: sw-full-cs.c:199-203,439-552) exists in the four-window kernel only.
   const bool want_g4 = !(gm_tune("GM_P2_G4") && atoi(gm_tune("GM_P2_G4")) == 0) && grid >= 4;
-  if (sc.local && d_xover) { gm_set_error("colour space: local alignment is not combined with per-position crossover scores (reads with quality values)"); return GM_E_ARG; }
   if (want_g4 || sc.local) {
     const size_t q16 = (size_t)((read_len + 15) & ~15), lds4 = 20 * q16 + 4 * (size_t)((window_len + 15) & ~15) + 4 * (size_t)window_len * 48 + 64;
     if (lds4 <= 160 * 1024 && grid >= 4) {

@@ -690,6 +690,21 @@ def test_fastq_quals_match_reference_golden(gm, tag):
     assert got == sam, _first_diff(got, sam)
 
 
+def test_colour_space_fastq_local_matches_reference_golden(gm):
+    """csfastq with --local: per-position crossover scores in the local mode of sw_full_cs (out-of-band cells carry their ROW's crossover score, ref: sw-full-cs.c:312-322),
+    no post_sw, QUAL '*', CQ:Z -- byte-identical to gmapper-cs --local on the csfastq file"""
+    import gzip
+    from tests.test_oracle import _cs_fastq_case
+    contigs, reads, quals, delta, _ = _cs_fastq_case()
+    with gzip.open(os.path.join(oa.ROOT, "tests", "golden", "cfg4s_50col_fq@cs_fq_local.sam.gz"), "rb") as f: want = f.read()
+    p = gm.default_params_cs(); p.sam_unaligned = 1; p.local_alignment = 1
+    ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p, max_batch_reads=512)
+    got = oa.sam_header(contigs) + s.map_reads_cs_fastq(reads, quals, delta)
+    st = s.stats
+    s.close(); ix.close()
+    assert got == want, (_first_diff(got, want), st)
+
+
 def test_colour_space_fastq_matches_reference_golden(gm, monkeypatch):
     """gm_map_reads_cs_fastq: per-position crossover scores on the device, post_sw with per-colour error rates, QUAL from post_sw,
     CQ:Z -- byte-identical to gmapper-cs on a csfastq file.  post_sw runs on the device for these reads too (round 3: error rates from the host's table,

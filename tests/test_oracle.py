@@ -1,6 +1,7 @@
 """The CPU restatement (oracle/) against the reference's own outputs (tests/golden/*, generated
 by tools/make_golden.py from the reference binary built from /root/reference)."""
 import ctypes as C
+import os
 import numpy as np
 import pytest
 from tests import oracle_api as oa
@@ -211,6 +212,17 @@ def test_oracle_colour_space_fastq_matches_reference(oracle_lib):
     got = oa.sam_header(contigs) + s.map_sam_q(reads, quals, delta, nthreads=4)
     s.close()
     assert got == sam
+
+
+def test_oracle_colour_space_fastq_local_matches_reference(oracle_lib):
+    """csfastq with --local: per-position crossover scores in sw_full_cs's local mode (the left-of-band cell of a row takes the row's score, ref: sw-full-cs.c:312-322), no post_sw"""
+    import gzip
+    contigs, reads, quals, delta, _ = _cs_fastq_case()
+    with gzip.open(os.path.join(oa.ROOT, "tests", "golden", "cfg4s_50col_fq@cs_fq_local.sam.gz"), "rb") as f: want = f.read()
+    s = oa.Session(contigs, opts="colour=1;local=1"); s.set(True, True)
+    got = oa.sam_header(contigs) + s.map_sam_q(reads, quals, delta, nthreads=4)
+    s.close()
+    assert got == want
 
 
 def test_oracle_sw_full_ls_local_known_answers(oracle_lib):

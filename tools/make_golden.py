@@ -417,9 +417,13 @@ def cs_fastq_cases():
         if p.returncode != 0:
             print(p.stderr.decode()[-2000:]); raise SystemExit(1)
         body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+        pl = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "gmapper-cs"), "-N", "4", "--sam-unaligned", "--local", r, g], capture_output=True, check=True)      # the same reads with --local
+        body_l = b"".join(l + b"\n" for l in pl.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
     np.savez_compressed(os.path.join(OUT, "cfg4s_50col_fq.npz"), quals=q, n_reads=np.array(len(reads)), qual_delta=np.array(33))
     with gzip.open(os.path.join(OUT, "cfg4s_50col_fq.sam.gz"), "wb", compresslevel=9) as f:
         f.write(body)
+    with gzip.open(os.path.join(OUT, "cfg4s_50col_fq@cs_fq_local.sam.gz"), "wb", compresslevel=9) as f:
+        f.write(body_l)
     print("cfg4s_50col_fq: %d SAM records" % sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@")))
 
 
