@@ -1145,6 +1145,24 @@ def test_colour_space_fastq_pairs_match_reference_golden(gm, mode):
     assert got == want, (_first_diff(got, want), st)
 
 
+@pytest.mark.parametrize("mode", ["opp-in", "col-bw"])
+def test_colour_space_fastq_pairs_local_match_reference_golden(gm, mode):
+    """csfastq pairs with --local: per-position crossover scores in sw_full_cs's local mode for both mates, no post_sw (QUAL '*'), CQ:Z -- gmapper-cs -p <mode> --local on the csfastq
+    file of the test above"""
+    import gzip
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    g = oa.load_golden_pairs("cs_pairs_50col_" + mode); zq = np.load(os.path.join(G, "cs_pairs_fq_%s.npz" % mode)); N = int(zq["n_pairs"])
+    want = gzip.open(os.path.join(G, "cs_pairs_fq_%s@cs_pairs_fq_local.sam.gz" % mode), "rb").read()
+    p = gm.default_params_cs(); p.sam_unaligned = 1; p.local_alignment = 1
+    ix = gm.Index(g["contigs"], names=g["contig_names"], params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_cs(g["m1"][:N], g["m2"][:N], list(g["names1"][:N]), list(g["names2"][:N]), mode=mode,
+                                                                          min_insert=g["ins"][0], max_insert=g["ins"][1], quals1=zq["quals1"], quals2=zq["quals2"],
+                                                                          qual_delta=int(zq["qual_delta"]))
+    st = s.stats
+    s.close(); ix.close()
+    assert got == want, (_first_diff(got, want), st)
+
+
 @pytest.mark.parametrize("case", ["two_fastq_gz", "interleaved_fasta"])
 def test_pair_files_match_reference_golden(gm, case, tmp_path):
     """gm_map_pairs_file: `gmapper -1 a.fq.gz -2 b.fq.gz` (PHRED+33, mates cut to a mix of lengths) and one FASTA file with the mates adjacent -- the files the

@@ -626,6 +626,12 @@ def cs_paired_fastq_cases():
             if p.returncode != 0:
                 print(p.stderr.decode()[-1500:]); raise SystemExit(1)
             body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+            pl = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "gmapper-cs"), "-N", "4", "--sam-unaligned", "--local", "-p", mode, "-I", "%d,%d" % tuple(int(x) for x in z["ins"]), r, g],
+                                capture_output=True)
+            if pl.returncode != 0:
+                print(pl.stderr.decode()[-1500:]); raise SystemExit(1)
+            with gzip.open(os.path.join(OUT, "cs_pairs_fq_%s@cs_pairs_fq_local.sam.gz" % mode), "wb", compresslevel=9) as f:      # the same pairs with --local
+                f.write(b"".join(l + b"\n" for l in pl.stdout.split(b"\n") if l and not l.startswith(b"@PG")))
         np.savez_compressed(os.path.join(OUT, "cs_pairs_fq_%s.npz" % mode), quals1=q1, quals2=q2, n_pairs=np.array(N), qual_delta=np.array(33))
         with gzip.open(os.path.join(OUT, "cs_pairs_fq_%s.sam.gz" % mode), "wb", compresslevel=9) as f:
             f.write(body)
