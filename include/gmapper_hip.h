@@ -67,7 +67,7 @@ typedef struct gm_params {
   double pr_xover;                             /* ref: gmapper.h:119  0.03: fixes score_alpha in colour space (gmapper.c:2557-2563) */
   int local_alignment;                         /* --local, i.e. Gflag off (ref: gmapper.c:2303-2305): sw_full_ls in local mode (soft clips); mapping qualities
                                                   are then unavailable (gmapper.c:2325-2328): MAPQ 255, no Z0-Z6 tags.  Letter space and colour space, unpaired and paired (sw_full_cs with
-                                                  local_alignment, ref: sw-full-cs.c:199-203,315,439-552; no post_sw then, mapping.c:1648; with csfastq quality values for unpaired reads, not for pairs).  0 */
+                                                  local_alignment, ref: sw-full-cs.c:199-203,315,439-552; no post_sw then, mapping.c:1648; with csfastq quality values too, unpaired and paired).  0 */
   int ungapped;                                /* -U (gapless_sw): pass 1 scores windows with sw_gapless (ref: sw-gapless.c:57-117), every anchor opens a window
                                                   (mapping.c:1095,1154).  As the reference's -U does, also set anchor_width 0, both gap opens -255 and
                                                   hash_filter_calls 0; requires local_alignment (gmapper.c:2330-2333).  In colour space sw_gapless runs on the contig's colour translation with the
