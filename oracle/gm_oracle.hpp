@@ -1261,7 +1261,7 @@ struct Mapper {
   void read_get_anchor_list(const ThreadState& T, Read& re, int st) const {
     int ns = (int)P.seeds.size();
     // unpaired: use_region_counts = (match_mode == 2) (gmapper.c:2615); paired default (mode 4, half-paired): true, no mp counts (:2652-2660)
-    bool use_region_counts = re.paired ? true : (P.match_mode == 2);
+    bool use_region_counts = re.paired ? (P.mp_match_mode != 2) : (P.match_mode == 2);    // paired -n 2: no region counts at all (gmapper.c:2652-2657)
     const int nip = (re.first_in_pair || !re.paired) ? 0 : 1;
     const int mp_mode = re.paired ? mp_region_mode() : 0;
     re.anchors[st].clear();
@@ -1301,7 +1301,12 @@ struct Mapper {
   }
 
   // read_get_hit_list_per_strand (mapping.c:1025-1229), gapless = false, match_mode 1 or 2
-  void read_get_hit_list(Read& re, int st) const {
+  // hit_list.match_mode: unpaired 1 / 2 (gmapper.c:2619); paired: -n 4 -> 2, -n 3 -> 3, -n 2 -> 1 (gmapper.c:2666-2668)
+  int hit_match_mode(const Read& re) const { return !re.paired ? P.match_mode : (P.mp_match_mode == 3 ? 3 : (P.mp_match_mode == 2 ? 1 : 2)); }
+  // pass1.min_matches of the paired option set (gmapper.c:2673): 2 for -n 4, else 1; the unpaired sets (also the half-paired rescue, :2708) keep match_mode / 2
+  int pair_min_matches() const { return (P.mp_match_mode == 3 || P.mp_match_mode == 2) ? 1 : 2; }
+  void read_get_hit_list(Read& re, int st, const ThreadState* T = nullptr) const {
+    const int hmode = hit_match_mode(re);
     std::vector<Anchor>& A = re.anchors[st];
     std::vector<Hit>& H = re.hits[st];
     H.clear();
@@ -1315,7 +1320,14 @@ struct Mapper {
       llint gstart = (gend >= re.window_len) ? gend - re.window_len : 0;
       int max_idx = i;
       int max_score = A[i].length * P.match_score;
-      if (!P.gapless && P.match_mode == 2 && A[i].weight == 1) max_score = -1;
+      bool heavy_mp = false;
+      if (hmode == 3) {                                            // mapping.c:1080-1093: the mate has a region marked twice within reach of this anchor's region
+        const uint16_t* rm = T->region_map[re.first_in_pair ? 0 : 1][st].data();
+        int region = (int)(A[i].x >> P.region_bits);
+        heavy_mp = ((rm[region] >> 1) & 0x3) >= 2;
+        if (!heavy_mp && region > 0 && (A[i].x & ((1u << P.region_bits) - 1)) < (uint32_t)P.region_overlap) heavy_mp = ((rm[region - 1] >> 1) & 0x3) >= 2;
+      }
+      if (!P.gapless && (hmode == 2 || (hmode == 3 && !heavy_mp)) && A[i].weight == 1) max_score = -1;
       for (int j = i - 1; !P.gapless && j >= 0 && A[j].x >= (llint)G->offsets[cn] + gstart; j--) {   // gapless: only the anchor itself (mapping.c:1095)
         if (A[j].y >= A[i].y) continue;
         int short_len, long_len;
@@ -1329,7 +1341,7 @@ struct Mapper {
         else tmp_score = short_len * P.match_score;
         if (tmp_score > max_score) { max_idx = j; max_score = tmp_score; }
       }
-      if (P.gapless || P.match_mode == 1 ||
+      if (P.gapless || hmode == 1 || (hmode == 3 && heavy_mp) ||                                  // mapping.c:1153-1157
           max_score >= (int)GMO_ABS_OR_PCT(P.window_gen_threshold, (re.read_len < w_len ? re.read_len : w_len) * P.match_score)) {
         int x_len = (int)(A[i].x - A[max_idx].x) + A[i].length;
         llint goff;
@@ -1377,12 +1389,13 @@ struct Mapper {
   }
 
   // read_pass1_per_strand (mapping.c:1261-1339), letter space, only_paired = false
-  void read_pass1(ThreadState& T, Read& re, int st, bool only_paired = false) const {
+  void read_pass1(ThreadState& T, Read& re, int st, bool only_paired = false, int min_matches = -1) const {
+    if (min_matches < 0) min_matches = P.match_mode;
     int last_good_cn = -1; unsigned int last_good_g_off = 0;
     T.f1_hash_tag++;
     for (auto& h : re.hits[st]) {
       if (only_paired && h.pair_min < 0) continue;                 // mapping.c:1271-1273
-      if (h.matches < P.match_mode) continue;  // pass1.min_matches = match_mode (gmapper.c:2625)
+      if (h.matches < min_matches) continue;   // pass1.min_matches = match_mode (gmapper.c:2625); paired: gmapper.c:2673
       if (h.saved == 1) { last_good_cn = h.cn; last_good_g_off = (unsigned int)h.g_off_pos_strand; continue; }
       if (last_good_cn >= 0 && h.cn == last_good_cn &&
           h.g_off_pos_strand + (unsigned int)GMO_ABS_OR_PCT(P.window_overlap, re.window_len) <= (llint)(unsigned int)(last_good_g_off + re.window_len)) {
@@ -1890,7 +1903,7 @@ struct Mapper {
   // handle_read as the half-paired fall-back (unpaired_mapping_options[nip][0], gmapper.c:2700-2714):
   // regions / anchors / windows are reused, pass 1 re-runs over all windows, results are saved, not printed
   void handle_read_half(ThreadState& T, Read& re) const {
-    read_pass1(T, re, 0, false); read_pass1(T, re, 1, false);
+    read_pass1(T, re, 0, false, 2); read_pass1(T, re, 1, false, 2);                  // unpaired_mapping_options[..][0].pass1.min_matches = 2 (gmapper.c:2708)
     std::vector<Hit*> p1, p2; int n1 = 0;
     read_get_vector_hits(re, p1, n1);
     read_pass2(T, re, p1, n1, p2);
@@ -2129,21 +2142,23 @@ struct Mapper {
     PairEntry pe; pe.re[0] = &re1; pe.re[1] = &re2;
     read_get_mapidxs(re1); read_get_mapidxs(re2);
     readpair_compute_mp_ranges(re1, re2);
+    if (P.mp_match_mode != 2) {                                              // regions.recompute = use_regions && match_mode != 2 (gmapper.c:2652)
     T.region_map_id++; T.region_map_id &= ((1 << region_map_id_bits) - 1);
     read_get_region_counts(T, re1, 0); read_get_region_counts(T, re1, 1);
     read_get_region_counts(T, re2, 0); read_get_region_counts(T, re2, 1);
+    }
     if (mp_region_mode()) { read_get_mp_region_counts(T, re1, 0); read_get_mp_region_counts(T, re1, 1); read_get_mp_region_counts(T, re2, 0); read_get_mp_region_counts(T, re2, 1); }   // mapping.c:2531-2538
     read_get_anchor_list(T, re1, 0); read_get_anchor_list(T, re1, 1);
     read_get_anchor_list(T, re2, 0); read_get_anchor_list(T, re2, 1);
     for (Read* re : {&re1, &re2}) {
-      read_get_hit_list(*re, 0); read_get_hit_list(*re, 1);
+      read_get_hit_list(*re, 0, &T); read_get_hit_list(*re, 1, &T);
       for (size_t i = 0; i < re->hits[0].size(); i++) re->hits[0][i].sort_idx = (int)i;
       for (size_t i = 0; i < re->hits[1].size(); i++) re->hits[1][i].sort_idx = (int)(re->hits[0].size() + i);
     }
     for (Read* re : {&re1, &re2}) for (int st = 0; st < 2; st++) { T.stats.pair_anchors += re->anchors[st].size(); T.stats.pair_windows += re->hits[st].size(); }
     readpair_pair_up_hits(re1, re2);
-    read_pass1(T, re1, 0, true); read_pass1(T, re1, 1, true);
-    read_pass1(T, re2, 0, true); read_pass1(T, re2, 1, true);
+    read_pass1(T, re1, 0, true, pair_min_matches()); read_pass1(T, re1, 1, true, pair_min_matches());
+    read_pass1(T, re2, 0, true, pair_min_matches()); read_pass1(T, re2, 1, true, pair_min_matches());
     std::vector<HitPair> p1, p2; int n1 = 0;
     readpair_get_vector_hits(re1, re2, p1, n1);
     readpair_pass2(T, re1, re2, p1, n1, p2);

@@ -212,6 +212,8 @@ OPTION_CASES = {
     "ungapped60_n1": ("stress_60bp", "local=1;ungapped=1;cmw-mode=1;full-threshold=45;vec-threshold=45",
                       dict(local_alignment=1, ungapped=1, anchor_width=0, a_gap_open_score=-255, b_gap_open_score=-255, hash_filter_calls=0, match_mode=1,
                            sw_full_threshold=45.0, sw_vect_threshold=45.0), None),
+    # -n 1: use_region_counts off -- all list entries are anchors, a window per anchor, one k-mer match is enough (gmapper.c:2610-2625)
+    "n1": ("stress_60bp", "cmw-mode=1", dict(match_mode=1), None),
     # -H: hashed seeds (4^12 lists per seed, any weight)
     "hashed": ("stress_60bp", "hash-spaced-kmers=1", dict(hash_seeds=1), None),
     "hashed_w16": ("cfg2s_100bp_2Mbp", "hash-spaced-kmers=1;seeds=11111111101111111,1111110111011101111,111101110010000101111011", dict(hash_seeds=1),
@@ -222,6 +224,18 @@ OPTION_CASES = {
                                                                         hash_filter_calls=0), None),
 }
 
+
+# paired match modes (tools/make_golden.py OPTION_CASES pairs_n3 ... cfg5_n2): tag -> (base pair golden, oracle option string, gm_pair_opts_t fields)
+#   -n 3: a region marked once counts when the mate has hits within reach (use_mp_region_counts 2; 3 with --no-half-paired), hit list mode 3 (mapping.c:733-742,1080-1093,1153-1157)
+#   -n 2: no region counts at all, a window per anchor (gmapper.c:2652-2673)
+PAIR_MODE_CASES = {
+    "pairs_n3": ("stress_pairs_2x100", "mp-match-mode=3", dict(match_mode=3)),
+    "pairs_n3_nhp": ("stress_pairs_2x100", "mp-match-mode=3;half-paired=0", dict(match_mode=3, half_paired=0)),
+    "cfg5_n3": ("cfg5s_2x150_1Mbp", "mp-match-mode=3", dict(match_mode=3)),
+    "cfg5_n3_nhp": ("cfg5s_2x150_1Mbp", "mp-match-mode=3;half-paired=0", dict(match_mode=3, half_paired=0)),
+    "pairs_n2": ("stress_pairs_2x100", "mp-match-mode=2", dict(match_mode=2)),
+    "cfg5_n2": ("cfg5s_2x150_1Mbp", "mp-match-mode=2", dict(match_mode=2)),
+}
 
 # colour-space option sets (tools/make_golden.py CS_OPTION_CASES: gmapper-cs with these options on a committed colour-space golden's inputs):
 # tag -> (base golden, oracle option string, product gm_params_t fields, sam_unaligned)

@@ -286,6 +286,26 @@ def test_option_sets_match_reference_golden(gm, tag):
     assert got == want, (_first_diff(got, want), st)
 
 
+def test_n1_on_noisy_reads_matches_reference_golden(gm):
+    """match_mode 1 (-n 1) where it matters: 70-base reads with 9 % substitutions, 57 of which map only because ONE k-mer match is enough -- the lookup kernel keeps
+    every list entry (no region counts, gmapper.c:2610-2616), a window per anchor, pass 1 with min_matches 1"""
+    contigs, reads, want = oa.load_golden("n1_noisy_70bp")
+    p = gm.default_params(); p.match_mode = 1
+    ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+    got = oa.sam_header(contigs) + s.map_reads(reads)
+    st = s.stats
+    s.close(); ix.close()
+    assert got == want, (_first_diff(got, want), st)
+    # reads built to have ONE list entry each: a region marked once must still give an anchor (390 of 400 map in the reference with -n 1 -h 30%, none without -n 1)
+    contigs, reads, want = oa.load_golden("n1_onehit_60bp")
+    p = gm.default_params(); p.match_mode = 1; p.sw_full_threshold = 30.0; p.sw_vect_threshold = 30.0
+    ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+    got = oa.sam_header(contigs) + s.map_reads(reads)
+    st = s.stats
+    s.close(); ix.close()
+    assert got == want, (_first_diff(got, want), st)
+
+
 def _idxfix(which="idxfix"):
     import gzip, os
     d = os.path.join(oa.ROOT, "tests", "golden", which)

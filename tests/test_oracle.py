@@ -102,6 +102,25 @@ def test_oracle_option_sets_match_reference(tag, oracle_lib):
     assert got == want, "oracle SAM differs from the reference for option set %s" % tag
 
 
+def test_oracle_n1_on_noisy_reads_matches_reference(oracle_lib):
+    """-n 1 where it matters: 70-base reads with 9 % substitutions, 57 of which map only because ONE k-mer match is enough (no region counts, a window per
+    anchor, gmapper.c:2610-2625)"""
+    contigs, reads, want = oa.load_golden("n1_noisy_70bp")
+    s = oa.Session(contigs, opts="cmw-mode=1")
+    got = oa.sam_header(contigs) + s.map_sam(reads, nthreads=4)
+    s2 = oa.Session(contigs)
+    dflt = s2.map_sam(reads, nthreads=4)
+    s.close(); s2.close()
+    assert got == want
+    assert dflt.count(b"\n") < got.count(b"\n") - 50          # the default mode loses them: the case does tell the two apart
+    # reads built to have ONE list entry each (a 14-base block intact, substitutions around it): regions marked once must still give anchors
+    contigs, reads, want = oa.load_golden("n1_onehit_60bp")
+    s = oa.Session(contigs, opts="cmw-mode=1;full-threshold=30;vec-threshold=30")
+    got = oa.sam_header(contigs) + s.map_sam(reads, nthreads=4)
+    s.close()
+    assert got == want and got.count(b"\n") > 380
+
+
 def test_oracle_colour_space_kernels_match_reference_known_answers(oracle_lib):
     """S1/S2 in colour space: the restated sw_vector (first-colour row) and sw_full_cs (4 layers, crossovers, traceback,
     alignment strings) against the reference's own functions on 700 random cases x 2 tie-break directions"""
@@ -256,6 +275,19 @@ def test_oracle_paired_fastq_matches_reference(oracle_lib):
     got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_sam_q(g["m1"], g["m2"], q1, q2, delta, g["names1"], g["names2"], nthreads=4)
     s.close()
     assert got == sam
+
+
+@pytest.mark.parametrize("tag", sorted(oa.PAIR_MODE_CASES))
+def test_oracle_paired_match_modes_match_reference(oracle_lib, tag):
+    """-n 3 and -n 2 in paired mode (with and without --no-half-paired) against gmapper -p <mode> -n 3 / -n 2 on committed pairs; each differs from the
+    default mode's output on the same pairs"""
+    base, opts, _ = oa.PAIR_MODE_CASES[tag]
+    g = oa.load_golden_pairs(base); want = oa.load_option_sam(base, tag)
+    s = oa.Session(g["contigs"], g["contig_names"], opts=opts); s.set_pairing(g["mode"], *g["ins"])
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_sam(g["m1"], g["m2"], g["names1"], g["names2"], nthreads=4)
+    s.close()
+    assert got == want
+    assert want != g["sam"]
 
 
 NO_HALF_PAIRED = [("stress_pairs_2x100", "no_half_paired"), ("cfg5s_2x150_1Mbp", "cfg5_no_half_paired")]

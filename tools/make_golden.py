@@ -76,6 +76,25 @@ def run_case(name, contigs, reads, extra=()):
     print(f"{name}: {len(reads)} reads -> {n_map} SAM records")
 
 
+def n1_noisy_case():
+    """-n 1 on noisy reads (9 % substitutions): reads whose only evidence is ONE k-mer match still map -- no region counts, a window per anchor (gmapper.c:2610-2625)"""
+    contigs = synth.make_genome([400000, 250000], 77)
+    reads, _ = synth.make_reads(contigs, 4000, 70, 78, p_sub=0.09, p_ins=0.004, p_del=0.004)
+    run_case("n1_noisy_70bp", contigs, reads, extra=("-n", "1"))
+    # reads built to have exactly ONE list entry: a 14-base block (one placement of the span-14 default seed) left intact, a substitution next to it on either side
+    # and every 4th base from there on; -h 30% lets their alignments through.  390 of 400 map with -n 1, none without it.
+    rng = np.random.default_rng(5); L = 60
+    one = np.empty((400, L), dtype=np.uint8)
+    for i in range(len(one)):
+        c = contigs[rng.integers(0, len(contigs))]
+        p = int(rng.integers(0, len(c) - L)); r = c[p:p + L].copy()
+        b = int(rng.integers(0, L - 14 + 1))
+        for j in list(range(b - 1, -1, -4)) + list(range(b + 14, L, 4)): r[j] = (r[j] + 1 + rng.integers(0, 3)) & 3
+        if rng.random() < 0.5: r = (3 - r[::-1]).astype(np.uint8)
+        one[i] = r
+    run_case("n1_onehit_60bp", contigs, one, extra=("-n", "1", "-h", "30%"))
+
+
 def read_fa(path):
     names, seqs = [], []
     for line in open(path, "rb"):
@@ -150,6 +169,8 @@ OPTION_CASES = {
     "local_cfg2": ("cfg2s_100bp_2Mbp", ["--local"]),
     "ungapped":  ("stress_100bp_unal", ["--local", "-U", "--sam-unaligned"]),
     "ungapped60_n1": ("stress_60bp", ["--local", "-U", "-n", "1", "-h", "45%"]),
+    # -n 1 on its own: no region counts at all, every list entry becomes an anchor and every anchor a window (gmapper.c:2610-2624)
+    "n1":        ("stress_60bp", ["-n", "1"]),
     "hashed":    ("stress_60bp", ["-H"]),
     "hashed_w16": ("cfg2s_100bp_2Mbp", ["-H", "-s", "11111111101111111,1111110111011101111,111101110010000101111011"]),
     "pairs_hashed": ("stress_pairs_2x100", ["-H", "-o", "3"]),
@@ -158,6 +179,14 @@ OPTION_CASES = {
     # --no-half-paired: mate-pair region counts in the anchor lists (use_mp_region_counts = 1), no unpaired rescue
     "no_half_paired": ("stress_pairs_2x100", ["--no-half-paired"]),
     "cfg5_no_half_paired": ("cfg5s_2x150_1Mbp", ["--no-half-paired"]),
+    # -n 3 in paired mode: a region marked once counts when the mate has hits within reach (use_mp_region_counts 2, or 3 with --no-half-paired; hit list mode 3,
+    # gmapper.c:2657-2673); -n 2 in paired mode: no region counts at all, a window per anchor
+    "pairs_n3": ("stress_pairs_2x100", ["-n", "3"]),
+    "pairs_n3_nhp": ("stress_pairs_2x100", ["-n", "3", "--no-half-paired"]),
+    "cfg5_n3": ("cfg5s_2x150_1Mbp", ["-n", "3"]),
+    "cfg5_n3_nhp": ("cfg5s_2x150_1Mbp", ["-n", "3", "--no-half-paired"]),
+    "pairs_n2": ("stress_pairs_2x100", ["-n", "2"]),
+    "cfg5_n2": ("cfg5s_2x150_1Mbp", ["-n", "2"]),
 }
 
 
@@ -212,9 +241,10 @@ def cs_pair_option_cases():
         print("%s@%s: %d SAM records" % (base, tag, sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@"))))
 
 
-def option_cases():
+def option_cases(only=None):
     """non-default options on inputs that are already committed: only the reference's SAM body is stored (<base>@<tag>.sam.gz)"""
     for tag, (base, extra) in OPTION_CASES.items():
+        if only and tag not in only: continue
         z = np.load(os.path.join(OUT, base + ".npz"))
         contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
         with tempfile.TemporaryDirectory() as d:
@@ -475,6 +505,10 @@ def main():
         index_cases(); return
     if "--options-only" in sys.argv:
         option_cases(); return
+    if "--option-tags" in sys.argv:                                   # --option-tags pairs_n3,cfg5_n3: just these
+        option_cases(only=sys.argv[sys.argv.index("--option-tags") + 1].split(",")); return
+    if "--n1-only" in sys.argv:
+        n1_noisy_case(); return
     if "--paired-only" in sys.argv:
         paired_cases(); return
     contigs, reads, _ = synth.make_config("cfg1")
@@ -490,6 +524,7 @@ def main():
     print("sw_kat:", kat.count(b"\nV ") + 1, "vector,", kat.count(b"\nF "), "full")
     paired_cases()
     option_cases()
+    n1_noisy_case()
     cs_option_cases()
     index_cases()
     cs_kat_cases()
