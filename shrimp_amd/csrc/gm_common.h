@@ -48,6 +48,7 @@ struct GmIndexDev {
   int hflag;                          // -H: lists are keyed by kmer_to_mapidx_hash, 4^12 of them per seed (ref: gmapper.h:323-336)
   int cs_flip;                        // colour space, a mate the pair mode reverses (read_reverse, ref: gmapper.c:174-185): the read keeps its colours, its strand LABELS
                                       // swap -- strand label st stands for strand st ^ cs_flip of the read as sequenced, which is then the read's input strand
+  int no_region_counts;               // set per call: the lookup keeps EVERY list entry -- unpaired -n 1, paired -n 2 (use_region_counts off, ref: gmapper.c:2610-2616,2652-2657)
   uint64_t total_len;                 // sum of contig lengths (< 2^32)
   int n_contigs;
   const uint32_t* contig_off;         // [n_contigs+1] global offsets (ref: contig_offsets[])

@@ -427,7 +427,8 @@ static void choose_caps(gm_session* s, DevSet& D, int read_len) {
   }
   const double entries = lists * avg_len;
   const double region = (double)(1 << ix->params.region_bits) + ix->params.region_overlap;
-  const double expected = entries * std::min(1.0, entries * region / std::max(1.0, (double)ix->total_len)) + lists;
+  double expected = entries * std::min(1.0, entries * region / std::max(1.0, (double)ix->total_len)) + lists;
+  if (s->P.match_mode == 1) expected = entries + lists;                        // -n 1: every list entry is kept
   // scap = capacity of the LDS tier of K2 (16 B of LDS per entry); read-strands beyond it take the heavy tier
   // chance partial matches echo on neighbouring offsets / other seeds, so the survivors come out ~1.6x the independence estimate
   D.scap = std::min(16384, std::max(256, pow2ceil((long long)(2.2 * expected) + 128)));
@@ -1123,10 +1124,13 @@ static int launch_prune_anchors(gm_session* s, DevSet& D, const GmIndexDev& dv, 
 // 56-64 VGPRs, ~1 KB of LDS per wave) shares the CUs with the front of sub-batch i + 1 (K1: one 1 024-thread workgroup per CU that waits on
 // memory most of the time and leaves 96 VGPRs per SIMD and 26 KB of LDS free).  Each half uses the buffer set k of its sub-batch only.
 //
+// the index as the kernels see it, with the session's per-call switches: -n 1 keeps every list entry (use_region_counts off, ref: gmapper.c:2610-2616)
+static GmIndexDev session_view(const gm_session* s) { GmIndexDev dv = s->ix->dev_view(); dv.no_region_counts = s->P.match_mode == 1 ? 1 : 0; return dv; }
+
 // Front, stream A: K1, K1b, K2; nothing here waits on the host (the heavy count lands in pinned memory, event pev[k][6] marks the end).
 static int pipeline_front(gm_session* s, int k, int n, int read_len) {
   DevSet& D = s->set[k];
-  const GmIndexDev dv = s->ix->dev_view();
+  const GmIndexDev dv = session_view(s);
   const int read_words = (read_len + 7) / 8;
   const int W = window_len_of(s->P, read_len);
   hipStream_t q = s->stream;
@@ -1152,7 +1156,7 @@ static int pipeline_front(gm_session* s, int k, int n, int read_len) {
 // (the buffers of set k were re-allocated: the caller re-submits the sub-batch from the front).
 static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len, gm_map_stats_t* st, float* lookup_ms, bool next_front_queued = false) {
   DevSet& D = s->set[k];
-  const GmIndexDev dv = s->ix->dev_view();
+  const GmIndexDev dv = session_view(s);
   const int read_words = (read_len + 7) / 8;
   const int W = window_len_of(s->P, read_len);
   const int overlap_abs = (int)(unsigned int)(s->P.window_overlap < 0 ? -s->P.window_overlap : W * (s->P.window_overlap / 100.0));   // ref: mapping.c:1289

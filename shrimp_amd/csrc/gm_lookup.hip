@@ -80,6 +80,7 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
   uint32_t* bm = smem + ((code_words + 6 * NL + 1 + 3) & ~3);     // 16-byte aligned for the b128 clears
   const int S = ix.n_slabs, rb = ix.region_bits;
   const uint32_t rmask = (1u << rb) - 1u, ovl = (uint32_t)ix.region_overlap;
+  const bool all = ix.no_region_counts != 0;      // no region counts: every list entry survives (the marks are still made, nothing reads them)
 
   // ---- 0. read codes of this strand (strand 1 = reverse complement, ref: util.c:540-596) ----
   const uint32_t* rw = reads + (size_t)rd * read_words;
@@ -226,7 +227,7 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
           if ((uint32_t)u < blen) {
             const uint32_t pv = bp[u + 1]; const uint32_t reg = pv >> rb, rloc = reg - rbase + 1u;
             const bool strip = ((pv & rmask) < ovl) && reg > 0;
-            if (k1_has2(bm, rloc) || (strip && k1_has2(bm, rloc - 1u))) alive |= 1u << u;
+            if (all || k1_has2(bm, rloc) || (strip && k1_has2(bm, rloc - 1u))) alive |= 1u << u;
           }
         if (alive) {
           const uint32_t cnt = __popc(alive);
@@ -251,7 +252,7 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
               if (e + u < h) {
                 const uint32_t reg = p[u] >> rb, rloc = reg - rbase + 1u;
                 const bool strip = ((p[u] & rmask) < ovl) && reg > 0;
-                if (k1_has2(bm, rloc) || (strip && k1_has2(bm, rloc - 1u))) emit(p[u], off);
+                if (all || k1_has2(bm, rloc) || (strip && k1_has2(bm, rloc - 1u))) emit(p[u], off);
               }
           }
         }
@@ -276,7 +277,7 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
             if (phase == 0) {
               k1_mark(bm, rloc);
               if (strip) k1_mark(bm, rloc - 1u);
-            } else if (k1_has2(bm, rloc) || (strip && k1_has2(bm, rloc - 1u))) emit(p, off);
+            } else if (all || k1_has2(bm, rloc) || (strip && k1_has2(bm, rloc - 1u))) emit(p, off);
           } else if (phase == 0) {
             if (idx < l) {
               if (reg + 1u == rbase) {
@@ -1142,8 +1143,9 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     GM_HIP(hipFuncSetAttribute((const void*)k_lookup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = lds;
   }
-  const bool bkt = ix.seed[0].bkt != nullptr && ix.n_slabs == 1 && NL <= 512 && !gm_tune("GM_NO_BUCKETS");
-  if (!bkt && NL < 65536 && !gm_tune("GM_K1_V2") && !gm_tune("GM_K1_V3") && !gm_tune("GM_K1_V4") && !gm_tune("GM_NO_V5")) {
+  const bool all = ix.no_region_counts != 0;      // every list entry survives: the generic slab-sweep kernel carries that switch, the filtering kernels do not apply
+  const bool bkt = !all && ix.seed[0].bkt != nullptr && ix.n_slabs == 1 && NL <= 512 && !gm_tune("GM_NO_BUCKETS");
+  if (!all && !bkt && NL < 65536 && !gm_tune("GM_K1_V2") && !gm_tune("GM_K1_V3") && !gm_tune("GM_K1_V4") && !gm_tune("GM_NO_V5")) {
     // k_lookup_v5 (gm_lookup5.hip): wave-per-list streaming, candidates and the exact rule in LDS, K1b's prune rules fused when the caller allows.
     // It takes the read-strands with many list entries (gm_lookup5_launch declines the others: 50-colour reads, small genomes) -- round 2: 24 %
     // fewer VALU instructions than v4 + K1b, 2.09 M reads/s against 1.90 M on the 3 Gbp workload.
@@ -1191,11 +1193,11 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     const size_t lds_b = (size_t)((((read_len + 3) / 4) + 3) & ~3) * 4 + (size_t)bm_words * 4;
     hipLaunchKernelGGL(k_lookup_bkt, dim3(n_reads * 2), dim3((NL + 63) & ~63), lds_b, stream, ix, d_reads, n_reads, read_len, read_words,
                        max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, d_surv_seg);
-  } else if (ix.n_slabs > 1 && NL < 65536 && !gm_tune("GM_K1_V2") && !gm_tune("GM_K1_V3") && k4_launch(ix, d_reads, n_reads, read_len, read_words, max_n_kmers, NL, d_surv, d_surv_cnt, scap,
+  } else if (!all && ix.n_slabs > 1 && NL < 65536 && !gm_tune("GM_K1_V2") && !gm_tune("GM_K1_V3") && k4_launch(ix, d_reads, n_reads, read_len, read_words, max_n_kmers, NL, d_surv, d_surv_cnt, scap,
                                                                                                    d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, stream, d_surv_seg, lds, bm_words)) {
     // k_lookup_v4 ran (hashed pre-count + exact count on the candidates); read-strands it could not hold were redone in list mode
     g_k1_name = "k_lookup_v4";
-  } else if (ix.list_cutoff < 65536u && !gm_tune("GM_K1_V2") &&
+  } else if (!all && ix.list_cutoff < 65536u && !gm_tune("GM_K1_V2") &&
              (size_t)((((read_len + 3) / 4) + 3 * NL + ix.n_slabs * NL + (ix.n_slabs + 1) / 2 + (NL * (ix.n_slabs + 1) + 1) / 2 + 3) & ~3) * 4 + (size_t)bm_words * 4 <= 160 * 1024) {
     // (long reads on many slabs: the per-slab window maps outgrow the LDS and the lane-per-list kernel below takes over)
     g_k1_name = "k_lookup_v3";
