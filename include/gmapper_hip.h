@@ -298,6 +298,11 @@ typedef struct gm_pair_opts {
   double insert_size_mean, insert_size_stddev; /* ref: gmapper-defaults.h:30-31  200 / 100 */
   int half_paired;                             /* ref: gmapper.h:181 true; 0 = --no-half-paired: each mate's list entries are filtered by the other mate's region
                                                   counts (mapping.c:545-608,733-742, use_mp_region_counts = 1) and no unpaired rescue runs (gmapper.c:2657-2683) */
+  int match_mode;                              /* the reference's -n in paired mode (ref: gmapper-defaults.h:35 DEF_MATCH_MODE_PAIRED 4; gmapper.c:2652-2673):
+                                                  4: two k-mer matches per mate (region counts; with half_paired = 0 also the mate's);
+                                                  3: one match is enough where the mate has hits within reach (use_mp_region_counts 2, or 3 with half_paired = 0;
+                                                     hit list mode 3, mapping.c:733-742,1080-1093,1153-1157);
+                                                  2: no region counts at all, a window per anchor.   0 is read as 4 */
 } gm_pair_opts_t;
 void gm_pair_opts_default(gm_pair_opts_t *o);
 int gm_map_pairs(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_packed, int len2, const uint32_t *mates2_packed,

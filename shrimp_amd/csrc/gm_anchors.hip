@@ -324,8 +324,13 @@ __device__ int k2_collapse_par(const GmIndexDev& ix, K2Ws<false>& ws, uint32_t* 
 // DETECT additionally reports whether the open order of equal-x anchors could matter. ----------------
 template <bool BIG, bool DETECT>
 __device__ int k2_windows(const GmIndexDev& ix, const GmScoreDev& sc, K2Ws<BIG>& ws, int na, int read_len, int window_len,
-                          GmHit* H, uint32_t* hitx, int hcap, int lane, bool* sensitive) {
+                          GmHit* H, uint32_t* hitx, int hcap, int lane, bool* sensitive, int rs) {
   const int match = sc.match;
+  // match_mode 3 (paired -n 3): an anchor whose region the mate reaches with a region it marked twice ("heavy_mp", ref: mapping.c:1080-1093) opens a window on its
+  // own weight and skips the threshold (:1100-1103,1153-1157).  The mate's row: GmMpDev.
+  const uint32_t mp_n = sc.match_mode == 3 ? ix.mp.cnt[rs ^ 1] : 0u;
+  const uint32_t* mp_row = sc.match_mode == 3 ? ix.mp.rows + (size_t)(rs ^ 1) * GM_MP_CAP : nullptr;
+  const int mp_dmin = ix.mp.dmin[rs & 1], mp_dmax = ix.mp.dmax[rs & 1];
   int nh = 0; bool sens = false;
   for (int c0 = 0; c0 < na; c0 += GM_WAVE) {
     const int i = c0 + lane;
@@ -345,7 +350,14 @@ __device__ int k2_windows(const GmIndexDev& ix, const GmScoreDev& sc, K2Ws<BIG>&
       const long long gstart = (gend >= window_len) ? gend - window_len : 0;
       int max_idx = i;
       int max_score = leni * match;
-      if (!sc.gapless && sc.match_mode == 2 && wi == 1) max_score = -1;
+      bool heavy_mp = false;
+      if (sc.match_mode == 3 && mp_n <= (uint32_t)GM_MP_CAP) {
+        const uint32_t reg = (uint32_t)xi >> ix.region_bits;
+        heavy_mp = gm_mp_reach(mp_row, mp_n, (long long)reg + mp_dmin, (long long)reg + mp_dmax);
+        if (!heavy_mp && reg > 0 && ((uint32_t)xi & ((1u << ix.region_bits) - 1u)) < (uint32_t)ix.region_overlap)
+          heavy_mp = gm_mp_reach(mp_row, mp_n, (long long)reg - 1 + mp_dmin, (long long)reg - 1 + mp_dmax);
+      }
+      if (!sc.gapless && (sc.match_mode == 2 || (sc.match_mode == 3 && !heavy_mp)) && wi == 1) max_score = -1;
       bool tie_sibling = false;        // another candidate with the argmax's x reached the same score
       for (int j = i - 1; !sc.gapless && j >= 0; j--) {           // -U: only the anchor itself, no threshold (ref: mapping.c:1070,1095,1154)
         const uint64_t aj = ws.key[j];
@@ -363,7 +375,7 @@ __device__ int k2_windows(const GmIndexDev& ix, const GmScoreDev& sc, K2Ws<BIG>&
         else if (DETECT && tmp == max_score && max_idx != i && xj == (long long)(ws.key[max_idx] >> 32)) tie_sibling = true;
       }
       const int base = (read_len < w_len ? read_len : w_len) * match;
-      if (sc.gapless || sc.match_mode == 1 || max_score >= k2_threshold(sc.wgen_thr_frac, sc.wgen_abs, base)) {
+      if (sc.gapless || sc.match_mode == 1 || (sc.match_mode == 3 && heavy_mp) || max_score >= k2_threshold(sc.wgen_thr_frac, sc.wgen_abs, base)) {
         const uint64_t am = ws.key[max_idx]; const uint32_t aum = ws.aux[max_idx];
         const long long xm = (long long)(am >> 32);
         if (DETECT && max_idx != i && (tie_sibling || xm == xi)) sens = true;          // case (a)
@@ -515,7 +527,7 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
     na = k2_collapse_par<RMAX>(ix, *(K2Ws<false>*)&ws, scratch32, n, npad, read_len, lane);
     K2_STAMP(2);
     bool sens = false;
-    nh = k2_windows<BIG, true>(ix, sc, ws, na, read_len, window_len, H, scratch32, hcap, lane, &sens);
+    nh = k2_windows<BIG, true>(ix, sc, ws, na, read_len, window_len, H, scratch32, hcap, lane, &sens, rs);
     k2_sync<BIG>();
     K2_STAMP(3);
     need_exact = sens;
@@ -541,7 +553,7 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
     k2_sync<BIG>();
     na = sh_na;
     bool dummy;
-    nh = k2_windows<BIG, false>(ix, sc, ws, na, read_len, window_len, H, scratch32, hcap, lane, &dummy);
+    nh = k2_windows<BIG, false>(ix, sc, ws, na, read_len, window_len, H, scratch32, hcap, lane, &dummy, rs);
     k2_sync<BIG>();
     sort_windows(min(nh, hcap), false);
   }

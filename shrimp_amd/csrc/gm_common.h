@@ -41,6 +41,34 @@ struct GmSeedDev {
   uint32_t n_pos;
 };
 
+// Paired -n 3 (mate-pair region counts 2 / 3, ref: mapping.c:545-608,733-742,1080-1093): what the lookup and the window kernels need to know about the MATE.
+// A row holds, sorted, the regions one read-strand marked twice or more (its RG_GET_HAS_2 set); a region R of the other mate's opposite strand then has
+// RG_GET_MP_CNT(R) >= 2 exactly when some row entry lies in [R + dmin, R + dmax].  cnt[rs] > cap: the row did not fit (the consumers count the item, the host refuses).
+#define GM_MP_CAP 2048
+#define GM_MP_FLAG 0x80000000u
+struct GmMpDev {
+  int mode;                           // 0: off; else the lookup's generic kernel runs in one of these modes (the window kernel reads rows / cnt / dmin / dmax whatever the mode):
+                                      // 1: it only LISTS the regions each read-strand marked twice (out_rows / out_cnt);
+                                      // 2: it keeps, besides the entries of regions marked twice, those of regions the mate reaches -- count_main >= 2 || count_mp >= 2,
+                                      //    use_mp_region_counts == 2 (-n 3);
+                                      // 3: it only FLAGS (GM_MP_FLAG in the row word) the mate's row entries that some region this read-strand marked reaches: for a region
+                                      //    the mate marked twice that is count_mp >= 1;
+                                      // 4: it keeps the entries of regions with count_mp >= 1 && count_main + count_mp >= 3, use_mp_region_counts == 3 (-n 3 without half-paired):
+                                      //    the mate reaches the region (count_mp == 2), or the region is marked twice and its own row entry carries the flag
+  int dmin[2], dmax[2];               // this mate's region deltas per strand (delta_region_min / _max, ref: mapping.c:2422-2430)
+  uint32_t* rows; const uint32_t* cnt;           // the mate's rows: read-strand rs of this mate looks at row rs ^ 1 (same pair, other strand)
+  uint32_t* out_rows; uint32_t* out_cnt;         // this mate's own rows (written in mode 1, read in mode 4)
+};
+// some row entry in [lo, hi]?  (row sorted ascending; the flag bit is not part of the value).  *first: index of the first such entry
+__device__ __forceinline__ bool gm_mp_reach(const uint32_t* row, uint32_t n, long long lo, long long hi, uint32_t* first = nullptr) {
+  if (hi < 0 || n == 0) return false;
+  if (lo < 0) lo = 0;
+  uint32_t a = 0, z = n;
+  while (a < z) { const uint32_t m = (a + z) >> 1; if ((long long)(row[m] & ~GM_MP_FLAG) < lo) a = m + 1; else z = m; }
+  if (first) *first = a;
+  return a < n && (long long)(row[a] & ~GM_MP_FLAG) <= hi;
+}
+
 struct GmIndexDev {
   const uint32_t* genome;
   const uint32_t* genome_cs;          // colour space only: colour p = lstocs(letter p-1, letter p), 'T' before a contig's first letter (ref: fasta.c:586-606)
@@ -49,6 +77,7 @@ struct GmIndexDev {
   int cs_flip;                        // colour space, a mate the pair mode reverses (read_reverse, ref: gmapper.c:174-185): the read keeps its colours, its strand LABELS
                                       // swap -- strand label st stands for strand st ^ cs_flip of the read as sequenced, which is then the read's input strand
   int no_region_counts;               // set per call: the lookup keeps EVERY list entry -- unpaired -n 1, paired -n 2 (use_region_counts off, ref: gmapper.c:2610-2616,2652-2657)
+  GmMpDev mp;                         // set per call (paired -n 3)
   uint64_t total_len;                 // sum of contig lengths (< 2^32)
   int n_contigs;
   const uint32_t* contig_off;         // [n_contigs+1] global offsets (ref: contig_offsets[])

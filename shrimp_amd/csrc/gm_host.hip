@@ -293,6 +293,8 @@ struct DevSet {
   GmPostRes* d_post = nullptr; double* d_post_fw = nullptr; uint32_t* d_post_info = nullptr;   // colour space: post_sw on the device (gm_post.hip), its per-thread scratch
   // paired mode only: mate range of every window (by sorted position) and the "saved" mark (by hit slot)
   int32_t* d_pmin = nullptr; int32_t* d_pmax = nullptr; uint8_t* d_saved = nullptr; uint32_t* d_saved_list = nullptr;
+  int caps_pair_mode = 0;      // the paired match mode the capacities were chosen for
+  uint32_t* d_mp_rows = nullptr; uint32_t* d_mp_cnt = nullptr; int mp_rows_for = 0;     // paired -n 3: the regions each read-strand marked twice (GmMpDev), for mp_rows_for read-strands
 };
 
 // Pinned host staging for one sub-batch's results: device-to-host copies run at link rate and the buffers are reused
@@ -347,13 +349,14 @@ struct gm_session {
 static void free_buffers(DevSet& D) {
   void* ptrs[] = {D.d_xover, D.d_reads, D.d_initbp, D.d_surv, D.d_surv_cnt, D.d_surv_seg, D.d_surv2, D.d_surv_cnt2, D.d_hits, D.d_perm, D.d_hit_cnt, D.d_slots, D.d_heavy_list, D.d_heavy_cnt,
                   D.d_sel, D.d_sel_sidx, D.d_sel_cnt, D.d_sel_off, D.d_work, D.d_n_work, D.d_res, D.d_ops, D.d_back,
-                  D.d_pmin, D.d_pmax, D.d_saved, D.d_saved_list, D.d_post, D.d_post_fw, D.d_post_info, D.d_qv, D.d_post_bq};
+                  D.d_pmin, D.d_pmax, D.d_saved, D.d_saved_list, D.d_post, D.d_post_fw, D.d_post_info, D.d_qv, D.d_post_bq, D.d_mp_rows, D.d_mp_cnt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   D.d_post = nullptr; D.d_post_fw = nullptr; D.d_post_info = nullptr; D.d_qv = nullptr; D.d_post_bq = nullptr;
   D.d_xover = nullptr; D.d_reads = nullptr; D.d_initbp = nullptr; D.d_surv = nullptr; D.d_surv_cnt = nullptr; D.d_surv_seg = nullptr; D.d_surv2 = nullptr; D.d_surv_cnt2 = nullptr; D.d_hits = nullptr; D.d_perm = nullptr; D.d_hit_cnt = nullptr; D.d_slots = nullptr;
   D.d_heavy_list = nullptr; D.d_heavy_cnt = nullptr; D.d_sel = nullptr; D.d_sel_sidx = nullptr; D.d_sel_cnt = nullptr; D.d_sel_off = nullptr;
   D.d_work = nullptr; D.d_n_work = nullptr; D.d_res = nullptr; D.d_ops = nullptr; D.d_back = nullptr;
   D.d_pmin = nullptr; D.d_pmax = nullptr; D.d_saved = nullptr; D.d_saved_list = nullptr;
+  D.d_mp_rows = nullptr; D.d_mp_cnt = nullptr; D.mp_rows_for = 0;
   D.cur_len = -1;
 }
 
@@ -417,7 +420,9 @@ static int alloc_buffers(gm_session* s, DevSet& D, int read_len, bool paired = f
   return GM_OK;
 }
 
-static void choose_caps(gm_session* s, DevSet& D, int read_len) {
+// pair_mode: the paired match mode when called for pairs (0: unpaired).  Modes 3 and 2 have no prune rules (a single k-mer match can open a window) and K2 takes
+// the lookup's rows directly: its LDS tier holds 4096 keys; mode 2 keeps every list entry
+static void choose_caps(gm_session* s, DevSet& D, int read_len, int pair_mode = 0) {
   const gm_index* ix = s->ix;
   const int max_n_kmers = std::max(0, read_len - ix->min_seed_span + 1);
   double lists = 0, avg_len = 0;
@@ -428,7 +433,7 @@ static void choose_caps(gm_session* s, DevSet& D, int read_len) {
   const double entries = lists * avg_len;
   const double region = (double)(1 << ix->params.region_bits) + ix->params.region_overlap;
   double expected = entries * std::min(1.0, entries * region / std::max(1.0, (double)ix->total_len)) + lists;
-  if (s->P.match_mode == 1) expected = entries + lists;                        // -n 1: every list entry is kept
+  if (pair_mode ? pair_mode == 2 : s->P.match_mode == 1) expected = entries + lists;                        // -n 1 (paired: -n 2): every list entry is kept
   // scap = capacity of the LDS tier of K2 (16 B of LDS per entry); read-strands beyond it take the heavy tier
   // chance partial matches echo on neighbouring offsets / other seeds, so the survivors come out ~1.6x the independence estimate
   D.scap = std::min(16384, std::max(256, pow2ceil((long long)(2.2 * expected) + 128)));
@@ -436,6 +441,7 @@ static void choose_caps(gm_session* s, DevSet& D, int read_len) {
   // K1b (exact isolation prune) shrinks K2's input; its LDS tier is sized for what typically remains
   // K1b's bounds assume the window-generation threshold: not in -U mode
   D.scap2 = (s->P.match_mode == 2 && !s->P.ungapped && !gm_tune("GM_NO_PRUNE")) ? std::max(std::min(D.scap, 256), D.scap / 8) : 0;
+  if (pair_mode == 2 || pair_mode == 3) { D.scap = std::min(D.scap, 4096); D.scap2 = 0; }
   if (const char* e = gm_tune("GM_SCAP")) D.scap = std::min(16384, std::max(64, pow2ceil(atoi(e))));
   if (const char* e = gm_tune("GM_SCAP2")) { if (D.scap2) D.scap2 = std::min(D.scap, std::max(64, pow2ceil(atoi(e)))); }
   if (const char* e = gm_tune("GM_HCAP")) D.hcap = std::min(32768, std::max(4, pow2ceil(atoi(e))));
@@ -1045,7 +1051,8 @@ struct Finalizer {
 // repeats).  Sizes are known now, so every array is allocated exactly, the keys are re-emitted by K1
 // and sorted by one segmented radix sort; then K2 runs on global arrays.  Rare by construction.
 static int run_heavy_tier(gm_session* s, DevSet& D, const GmIndexDev& dv, int n, int read_len, int read_words, int W, int n_heavy,
-                          unsigned long long* d_stats = nullptr) {
+                          unsigned long long* d_stats = nullptr, const GmScoreDev* sc = nullptr) {
+  if (!sc) sc = &s->sc;
   hipStream_t q = s->stream;
   if (!d_stats) d_stats = s->d_stats;
   std::vector<uint32_t> list(n_heavy), cnt_all((size_t)n * 2);
@@ -1075,7 +1082,7 @@ static int run_heavy_tier(gm_session* s, DevSet& D, const GmIndexDev& dv, int n,
   GM_HIP(hipMemsetAsync(d_ks, 0xff, tot * 8, q));
   int rc = gm_launch_lookup_redo(dv, D.d_reads, n, read_len, read_words, n_heavy, d_list, d_off, d_kin, d_stats, q);
   if (rc == GM_OK)
-    rc = gm_launch_anchors_heavy(dv, s->sc, n, read_len, W, n_heavy, d_list, d_off, d_segn, d_b32, d_e32, tot, d_kin, d_ks, d_aux, d_nxt, d_ord,
+    rc = gm_launch_anchors_heavy(dv, *sc, n, read_len, W, n_heavy, d_list, d_off, d_segn, d_b32, d_e32, tot, d_kin, d_ks, d_aux, d_nxt, d_ord,
                                  D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, d_stats, q);
   GM_HIP(hipStreamSynchronize(q));
   (void)hipFree(d_list); (void)hipFree(d_segn); (void)hipFree(d_b32); (void)hipFree(d_e32); (void)hipFree(d_off);
@@ -1287,7 +1294,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   GM_HIP(hipSetDevice(s->ix->device));
   DevSet& D = s->set[0];
   if (stats) memset(stats, 0, sizeof *stats);
-  if (D.cur_len != read_len) { choose_caps(s, D, read_len); int rc = alloc_buffers(s, D, read_len); if (rc) return rc; }
+  if (D.cur_len != read_len || (D.caps_pair_mode != 0 && D.caps_pair_mode != 4)) { choose_caps(s, D, read_len); D.caps_pair_mode = 0; int rc = alloc_buffers(s, D, read_len); if (rc) return rc; }
   const int read_words = (read_len + 7) / 8;
   if (s->P.output_format && s->h_genome.empty()) {                // the SHRiMP / pretty formats print genome letters: one download per session
     s->h_genome.resize(s->ix->genome_words);
@@ -1731,7 +1738,7 @@ extern "C" int gm_debug_tophits(gm_session_t* s, int n_reads, int read_len, cons
   if (!s) return GM_E_ARG;
   GM_HIP(hipSetDevice(s->ix->device));
   DevSet& D = s->set[0];
-  if (D.cur_len != read_len) { choose_caps(s, D, read_len); int rc = alloc_buffers(s, D, read_len); if (rc) return rc; }
+  if (D.cur_len != read_len || (D.caps_pair_mode != 0 && D.caps_pair_mode != 4)) { choose_caps(s, D, read_len); D.caps_pair_mode = 0; int rc = alloc_buffers(s, D, read_len); if (rc) return rc; }
   if (n_reads > D.eff_batch) { gm_set_error("gm_debug_tophits: at most %d reads per call", D.eff_batch); return GM_E_ARG; }
   const int read_words = (read_len + 7) / 8;
   float lk; int rc;

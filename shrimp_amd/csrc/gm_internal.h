@@ -143,6 +143,8 @@ int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs
 
 // paired mode (gm_pair.hip): mate ranges per window, pair top-K, saved marks, mate reversal
 int gm_launch_revcomp_reads(uint32_t* d_reads, int n_reads, int read_len, int read_words, hipStream_t stream);
+struct MpDelta { int amin[2], amax[2], bmin[2], bmax[2]; };   // region deltas of mate 1 / mate 2 per strand (ref: mapping.c:2422-2430)
+MpDelta gm_mp_region_deltas(int region_bits, const int* dmin1, const int* dmax1, const int* dmin2, const int* dmax2);
 int gm_launch_mp_filter(int n_pairs, int region_bits, int region_overlap, uint64_t* d_surv1, uint32_t* d_cnt1, int scap1, uint64_t* d_surv2, uint32_t* d_cnt2, int scap2,
                         const int* dmin1, const int* dmax1, const int* dmin2, const int* dmax2, uint32_t* d_seg1, uint32_t* d_seg2, int n_slabs,
                         unsigned long long* d_unfiltered, hipStream_t stream);

@@ -50,7 +50,8 @@ __device__ __forceinline__ bool k1_has2(const uint32_t* bm, uint32_t rloc) {
 }
 
 // dynamic LDS layout: codes[read_len pad 4] | kS[NL] | lbeg[NL] | lend[NL] | lo[NL] | hi[NL] | pre[NL+1] | bitmap[bm_words]
-template <bool BKT>
+// MP (paired -n 3): the modes of GmMpDev -- 1 lists the regions this read-strand marks twice, 2 / 4 widen or narrow the survival rule by the mate's rows, 3 flags the mate's rows
+template <bool BKT, int MP = 0>
 __device__ __forceinline__ void
 k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
          int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
@@ -81,6 +82,8 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
   const int S = ix.n_slabs, rb = ix.region_bits;
   const uint32_t rmask = (1u << rb) - 1u, ovl = (uint32_t)ix.region_overlap;
   const bool all = ix.no_region_counts != 0;      // no region counts: every list entry survives (the marks are still made, nothing reads them)
+  __shared__ uint32_t sh_mp_row[MP ? GM_MP_CAP : 1]; __shared__ uint32_t sh_mp_n;            // MP 1: the row being collected; 2, 3, 4: the mate's row
+  __shared__ uint32_t sh_own_row[MP == 4 ? GM_MP_CAP : 1]; __shared__ uint32_t sh_own_n;       // MP 4: this read-strand's own row, with the flags the mate's pass left
 
   // ---- 0. read codes of this strand (strand 1 = reverse complement, ref: util.c:540-596) ----
   const uint32_t* rw = reads + (size_t)rd * read_words;
@@ -88,7 +91,40 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
     codes[i] = (uint8_t)gm_read_code(rw, read_len, st ^ ix.cs_flip, ix.colour, i);   // strand 1 = reverse complement (ref: util.c:540-617)
   }
   if (tid == 0) sh.n_surv = 0;
+  if (MP == 1 && tid == 0) sh_mp_n = 0;
+  if (MP >= 2) {   // the mate's row (other strand of the same pair), held in LDS for the reach tests
+    const uint32_t mn = ix.mp.cnt[rs ^ 1];
+    if (tid == 0) { sh_mp_n = mn <= (uint32_t)GM_MP_CAP ? mn : 0u; if (mn > (uint32_t)GM_MP_CAP && !redo && MP != 3) GS_ADD(stats, GS_MP_UNFILTERED, 1ull); }
+    if (mn <= (uint32_t)GM_MP_CAP) for (uint32_t i = tid; i < mn; i += nthr) sh_mp_row[i] = ix.mp.rows[(size_t)(rs ^ 1) * GM_MP_CAP + i] & ~GM_MP_FLAG;
+  }
+  if (MP == 4) {
+    const uint32_t on = ix.mp.out_cnt[rs];
+    if (tid == 0) { sh_own_n = on <= (uint32_t)GM_MP_CAP ? on : 0u; if (on > (uint32_t)GM_MP_CAP && !redo) GS_ADD(stats, GS_MP_UNFILTERED, 1ull); }
+    if (on <= (uint32_t)GM_MP_CAP) for (uint32_t i = tid; i < on; i += nthr) sh_own_row[i] = ix.mp.out_rows[(size_t)rs * GM_MP_CAP + i];
+  }
   __syncthreads();
+  const int mp_dmin = MP >= 2 ? ix.mp.dmin[st] : 0, mp_dmax = MP >= 2 ? ix.mp.dmax[st] : 0;
+  // count_mp >= 2 for region reg: the mate marked a region twice within [reg + dmin, reg + dmax] (ref: mapping.c:573-582)
+  auto mp_reach = [&](uint32_t reg) -> bool { return (MP == 2 || MP == 4) && gm_mp_reach(sh_mp_row, sh_mp_n, (long long)reg + mp_dmin, (long long)reg + mp_dmax); };
+  // MP 3: this read-strand marks reg -- every region the mate marked twice within reach of it has count_mp >= 1 (the relation is symmetric: the mate's deltas are these, negated)
+  auto mp_flag = [&](uint32_t reg) {
+    uint32_t a;
+    if (gm_mp_reach(sh_mp_row, sh_mp_n, (long long)reg + mp_dmin, (long long)reg + mp_dmax, &a))
+      for (; a < sh_mp_n && (long long)sh_mp_row[a] <= (long long)reg + mp_dmax; a++) atomicOr(&ix.mp.rows[(size_t)(rs ^ 1) * GM_MP_CAP + a], GM_MP_FLAG);
+  };
+  // MP 4: count_mp >= 1 && count_main + count_mp >= 3 (ref: mapping.c:733-742)
+  auto mp_ok3 = [&](uint32_t reg, uint32_t rloc) -> bool {
+    if (mp_reach(reg)) return true;
+    if (!k1_has2(bm, rloc)) return false;
+    uint32_t a;
+    return gm_mp_reach(sh_own_row, sh_own_n, (long long)reg, (long long)reg, &a) && (sh_own_row[a] & GM_MP_FLAG) != 0u;
+  };
+  // does the list entry survive?  Default: its region, or the one before it when the entry lies in the overlap strip, was marked twice (ref: mapping.c:733-777)
+  auto keep = [&](uint32_t reg, uint32_t rloc, bool strip) -> bool {
+    if (MP == 3) { mp_flag(reg); if (strip) mp_flag(reg - 1u); return false; }
+    if (MP == 4) return mp_ok3(reg, rloc) || (strip && mp_ok3(reg - 1u, rloc - 1u));
+    return all || k1_has2(bm, rloc) || mp_reach(reg) || (strip && (k1_has2(bm, rloc - 1u) || mp_reach(reg - 1u)));
+  };
 
   // ---- 1. map indexes + whole-list bounds (ref: mapping.c:53-66, KMER_TO_MAPIDX gmapper.h:349-368) ----
   // BKT (small genomes, one slab, one list per thread): the probe is ONE 64-byte bucket per k-mer holding the
@@ -219,7 +255,7 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
       __syncthreads();
       total = sh.total;
     }
-    for (int phase = 0; phase < 2; phase++) {
+    for (int phase = 0; phase < (MP == 1 ? 1 : 2); phase++) {
       if (BKT && phase == 1) {
         uint32_t alive = 0;                 // bit u: register entry u survives
 #pragma unroll
@@ -227,7 +263,7 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
           if ((uint32_t)u < blen) {
             const uint32_t pv = bp[u + 1]; const uint32_t reg = pv >> rb, rloc = reg - rbase + 1u;
             const bool strip = ((pv & rmask) < ovl) && reg > 0;
-            if (all || k1_has2(bm, rloc) || (strip && k1_has2(bm, rloc - 1u))) alive |= 1u << u;
+            if (keep(reg, rloc, strip)) alive |= 1u << u;
           }
         if (alive) {
           const uint32_t cnt = __popc(alive);
@@ -252,7 +288,7 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
               if (e + u < h) {
                 const uint32_t reg = p[u] >> rb, rloc = reg - rbase + 1u;
                 const bool strip = ((p[u] & rmask) < ovl) && reg > 0;
-                if (all || k1_has2(bm, rloc) || (strip && k1_has2(bm, rloc - 1u))) emit(p[u], off);
+                if (keep(reg, rloc, strip)) emit(p[u], off);
               }
           }
         }
@@ -277,7 +313,7 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
             if (phase == 0) {
               k1_mark(bm, rloc);
               if (strip) k1_mark(bm, rloc - 1u);
-            } else if (all || k1_has2(bm, rloc) || (strip && k1_has2(bm, rloc - 1u))) emit(p, off);
+            } else if (keep(reg, rloc, strip)) emit(p, off);
           } else if (phase == 0) {
             if (idx < l) {
               if (reg + 1u == rbase) {
@@ -299,8 +335,40 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
       }
       __syncthreads();
     }
+    if (MP == 1) {   // the regions of THIS slab marked twice: local indexes 1 .. rend - rbase (their counts are complete: the border entries of both neighbours are in)
+      const uint32_t last = (uint32_t)min((uint64_t)rend, (ix.total_len >> rb) + 1u) - rbase;
+      for (int w = tid; w < bm_words; w += nthr) {
+        uint32_t m = bm[w] & 0xAAAAAAAAu;
+        while (m) {
+          const int b = __ffs(m) - 1; m &= m - 1u;
+          const uint32_t rloc = (uint32_t)w * 16u + (uint32_t)(b >> 1);
+          if (rloc >= 1u && rloc <= last) { const uint32_t slot = atomicAdd(&sh_mp_n, 1u); if (slot < (uint32_t)GM_MP_CAP) sh_mp_row[slot] = rloc - 1u + rbase; }
+        }
+      }
+      __syncthreads();
+    }
     if (surv_seg && tid == 0) surv_seg[(size_t)rs * (S + 1) + s + 1] = sh.n_surv;      // survivors come out slab by slab: K1b prunes per slab
   }
+  if (MP == 1) {   // sort the row (the slabs come in order, the lanes within one do not), write it out; nothing else leaves the kernel in this mode
+    const uint32_t n = sh_mp_n;
+    if (tid == 0) ix.mp.out_cnt[rs] = n;
+    if (n <= (uint32_t)GM_MP_CAP) {
+      uint32_t np = 1; while (np < n) np <<= 1;
+      for (uint32_t i = n + tid; i < np; i += nthr) sh_mp_row[i] = 0xFFFFFFFFu;
+      __syncthreads();
+      for (uint32_t k = 2; k <= np; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+          for (uint32_t i = tid; i < np; i += nthr) {
+            const uint32_t l = i ^ j;
+            if (l > i) { const uint32_t a = sh_mp_row[i], b = sh_mp_row[l]; if (((i & k) == 0) ? (a > b) : (a < b)) { sh_mp_row[i] = b; sh_mp_row[l] = a; } }
+          }
+          __syncthreads();
+        }
+      for (uint32_t i = tid; i < n; i += nthr) ix.mp.out_rows[(size_t)rs * GM_MP_CAP + i] = sh_mp_row[i];
+    }
+    return;
+  }
+  if (MP == 3) return;                   // (only the flags leave the kernel in this mode)
   if (redo) return;                      // counters were taken by the first run
   if (tid == 0) {
     surv_cnt[rs] = sh.n_surv;
@@ -318,7 +386,7 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
 
 // One block per read-strand; in list mode (fb_list) a bounded grid walks the list -- one block per possible entry meant hundreds of thousands of empty
 // workgroups per launch, each of which still had to be given its LDS before it could return (1 ms per launch with an empty list).
-template <bool BKT>
+template <bool BKT, int MP = 0>
 __global__ void __launch_bounds__(1024)
 k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
          int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
@@ -329,11 +397,11 @@ k_lookup(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int rea
   if (fb_cnt) {
     const int n_items = (int)*fb_cnt;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-      k_lookup_body<BKT>(item, ix, reads, n_reads, read_len, read_words, max_n_kmers, NL, bm_words, surv, surv_cnt, scap_all, heavy_list, heavy_cnt, heavy_cap,
+      k_lookup_body<BKT, MP>(item, ix, reads, n_reads, read_len, read_words, max_n_kmers, NL, bm_words, surv, surv_cnt, scap_all, heavy_list, heavy_cnt, heavy_cap,
                          redo_list, redo_off, fb_list, fb_cnt, stats, ablate, surv_seg);
       __syncthreads();
     }
-  } else k_lookup_body<BKT>((int)blockIdx.x, ix, reads, n_reads, read_len, read_words, max_n_kmers, NL, bm_words, surv, surv_cnt, scap_all, heavy_list, heavy_cnt, heavy_cap,
+  } else k_lookup_body<BKT, MP>((int)blockIdx.x, ix, reads, n_reads, read_len, read_words, max_n_kmers, NL, bm_words, surv, surv_cnt, scap_all, heavy_list, heavy_cnt, heavy_cap,
                             redo_list, redo_off, fb_list, fb_cnt, stats, ablate, surv_seg);
 }
 
@@ -1126,6 +1194,19 @@ size_t gm_lookup_lds_bytes(const GmIndexDev& ix, int read_len) {
   int a, b, c; size_t l; k1_geometry(ix, read_len, &a, &b, &c, &l); return l;
 }
 
+// the mate-pair modes of the generic kernel: their dynamic LDS limit (set once per device for both instantiations)
+static int k1_mp_lds(size_t lds) {
+  static GmLdsLimit lim_mp; size_t& configured = lim_mp.cur();
+  if (lds > 48 * 1024 && lds > configured) {
+    GM_HIP(hipFuncSetAttribute((const void*)k_lookup<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GM_HIP(hipFuncSetAttribute((const void*)k_lookup<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GM_HIP(hipFuncSetAttribute((const void*)k_lookup<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GM_HIP(hipFuncSetAttribute((const void*)k_lookup<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = lds;
+  }
+  return GM_OK;
+}
+
 static const char* g_k1_name = "";
 extern "C" const char* gm_last_lookup_kernel(void) { return g_k1_name; }   // which K1 variant the last gm_launch_lookup chose (for bench.py / profiles)
 
@@ -1142,6 +1223,29 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
   if (lds > 48 * 1024 && lds > configured) {
     GM_HIP(hipFuncSetAttribute((const void*)k_lookup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = lds;
+  }
+  if (ix.mp.mode) {   // paired -n 3: the generic slab-sweep kernel in one of its mate-pair modes (GmMpDev)
+    int rc = k1_mp_lds(lds); if (rc) return rc;
+    const int k1_threads = std::min(1024, std::max(256, (NL + 63) & ~63));
+    g_k1_name = "k_lookup";
+    if (ix.mp.mode == 1)
+      hipLaunchKernelGGL((k_lookup<false, 1>), dim3(n_reads * 2), dim3(k1_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+                         max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
+                         (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_stats, 0, (uint32_t*)nullptr);
+    else if (ix.mp.mode == 3)
+      hipLaunchKernelGGL((k_lookup<false, 3>), dim3(n_reads * 2), dim3(k1_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+                         max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
+                         (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_stats, 0, (uint32_t*)nullptr);
+    else if (ix.mp.mode == 4)
+      hipLaunchKernelGGL((k_lookup<false, 4>), dim3(n_reads * 2), dim3(k1_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+                         max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
+                         (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_stats, 0, d_surv_seg);
+    else
+      hipLaunchKernelGGL((k_lookup<false, 2>), dim3(n_reads * 2), dim3(k1_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+                         max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
+                         (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_stats, 0, d_surv_seg);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
   }
   const bool all = ix.no_region_counts != 0;      // every list entry survives: the generic slab-sweep kernel carries that switch, the filtering kernels do not apply
   const bool bkt = !all && ix.seed[0].bkt != nullptr && ix.n_slabs == 1 && NL <= 512 && !gm_tune("GM_NO_BUCKETS");
@@ -1230,6 +1334,18 @@ int gm_launch_lookup_redo(const GmIndexDev& ix, const uint32_t* d_reads, int n_r
   int max_n_kmers, NL, bm_words; size_t lds;
   k1_geometry(ix, read_len, &max_n_kmers, &NL, &bm_words, &lds);
   if (n_heavy == 0) return GM_OK;
+  if (ix.mp.mode == 4) {
+    int rc = k1_mp_lds(lds); if (rc) return rc;
+    hipLaunchKernelGGL((k_lookup<false, 4>), dim3(n_heavy), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+                       max_n_kmers, NL, bm_words, d_out, (uint32_t*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0,
+                       d_redo_list, d_redo_off, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_stats, 0, (uint32_t*)nullptr);
+  } else
+  if (ix.mp.mode == 2) {
+    int rc = k1_mp_lds(lds); if (rc) return rc;
+    hipLaunchKernelGGL((k_lookup<false, 2>), dim3(n_heavy), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+                       max_n_kmers, NL, bm_words, d_out, (uint32_t*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0,
+                       d_redo_list, d_redo_off, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_stats, 0, (uint32_t*)nullptr);
+  } else
   hipLaunchKernelGGL(k_lookup<false>, dim3(n_heavy), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
                      max_n_kmers, NL, bm_words, d_out, (uint32_t*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0,
                      d_redo_list, d_redo_off, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_stats, 0, (uint32_t*)nullptr);

@@ -203,7 +203,6 @@ int gm_launch_mark_saved(uint8_t* d_saved, const uint32_t* d_list, int n, hipStr
 #define MPF_THREADS 1024
 #define MPF_HBITS 14
 #define MPF_PER_THREAD 16          // survivors per thread held in registers during the compaction: scap <= 16 384
-struct MpDelta { int amin[2], amax[2], bmin[2], bmax[2]; };   // region deltas of mate 1 / mate 2 per strand (ref: mapping.c:2422-2430)
 
 __global__ void __launch_bounds__(MPF_THREADS)
 k_mp_filter(int n_pairs, int rb, uint32_t ovl, uint64_t* __restrict__ surv1, uint32_t* __restrict__ cnt1, int scap1,
@@ -286,15 +285,20 @@ k_mp_filter(int n_pairs, int rb, uint32_t ovl, uint64_t* __restrict__ surv1, uin
   }
 }
 
-int gm_launch_mp_filter(int n_pairs, int region_bits, int region_overlap, uint64_t* d_surv1, uint32_t* d_cnt1, int scap1, uint64_t* d_surv2, uint32_t* d_cnt2, int scap2,
-                        const int* dmin1, const int* dmax1, const int* dmin2, const int* dmax2, uint32_t* d_seg1, uint32_t* d_seg2, int n_slabs,
-                        unsigned long long* d_unfiltered, hipStream_t stream) {
-  if (n_pairs == 0) return GM_OK;
+MpDelta gm_mp_region_deltas(int region_bits, const int* dmin1, const int* dmax1, const int* dmin2, const int* dmax2) {
   MpDelta dl;
   const int R = 1 << region_bits;
   auto rmin = [&](int v) { return v >= 0 ? v / R : -1 - (-v - 1) / R; };          // ref: mapping.c:2422-2430
   auto rmax = [&](int v) { return v > 0 ? 1 + (v - 1) / R : -(-v / R); };
   for (int st = 0; st < 2; st++) { dl.amin[st] = rmin(dmin1[st]); dl.amax[st] = rmax(dmax1[st]); dl.bmin[st] = rmin(dmin2[st]); dl.bmax[st] = rmax(dmax2[st]); }
+  return dl;
+}
+
+int gm_launch_mp_filter(int n_pairs, int region_bits, int region_overlap, uint64_t* d_surv1, uint32_t* d_cnt1, int scap1, uint64_t* d_surv2, uint32_t* d_cnt2, int scap2,
+                        const int* dmin1, const int* dmax1, const int* dmin2, const int* dmax2, uint32_t* d_seg1, uint32_t* d_seg2, int n_slabs,
+                        unsigned long long* d_unfiltered, hipStream_t stream) {
+  if (n_pairs == 0) return GM_OK;
+  const MpDelta dl = gm_mp_region_deltas(region_bits, dmin1, dmax1, dmin2, dmax2);
   const size_t lds = (size_t)(2u << MPF_HBITS) * 4;
   static GmLdsLimit lim_mp; size_t& configured = lim_mp.cur();
   if (lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_mp_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }

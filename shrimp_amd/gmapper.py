@@ -51,7 +51,7 @@ PAIR_MODES = {"opp-in": 1, "opp-out": 2, "col-fw": 3, "col-bw": 4}   # ref: gmap
 
 class PairOpts(C.Structure):    # gm_pair_opts_t
     _fields_ = [("pair_mode", C.c_int), ("min_insert_size", C.c_int), ("max_insert_size", C.c_int),
-                ("insert_size_mean", C.c_double), ("insert_size_stddev", C.c_double), ("half_paired", C.c_int)]
+                ("insert_size_mean", C.c_double), ("insert_size_stddev", C.c_double), ("half_paired", C.c_int), ("match_mode", C.c_int)]
 
     @staticmethod
     def default(mode="opp-in", min_insert=0, max_insert=1000):

@@ -994,6 +994,27 @@ def test_text_input_matches_reference_golden(gm, mode):
     assert any(ch in l.split(b"\t")[9] for l in sam.split(b"\n") if l and not l.startswith(b"@") for ch in (b"X", b"U", b".")) or mode == "cs"
 
 
+@pytest.mark.parametrize("tag", sorted(oa.PAIR_MODE_CASES))
+def test_paired_match_modes_match_reference_golden(gm, oracle_lib, tag):
+    """gm_pair_opts_t.match_mode 3 and 2 (gmapper -p <mode> -n 3 / -n 2), with and without half-paired.  Mode 3: the lookup lists each read-strand's regions marked
+    twice, then keeps the entries of such regions and of regions the mate reaches (GmMpDev; rule 3 in k_mp_filter without half-paired), the window kernel runs hit-list
+    mode 3 (heavy_mp, mapping.c:1080-1093,1153-1157), pass 1 takes one match.  Mode 2: every list entry, a window per anchor.  SAM == the reference's; the stage
+    check is the collapsed-anchor and window counts against the oracle's."""
+    base, oopts, fields = oa.PAIR_MODE_CASES[tag]
+    g = oa.load_golden_pairs(base); want = oa.load_option_sam(base, tag)
+    o = oa.Session(g["contigs"], g["contig_names"], opts=oopts); o.set_pairing(g["mode"], *g["ins"])
+    o.map_pairs_sam(g["m1"], g["m2"], g["names1"], g["names2"], nthreads=8)
+    want_anchors, want_windows = o.last_pair_counts(); o.close()
+    ix = gm.Index(g["contigs"], names=g["contig_names"]); s = gm.Session(ix, max_batch_reads=4096)
+    opts = gm.PairOpts.default(g["mode"], g["ins"][0], g["ins"][1])
+    for k, v in fields.items(): setattr(opts, k, v)
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs(g["m1"], g["m2"], g["names1"], g["names2"], opts=opts)
+    st = s.stats
+    s.close(); ix.close()
+    assert got == want, (_first_diff(got, want), st)
+    assert (st["anchors"], st["windows"]) == (want_anchors, want_windows), (st["anchors"], st["windows"], want_anchors, want_windows)
+
+
 @pytest.mark.parametrize("base,tag", [("stress_pairs_2x100", "no_half_paired"), ("cfg5s_2x150_1Mbp", "cfg5_no_half_paired")])
 def test_no_half_paired_mate_pair_region_counts(gm, oracle_lib, base, tag):
     """A7: gm_pair_opts_t.half_paired = 0 -- k_mp_filter applies the other mate's region counts to each mate's list entries (mapping.c:545-608,733-742)
