@@ -106,11 +106,12 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
   const int mp_dmin = MP >= 2 ? ix.mp.dmin[st] : 0, mp_dmax = MP >= 2 ? ix.mp.dmax[st] : 0;
   // count_mp >= 2 for region reg: the mate marked a region twice within [reg + dmin, reg + dmax] (ref: mapping.c:573-582)
   auto mp_reach = [&](uint32_t reg) -> bool { return (MP == 2 || MP == 4) && gm_mp_reach(sh_mp_row, sh_mp_n, (long long)reg + mp_dmin, (long long)reg + mp_dmax); };
-  // MP 3: this read-strand marks reg -- every region the mate marked twice within reach of it has count_mp >= 1 (the relation is symmetric: the mate's deltas are these, negated)
+  // MP 3: this read-strand marks reg -- every region X the mate (strand 1 - st) marked twice that reaches it, X + mate_dmin <= reg <= X + mate_dmax, has count_mp >= 1
+  const int mt_dmin = MP == 3 ? ix.mp.mate_dmin[1 - st] : 0, mt_dmax = MP == 3 ? ix.mp.mate_dmax[1 - st] : 0;
   auto mp_flag = [&](uint32_t reg) {
     uint32_t a;
-    if (gm_mp_reach(sh_mp_row, sh_mp_n, (long long)reg + mp_dmin, (long long)reg + mp_dmax, &a))
-      for (; a < sh_mp_n && (long long)sh_mp_row[a] <= (long long)reg + mp_dmax; a++) atomicOr(&ix.mp.rows[(size_t)(rs ^ 1) * GM_MP_CAP + a], GM_MP_FLAG);
+    if (gm_mp_reach(sh_mp_row, sh_mp_n, (long long)reg - mt_dmax, (long long)reg - mt_dmin, &a))
+      for (; a < sh_mp_n && (long long)sh_mp_row[a] <= (long long)reg - mt_dmin; a++) atomicOr(&ix.mp.rows[(size_t)(rs ^ 1) * GM_MP_CAP + a], GM_MP_FLAG);
   };
   // MP 4: count_mp >= 1 && count_main + count_mp >= 3 (ref: mapping.c:733-742)
   auto mp_ok3 = [&](uint32_t reg, uint32_t rloc) -> bool {

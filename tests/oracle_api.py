@@ -252,6 +252,10 @@ CS_OPTION_CASES = {
 CS_PAIR_OPTION_CASES = {
     "cs_pairs_local": ("cs_pairs_50col_opp-in", "colour=1;local=1", dict(local_alignment=1)),
     "cs_pairs_local_colbw": ("cs_pairs_50col_col-bw", "colour=1;local=1", dict(local_alignment=1)),
+    # paired match modes in colour space ("pair_" fields go to gm_pair_opts_t)
+    "cs_pairs_n3": ("cs_pairs_50col_opp-in", "colour=1;mp-match-mode=3", dict(pair_match_mode=3)),
+    "cs_pairs_n3_colbw_nhp": ("cs_pairs_50col_col-bw", "colour=1;mp-match-mode=3;half-paired=0", dict(pair_match_mode=3, pair_half_paired=0)),
+    "cs_pairs_n2": ("cs_pairs_50col_opp-in", "colour=1;mp-match-mode=2", dict(pair_match_mode=2)),
 }
 
 

@@ -1068,14 +1068,36 @@ def test_colour_space_pairs_local_match_reference_golden(gm, tag):
     g = oa.load_golden_pairs(base)
     want = oa.load_option_sam(base, tag)
     p = gm.default_params_cs(); p.sam_unaligned = 1
-    for k, v in fields.items(): setattr(p, k, v)
+    opts = gm.PairOpts.default(g["mode"], g["ins"][0], g["ins"][1])
+    for k, v in fields.items():
+        if k.startswith("pair_"): setattr(opts, k[5:], v)         # gm_pair_opts_t: match_mode 3 / 2, half_paired (the -n 3 / -n 2 cases)
+        else: setattr(p, k, v)
     ix = gm.Index(g["contigs"], names=g["contig_names"], params=p)
     s = gm.Session(ix, params=p, max_batch_reads=4096)
-    got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_cs(g["m1"], g["m2"], g["names1"], g["names2"], mode=g["mode"],
-                                                                           min_insert=g["ins"][0], max_insert=g["ins"][1])
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_cs(g["m1"], g["m2"], g["names1"], g["names2"], opts=opts)
     st = s.stats
     s.close(); ix.close()
     assert got == want, (_first_diff(got, want), st)
+
+
+@pytest.mark.parametrize("pair_mode", ["opp-in", "opp-out", "col-fw", "col-bw"])
+@pytest.mark.parametrize("mm,hp", [(3, 1), (3, 0), (2, 1), (4, 0)])
+def test_paired_match_modes_in_every_pair_mode_vs_oracle(gm, oracle_lib, pair_mode, mm, hp):
+    """match_mode x half_paired x pair mode on the colour-space pairs of each pair mode, against the oracle (pinned to the reference on the opp-in and col-bw cases
+    above): SAM and the anchor / window counts.  In col-fw / col-bw the two mates' region deltas are not each other's negation (mapping.c:2381-2384,2407-2410), which
+    the flag pass of rule 3 has to respect."""
+    g = oa.load_golden_pairs("cs_pairs_50col_" + pair_mode)
+    o = oa.Session(g["contigs"], g["contig_names"], opts="colour=1;mp-match-mode=%d;half-paired=%d" % (mm, hp)); o.set(True, True); o.set_pairing(g["mode"], *g["ins"])
+    want = oa.sam_header(g["contigs"], g["contig_names"]) + o.map_pairs_sam(g["m1"], g["m2"], g["names1"], g["names2"], nthreads=8)
+    want_counts = o.last_pair_counts(); o.close()
+    p = gm.default_params_cs(); p.sam_unaligned = 1
+    opts = gm.PairOpts.default(g["mode"], g["ins"][0], g["ins"][1]); opts.match_mode = mm; opts.half_paired = hp
+    ix = gm.Index(g["contigs"], names=g["contig_names"], params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs_cs(g["m1"], g["m2"], g["names1"], g["names2"], opts=opts)
+    st = s.stats
+    s.close(); ix.close()
+    assert got == want, (_first_diff(got, want), st)
+    if st["mp_unfiltered"] == 0: assert (st["anchors"], st["windows"]) == want_counts, (st["anchors"], st["windows"], want_counts)
 
 
 @pytest.mark.parametrize("paired", [False, True])

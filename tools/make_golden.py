@@ -217,12 +217,16 @@ def cs_option_cases():
 CS_PAIR_OPTION_CASES = {        # tag -> (base colour-space pair golden, extra gmapper-cs options)
     "cs_pairs_local": ("cs_pairs_50col_opp-in", ["--local"]),
     "cs_pairs_local_colbw": ("cs_pairs_50col_col-bw", ["--local"]),
+    "cs_pairs_n3": ("cs_pairs_50col_opp-in", ["-n", "3"]),                                # paired match mode 3 in colour space; with --no-half-paired on a mode that reverses a mate
+    "cs_pairs_n3_colbw_nhp": ("cs_pairs_50col_col-bw", ["-n", "3", "--no-half-paired"]),
+    "cs_pairs_n2": ("cs_pairs_50col_opp-in", ["-n", "2"]),
 }
 
 
-def cs_pair_option_cases():
+def cs_pair_option_cases(only=None):
     """non-default options on the committed colour-space pairs (mates adjacent in one csfasta file, as cs_pair_case writes them): only the reference's SAM body is stored"""
     for tag, (base, extra) in CS_PAIR_OPTION_CASES.items():
+        if only and tag not in only: continue
         z = np.load(os.path.join(OUT, base + ".npz"))
         contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
         m1, m2 = z["mates1"], z["mates2"]; n = len(m1)
@@ -497,6 +501,8 @@ def main():
         post_kat_cases(); return
     if "--cs-kat-only" in sys.argv:
         cs_kat_cases(); return
+    if "--cs-pair-option-tags" in sys.argv:
+        cs_pair_option_cases(only=sys.argv[sys.argv.index("--cs-pair-option-tags") + 1].split(",")); return
     if "--cs-pair-options-only" in sys.argv:
         cs_pair_option_cases(); return
     if "--cs-options-only" in sys.argv:
