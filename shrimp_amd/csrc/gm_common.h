@@ -44,7 +44,7 @@ struct GmSeedDev {
 // Paired -n 3 (mate-pair region counts 2 / 3, ref: mapping.c:545-608,733-742,1080-1093): what the lookup and the window kernels need to know about the MATE.
 // A row holds, sorted, the regions one read-strand marked twice or more (its RG_GET_HAS_2 set); a region R of the other mate's opposite strand then has
 // RG_GET_MP_CNT(R) >= 2 exactly when some row entry lies in [R + dmin, R + dmax].  cnt[rs] > cap: the row did not fit (the consumers count the item, the host refuses).
-#define GM_MP_CAP 2048
+#define GM_MP_CAP 8192              // (150-base reads on 3 Gbp: 72 k list entries per read-strand over 1.46 M regions mark ~1 800 regions twice by chance alone)
 #define GM_MP_FLAG 0x80000000u
 struct GmMpDev {
   int mode;                           // 0: off; else the lookup's generic kernel runs in one of these modes (the window kernel reads rows / cnt / dmin / dmax whatever the mode):

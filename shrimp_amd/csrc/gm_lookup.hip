@@ -82,8 +82,9 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
   const int S = ix.n_slabs, rb = ix.region_bits;
   const uint32_t rmask = (1u << rb) - 1u, ovl = (uint32_t)ix.region_overlap;
   const bool all = ix.no_region_counts != 0;      // no region counts: every list entry survives (the marks are still made, nothing reads them)
-  __shared__ uint32_t sh_mp_row[MP ? GM_MP_CAP : 1]; __shared__ uint32_t sh_mp_n;            // MP 1: the row being collected; 2, 3, 4: the mate's row
-  __shared__ uint32_t sh_own_row[MP == 4 ? GM_MP_CAP : 1]; __shared__ uint32_t sh_own_n;       // MP 4: this read-strand's own row, with the flags the mate's pass left
+  uint32_t* const sh_mp_row = bm + bm_words;             // (dynamic LDS behind the region counters; MP launches only) MP 1: the row being collected; 2, 3, 4: the mate's row
+  uint32_t* const sh_own_row = sh_mp_row + GM_MP_CAP;     // MP 4: this read-strand's own row, with the flags the mate's pass left
+  __shared__ uint32_t sh_mp_n, sh_own_n;
 
   // ---- 0. read codes of this strand (strand 1 = reverse complement, ref: util.c:540-596) ----
   const uint32_t* rw = reads + (size_t)rd * read_words;
@@ -1196,7 +1197,9 @@ size_t gm_lookup_lds_bytes(const GmIndexDev& ix, int read_len) {
 }
 
 // the mate-pair modes of the generic kernel: their dynamic LDS limit (set once per device for both instantiations)
-static int k1_mp_lds(size_t lds) {
+static int k1_mp_lds(size_t& lds) {
+  lds += (size_t)2 * GM_MP_CAP * 4;                                   // the mate's row and this read-strand's own
+  if (lds + 64 > 160 * 1024) { gm_set_error("lookup kernel (mate-pair modes) needs %zu bytes of LDS", lds); return GM_E_ARG; }
   static GmLdsLimit lim_mp; size_t& configured = lim_mp.cur();
   if (lds > 48 * 1024 && lds > configured) {
     GM_HIP(hipFuncSetAttribute((const void*)k_lookup<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
