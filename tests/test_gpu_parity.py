@@ -1276,6 +1276,31 @@ def test_csfastq_files_match_reference_golden(gm, tmp_path):
     assert got == want, _first_diff(got, want)
 
 
+def test_100mbp_genome_every_list_entry_an_anchor_vs_oracle(gm, oracle_lib):
+    """-n 1 (unpaired) and -n 2 (paired) on the 100 Mbp genome of BASELINE configs[1]: ~1 600 list entries per read-strand all become anchors and windows -- rows beyond
+    K2's LDS tier (the heavy tier's re-emission keeps every entry too), window lists that grow past their first capacity -- against the CPU oracle, stage counts included."""
+    from shrimp_amd import synth
+    contigs = synth.make_genome(synth.contig_lengths("cfg2", 1.0), 2)
+    reads, _ = synth.make_reads(contigs, 3000, 100, 43)
+    pr, _ = synth.make_pairs(contigs, 1500, 100, 44); m1, m2 = pr[0::2], pr[1::2]
+    o = oa.Session(contigs, opts="cmw-mode=1;mp-match-mode=2")
+    want = o.map_sam(reads, nthreads=16)
+    o.set_pairing("opp-in", 100, 600)
+    want_p = o.map_pairs_sam(m1, m2, nthreads=16); want_counts = o.last_pair_counts(); o.close()
+    p = gm.default_params(); p.match_mode = 1
+    ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+    got = s.map_reads(reads); st = s.stats
+    kern = gm.lib().gm_last_lookup_kernel().decode()
+    opts = gm.PairOpts.default("opp-in", 100, 600); opts.match_mode = 2
+    got_p = s.map_pairs(m1, m2, opts=opts); st_p = s.stats
+    s.close(); ix.close()
+    assert kern == "k_lookup", kern                                           # the generic slab-sweep kernel: the others all apply the two-marks rule
+    assert got == want, (_first_diff(got, want), st)
+    assert st["anchors"] > 1000 * len(reads), st["anchors"]
+    assert got_p == want_p, (_first_diff(got_p, want_p), st_p)
+    assert (st_p["anchors"], st_p["windows"]) == want_counts, (st_p["anchors"], st_p["windows"], want_counts)
+
+
 def test_100mbp_genome_bucket_lookup_vs_oracle(gm, oracle_lib):
     """BASELINE configs[1] at full genome size: 4 x 25 Mbp (one slab, Poisson(6) lists -> k_lookup_bkt, the 64-byte bucket kernel: length + the first 15 positions
     per k-mer, longer lists continue in pos[]).  20 000 reads of the workload plus reads placed on lists LONGER than a bucket holds, against the CPU oracle."""
