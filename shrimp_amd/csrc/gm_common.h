@@ -55,6 +55,8 @@ struct GmMpDev {
                                       //    the mate marked twice that is count_mp >= 1;
                                       // 4: it keeps the entries of regions with count_mp >= 1 && count_main + count_mp >= 3, use_mp_region_counts == 3 (-n 3 without half-paired):
                                       //    the mate reaches the region (count_mp == 2), or the region is marked twice and its own row entry carries the flag
+                                      // 5: it keeps the entries of regions marked twice that the mate reaches -- count_main >= 2 && count_mp >= 2, use_mp_region_counts == 1
+                                      //    (-n 4 without half-paired): the exact path for sub-batches in which k_mp_filter's LDS tiers did not hold every pair
   int dmin[2], dmax[2];               // this mate's region deltas per strand (delta_region_min / _max, ref: mapping.c:2422-2430)
   int mate_dmin[2], mate_dmax[2];     // the mate's, per ITS strand (mode 3 asks the mate's question: in the col-fw / col-bw pair modes the two are not each other's negation)
   uint32_t* rows; const uint32_t* cnt;           // the mate's rows: read-strand rs of this mate looks at row rs ^ 1 (same pair, other strand)

@@ -106,7 +106,7 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
   __syncthreads();
   const int mp_dmin = MP >= 2 ? ix.mp.dmin[st] : 0, mp_dmax = MP >= 2 ? ix.mp.dmax[st] : 0;
   // count_mp >= 2 for region reg: the mate marked a region twice within [reg + dmin, reg + dmax] (ref: mapping.c:573-582)
-  auto mp_reach = [&](uint32_t reg) -> bool { return (MP == 2 || MP == 4) && gm_mp_reach(sh_mp_row, sh_mp_n, (long long)reg + mp_dmin, (long long)reg + mp_dmax); };
+  auto mp_reach = [&](uint32_t reg) -> bool { return (MP == 2 || MP == 4 || MP == 5) && gm_mp_reach(sh_mp_row, sh_mp_n, (long long)reg + mp_dmin, (long long)reg + mp_dmax); };
   // MP 3: this read-strand marks reg -- every region X the mate (strand 1 - st) marked twice that reaches it, X + mate_dmin <= reg <= X + mate_dmax, has count_mp >= 1
   const int mt_dmin = MP == 3 ? ix.mp.mate_dmin[1 - st] : 0, mt_dmax = MP == 3 ? ix.mp.mate_dmax[1 - st] : 0;
   auto mp_flag = [&](uint32_t reg) {
@@ -125,6 +125,7 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
   auto keep = [&](uint32_t reg, uint32_t rloc, bool strip) -> bool {
     if (MP == 3) { mp_flag(reg); if (strip) mp_flag(reg - 1u); return false; }
     if (MP == 4) return mp_ok3(reg, rloc) || (strip && mp_ok3(reg - 1u, rloc - 1u));
+    if (MP == 5) return (k1_has2(bm, rloc) && mp_reach(reg)) || (strip && k1_has2(bm, rloc - 1u) && mp_reach(reg - 1u));
     return all || k1_has2(bm, rloc) || mp_reach(reg) || (strip && (k1_has2(bm, rloc - 1u) || mp_reach(reg - 1u)));
   };
 
@@ -1206,6 +1207,7 @@ static int k1_mp_lds(size_t& lds) {
     GM_HIP(hipFuncSetAttribute((const void*)k_lookup<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GM_HIP(hipFuncSetAttribute((const void*)k_lookup<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GM_HIP(hipFuncSetAttribute((const void*)k_lookup<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GM_HIP(hipFuncSetAttribute((const void*)k_lookup<false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = lds;
   }
   return GM_OK;
@@ -1240,6 +1242,10 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
       hipLaunchKernelGGL((k_lookup<false, 3>), dim3(n_reads * 2), dim3(k1_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words,
                          max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
                          (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_stats, 0, (uint32_t*)nullptr);
+    else if (ix.mp.mode == 5)
+      hipLaunchKernelGGL((k_lookup<false, 5>), dim3(n_reads * 2), dim3(k1_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+                         max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
+                         (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_stats, 0, d_surv_seg);
     else if (ix.mp.mode == 4)
       hipLaunchKernelGGL((k_lookup<false, 4>), dim3(n_reads * 2), dim3(k1_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words,
                          max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
@@ -1338,6 +1344,12 @@ int gm_launch_lookup_redo(const GmIndexDev& ix, const uint32_t* d_reads, int n_r
   int max_n_kmers, NL, bm_words; size_t lds;
   k1_geometry(ix, read_len, &max_n_kmers, &NL, &bm_words, &lds);
   if (n_heavy == 0) return GM_OK;
+  if (ix.mp.mode == 5) {
+    int rc = k1_mp_lds(lds); if (rc) return rc;
+    hipLaunchKernelGGL((k_lookup<false, 5>), dim3(n_heavy), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+                       max_n_kmers, NL, bm_words, d_out, (uint32_t*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0,
+                       d_redo_list, d_redo_off, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_stats, 0, (uint32_t*)nullptr);
+  } else
   if (ix.mp.mode == 4) {
     int rc = k1_mp_lds(lds); if (rc) return rc;
     hipLaunchKernelGGL((k_lookup<false, 4>), dim3(n_heavy), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,

@@ -1035,12 +1035,13 @@ def test_no_half_paired_mate_pair_region_counts(gm, oracle_lib, base, tag):
     st_default = s.stats
     s.close(); ix.close()
     assert got == want, (_first_diff(got, want), st)
-    # gm_map_stats_t.mp_unfiltered: (pair, strand) items beyond the filter's LDS tiers, left as a superset of the reference's anchors (paired mode).
-    # None on the uniform genome -- the filter is exact for every pair there; the repeat-rich stress genome has some (heavy-tier read-strands), counted, same SAM.
-    if base.startswith("cfg5s"): assert st["mp_unfiltered"] == 0, st["mp_unfiltered"]
-    else: assert 0 < st["mp_unfiltered"] < len(g["m1"]) // 4, st["mp_unfiltered"]
+    # gm_map_stats_t.mp_unfiltered: (pair, strand) items beyond the filter's LDS tiers.  None may be left in a result: a sub-batch that has some (the repeat-rich
+    # stress genome: heavy-tier read-strands) is redone through the generic kernel's mate-pair modes (rows of regions marked twice, rule 1 in the sweep), which is exact
+    # for rows of any length -- the window count equals the oracle's on both genomes.
+    assert st["mp_unfiltered"] == 0, st["mp_unfiltered"]
+    if not base.startswith("cfg5s"): assert st["retries"] >= 1, st
     assert st["windows"] < st_default["windows"], (st["windows"], st_default["windows"])
-    if base.startswith("cfg5s"): assert st["windows"] == want_windows, (st["windows"], want_windows)     # (no read-strand beyond the LDS tiers on the uniform genome)
+    assert st["windows"] == want_windows, (st["windows"], want_windows)
 
 
 @pytest.mark.parametrize("mode", ["opp-in", "opp-out", "col-fw", "col-bw"])
@@ -1097,7 +1098,7 @@ def test_paired_match_modes_in_every_pair_mode_vs_oracle(gm, oracle_lib, pair_mo
     st = s.stats
     s.close(); ix.close()
     assert got == want, (_first_diff(got, want), st)
-    if st["mp_unfiltered"] == 0: assert (st["anchors"], st["windows"]) == want_counts, (st["anchors"], st["windows"], want_counts)
+    assert st["mp_unfiltered"] == 0 and (st["anchors"], st["windows"]) == want_counts, (st["anchors"], st["windows"], want_counts)
 
 
 @pytest.mark.parametrize("paired", [False, True])
