@@ -231,8 +231,8 @@ typedef struct gm_map_stats {
   uint64_t exact_order_reads;                      /* read-strands that needed heap-order emulation */
   uint64_t retries;                                /* capacity-overflow re-runs */
   uint64_t survivors_pruned;                       /* survivors with no neighbour within window_len + read_len, removed before K2 (exact) */
-  uint64_t mp_unfiltered;                          /* --no-half-paired: (pair, strand) items the mate-pair region filter had to leave unfiltered (beyond its LDS tiers): a
-                                                      superset of the reference's anchors for those; 0 means the filter was exact for every pair of the call */
+  uint64_t mp_unfiltered;                          /* mate-pair region counts: always 0 in a result -- a sub-batch with (pair, strand) items beyond the filter's LDS tiers is
+                                                      redone through the exact row-based path (counted in retries); rows beyond their capacity fail the call (GM_E_OVERFLOW) */
   uint64_t post_sw_host_redo;                      /* colour space: device post_sw results the host routine redid because a value to be rounded (AS, MAPQ, Z0 / Z1) lay at a boundary */
   double   ms_lookup, ms_anchors, ms_pass1, ms_select, ms_pass2, ms_host;   /* device time per stage (events) */
 } gm_map_stats_t;
