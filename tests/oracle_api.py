@@ -259,6 +259,13 @@ CS_PAIR_OPTION_CASES = {
 }
 
 
+# -M mirna (gmapper.c:1497-1517 + gmapper-defaults.h:230-238): (oracle option string, gm_params_t fields, seeds)
+MIRNA_SEEDS = ["00111111001111111100", "00111111110011111100", "00111111111100111100", "00111111111111001100", "00111111111111110000"]
+MIRNA_MODE = ("hash-spaced-kmers=1;seeds=%s;local=1;ungapped=1;cmw-mode=1;match-window=100" % ",".join(MIRNA_SEEDS),
+              dict(hash_seeds=1, ungapped=1, local_alignment=1, anchor_width=0, a_gap_open_score=-255, b_gap_open_score=-255, hash_filter_calls=0, match_mode=1,
+                   window_len=100.0), MIRNA_SEEDS)
+
+
 def load_option_sam(base, tag):
     with gzip.open(os.path.join(ROOT, "tests", "golden", "%s@%s.sam.gz" % (base, tag)), "rb") as f:
         return f.read()

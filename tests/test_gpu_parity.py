@@ -286,6 +286,20 @@ def test_option_sets_match_reference_golden(gm, tag):
     assert got == want, (_first_diff(got, want), st)
 
 
+def test_mirna_mode_matches_reference_golden(gm):
+    """gmapper -M mirna (gmapper.c:1497-1517): the bundle -H, -U, anchor width 0, gap opens -255, no f1 cache, -n 1, window 100 %, --local with the mode's five
+    seeds (span 20, weight 14, zeros at both ends) on 22-base reads -- byte-identical SAM"""
+    contigs, reads, want = oa.load_golden("mirna_22bp")
+    _, fields, seeds = oa.MIRNA_MODE
+    p = gm.default_params()
+    for k, v in fields.items(): setattr(p, k, v)
+    ix = gm.Index(contigs, seeds=seeds, params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+    got = oa.sam_header(contigs) + s.map_reads(reads)
+    st = s.stats
+    s.close(); ix.close()
+    assert got == want, (_first_diff(got, want), st)
+
+
 def test_n1_on_noisy_reads_matches_reference_golden(gm):
     """match_mode 1 (-n 1) where it matters: 70-base reads with 9 % substitutions, 57 of which map only because ONE k-mer match is enough -- the lookup kernel keeps
     every list entry (no region counts, gmapper.c:2610-2616), a window per anchor, pass 1 with min_matches 1"""

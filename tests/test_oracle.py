@@ -102,6 +102,14 @@ def test_oracle_option_sets_match_reference(tag, oracle_lib):
     assert got == want, "oracle SAM differs from the reference for option set %s" % tag
 
 
+def test_oracle_mirna_mode_matches_reference(oracle_lib):
+    """gmapper -M mirna on 22-base reads: hashed seeds of span 20 with zeros at both ends, -U, -n 1, window 100 %, --local"""
+    contigs, reads, want = oa.load_golden("mirna_22bp")
+    s = oa.Session(contigs, opts=oa.MIRNA_MODE[0])
+    got = oa.sam_header(contigs) + s.map_sam(reads, nthreads=4); s.close()
+    assert got == want and got.count(b"\n") > 2400
+
+
 def test_oracle_n1_on_noisy_reads_matches_reference(oracle_lib):
     """-n 1 where it matters: 70-base reads with 9 % substitutions, 57 of which map only because ONE k-mer match is enough (no region counts, a window per
     anchor, gmapper.c:2610-2625)"""

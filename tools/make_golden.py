@@ -95,6 +95,14 @@ def n1_noisy_case():
     run_case("n1_onehit_60bp", contigs, one, extra=("-n", "1", "-h", "30%"))
 
 
+def mirna_case():
+    """-M mirna: the mode's option bundle (gmapper.c:1497-1517: -H, -U, anchor width 0, gap opens -255, no f1 cache, -n 1, window 100 %, --local, no mapping
+    qualities) with its five default seeds of span 20 / weight 14 (leading and trailing zeros, gmapper-defaults.h:230-238) on 22-base reads"""
+    contigs = synth.make_genome([300000, 200000], 91)
+    reads, _ = synth.make_reads(contigs, 3000, 22, 92, p_sub=0.04, p_ins=0.0, p_del=0.0)
+    run_case("mirna_22bp", contigs, reads, extra=("-M", "mirna"))
+
+
 def read_fa(path):
     names, seqs = [], []
     for line in open(path, "rb"):
@@ -513,6 +521,8 @@ def main():
         option_cases(); return
     if "--option-tags" in sys.argv:                                   # --option-tags pairs_n3,cfg5_n3: just these
         option_cases(only=sys.argv[sys.argv.index("--option-tags") + 1].split(",")); return
+    if "--mirna-only" in sys.argv:
+        mirna_case(); return
     if "--n1-only" in sys.argv:
         n1_noisy_case(); return
     if "--paired-only" in sys.argv:
@@ -531,6 +541,7 @@ def main():
     paired_cases()
     option_cases()
     n1_noisy_case()
+    mirna_case()
     cs_option_cases()
     index_cases()
     cs_kat_cases()
