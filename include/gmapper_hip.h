@@ -80,6 +80,9 @@ typedef struct gm_params {
                                                   (ref: common/output.c:118-262 output_pretty).  Unaligned reads print nothing in 1 / 2; in paired mode every mate has its
                                                   own line under its own name, and the unmapped mate of a half-paired mapping prints ">name" (gmapper/output.c:292-294).  0 */
   int print_read_seq;                          /* -R: the read's sequence as a last column of the SHRiMP-format line (ref: gmapper.h Rflag, output.c:310-313)  0 */
+  int strand_only;                             /* 1: -F / --positive (only the read as given), 2: -C / --negative (only its reverse complement): the other strand gets no
+                                                  anchor list (ref: mapping.c:879-880, gmapper.c:1979-1992).  Unpaired only -- paired mode maps both strands, as the
+                                                  reference does after its warning (gmapper.c:2448-2451).  0 */
 } gm_params_t;
 
 void gm_params_default(gm_params_t *p);        /* letter-space defaults of the reference binary (gmapper-ls) */

@@ -94,6 +94,7 @@ struct Params {
   bool gapless = false;           // -U: ungapped filter (gapless_sw; gmapper.c:2057-2062 also sets anchor_width 0, gap opens -255, no f1 cache)
   bool Tflag = true, Gflag = true, compute_mapping_qualities = true;
   bool strata = false;
+  bool Fflag = true, Cflag = true;  // -F / -C: positive / negative strand only (gmapper.c:1979-1992,2444-2451); both in paired mode
   int max_alignments = 0;
   bool sam_unaligned = false;
   int longest_read_len = 1000;
@@ -1266,6 +1267,7 @@ struct Mapper {
     const int mp_mode = re.paired ? mp_region_mode() : 0;
     re.anchors[st].clear();
     if (re.mapidx[st].empty()) return;
+    if (!re.paired && ((st == 0 && !P.Fflag) || (st == 1 && !P.Cflag))) return;                    // mapping.c:879-880
     HeapUU h; h.a.resize((size_t)ns * re.max_n_kmers + 1);
     std::vector<uint32_t> idx((size_t)ns * re.max_n_kmers, 0);
     std::vector<int> anchor_cache(re.read_len, -1);

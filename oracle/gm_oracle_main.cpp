@@ -217,6 +217,8 @@ static void apply_opts(Params& P, const char* opts) {
     else if (k == "report") P.num_outputs = (int)d; else if (k == "anchor-width") P.anchor_width = (int)d;
     else if (k == "cutoff") P.list_cutoff = (uint32_t)d; else if (k == "strata") P.strata = d != 0;
     else if (k == "max-alignments") P.max_alignments = (int)d;
+    else if (k == "positive") { if (d != 0) { P.Fflag = true; P.Cflag = false; } }      // -F
+    else if (k == "negative") { if (d != 0) { P.Cflag = true; P.Fflag = false; } }      // -C
     else if (k == "mp-match-mode") P.mp_match_mode = (int)d;     // 4 (default) / 3: the paired option set's match mode; 0 switches the mate-pair region counts off (sensitivity checks)
     else if (k == "half-paired") P.half_paired = d != 0;        // --no-half-paired: mate-pair region counts, no unpaired rescue (gmapper.c:2657-2683)
     else if (k == "local") { P.Gflag = d == 0; if (!P.Gflag) P.compute_mapping_qualities = false; }   // --local (gmapper.c:2303-2305,2325-2328)

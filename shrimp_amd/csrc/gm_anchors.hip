@@ -430,12 +430,13 @@ k_anchors(GmIndexDev ix, GmScoreDev sc, int n_reads, int read_len, int window_le
   if (BIG) {
     if ((int)blockIdx.x >= n_heavy) return;
     rs = (int)heavy_list[blockIdx.x];
+    if ((sc.skip_strands >> (rs & 1)) & 1) { if (lane == 0) hit_cnt[rs] = 0; return; }                   // -C / -F
     n = (int)seg_n[blockIdx.x];
     const uint64_t o = seg_off[blockIdx.x];
     ws.key = big_keys + o; ws.aux = big_aux + o; ws.nxt = (idx_t*)(big_nxt + o); ws.ord = (idx_t*)(big_ord + o);
   } else {
     rs = blockIdx.x;
-    const uint32_t n_all = surv_cnt[rs];
+    const uint32_t n_all = ((sc.skip_strands >> (rs & 1)) & 1) ? 0u : surv_cnt[rs];                     // -C / -F: this strand has no anchor list (ref: mapping.c:879-880)
     if (n_all == 0 || n_all > (uint32_t)scap) { if (lane == 0 && lmin == 0) hit_cnt[rs] = 0; return; }   // > scap: heavy tier
     if (n_all <= (uint32_t)lmin || n_all > (uint32_t)lcap) return;                       // another launch's
     n = (int)n_all;

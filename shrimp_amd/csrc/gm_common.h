@@ -97,6 +97,7 @@ struct GmScoreDev {
   int a_go, a_ge, b_go, b_ge;         // positive penalties (= -score), as sw_vector_setup stores them
   int anchor_width;
   int match_mode, min_matches;
+  int skip_strands;                   // bit st set: strand st gets no anchor list (-C / -F, ref: mapping.c:879-880)
   int num_tmp_outputs;
   int tiebreak_rev;
   int hash_filter_calls;

@@ -61,7 +61,7 @@ extern "C" void gm_params_default(gm_params_t* p) {
   p->match_mode = 2; p->num_outputs = 10; p->num_tmp_outputs = 30; p->anchor_width = 8;
   p->region_bits = 11; p->region_overlap = 50; p->list_cutoff = 0; p->hash_filter_calls = 1; p->tiebreak_rev = 1;
   p->sam_unaligned = 0; p->longest_read_len = 1000; p->strata = 0; p->max_alignments = 0;
-  p->colour_space = 0; p->crossover_score = -20; p->indel_taboo_len = 0; p->pr_xover = 0.03; p->local_alignment = 0; p->ungapped = 0; p->hash_seeds = 0; p->output_format = 0; p->print_read_seq = 0;
+  p->colour_space = 0; p->crossover_score = -20; p->indel_taboo_len = 0; p->pr_xover = 0.03; p->local_alignment = 0; p->ungapped = 0; p->hash_seeds = 0; p->output_format = 0; p->print_read_seq = 0; p->strand_only = 0;
 }
 // the gmapper-cs binary's defaults (ref: gmapper.c:1748-1755, gmapper-defaults.h:52-58,64-66)
 extern "C" void gm_params_default_cs(gm_params_t* p) {
@@ -75,6 +75,7 @@ static GmScoreDev make_score(const gm_params_t& P) {
   s.mismatch = P.colour_space ? P.match_score + P.crossover_score : P.mismatch_score;   // what f1_setup hands the vector filter (ref: gmapper.c:2933-2936)
   s.a_go = -P.a_gap_open_score; s.a_ge = -P.a_gap_extend_score; s.b_go = -P.b_gap_open_score; s.b_ge = -P.b_gap_extend_score;
   s.anchor_width = P.anchor_width; s.match_mode = P.match_mode; s.min_matches = P.match_mode;   // ref: gmapper.c:2625
+  s.skip_strands = P.strand_only == 1 ? 2 : (P.strand_only == 2 ? 1 : 0);                       // -F: no strand 1; -C: no strand 0
   s.num_tmp_outputs = P.num_tmp_outputs; s.tiebreak_rev = P.tiebreak_rev; s.hash_filter_calls = P.hash_filter_calls; s.local = P.local_alignment ? 1 : 0; s.gapless = P.ungapped ? 1 : 0;
   auto frac = [](double thr, double* f, int* a) { if (thr < 0) { *f = -1.0; *a = (int)(-thr); } else { *f = thr / 100.0; *a = 0; } };
   frac(P.window_gen_threshold, &s.wgen_thr_frac, &s.wgen_abs);
@@ -480,6 +481,7 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
     GM_HIP(hipMalloc(&s->d_qtab, qt.size() * 8));
     GM_HIP(hipMemcpy(s->d_qtab, qt.data(), qt.size() * 8, hipMemcpyHostToDevice));
   }
+  if (s->P.strand_only < 0 || s->P.strand_only > 2) { delete s; gm_set_error("strand_only %d: 0 (both), 1 (-F) or 2 (-C)", params ? params->strand_only : 0); return GM_E_ARG; }
   if (s->P.match_mode != 1 && s->P.match_mode != 2) { delete s; gm_set_error("match_mode %d: 1 or 2 (ref: gmapper.c:2624; 3 and 4 are paired-mode settings with mate-pair region counts)", s->P.match_mode); return GM_E_ARG; }
   if (s->P.ungapped && !s->P.local_alignment) { delete s; gm_set_error("ungapped mode needs local alignment (ref: gmapper.c:2330-2333)"); return GM_E_ARG; }
   if ((s->P.colour_space != 0) != (ix->params.colour_space != 0)) { delete s; gm_set_error("session and index disagree on colour space"); return GM_E_ARG; }

@@ -212,6 +212,9 @@ OPTION_CASES = {
     "ungapped60_n1": ("stress_60bp", "local=1;ungapped=1;cmw-mode=1;full-threshold=45;vec-threshold=45",
                       dict(local_alignment=1, ungapped=1, anchor_width=0, a_gap_open_score=-255, b_gap_open_score=-255, hash_filter_calls=0, match_mode=1,
                            sw_full_threshold=45.0, sw_vect_threshold=45.0), None),
+    # -F / -C: one strand only (mapping.c:879-880)
+    "positive": ("stress_60bp", "positive=1", dict(strand_only=1), None),
+    "negative": ("stress_60bp", "negative=1", dict(strand_only=2), None),
     # -n 1: use_region_counts off -- all list entries are anchors, a window per anchor, one k-mer match is enough (gmapper.c:2610-2625)
     "n1": ("stress_60bp", "cmw-mode=1", dict(match_mode=1), None),
     # -H: hashed seeds (4^12 lists per seed, any weight)

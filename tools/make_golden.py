@@ -177,6 +177,9 @@ OPTION_CASES = {
     "local_cfg2": ("cfg2s_100bp_2Mbp", ["--local"]),
     "ungapped":  ("stress_100bp_unal", ["--local", "-U", "--sam-unaligned"]),
     "ungapped60_n1": ("stress_60bp", ["--local", "-U", "-n", "1", "-h", "45%"]),
+    # -F / -C: only the read as given / only its reverse complement
+    "positive": ("stress_60bp", ["-F"]),
+    "negative": ("stress_60bp", ["-C"]),
     # -n 1 on its own: no region counts at all, every list entry becomes an anchor and every anchor a window (gmapper.c:2610-2624)
     "n1":        ("stress_60bp", ["-n", "1"]),
     "hashed":    ("stress_60bp", ["-H"]),
