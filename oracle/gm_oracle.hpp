@@ -94,6 +94,7 @@ struct Params {
   bool gapless = false;           // -U: ungapped filter (gapless_sw; gmapper.c:2057-2062 also sets anchor_width 0, gap opens -255, no f1 cache)
   bool Tflag = true, Gflag = true, compute_mapping_qualities = true;
   bool strata = false;
+  bool single_best_mapping = false, all_contigs = false, improper_mappings = true;   // --single-best-mapping, --all-contigs, --no-improper-mappings (gmapper.c:2252-2268)
   bool Fflag = true, Cflag = true;  // -F / -C: positive / negative strand only (gmapper.c:1979-1992,2444-2451); both in paired mode
   int max_alignments = 0;
   bool sam_unaligned = false;
@@ -1647,7 +1648,7 @@ struct Mapper {
     for (auto& c : cigar) { snprintf(buf, sizeof buf, "%d%c", c.first, c.second); out += buf; }
     out += "\t*\t0\t0\t"; out += seq; out += "\t"; out += qual;
     snprintf(buf, sizeof buf, "\tAS:i:%d", rh->score_full); out += buf;
-    if (P.compute_mapping_qualities) { snprintf(buf, sizeof buf, "\tZ0:i:%d\tZ1:i:%d", double_to_neglog(s.z0), double_to_neglog(s.z1)); out += buf; }
+    if (P.compute_mapping_qualities && !P.all_contigs) { snprintf(buf, sizeof buf, "\tZ0:i:%d\tZ1:i:%d", double_to_neglog(s.z0), double_to_neglog(s.z1)); out += buf; }   // output.c:691
     snprintf(buf, sizeof buf, "\tNM:i:%d", s.mismatches + s.deletions + s.insertions); out += buf;
     if (P.colour) {                             // output.c:717-730
       if (P.Qflag) { out += "\tCQ:Z:"; out += re.qual; }
@@ -1667,6 +1668,12 @@ struct Mapper {
         h->sfr.z0 = h->sfr.posterior; h->sfr.z1 = z1;
         h->sfr.mqv = qv_from_pr_corr(h->sfr.posterior / z1);
         if (h->sfr.mqv < 4) h->sfr.mqv = 0;
+      }
+      if (P.single_best_mapping) {                                 // output.c:977-984: the first mapping with the highest quality
+        size_t mx = 0;
+        for (size_t i = 1; i < p2.size(); i++) if (p2[i]->sfr.mqv > p2[mx]->sfr.mqv) mx = i;
+        hit_output(re, p2[mx], out);
+        return;
       }
     }
     for (auto* h : p2) hit_output(re, h, out);
@@ -2097,7 +2104,7 @@ struct Mapper {
       out += qual;
     } else out += "*";
     snprintf(buf, sizeof buf, "\tAS:i:%d", rh->score_full); out += buf;
-    if (P.compute_mapping_qualities) {
+    if (P.compute_mapping_qualities && !P.all_contigs) {
       if (rh != nullptr && rh_mp != nullptr && !improper)
         snprintf(buf, sizeof buf, "\tZ2:i:%d\tZ3:i:%d\tZ4:i:%d\tZ6:i:%d", double_to_neglog(s.z2), double_to_neglog(s.z3),
                  double_to_neglog(s.pr_top_random_at_location), double_to_neglog(s.insert_size_denom));
@@ -2116,15 +2123,66 @@ struct Mapper {
   }
 
   // readpair_output (output.c:1070-1291), default flags (no single-best-mapping)
+  // get_idx_mp_max_mqv (output.c:1049-1067): the pair that holds pool hit idx of mate nip and, of those, the other mate's best mapping quality (first one)
+  int get_idx_mp_max_mqv(const PairEntry& pe, int nip, int idx) const {
+    int best_other = -1, idx_pair = -1;
+    for (int pi : pe.pool[nip][idx].paired_hit_idx) {
+      const Hit& o = pe.pool[1 - nip][pe.final_paired_hits[pi].rh_idx[1 - nip]];
+      if (o.sfr.mqv > best_other) { best_other = o.sfr.mqv; idx_pair = pi; }
+    }
+    return idx_pair;
+  }
   void readpair_output(PairEntry& pe, std::string& out) const {
-    if (P.compute_mapping_qualities) compute_paired_mqv(pe);
-    for (auto& hp : pe.final_paired_hits) {
-      Hit* rh1 = &pe.pool[0][hp.rh_idx[0]]; Hit* rh2 = &pe.pool[1][hp.rh_idx[1]];
+    int first[3] = {0, 0, 0}, last[3] = {(int)pe.re[0]->final_unpaired_hits.size(), (int)pe.re[1]->final_unpaired_hits.size(), (int)pe.final_paired_hits.size()};
+    if (P.compute_mapping_qualities) {
+      compute_paired_mqv(pe);
+      if (P.single_best_mapping && (last[2] > 0 || last[0] > 0 || last[1] > 0)) {                          // output.c:1094-1235
+        int max_idx_unpaired[2] = {-1, -1}, max_idx_paired[2] = {-1, -1}, max_mqv_unpaired[2] = {-1, -1}, max_mqv_paired[2] = {-1, -1};
+        for (int nip = 0; nip < 2; nip++) {
+          const auto& U = pe.re[nip]->final_unpaired_hits;
+          for (int i = 0; i < (int)U.size(); i++) if (U[i].sfr.mqv > max_mqv_unpaired[nip]) { max_mqv_unpaired[nip] = U[i].sfr.mqv; max_idx_unpaired[nip] = i; }
+          for (int i = 0; i < (int)pe.pool[nip].size(); i++) if (pe.pool[nip][i].sfr.mqv > max_mqv_paired[nip]) { max_mqv_paired[nip] = pe.pool[nip][i].sfr.mqv; max_idx_paired[nip] = i; }
+        }
+        if (!P.all_contigs) {                                       // the top mapping of each class
+          for (int nip = 0; nip < 2; nip++) if (max_idx_unpaired[nip] >= 0) { first[nip] = max_idx_unpaired[nip]; last[nip] = first[nip] + 1; }
+          const int best_nip = max_mqv_paired[0] > max_mqv_paired[1] ? 0 : 1;
+          if (max_mqv_paired[best_nip] >= 0) { first[2] = get_idx_mp_max_mqv(pe, best_nip, max_idx_paired[best_nip]); last[2] = first[2] + 1; }
+        } else {                                                    // the top mapping over all classes
+          int max_mqv[2], max_is_paired[2], max_idx[2];
+          for (int nip = 0; nip < 2; nip++) {
+            if (max_mqv_unpaired[nip] > max_mqv_paired[nip]) { max_mqv[nip] = max_mqv_unpaired[nip]; max_is_paired[nip] = 0; max_idx[nip] = max_idx_unpaired[nip]; }
+            else { max_mqv[nip] = max_mqv_paired[nip]; max_is_paired[nip] = 1; max_idx[nip] = max_idx_paired[nip]; }
+          }
+          const int best_nip = max_mqv[0] >= max_mqv[1] ? 0 : 1;
+          if (max_is_paired[best_nip] == 1) {
+            last[0] = 0; last[1] = 0; first[2] = get_idx_mp_max_mqv(pe, best_nip, max_idx[best_nip]); last[2] = first[2] + 1;
+          } else {                                                  // an unpaired mapping wins: can it be paired with the other mate's best one, across contigs?
+            auto& OU = pe.re[1 - best_nip]->final_unpaired_hits;
+            int idx_best_other = -1; double max_other_z0 = 0.0;
+            for (int i = 0; i < (int)OU.size(); i++) if (OU[i].sfr.z0 > max_other_z0) { max_other_z0 = OU[i].sfr.z0; idx_best_other = i; }
+            int best_other_mqv = -1;
+            if (idx_best_other >= 0) best_other_mqv = qv_from_pr_corr(max_other_z0 / OU[idx_best_other].sfr.z1);
+            if (!P.improper_mappings || max_mqv_unpaired[best_nip] < 10 || best_other_mqv < 10) {
+              last[2] = 0; last[1 - best_nip] = 0; first[best_nip] = max_idx[best_nip]; last[best_nip] = first[best_nip] + 1;
+            } else {
+              HitPair hp; hp.rh[best_nip] = &pe.re[best_nip]->final_unpaired_hits[max_idx[best_nip]]; hp.rh[1 - best_nip] = &OU[idx_best_other];
+              hp.score_max = hp.rh[0]->score_max + hp.rh[1]->score_max; hp.insert_size = get_insert_size(hp.rh[best_nip], hp.rh[1 - best_nip]); hp.improper_mapping = true;
+              pe.final_paired_hits.push_back(hp);
+              last[0] = 0; last[1] = 0; first[2] = (int)pe.final_paired_hits.size() - 1; last[2] = first[2] + 1;
+            }
+          }
+        }
+      }
+    }
+    for (int i = first[2]; i < last[2]; i++) {
+      HitPair& hp = pe.final_paired_hits[i];
+      Hit* rh1 = hp.rh[0] ? hp.rh[0] : &pe.pool[0][hp.rh_idx[0]]; Hit* rh2 = hp.rh[1] ? hp.rh[1] : &pe.pool[1][hp.rh_idx[1]];
       hit_output_paired(*pe.re[0], rh1, rh2, true, hp.improper_mapping, out);
       hit_output_paired(*pe.re[1], rh2, rh1, false, hp.improper_mapping, out);
     }
     for (int nip = 0; nip < 2; nip++)
-      for (auto& rh : pe.re[nip]->final_unpaired_hits) {
+      for (int ui = first[nip]; ui < last[nip]; ui++) {
+        Hit& rh = pe.re[nip]->final_unpaired_hits[ui];
         Read& rep = *pe.re[nip];
         if (rep.first_in_pair) { hit_output_paired(rep, &rh, nullptr, true, false, out); hit_output_paired(*rep.mate_pair, nullptr, &rh, false, false, out); }
         else { hit_output_paired(*rep.mate_pair, nullptr, &rh, true, false, out); hit_output_paired(rep, &rh, nullptr, false, false, out); }

@@ -217,6 +217,10 @@ static void apply_opts(Params& P, const char* opts) {
     else if (k == "report") P.num_outputs = (int)d; else if (k == "anchor-width") P.anchor_width = (int)d;
     else if (k == "cutoff") P.list_cutoff = (uint32_t)d; else if (k == "strata") P.strata = d != 0;
     else if (k == "max-alignments") P.max_alignments = (int)d;
+    else if (k == "single-best-mapping") P.single_best_mapping = d != 0;
+    else if (k == "all-contigs") P.all_contigs = d != 0;
+    else if (k == "no-mapping-qualities") { if (d != 0) P.compute_mapping_qualities = false; }
+    else if (k == "no-improper-mappings") P.improper_mappings = d == 0;
     else if (k == "positive") { if (d != 0) { P.Fflag = true; P.Cflag = false; } }      // -F
     else if (k == "negative") { if (d != 0) { P.Cflag = true; P.Fflag = false; } }      // -C
     else if (k == "mp-match-mode") P.mp_match_mode = (int)d;     // 4 (default) / 3: the paired option set's match mode; 0 switches the mate-pair region counts off (sensitivity checks)

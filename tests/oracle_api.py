@@ -212,6 +212,20 @@ OPTION_CASES = {
     "ungapped60_n1": ("stress_60bp", "local=1;ungapped=1;cmw-mode=1;full-threshold=45;vec-threshold=45",
                       dict(local_alignment=1, ungapped=1, anchor_width=0, a_gap_open_score=-255, b_gap_open_score=-255, hash_filter_calls=0, match_mode=1,
                            sw_full_threshold=45.0, sw_vect_threshold=45.0), None),
+    # output policy (output.c:955-1008,1070-1291)
+    "single_best": ("stress_60bp", "single-best-mapping=1", dict(single_best_mapping=1), None),
+    "all_contigs": ("stress_60bp", "all-contigs=1", dict(all_contigs=1), None),
+    "no_mapq": ("stress_100bp_unal", "no-mapping-qualities=1", dict(no_mapping_qualities=1, sam_unaligned=1), None),
+    "pairs_single_best": ("stress_pairs_2x100", "single-best-mapping=1", dict(single_best_mapping=1), None),
+    "pairs_single_best_all": ("stress_pairs_2x100", "single-best-mapping=1;all-contigs=1", dict(single_best_mapping=1, all_contigs=1), None),
+    "pairs_single_best_all_noimp": ("stress_pairs_2x100", "single-best-mapping=1;all-contigs=1;no-improper-mappings=1",
+                                    dict(single_best_mapping=1, all_contigs=1, no_improper_mappings=1), None),
+    "pairs_no_mapq": ("stress_pairs_2x100", "no-mapping-qualities=1", dict(no_mapping_qualities=1), None),
+    # chimeric pairs (mates from different places): improper pairs of two unpaired mappings with --single-best-mapping --all-contigs (output.c:1178-1226)
+    "chim_single_best_all": ("chimeric_pairs_2x150", "single-best-mapping=1;all-contigs=1", dict(single_best_mapping=1, all_contigs=1), None),
+    "chim_single_best_all_noimp": ("chimeric_pairs_2x150", "single-best-mapping=1;all-contigs=1;no-improper-mappings=1",
+                                   dict(single_best_mapping=1, all_contigs=1, no_improper_mappings=1), None),
+    "chim_single_best": ("chimeric_pairs_2x150", "single-best-mapping=1", dict(single_best_mapping=1), None),
     # -F / -C: one strand only (mapping.c:879-880)
     "positive": ("stress_60bp", "positive=1", dict(strand_only=1), None),
     "negative": ("stress_60bp", "negative=1", dict(strand_only=2), None),

@@ -270,7 +270,7 @@ def test_option_sets_match_reference_golden(gm, tag):
     want = oa.load_option_sam(base, tag)
     p = gm.default_params()
     for k, v in fields.items(): setattr(p, k, v)
-    if base.startswith("stress_pairs"):
+    if base.startswith("stress_pairs") or base.startswith("chimeric_pairs"):
         g = oa.load_golden_pairs(base)
         ix = gm.Index(g["contigs"], names=g["contig_names"], seeds=seeds, params=p)
         s = gm.Session(ix, params=p, max_batch_reads=4096)

@@ -88,7 +88,7 @@ def test_oracle_option_sets_match_reference(tag, oracle_lib):
     cutoff; paired --strata) against the reference binary run with the same options"""
     base, opts, _, _ = oa.OPTION_CASES[tag]
     want = oa.load_option_sam(base, tag)
-    if base.startswith("stress_pairs"):
+    if base.startswith("stress_pairs") or base.startswith("chimeric_pairs"):
         g = oa.load_golden_pairs(base)
         s = oa.Session(g["contigs"], g["contig_names"], opts=opts)
         s.set_pairing(g["mode"], *g["ins"])

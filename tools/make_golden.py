@@ -164,8 +164,23 @@ def paired_cases():
                   [b"q%d:1" % i for i in range(n)], [b"q%d:2" % i for i in range(n)], "opp-in", (100, 600))
 
 
+def chimeric_pairs_case():
+    """pairs whose mates come from different places (every third pair of the cfg5-like set takes the second mate of another pair): both mates map on their own, never
+    as a pair -- what --single-best-mapping --all-contigs turns into IMPROPER pairs (output.c:1178-1226); the default run is the base golden"""
+    z = np.load(os.path.join(OUT, "cfg5s_2x150_1Mbp.npz"))
+    contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
+    N = 600
+    m1 = z["mates1"][:N].copy(); m2 = z["mates2"][:N].copy()
+    src = np.arange(N); src[0::3] = (src[0::3] + 301) % N
+    m2 = m2[src]
+    run_pair_case("chimeric_pairs_2x150", contigs, [bytes(x) for x in z["contig_names"]], m1, m2, [b"c%d/1" % i for i in range(N)], [b"c%d/2" % i for i in range(N)], "opp-in", (100, 600))
+
+
 OPTION_CASES = {
     # tag: (base golden whose inputs are reused, reference command-line options)
+    "chim_single_best_all": ("chimeric_pairs_2x150", ["--single-best-mapping", "--all-contigs"]),
+    "chim_single_best_all_noimp": ("chimeric_pairs_2x150", ["--single-best-mapping", "--all-contigs", "--no-improper-mappings"]),
+    "chim_single_best": ("chimeric_pairs_2x150", ["--single-best-mapping"]),
     "strata":    ("stress_60bp", ["--strata"]),
     "max3_o5":   ("stress_60bp", ["--max-alignments", "3", "-o", "5"]),
     "scores":    ("stress_100bp_unal", ["-m", "8", "-i", "-12", "-g", "-30", "-q", "-28", "-e", "-5", "-f", "-4", "-h", "60%", "-w", "150%",
@@ -177,6 +192,15 @@ OPTION_CASES = {
     "local_cfg2": ("cfg2s_100bp_2Mbp", ["--local"]),
     "ungapped":  ("stress_100bp_unal", ["--local", "-U", "--sam-unaligned"]),
     "ungapped60_n1": ("stress_60bp", ["--local", "-U", "-n", "1", "-h", "45%"]),
+    # output policy of read_output / readpair_output (output.c:955-1008,1070-1291): the best mapping only, per class or over all classes (with an improper pair of two
+    # unpaired mappings when both are good), no Z tags with --all-contigs, no mapping qualities at all
+    "single_best": ("stress_60bp", ["--single-best-mapping"]),
+    "all_contigs": ("stress_60bp", ["--all-contigs"]),
+    "no_mapq": ("stress_100bp_unal", ["--no-mapping-qualities", "--sam-unaligned"]),
+    "pairs_single_best": ("stress_pairs_2x100", ["--single-best-mapping"]),
+    "pairs_single_best_all": ("stress_pairs_2x100", ["--single-best-mapping", "--all-contigs"]),
+    "pairs_single_best_all_noimp": ("stress_pairs_2x100", ["--single-best-mapping", "--all-contigs", "--no-improper-mappings"]),
+    "pairs_no_mapq": ("stress_pairs_2x100", ["--no-mapping-qualities"]),
     # -F / -C: only the read as given / only its reverse complement
     "positive": ("stress_60bp", ["-F"]),
     "negative": ("stress_60bp", ["-C"]),
@@ -524,6 +548,8 @@ def main():
         option_cases(); return
     if "--option-tags" in sys.argv:                                   # --option-tags pairs_n3,cfg5_n3: just these
         option_cases(only=sys.argv[sys.argv.index("--option-tags") + 1].split(",")); return
+    if "--chimeric-only" in sys.argv:
+        chimeric_pairs_case(); option_cases(only=["chim_single_best_all", "chim_single_best_all_noimp", "chim_single_best"]); return
     if "--mirna-only" in sys.argv:
         mirna_case(); return
     if "--n1-only" in sys.argv:
@@ -542,6 +568,7 @@ def main():
         f.write(kat)
     print("sw_kat:", kat.count(b"\nV ") + 1, "vector,", kat.count(b"\nF "), "full")
     paired_cases()
+    chimeric_pairs_case()
     option_cases()
     n1_noisy_case()
     mirna_case()
