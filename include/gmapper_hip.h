@@ -83,6 +83,14 @@ typedef struct gm_params {
   int strand_only;                             /* 1: -F / --positive (only the read as given), 2: -C / --negative (only its reverse complement): the other strand gets no
                                                   anchor list (ref: mapping.c:879-880, gmapper.c:1979-1992).  Unpaired only -- paired mode maps both strands, as the
                                                   reference does after its warning (gmapper.c:2448-2451).  0 */
+  /* output policy of read_output / readpair_output (ref: output.c:955-1008,1070-1291; gmapper.c:2252-2268) */
+  int single_best_mapping;                     /* --single-best-mapping: only the mapping with the highest quality -- unpaired: the first such; paired: the best unpaired
+                                                  mapping of each mate and the pair that holds the best paired one (with all_contigs: ONE record pair over all classes;
+                                                  an unpaired winner is joined with the other mate's best unpaired mapping into an IMPROPER pair when both qualities
+                                                  reach 10, unless no_improper_mappings).  Without mapping qualities (--local, no_mapping_qualities) it does nothing, as in the reference.  0 */
+  int all_contigs;                             /* --all-contigs: no Z0-Z6 tags (ref: output.c:691); changes what single_best_mapping selects.  0 */
+  int no_mapping_qualities;                    /* --no-mapping-qualities: MAPQ 255, no Z tags, no post_sw (colour space prints sw_full_cs's own strings), as --local implies.  0 */
+  int no_improper_mappings;                    /* --no-improper-mappings  0 */
 } gm_params_t;
 
 void gm_params_default(gm_params_t *p);        /* letter-space defaults of the reference binary (gmapper-ls) */

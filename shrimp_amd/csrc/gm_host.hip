@@ -62,7 +62,10 @@ extern "C" void gm_params_default(gm_params_t* p) {
   p->region_bits = 11; p->region_overlap = 50; p->list_cutoff = 0; p->hash_filter_calls = 1; p->tiebreak_rev = 1;
   p->sam_unaligned = 0; p->longest_read_len = 1000; p->strata = 0; p->max_alignments = 0;
   p->colour_space = 0; p->crossover_score = -20; p->indel_taboo_len = 0; p->pr_xover = 0.03; p->local_alignment = 0; p->ungapped = 0; p->hash_seeds = 0; p->output_format = 0; p->print_read_seq = 0; p->strand_only = 0;
+  p->single_best_mapping = 0; p->all_contigs = 0; p->no_mapping_qualities = 0; p->no_improper_mappings = 0;
 }
+// compute_mapping_qualities (ref: gmapper.c:2258,2325-2328): off with --no-mapping-qualities and in local mode -- then MAPQ 255, no Z tags, no post_sw (mapping.c:1648)
+static inline bool gm_mqv_on(const gm_params_t& P) { return !P.local_alignment && !P.no_mapping_qualities; }
 // the gmapper-cs binary's defaults (ref: gmapper.c:1748-1755, gmapper-defaults.h:52-58,64-66)
 extern "C" void gm_params_default_cs(gm_params_t* p) {
   gm_params_default(p);
@@ -861,7 +864,7 @@ struct Finalizer {
     h.z2 = h.z3 = h.pr_top_random = h.insert_size_denom = h.pr_missed_mp = 0;
     h.score_full = r->score;
     h.pct_score_full = (1000 * 100 * h.score_full) / r->score_max;                 // ref: mapping.c:400-401
-    if (h.score_full > 0 && !P.local_alignment) {                  // local mode: mapping qualities are off (ref: gmapper.c:2325-2328, mapping.c:1648)
+    if (h.score_full > 0 && gm_mqv_on(P)) {                        // local mode / --no-mapping-qualities: no post_sw (ref: gmapper.c:2325-2328, mapping.c:1648)
       const double a = s->score_alpha, b = s->score_beta;
       if (P.colour_space) {
         if (post_base && (!qual_ptr || bq_base) && post_base[r - res_base].valid == 1) {   // k_post_sw_cs ran: the op record carries the re-called letters in its spare bits
@@ -938,7 +941,7 @@ struct Finalizer {
       }
       return 0;
     }
-    if (!P.local_alignment) {                                                      // compute_unpaired_mqv, ref: output.c:777-793,975
+    if (gm_mqv_on(P)) {                                                            // compute_unpaired_mqv, ref: output.c:777-793,975
       for (int pass = 0; pass < 2; pass++) {
         double z1 = 0.0;
         for (auto* h : p2) z1 += h->posterior;
@@ -951,6 +954,11 @@ struct Finalizer {
         for (auto* h : p2) near = near || near_qv(h->posterior / z1) || near_trunc(1000.0 * -log(h->z0));
         if (!near) break;
         for (auto* h : p2) if (h->dev_post) redo_on_host(*h);
+      }
+      if (P.single_best_mapping) {                                                 // the first mapping with the highest quality, ref: output.c:977-984
+        size_t mx = 0;
+        for (size_t i = 1; i < p2.size(); i++) if (p2[i]->mqv > p2[mx]->mqv) mx = i;
+        FHit* best = p2[mx]; p2.assign(1, best);
       }
     }
     if (P.output_format) {                                                         // --shrimp-format / --pretty, ref: gmapper/output.c:270-296
@@ -1010,7 +1018,7 @@ struct Finalizer {
           if (!rev) p = put_str(p, h->qual.data(), (size_t)nq); else for (int i = nq - 1; i >= 0; i--) *p++ = h->qual[i];
         } else *p++ = '*';
         p = put_str(p, "\tAS:i:", 6); p = put_int(p, h->score_full);
-        if (!P.local_alignment) {                                                    // ref: output.c:691-696
+        if (gm_mqv_on(P) && !P.all_contigs) {                                        // ref: output.c:691-696
           p = put_str(p, "\tZ0:i:", 6); p = put_int(p, double_to_neglog(h->z0));
           p = put_str(p, "\tZ1:i:", 6); p = put_int(p, double_to_neglog(h->z1));
         }
@@ -1037,7 +1045,7 @@ struct Finalizer {
         p = put_str(p, "\tAS:i:", 6);
       } else p = put_str(p, "\t*\tAS:i:", 8);
       p = put_int(p, h->score_full);
-      if (!P.local_alignment) {                                                    // ref: output.c:691-696
+      if (gm_mqv_on(P) && !P.all_contigs) {                                        // ref: output.c:691-696
         p = put_str(p, "\tZ0:i:", 6); p = put_int(p, double_to_neglog(h->z0));
         p = put_str(p, "\tZ1:i:", 6); p = put_int(p, double_to_neglog(h->z1));
       }
@@ -1223,7 +1231,7 @@ static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len,
                               D.d_res, D.d_ops, D.ops_stride, (uint32_t*)D.d_back, D.back_stride / 4, D.p2_grid, d_stats, q, D.xover_on ? D.d_xover : nullptr);
       // post_sw of every result on the device (with the reads' quality values where they have them: per-colour error rates from the host's table, base qualities back), unless
       // the alignment is local (no mapping qualities at all, ref: gmapper.c:2325-2328)
-      H.post_on = rc == GM_OK && D.d_post && !s->P.local_alignment && (!D.xover_on || s->d_qtab);
+      H.post_on = rc == GM_OK && D.d_post && gm_mqv_on(s->P) && (!D.xover_on || s->d_qtab);
       H.post_bq_on = H.post_on && D.xover_on;
       if (H.post_on) {
         const CsPostConsts c = cs_post_consts(s);
