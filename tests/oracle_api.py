@@ -262,6 +262,8 @@ CS_OPTION_CASES = {
     "cs_ungapped": ("cfg4s_50col_2Mbp", "colour=1;local=1;ungapped=1", dict(local_alignment=1, ungapped=1, anchor_width=0, a_gap_open_score=-255, b_gap_open_score=-255, hash_filter_calls=0), False),
     "cs_ungapped_unal": ("stress_cs_60col_unal", "colour=1;local=1;ungapped=1;full-threshold=40",
                          dict(local_alignment=1, ungapped=1, anchor_width=0, a_gap_open_score=-255, b_gap_open_score=-255, hash_filter_calls=0, sw_full_threshold=40.0, sam_unaligned=1), True),
+    "cs_no_mapq": ("cfg4s_50col_2Mbp", "colour=1;no-mapping-qualities=1", dict(no_mapping_qualities=1), False),
+    "cs_single_best": ("stress_cs_60col_unal", "colour=1;single-best-mapping=1", dict(single_best_mapping=1, sam_unaligned=1), True),
 }
 
 

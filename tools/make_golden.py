@@ -231,11 +231,14 @@ CS_OPTION_CASES = {
     "cs_local_unal":   ("stress_cs_60col_unal", ["--local", "--sam-unaligned"]),
     "cs_ungapped":     ("cfg4s_50col_2Mbp", ["--local", "-U"]),
     "cs_ungapped_unal": ("stress_cs_60col_unal", ["--local", "-U", "--sam-unaligned", "-h", "40%"]),
+    "cs_no_mapq":      ("cfg4s_50col_2Mbp", ["--no-mapping-qualities"]),         # global sw_full_cs, no post_sw: sw_full_cs's own strings and counts in the output
+    "cs_single_best":  ("stress_cs_60col_unal", ["--single-best-mapping", "--sam-unaligned"]),
 }
 
 
-def cs_option_cases():
+def cs_option_cases(only=None):
     for tag, (base, extra) in CS_OPTION_CASES.items():
+        if only and tag not in only: continue
         z = np.load(os.path.join(OUT, base + ".npz"))
         contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
         with tempfile.TemporaryDirectory() as d:
@@ -540,6 +543,8 @@ def main():
         cs_pair_option_cases(only=sys.argv[sys.argv.index("--cs-pair-option-tags") + 1].split(",")); return
     if "--cs-pair-options-only" in sys.argv:
         cs_pair_option_cases(); return
+    if "--cs-option-tags" in sys.argv:
+        cs_option_cases(only=sys.argv[sys.argv.index("--cs-option-tags") + 1].split(",")); return
     if "--cs-options-only" in sys.argv:
         cs_option_cases(); return
     if "--index-only" in sys.argv:
