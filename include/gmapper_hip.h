@@ -91,6 +91,11 @@ typedef struct gm_params {
   int all_contigs;                             /* --all-contigs: no Z0-Z6 tags (ref: output.c:691); changes what single_best_mapping selects.  0 */
   int no_mapping_qualities;                    /* --no-mapping-qualities: MAPQ 255, no Z tags, no post_sw (colour space prints sw_full_cs's own strings), as --local implies.  0 */
   int no_improper_mappings;                    /* --no-improper-mappings  0 */
+  /* optional tail of every SAM record (ref: output.c:452-465,729-756) */
+  int extra_sam_fields;                        /* --extra-sam-fields: ZM:i matches, ZR:i window-generation score, ZV:i vector score, ZH:i full SW score, ZE:Z edit string
+                                                  (alignment_edit_string, reversed for mappings on the reverse strand) on mapped records.  0 */
+  int sam_r2;                                  /* --sam-r2 (paired mode only): R2:Z (colour space: X2:Z) = the mate's sequence as given.  0 */
+  char read_group[64];                         /* --read-group: RG:Z:<name> on every record ("" = none; the @RG header line is the caller's, as the @SQ lines are) */
 } gm_params_t;
 
 void gm_params_default(gm_params_t *p);        /* letter-space defaults of the reference binary (gmapper-ls) */

@@ -63,6 +63,7 @@ extern "C" void gm_params_default(gm_params_t* p) {
   p->sam_unaligned = 0; p->longest_read_len = 1000; p->strata = 0; p->max_alignments = 0;
   p->colour_space = 0; p->crossover_score = -20; p->indel_taboo_len = 0; p->pr_xover = 0.03; p->local_alignment = 0; p->ungapped = 0; p->hash_seeds = 0; p->output_format = 0; p->print_read_seq = 0; p->strand_only = 0;
   p->single_best_mapping = 0; p->all_contigs = 0; p->no_mapping_qualities = 0; p->no_improper_mappings = 0;
+  p->extra_sam_fields = 0; p->sam_r2 = 0; memset(p->read_group, 0, sizeof p->read_group);
 }
 // compute_mapping_qualities (ref: gmapper.c:2258,2325-2328): off with --no-mapping-qualities and in local mode -- then MAPQ 255, no Z tags, no post_sw (mapping.c:1648)
 static inline bool gm_mqv_on(const gm_params_t& P) { return !P.local_alignment && !P.no_mapping_qualities; }
@@ -786,6 +787,29 @@ struct Finalizer {
       else o += qr[i];
     }
   }
+  // reverse_alignment_edit_string, ref: gmapper/output.c:83-122
+  static void reverse_edit_string(std::string& e) {
+    const int n = (int)e.size(); std::string r(e.size(), ' ');
+    for (int i = 0; i < n;) {
+      const char c = e[n - 1 - i];
+      if (isdigit((unsigned char)c)) { int j = i + 1; while (j < n && isdigit((unsigned char)e[n - 1 - j])) j++; j--; memcpy(&r[i], &e[n - 1 - j], (size_t)(j - i + 1)); i = j + 1; }
+      else { r[i] = c == ')' ? '(' : c == '(' ? ')' : c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c; i++; }
+    }
+    e.swap(r);
+  }
+  // the optional tail of a SAM record and its newline (ref: output.c:452-465,729-761): R2:Z / X2:Z (--sam-r2), RG:Z (--read-group), --extra-sam-fields of a mapping
+  static void sam_tail(const gm_params_t& P, std::string& out, const std::string* mate_seq, const FHit* h, const std::string* db, const std::string* qr) {
+    if (mate_seq) { out += P.colour_space ? "\tX2:Z:" : "\tR2:Z:"; out += *mate_seq; }
+    if (P.read_group[0]) { out += "\tRG:Z:"; out.append(P.read_group, strnlen(P.read_group, sizeof P.read_group)); }
+    if (h && P.extra_sam_fields) {
+      char b[96]; const GmFullRes& r = *h->r;
+      out.append(b, (size_t)snprintf(b, sizeof b, "\tZM:i:%d\tZR:i:%d\tZV:i:%d\tZH:i:%d\tZE:Z:", r.matches, r.score_window_gen, r.score_vector, r.score));
+      std::string e; edit_string(*db, *qr, e);
+      if (r.gen_st == 1) reverse_edit_string(e);
+      out += e;
+    }
+    out += '\n';
+  }
   // one mapping in the SHRiMP format, with the pretty rows when asked (ref: gmapper/output.c:270-296; common/output.c:280-352 output_normal, :118-262 output_pretty)
   void emit_shrimp(const FHit& h, const char* nm, size_t nl, int rd, const uint32_t* rw, const std::string& db, const std::string& qr, std::string& out) const {
     const gm_params_t& P = s->P; const gm_index* ix = s->ix; const GmFullRes& r = *h.r;
@@ -930,13 +954,13 @@ struct Finalizer {
         if (P.colour_space) {                                                        // ref: output.c:353-355,441-451
           p = put_str(p, "*\t*\tCQ:Z:", 9);
           if (qual_ptr) p = put_str(p, qual_ptr[rd], (size_t)read_len); else *p++ = '*';
-          p = put_str(p, "\tCS:Z:", 6); p = put_csfasta(p); *p++ = '\n'; out.resize(p - out.data()); return 1;
+          p = put_str(p, "\tCS:Z:", 6); p = put_csfasta(p); out.resize(p - out.data()); sam_tail(P, out, nullptr, nullptr, nullptr, nullptr); return 1;
         }
         if (seq_ptr) for (int i = 0; i < read_len; i++) *p++ = seq_from_text(seq_ptr[rd][i]);
         else for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = (c < 4) ? "ACGT"[c] : 'N'; }
-        if (qual_ptr) { *p++ = '\t'; p = put_str(p, qual_ptr[rd], (size_t)read_len); *p++ = '\n'; }      // ref: output.c:419-421 (verbatim)
-        else p = put_str(p, "\t*\n", 3);
-        out.resize(p - out.data());
+        if (qual_ptr) { *p++ = '\t'; p = put_str(p, qual_ptr[rd], (size_t)read_len); }      // ref: output.c:419-421 (verbatim)
+        else p = put_str(p, "\t*", 2);
+        out.resize(p - out.data()); sam_tail(P, out, nullptr, nullptr, nullptr, nullptr);
         return 1;
       }
       return 0;
@@ -1027,8 +1051,7 @@ struct Finalizer {
         p = put_str(p, "\tCS:Z:", 6); p = put_csfasta(p);
         p = put_str(p, "\tCM:i:", 6); p = put_int(p, h->cs_xover);
         p = put_str(p, "\tXX:Z:", 6); p = put_str(p, h->qr.data(), h->qr.size());
-        *p++ = '\n';
-        out.resize(p - out.data());
+        out.resize(p - out.data()); sam_tail(P, out, nullptr, h, &h->db, &h->qr);
         continue;
       }
       // SEQ: read bases in input orientation (aligned part from qralign == the read's own letters), revcomp on '-'
@@ -1050,8 +1073,9 @@ struct Finalizer {
         p = put_str(p, "\tZ1:i:", 6); p = put_int(p, double_to_neglog(h->z1));
       }
       p = put_str(p, "\tNM:i:", 6); p = put_int(p, r.n_mismatch + r.n_del + r.n_ins);
-      *p++ = '\n';
       out.resize(p - out.data());
+      if (P.extra_sam_fields) { std::string db, qr; ls_alignment_strings(r, h->ops, std::min(r.n_ops, ops_stride), rw, db, qr); sam_tail(P, out, nullptr, h, &db, &qr); }
+      else sam_tail(P, out, nullptr, nullptr, nullptr, nullptr);
     }
     return (int)p2.size();
   }
@@ -1306,7 +1330,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   if (stats) memset(stats, 0, sizeof *stats);
   if (D.cur_len != read_len || (D.caps_pair_mode != 0 && D.caps_pair_mode != 4)) { choose_caps(s, D, read_len); D.caps_pair_mode = 0; int rc = alloc_buffers(s, D, read_len); if (rc) return rc; }
   const int read_words = (read_len + 7) / 8;
-  if (s->P.output_format && s->h_genome.empty()) {                // the SHRiMP / pretty formats print genome letters: one download per session
+  if ((s->P.output_format || s->P.extra_sam_fields) && s->h_genome.empty()) {    // the SHRiMP / pretty formats and the ZE:Z edit string print genome letters: one download per session
     s->h_genome.resize(s->ix->genome_words);
     GM_HIP(hipMemcpy(s->h_genome.data(), s->ix->d_genome, s->ix->genome_words * 4, hipMemcpyDeviceToHost));
   }
@@ -1360,7 +1384,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     if (const char* e = gm_tune("GM_POST_GUARD_TOL")) F.guard_tol = atof(e);          // (tests: a huge tolerance sends every result through the redo path)
     if (quals) { F.qual_ptr = qptr.data() + J->base; F.qual_delta = qual_delta; }
     if (seq_text) F.seq_ptr = sptr.data() + J->base;
-    if (s->P.output_format) F.hgen = s->h_genome.data();
+    if (s->P.output_format || s->P.extra_sam_fields) F.hgen = s->h_genome.data();
     auto worker = [&]() {
       std::vector<FHit> fh; std::vector<FHit*> p2;
       for (;;) {

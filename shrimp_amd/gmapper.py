@@ -34,7 +34,8 @@ class Params(C.Structure):   # gm_params_t (include/gmapper_hip.h)
                 ("strata", C.c_int), ("max_alignments", C.c_int),
                 ("colour_space", C.c_int), ("crossover_score", C.c_int), ("indel_taboo_len", C.c_int), ("pr_xover", C.c_double),
                 ("local_alignment", C.c_int), ("ungapped", C.c_int), ("hash_seeds", C.c_int), ("output_format", C.c_int), ("print_read_seq", C.c_int), ("strand_only", C.c_int),
-                ("single_best_mapping", C.c_int), ("all_contigs", C.c_int), ("no_mapping_qualities", C.c_int), ("no_improper_mappings", C.c_int)]
+                ("single_best_mapping", C.c_int), ("all_contigs", C.c_int), ("no_mapping_qualities", C.c_int), ("no_improper_mappings", C.c_int),
+                ("extra_sam_fields", C.c_int), ("sam_r2", C.c_int), ("read_group", C.c_char * 64)]
 
 
 class MapStats(C.Structure):   # gm_map_stats_t

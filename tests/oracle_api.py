@@ -285,6 +285,19 @@ MIRNA_MODE = ("hash-spaced-kmers=1;seeds=%s;local=1;ungapped=1;cmw-mode=1;match-
                    window_len=100.0), MIRNA_SEEDS)
 
 
+# the optional tail of the SAM records (--extra-sam-fields, --read-group, --sam-r2; output.c:452-465,729-756): host formatting pinned on the product directly against the
+# reference's output -- the oracle does not restate it.  tag -> (base golden, gm_params_t fields, colour space, pairs)
+SAM_TAIL_CASES = {
+    "extra_fields": ("cfg2s_100bp_2Mbp", dict(extra_sam_fields=1), False, False),
+    "extra_fields_rg_unal": ("n1_noisy_70bp", dict(extra_sam_fields=1, read_group=b"grp1", sam_unaligned=1), False, False),
+    "rg_unal": ("stress_100bp_unal", dict(read_group=b"grp1", sam_unaligned=1), False, False),
+    "pairs_r2_rg_extra": ("cfg5s_2x150_1Mbp", dict(sam_r2=1, read_group=b"grp1", extra_sam_fields=1), False, True),
+    "pairs_r2_rg": ("stress_pairs_2x100", dict(sam_r2=1, read_group=b"grp1"), False, True),
+    "cs_extra_rg": ("cfg4s_50col_2Mbp", dict(extra_sam_fields=1, read_group=b"grp1", sam_unaligned=1), True, False),
+    "cs_pairs_r2_extra": ("cs_pairs_50col_col-bw", dict(sam_r2=1, extra_sam_fields=1, sam_unaligned=1), True, True),
+}
+
+
 def load_option_sam(base, tag):
     with gzip.open(os.path.join(ROOT, "tests", "golden", "%s@%s.sam.gz" % (base, tag)), "rb") as f:
         return f.read()

@@ -320,6 +320,28 @@ def test_n1_on_noisy_reads_matches_reference_golden(gm):
     assert got == want, (_first_diff(got, want), st)
 
 
+@pytest.mark.parametrize("tag", sorted(oa.SAM_TAIL_CASES))
+def test_sam_record_tail_options_match_reference_golden(gm, tag):
+    """--extra-sam-fields (ZM / ZR / ZV / ZH / ZE: the window's match count and scores, the edit string, reversed on the reverse strand), --read-group (RG:Z) and
+    --sam-r2 (R2:Z / X2:Z: the mate's sequence) on mapped, half-mapped and unaligned records, letter and colour space, unpaired and paired"""
+    base, fields, cs, pairs = oa.SAM_TAIL_CASES[tag]
+    want = oa.load_option_sam(base, tag)
+    p = gm.default_params_cs() if cs else gm.default_params()
+    for k, v in fields.items(): setattr(p, k, v)
+    if pairs:
+        g = oa.load_golden_pairs(base)
+        ix = gm.Index(g["contigs"], names=g["contig_names"], params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+        fn = s.map_pairs_cs if cs else s.map_pairs
+        got = oa.sam_header(g["contigs"], g["contig_names"]) + fn(g["m1"], g["m2"], g["names1"], g["names2"], mode=g["mode"], min_insert=g["ins"][0], max_insert=g["ins"][1])
+    else:
+        contigs, reads, _ = oa.load_golden(base)
+        ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+        got = oa.sam_header(contigs) + (s.map_reads_cs(reads) if cs else s.map_reads(reads))
+    st = s.stats
+    s.close(); ix.close()
+    assert got == want, (_first_diff(got, want), st)
+
+
 def _idxfix(which="idxfix"):
     import gzip, os
     d = os.path.join(oa.ROOT, "tests", "golden", which)

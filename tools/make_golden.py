@@ -201,6 +201,13 @@ OPTION_CASES = {
     "pairs_single_best_all": ("stress_pairs_2x100", ["--single-best-mapping", "--all-contigs"]),
     "pairs_single_best_all_noimp": ("stress_pairs_2x100", ["--single-best-mapping", "--all-contigs", "--no-improper-mappings"]),
     "pairs_no_mapq": ("stress_pairs_2x100", ["--no-mapping-qualities"]),
+    # the optional tail of the SAM records (output.c:452-465,729-756): --extra-sam-fields (ZM / ZR / ZV / ZH / ZE), --read-group, --sam-r2 (paired mode)
+    # (inputs without N: the reference's reverse_alignment_edit_string never returns on a letter it does not know -- its assert(0) is compiled out)
+    "extra_fields": ("cfg2s_100bp_2Mbp", ["--extra-sam-fields"]),
+    "extra_fields_rg_unal": ("n1_noisy_70bp", ["--extra-sam-fields", "--read-group", "grp1,sampleA", "--sam-unaligned"]),
+    "rg_unal": ("stress_100bp_unal", ["--read-group", "grp1,sampleA", "--sam-unaligned"]),
+    "pairs_r2_rg_extra": ("cfg5s_2x150_1Mbp", ["--sam-r2", "--read-group", "grp1,sampleA", "--extra-sam-fields"]),
+    "pairs_r2_rg": ("stress_pairs_2x100", ["--sam-r2", "--read-group", "grp1,sampleA"]),
     # -F / -C: only the read as given / only its reverse complement
     "positive": ("stress_60bp", ["-F"]),
     "negative": ("stress_60bp", ["-C"]),
@@ -233,6 +240,7 @@ CS_OPTION_CASES = {
     "cs_ungapped_unal": ("stress_cs_60col_unal", ["--local", "-U", "--sam-unaligned", "-h", "40%"]),
     "cs_no_mapq":      ("cfg4s_50col_2Mbp", ["--no-mapping-qualities"]),         # global sw_full_cs, no post_sw: sw_full_cs's own strings and counts in the output
     "cs_single_best":  ("stress_cs_60col_unal", ["--single-best-mapping", "--sam-unaligned"]),
+    "cs_extra_rg":     ("cfg4s_50col_2Mbp", ["--extra-sam-fields", "--read-group", "grp1,sampleA", "--sam-unaligned"]),
 }
 
 
@@ -246,7 +254,7 @@ def cs_option_cases(only=None):
             write_fa_codes(g, [b"contig%d" % (i + 1) for i in range(len(contigs))], contigs)
             synth.write_csfasta_reads(r, z["reads"])
             p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "gmapper-cs"), "-N", "4", *extra, r, g], capture_output=True, check=True)
-            body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+            body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG") and not l.startswith(b"@RG"))
         with gzip.open(os.path.join(OUT, "%s@%s.sam.gz" % (base, tag)), "wb", compresslevel=9) as f:
             f.write(body)
         print("%s@%s: %d SAM records" % (base, tag, sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@"))))
@@ -258,6 +266,7 @@ CS_PAIR_OPTION_CASES = {        # tag -> (base colour-space pair golden, extra g
     "cs_pairs_n3": ("cs_pairs_50col_opp-in", ["-n", "3"]),                                # paired match mode 3 in colour space; with --no-half-paired on a mode that reverses a mate
     "cs_pairs_n3_colbw_nhp": ("cs_pairs_50col_col-bw", ["-n", "3", "--no-half-paired"]),
     "cs_pairs_n2": ("cs_pairs_50col_opp-in", ["-n", "2"]),
+    "cs_pairs_r2_extra": ("cs_pairs_50col_col-bw", ["--sam-r2", "--extra-sam-fields"]),
 }
 
 
@@ -277,7 +286,7 @@ def cs_pair_option_cases(only=None):
                         f.write(b">" + nm + b"\n" + b"ACGT"[row[0]:row[0] + 1] + bytes(b"0123"[c] if c < 4 else ord(".") for c in row[1:]) + b"\n")
             ins = tuple(int(x) for x in z["ins"])
             p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "gmapper-cs"), "-N", "4", "-p", str(z["mode"]), "-I", "%d,%d" % ins, "--sam-unaligned", *extra, r, g], capture_output=True, check=True)
-            body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+            body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG") and not l.startswith(b"@RG"))
         with gzip.open(os.path.join(OUT, "%s@%s.sam.gz" % (base, tag)), "wb", compresslevel=9) as f:
             f.write(body)
         print("%s@%s: %d SAM records" % (base, tag, sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@"))))
@@ -302,7 +311,7 @@ def option_cases(only=None):
                 write_fa_codes(g, [b"contig%d" % (i + 1) for i in range(len(contigs))], contigs)
                 write_fa_codes(r, [b"r%d" % i for i in range(len(z["reads"]))], list(z["reads"]))
             p = subprocess.run([REF, "-N", "4", *extra, r, g], capture_output=True, check=True)
-            body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+            body = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG") and not l.startswith(b"@RG"))     # (--read-group adds an @RG header line)
         with gzip.open(os.path.join(OUT, "%s@%s.sam.gz" % (base, tag)), "wb", compresslevel=9) as f:
             f.write(body)
         print("%s@%s: %d SAM records" % (base, tag, sum(1 for l in body.split(b"\n") if l and not l.startswith(b"@"))))
