@@ -50,7 +50,9 @@ __device__ __forceinline__ bool k1_has2(const uint32_t* bm, uint32_t rloc) {
 }
 
 // dynamic LDS layout: codes[read_len pad 4] | kS[NL] | lbeg[NL] | lend[NL] | lo[NL] | hi[NL] | pre[NL+1] | bitmap[bm_words]
-// MP (paired -n 3): the modes of GmMpDev -- 1 lists the regions this read-strand marks twice, 2 / 4 widen or narrow the survival rule by the mate's rows, 3 flags the mate's rows
+// MP (paired -n 3): the modes of GmMpDev -- 1 lists the regions this read-strand marks twice, 2 / 4 / 5 widen or narrow the survival rule by the mate's rows, 3 flags the
+// mate's rows; 6: GmIndexDev.no_region_counts, every list entry survives.  (A template parameter, not a run-time switch: one more live scalar in the default
+// instantiation tips its SGPR spills into scratch memory, and a kernel with scratch takes 0.95 ms to dispatch instead of 0.07 -- measured on the fall-back launch.)
 template <bool BKT, int MP = 0>
 __device__ __forceinline__ void
 k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
@@ -81,7 +83,6 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
   uint32_t* bm = smem + ((code_words + 6 * NL + 1 + 3) & ~3);     // 16-byte aligned for the b128 clears
   const int S = ix.n_slabs, rb = ix.region_bits;
   const uint32_t rmask = (1u << rb) - 1u, ovl = (uint32_t)ix.region_overlap;
-  const bool all = ix.no_region_counts != 0;      // no region counts: every list entry survives (the marks are still made, nothing reads them)
   uint32_t* const sh_mp_row = bm + bm_words;             // (dynamic LDS behind the region counters; MP launches only) MP 1: the row being collected; 2, 3, 4: the mate's row
   uint32_t* const sh_own_row = sh_mp_row + GM_MP_CAP;     // MP 4: this read-strand's own row, with the flags the mate's pass left
   __shared__ uint32_t sh_mp_n, sh_own_n;
@@ -93,7 +94,7 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
   }
   if (tid == 0) sh.n_surv = 0;
   if (MP == 1 && tid == 0) sh_mp_n = 0;
-  if (MP >= 2) {   // the mate's row (other strand of the same pair), held in LDS for the reach tests
+  if (MP >= 2 && MP <= 5) {   // the mate's row (other strand of the same pair), held in LDS for the reach tests
     const uint32_t mn = ix.mp.cnt[rs ^ 1];
     if (tid == 0) { sh_mp_n = mn <= (uint32_t)GM_MP_CAP ? mn : 0u; if (mn > (uint32_t)GM_MP_CAP && !redo && MP != 3) GS_ADD(stats, GS_MP_UNFILTERED, 1ull); }
     if (mn <= (uint32_t)GM_MP_CAP) for (uint32_t i = tid; i < mn; i += nthr) sh_mp_row[i] = ix.mp.rows[(size_t)(rs ^ 1) * GM_MP_CAP + i] & ~GM_MP_FLAG;
@@ -104,29 +105,31 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
     if (on <= (uint32_t)GM_MP_CAP) for (uint32_t i = tid; i < on; i += nthr) sh_own_row[i] = ix.mp.out_rows[(size_t)rs * GM_MP_CAP + i];
   }
   __syncthreads();
-  const int mp_dmin = MP >= 2 ? ix.mp.dmin[st] : 0, mp_dmax = MP >= 2 ? ix.mp.dmax[st] : 0;
+  const int mp_dmin = (MP >= 2 && MP <= 5) ? ix.mp.dmin[st] : 0, mp_dmax = (MP >= 2 && MP <= 5) ? ix.mp.dmax[st] : 0;
   // count_mp >= 2 for region reg: the mate marked a region twice within [reg + dmin, reg + dmax] (ref: mapping.c:573-582)
-  auto mp_reach = [&](uint32_t reg) -> bool { return (MP == 2 || MP == 4 || MP == 5) && gm_mp_reach(sh_mp_row, sh_mp_n, (long long)reg + mp_dmin, (long long)reg + mp_dmax); };
+  auto mp_reach = [&](uint32_t reg) __attribute__((always_inline)) -> bool { return (MP == 2 || MP == 4 || MP == 5) && gm_mp_reach(sh_mp_row, sh_mp_n, (long long)reg + mp_dmin, (long long)reg + mp_dmax); };
   // MP 3: this read-strand marks reg -- every region X the mate (strand 1 - st) marked twice that reaches it, X + mate_dmin <= reg <= X + mate_dmax, has count_mp >= 1
   const int mt_dmin = MP == 3 ? ix.mp.mate_dmin[1 - st] : 0, mt_dmax = MP == 3 ? ix.mp.mate_dmax[1 - st] : 0;
-  auto mp_flag = [&](uint32_t reg) {
+  auto mp_flag = [&](uint32_t reg) __attribute__((always_inline)) {
     uint32_t a;
     if (gm_mp_reach(sh_mp_row, sh_mp_n, (long long)reg - mt_dmax, (long long)reg - mt_dmin, &a))
       for (; a < sh_mp_n && (long long)sh_mp_row[a] <= (long long)reg - mt_dmin; a++) atomicOr(&ix.mp.rows[(size_t)(rs ^ 1) * GM_MP_CAP + a], GM_MP_FLAG);
   };
   // MP 4: count_mp >= 1 && count_main + count_mp >= 3 (ref: mapping.c:733-742)
-  auto mp_ok3 = [&](uint32_t reg, uint32_t rloc) -> bool {
+  auto mp_ok3 = [&](uint32_t reg, uint32_t rloc) __attribute__((always_inline)) -> bool {
     if (mp_reach(reg)) return true;
     if (!k1_has2(bm, rloc)) return false;
     uint32_t a;
     return gm_mp_reach(sh_own_row, sh_own_n, (long long)reg, (long long)reg, &a) && (sh_own_row[a] & GM_MP_FLAG) != 0u;
   };
   // does the list entry survive?  Default: its region, or the one before it when the entry lies in the overlap strip, was marked twice (ref: mapping.c:733-777)
-  auto keep = [&](uint32_t reg, uint32_t rloc, bool strip) -> bool {
+  auto keep = [&](uint32_t reg, uint32_t rloc, bool strip) __attribute__((always_inline)) -> bool {   // (inlined: a call would put the captures in scratch memory, and a kernel
+                                                                                                       // with scratch takes 0.9 ms to dispatch instead of 0.07)
     if (MP == 3) { mp_flag(reg); if (strip) mp_flag(reg - 1u); return false; }
     if (MP == 4) return mp_ok3(reg, rloc) || (strip && mp_ok3(reg - 1u, rloc - 1u));
     if (MP == 5) return (k1_has2(bm, rloc) && mp_reach(reg)) || (strip && k1_has2(bm, rloc - 1u) && mp_reach(reg - 1u));
-    return all || k1_has2(bm, rloc) || mp_reach(reg) || (strip && (k1_has2(bm, rloc - 1u) || mp_reach(reg - 1u)));
+    if (MP == 6) return true;                      // no region counts (-n 1; paired -n 2): every list entry survives (the marks are still made, nothing reads them)
+    return k1_has2(bm, rloc) || mp_reach(reg) || (strip && (k1_has2(bm, rloc - 1u) || mp_reach(reg - 1u)));
   };
 
   // ---- 1. map indexes + whole-list bounds (ref: mapping.c:53-66, KMER_TO_MAPIDX gmapper.h:349-368) ----
@@ -1328,6 +1331,13 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     // one list per lane when the read-strand's lists fit a workgroup: every list slice is in flight at once
     int k1_threads = std::min(1024, (NL + 63) & ~63);
     if (const char* e = gm_tune("GM_K1_THREADS")) k1_threads = std::max(64, std::min(1024, atoi(e) & ~63));
+    if (all) {
+      static GmLdsLimit lim6; size_t& c6 = lim6.cur();
+      if (lds > 48 * 1024 && lds > c6) { GM_HIP(hipFuncSetAttribute((const void*)k_lookup<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); c6 = lds; }
+      hipLaunchKernelGGL((k_lookup<false, 6>), dim3(n_reads * 2), dim3(k1_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+                         max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
+                         (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_stats, 0, d_surv_seg);
+    } else
     hipLaunchKernelGGL(k_lookup<false>, dim3(n_reads * 2), dim3(k1_threads), lds, stream, ix, d_reads, n_reads, read_len, read_words,
                        max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap,
                        (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_stats,
@@ -1344,6 +1354,13 @@ int gm_launch_lookup_redo(const GmIndexDev& ix, const uint32_t* d_reads, int n_r
   int max_n_kmers, NL, bm_words; size_t lds;
   k1_geometry(ix, read_len, &max_n_kmers, &NL, &bm_words, &lds);
   if (n_heavy == 0) return GM_OK;
+  if (ix.no_region_counts) {
+    static GmLdsLimit lim6r; size_t& c6 = lim6r.cur();
+    if (lds > 48 * 1024 && lds > c6) { GM_HIP(hipFuncSetAttribute((const void*)k_lookup<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); c6 = lds; }
+    hipLaunchKernelGGL((k_lookup<false, 6>), dim3(n_heavy), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
+                       max_n_kmers, NL, bm_words, d_out, (uint32_t*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0,
+                       d_redo_list, d_redo_off, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_stats, 0, (uint32_t*)nullptr);
+  } else
   if (ix.mp.mode == 5) {
     int rc = k1_mp_lds(lds); if (rc) return rc;
     hipLaunchKernelGGL((k_lookup<false, 5>), dim3(n_heavy), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,
