@@ -217,6 +217,8 @@ static void apply_opts(Params& P, const char* opts) {
     else if (k == "report") P.num_outputs = (int)d; else if (k == "anchor-width") P.anchor_width = (int)d;
     else if (k == "cutoff") P.list_cutoff = (uint32_t)d; else if (k == "strata") P.strata = d != 0;
     else if (k == "max-alignments") P.max_alignments = (int)d;
+    else if (k == "region-bits") P.region_bits = (int)d; else if (k == "region-overlap") P.region_overlap = (int)d;
+    else if (k == "pr-xover") P.pr_xover = d;
     else if (k == "tiebreak-off") { if (d != 0) P.Tflag = false; }                       // -t: no reversed tie-breaks on the negative strand (mapping.c:378,393)
     else if (k == "single-best-mapping") P.single_best_mapping = d != 0;
     else if (k == "all-contigs") P.all_contigs = d != 0;

@@ -226,6 +226,9 @@ OPTION_CASES = {
     "chim_single_best_all_noimp": ("chimeric_pairs_2x150", "single-best-mapping=1;all-contigs=1;no-improper-mappings=1",
                                    dict(single_best_mapping=1, all_contigs=1, no_improper_mappings=1), None),
     "chim_single_best": ("chimeric_pairs_2x150", "single-best-mapping=1", dict(single_best_mapping=1), None),
+    # --region-bits / --region-overlap
+    "regions_10_30": ("stress_60bp", "region-bits=10;region-overlap=30", dict(region_bits=10, region_overlap=30), None),
+    "regions_12_200": ("cfg2s_100bp_2Mbp", "region-bits=12;region-overlap=200", dict(region_bits=12, region_overlap=200), None),
     # -t: Tflag off
     "tiebreak_off": ("stress_100bp_unal", "tiebreak-off=1", dict(tiebreak_rev=0, sam_unaligned=1), None),
     "pairs_tiebreak_off": ("stress_pairs_2x100", "tiebreak-off=1", dict(tiebreak_rev=0), None),
@@ -266,6 +269,8 @@ CS_OPTION_CASES = {
     "cs_ungapped_unal": ("stress_cs_60col_unal", "colour=1;local=1;ungapped=1;full-threshold=40",
                          dict(local_alignment=1, ungapped=1, anchor_width=0, a_gap_open_score=-255, b_gap_open_score=-255, hash_filter_calls=0, sw_full_threshold=40.0, sam_unaligned=1), True),
     "cs_tiebreak_off": ("stress_cs_60col_unal", "colour=1;tiebreak-off=1", dict(tiebreak_rev=0, sam_unaligned=1), True),
+    "cs_xover_taboo": ("stress_cs_60col_unal", "colour=1;crossover=-25;indel-taboo-len=3;pr-xover=0.05",
+                       dict(crossover_score=-25, indel_taboo_len=3, pr_xover=0.05, sam_unaligned=1), True),
     "cs_no_mapq": ("cfg4s_50col_2Mbp", "colour=1;no-mapping-qualities=1", dict(no_mapping_qualities=1), False),
     "cs_single_best": ("stress_cs_60col_unal", "colour=1;single-best-mapping=1", dict(single_best_mapping=1, sam_unaligned=1), True),
 }

@@ -208,6 +208,9 @@ OPTION_CASES = {
     "rg_unal": ("stress_100bp_unal", ["--read-group", "grp1,sampleA", "--sam-unaligned"]),
     "pairs_r2_rg_extra": ("cfg5s_2x150_1Mbp", ["--sam-r2", "--read-group", "grp1,sampleA", "--extra-sam-fields"]),
     "pairs_r2_rg": ("stress_pairs_2x100", ["--sam-r2", "--read-group", "grp1,sampleA"]),
+    # region geometry of the k-mer hit counts (--region-bits, --region-overlap)
+    "regions_10_30": ("stress_60bp", ["--region-bits", "10", "--region-overlap", "30"]),
+    "regions_12_200": ("cfg2s_100bp_2Mbp", ["--region-bits", "12", "--region-overlap", "200"]),
     # -t: the full-SW tie-breaks are not reversed for hits on the negative strand (Tflag off; mapping.c:378,393)
     "tiebreak_off": ("stress_100bp_unal", ["-t", "--sam-unaligned"]),
     "pairs_tiebreak_off": ("stress_pairs_2x100", ["-t"]),
@@ -242,6 +245,7 @@ CS_OPTION_CASES = {
     "cs_ungapped":     ("cfg4s_50col_2Mbp", ["--local", "-U"]),
     "cs_ungapped_unal": ("stress_cs_60col_unal", ["--local", "-U", "--sam-unaligned", "-h", "40%"]),
     "cs_tiebreak_off": ("stress_cs_60col_unal", ["-t", "--sam-unaligned"]),
+    "cs_xover_taboo":  ("stress_cs_60col_unal", ["-x", "-25", "--indel-taboo-len", "3", "--pr-xover", "0.05", "--sam-unaligned"]),
     "cs_no_mapq":      ("cfg4s_50col_2Mbp", ["--no-mapping-qualities"]),         # global sw_full_cs, no post_sw: sw_full_cs's own strings and counts in the output
     "cs_single_best":  ("stress_cs_60col_unal", ["--single-best-mapping", "--sam-unaligned"]),
     "cs_extra_rg":     ("cfg4s_50col_2Mbp", ["--extra-sam-fields", "--read-group", "grp1,sampleA", "--sam-unaligned"]),
