@@ -1000,6 +1000,14 @@ def test_full_size_genome_vs_oracle(gm, oracle_lib):
     assert sum(1 for l in got.split(b"\n") if l and l.split(b"\t")[2] in high) > 1000       # hits at global positions >= 2^31
     assert got_p == want_p, _first_diff(got_p, want_p)
     assert got_n == want_n, _first_diff(got_n, want_n)
+    # a region geometry other than the default at full size (--region-bits 10 --region-overlap 30: twice the regions, the fast lookup kernel's tables twice as loaded)
+    o = oa.Session(contigs, opts="region-bits=10;region-overlap=30")
+    want_r = o.map_sam(reads[:4000], nthreads=16); o.close()
+    pr_ = gm.default_params(); pr_.region_bits = 10; pr_.region_overlap = 30
+    ix = gm.Index(contigs, params=pr_); s = gm.Session(ix, params=pr_)
+    got_r = s.map_reads(reads[:4000]); kern_r = gm.lib().gm_last_lookup_kernel().decode()
+    s.close(); ix.close()
+    assert got_r == want_r, (kern_r, _first_diff(got_r, want_r))
     cs, _ = synth.make_cs_reads(contigs, 5000, 50, 37)
     o = oa.Session(contigs, opts="colour=1")
     want_c = o.map_sam(cs, nthreads=16); o.close()
