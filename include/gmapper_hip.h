@@ -16,7 +16,8 @@
  * parameter lists (for drop-in linking) and are thin wrappers over a batch of one.
  *
  * Errors: integer return codes (0 = ok, <0 = GM_E_*); nothing throws across the ABI.
- * Threading: one host thread per gm_session; a session owns one HIP stream on one device.
+ * Threading: one host thread per gm_session; a session owns its HIP streams on one device.  Mapping calls of different sessions on the SAME device take turns
+ * (the lookup kernels keep per-device scratch); sessions on different devices run side by side.
  */
 #ifndef GMAPPER_HIP_H
 #define GMAPPER_HIP_H

@@ -1318,6 +1318,11 @@ static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int
   return pipeline_back(s, 0, H, n, read_len, st, lookup_ms);
 }
 
+// The lookup kernels keep per-DEVICE scratch (fall-back lists, start flags, the rounds kernel's rows: gm_lookup.hip, gm_lookup5.hip), shared by every session on that
+// device: mapping calls of different sessions on one device take turns (a single call already fills the GPU).  Sessions on different devices run side by side.
+static std::mutex g_dev_call_mutex[16];
+static std::mutex& dev_call_mutex(const gm_session* s) { return g_dev_call_mutex[(unsigned)s->ix->device & 15u]; }
+
 static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* reads_host, const void* reads_dev,
                     const char* names, int emit_sam, char** sam, size_t* sam_len, gm_map_stats_t* stats, const uint8_t* initbp_host = nullptr,
                     const char* quals = nullptr, int qual_delta = 33, const char* seq_text = nullptr, uint32_t* per_read_bytes = nullptr) {
@@ -1325,6 +1330,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   if ((s->P.colour_space != 0) != (initbp_host != nullptr)) {
     gm_set_error(s->P.colour_space ? "colour-space session: use gm_map_reads_cs (colours + primer letters)" : "gm_map_reads_cs needs a colour-space session"); return GM_E_ARG; }
   if (read_len > s->P.longest_read_len || read_len >= 32768 / std::max(1, s->P.match_score)) { gm_set_error("read length %d out of range (ref: sw-vector.c:393-398)", read_len); return GM_E_RANGE; }
+  std::lock_guard<std::mutex> dev_turn(dev_call_mutex(s));
   GM_HIP(hipSetDevice(s->ix->device));
   DevSet& D = s->set[0];
   if (stats) memset(stats, 0, sizeof *stats);

@@ -300,6 +300,26 @@ def test_mirna_mode_matches_reference_golden(gm):
     assert got == want, (_first_diff(got, want), st)
 
 
+def test_two_sessions_on_one_device_from_two_threads(gm):
+    """two sessions of one index mapping at the same time from two host threads (ctypes drops the GIL during the calls): the lookup kernels' per-device scratch is
+    shared, so the library makes such calls take turns -- both outputs equal the golden, repeatedly"""
+    import threading
+    contigs, reads, sam = oa.load_golden("cfg2s_100bp_2Mbp")
+    g = oa.load_golden_pairs("cfg5s_2x150_1Mbp")
+    ix = gm.Index(contigs); ixp = gm.Index(g["contigs"], names=g["contig_names"])
+    s1 = gm.Session(ix, max_batch_reads=2048); s2 = gm.Session(ixp, max_batch_reads=1024)
+    out = {"a": [], "b": []}
+    def run_a():
+        for _ in range(4): out["a"].append(oa.sam_header(contigs) + s1.map_reads(reads))
+    def run_b():
+        for _ in range(4): out["b"].append(oa.sam_header(g["contigs"], g["contig_names"]) + s2.map_pairs(g["m1"], g["m2"], g["names1"], g["names2"], mode=g["mode"], min_insert=g["ins"][0], max_insert=g["ins"][1]))
+    ta = threading.Thread(target=run_a); tb = threading.Thread(target=run_b)
+    ta.start(); tb.start(); ta.join(); tb.join()
+    s1.close(); s2.close(); ix.close(); ixp.close()
+    assert len(out["a"]) == 4 and all(o == sam for o in out["a"])
+    assert len(out["b"]) == 4 and all(o == g["sam"] for o in out["b"])
+
+
 def test_n1_on_noisy_reads_matches_reference_golden(gm):
     """match_mode 1 (-n 1) where it matters: 70-base reads with 9 % substitutions, 57 of which map only because ONE k-mer match is enough -- the lookup kernel keeps
     every list entry (no region counts, gmapper.c:2610-2616), a window per anchor, pass 1 with min_matches 1"""
