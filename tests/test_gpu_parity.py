@@ -1079,6 +1079,22 @@ def test_paired_match_modes_match_reference_golden(gm, oracle_lib, tag):
     assert (st["anchors"], st["windows"]) == (want_anchors, want_windows), (st["anchors"], st["windows"], want_anchors, want_windows)
 
 
+@pytest.mark.parametrize("tag,fields", [("pairs_n3", dict(match_mode=3)), ("pairs_n3_nhp", dict(match_mode=3, half_paired=0)), ("pairs_n2", dict(match_mode=2)),
+                                         ("no_half_paired", dict(half_paired=0))])
+def test_paired_match_modes_over_many_sub_batches(gm, tag, fields):
+    """the same reference goldens with 256-pair sub-batches: the front of sub-batch i + 1 (its own mate-pair rows and views, per buffer pair) is queued beside the back
+    of sub-batch i; heavy-tier read-strands and the exact redo of --no-half-paired fall inside the pipeline"""
+    g = oa.load_golden_pairs("stress_pairs_2x100"); want = oa.load_option_sam("stress_pairs_2x100", tag)
+    ix = gm.Index(g["contigs"], names=g["contig_names"]); s = gm.Session(ix, max_batch_reads=256)
+    opts = gm.PairOpts.default(g["mode"], g["ins"][0], g["ins"][1])
+    for k, v in fields.items(): setattr(opts, k, v)
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs(g["m1"], g["m2"], g["names1"], g["names2"], opts=opts)
+    st = s.stats
+    s.close(); ix.close()
+    assert got == want, (_first_diff(got, want), st)
+    assert st["mp_unfiltered"] == 0
+
+
 @pytest.mark.parametrize("base,tag", [("stress_pairs_2x100", "no_half_paired"), ("cfg5s_2x150_1Mbp", "cfg5_no_half_paired")])
 def test_no_half_paired_mate_pair_region_counts(gm, oracle_lib, base, tag):
     """A7: gm_pair_opts_t.half_paired = 0 -- k_mp_filter applies the other mate's region counts to each mate's list entries (mapping.c:545-608,733-742)
