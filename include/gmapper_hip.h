@@ -39,6 +39,9 @@ extern "C" {
 #define GM_E_NOMEM      -6
 
 const char *gm_last_error(void);
+/* sizeof of the structs that cross the ABI, for bindings to check their mirrors against: which = 0 gm_params_t, 1 gm_pair_opts_t, 2 gm_map_stats_t, 3 gm_merge_options_t
+ * (-1 for any other value) */
+int gm_abi_sizeof(int which);
 /* number of visible HIP devices (0 when none); never initialises more than the runtime */
 int gm_device_count(void);
 

@@ -65,6 +65,10 @@ extern "C" void gm_params_default(gm_params_t* p) {
   p->single_best_mapping = 0; p->all_contigs = 0; p->no_mapping_qualities = 0; p->no_improper_mappings = 0;
   p->extra_sam_fields = 0; p->sam_r2 = 0; memset(p->read_group, 0, sizeof p->read_group);
 }
+extern "C" int gm_abi_sizeof(int which) {
+  switch (which) { case 0: return (int)sizeof(gm_params_t); case 1: return (int)sizeof(gm_pair_opts_t); case 2: return (int)sizeof(gm_map_stats_t); case 3: return (int)sizeof(gm_merge_options_t); }
+  return -1;
+}
 // compute_mapping_qualities (ref: gmapper.c:2258,2325-2328): off with --no-mapping-qualities and in local mode -- then MAPQ 255, no Z tags, no post_sw (mapping.c:1648)
 static inline bool gm_mqv_on(const gm_params_t& P) { return !P.local_alignment && !P.no_mapping_qualities; }
 // the gmapper-cs binary's defaults (ref: gmapper.c:1748-1755, gmapper-defaults.h:52-58,64-66)

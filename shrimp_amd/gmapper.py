@@ -115,7 +115,7 @@ EXPORTS = ["gm_map_pairs_file", "gm_map_pairs_cs_fastq", "gm_map_reads_file", "g
            "post_sw_setup", "post_sw", "post_sw_cleanup", "post_sw_stats",
            "gm_session_create", "gm_session_free", "gm_sequence_to_bitfield", "gm_map_reads_text", "gm_map_reads", "gm_map_reads_fastq", "gm_map_reads_cs", "gm_map_reads_cs_fastq", "gm_map_reads_device", "gm_free", "gm_debug_tophits",
            "gm_pair_opts_default", "gm_map_pairs", "gm_map_pairs_fastq",
-           "gm_last_lookup_timing", "gm_last_lookup_kernel"]
+           "gm_last_lookup_timing", "gm_last_lookup_kernel", "gm_abi_sizeof"]
 
 _lib = None
 

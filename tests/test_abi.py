@@ -113,3 +113,13 @@ def test_nothing_built_from_the_reference_travels_to_the_gpu_box():
     """oracle/_ref/ (the reference compiled by oracle/Makefile.ref) is kept out of history AND out of the gpurun snapshot"""
     assert "oracle/_ref/" in open(os.path.join(ROOT, ".gitignore")).read().split()
     assert "oracle/_ref/" in open(os.path.join(ROOT, ".gpurunignore")).read().split()
+
+
+def test_struct_sizes_match_the_python_mirrors():
+    """gm_abi_sizeof: the ctypes mirrors in shrimp_amd/gmapper.py have the size the library was compiled with (a shorter mirror would let gm_params_default write past it)"""
+    import ctypes as C
+    from shrimp_amd import gmapper as gm
+    L = gm.lib(); L.gm_abi_sizeof.restype = C.c_int; L.gm_abi_sizeof.argtypes = [C.c_int]
+    for which, cls in enumerate((gm.Params, gm.PairOpts, gm.MapStats, gm.MergeOptions)):
+        assert L.gm_abi_sizeof(which) == C.sizeof(cls), (cls.__name__, L.gm_abi_sizeof(which), C.sizeof(cls))
+    assert L.gm_abi_sizeof(99) == -1
