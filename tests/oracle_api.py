@@ -257,6 +257,9 @@ PAIR_MODE_CASES = {
     "cfg5_n3": ("cfg5s_2x150_1Mbp", "mp-match-mode=3", dict(match_mode=3)),
     "cfg5_n3_nhp": ("cfg5s_2x150_1Mbp", "mp-match-mode=3;half-paired=0", dict(match_mode=3, half_paired=0)),
     "pairs_n2": ("stress_pairs_2x100", "mp-match-mode=2", dict(match_mode=2)),
+    # ("param_" fields go to gm_params_t)
+    "pairs_hashed_n3": ("stress_pairs_2x100", "hash-spaced-kmers=1;mp-match-mode=3", dict(match_mode=3, param_hash_seeds=1)),
+    "pairs_local_n3_nhp": ("stress_pairs_2x100", "local=1;mp-match-mode=3;half-paired=0", dict(match_mode=3, half_paired=0, param_local_alignment=1)),
     "cfg5_n2": ("cfg5s_2x150_1Mbp", "mp-match-mode=2", dict(match_mode=2)),
 }
 

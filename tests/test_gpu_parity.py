@@ -1069,9 +1069,12 @@ def test_paired_match_modes_match_reference_golden(gm, oracle_lib, tag):
     o = oa.Session(g["contigs"], g["contig_names"], opts=oopts); o.set_pairing(g["mode"], *g["ins"])
     o.map_pairs_sam(g["m1"], g["m2"], g["names1"], g["names2"], nthreads=8)
     want_anchors, want_windows = o.last_pair_counts(); o.close()
-    ix = gm.Index(g["contigs"], names=g["contig_names"]); s = gm.Session(ix, max_batch_reads=4096)
+    p = gm.default_params()
     opts = gm.PairOpts.default(g["mode"], g["ins"][0], g["ins"][1])
-    for k, v in fields.items(): setattr(opts, k, v)
+    for k, v in fields.items():
+        if k.startswith("param_"): setattr(p, k[6:], v)
+        else: setattr(opts, k, v)
+    ix = gm.Index(g["contigs"], names=g["contig_names"], params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
     got = oa.sam_header(g["contigs"], g["contig_names"]) + s.map_pairs(g["m1"], g["m2"], g["names1"], g["names2"], opts=opts)
     st = s.stats
     s.close(); ix.close()

@@ -234,6 +234,8 @@ OPTION_CASES = {
     "cfg5_n3": ("cfg5s_2x150_1Mbp", ["-n", "3"]),
     "cfg5_n3_nhp": ("cfg5s_2x150_1Mbp", ["-n", "3", "--no-half-paired"]),
     "pairs_n2": ("stress_pairs_2x100", ["-n", "2"]),
+    "pairs_hashed_n3": ("stress_pairs_2x100", ["-H", "-n", "3"]),                       # hashed seeds under the mate-pair modes of the generic lookup kernel
+    "pairs_local_n3_nhp": ("stress_pairs_2x100", ["--local", "-n", "3", "--no-half-paired"]),
     "cfg5_n2": ("cfg5s_2x150_1Mbp", ["-n", "2"]),
 }
 
