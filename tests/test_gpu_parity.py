@@ -300,6 +300,30 @@ def test_mirna_mode_matches_reference_golden(gm):
     assert got == want, (_first_diff(got, want), st)
 
 
+def test_one_session_through_every_mode_in_turn(gm):
+    """one session, its buffer sets and capacities re-chosen as the calls change mode: unpaired, pairs -n 3, unpaired, pairs (default), pairs -n 2, pairs --no-half-paired,
+    pairs -n 3 --no-half-paired, unpaired -- every output equals its reference golden"""
+    g = oa.load_golden_pairs("stress_pairs_2x100")
+    names = g["contig_names"]
+    reads = np.concatenate([g["m1"][:400], g["m2"][:400]])
+    ix = gm.Index(g["contigs"], names=names); s = gm.Session(ix, max_batch_reads=512)
+    o = oa.Session(g["contigs"], names); want_u = o.map_sam(reads, nthreads=8); o.close()
+    def pairs(**f):
+        opts = gm.PairOpts.default(g["mode"], g["ins"][0], g["ins"][1])
+        for k, v in f.items(): setattr(opts, k, v)
+        return oa.sam_header(g["contigs"], names) + s.map_pairs(g["m1"], g["m2"], g["names1"], g["names2"], opts=opts)
+    assert s.map_reads(reads) == want_u
+    assert pairs(match_mode=3) == oa.load_option_sam("stress_pairs_2x100", "pairs_n3")
+    assert s.map_reads(reads) == want_u
+    assert pairs() == g["sam"]
+    assert pairs(match_mode=2) == oa.load_option_sam("stress_pairs_2x100", "pairs_n2")
+    assert pairs(half_paired=0) == oa.load_option_sam("stress_pairs_2x100", "no_half_paired")
+    assert pairs(match_mode=3, half_paired=0) == oa.load_option_sam("stress_pairs_2x100", "pairs_n3_nhp")
+    assert pairs() == g["sam"]
+    assert s.map_reads(reads) == want_u
+    s.close(); ix.close()
+
+
 def test_two_sessions_on_one_device_from_two_threads(gm):
     """two sessions of one index mapping at the same time from two host threads (ctypes drops the GIL during the calls): the lookup kernels' per-device scratch is
     shared, so the library makes such calls take turns -- both outputs equal the golden, repeatedly"""
