@@ -205,8 +205,10 @@ void sw_full_ls_stats(uint64_t *invocs, uint64_t *cells, double *secs);   /* ref
  * lstocs(genome_ls[j], initbp) (ref: common/sw-vector.c:112-146); `mismatch` is then match + crossover (ref: gmapper.c:2935).
  * sw_full_cs: four letter-space translations of the colour read, 3-state affine DP in four layers with crossovers between
  * layers on the NW and N transitions, traceback with crossover marks (lower-case in qralign), ref: common/sw-full-cs.c:249-1236.
- * Both modes (local_alignment 0 / 1, ref: sw-full-cs.c:199-203,315,439-552) and one anchor box, as gmapper calls it (ref: mapping.c:375-379); crossover_score
- * (per-position penalties from read qualities) must be NULL at this seam; the read pipeline (gm_map_reads_cs*) takes them from the QVs itself.
+ * Both modes (local_alignment 0 / 1, ref: sw-full-cs.c:199-203,315,439-552) and one anchor box, as gmapper calls it (ref: mapping.c:375-379).  crossover_score: NULL (the
+ * global penalty everywhere) or rlen per-position penalties, what gmapper passes for every read with quality values (ref: mapping.c:375-379, gmapper.c:532-544, used per row
+ * at sw-full-cs.c:312-322); the device keeps them in 8 bits (gmapper clamps them to [2 * global, -1]).  An argument combination that is not implemented (several anchors, a
+ * score outside [-128, 127]) is refused LOUDLY -- the reason on stderr and in gm_last_error(), sfr->score = 0 -- never answered as if the window held no alignment.
  * ------------------------------------------------------------------------------------------- */
 int sw_full_cs_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
                      int match, int mismatch, int global_xover_penalty, bool reset_stats, int anchor_width, int indel_taboo_len);

@@ -196,6 +196,19 @@ int gmo_sw_full_cs_mode(const uint32_t* genome_ls, int goff, int glen, const uin
   return 0;
 }
 
+// sw_full_cs with a per-position crossover_score[] (ref: sw-full-cs.c:312; gmapper.c:532-544 builds it from the read's QVs), either mode
+int gmo_sw_full_cs_xover(const uint32_t* genome_ls, int goff, int glen, const uint32_t* read, int rlen, int initbp, int thresh,
+                         long long ax, long long ay, int alen, int awidth, int revcmpl, int local, const int* xover, int* out, char* dbalign, char* qralign, int cap) {
+  CsParams C; SwFullCsResults s;
+  Anchor a; a.x = ax; a.y = ay; a.length = alen; a.width = awidth; a.weight = 1;
+  sw_full_cs(C, genome_ls, goff, glen, read, rlen, initbp, thresh, &s, revcmpl != 0, &a, 1, xover, local);
+  int v[10] = {s.score, s.read_start, s.rmapped, s.genome_start, s.gmapped, s.matches, s.mismatches, s.insertions, s.deletions, s.crossovers};
+  memcpy(out, v, sizeof v);
+  if ((int)s.dbalign.size() + 1 > cap) return -1;
+  strcpy(dbalign, s.dbalign.c_str()); strcpy(qralign, s.qralign.c_str());
+  return 0;
+}
+
 // opts = "key=value;key=value": the reference's command-line options by their long names (gmapper.c:1040-1140):
 // match mismatch open-r ext-r open-q ext-q match-window cmw-overlap cmw-threshold vec-threshold full-threshold
 // cmw-mode report anchor-width cutoff strata max-alignments seeds (comma separated 0/1 strings)

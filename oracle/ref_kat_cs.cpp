@@ -6,6 +6,9 @@
 //   S goff glen rlen initbp ax ay alen awidth revcmpl thresh <genome_ls words> <read colour words>
 //     score read_start rmapped genome_start gmapped matches mismatches insertions deletions crossovers dbalign qralign   ("-" when empty)
 //   L ...  (second argument "local"): the S record's fields for sw_full_cs in local mode -> tests/golden/sw_kat_cs_local.txt.gz
+//   X / Y ...  (second argument "xover"): sw_full_cs with a per-position crossover_score[] (what every csfastq read hands it, ref: mapping.c:375-379, gmapper.c:532-544),
+//     global (X) and local (Y) mode; the S record's fields with the rlen scores (comma separated, in [2 * global, -1] as gmapper.c:538-542 clamps them) behind the read words
+//     -> tests/golden/sw_kat_cs_xover.txt.gz
 // Scores are the binary's colour-space defaults (ref: gmapper-defaults.h:52-58): match 10, mismatch -24, crossover -20,
 // gaps -33/-7 (reference) -33/-3 (query); the vector filter's mismatch is match + crossover (ref: gmapper.c:2935).
 #include <cstdio>
@@ -26,7 +29,8 @@ static void dump(const std::vector<uint32_t>& bf) { for (size_t i = 0; i < bf.si
 int main(int argc, char** argv) {
   int n = argc > 1 ? atoi(argv[1]) : 1500;
   const bool local = argc > 2 && !strcmp(argv[2], "local");     // "L" records: the same cases through sw_full_cs(.., local_alignment = true) (ref: sw-full-cs.c:199-203,315,439-552); no C / S records
-  std::mt19937_64 rng(20260202);
+  const bool xover = argc > 2 && !strcmp(argv[2], "xover");     // "X" / "Y" records only
+  std::mt19937_64 rng(20260202), xrng(20261005);
   sw_vector_setup(1400, 1000, -33, -7, -33, -3, 10, 10 + (-20), 1, true);
   sw_full_cs_setup(1400, 1000, -33, -7, -33, -3, 10, -24, -20, true, 8, 0);
   for (int t = 0; t < n; t++) {
@@ -62,11 +66,29 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < g.size(); i++) { put(gl, (int)i, g[i]); put(gc, (int)i, lstocs(i ? g[i - 1] : BASE_T, g[i], false)); }   // ref: fasta.c:586-607
     for (int i = 0; i < rlen; i++) put(rb, i, rc[i]);
     int sv = sw_vector(gc.data(), goff, glen, rb.data(), rlen, gl.data(), initbp, false);
-    if (!local) { printf("C %d %d %d %d ", goff, glen, rlen, initbp); dump(gc); printf(" "); dump(gl); printf(" "); dump(rb); printf(" %d\n", sv); }
+    if (!local && !xover) { printf("C %d %d %d %d ", goff, glen, rlen, initbp); dump(gc); printf(" "); dump(gl); printf(" "); dump(rb); printf(" %d\n", sv); }
     struct anchor a; memset(&a, 0, sizeof a);
     a.x = (start - goff) + (int)(rng() % 7) - 3; a.y = 0; a.length = 10 + rng() % (rlen > 16 ? rlen - 10 : 6); a.width = 1 + rng() % 4; a.weight = 2;
     if (rng() % 4 == 0) { a.y = rng() % 10; a.x += a.y; }
     int thresh = (rng() % 3 == 0) ? (int)(0.6 * rlen * 10) : (int)(0.3 * rlen * 10);
+    if (xover) {
+      // per-position scores as the read loop derives them from quality values: most positions good (near the global -20 .. -40), some poor (-1 .. -8)
+      std::vector<int> xs(rlen);
+      for (int i = 0; i < rlen; i++) { const int u = xrng() % 10; xs[i] = u < 6 ? -(int)(14 + xrng() % 27) : (u < 9 ? -(int)(1 + xrng() % 12) : -40); }
+      for (int md = 0; md < 2; md++) for (int rv = 0; rv < 2; rv++) {
+        if (md == 1 && (t & 1)) continue;                                    // local mode on every other case
+        struct sw_full_results sfr; memset(&sfr, 0, sizeof sfr);
+        sw_full_cs(gl.data(), goff, glen, rb.data(), rlen, initbp, thresh, &sfr, rv != 0, false, &a, 1, md, xs.data());
+        printf("%s %d %d %d %d %lld %lld %d %d %d %d ", md ? "Y" : "X", goff, glen, rlen, initbp, (long long)a.x, (long long)a.y, a.length, a.width, rv, thresh);
+        dump(gl); printf(" "); dump(rb); printf(" ");
+        for (int i = 0; i < rlen; i++) printf("%s%d", i ? "," : "", xs[i]);
+        printf(" %d %d %d %d %d %d %d %d %d %d %s %s\n", sfr.score, sfr.read_start, sfr.rmapped, sfr.genome_start, sfr.gmapped,
+               sfr.matches, sfr.mismatches, sfr.insertions, sfr.deletions, sfr.crossovers,
+               (sfr.dbalign && sfr.dbalign[0]) ? sfr.dbalign : "-", (sfr.qralign && sfr.qralign[0]) ? sfr.qralign : "-");
+        free(sfr.dbalign); free(sfr.qralign);
+      }
+      continue;
+    }
     for (int rv = 0; rv < 2; rv++) {
       struct sw_full_results sfr; memset(&sfr, 0, sizeof sfr);
       sw_full_cs(gl.data(), goff, glen, rb.data(), rlen, initbp, thresh, &sfr, rv != 0, false, &a, 1, local ? 1 : 0, NULL);

@@ -339,9 +339,9 @@ struct gm_session {
   hipStream_t stream = nullptr;                   // front of the pipeline (reads in, K1, K1b, K2); the only stream of the paired path
   hipStream_t stream_b = nullptr;                 // back of the pipeline (pass 1, selection, pass 2, results out): runs beside the next sub-batch's front
   hipStream_t stream_c = nullptr;                 // host -> device copies of the next sub-batch (never queued behind kernels)
-  hipEvent_t ev[12];
-  hipEvent_t pev[2][10];                           // per buffer set: stage boundaries, front done, copies done
-  hipEvent_t pkev[2][4];                           // paired mode: begin / end of K1 for mate set 0 and 1 of buffer pair k
+  hipEvent_t ev[12] = {};                          // (null until created: gm_session_free also takes a session whose set-up stopped half-way)
+  hipEvent_t pev[2][10] = {};                      // per buffer set: stage boundaries, front done, copies done
+  hipEvent_t pkev[2][4] = {};                      // paired mode: begin / end of K1 for mate set 0 and 1 of buffer pair k
   unsigned long long* d_pstats[2] = {nullptr, nullptr};   // per buffer set: counters of one sub-batch
   uint32_t* h_pin = nullptr;                      // pinned words the front writes (heavy count per set); from word 16 on: K1's start flags
   uint32_t flag_epoch = 0, front_epoch[2] = {0, 0}; int front_flag_grid[2] = {0, 0};
@@ -463,7 +463,13 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   GM_HIP(hipSetDevice(ix->device));
   gm_session* s = new gm_session();
   s->ix = ix; s->P = params ? *params : ix->params;
+  // (the parameters are checked before anything is allocated; every failure further down goes through gm_session_free, which releases what exists by then)
+  if (s->P.strand_only < 0 || s->P.strand_only > 2) { delete s; gm_set_error("strand_only %d: 0 (both), 1 (-F) or 2 (-C)", params ? params->strand_only : 0); return GM_E_ARG; }
+  if (s->P.match_mode != 1 && s->P.match_mode != 2) { delete s; gm_set_error("match_mode %d: 1 or 2 (ref: gmapper.c:2624; 3 and 4 are paired-mode settings with mate-pair region counts)", s->P.match_mode); return GM_E_ARG; }
+  if (s->P.ungapped && !s->P.local_alignment) { delete s; gm_set_error("ungapped mode needs local alignment (ref: gmapper.c:2330-2333)"); return GM_E_ARG; }
+  if ((s->P.colour_space != 0) != (ix->params.colour_space != 0)) { delete s; gm_set_error("session and index disagree on colour space"); return GM_E_ARG; }
   s->sc = make_score(s->P);
+#define GM_HIP_S(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gm_set_error("%s: %s", #call, hipGetErrorString(e_)); gm_session_free(s); return GM_E_NODEVICE; } } while (0)
   // score -> probability derivation (ref: gmapper.c:2557-2572)
   if (s->P.colour_space) {   // pr_xover => alpha => pr_mismatch
     s->score_alpha = (double)s->P.crossover_score / (log(s->P.pr_xover / 3) / log(2.0));
@@ -486,28 +492,24 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
       if (e > .75) e = .75;
       qt[2 * q] = log(1 - e); qt[2 * q + 1] = log(e / 3.0);
     }
-    GM_HIP(hipMalloc(&s->d_qtab, qt.size() * 8));
-    GM_HIP(hipMemcpy(s->d_qtab, qt.data(), qt.size() * 8, hipMemcpyHostToDevice));
+    GM_HIP_S(hipMalloc(&s->d_qtab, qt.size() * 8));
+    GM_HIP_S(hipMemcpy(s->d_qtab, qt.data(), qt.size() * 8, hipMemcpyHostToDevice));
   }
-  if (s->P.strand_only < 0 || s->P.strand_only > 2) { delete s; gm_set_error("strand_only %d: 0 (both), 1 (-F) or 2 (-C)", params ? params->strand_only : 0); return GM_E_ARG; }
-  if (s->P.match_mode != 1 && s->P.match_mode != 2) { delete s; gm_set_error("match_mode %d: 1 or 2 (ref: gmapper.c:2624; 3 and 4 are paired-mode settings with mate-pair region counts)", s->P.match_mode); return GM_E_ARG; }
-  if (s->P.ungapped && !s->P.local_alignment) { delete s; gm_set_error("ungapped mode needs local alignment (ref: gmapper.c:2330-2333)"); return GM_E_ARG; }
-  if ((s->P.colour_space != 0) != (ix->params.colour_space != 0)) { delete s; gm_set_error("session and index disagree on colour space"); return GM_E_ARG; }
   s->max_batch = std::max(64, std::min(max_batch_reads > 0 ? max_batch_reads : 131072, 1 << 20));
   if (const char* e = gm_tune("GM_P2_GRID")) s->p2_grid = std::max(64, std::min(65536, atoi(e)));
   // The front stream gets the higher queue priority: K1's fall-back kernels (a few workgroups that each want most of a CU's LDS) otherwise wait for milliseconds
   // behind the back stream's thousands of small pass-1 workgroups, which refill every CU the moment the persistent K1 grid has left it.
   { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if (getenv("GM_STREAM_PRIO_OFF") || hi == lo) { GM_HIP(hipStreamCreate(&s->stream)); }
-    else GM_HIP(hipStreamCreateWithPriority(&s->stream, hipStreamDefault, hi)); }
-  GM_HIP(hipStreamCreateWithFlags(&s->stream_b, hipStreamNonBlocking));
-  GM_HIP(hipStreamCreateWithFlags(&s->stream_c, hipStreamNonBlocking));
-  for (auto& e : s->ev) GM_HIP(hipEventCreate(&e));
-  for (auto& row : s->pev) for (auto& e : row) GM_HIP(hipEventCreate(&e));
-  for (auto& row : s->pkev) for (auto& e : row) GM_HIP(hipEventCreate(&e));
-  GM_HIP(hipMalloc(&s->d_stats, (size_t)GS_STRIPES * GS_STRIDE * 8));
-  for (auto& d : s->d_pstats) GM_HIP(hipMalloc(&d, (size_t)GS_STRIPES * GS_STRIDE * 8));
-  GM_HIP(hipHostMalloc((void**)&s->h_pin, (16 + 1024) * 4, hipHostMallocDefault));
+    if (getenv("GM_STREAM_PRIO_OFF") || hi == lo) { GM_HIP_S(hipStreamCreate(&s->stream)); }
+    else GM_HIP_S(hipStreamCreateWithPriority(&s->stream, hipStreamDefault, hi)); }
+  GM_HIP_S(hipStreamCreateWithFlags(&s->stream_b, hipStreamNonBlocking));
+  GM_HIP_S(hipStreamCreateWithFlags(&s->stream_c, hipStreamNonBlocking));
+  for (auto& e : s->ev) GM_HIP_S(hipEventCreate(&e));
+  for (auto& row : s->pev) for (auto& e : row) GM_HIP_S(hipEventCreate(&e));
+  for (auto& row : s->pkev) for (auto& e : row) GM_HIP_S(hipEventCreate(&e));
+  GM_HIP_S(hipMalloc(&s->d_stats, (size_t)GS_STRIPES * GS_STRIDE * 8));
+  for (auto& d : s->d_pstats) GM_HIP_S(hipMalloc(&d, (size_t)GS_STRIPES * GS_STRIDE * 8));
+  GM_HIP_S(hipHostMalloc((void**)&s->h_pin, (16 + 1024) * 4, hipHostMallocDefault));
   memset(s->h_pin, 0, (16 + 1024) * 4);
   // k_lookup_v5 streams large indexes with the help of per-list strip lists, derived once per index (not stored in the index files)
   if ((ix->n_slabs > 1 || gm_tune("GM_K1_V5")) && !gm_tune("GM_NO_V5") && ix->params.region_bits >= 9 && ix->params.region_bits <= 16) {
@@ -516,6 +518,7 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   }
   *out = s;
   return GM_OK;
+#undef GM_HIP_S
 }
 extern "C" void gm_session_free(gm_session_t* s) {
   if (!s) return;
@@ -525,13 +528,13 @@ extern "C" void gm_session_free(gm_session_t* s) {
   if (s->d_qtab) (void)hipFree(s->d_qtab);
   if (s->d_pairs) (void)hipFree(s->d_pairs);
   if (s->d_pair_cnt) (void)hipFree(s->d_pair_cnt);
-  (void)hipFree(s->d_stats);
+  if (s->d_stats) (void)hipFree(s->d_stats);
   for (auto& d : s->d_pstats) if (d) (void)hipFree(d);
   if (s->h_pin) (void)hipHostFree(s->h_pin);
-  for (auto& e : s->ev) (void)hipEventDestroy(e);
-  for (auto& row : s->pev) for (auto& e : row) (void)hipEventDestroy(e);
-  for (auto& row : s->pkev) for (auto& e : row) (void)hipEventDestroy(e);
-  (void)hipStreamDestroy(s->stream);
+  for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& row : s->pev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
+  for (auto& row : s->pkev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
   if (s->stream_b) (void)hipStreamDestroy(s->stream_b);
   if (s->stream_c) (void)hipStreamDestroy(s->stream_c);
   delete s;
@@ -1780,6 +1783,7 @@ extern "C" int gm_last_lookup_timing(gm_session_t* s, double* ms, uint64_t* alg_
 // stage dump for parity tests: hits selected by pass 1, in ext-heap array order (before pass 2 / reverse_hit)
 extern "C" int gm_debug_tophits(gm_session_t* s, int n_reads, int read_len, const uint32_t* reads_packed, long long* rows, long cap, long* n_rows) {
   if (!s) return GM_E_ARG;
+  std::lock_guard<std::mutex> dev_turn(dev_call_mutex(s));     // (the device's lookup scratch is shared by its sessions: one call at a time, like the mapping entries)
   GM_HIP(hipSetDevice(s->ix->device));
   DevSet& D = s->set[0];
   if (D.cur_len != read_len || (D.caps_pair_mode != 0 && D.caps_pair_mode != 4)) { choose_caps(s, D, read_len); D.caps_pair_mode = 0; int rc = alloc_buffers(s, D, read_len); if (rc) return rc; }
@@ -1897,6 +1901,9 @@ extern "C" void sw_gapless_stats(uint64_t* invocs, uint64_t* cells, uint64_t* ti
 }
 // n independent calls; call i's genome bitfield starts at word genome_woff[i] of `genome` (and of `genome_ls`, colour space only: then `genome` holds colours,
 // `genome_ls` the letters of the same contig and initbp[i] the read's primer letter) and holds glen[i] positions
+// device buffers released when the holder goes out of scope
+struct GmDevBufs { std::vector<void*> p; ~GmDevBufs() { for (void* q : p) if (q) (void)hipFree(q); }
+                   template <class T> hipError_t get(T** out, size_t bytes) { void* q = nullptr; const hipError_t e = hipMalloc(&q, bytes); if (e == hipSuccess) { p.push_back(q); *out = (T*)q; } return e; } };
 extern "C" int gm_sw_gapless_batch(int n, const uint32_t* genome, const uint32_t* genome_ls, uint64_t genome_words, const int64_t* genome_woff, const int* glen,
                                    const uint32_t* reads, int read_words, const int* rlen, const int* g_idx, const int* r_idx, const int* initbp, int* scores) {
   if (!g_sg.init) { gm_set_error("sw_gapless called before sw_gapless_setup"); return GM_E_NOTSETUP; }
@@ -1909,20 +1916,21 @@ extern "C" int gm_sw_gapless_batch(int n, const uint32_t* genome, const uint32_t
     max_r = std::max(max_r, rlen[i]);
   }
   const auto t0 = std::chrono::steady_clock::now();
+  GmDevBufs bufs;      // (owns every device buffer below: a failing call in the middle returns without leaking the ones allocated before it)
   uint32_t *dg = nullptr, *dgl = nullptr, *dr = nullptr; long long* dwo = nullptr; int *dn = nullptr, *drl = nullptr, *dgi = nullptr, *dri = nullptr, *dib = nullptr, *ds = nullptr;
-  GM_HIP(hipMalloc(&dg, (genome_words + 8) * 4)); GM_HIP(hipMemset(dg, 0, (genome_words + 8) * 4)); GM_HIP(hipMemcpy(dg, genome, genome_words * 4, hipMemcpyHostToDevice));
-  if (genome_ls) { GM_HIP(hipMalloc(&dgl, (genome_words + 8) * 4)); GM_HIP(hipMemset(dgl, 0, (genome_words + 8) * 4)); GM_HIP(hipMemcpy(dgl, genome_ls, genome_words * 4, hipMemcpyHostToDevice)); }
-  GM_HIP(hipMalloc(&dr, (size_t)n * read_words * 4 + 32)); GM_HIP(hipMemcpy(dr, reads, (size_t)n * read_words * 4, hipMemcpyHostToDevice));
-  GM_HIP(hipMalloc(&dwo, (size_t)n * 8)); GM_HIP(hipMemcpy(dwo, genome_woff, (size_t)n * 8, hipMemcpyHostToDevice));
+  GM_HIP(bufs.get(&dg, (genome_words + 8) * 4)); GM_HIP(hipMemset(dg, 0, (genome_words + 8) * 4)); GM_HIP(hipMemcpy(dg, genome, genome_words * 4, hipMemcpyHostToDevice));
+  if (genome_ls) { GM_HIP(bufs.get(&dgl, (genome_words + 8) * 4)); GM_HIP(hipMemset(dgl, 0, (genome_words + 8) * 4)); GM_HIP(hipMemcpy(dgl, genome_ls, genome_words * 4, hipMemcpyHostToDevice)); }
+  GM_HIP(bufs.get(&dr, (size_t)n * read_words * 4 + 32)); GM_HIP(hipMemcpy(dr, reads, (size_t)n * read_words * 4, hipMemcpyHostToDevice));
+  GM_HIP(bufs.get(&dwo, (size_t)n * 8)); GM_HIP(hipMemcpy(dwo, genome_woff, (size_t)n * 8, hipMemcpyHostToDevice));
   int** const dst[5] = {&dn, &drl, &dgi, &dri, &dib}; const int* const src[5] = {glen, rlen, g_idx, r_idx, initbp};
-  for (int k = 0; k < 5; k++) { if (!src[k]) continue; GM_HIP(hipMalloc(dst[k], (size_t)n * 4)); GM_HIP(hipMemcpy(*dst[k], src[k], (size_t)n * 4, hipMemcpyHostToDevice)); }
-  GM_HIP(hipMalloc(&ds, (size_t)n * 4));
+  for (int k = 0; k < 5; k++) { if (!src[k]) continue; GM_HIP(bufs.get(dst[k], (size_t)n * 4)); GM_HIP(hipMemcpy(*dst[k], src[k], (size_t)n * 4, hipMemcpyHostToDevice)); }
+  GM_HIP(bufs.get(&ds, (size_t)n * 4));
   int rc = gm_launch_sw_gapless_batch(n, g_sg.match, g_sg.mismatch, dg, dgl, dwo, dn, dr, read_words, drl, dgi, dri, dib, max_r, ds, 0);
   if (rc == GM_OK) { GM_HIP(hipDeviceSynchronize()); GM_HIP(hipMemcpy(scores, ds, (size_t)n * 4, hipMemcpyDeviceToHost)); }
-  (void)hipFree(dg); if (dgl) (void)hipFree(dgl); (void)hipFree(dr); (void)hipFree(dwo); (void)hipFree(dn); (void)hipFree(drl); (void)hipFree(dgi); (void)hipFree(dri);
-  if (dib) (void)hipFree(dib); (void)hipFree(ds);
-  for (int i = 0; i < n; i++) { g_sg.invocs++; g_sg.cells += (uint64_t)rlen[i]; }              // ref: sw-gapless.c:111 (cells += rlen)
-  g_sg.ticks += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  if (rc == GM_OK) {                                                                             // (a failed launch scored nothing: it does not count)
+    for (int i = 0; i < n; i++) { g_sg.invocs++; g_sg.cells += (uint64_t)rlen[i]; }              // ref: sw-gapless.c:111 (cells += rlen)
+    g_sg.ticks += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  }
   return rc;
 }
 extern "C" int sw_gapless(uint32_t* genome, int glen, uint32_t* read, int rlen, int g_idx, int r_idx, uint32_t* genome_ls, int init_bp, bool is_rna) {
@@ -2043,28 +2051,39 @@ extern "C" void sw_full_cs(uint32_t* genome_ls, int goff, int glen, uint32_t* re
   (void)is_rna;
   if (!g_sc.init) abort();   // ref: sw-full-cs.c:1155-1156
   SeamTimer tm(&g_sc.secs); g_sc.invocs++; g_sc.cells += 4ull * (uint64_t)std::max(glen, 0) * (uint64_t)std::max(rlen, 0);
-  auto fail = [&](const char* why) { gm_set_error("sw_full_cs: %s", why); sfr->score = 0; sfr->dbalign = nullptr; sfr->qralign = nullptr; };
-  if (crossover_score || anchors == nullptr || anchors_cnt != 1 || glen > g_sc.dblen || rlen > g_sc.qrlen || glen < 1 || rlen < 1 ||
+  // A refusal must not read as "no alignment" (score 0 is what a window below the threshold returns): the reason goes to stderr as well as to gm_last_error().
+  auto fail = [&](const char* why) { gm_set_error("sw_full_cs: %s", why); fprintf(stderr, "gmapper_hip: sw_full_cs refused: %s\n", why); sfr->score = 0; sfr->dbalign = nullptr; sfr->qralign = nullptr; };
+  if (anchors == nullptr || anchors_cnt != 1 || glen > g_sc.dblen || rlen > g_sc.qrlen || glen < 1 || rlen < 1 ||
       initbp < 0 || initbp > 3 || g_sc.p[7] < 0) {
-    fail("only one anchor box and the global crossover penalty (gmapper's call, ref: mapping.c:375-379) are implemented"); return;
+    fail("only one anchor box (gmapper's call, ref: mapping.c:375-379) is implemented"); return;
+  }
+  // crossover_score: one score per read position (from the QVs, ref: gmapper.c:532-544 -- clamped there to [2 * global, -1]); the kernels keep a row of them in 8 bits
+  std::vector<int8_t> xrow;
+  if (crossover_score) {
+    xrow.resize((size_t)rlen + 16, 0);
+    for (int i = 0; i < rlen; i++) {
+      if (crossover_score[i] < -128 || crossover_score[i] > 127) { fail("a per-position crossover score outside [-128, 127] (the device keeps them in 8 bits)"); return; }
+      xrow[i] = (int8_t)crossover_score[i];
+    }
   }
   const uint64_t gw = ((uint64_t)goff + glen + 7) / 8 + 8; const int rwords = (rlen + 7) / 8 + 1;
   const int ops_cap = glen + rlen + 8;
   const size_t back_bytes = ((size_t)glen * rlen * 3 + 64) * 4;
-  uint32_t *dg = nullptr, *dr = nullptr, *dback = nullptr; uint8_t* dops = nullptr; int* dout = nullptr;
+  uint32_t *dg = nullptr, *dr = nullptr, *dback = nullptr; uint8_t* dops = nullptr; int* dout = nullptr; int8_t* dx = nullptr;
   bool ok = hipMalloc(&dg, gw * 4) == hipSuccess && hipMalloc(&dr, (size_t)rwords * 4) == hipSuccess && hipMalloc(&dback, back_bytes) == hipSuccess &&
-            hipMalloc(&dops, ops_cap) == hipSuccess && hipMalloc(&dout, 16 * 4) == hipSuccess;
+            hipMalloc(&dops, ops_cap) == hipSuccess && hipMalloc(&dout, 16 * 4) == hipSuccess && (xrow.empty() || hipMalloc(&dx, xrow.size()) == hipSuccess);
   int out[16] = {0}; std::vector<uint8_t> ops(ops_cap);
   if (ok) {
     ok = hipMemset(dg, 0, gw * 4) == hipSuccess && hipMemcpy(dg, genome_ls, (gw - 8) * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemset(dr, 0, (size_t)rwords * 4) == hipSuccess && hipMemcpy(dr, read, (size_t)(rwords - 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         (!dx || hipMemcpy(dx, xrow.data(), xrow.size(), hipMemcpyHostToDevice) == hipSuccess) &&
          hipMemset(dback, 0, back_bytes) == hipSuccess &&                                     // out-of-band cells: back == 0 (ref: init_cell)
          gm_launch_sw_full_cs_single(g_sc.p, dg, goff, glen, dr, rlen, initbp, threshscore, anchors[0].x, anchors[0].y, anchors[0].length, anchors[0].width,
-                                     revcmpl ? 1 : 0, dback, dout, dops, ops_cap, 0, local_alignment ? 1 : 0) == GM_OK &&
+                                     revcmpl ? 1 : 0, dback, dout, dops, ops_cap, 0, local_alignment ? 1 : 0, dx) == GM_OK &&
          hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, dout, 12 * 4, hipMemcpyDeviceToHost) == hipSuccess &&
          hipMemcpy(ops.data(), dops, ops_cap, hipMemcpyDeviceToHost) == hipSuccess;
   }
-  (void)hipFree(dg); (void)hipFree(dr); (void)hipFree(dback); (void)hipFree(dops); (void)hipFree(dout);
+  (void)hipFree(dg); (void)hipFree(dr); (void)hipFree(dback); (void)hipFree(dops); (void)hipFree(dout); (void)hipFree(dx);
   if (!ok) { fail("HIP failure"); return; }
   sfr->score = out[0];
   if (out[0] <= 0) { sfr->score = 0; sfr->dbalign = nullptr; sfr->qralign = nullptr; return; }          // below threshold: no strings (ref :1224-1226)

@@ -77,6 +77,7 @@ int gm_index_derive_strips(GmIndexHost* ix, hipStream_t stream);     // strip li
 void gm_lookup5_set_start_flags(uint32_t* flags, int cap, uint32_t epoch);
 int gm_lookup5_start_flag_grid(void);
 int gm_lookup5_last_rounds(void);
+int gm_lookup5_last_half(void);
 int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words, int max_n_kmers, int NL,
                       uint64_t* d_out, uint32_t* d_out_cnt, int out_cap, uint32_t* d_surv_cnt, int prune, uint32_t D, int e_max,
                       uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap, unsigned long long* d_stats, hipStream_t stream,
@@ -177,4 +178,4 @@ int gm_launch_sw_vector_batch_cs(const GmScoreDev& sc, int n, const uint32_t* d_
                                  int* d_scores, hipStream_t stream);
 int gm_launch_sw_full_cs_single(const int* cs_params9, const uint32_t* d_genome_ls, long long goff, int glen, const uint32_t* d_read, int rlen, int initbp,
                                 int thresh, long long ax, long long ay, int alen, int awidth, int revcmpl, uint32_t* d_back, int* d_out, uint8_t* d_ops,
-                                int ops_cap, hipStream_t stream, int local = 0);
+                                int ops_cap, hipStream_t stream, int local = 0, const int8_t* d_xrow = nullptr);

@@ -1120,7 +1120,9 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
 }
 
 // start flags of the persistent K1 grid (see gm_host.hip, pipeline_back): set before a launch, consumed by it
-static uint32_t* g_k4_flags = nullptr; static uint32_t g_k4_epoch = 0; static int g_k4_flag_cap = 0, g_k4_flag_grid = 0;
+// Launch state of the CALLING THREAD (thread_local: a session's front pipeline sets the flags, launches and reads the grid back on one host thread; two threads that map
+// on two devices side by side each keep their own -- round 3 advisor: as process-wide statics one session could launch with the other's pinned flag pointer and epoch).
+static thread_local uint32_t* g_k4_flags = nullptr; static thread_local uint32_t g_k4_epoch = 0; static thread_local int g_k4_flag_cap = 0, g_k4_flag_grid = 0;
 void gm_lookup_set_start_flags(uint32_t* flags, int cap, uint32_t epoch) { g_k4_flags = flags; g_k4_flag_cap = cap; g_k4_epoch = epoch; g_k4_flag_grid = 0; }
 int gm_lookup_start_flag_grid(void) { return g_k4_flag_grid; }   // workgroups that will raise a flag for the last launch (0: none)
 
@@ -1216,8 +1218,8 @@ static int k1_mp_lds(size_t& lds) {
   return GM_OK;
 }
 
-static const char* g_k1_name = "";
-extern "C" const char* gm_last_lookup_kernel(void) { return g_k1_name; }   // which K1 variant the last gm_launch_lookup chose (for bench.py / profiles)
+static thread_local const char* g_k1_name = "";
+extern "C" const char* gm_last_lookup_kernel(void) { return g_k1_name; }   // which K1 variant the calling thread's last gm_launch_lookup chose (for bench.py / profiles)
 
 int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words,
                      uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
@@ -1284,7 +1286,7 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     gm_lookup5_set_start_flags(nullptr, 0, 0);
     if (r < 0) return r;
     if (r == 1) {
-      g_k1_name = gm_lookup5_last_rounds() > 1 ? "k_lookup_v5_rounds" : "k_lookup_v5";
+      g_k1_name = gm_lookup5_last_half() ? "k_lookup_v5_half" : gm_lookup5_last_rounds() > 1 ? "k_lookup_v5_rounds" : "k_lookup_v5";
       // read-strands whose candidates did not fit the LDS tiers (none on the benchmark genome): the slab-sweep kernel in list mode (blocks beyond the list's end
       // return at once), then K1b for those.  (k_lookup_v4 in list mode was tried for them: no faster, and its 134 KB workgroups wait longer for a CU.)
       hipLaunchKernelGGL(k_lookup<false>, dim3(std::min(fbcap, 1024)), dim3(K1_THREADS), lds, stream, ix, d_reads, n_reads, read_len, read_words,

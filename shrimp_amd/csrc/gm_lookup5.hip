@@ -45,7 +45,7 @@ typedef __attribute__((address_space(3))) uint16_t k5_lds_u16;
 #ifndef K5_Q
 #define K5_Q 4            // list chunks in flight per wave (r03 sweep, ms per 262 144 reads: 1: 87.3, 2: 71.0, 3: 68.6, 4: 65.2, 5: see DESIGN, 6: 69.9, 10: 74.3)
 #endif
-enum { C_NCAND = 0, C_OVERFLOW, C_NMEMB, C_NKEEP, C_NSTRIP, C_NEDGE, C_NLISTS /* two words: read-strands alternate */, C_SINK = 8, C_NRAW = 9, C_NDEFER = 10, C_SPILL = 12 /* K5_MAX_ROUNDS - 1 words */, C_WORDS = 16 };
+enum { C_NCAND = 0, C_OVERFLOW, C_NMEMB, C_NKEEP, C_NSTRIP, C_NEDGE, C_NLISTS /* two words: read-strands alternate */, C_SINK = 8, C_NRAW = 9, C_NDEFER = 10, C_NCAND0 = 11 /* rounds: the candidates of part 0 */, C_SPILL = 12 /* K5_MAX_ROUNDS - 1 words */, C_WORDS = 16 };
 #define K5_MAX_ROUNDS 4
 
 // Diagnostic build (-DK5_STAMPS): thread 0 of every workgroup adds the cycles between the phase boundaries of each read-strand to k5_stamps[]
@@ -108,6 +108,26 @@ __device__ __forceinline__ uint32_t k5_lane_times(int lane, uint32_t W) {
 #define K5_KERNEL_LSWC 15
 #include "gm_lookup5_kernel.inc"
 #undef K5_KERNEL_HEAD
+#undef K5_KERNEL_MULTI
+#undef K5_KERNEL_LSWC
+// The HALF-SIZE shape with rounds (round 4): 512 threads, tables of 2^19 + 2^16 bits -- 80 KB of LDS with the records, so that TWO workgroups share a CU and the phases of two
+// read-strands (pass A: memory; pass B: L2 / vector issue; exact stages: LDS round trips) overlap instead of running one after the other.  The smaller seen[] table is a blocked
+// Bloom filter (two bits per region, see the kernel body); the candidates (2 720 slots, region table of 4 096) go through the rounds of k_lookup_v5_rounds.
+#define K5_KERNEL_HEAD __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) k_lookup_v5_half(GmIndexDev ix, K5Args a)
+#define K5_KERNEL_MULTI true
+#define K5_KERNEL_LSWC 14
+#define K5_KERNEL_BLOOM true
+#include "gm_lookup5_kernel.inc"
+#undef K5_KERNEL_HEAD
+#undef K5_KERNEL_BLOOM
+#ifdef GM_TUNING
+// (the same without the Bloom bits: the measurement beside it, tuning builds only)
+#define K5_KERNEL_HEAD __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) k_lookup_v5_half_plain(GmIndexDev ix, K5Args a)
+#define K5_KERNEL_BLOOM false
+#include "gm_lookup5_kernel.inc"
+#undef K5_KERNEL_HEAD
+#undef K5_KERNEL_BLOOM
+#endif
 #undef K5_KERNEL_MULTI
 #undef K5_KERNEL_LSWC
 
@@ -193,11 +213,13 @@ int gm_index_derive_strips(GmIndexHost* ix, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 struct K5Scratch { uint32_t* fb = nullptr; uint32_t* pl = nullptr; int fb_cap = 0; int cus = 0; uint2* spill = nullptr; size_t spill_n = 0; };   // fb: read-strands for the lane-per-list kernel + K1b; pl: for K1b only
 static K5Scratch g_k5[16];
-static uint32_t* g_k5_flags = nullptr; static uint32_t g_k5_epoch = 0; static int g_k5_flag_cap = 0, g_k5_flag_grid = 0;
+// (launch state of the calling thread, like gm_lookup.hip's: set, used and read back by one host thread per launch)
+static thread_local uint32_t* g_k5_flags = nullptr; static thread_local uint32_t g_k5_epoch = 0; static thread_local int g_k5_flag_cap = 0, g_k5_flag_grid = 0;
 void gm_lookup5_set_start_flags(uint32_t* flags, int cap, uint32_t epoch) { g_k5_flags = flags; g_k5_flag_cap = cap; g_k5_epoch = epoch; g_k5_flag_grid = 0; }
 int gm_lookup5_start_flag_grid(void) { return g_k5_flag_grid; }
-static int g_k5_last_rounds = 1;
+static thread_local int g_k5_last_rounds = 1, g_k5_last_half = 0;
 int gm_lookup5_last_rounds(void) { return g_k5_last_rounds; }      // rounds of the last launch (> 1: k_lookup_v5_rounds)
+int gm_lookup5_last_half(void) { return g_k5_last_half; }            // the last launch was k_lookup_v5_half
 
 int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words, int max_n_kmers, int NL,
                       uint64_t* d_out, uint32_t* d_out_cnt, int out_cap, uint32_t* d_surv_cnt, int prune, uint32_t D, int e_max,
@@ -238,9 +260,19 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
     const double cap14 = (double)(((4u << 14) / 4u / 6u) & ~15u);
     if (memb + late + first <= 0.5 * cap14 && fixed + (size_t)(4u << 14) + (size_t)(4u << 11) <= 96 * 1024) { small_shape = true; lsw = 14; threads = 512; }
   }
+  // The half-size shape with rounds (k_lookup_v5_half): two 512-thread workgroups per CU, 80 KB of LDS each.  GM_K5_HALF=1 forces it, =2 takes the variant without the
+  // Bloom bits (tuning builds), =0 switches it off.
+  int half = 0;
+  if (const char* e = gm_tune("GM_K5_HALF")) half = atoi(e);
+  const size_t half_budget = 80 * 1024 - 512, half_tables = (size_t)(4u << 14) + (size_t)(4u << 11);
+  if (half && (ix.region_bits < 11 || NL > 512 || fixed0 + 24 * 8 + half_tables > half_budget)) half = 0;
+  if (half) { lsw = 14; threads = 512; xrec = (int)std::min<size_t>(64, (half_budget - half_tables - fixed0) / 24); }
+  const size_t fixed_h = fixed0 + 24 * (size_t)xrec;
+  if (!half)
   if (const char* e = gm_tune("GM_K5_LSW")) lsw = std::max(8, std::min(15, atoi(e)));
-  while (lsw >= 8 && fixed + (size_t)(4u << lsw) + (size_t)(4u << (lsw - 3)) > budget) lsw--;
+  while (!half && lsw >= 8 && fixed + (size_t)(4u << lsw) + (size_t)(4u << (lsw - 3)) > budget) lsw--;
   if (lsw < 8) return 0;
+  if (!half)
   if (const char* e = gm_tune("GM_K1_THREADS")) { const int v = std::max(64, std::min(1024, atoi(e))); threads = 64; while (threads * 2 <= v) threads *= 2; }
   const int ltw = lsw - 3;                                     // twice[] = an eighth of seen[]
   const int hbits = lsw - 2;                                   // the region table (12 B per slot) takes three quarters of the seen[] area,
@@ -252,25 +284,26 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
     // echoes of a real hit) + later arrivals on a shared seen[] bit + first arrivals that meet a set twice[] bit.  Read-strands beyond the candidate
     // array fall back to the slab-sweep kernel: when that would be the rule (2 x 150 bp reads on 3 Gbp: ~9 k), k_lookup_v4 is the better kernel.
     const double lam = entries * (double)((1u << ix.region_bits) + ix.region_overlap) / std::max(1.0, (double)ix.total_len);
-    const double memb = 2.0 * entries * std::min(1.0, lam), late = 0.5 * entries * std::min(1.0, entries / (double)(32ull << lsw));
+    // (the Bloom bits of the half-size shape: the rate of a table of twice the size)
+    const double memb = 2.0 * entries * std::min(1.0, lam), late = 0.5 * entries * std::min(1.0, entries / (double)(32ull << (lsw + (half == 1 ? 1 : 0))));
     const double first = entries * std::min(1.0, (late + 0.5 * memb) / (double)(32ull << (lsw - 3)));
     // More than one round (pass B and the exact stages per part of the genome) for long reads, as long as the passes over the lists stay cheaper than the separate
     // kernels: up to four.
     // (The estimate is generous for long reads -- 12.8 k against 9.2 k counted for 150-base reads on 3 Gbp -- and a round costs 10 % of the kernel: two parts there, 4.6 k
     // candidates each against 5 456 slots, no read-strand of 262 144 fell back; one that does is redone exactly by the fall-back kernels.)
     if (memb + late + first > 0.85 * cand_cap) {
-      rounds = (int)std::ceil((memb + late + first) / (1.25 * cand_cap));
+      rounds = (int)std::ceil((memb + late + first) / ((half ? 0.95 : 1.25) * cand_cap));
       rounds = std::max(rounds, 2);
-      if (rounds > K5_MAX_ROUNDS || NL > threads || lsw != 15) return 0;
+      if (rounds > K5_MAX_ROUNDS || NL > threads || lsw != (half ? 14 : 15)) return 0;
     }
   }
-  if (const char* e = gm_tune("GM_K5_ROUNDS")) { rounds = std::max(1, std::min(K5_MAX_ROUNDS, atoi(e))); if (rounds > 1 && (NL > threads || lsw != 15)) return 0; }
+  if (const char* e = gm_tune("GM_K5_ROUNDS")) { rounds = std::max(1, std::min(K5_MAX_ROUNDS, atoi(e))); if (rounds > 1 && (NL > threads || lsw != (half ? 14 : 15))) return 0; }
   // the genome's regions dealt evenly to the rounds (positions are 32 bits; the last round takes what is left)
   const uint32_t n_regs = (uint32_t)((ix.total_len + (1ull << ix.region_bits) - 1) >> ix.region_bits);
   const uint32_t round_regs = std::max(1u, (n_regs + (uint32_t)rounds - 1u) / (uint32_t)rounds);
   if (const char* e = gm_tune("GM_K5_CANDLIMIT")) cand_limit = std::max(1, std::min(cand_limit, atoi(e)));
   if (prune && (D + (uint32_t)std::max(0, e_max) > (1u << ix.region_bits) || D > 0xFFFFu)) return 0;   // the prune rules need bins (= regions) of at least D + e_max positions
-  const size_t lds = fixed + (size_t)(4u << lsw) + (size_t)(4u << ltw);
+  const size_t lds = (half ? fixed_h : fixed) + (size_t)(4u << lsw) + (size_t)(4u << ltw);
   const int fb_cap = std::max(4096, 2 * n_reads);              // every read-strand may fall back (tiny tables in the tests, repeats)
   if (!K.cus) { if (hipDeviceGetAttribute(&K.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || K.cus < 1) K.cus = 256; }
   if (fb_cap > K.fb_cap) {
@@ -286,10 +319,14 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
     if (hipFuncSetAttribute((const void*)k_lookup_v5<15>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_lookup_v5<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_lookup_v5_rounds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_lookup_v5_half, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+#ifdef GM_TUNING
+        hipFuncSetAttribute((const void*)k_lookup_v5_half_plain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+#endif
         hipFuncSetAttribute((const void*)k_lookup_v5<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
     configured = lds;
   }
-  int grid = std::min(2 * n_reads, K.cus);
+  int grid = std::min(2 * n_reads, half ? 2 * K.cus : K.cus);
   if (const char* e = gm_tune("GM_K5_GRID")) grid = std::max(1, std::min(2 * n_reads, atoi(e)));
   K5Args a;
   a.reads = d_reads; a.n_reads = n_reads; a.read_len = read_len; a.read_words = read_words; a.max_n_kmers = max_n_kmers; a.NL = NL;
@@ -301,7 +338,7 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   const bool use_flags = g_k5_flags && grid <= g_k5_flag_cap;
   g_k5_flag_grid = use_flags ? grid : 0;
   a.start_flags = use_flags ? g_k5_flags : nullptr; a.start_epoch = g_k5_epoch;
-  g_k5_last_rounds = rounds;
+  g_k5_last_rounds = rounds; g_k5_last_half = half;
   a.spill = nullptr; a.spill_cap = cand_cap;
   if (rounds > 1) {
     const size_t need = (size_t)grid * (size_t)(rounds - 1) * (size_t)cand_cap;
@@ -312,7 +349,12 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
     }
     a.spill = K.spill;
   }
-  if (rounds > 1) hipLaunchKernelGGL(k_lookup_v5_rounds, dim3(grid), dim3(threads), lds, stream, ix, a);
+  if (half) {
+#ifdef GM_TUNING
+    if (half == 2) hipLaunchKernelGGL(k_lookup_v5_half_plain, dim3(grid), dim3(threads), lds, stream, ix, a); else
+#endif
+    hipLaunchKernelGGL(k_lookup_v5_half, dim3(grid), dim3(threads), lds, stream, ix, a);
+  } else if (rounds > 1) hipLaunchKernelGGL(k_lookup_v5_rounds, dim3(grid), dim3(threads), lds, stream, ix, a);
   else if (lsw == 15) hipLaunchKernelGGL((k_lookup_v5<15>), dim3(grid), dim3(threads), lds, stream, ix, a);
   else if (lsw == 14) hipLaunchKernelGGL((k_lookup_v5<14>), dim3(grid), dim3(threads), lds, stream, ix, a);
   else hipLaunchKernelGGL((k_lookup_v5<0>), dim3(grid), dim3(threads), lds, stream, ix, a);

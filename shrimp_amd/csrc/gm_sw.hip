@@ -1483,7 +1483,7 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
 __global__ void __launch_bounds__(GM_WAVE)
 k_sw_full_cs_single(GmCsDev P, const uint32_t* __restrict__ genome_ls, long long goff, int glen, const uint32_t* __restrict__ read, int rlen, int initbp,
                     int thresh, long long ax, long long ay, int alen, int awidth, int revcmpl, uint32_t* __restrict__ back, int* __restrict__ out,
-                    uint8_t* __restrict__ ops, int ops_cap, int local) {
+                    uint8_t* __restrict__ ops, int ops_cap, int local, const int8_t* __restrict__ xrow) {
   extern __shared__ __align__(16) uint8_t sm[];
   const int lane = threadIdx.x;
   const int qstride = (rlen + 15) & ~15;
@@ -1514,11 +1514,11 @@ k_sw_full_cs_single(GmCsDev P, const uint32_t* __restrict__ genome_ls, long long
   CsBest fo;
   if (local) {                                        // ref: sw-full-cs.c:199-203,315,439-552
     const bool act = lane < 16;
-    if (revcmpl) fo = P.taboo > 0 ? full_sw_cs_g4<true, true, true>(db, glen, qr4, qstride, rlen, P, act, (int)rx, (int)ry, rl, rw, back, carry, lane, nullptr)
-                                  : full_sw_cs_g4<true, false, true>(db, glen, qr4, qstride, rlen, P, act, (int)rx, (int)ry, rl, rw, back, carry, lane, nullptr);
-    else fo = P.taboo > 0 ? full_sw_cs_g4<false, true, true>(db, glen, qr4, qstride, rlen, P, act, (int)rx, (int)ry, rl, rw, back, carry, lane, nullptr)
-                          : full_sw_cs_g4<false, false, true>(db, glen, qr4, qstride, rlen, P, act, (int)rx, (int)ry, rl, rw, back, carry, lane, nullptr);
-  } else fo = full_sw_cs_wave<true>(db, glen, qr4, qstride, rlen, P, revcmpl != 0, rx, ry, rl, rw, back, carry, lane);
+    if (revcmpl) fo = P.taboo > 0 ? full_sw_cs_g4<true, true, true>(db, glen, qr4, qstride, rlen, P, act, (int)rx, (int)ry, rl, rw, back, carry, lane, xrow)
+                                  : full_sw_cs_g4<true, false, true>(db, glen, qr4, qstride, rlen, P, act, (int)rx, (int)ry, rl, rw, back, carry, lane, xrow);
+    else fo = P.taboo > 0 ? full_sw_cs_g4<false, true, true>(db, glen, qr4, qstride, rlen, P, act, (int)rx, (int)ry, rl, rw, back, carry, lane, xrow)
+                          : full_sw_cs_g4<false, false, true>(db, glen, qr4, qstride, rlen, P, act, (int)rx, (int)ry, rl, rw, back, carry, lane, xrow);
+  } else fo = full_sw_cs_wave<true>(db, glen, qr4, qstride, rlen, P, revcmpl != 0, rx, ry, rl, rw, back, carry, lane, xrow);
   __syncthreads();
   __threadfence();
   if (lane == 0) {
@@ -2212,7 +2212,7 @@ int gm_launch_sw_vector_batch_cs(const GmScoreDev& sc, int n, const uint32_t* d_
 
 int gm_launch_sw_full_cs_single(const int* cs_params9, const uint32_t* d_genome_ls, long long goff, int glen, const uint32_t* d_read, int rlen, int initbp,
                                 int thresh, long long ax, long long ay, int alen, int awidth, int revcmpl, uint32_t* d_back, int* d_out, uint8_t* d_ops,
-                                int ops_cap, hipStream_t stream, int local) {
+                                int ops_cap, hipStream_t stream, int local, const int8_t* d_xrow) {
   GmCsDev P; P.match = cs_params9[0]; P.mismatch = cs_params9[1]; P.xover = cs_params9[2]; P.a_go = cs_params9[3]; P.a_ge = cs_params9[4];
   P.b_go = cs_params9[5]; P.b_ge = cs_params9[6]; P.anchor_width = cs_params9[7]; P.taboo = cs_params9[8];
   const size_t lds = 5 * (size_t)((rlen + 15) & ~15) + ((glen + 15) & ~15) + (size_t)glen * 48 + 64;
@@ -2220,7 +2220,7 @@ int gm_launch_sw_full_cs_single(const int* cs_params9, const uint32_t* d_genome_
   if (lds > 160 * 1024) { gm_set_error("sw_full_cs: window of %d does not fit LDS", glen); return GM_E_ARG; }
   if (lds > 48 * 1024 && lds > configured) { GM_HIP(hipFuncSetAttribute((const void*)k_sw_full_cs_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
   hipLaunchKernelGGL(k_sw_full_cs_single, dim3(1), dim3(GM_WAVE), lds, stream, P, d_genome_ls, goff, glen, d_read, rlen, initbp, thresh, ax, ay, alen, awidth,
-                     revcmpl, d_back, d_out, d_ops, ops_cap, local);
+                     revcmpl, d_back, d_out, d_ops, ops_cap, local, d_xrow);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

@@ -641,14 +641,16 @@ def sw_full_cs_setup(dblen, qrlen, a_gap_open, a_gap_ext, b_gap_open, b_gap_ext,
            "sw_full_cs_setup")
 
 
-def sw_full_cs(genome_ls, goff, glen, read_words, rlen, initbp, thresh, anchor, revcmpl=False, local=False):
-    """anchor = (x, y, length, width); local: the reference's local_alignment argument; returns (fields dict incl. crossovers, dbalign, qralign)."""
+def sw_full_cs(genome_ls, goff, glen, read_words, rlen, initbp, thresh, anchor, revcmpl=False, local=False, xover=None):
+    """anchor = (x, y, length, width); local: the reference's local_alignment argument; xover: the reference's crossover_score argument (one int per read position, what
+    gmapper hands over for a read with quality values, ref: mapping.c:375-379) or None; returns (fields dict incl. crossovers, dbalign, qralign)."""
     L = lib()
     g = np.ascontiguousarray(genome_ls, dtype=np.uint32); r = np.ascontiguousarray(read_words, dtype=np.uint32)
     a = Anchor(anchor[0], anchor[1], anchor[2], anchor[3], 1, 0, 0)
     s = SwFullResults()
+    xs = None if xover is None else np.ascontiguousarray(xover, dtype=np.int32)
     L.sw_full_cs(g.ctypes.data_as(C.POINTER(C.c_uint32)), goff, glen, r.ctypes.data_as(C.POINTER(C.c_uint32)), rlen, initbp, thresh,
-                 C.byref(s), bool(revcmpl), False, C.byref(a), 1, 1 if local else 0, None)
+                 C.byref(s), bool(revcmpl), False, C.byref(a), 1, 1 if local else 0, None if xs is None else xs.ctypes.data_as(C.POINTER(C.c_int)))
     db = C.string_at(s.dbalign).decode() if s.dbalign else ""
     qr = C.string_at(s.qralign).decode() if s.qralign else ""
     if s.dbalign: L.gm_free(s.dbalign)

@@ -334,6 +334,9 @@ def load_kat_cs(name="sw_kat_cs.txt.gz"):
             t = line.split()
             if t[0] == b"C":
                 recs.append(("C", int(t[1]), int(t[2]), int(t[3]), int(t[4]), words(t[5]), words(t[6]), words(t[7]), int(t[8])))
+            elif t[0] in (b"X", b"Y"):      # sw_kat_cs_xover.txt.gz: per-position crossover scores behind the read words (X: global, Y: local mode)
+                recs.append((t[0].decode(), [int(x) for x in t[1:11]], words(t[11]), words(t[12]), [int(x) for x in t[14:24]],
+                             b"" if t[24] == b"-" else t[24], b"" if t[25] == b"-" else t[25], np.array([int(x) for x in t[13].split(b",")], dtype=np.int32)))
             else:
                 recs.append((t[0].decode(), [int(x) for x in t[1:11]], words(t[11]), words(t[12]), [int(x) for x in t[13:23]],
                              b"" if t[23] == b"-" else t[23], b"" if t[24] == b"-" else t[24]))

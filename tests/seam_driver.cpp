@@ -98,14 +98,16 @@ int main() {
       printf("F %d %d %d %d %d %d %d %d %d %s %s\n", f.score, f.read_start, f.rmapped, f.genome_start, f.gmapped, f.matches, f.mismatches, f.insertions, f.deletions,
              str(f.dbalign), str(f.qralign));
       free(f.dbalign); free(f.qralign);
-    } else if (op == "S" || op == "P" || op == "L") {
+    } else if (op == "S" || op == "P" || op == "L" || op == "X" || op == "Y") {      // X / Y: crossover_score[] behind the read (global / local mode)
       std::string q; if (op == "P") in >> q;
-      int goff, glen, rlen, ib, rv, thresh; struct anchor a; memset(&a, 0, sizeof a); std::string gl, r;
+      int goff, glen, rlen, ib, rv, thresh; struct anchor a; memset(&a, 0, sizeof a); std::string gl, r, xs;
       in >> goff >> glen >> rlen >> ib >> a.x >> a.y >> a.length >> a.width >> rv >> thresh >> gl >> r; a.weight = 2;
+      std::vector<int> xv;
+      if (op == "X" || op == "Y") { in >> xs; const char* p = xs.c_str(); while (*p) { char* e; xv.push_back((int)strtol(p, &e, 10)); p = e; if (*p == ',') p++; } }
       auto glw = words(gl), rw = words(r);
       struct sw_full_results f; memset(&f, 0, sizeof f);
-      sw_full_cs(glw.data(), goff, glen, rw.data(), rlen, ib, thresh, &f, rv != 0, false, &a, 1, op == "L" ? 1 : 0, nullptr);
-      if (op == "S" || op == "L") {
+      sw_full_cs(glw.data(), goff, glen, rw.data(), rlen, ib, thresh, &f, rv != 0, false, &a, 1, (op == "L" || op == "Y") ? 1 : 0, xv.empty() ? nullptr : xv.data());
+      if (op != "P") {
         printf("%s %d %d %d %d %d %d %d %d %d %d %s %s\n", op.c_str(), f.score, f.read_start, f.rmapped, f.genome_start, f.gmapped, f.matches, f.mismatches, f.insertions, f.deletions,
                f.crossovers, str(f.dbalign), str(f.qralign));
       } else {

@@ -234,6 +234,11 @@ KERNEL_VARIANTS = [
     {"GM_NO_BUCKETS": "1", "GM_K1_V5": "1", "GM_K5_ROUNDS": "2"},   # ... per half, one-slab index
     {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_ROUNDS": "4", "GM_NO_PRUNE": "1"},   # ... four parts, without the prune rules
     {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_ROUNDS": "3", "GM_SCAP": "256", "GM_SCAP2": "64"},   # ... more kept than K2's LDS tier takes: the whole read-strand falls back
+    {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_HALF": "1", "GM_K5_ROUNDS": "3"},   # the half-size shape (k_lookup_v5_half: two 512-thread workgroups per CU, Bloom bits in seen[], rounds)
+    {"GM_NO_BUCKETS": "1", "GM_K1_V5": "1", "GM_K5_HALF": "1", "GM_K5_ROUNDS": "2"},   # ... one-slab index, two parts
+    {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_HALF": "1", "GM_K5_ROUNDS": "1", "GM_NO_PRUNE": "1"},   # ... one part, without the prune rules
+    {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_HALF": "2", "GM_K5_ROUNDS": "4"},   # ... the variant without the Bloom bits, four parts
+    {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_HALF": "1", "GM_K5_ROUNDS": "2", "GM_K5_CANDLIMIT": "40"},   # ... most read-strands fall back
     {"GM_P1_EARLY": "0"},                                    # pass 1 without the early stop of windows that cannot reach the threshold
 ]
 
@@ -258,7 +263,7 @@ def test_kernel_variants_match_reference_golden(gm, name, env):
             if v is None: os.environ.pop(k, None)
             else: os.environ[k] = v
     assert got == sam, (_first_diff(got, sam), st)
-    want_kern = ("k_lookup_v5_rounds" if "GM_K5_ROUNDS" in env else "k_lookup_v5") if "GM_K1_V5" in env else ("k_lookup_v4" if "GM_K1_V4" in env else None)
+    want_kern = ("k_lookup_v5_half" if "GM_K5_HALF" in env else "k_lookup_v5_rounds" if "GM_K5_ROUNDS" in env else "k_lookup_v5") if "GM_K1_V5" in env else ("k_lookup_v4" if "GM_K1_V4" in env else None)
     assert want_kern is None or kern == want_kern, kern
 
 
@@ -631,6 +636,23 @@ def test_colour_space_kernels_known_answers(gm):
             assert got == want and gdb.encode() == db and gqr.encode() == qr, (got, want, gdb, db, gqr, qr)
         nl += 1
     assert nl >= 800
+    # per-position crossover scores (crossover_score[]: what gmapper passes for every read with quality values, ref: mapping.c:375-379, sw-full-cs.c:312-322), global and local mode
+    nx = ny = 0
+    for r in oa.load_kat_cs("sw_kat_cs_xover.txt.gz"):
+        kind, (goff, glen, rlen, initbp, ax, ay, alen, awidth, rv, thresh), gls, rd, want, db, qr, xs = r
+        f, gdb, gqr = gm.sw_full_cs(gls, goff, glen, rd, rlen, initbp, thresh, (ax, ay, alen, awidth), revcmpl=bool(rv), local=(kind == "Y"), xover=xs)
+        if want[0] == 0:
+            assert f["score"] == 0, (f, want)
+        else:
+            got = [f[k] for k in ("score", "read_start", "rmapped", "genome_start", "gmapped", "matches", "mismatches", "insertions", "deletions", "crossovers")]
+            assert got == want and gdb.encode() == db and gqr.encode() == qr, (kind, got, want, gdb, db, gqr, qr)
+        nx += kind == "X"; ny += kind == "Y"
+    assert nx >= 1000 and ny >= 500
+    # a score the device cannot hold (8 bits a position) is refused loudly, not answered with "no alignment": the reason is in gm_last_error()
+    kind, (goff, glen, rlen, initbp, ax, ay, alen, awidth, rv, thresh), gls, rd, want, db, qr, xs = oa.load_kat_cs("sw_kat_cs_xover.txt.gz")[0]
+    bad = xs.copy(); bad[0] = -1000
+    f, _, _ = gm.sw_full_cs(gls, goff, glen, rd, rlen, initbp, thresh, (ax, ay, alen, awidth), xover=bad)
+    assert f["score"] == 0 and b"crossover score outside" in gm.lib().gm_last_error()
 
 
 CS_GOLDEN = ["cfg4s_50col_2Mbp", "stress_cs_60col_unal"]
@@ -980,6 +1002,11 @@ def test_mangled_seams_on_every_known_answer(gm, tmp_path):
         w, db, qr = r[4], r[5], r[6]
         req.append("L " + s_args(r))
         want.append("L " + " ".join(str(x) for x in w) + " %s %s" % ((db or b"-").decode(), (qr or b"-").decode()) if w[0] != 0 else None)
+    xrecs = oa.load_kat_cs("sw_kat_cs_xover.txt.gz")                # sw_full_cs with crossover_score[] (X: global, Y: local)
+    for r in xrecs:
+        w, db, qr = r[4], r[5], r[6]
+        req.append(r[0] + " " + s_args(r[:7]) + " " + ",".join(str(int(x)) for x in r[7]))
+        want.append(r[0] + " " + " ".join(str(x) for x in w) + " %s %s" % ((db or b"-").decode(), (qr or b"-").decode()) if w[0] != 0 else None)
     with gzip.open(os.path.join(oa.ROOT, "tests", "golden", "sw_kat_post.txt.gz"), "rt") as f: post = [l.split() for l in f if l.strip()]
     K = [t for t in post if t[0] == "K"][0][1:]
     nP = 0
@@ -1004,13 +1031,13 @@ def test_mangled_seams_on_every_known_answer(gm, tmp_path):
     bad = []
     for i, w in enumerate(want):
         if w is None:
-            if not (got[i].startswith("S 0 ") or got[i].startswith("L 0 ")): bad.append((i, got[i][:200], "S 0 ... / L 0 ..."))
+            if not got[i][:4] in ("S 0 ", "L 0 ", "X 0 ", "Y 0 "): bad.append((i, got[i][:200], "S 0 ... / L 0 ... / X 0 ... / Y 0 ..."))
         elif got[i] != w: bad.append((i, got[i][:300], w[:300]))
     assert not bad, (len(bad), bad[:5])
     st = [int(x) for x in got[len(want)].split()[1:]]
     # the *_stats entries (ref: gmapper.c:734-745 reads them): every set-up above resets its counters, so each shows the calls since its last set-up
     nq = sum(1 for t in post if t[0] == "P" and t[2] == "1")
-    assert st == [700, nG // 2, nF, len(srecs) + len(lrecs) + nP, nq], st
+    assert st == [700, nG // 2, nF, len(srecs) + len(lrecs) + len(xrecs) + nP, nq], st
 
 
 def test_full_size_genome_vs_oracle(gm, oracle_lib):

@@ -170,6 +170,23 @@ def test_oracle_sw_full_cs_local_mode_matches_reference_known_answers(oracle_lib
     assert n >= 800
 
 
+def test_oracle_sw_full_cs_crossover_scores_match_reference_known_answers(oracle_lib):
+    """sw_full_cs with crossover_score[] (per-position scores from the QVs, ref: sw-full-cs.c:312-322, gmapper.c:532-544): 500 cases x 2 tie-break directions in global
+    mode, every other case in local mode too, from the reference's own function (oracle/ref_kat_cs.cpp "xover")"""
+    import ctypes as C
+    L = oa.load(); u32p = C.POINTER(C.c_uint32)
+    n = 0
+    for r in oa.load_kat_cs("sw_kat_cs_xover.txt.gz"):
+        kind, (goff, glen, rlen, initbp, ax, ay, alen, awidth, rv, thresh), gls, rd, want, db, qr, xs = r
+        out = (C.c_int * 10)(); dba = C.create_string_buffer(4096); qra = C.create_string_buffer(4096)
+        assert L.gmo_sw_full_cs_xover(gls.ctypes.data_as(u32p), goff, glen, rd.ctypes.data_as(u32p), rlen, initbp, thresh, C.c_longlong(ax), C.c_longlong(ay), alen, awidth, rv,
+                                      1 if kind == "Y" else 0, xs.ctypes.data_as(C.POINTER(C.c_int)), out, dba, qra, 4096) == 0
+        if want[0] == 0: assert out[0] == 0
+        else: assert list(out) == want and dba.value == db and qra.value == qr, (kind, list(out), want, dba.value, db, qra.value, qr)
+        n += 1
+    assert n >= 1500
+
+
 CS_GOLDEN = ["cfg4s_50col_2Mbp", "stress_cs_60col_unal"]
 
 

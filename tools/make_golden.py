@@ -370,6 +370,10 @@ def cs_kat_cases():
     with gzip.open(os.path.join(OUT, "sw_kat_cs_local.txt.gz"), "wb", compresslevel=9) as f:
         f.write(katl)
     print("sw_kat_cs_local:", katl.count(b"\nL ") + 1, "sw_full_cs in local mode")
+    katx = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_kat_cs"), "500", "xover"], capture_output=True, check=True).stdout
+    with gzip.open(os.path.join(OUT, "sw_kat_cs_xover.txt.gz"), "wb", compresslevel=9) as f:
+        f.write(katx)
+    print("sw_kat_cs_xover:", katx.count(b"\nX ") + 1, "sw_full_cs with per-position crossover scores,", katx.count(b"\nY "), "of them in local mode")
 
 
 def post_kat_cases():
