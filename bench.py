@@ -205,12 +205,8 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if not have_ranks and args.gpus > 1:
-        # plain `python bench.py --gpus N`: start the N ranks as a child job.  This process has not touched the GPU (device_count() does not initialise HIP).
-        if not args.selftest_ranks:
-            import torch
-            have = torch.cuda.device_count()
-            if have < args.gpus:
-                raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, have))
+        # plain `python bench.py --gpus N`: start the N ranks as a child job.  This process makes no GPU call of any kind (not even a device count): a rank without
+        # a GPU fails by itself ("local rank k has no GPU") and the child's exit code is ours.
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
@@ -253,7 +249,7 @@ def main():
     t0 = time.time()
     contigs = synth.make_genome(synth.contig_lengths(gname, args.scale), gseed)
     t_gen = time.time() - t0
-    n_pool = min(2, args.steps + args.warmup)            # distinct batches, cycled
+    n_pool = min(10, args.steps + args.warmup)           # distinct batches, cycled: 10 x 1 M reads = the 10 M reads of BASELINE configs[2] (round 3 cycled two)
     pools = make_pools(synth, contigs, kind, R, L, rseed, rank, n_pool, dev)
     n_sample = args.cpu_sample or {"ls": 200_000, "cs": 50_000, "pairs": 20_000}[kind]
     sample = make_sample(synth, contigs, kind, n_sample, L, rseed)
@@ -289,7 +285,7 @@ def main():
         "config": {"workload": descr, ("pairs_per_step_per_gpu" if kind == "pairs" else "reads_per_step_per_gpu"): R, "read_len": L,
                    "genome_bp": int(sum(len(c) for c in contigs)),
                    "parallelism": "read-sharded x%d, index replicated (1 RCCL broadcast at start-up)" % world,
-                   "inputs": "reads resident in HBM" if kind == "ls" else "packed reads in host buffers, uploaded every step",
+                   "inputs": "reads resident in HBM" if kind == "ls" else "packed reads in host buffers, uploaded every step", "distinct_batches": n_pool,
                    "library": os.path.basename(gm.LIB_PATH) + ("" if not knobs else " (tuning knobs set: %s)" % ",".join(sorted(knobs))),
                    "sam_emitted": not args.no_sam, "scale": args.scale, "host_threads_per_rank": host_threads, "host_threads": threads_all,
                    "sub_batch_pipeline": "stage order" if os.environ.get("GM_OVERLAP") == "0" else "two streams (lookup of sub-batch i+1 beside SW of sub-batch i)",
@@ -396,7 +392,59 @@ def main():
                 others["cfg2"] = e
             except Exception as ex:
                 others["cfg2"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            # cfg3 end to end from TEXT: the same 1 M reads as FASTA-style lines through gm_map_reads_text -- parsing, packing to 4-bit codes and the upload are inside the
+            # timed region, as they are inside the reference's "Read Mapping Time" (ref: gmapper.c:322-398,800-804)
+            try:
+                reads_t, _ = synth.make_reads(contigs, R_def, L, shard_seed(rseed, 0, 10, 0))
+                lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+                lines = np.empty((R_def, L + 1), dtype=np.uint8); lines[:, :L] = lut[reads_t]; lines[:, L] = 10
+                text = lines.tobytes()[:-1]; del lines, reads_t
+                sess.map_text_buffer(text, R_def, L, return_bytes=False)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(3): sess.map_text_buffer(text, R_def, L, return_bytes=False)
+                torch.cuda.synchronize(); dt3 = time.perf_counter() - t0
+                others["cfg3_text"] = {"metric": metric, "unit": unit, "workload": descr + "; input = text lines (gm_map_reads_text: parse + pack + upload inside the timed region)",
+                                       "value": R_def * 3 / dt3, "steps": 3, "warmup": 1, "ms_per_step": 1e3 * dt3 / 3, "text_bytes_per_step": len(text)}
+                # ... and from a FASTA FILE through the streaming entry (gm_map_reads_file_cb: the reference's reader, chunks of 2^20 reads read and preprocessed by a second
+                # thread while the chunk before is mapped, records handed to a write function): 2 M reads, so that two chunks overlap
+                import tempfile
+                with tempfile.TemporaryDirectory() as td:
+                    fpath = os.path.join(td, "reads.fa")
+                    nm = np.char.add(np.char.add(">r", np.arange(R_def).astype("U8")), "\n").astype("S")
+                    body = text.split(b"\n")
+                    with open(fpath, "wb") as f:
+                        for rep in range(2): f.write(b"".join(a + b + b"\n" for a, b in zip(nm.tolist(), body)))
+                    del nm, body
+                    sess.map_reads_file_chunks(fpath, collect=False)
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    parts = sess.map_reads_file_chunks(fpath, collect=False)
+                    torch.cuda.synchronize(); dtf = time.perf_counter() - t0
+                    others["cfg3_file"] = {"metric": metric, "unit": unit, "workload": descr + "; input = a FASTA file of 2 M reads (gm_map_reads_file_cb: read + parse + preprocess + pack + upload inside the timed region)",
+                                           "value": 2 * R_def / dtf, "steps": 1, "warmup": 1, "ms_per_step": 1e3 * dtf, "chunks": len(parts), "file_bytes": os.path.getsize(fpath), "sam_bytes": int(sum(parts))}
+                del text
+            except Exception as ex:
+                others["cfg3_text"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
             out["other_workloads"] = others
+            # how the step depends on the host threads a rank gets (an 8-rank job on this node leaves each rank cores / 8): the headline workload and the host-bound
+            # 100 Mbp one again at 16 and 8 threads, three steps each (the library reads GM_HOST_THREADS at every call)
+            try:
+                hs = {}
+                keep = os.environ.get("GM_HOST_THREADS")
+                contigs2 = synth.make_genome(synth.contig_lengths("cfg2", 1.0), 2); ix2 = gm.Index(contigs2, device=local, params=params)
+                s2 = gm.Session(ix2, params=params, max_batch_reads=sub_batch("ls"))
+                pools2 = make_pools(synth, contigs2, "ls", 1_000_000, 100, 2, 0, 2, dev)
+                for nt in (32, 16, 8):
+                    if nt > host_threads and nt != 32: continue
+                    os.environ["GM_HOST_THREADS"] = str(min(nt, host_threads))
+                    d3 = timed_steps(gm, sess, kind, pools[:2], R, L, 3, 1, 1, dist, dev)
+                    d2 = timed_steps(gm, s2, "ls", pools2, 1_000_000, 100, 3, 1, 1, dist, dev)
+                    hs[str(min(nt, host_threads))] = {"cfg3_reads_per_s": R * 3 / d3[0], "cfg3_ms_host": d3[4]["ms_host"] / 3, "cfg2_reads_per_s": 3e6 / d2[0], "cfg2_ms_host": d2[4]["ms_host"] / 3}
+                if keep is None: os.environ.pop("GM_HOST_THREADS", None)
+                else: os.environ["GM_HOST_THREADS"] = keep
+                s2.close(); ix2.close(); del pools2, contigs2
+                out["host_sensitivity"] = hs
+            except Exception as ex:
+                out["host_sensitivity"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if o_ls is not None: o_ls.close()
         print(json.dumps(out))
     sess.close()

@@ -100,6 +100,17 @@ typedef struct gm_params {
                                                   (alignment_edit_string, reversed for mappings on the reverse strand) on mapped records.  0 */
   int sam_r2;                                  /* --sam-r2 (paired mode only): R2:Z (colour space: X2:Z) = the mate's sequence as given.  0 */
   char read_group[64];                         /* --read-group: RG:Z:<name> on every record ("" = none; the @RG header line is the caller's, as the @SQ lines are) */
+  /* the read loop's preprocessing, applied by the file entry points to every read before it is mapped (ref: gmapper.c:262-284 trim_read, :427-472, :495-521) */
+  int trim_front, trim_end;                    /* --trim-front / --trim-end: that many characters off either end of the sequence (and its quality string).  0, 0.
+                                                  trim_front is refused in colour space, as the binary refuses it (gmapper.c:2134-2137) */
+  int trim_first, trim_second;                 /* paired mode: which mates are trimmed (--trim-first: 1, 0; --trim-second: 0, 1).  1, 1 -- but trimming the FIRST mate is
+                                                  refused: the reference trims it after packing it (gmapper.c:427-438,474-475) and prints records that contradict themselves */
+  int trim_illumina;                           /* --trim-illumina (letter space, FASTQ): a tail of 'B' quality values is cut off with its bases.  0 */
+  int min_avg_qv;                              /* --min-avg-qv: a read with quality values whose integer mean (sum / length) is below this gets no record at all (ref: gmapper.h:81,
+                                                  gmapper.c:456-462,491-498).  10; < 0: none */
+  int ignore_qvs;                              /* --ignore-qvs: the quality values are printed but not used -- no min_avg_qv, no range check; colour space: the global crossover
+                                                  score and error rates (ref: gmapper.c:532,2962).  0 */
+  int no_qv_check;                             /* --no-qv-check: a quality value outside [-10, 50] is NOT an error (ref: gmapper.c:463-472: the binary exits there).  0 */
 } gm_params_t;
 
 void gm_params_default(gm_params_t *p);        /* letter-space defaults of the reference binary (gmapper-ls) */
@@ -273,6 +284,16 @@ int gm_map_reads_text(gm_session_t *s, int n_reads, int read_len, const char *se
  * dropped without a record and reading stops at a malformed entry, as in the reference (gmapper.c:495-521, fasta.c:362-372).  Records come back in
  * the file's order. */
 int gm_map_reads_file(gm_session_t *s, const char *path, int fastq, int qual_delta, char **sam, size_t *sam_len, gm_map_stats_t *stats);
+/* The same, streaming (ref: gmapper.c:322-398,588-607: the reference reads chunks of reads and prints as it goes): the file is read at most chunk_reads reads at a time
+ * (0 = 2^20; the next chunk is read and preprocessed by a second thread while this one is mapped), every read goes through the read loop's preprocessing (gm_params_t:
+ * trim_*, min_avg_qv, ignore_qvs, no_qv_check) and each chunk's records are handed to `write` in the file's order.  Neither the file nor the output is held whole: host
+ * memory stays at a few hundred bytes per read of one chunk.  `write` returns 0 to go on; anything else stops the call with an error.
+ * gm_map_reads_file is this function with a write function that collects the text. */
+typedef int (*gm_write_fn)(void *ctx, const char *text, size_t len);
+int gm_map_reads_file_cb(gm_session_t *s, const char *path, int fastq, int qual_delta, size_t chunk_reads, gm_write_fn write, void *ctx, gm_map_stats_t *stats);
+/* The preprocessing by itself (host code, no device): seq (primer letter first in colour space) and qual (NULL for FASTA input) are NUL-terminated and edited in place;
+ * *drop = 1 when the read gets no record.  mate: 0 unpaired, 1 / 2 the mates of a pair. */
+int gm_preprocess_read_text(const gm_params_t *params, int mate, char *seq, char *qual, int qual_delta, int *drop);
 /* host-buffer form: reads are uploaded, SAM text is returned in a malloc()ed buffer (*sam, *sam_len) */
 int gm_map_reads(gm_session_t *s, int n_reads, int read_len, const uint32_t *reads_packed,
                  const char *names, char **sam, size_t *sam_len, gm_map_stats_t *stats);
@@ -340,6 +361,9 @@ int gm_map_pairs_cs(gm_session_t *s, int n_pairs, int len1, const uint32_t *mate
  * Formats and rules as gm_map_reads_file; pairs of any mix of lengths; a pair with a mate beyond longest_read_len is dropped whole.  Letter or colour space by the session. */
 int gm_map_pairs_file(gm_session_t *s, const char *path1, const char *path2, int fastq, int qual_delta, const gm_pair_opts_t *opts,
                       char **sam, size_t *sam_len, gm_map_stats_t *stats);
+/* streaming form (see gm_map_reads_file_cb): at most chunk_pairs pairs at a time (0 = 2^19); a pair is never split across chunks (ref: gmapper.c:2319-2322) */
+int gm_map_pairs_file_cb(gm_session_t *s, const char *path1, const char *path2, int fastq, int qual_delta, const gm_pair_opts_t *opts, size_t chunk_pairs,
+                         gm_write_fn write, void *ctx, gm_map_stats_t *stats);
 /* csfastq pairs: as gm_map_pairs_cs, plus one QV character per colour and mate ('\n' separated strings, offset qual_delta), used as gm_map_reads_cs_fastq uses them
  * (per-position crossover scores in sw_full_cs, per-colour error rates in post_sw, QUAL = post_sw's base qualities, CQ:Z). */
 int gm_map_pairs_cs_fastq(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_packed, const uint8_t *initbp1, int len2, const uint32_t *mates2_packed,

@@ -19,6 +19,8 @@
 #include <mutex>
 #include <condition_variable>
 #include <functional>
+#include <future>
+#include <unordered_map>
 #include <zlib.h>
 #include "gm_common.h"
 #include "gm_internal.h"
@@ -64,6 +66,7 @@ extern "C" void gm_params_default(gm_params_t* p) {
   p->colour_space = 0; p->crossover_score = -20; p->indel_taboo_len = 0; p->pr_xover = 0.03; p->local_alignment = 0; p->ungapped = 0; p->hash_seeds = 0; p->output_format = 0; p->print_read_seq = 0; p->strand_only = 0;
   p->single_best_mapping = 0; p->all_contigs = 0; p->no_mapping_qualities = 0; p->no_improper_mappings = 0;
   p->extra_sam_fields = 0; p->sam_r2 = 0; memset(p->read_group, 0, sizeof p->read_group);
+  p->trim_front = 0; p->trim_end = 0; p->trim_first = 1; p->trim_second = 1; p->trim_illumina = 0; p->min_avg_qv = 10; p->ignore_qvs = 0; p->no_qv_check = 0;      // ref: gmapper.h:63-67,75,81,104
 }
 extern "C" int gm_abi_sizeof(int which) {
   switch (which) { case 0: return (int)sizeof(gm_params_t); case 1: return (int)sizeof(gm_pair_opts_t); case 2: return (int)sizeof(gm_map_stats_t); case 3: return (int)sizeof(gm_merge_options_t); }
@@ -370,6 +373,39 @@ static void free_buffers(DevSet& D) {
 }
 
 static int pow2ceil(long long v) { int p = 1; while (p < v) p <<= 1; return p; }
+// host threads of this process's share (a multi-rank job divides the cores itself: GM_HOST_THREADS)
+static int gm_host_threads() {
+  int n = (int)std::min<unsigned>(32, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* e = getenv("GM_HOST_THREADS")) n = std::max(1, atoi(e));
+  return n;
+}
+// fn(begin, end) over [0, n) in pieces of `grain`, on the host threads
+template <class F> static void gm_parallel_for(size_t n, size_t grain, F fn) {
+  const size_t pieces = (n + grain - 1) / std::max<size_t>(1, grain);
+  const int nt = (int)std::min<size_t>((size_t)gm_host_threads(), pieces);
+  if (nt <= 1) { if (n) fn((size_t)0, n); return; }
+  std::atomic<size_t> next(0);
+  auto worker = [&]() { for (;;) { const size_t c = next.fetch_add(1); if (c >= pieces) break; fn(c * grain, std::min(n, (c + 1) * grain)); } };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; t++) th.emplace_back(worker);
+  worker();
+  for (auto& t : th) t.join();
+}
+// n lines of exactly `want` characters with '\n' between them (the last one may or may not end in '\n'): true when the text has that layout, checked on the host threads --
+// the line starts are then i * (want + 1) and nothing has to be searched
+static bool gm_fixed_lines(const char* text, size_t n, size_t want) {
+  if (!n) return true;
+  const size_t len = strlen(text), stride = want + 1;
+  if (len != n * stride - 1 && len != n * stride) return false;
+  std::atomic<bool> ok(true);
+  gm_parallel_for(n, 16384, [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; i++) {
+      const char* p = text + i * stride;
+      if (memchr(p, '\n', want) != nullptr || (i + 1 < n && p[want] != '\n')) { ok = false; return; }
+    }
+  });
+  return ok;
+}
 
 static int window_len_of(const gm_params_t& P, int read_len) {   // ref: gmapper.c:530
   double w = P.window_len < 0 ? -P.window_len : read_len * (P.window_len / 100.0);
@@ -1351,6 +1387,10 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   // names
   std::vector<const char*> nptr; std::vector<int> nlen;
   std::vector<const char*> qptr; std::vector<int8_t> xbuf; std::vector<uint8_t> qvbuf; std::vector<const char*> sptr;
+  if (seq_text && gm_fixed_lines(seq_text, (size_t)n_reads, (size_t)(read_len + (s->P.colour_space ? 1 : 0)))) {     // (the usual case: no search for the line ends)
+    const size_t stride = (size_t)(read_len + (s->P.colour_space ? 1 : 0)) + 1; sptr.resize(n_reads);
+    for (int i = 0; i < n_reads; i++) sptr[i] = seq_text + (size_t)i * stride;
+  } else
   if (seq_text) {                                            // one line per read: read_len letters, or primer + read_len colours
     const char* p = seq_text; const int want = read_len + (s->P.colour_space ? 1 : 0);
     for (int i = 0; i < n_reads; i++) {
@@ -1359,6 +1399,9 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
       sptr.push_back(p); p = *e ? e + 1 : e;
     }
   }
+  if (quals && gm_fixed_lines(quals, (size_t)n_reads, (size_t)read_len)) {
+    qptr.resize(n_reads); for (int i = 0; i < n_reads; i++) qptr[i] = quals + (size_t)i * ((size_t)read_len + 1);
+  } else
   if (quals) {
     const char* p = quals;
     for (int i = 0; i < n_reads; i++) {
@@ -1630,6 +1673,17 @@ extern "C" int gm_map_reads_text(gm_session_t* s, int n_reads, int read_len, con
   if (!s || !seqs || n_reads < 0 || read_len < 1) { gm_set_error("gm_map_reads_text: bad arguments"); return GM_E_ARG; }
   const int cs = s->P.colour_space ? 1 : 0, line = read_len + cs, rwords = (read_len + 7) / 8;
   std::vector<uint32_t> packed((size_t)n_reads * rwords); std::vector<uint8_t> ibp(cs ? n_reads : 0);
+  if (gm_fixed_lines(seqs, (size_t)n_reads, (size_t)line)) {      // packing on the host threads (one thread took 90 ms per million 100-base reads)
+    std::atomic<int> bad_rc(GM_OK); std::mutex em; std::string emsg;
+    gm_parallel_for((size_t)n_reads, 8192, [&](size_t b0, size_t e0) {
+      for (size_t i = b0; i < e0 && bad_rc.load(std::memory_order_relaxed) == GM_OK; i++) {
+        int b = 0; const int rc = gm_sequence_to_bitfield(cs, seqs + i * ((size_t)line + 1), line, packed.data() + i * rwords, &b);
+        if (rc) { std::lock_guard<std::mutex> lk(em); if (bad_rc == GM_OK) { bad_rc = rc; emsg = gm_last_error(); } return; }
+        if (cs) ibp[i] = (uint8_t)b;
+      }
+    });
+    if (bad_rc != GM_OK) { gm_set_error("%s", emsg.c_str()); return bad_rc; }
+  } else {
   const char* p = seqs;
   for (int i = 0; i < n_reads; i++) {
     const char* e = strchr(p, '\n'); if (!e) e = p + strlen(p);
@@ -1638,138 +1692,11 @@ extern "C" int gm_map_reads_text(gm_session_t* s, int n_reads, int read_len, con
     if (cs) ibp[i] = (uint8_t)b;
     p = *e ? e + 1 : e;
   }
+  }
   return map_impl(s, n_reads, read_len, packed.data(), nullptr, names, 1, sam, sam_len, stats, cs ? ibp.data() : nullptr, quals, qual_delta, seqs);
 }
 
-// File entry point: the reference's reads reader -- FASTA / FASTQ, plain or gzip (zlib's gz* layer reads both, as fasta_open does), '#'
-// comment lines, sequences over several lines, names cut at the first blank, reads of any mix of lengths (ref: common/fasta.c:61-150 fasta_open,
-// :242-283 extract_name, :315-552 fasta_get_next_read_with_range; gmapper.c:462-521 for the reads that are dropped).  The device pipeline takes batches of
-// one length, so the reads are grouped by length, every group goes through map_impl, and the records return to the file's order.
-struct FileRead { std::string name, seq, qual; };
-static int read_reads_file(const char* path, int colour_space, int fastq, std::vector<FileRead>& out, bool* is_fastq) {
-  gzFile fp = gzopen(path, "r");
-  if (!fp) { gm_set_error("cannot open '%s' for reading", path); return GM_E_ARG; }
-  gzbuffer(fp, 1 << 20);
-  if (fastq < 0) {                                                 // ref: fasta.c:99-127
-    int c = gzgetc(fp);
-    while (c == '#' || c == ';') { while (c != -1 && c != '\n') c = gzgetc(fp); if (gzeof(fp)) break; if (c == -1) break; c = gzgetc(fp); }
-    fastq = 0;
-    if (!gzeof(fp) && c != -1) {
-      if (c == '@') fastq = 1; else if (c == '>') fastq = 0;
-      else { gzclose(fp); gm_set_error("unrecognized character [%c] in input file [%s]", (char)c, path); return GM_E_ARG; }
-      gzungetc(c, fp);
-    }
-  }
-  *is_fastq = fastq != 0;
-  const char mark = fastq ? '@' : '>';
-  std::string line, pending; bool have_pending = false, eof = false;
-  std::vector<char> buf(1 << 16);
-  auto getline = [&](std::string& l) -> bool {                     // one line without its '\n'; `complete` is false for a last line that lacks it
-    l.clear();
-    for (;;) {
-      if (!gzgets(fp, buf.data(), (int)buf.size())) { eof = true; return !l.empty(); }
-      const size_t n = strlen(buf.data());
-      if (n && buf[n - 1] == '\n') { l.append(buf.data(), n - 1); return true; }
-      l.append(buf.data(), n);
-    }
-  };
-  for (;;) {
-    // ---- name line ----
-    bool got = false;
-    for (;;) {
-      if (have_pending) { line.swap(pending); have_pending = false; } else if (!getline(line)) break;
-      if (line.empty()) { got = false; break; }
-      if (line[0] == '#') continue;
-      if (line[0] != mark) { got = false; line.clear(); break; }    // "Expecting ..." -- the reference stops reading here
-      got = true; break;
-    }
-    if (!got || line.size() <= 1) break;
-    FileRead R;
-    { size_t b = 1, e = line.find('\t', 1); if (e == std::string::npos) e = line.size();
-      while (b < e && isspace((unsigned char)line[b])) b++; while (e > b && isspace((unsigned char)line[e - 1])) e--;      // strtrim
-      size_t k = b; while (k < e && line[k] != ' ' && line[k] != '\t') k++;
-      R.name.assign(line, b, k - b); }
-    // ---- sequence ----
-    bool plus = false; std::string plus_line;
-    for (;;) {
-      if (!getline(line)) break;
-      if (fastq && !line.empty() && line[0] == '+') { plus = true; break; }
-      if (!fastq && !line.empty() && line[0] == '>') { pending = line; have_pending = true; break; }
-      if (!line.empty() && line[0] == '#') continue;
-      R.seq += line;
-    }
-    if (R.seq.empty()) break;
-    if (fastq) {
-      if (!plus) break;
-      const size_t want = R.seq.size() - (colour_space ? 1 : 0);
-      for (;;) {
-        if (!getline(line)) break;
-        R.qual += line;
-        if (R.qual.size() >= want) break;
-      }
-      if (R.qual.size() != want) {
-        if (R.qual.size() > want) { gzclose(fp); gm_set_error("read \"%s\": the quality string is longer than the sequence (ref: fasta.c:478-482)", R.name.c_str()); return GM_E_ARG; }
-        break;
-      }
-      for (char& c : R.qual) c = std::max(c, '!');
-    }
-    out.push_back(std::move(R));
-    if (eof && !have_pending) break;
-  }
-  gzclose(fp);
-  return GM_OK;
-}
-
-extern "C" int gm_map_reads_file(gm_session_t* s, const char* path, int fastq, int qual_delta, char** sam, size_t* sam_len, gm_map_stats_t* stats) {
-  if (!s || !path || !sam || !sam_len) { gm_set_error("gm_map_reads_file: bad arguments"); return GM_E_ARG; }
-  *sam = nullptr; *sam_len = 0;
-  const int cs = s->P.colour_space ? 1 : 0;
-  std::vector<FileRead> reads; bool is_fastq = false;
-  int rc = read_reads_file(path, cs, fastq, reads, &is_fastq); if (rc) return rc;
-  if (is_fastq) for (const FileRead& R : reads) for (char c : R.qual) {            // ref: gmapper.c:462-472
-    const int qv = (int)c - qual_delta;
-    if (qv < -10 || qv > 50) { gm_set_error("the quality offset might be set incorrectly: PHRED+%d gives a quality value of %d (read \"%s\")", qual_delta, qv, R.name.c_str()); return GM_E_ARG; }
-  }
-  // groups of one length, in order of first appearance; a read longer than longest_read_len is dropped without a record (ref: gmapper.c:495-521)
-  std::vector<int> lens; std::vector<std::vector<uint32_t>> members;
-  std::vector<int> group_of(reads.size(), -1);
-  for (uint32_t i = 0; i < reads.size(); i++) {
-    const int L = (int)reads[i].seq.size() - cs;
-    if (L < 1 || L > s->P.longest_read_len) continue;
-    size_t g = 0; for (; g < lens.size(); g++) if (lens[g] == L) break;
-    if (g == lens.size()) { lens.push_back(L); members.emplace_back(); }
-    members[g].push_back(i); group_of[i] = (int)g;
-  }
-  gm_map_stats_t total; memset(&total, 0, sizeof total);
-  std::vector<char*> gsam(lens.size(), nullptr); std::vector<size_t> glen(lens.size(), 0); std::vector<std::vector<uint32_t>> gbytes(lens.size());
-  auto cleanup = [&]() { for (char* p : gsam) free(p); };
-  for (size_t g = 0; g < lens.size(); g++) {
-    std::string seqs, names, quals;
-    for (uint32_t i : members[g]) { seqs += reads[i].seq; seqs += '\n'; names += reads[i].name; names += '\n'; if (is_fastq) { quals += reads[i].qual; quals += '\n'; } }
-    const int n = (int)members[g].size(), L = lens[g], rwords = (L + 7) / 8, line = L + cs;
-    std::vector<uint32_t> packed((size_t)n * rwords); std::vector<uint8_t> ibp(cs ? n : 0);
-    const char* p = seqs.data();
-    for (int i = 0; i < n; i++, p += line + 1) { int b = 0; rc = gm_sequence_to_bitfield(cs, p, line, packed.data() + (size_t)i * rwords, &b); if (rc) { cleanup(); return rc; } if (cs) ibp[i] = (uint8_t)b; }
-    gbytes[g].assign(n, 0);
-    gm_map_stats_t st;
-    rc = map_impl(s, n, L, packed.data(), nullptr, names.c_str(), 1, &gsam[g], &glen[g], &st, cs ? ibp.data() : nullptr, is_fastq ? quals.c_str() : nullptr, qual_delta,
-                  seqs.c_str(), gbytes[g].data());
-    if (rc) { cleanup(); return rc; }
-    { std::lock_guard<std::mutex> lk(g_outcache.m); if (gsam[g] == g_outcache.live) g_outcache.live = nullptr; }      // this buffer is freed here, not by the caller
-    { uint64_t* a = (uint64_t*)&total; const uint64_t* b = (const uint64_t*)&st;                 // the counters: every field up to the stage times
-      const size_t nu = offsetof(gm_map_stats_t, ms_lookup) / sizeof(uint64_t); for (size_t k = 0; k < nu; k++) a[k] += b[k]; }
-    total.ms_lookup += st.ms_lookup; total.ms_anchors += st.ms_anchors; total.ms_pass1 += st.ms_pass1; total.ms_select += st.ms_select; total.ms_pass2 += st.ms_pass2; total.ms_host += st.ms_host;
-  }
-  size_t tot = 0; for (size_t g = 0; g < lens.size(); g++) tot += glen[g];
-  char* outp = (char*)malloc(tot + 1); if (!outp) { cleanup(); gm_set_error("gm_map_reads_file: out of memory"); return GM_E_NOMEM; }
-  { std::vector<size_t> cur(lens.size(), 0), nxt(lens.size(), 0); size_t w = 0;
-    for (uint32_t i = 0; i < reads.size(); i++) { const int g = group_of[i]; if (g < 0) continue; const uint32_t b = gbytes[g][nxt[g]++]; memcpy(outp + w, gsam[g] + cur[g], b); cur[g] += b; w += b; }
-    outp[w] = 0; *sam_len = w; }
-  cleanup();
-  *sam = outp;
-  if (stats) *stats = total;
-  return GM_OK;
-}
+// (the file entry points -- the reads reader, the per-read preprocessing, chunked streaming -- live in gm_host_files.inc, included below)
 
 extern "C" int gm_last_lookup_timing(gm_session_t* s, double* ms, uint64_t* alg_bytes, int* launches) {
   if (!s) return GM_E_ARG;
@@ -1778,6 +1705,7 @@ extern "C" int gm_last_lookup_timing(gm_session_t* s, double* ms, uint64_t* alg_
 }
 
 #include "gm_host_pairs.inc"
+#include "gm_host_files.inc"
 #include "gm_index_io.inc"
 
 // stage dump for parity tests: hits selected by pass 1, in ext-heap array order (before pass 2 / reverse_hit)

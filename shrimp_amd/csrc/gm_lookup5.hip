@@ -113,7 +113,7 @@ __device__ __forceinline__ uint32_t k5_lane_times(int lane, uint32_t W) {
 // The HALF-SIZE shape with rounds (round 4): 512 threads, tables of 2^19 + 2^16 bits -- 80 KB of LDS with the records, so that TWO workgroups share a CU and the phases of two
 // read-strands (pass A: memory; pass B: L2 / vector issue; exact stages: LDS round trips) overlap instead of running one after the other.  The smaller seen[] table is a blocked
 // Bloom filter (two bits per region, see the kernel body); the candidates (2 720 slots, region table of 4 096) go through the rounds of k_lookup_v5_rounds.
-#define K5_KERNEL_HEAD __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) k_lookup_v5_half(GmIndexDev ix, K5Args a)
+#define K5_KERNEL_HEAD __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 5))) k_lookup_v5_half(GmIndexDev ix, K5Args a)
 #define K5_KERNEL_MULTI true
 #define K5_KERNEL_LSWC 14
 #define K5_KERNEL_BLOOM true
@@ -122,7 +122,7 @@ __device__ __forceinline__ uint32_t k5_lane_times(int lane, uint32_t W) {
 #undef K5_KERNEL_BLOOM
 #ifdef GM_TUNING
 // (the same without the Bloom bits: the measurement beside it, tuning builds only)
-#define K5_KERNEL_HEAD __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) k_lookup_v5_half_plain(GmIndexDev ix, K5Args a)
+#define K5_KERNEL_HEAD __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 5))) k_lookup_v5_half_plain(GmIndexDev ix, K5Args a)
 #define K5_KERNEL_BLOOM false
 #include "gm_lookup5_kernel.inc"
 #undef K5_KERNEL_HEAD
@@ -267,6 +267,7 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   const size_t half_budget = 80 * 1024 - 512, half_tables = (size_t)(4u << 14) + (size_t)(4u << 11);
   if (half && (ix.region_bits < 11 || NL > 512 || fixed0 + 24 * 8 + half_tables > half_budget)) half = 0;
   if (half) { lsw = 14; threads = 512; xrec = (int)std::min<size_t>(64, (half_budget - half_tables - fixed0) / 24); }
+  if (half) if (const char* e = gm_tune("GM_K5_HALF_THREADS")) threads = std::max(64, std::min(1024, atoi(e) & ~63));      // (probe: 640 = ten waves a workgroup, five a SIMD with two workgroups)
   const size_t fixed_h = fixed0 + 24 * (size_t)xrec;
   if (!half)
   if (const char* e = gm_tune("GM_K5_LSW")) lsw = std::max(8, std::min(15, atoi(e)));

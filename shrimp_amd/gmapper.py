@@ -35,7 +35,9 @@ class Params(C.Structure):   # gm_params_t (include/gmapper_hip.h)
                 ("colour_space", C.c_int), ("crossover_score", C.c_int), ("indel_taboo_len", C.c_int), ("pr_xover", C.c_double),
                 ("local_alignment", C.c_int), ("ungapped", C.c_int), ("hash_seeds", C.c_int), ("output_format", C.c_int), ("print_read_seq", C.c_int), ("strand_only", C.c_int),
                 ("single_best_mapping", C.c_int), ("all_contigs", C.c_int), ("no_mapping_qualities", C.c_int), ("no_improper_mappings", C.c_int),
-                ("extra_sam_fields", C.c_int), ("sam_r2", C.c_int), ("read_group", C.c_char * 64)]
+                ("extra_sam_fields", C.c_int), ("sam_r2", C.c_int), ("read_group", C.c_char * 64),
+                ("trim_front", C.c_int), ("trim_end", C.c_int), ("trim_first", C.c_int), ("trim_second", C.c_int), ("trim_illumina", C.c_int),
+                ("min_avg_qv", C.c_int), ("ignore_qvs", C.c_int), ("no_qv_check", C.c_int)]
 
 
 class MapStats(C.Structure):   # gm_map_stats_t
@@ -106,7 +108,7 @@ class SwFullResults(C.Structure):   # struct gm_sw_full_results == the reference
 
 
 # every entry point include/gmapper_hip.h declares
-EXPORTS = ["gm_map_pairs_file", "gm_map_pairs_cs_fastq", "gm_map_reads_file", "gm_merge_options_default", "gm_merge_sam", "gm_release_cache", "gm_map_pairs_cs", "gm_last_error", "gm_device_count", "gm_params_default", "gm_params_default_cs", "gm_index_build", "gm_index_free", "gm_index_list_cutoff",
+EXPORTS = ["gm_map_pairs_file", "gm_map_reads_file_cb", "gm_map_pairs_file_cb", "gm_preprocess_read_text", "gm_map_pairs_cs_fastq", "gm_map_reads_file", "gm_merge_options_default", "gm_merge_sam", "gm_release_cache", "gm_map_pairs_cs", "gm_last_error", "gm_device_count", "gm_params_default", "gm_params_default_cs", "gm_index_build", "gm_index_free", "gm_index_list_cutoff",
            "gm_index_save", "gm_index_load", "gm_index_bytes", "gm_index_n_slabs", "gm_index_has_buckets", "gm_index_get_list", "gm_index_device_array", "gm_index_meta", "gm_index_alloc_like",
            "sw_vector_setup", "sw_vector", "sw_vector_stats", "sw_vector_cleanup", "gm_sw_vector_batch", "gm_sw_vector_batch_bounded",
            "sw_gapless_setup", "sw_gapless", "sw_gapless_stats", "gm_sw_gapless_batch",
@@ -377,6 +379,29 @@ class Session:
         self.stats = st.as_dict()
         return out
 
+    def map_reads_file_chunks(self, path, chunk_reads=0, fastq=-1, qual_delta=None, collect=True):
+        """gm_map_reads_file_cb: the file in chunks of at most chunk_reads reads; returns the list of texts the write function received (one per chunk; with
+        collect=False their lengths only: the form a timed loop uses)."""
+        L = lib(); st = MapStats(); parts = []
+        qd = qual_delta if qual_delta is not None else (33 if self.params.colour_space else 64)
+        WRITE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+        cb = WRITE((lambda ctx, p, n: (parts.append(C.string_at(p, n)), 0)[1]) if collect else (lambda ctx, p, n: (parts.append(n), 0)[1]))
+        _check(L.gm_map_reads_file_cb(self.h, os.fsencode(path), int(fastq), int(qd), C.c_size_t(int(chunk_reads)), cb, None, C.byref(st)), "gm_map_reads_file_cb")
+        self.stats = st.as_dict()
+        return parts
+
+    def map_pairs_file_chunks(self, path1, path2=None, chunk_pairs=0, fastq=-1, qual_delta=None, mode="opp-in", min_insert=0, max_insert=1000, opts: "PairOpts | None" = None):
+        """gm_map_pairs_file_cb: at most chunk_pairs pairs at a time; returns the texts the write function received."""
+        L = lib(); st = MapStats(); parts = []
+        qd = qual_delta if qual_delta is not None else (33 if self.params.colour_space else 64)
+        o = opts if opts is not None else PairOpts.default(mode, min_insert, max_insert)
+        WRITE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+        cb = WRITE(lambda ctx, p, n: (parts.append(C.string_at(p, n)), 0)[1])
+        _check(L.gm_map_pairs_file_cb(self.h, os.fsencode(path1), None if path2 is None else os.fsencode(path2), int(fastq), int(qd), C.byref(o), C.c_size_t(int(chunk_pairs)),
+                                      cb, None, C.byref(st)), "gm_map_pairs_file_cb")
+        self.stats = st.as_dict()
+        return parts
+
     def map_pairs_file(self, path1, path2=None, fastq=-1, qual_delta=None, mode="opp-in", min_insert=0, max_insert=1000, opts: "PairOpts | None" = None) -> bytes:
         """Pairs from one file (mates adjacent) or two (-1 / -2): FASTA / FASTQ, plain or gzip, any mix of lengths (gm_map_pairs_file)."""
         L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
@@ -446,6 +471,17 @@ class Session:
         join = lambda v: None if v is None else b"\n".join(x if isinstance(x, bytes) else x.encode() for x in v)
         _check(L.gm_map_reads_text(self.h, n, read_len, b"\n".join(seqs), join(names), join(quals), int(qual_delta), C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_reads_text")
         out = C.string_at(sam, sl.value) if sam.value else b""
+        if sam.value: L.gm_free(sam)
+        self.stats = st.as_dict()
+        return out
+
+    def map_text_buffer(self, seq_buf: bytes, n: int, read_len: int, names_buf: "bytes | None" = None, return_bytes: bool = True):
+        """gm_map_reads_text on a ready-made buffer (n lines of read_len letters, '\\n' between them; names likewise): the form a timed loop uses -- parsing, packing and
+        the upload all happen inside the call.  With return_bytes=False the SAM text stays in the library's buffer and its length is returned."""
+        L = lib(); sam = C.c_void_p(); sl = C.c_size_t(); st = MapStats()
+        _check(L.gm_map_reads_text(self.h, n, read_len, seq_buf, names_buf, None, 64, C.byref(sam), C.byref(sl), C.byref(st)), "gm_map_reads_text")
+        out = sl.value
+        if return_bytes: out = C.string_at(sam, sl.value) if sam.value else b""
         if sam.value: L.gm_free(sam)
         self.stats = st.as_dict()
         return out
@@ -634,6 +670,13 @@ def sw_vector_batch_cs(genome_cs, genome_ls, g_off, glen, reads_words, rlen, ini
                                    go.ctypes.data_as(C.POINTER(C.c_int64)), ip(gn), r.ctypes.data_as(C.POINTER(C.c_uint32)), r.shape[1], ip(rl), ip(ib), ip(out)),
            "gm_sw_vector_batch_cs")
     return out
+
+
+def preprocess_read(params, seq: bytes, qual: "bytes | None" = None, qual_delta: int = 64, mate: int = 0):
+    """gm_preprocess_read_text (host only): what the file entries do to one read before mapping it -> (seq, qual, dropped)"""
+    sb = C.create_string_buffer(seq, len(seq) + 1); qb = None if qual is None else C.create_string_buffer(qual, len(qual) + 1); d = C.c_int(0)
+    _check(lib().gm_preprocess_read_text(C.byref(params), int(mate), sb, qb, int(qual_delta), C.byref(d)), "gm_preprocess_read_text")
+    return sb.value, (None if qb is None else qb.value), bool(d.value)
 
 
 def sw_full_cs_setup(dblen, qrlen, a_gap_open, a_gap_ext, b_gap_open, b_gap_ext, match, mismatch, xover, reset_stats=True, anchor_width=8, indel_taboo_len=0):

@@ -1361,6 +1361,38 @@ def test_colour_space_fastq_pairs_local_match_reference_golden(gm, mode):
     assert got == want, (_first_diff(got, want), st)
 
 
+def test_read_loop_preprocessing_matches_reference_golden(gm):
+    """the file entries with the read loop's preprocessing (gm_params_t trim_front / trim_end / trim_illumina / min_avg_qv / ignore_qvs; ref: gmapper.c:262-284,427-472,
+    495-521): the reference's SAM under each option set, whole and through the streaming form in chunks of 100 reads; paired: --trim-second"""
+    import gzip
+    from tools.make_golden import PREPROCESS_CASES
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(G, "stress_60bp.npz")); contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig")))]
+    for tag, (src, _, fields) in PREPROCESS_CASES.items():
+        p = gm.default_params(); p.sam_unaligned = 1
+        for k, v in fields.items(): setattr(p, k, v)
+        ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+        want = gzip.open(os.path.join(G, tag + ".sam.gz"), "rb").read()
+        got = oa.sam_header(contigs) + s.map_reads_file(os.path.join(G, src), qual_delta=64)
+        assert got == want, (tag, _first_diff(got, want), s.stats)
+        parts = s.map_reads_file_chunks(os.path.join(G, src), chunk_reads=100, qual_delta=64)
+        assert len(parts) >= 3 and oa.sam_header(contigs) + b"".join(parts) == want, (tag, len(parts))
+        s.close(); ix.close()
+    g = oa.load_golden_pairs("stress_pairs_2x100")
+    p = gm.default_params(); p.sam_unaligned = 1; p.trim_front = 2; p.trim_end = 4; p.trim_first = 0; p.trim_second = 1
+    ix = gm.Index(g["contigs"], names=g["contig_names"], params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+    want = gzip.open(os.path.join(G, "pre_pairs_trim_second.sam.gz"), "rb").read()
+    body = s.map_pairs_file(os.path.join(G, "file_pairs_1.fq.gz"), os.path.join(G, "file_pairs_2.fq.gz"), qual_delta=33, mode=g["mode"], min_insert=g["ins"][0], max_insert=g["ins"][1])
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + body
+    assert got == want, (_first_diff(got, want), s.stats)
+    parts = s.map_pairs_file_chunks(os.path.join(G, "file_pairs_1.fq.gz"), os.path.join(G, "file_pairs_2.fq.gz"), chunk_pairs=64, qual_delta=33, mode=g["mode"], min_insert=g["ins"][0], max_insert=g["ins"][1])
+    assert len(parts) >= 5 and b"".join(parts) == body
+    p.trim_first = 1                                           # the first mate: refused (the reference trims it after packing it)
+    s2 = gm.Session(ix, params=p, max_batch_reads=4096)
+    with pytest.raises(RuntimeError): s2.map_pairs_file(os.path.join(G, "file_pairs_1.fq.gz"), os.path.join(G, "file_pairs_2.fq.gz"), qual_delta=33, mode=g["mode"])
+    s2.close(); s.close(); ix.close()
+
+
 @pytest.mark.parametrize("case", ["two_fastq_gz", "interleaved_fasta"])
 def test_pair_files_match_reference_golden(gm, case, tmp_path):
     """gm_map_pairs_file: `gmapper -1 a.fq.gz -2 b.fq.gz` (PHRED+33, mates cut to a mix of lengths) and one FASTA file with the mates adjacent -- the files the

@@ -1,3 +1,4 @@
+import pytest
 """Host-side pieces that need no GPU: bitfield packing, synthetic inputs, read sharding."""
 import numpy as np
 from shrimp_amd import synth, parallel
@@ -54,3 +55,51 @@ def test_sequence_to_bitfield_follows_the_reference_tables():
     with pytest.raises(gm.GmError): gm.sequence_to_bitfield(b"ACGT0")                       # a colour in a letter-space read (the reference exits, fasta.c:639-650)
     with pytest.raises(gm.GmError): gm.sequence_to_bitfield(b"N0123", colour_space=True)    # no primer letter (the reference drops the read, :626-634)
     with pytest.raises(gm.GmError): gm.sequence_to_bitfield(b"TACGT", colour_space=True)    # letters in a colour-space read
+
+
+def _simple_reads(path):
+    """(name, seq, qual or None) of an unfolded FASTA / FASTQ fixture"""
+    import gzip
+    L = gzip.open(path, "rb").read().split(b"\n")
+    if L[0][:1] == b"@": return [(L[i][1:].split()[0], L[i + 1], L[i + 3]) for i in range(0, len(L) - 3, 4)]
+    return [(L[i][1:].split()[0], L[i + 1], None) for i in range(0, len(L) - 1, 2)]
+
+
+def test_read_preprocessing_matches_reference_goldens():
+    """A22's read-loop preprocessing (ref: gmapper.c:262-284 trim_read, :427-472 trimming / Illumina B tails / quality checks, :495-521 dropped reads) through
+    gm_preprocess_read_text, host code only: which reads the reference gave a record at all, and the SEQ / QUAL it printed for the forward-strand and the unaligned
+    ones, under --trim-front/--trim-end, --trim-illumina, --min-avg-qv (10 by default), --ignore-qvs"""
+    import gzip, os
+    from shrimp_amd import gmapper as gm
+    from tools.make_golden import PREPROCESS_CASES
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    tr = bytes.maketrans(b"RYSWKMBDHVacgtn", b"NNNNNNNNNNACGTN")
+    ndrop = 0
+    for tag, (src, _, fields) in PREPROCESS_CASES.items():
+        p = gm.default_params()
+        for k, v in fields.items(): setattr(p, k, v)
+        kept = []
+        for name, seq, qual in _simple_reads(os.path.join(G, src)):
+            sq, ql, drop = gm.preprocess_read(p, seq, qual, 64)
+            if drop: ndrop += 1
+            else: kept.append((name, sq, ql))
+        recs = {}
+        order = []
+        for l in gzip.open(os.path.join(G, tag + ".sam.gz"), "rb").read().split(b"\n"):
+            if not l or l[:1] == b"@": continue
+            t = l.split(b"\t")
+            if t[0] not in recs: recs[t[0]] = t; order.append(t[0])
+        assert order == [k[0] for k in kept], (tag, len(order), len(kept))
+        for name, sq, ql in kept:
+            t = recs[name]
+            if int(t[1]) & 16: continue
+            assert t[9] == sq.translate(tr), (tag, name, t[9], sq)
+            if ql is not None: assert t[10] == (ql if int(t[1]) & 4 else bytes(c - 31 for c in ql)), (tag, name)     # (unaligned: verbatim, ref: output.c:419-421; mapped: PHRED+33, :539-570)
+    assert ndrop > 300
+    # what is refused: the first mate of a pair (the reference trims it after packing it), a quality value out of range
+    p = gm.default_params(); p.trim_front = 2
+    with pytest.raises(RuntimeError): gm.preprocess_read(p, b"ACGTACGTAC", None, 64, mate=1)
+    p = gm.default_params()
+    with pytest.raises(RuntimeError): gm.preprocess_read(p, b"ACGT", b"!!!!", 64)
+    p.no_qv_check = 1; p.min_avg_qv = -1
+    assert gm.preprocess_read(p, b"ACGT", b"!!!!", 64) == (b"ACGT", b"!!!!", False)

@@ -778,6 +778,64 @@ def pair_file_cases():
     print("file_pairs_12:", sum(1 for l in sam12.split(b"\n") if l and not l.startswith(b"@")), "records; file_pairs_il:", sum(1 for l in samil.split(b"\n") if l and not l.startswith(b"@")))
 
 
+PREPROCESS_CASES = {
+    # tag: (input fixture, options of the reference, gm_params_t fields): the read loop's preprocessing (ref: gmapper.c:262-284,427-472,495-521)
+    "pre_trim": ("pre_reads.fa.gz", ["--trim-front", "3", "--trim-end", "5"], {"trim_front": 3, "trim_end": 5}),
+    "pre_q_default": ("pre_reads.fq.gz", ["--qv-offset", "64"], {}),                                    # --min-avg-qv is 10 unless told otherwise: low-quality reads get no record
+    "pre_q_min20": ("pre_reads.fq.gz", ["--qv-offset", "64", "--min-avg-qv", "20"], {"min_avg_qv": 20}),
+    "pre_q_none": ("pre_reads.fq.gz", ["--qv-offset", "64", "--min-avg-qv", "-1"], {"min_avg_qv": -1}),
+    "pre_q_illumina": ("pre_reads.fq.gz", ["--qv-offset", "64", "--trim-illumina"], {"trim_illumina": 1}),
+    "pre_q_ignore": ("pre_reads.fq.gz", ["--qv-offset", "64", "--ignore-qvs"], {"ignore_qvs": 1}),
+    "pre_q_trim": ("pre_reads.fq.gz", ["--qv-offset", "64", "--trim-front", "2", "--trim-end", "3", "--trim-illumina"], {"trim_front": 2, "trim_end": 3, "trim_illumina": 1}),
+}
+
+
+def preprocess_cases():
+    """The read loop's preprocessing through the reference: --trim-front / --trim-end, --trim-illumina, --min-avg-qv (default 10), --ignore-qvs on a FASTA and a FASTQ
+    (PHRED+64) file of mixed lengths, and --trim-second on the pair files of pair_file_cases.  Fixtures: the files + the reference's SAM per option set."""
+    rng = np.random.Generator(np.random.PCG64(5151))
+    sg = stress_genome()
+    LET = b"ACGTUMRWSYKVHDBN"
+    sets = [stress_reads(sg, 120, L, seed=500 + L) for L in (50, 75, 100)]
+    recs = [r for rs in sets for r in rs]
+    order = rng.permutation(len(recs))
+    fa = bytearray(); fq = bytearray()
+    for n, k in enumerate(order):
+        r = recs[k]; L = len(r); t = bytes(LET[c] for c in r)
+        fa += b">t%d\n" % n + t + b"\n"
+        kind = n % 6
+        if kind == 0: q = rng.integers(2, 9, L)                                    # poor read: mean below 10
+        elif kind == 1: q = rng.integers(8, 24, L)                                 # mean around 15: kept by default, dropped at 20
+        else: q = rng.integers(15, 41, L)
+        if kind in (2, 3): q[L - int(rng.integers(1, 12)):] = 2                    # an Illumina "B" tail (PHRED+64: 'B' = quality 2)
+        if n % 41 == 0: q[:] = 2                                                   # all B: --trim-illumina leaves nothing
+        fq += b"@t%d\n" % n + t + b"\n+\n" + bytes((q + 64).astype(np.uint8)) + b"\n"
+    with gzip.open(os.path.join(OUT, "pre_reads.fa.gz"), "wb", compresslevel=9) as f: f.write(bytes(fa))
+    with gzip.open(os.path.join(OUT, "pre_reads.fq.gz"), "wb", compresslevel=9) as f: f.write(bytes(fq))
+    with tempfile.TemporaryDirectory() as d:
+        g = os.path.join(d, "g.fa"); write_fa_codes(g, [b"contig%d" % (i + 1) for i in range(len(sg))], sg)
+        open(os.path.join(d, "pre_reads.fa.gz"), "wb").write(gzip.compress(bytes(fa))); open(os.path.join(d, "pre_reads.fq.gz"), "wb").write(gzip.compress(bytes(fq)))
+        for tag, (src, extra, _) in PREPROCESS_CASES.items():
+            p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "gmapper-ls"), "-N", "2", "--sam-unaligned", *extra, os.path.join(d, src), g], capture_output=True)
+            if p.returncode != 0: print(p.stderr.decode()[-1500:]); raise SystemExit(1)
+            sam = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+            with gzip.open(os.path.join(OUT, tag + ".sam.gz"), "wb", compresslevel=9) as f: f.write(sam)
+            print(tag + ":", sum(1 for l in sam.split(b"\n") if l and not l.startswith(b"@")), "records")
+    # pairs: --trim-second (the second mate only; the reference trims a first mate after packing it, see gm_check_pair_trim)
+    z = np.load(os.path.join(OUT, "stress_pairs_2x100.npz"))
+    contigs = [z["contig%d" % i] for i in range(sum(1 for f in z.files if f.startswith("contig") and f[6:].isdigit()))]
+    cn = [bytes(x) for x in z["contig_names"]]; ins = tuple(int(x) for x in z["ins"])
+    with tempfile.TemporaryDirectory() as d:
+        g = os.path.join(d, "g.fa"); write_fa_codes(g, cn, contigs)
+        for nm in ("file_pairs_1.fq.gz", "file_pairs_2.fq.gz"): open(os.path.join(d, nm), "wb").write(open(os.path.join(OUT, nm), "rb").read())
+        p = subprocess.run([REF, "-N", "4", "--sam-unaligned", "-p", str(z["mode"]), "-I", "%d,%d" % ins, "--qv-offset", "33", "--trim-second", "--trim-front", "2", "--trim-end", "4",
+                            "-1", os.path.join(d, "file_pairs_1.fq.gz"), "-2", os.path.join(d, "file_pairs_2.fq.gz"), g], capture_output=True)
+        if p.returncode != 0: print(p.stderr.decode()[-1500:]); raise SystemExit(1)
+        sam = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+    with gzip.open(os.path.join(OUT, "pre_pairs_trim_second.sam.gz"), "wb", compresslevel=9) as f: f.write(sam)
+    print("pre_pairs_trim_second:", sum(1 for l in sam.split(b"\n") if l and not l.startswith(b"@")), "records")
+
+
 FORMAT_CASES = {
     # tag: (base golden, program, options): the reference's SHRiMP-format / pretty output, whole (its #FORMAT line included)
     "fmt_shrimp": ("stress_60bp", "gmapper-ls", ["--shrimp-format"]),
@@ -828,5 +886,7 @@ if __name__ == "__main__":
         os.makedirs(OUT, exist_ok=True); format_cases()
     elif "--file-only" in sys.argv:
         os.makedirs(OUT, exist_ok=True); file_cases()
+    elif "--preprocess-only" in sys.argv:
+        os.makedirs(OUT, exist_ok=True); preprocess_cases()
     else:
         main()
