@@ -97,7 +97,10 @@ typedef struct gm_params {
   int no_improper_mappings;                    /* --no-improper-mappings  0 */
   /* optional tail of every SAM record (ref: output.c:452-465,729-756) */
   int extra_sam_fields;                        /* --extra-sam-fields: ZM:i matches, ZR:i window-generation score, ZV:i vector score, ZH:i full SW score, ZE:Z edit string
-                                                  (alignment_edit_string, reversed for mappings on the reverse strand) on mapped records.  0 */
+                                                  (alignment_edit_string, reversed for mappings on the reverse strand) on mapped records.  0.
+                                                  UNTESTED corner: a read or window letter outside A/C/G/T on a reverse-strand mapping -- the reference's
+                                                  reverse_alignment_edit_string never returns on such a letter (its loop index stops advancing, output.c:164-220), so no golden can
+                                                  exist; this library passes the letter through unchanged */
   int sam_r2;                                  /* --sam-r2 (paired mode only): R2:Z (colour space: X2:Z) = the mate's sequence as given.  0 */
   char read_group[64];                         /* --read-group: RG:Z:<name> on every record ("" = none; the @RG header line is the caller's, as the @SQ lines are) */
   /* the read loop's preprocessing, applied by the file entry points to every read before it is mapped (ref: gmapper.c:262-284 trim_read, :427-472, :495-521) */
@@ -220,6 +223,9 @@ void sw_full_ls_stats(uint64_t *invocs, uint64_t *cells, double *secs);   /* ref
  * global penalty everywhere) or rlen per-position penalties, what gmapper passes for every read with quality values (ref: mapping.c:375-379, gmapper.c:532-544, used per row
  * at sw-full-cs.c:312-322); the device keeps them in 8 bits (gmapper clamps them to [2 * global, -1]).  An argument combination that is not implemented (several anchors, a
  * score outside [-128, 127]) is refused LOUDLY -- the reason on stderr and in gm_last_error(), sfr->score = 0 -- never answered as if the window held no alignment.
+ * is_rna (all three seams; the reference sets it for a genome with uracil and no thymine, genome.c:1063-1064): the U-as-T colour translation of lstocs / cstols
+ * (util.h:157-205) is NOT implemented.  In letter space the argument changes nothing (sw-vector.c uses it in the colour-space row only); in colour space a call with is_rna
+ * set is refused the same loud way, and gm_index_build refuses a contig that holds U and no T, so that an RNA genome is never mapped with DNA rules unnoticed.
  * ------------------------------------------------------------------------------------------- */
 int sw_full_cs_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
                      int match, int mismatch, int global_xover_penalty, bool reset_stats, int anchor_width, int indel_taboo_len);

@@ -185,6 +185,17 @@ extern "C" int gm_index_build(gm_index_t** out, int device, int n_contigs, const
                               int n_seeds, const char* const* seeds, const gm_params_t* params) {
   if (!out || n_contigs < 1 || !contigs || !contig_len) { gm_set_error("gm_index_build: bad arguments"); return GM_E_ARG; }
   if (gm_device_count() <= device) { gm_set_error("no HIP device %d (the seed index lives in HBM; there is no CPU path)", device); return GM_E_NODEVICE; }
+  // RNA contigs (uracil and no thymine, ref: fasta.c:528-542 -> genome_is_rna, genome.c:1063-1064) make the reference translate U as T in lstocs / cstols and complement A
+  // to U (util.h:125-205).  That is not built: such a genome is refused here, loudly, instead of being mapped with DNA rules.  (A contig that has a T ends the scan at once.)
+  for (int c = 0; c < n_contigs; c++) {
+    bool got_u = false, got_t = false;
+    const uint64_t nw = ((uint64_t)contig_len[c] + 7) / 8;
+    for (uint64_t w = 0; w < nw && !got_t; w++) {
+      const uint32_t x = contigs[c][w]; const int nn = (int)std::min<uint64_t>(8, (uint64_t)contig_len[c] - 8 * w);
+      for (int k = 0; k < nn; k++) { const uint32_t b = (x >> (4 * k)) & 0xf; got_t |= b == 3u; got_u |= b == 4u; }
+    }
+    if (got_u && !got_t) { gm_set_error("contig %d holds uracil and no thymine: RNA genomes (the reference's is_rna translation, ref: genome.c:1063-1064, util.h:125-205) are not implemented", c); return GM_E_ARG; }
+  }
   GM_HIP(hipSetDevice(device));
   gm_index* ix = new gm_index();
   ix->device = device;
@@ -1801,8 +1812,9 @@ extern "C" int gm_sw_vector_batch_bounded(int n, const uint32_t* genome, uint64_
 }
 
 extern "C" int sw_vector(uint32_t* genome, int goff, int glen, uint32_t* read, int rlen, uint32_t* genome_ls, int initbp, bool is_rna) {
-  (void)is_rna;
   if (!g_sv.init) abort();   // ref: sw-vector.c:462-463
+  // is_rna only matters to the colour-space first-colour row (lstocs(genome_ls[j], initbp, is_rna), ref: sw-vector.c:129,289): not implemented, refused loudly
+  if (is_rna && genome_ls) { gm_set_error("sw_vector: is_rna (U translated as T, ref: sw-vector.c:129) is not implemented"); fprintf(stderr, "gmapper_hip: sw_vector refused: is_rna is not implemented\n"); return GM_E_ARG; }
   int64_t go = goff; int score = 0;
   const uint64_t gw = ((uint64_t)goff + glen + 7) / 8;
   if (g_sv.colours) {        // colour space: genome = colours, genome_ls = letters of the same contig (ref: sw-vector.c:476-479)
@@ -1862,8 +1874,8 @@ extern "C" int gm_sw_gapless_batch(int n, const uint32_t* genome, const uint32_t
   return rc;
 }
 extern "C" int sw_gapless(uint32_t* genome, int glen, uint32_t* read, int rlen, int g_idx, int r_idx, uint32_t* genome_ls, int init_bp, bool is_rna) {
-  (void)is_rna;
   if (!g_sg.init) abort();   // ref: sw-gapless.c:66-67
+  if (is_rna && genome_ls) { gm_set_error("sw_gapless: is_rna (ref: sw-gapless.c:84) is not implemented"); fprintf(stderr, "gmapper_hip: sw_gapless refused: is_rna is not implemented\n"); return GM_E_ARG; }
   int64_t wo = 0; int score = 0;
   int rc = gm_sw_gapless_batch(1, genome, genome_ls, ((uint64_t)glen + 7) / 8, &wo, &glen, read, (rlen + 7) / 8, &rlen, &g_idx, &r_idx, genome_ls ? &init_bp : nullptr, &score);
   return rc == GM_OK ? score : rc;
@@ -1976,8 +1988,9 @@ extern "C" void sw_full_cs_stats(uint64_t* invocs, uint64_t* cells, double* secs
 extern "C" void sw_full_cs(uint32_t* genome_ls, int goff, int glen, uint32_t* read, int rlen, int initbp, int threshscore,
                            struct gm_sw_full_results* sfr, bool revcmpl, bool is_rna, struct gm_anchor* anchors, int anchors_cnt,
                            int local_alignment, int* crossover_score) {
-  (void)is_rna;
   if (!g_sc.init) abort();   // ref: sw-full-cs.c:1155-1156
+  if (is_rna) { gm_set_error("sw_full_cs: is_rna (U translated as T, ref: sw-full-cs.c:1191, util.h:157-205) is not implemented"); fprintf(stderr, "gmapper_hip: sw_full_cs refused: is_rna is not implemented\n");
+                sfr->score = 0; sfr->dbalign = nullptr; sfr->qralign = nullptr; return; }
   SeamTimer tm(&g_sc.secs); g_sc.invocs++; g_sc.cells += 4ull * (uint64_t)std::max(glen, 0) * (uint64_t)std::max(rlen, 0);
   // A refusal must not read as "no alignment" (score 0 is what a window below the threshold returns): the reason goes to stderr as well as to gm_last_error().
   auto fail = [&](const char* why) { gm_set_error("sw_full_cs: %s", why); fprintf(stderr, "gmapper_hip: sw_full_cs refused: %s\n", why); sfr->score = 0; sfr->dbalign = nullptr; sfr->qralign = nullptr; };
