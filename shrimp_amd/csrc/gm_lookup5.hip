@@ -96,7 +96,7 @@ __device__ __forceinline__ uint32_t k5_lane_times(int lane, uint32_t W) {
 // whatever comes next, so pass B and the exact stages run a.rounds times, each time over the candidates of one part of the genome: a.round_regs regions plus ONE region
 // either side (a region's count takes the strip marks of the region behind it, its members look at the region before it, the prune rules at both neighbours -- with the
 // halo all of that is complete for every region of the part itself), and only candidates of the part itself are emitted.
-#define K5_KERNEL_HEAD template <int LSWC> __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 5))) k_lookup_v5(GmIndexDev ix, K5Args a)
+#define K5_KERNEL_HEAD template <int LSWC> __global__ void __launch_bounds__(1024) k_lookup_v5(GmIndexDev ix, K5Args a)
 #define K5_KERNEL_MULTI false
 #include "gm_lookup5_kernel.inc"
 #undef K5_KERNEL_HEAD

@@ -23,10 +23,10 @@ print("kernel", lib.gm_last_lookup_kernel().decode(), "map %.3fs" % dt, {k: v fo
 if has:
     lib.gm_debug_k5_stamps(out)
     v = [int(x) for x in out]; tot = sum(v) or 1
-    # (the exact stages: sorted form -- stamp 10 = counting sort to bucket order, 3 = position order, 4 = decisions + output; table form (-DK5_TABLE_EXACT) -- 10 / 3 = region
-    # table, 11 / 4 = rules + output)
-    names = ["setup(+clear wait)", "pass A", "pass B", "exact: order / table", "exact: decisions+output", "bookkeeping+clear"]
+    # (profiles/r04h, r04i were printed by the sorted-exact-stage experiment of commit 60c0567: there stamp 10 = counting sort to bucket order, 3 = position order,
+    # 4 = decisions + output)
+    names = ["setup(+clear wait)", "pass A", "pass B", "region table", "rules+output", "bookkeeping+clear"]
     tot = sum(v[:6]) or 1
     for nm, x in zip(names, v): print("%-20s %6.2f %%  %8.0f ticks per read-strand" % (nm, 100.0 * x / tot, x / (2.0 * n)))
-    for nm, x in zip(["  set-up: to the first barrier", "  set-up: k-mers ahead", "  exact: bucket order / table main loop", "  exact: (table form) rules main loop"], v[8:12]): print("%-32s %8.0f ticks per read-strand (not in the phase above)" % (nm, x / (2.0 * n)))
+    for nm, x in zip(["  set-up: to the first barrier", "  set-up: k-mers ahead", "  region table: main loop", "  rules: main loop (2a)"], v[8:12]): print("%-32s %8.0f ticks per read-strand (not in the phase above)" % (nm, x / (2.0 * n)))
     print("candidates per read-strand %.1f, fallbacks %d of %d" % (v[6] / (2.0 * n), v[7], 2 * n))
