@@ -351,7 +351,11 @@ typedef struct gm_pair_opts {
                                                   4: two k-mer matches per mate (region counts; with half_paired = 0 also the mate's);
                                                   3: one match is enough where the mate has hits within reach (use_mp_region_counts 2, or 3 with half_paired = 0;
                                                      hit list mode 3, mapping.c:733-742,1080-1093,1153-1157);
-                                                  2: no region counts at all, a window per anchor.   0 is read as 4 */
+                                                  2: no region counts at all, a window per anchor.   0 is read as 4.
+                                                  PERFORMANCE LIMIT of modes 2 and 3: a read-strand's list entries all reach the window kernel, whose LDS tier holds 4 096 of them;
+                                                  on genomes beyond a few hundred Mbp (17 k - 72 k entries per read-strand at 3 Gbp) nearly every read-strand then takes the
+                                                  heavy tier (a segmented sort and a stream synchronisation per sub-batch): the output stays exact, the throughput drops by
+                                                  more than an order of magnitude.  Mode 4 (the reference's default) has no such limit */
 } gm_pair_opts_t;
 void gm_pair_opts_default(gm_pair_opts_t *o);
 int gm_map_pairs(gm_session_t *s, int n_pairs, int len1, const uint32_t *mates1_packed, int len2, const uint32_t *mates2_packed,
