@@ -226,6 +226,8 @@ void sw_full_ls_stats(uint64_t *invocs, uint64_t *cells, double *secs);   /* ref
  * is_rna (all three seams; the reference sets it for a genome with uracil and no thymine, genome.c:1063-1064): the U-as-T colour translation of lstocs / cstols
  * (util.h:157-205) is NOT implemented.  In letter space the argument changes nothing (sw-vector.c uses it in the colour-space row only); in colour space a call with is_rna
  * set is refused the same loud way, and gm_index_build refuses a contig that holds U and no T, so that an RNA genome is never mapped with DNA rules unnoticed.
+ * The same goes for RNA READS in letter space (a read with U and no T has re->is_rna set, fasta.c:528-542, and its reverse complement then holds U for every A): the text and
+ * file entries refuse such a read with an error; the packed-code entries cannot tell and map it with the DNA complement.
  * ------------------------------------------------------------------------------------------- */
 int sw_full_cs_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
                      int match, int mismatch, int global_xover_penalty, bool reset_stats, int anchor_width, int indel_taboo_len);

@@ -402,6 +402,12 @@ template <class F> static void gm_parallel_for(size_t n, size_t grain, F fn) {
   worker();
   for (auto& t : th) t.join();
 }
+// A letter-space read with uracil and no thymine is an RNA read to the reference (re->is_rna, ref: fasta.c:528-542): its reverse complement then holds U for every A
+// (util.h:125-151), which changes its k-mers and scores.  Not implemented, so the text / file entries refuse such a read instead of mapping it with DNA rules.
+static bool gm_is_rna_text(const char* seq, size_t len) {
+  if (!memchr(seq, 'U', len) && !memchr(seq, 'u', len)) return false;
+  return !memchr(seq, 'T', len) && !memchr(seq, 't', len);
+}
 // n lines of exactly `want` characters with '\n' between them (the last one may or may not end in '\n'): true when the text has that layout, checked on the host threads --
 // the line starts are then i * (want + 1) and nothing has to be searched
 static bool gm_fixed_lines(const char* text, size_t n, size_t want) {
@@ -1688,7 +1694,8 @@ extern "C" int gm_map_reads_text(gm_session_t* s, int n_reads, int read_len, con
     std::atomic<int> bad_rc(GM_OK); std::mutex em; std::string emsg;
     gm_parallel_for((size_t)n_reads, 8192, [&](size_t b0, size_t e0) {
       for (size_t i = b0; i < e0 && bad_rc.load(std::memory_order_relaxed) == GM_OK; i++) {
-        int b = 0; const int rc = gm_sequence_to_bitfield(cs, seqs + i * ((size_t)line + 1), line, packed.data() + i * rwords, &b);
+        int b = 0; int rc = gm_sequence_to_bitfield(cs, seqs + i * ((size_t)line + 1), line, packed.data() + i * rwords, &b);
+        if (!rc && !cs && gm_is_rna_text(seqs + i * ((size_t)line + 1), (size_t)line)) { gm_set_error("read %zu holds uracil and no thymine: RNA reads (ref: fasta.c:528-542, util.h:125-151) are not implemented", i); rc = GM_E_ARG; }
         if (rc) { std::lock_guard<std::mutex> lk(em); if (bad_rc == GM_OK) { bad_rc = rc; emsg = gm_last_error(); } return; }
         if (cs) ibp[i] = (uint8_t)b;
       }
@@ -1700,6 +1707,7 @@ extern "C" int gm_map_reads_text(gm_session_t* s, int n_reads, int read_len, con
     const char* e = strchr(p, '\n'); if (!e) e = p + strlen(p);
     if ((int)(e - p) != line) { gm_set_error("read %d: %d characters, expected %d", i, (int)(e - p), line); return GM_E_ARG; }
     int b = 0; const int rc = gm_sequence_to_bitfield(cs, p, line, packed.data() + (size_t)i * rwords, &b); if (rc) return rc;
+    if (!cs && gm_is_rna_text(p, (size_t)line)) { gm_set_error("read %d holds uracil and no thymine: RNA reads (ref: fasta.c:528-542, util.h:125-151) are not implemented", i); return GM_E_ARG; }
     if (cs) ibp[i] = (uint8_t)b;
     p = *e ? e + 1 : e;
   }
