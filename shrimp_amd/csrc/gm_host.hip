@@ -18,6 +18,7 @@
 #include <thread>
 #include <mutex>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <future>
 #include <unordered_map>
@@ -41,7 +42,8 @@ static char* outcache_take(size_t want, size_t* cap) {
   return nullptr;
 }
 static void outcache_track(char* p, size_t cap) { std::lock_guard<std::mutex> g(g_outcache.m); g_outcache.live = p; g_outcache.live_cap = cap; }
-extern "C" void gm_release_cache(void) { std::lock_guard<std::mutex> g(g_outcache.m); free(g_outcache.p); g_outcache.p = nullptr; g_outcache.cap = 0; }
+static void gm_text_pool_drop();
+extern "C" void gm_release_cache(void) { { std::lock_guard<std::mutex> g(g_outcache.m); free(g_outcache.p); g_outcache.p = nullptr; g_outcache.cap = 0; } gm_text_pool_drop(); }
 extern "C" void gm_free(void* p) {
   if (!p) return;
   { std::lock_guard<std::mutex> g(g_outcache.m);
@@ -390,17 +392,55 @@ static int gm_host_threads() {
   if (const char* e = getenv("GM_HOST_THREADS")) n = std::max(1, atoi(e));
   return n;
 }
+// The host side's worker threads, kept for the life of the process (round 4: every sub-batch's finalisation started -- and joined -- up to 32 threads of its own, eight times
+// per million reads).  gm_run_on_threads(n, f) runs f on n threads at once (n - 1 pool threads + the caller) and returns when all are done; calls from different threads
+// (two finalisation jobs overlap) share the pool, which grows to the largest n asked for.
+namespace {
+struct GmThreadPool {
+  // one call of run(): shared by the caller and the queue entries, so that whoever finishes last still finds it alive
+  struct Call { const std::function<void()>* fn = nullptr; int left = 0; std::mutex m; std::condition_variable cv; };
+  std::mutex m; std::condition_variable cv; std::deque<std::shared_ptr<Call>> q; std::vector<std::thread> workers; bool stop = false;
+  ~GmThreadPool() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_all(); for (auto& t : workers) if (t.joinable()) t.join(); }
+  void loop() {
+    for (;;) {
+      std::shared_ptr<Call> c;
+      { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return stop || !q.empty(); }); if (q.empty()) return; c = std::move(q.front()); q.pop_front(); }
+      (*c->fn)();
+      { std::lock_guard<std::mutex> lk(c->m); if (--c->left == 0) c->cv.notify_all(); }
+    }
+  }
+  void run(int n, const std::function<void()>& fn) {
+    if (n <= 1) { fn(); return; }
+    auto c = std::make_shared<Call>(); c->fn = &fn; c->left = n - 1;
+    { std::lock_guard<std::mutex> lk(m);
+      while ((int)workers.size() < n - 1) workers.emplace_back([this] { loop(); });
+      for (int t = 1; t < n; t++) q.push_back(c); }
+    cv.notify_all();
+    fn();
+    std::unique_lock<std::mutex> lk(c->m); c->cv.wait(lk, [&] { return c->left == 0; });      // (fn stays valid until here: every worker has returned from it)
+  }
+};
+GmThreadPool& gm_pool() { static GmThreadPool* p = new GmThreadPool(); return *p; }      // (never destroyed: no join at process exit while a caller may still hold the library)
+}
+static void gm_run_on_threads(int n, const std::function<void()>& fn) { gm_pool().run(n, fn); }
+// Text buffers of the finalisation chunks, recycled across sub-batches and calls: a fresh std::string per chunk and job meant ~250 MB of first-touch page faults per million reads.
+namespace {
+struct GmTextPool {
+  std::mutex m; std::vector<std::string> free_;
+  std::string take() { std::lock_guard<std::mutex> lk(m); if (free_.empty()) return std::string(); std::string t = std::move(free_.back()); free_.pop_back(); t.clear(); return t; }
+  void give(std::string&& t) { if (t.capacity() == 0 || t.capacity() > (16u << 20)) return; std::lock_guard<std::mutex> lk(m); if (free_.size() < 512) free_.push_back(std::move(t)); }
+  void drop() { std::lock_guard<std::mutex> lk(m); free_.clear(); free_.shrink_to_fit(); }
+};
+GmTextPool& gm_text_pool() { static GmTextPool* p = new GmTextPool(); return *p; }
+}
+static void gm_text_pool_drop() { gm_text_pool().drop(); }
 // fn(begin, end) over [0, n) in pieces of `grain`, on the host threads
 template <class F> static void gm_parallel_for(size_t n, size_t grain, F fn) {
   const size_t pieces = (n + grain - 1) / std::max<size_t>(1, grain);
   const int nt = (int)std::min<size_t>((size_t)gm_host_threads(), pieces);
   if (nt <= 1) { if (n) fn((size_t)0, n); return; }
   std::atomic<size_t> next(0);
-  auto worker = [&]() { for (;;) { const size_t c = next.fetch_add(1); if (c >= pieces) break; fn(c * grain, std::min(n, (c + 1) * grain)); } };
-  std::vector<std::thread> th;
-  for (int t = 1; t < nt; t++) th.emplace_back(worker);
-  worker();
-  for (auto& t : th) t.join();
+  gm_run_on_threads(nt, [&]() { for (;;) { const size_t c = next.fetch_add(1); if (c >= pieces) break; fn(c * grain, std::min(n, (c + 1) * grain)); } });
 }
 // A letter-space read with uracil and no thymine is an RNA read to the reference (re->is_rna, ref: fasta.c:528-542): its reverse complement then holds U for every A
 // (util.h:125-151), which changes its k-mers and scores.  Not implemented, so the text / file entries refuse such a read instead of mapping it with DNA rules.
@@ -1003,7 +1043,8 @@ struct Finalizer {
     char nbuf[32]; const char* nm; size_t nl;
     if (name_ptr) { nm = name_ptr[rd]; nl = (size_t)name_len[rd]; }
     else { nl = (size_t)snprintf(nbuf, sizeof nbuf, "r%ld", name_base + rd); nm = nbuf; }
-    const size_t need = 64 + nl + 8 * (size_t)read_len + 320;
+    // room reserved per record (std::string::resize zero-fills it: a letter-space record writes SEQ + QUAL + fixed fields, a colour-space one also CQ / CS / XX)
+    const size_t need = 64 + nl + (P.colour_space ? 8 : 3) * (size_t)read_len + 320;
     // colour space: the read as csfasta text, primer letter + colours ('.' for a skipped cycle), for the CS:Z tag (ref: output.c:451,730)
     auto put_csfasta = [&](char* p) { if (seq_ptr) return put_str(p, seq_ptr[rd], (size_t)read_len + 1);     // verbatim, as the reference prints re->seq
       *p++ = "ACGT"[initbp[rd] & 3]; for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = (c < 4) ? (char)('0' + c) : '.'; } return p; };
@@ -1055,7 +1096,7 @@ struct Finalizer {
     }
     for (auto* h : p2) {
       const GmFullRes& r = *h->r;
-      size_t o = out.size(); out.resize(o + need + 12 * (size_t)r.n_ops); char* p = &out[o];
+      size_t o = out.size(); out.resize(o + need + 12 * (size_t)r.n_ops + ix->names[r.cn].size()); char* p = &out[o];
       const bool rev = r.gen_st == 1;
       const int read_start = r.read_start + 1, read_end = read_start + r.rmapped - 1;
       const int glen = (int)(ix->contig_off[r.cn + 1] - ix->contig_off[r.cn]);
@@ -1462,7 +1503,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
       std::vector<FHit> fh; std::vector<FHit*> p2;
       for (;;) {
         int c = next.fetch_add(1); if (c >= nchunks) break;
-        std::string& o = J->outs[c]; if (emit_sam) o.reserve((size_t)chunk * (read_len + 120));
+        std::string& o = J->outs[c]; o = gm_text_pool().take(); if (emit_sam) o.reserve((size_t)chunk * (read_len + 120));
         for (int rd = c * chunk; rd < std::min(n, (c + 1) * chunk); rd++) {
           const uint32_t cnt = J->hs->sel_cnt[rd], off = J->hs->sel_off[rd];
           const size_t before = o.size();
@@ -1474,10 +1515,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
         }
       }
     };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nthreads; t++) th.emplace_back(worker);
-    worker();
-    for (auto& t : th) t.join();
+    gm_run_on_threads(nthreads, worker);
     J->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (emit_sam) {
       size_t sz = 0; for (auto& o : J->outs) sz += o.size();
@@ -1495,16 +1533,14 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
         char* dst = ob.p + ob.len;
         std::vector<size_t> off(J->outs.size()); size_t a = 0; for (size_t c = 0; c < J->outs.size(); c++) { off[c] = a; a += J->outs[c].size(); }
         std::atomic<size_t> nextc(0);
-        auto copier = [&]() { for (;;) { const size_t c = nextc.fetch_add(1); if (c >= J->outs.size()) break; memcpy(dst + off[c], J->outs[c].data(), J->outs[c].size()); std::string().swap(J->outs[c]); } };
-        std::vector<std::thread> ct;
-        for (int t = 1; t < std::min(nthreads, 4); t++) ct.emplace_back(copier);
-        copier();
-        for (auto& t : ct) t.join();
+        auto copier = [&]() { for (;;) { const size_t c = nextc.fetch_add(1); if (c >= J->outs.size()) break; memcpy(dst + off[c], J->outs[c].data(), J->outs[c].size()); gm_text_pool().give(std::move(J->outs[c])); J->outs[c] = std::string(); } };
+        gm_run_on_threads(std::min(nthreads, 4), copier);
         ob.len += sz;
       }
       ob.turn = J->idx + 1;
       lk.unlock(); ob.cv.notify_all();
     }
+    for (auto& o : J->outs) gm_text_pool().give(std::move(o));          // (what the copy above did not hand back already)
   };
   size_t joined = 0;
   // Two buffer sets: the front of sub-batch i + 1 (stream A) is queued before the host turns to the back of sub-batch i (stream B),
