@@ -1393,6 +1393,43 @@ def test_read_loop_preprocessing_matches_reference_golden(gm):
     s2.close(); s.close(); ix.close()
 
 
+def test_file_entries_edge_cases(gm, tmp_path):
+    """the streaming file entries at their edges: an empty file, a file whose reads are all dropped (mean quality below --min-avg-qv), a chunk size that equals the number of
+    reads, a chunk of one read, an odd read at the end of an interleaved pair file (it has no mate and is ignored), a write function that asks to stop"""
+    import ctypes as C
+    contigs, reads, _ = oa.load_golden("stress_60bp")
+    p = gm.default_params(); p.sam_unaligned = 1
+    ix = gm.Index(contigs, params=p); s = gm.Session(ix, params=p, max_batch_reads=4096)
+    T = np.frombuffer(b"ACGTUMRWSYKVHDBN", dtype=np.uint8)
+    empty = str(tmp_path / "empty.fa"); open(empty, "wb").close()
+    assert s.map_reads_file(empty) == b"" and s.map_reads_file_chunks(empty, chunk_reads=7) == []
+    fq = str(tmp_path / "low.fq")
+    with open(fq, "wb") as f:
+        for i, r in enumerate(reads[:40]): f.write(b"@q%d\n" % i + T[r].tobytes() + b"\n+\n" + b"#" * len(r) + b"\n")       # PHRED+33 '#': quality 2
+    assert s.map_reads_file(fq, qual_delta=33) == b""
+    fa = str(tmp_path / "r.fa")
+    with open(fa, "wb") as f:
+        for i, r in enumerate(reads[:50]): f.write(b">r%d\n" % i + T[r].tobytes() + b"\n")
+    whole = s.map_reads_file(fa)
+    assert whole.count(b"\n") >= 50
+    for chunk in (50, 1, 49, 51):
+        parts = s.map_reads_file_chunks(fa, chunk_reads=chunk)
+        assert b"".join(parts) == whole and len(parts) == (50 + chunk - 1) // chunk, (chunk, len(parts))
+    il = str(tmp_path / "il.fa")
+    with open(il, "wb") as f:
+        for i, r in enumerate(reads[:21]): f.write(b">p%d/%d\n" % (i // 2, 1 + i % 2) + T[r].tobytes() + b"\n")
+    body = s.map_pairs_file(il, mode="opp-in", min_insert=0, max_insert=1000)
+    names = {l.split(b"\t")[0] for l in body.split(b"\n") if l}                 # (a pair prints under the common prefix of its mates' names)
+    assert b"p9" in names and not any(n.startswith(b"p10") for n in names)
+    # a write function that returns non-zero stops the call with an error
+    WRITE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+    cb = WRITE(lambda ctx, pp, n: 1)
+    st = gm.MapStats()
+    rc = gm.lib().gm_map_reads_file_cb(s.h, fa.encode(), -1, 64, C.c_size_t(10), cb, None, C.byref(st))
+    assert rc != 0 and b"asked to stop" in gm.lib().gm_last_error()
+    s.close(); ix.close()
+
+
 @pytest.mark.parametrize("case", ["two_fastq_gz", "interleaved_fasta"])
 def test_pair_files_match_reference_golden(gm, case, tmp_path):
     """gm_map_pairs_file: `gmapper -1 a.fq.gz -2 b.fq.gz` (PHRED+33, mates cut to a mix of lengths) and one FASTA file with the mates adjacent -- the files the
