@@ -51,9 +51,15 @@ static inline int char_to_code_ls(unsigned char c) {  // fasta_open translate ta
 }
 static const char LSTRANS[17] = "ACGTUMRWSYKVHDBN";  // base_translate, common/fasta.c:689-690
 
-static inline int complement_base(int b) {  // common/util.h:125-151 (is_rna=false)
+static inline int complement_base(int b, bool is_rna = false) {  // common/util.h:125-151: in an RNA sequence the complement of A is U
   static const int cmpl[16] = {3, 2, 1, 0, 0, 10, 9, 7, 8, 6, 5, 14, 13, 12, 11, 15};
-  return cmpl[b];
+  return (is_rna && cmpl[b] == 3) ? 4 : cmpl[b];
+}
+// "is RNA": uracil and no thymine (common/fasta.c:528-542, on the text; the same test on the 4-bit codes)
+static inline bool codes_are_rna(const uint8_t* codes, size_t n) {
+  bool u = false, t = false;
+  for (size_t i = 0; i < n; i++) { u |= codes[i] == 4; t |= codes[i] == 3; }
+  return u && !t;
 }
 
 static inline std::vector<uint32_t> pack_codes(const uint8_t* codes, size_t n) {  // fasta_sequence_to_bitfield, fasta.c:609-673
@@ -63,10 +69,10 @@ static inline std::vector<uint32_t> pack_codes(const uint8_t* codes, size_t n) {
 }
 
 // reverse_complement_read_ls (common/util.c:540-596): rc[i] = cmpl(read[len-1-i]), unused nibbles 0.
-static inline std::vector<uint32_t> revcomp_ls(const uint32_t* read, size_t len) {
+static inline std::vector<uint32_t> revcomp_ls(const uint32_t* read, size_t len, bool is_rna = false) {
   std::vector<uint32_t> rc((len + 7) / 8, 0);
   for (size_t i = 0; i < len; i++) {
-    int b = complement_base(EXTRACT(read, (llint)(len - 1 - i)));
+    int b = complement_base(EXTRACT(read, (llint)(len - 1 - i)), is_rna);
     rc[i / 8] |= (uint32_t)b << (4 * (i % 8));
   }
   return rc;
@@ -156,15 +162,18 @@ static inline void set_colour_space(Params& P) {
   derive_score_probs(P);
 }
 
-// lstocs / cstols (common/util.h:157-205), is_rna = false
-static inline int lstocs(int first_letter, int second_letter) {
+// lstocs / cstols (common/util.h:157-205).  With is_rna a U counts as T going in, and cstols hands back U where it would hand back T.
+static inline int lstocs(int first_letter, int second_letter, bool is_rna = false) {
   static const int colourmat[4][4] = {{0, 1, 2, 3}, {1, 0, 3, 2}, {2, 3, 0, 1}, {3, 2, 1, 0}};
+  if (is_rna) { if (first_letter == 4) first_letter = 3; if (second_letter == 4) second_letter = 3; }
   if (first_letter > 3 || second_letter > 3) return 15;     // anything non-{A,C,G,T} -> N
   return colourmat[first_letter][second_letter];
 }
-static inline int cstols(int first_letter, int colour) {
+static inline int cstols(int first_letter, int colour, bool is_rna = false) {
   if (first_letter == 15 || !(colour >= 0 && colour <= 3)) return 15;
-  return (first_letter % 2 == 0) ? ((4 + first_letter + colour) % 4) : ((4 + first_letter - colour) % 4);
+  if (is_rna && first_letter == 4) first_letter = 3;
+  const int ret = (first_letter % 2 == 0) ? ((4 + first_letter + colour) % 4) : ((4 + first_letter - colour) % 4);
+  return (is_rna && ret == 3) ? 4 : ret;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -176,22 +185,26 @@ struct Genome {
   std::vector<std::vector<uint32_t>> fwd, rc;    // genome_contigs[], genome_contigs_rc[]
   std::vector<std::vector<uint32_t>> cs_fwd, cs_rc;   // genome_cs_contigs[], genome_cs_contigs_rc[] (colour space only)
   bool colour = false;
+  bool is_rna = false;                           // genome_is_rna: the flag of the LAST contig read (genome.c:1063-1064); the SW calls get this one
+  std::vector<uint8_t> contig_rna;               // each contig's own flag: its reverse complement and colour translation use that (genome.c:1107-1118)
   int num_contigs() const { return (int)len.size(); }
   // bitfield_to_colourspace (common/fasta.c:586-606): colour i = lstocs(letter i-1, letter i), a T before the first letter
-  static std::vector<uint32_t> to_colourspace(const uint32_t* src, size_t n) {
+  static std::vector<uint32_t> to_colourspace(const uint32_t* src, size_t n, bool rna = false) {
     std::vector<uint32_t> dst((n + 7) / 8, 0u);
     int lastbp = 3;
-    for (size_t i = 0; i < n; i++) { int a = EXTRACT(src, (llint)i); dst[i / 8] |= (uint32_t)lstocs(lastbp, a) << (4 * (i % 8)); lastbp = a; }
+    for (size_t i = 0; i < n; i++) { int a = EXTRACT(src, (llint)i); dst[i / 8] |= (uint32_t)lstocs(lastbp, a, rna) << (4 * (i % 8)); lastbp = a; }
     return dst;
   }
   void add_contig(const std::string& name, const uint8_t* codes, size_t n) {
     uint32_t off = offsets.empty() ? 0u : offsets.back() + len.back();
     names.push_back(name); offsets.push_back(off); len.push_back((uint32_t)n);
+    const bool rna = codes_are_rna(codes, n);
+    contig_rna.push_back(rna ? 1 : 0); is_rna = rna;
     fwd.push_back(pack_codes(codes, n));
-    rc.push_back(revcomp_ls(fwd.back().data(), n));
+    rc.push_back(revcomp_ls(fwd.back().data(), n, rna));
     if (colour) {   // genome.c:1108-1119
-      cs_fwd.push_back(to_colourspace(fwd.back().data(), n));
-      cs_rc.push_back(to_colourspace(rc.back().data(), n));
+      cs_fwd.push_back(to_colourspace(fwd.back().data(), n, rna));
+      cs_rc.push_back(to_colourspace(rc.back().data(), n, rna));
     }
   }
   // the sequence the seed index is built over (genome.c:1126-1136: the colour translation in colour space)
@@ -481,13 +494,13 @@ static inline int sw_vector(const Params& P, const uint32_t* genome, llint goff,
 // genome holds colours): a diagonal that starts at the read's first colour compares it with lstocs(letter, primer) first (:84-94); `mismatch` is what
 // sw_gapless_setup got (f1_setup hands over match + crossover in colour space, gmapper.c:2935, f1-wrapper.h:66-68).
 static inline int sw_gapless(const Params& P, const uint32_t* genome, int glen, const uint32_t* read, int rlen, int g_idx, int r_idx,
-                             const uint32_t* genome_ls = nullptr, int init_bp = -1) {
+                             const uint32_t* genome_ls = nullptr, int init_bp = -1, bool is_rna = false) {
   const int mismatch = genome_ls ? P.match_score + P.crossover_score : P.mismatch_score;
   int g_left, r_left;
   if (g_idx < r_idx) { g_left = 0; r_left = r_idx - g_idx; } else { g_left = g_idx - r_idx; r_left = 0; }
   int g_right = g_left, r_right = r_left, score = 0, max_score = 0;
   if (genome_ls != nullptr && r_left == 0) {           // forcefully match the first colour of the read
-    const int real_colour = lstocs((int)EXTRACT(genome_ls, g_right), init_bp);
+    const int real_colour = lstocs((int)EXTRACT(genome_ls, g_right), init_bp, is_rna);
     if (real_colour == (int)EXTRACT(read, 0)) score = P.match_score; else { r_left++; g_left++; }
     r_right++; g_right++;
     max_score = score;
@@ -506,7 +519,7 @@ static inline int sw_gapless(const Params& P, const uint32_t* genome, int glen, 
 // colour between the read's initial base and the genome letter.  `mismatch` is what sw_vector_setup got: match + crossover
 // in colour space (gmapper.c:2935).
 static inline int sw_vector_cs(const Params& P, int mismatch, const uint32_t* genome_cs, llint goff, int glen,
-                               const uint32_t* read, int rlen, const uint32_t* genome_ls, int initbp) {
+                               const uint32_t* read, int rlen, const uint32_t* genome_ls, int initbp, bool is_rna = false) {
   const int a_go = -P.a_gap_open_score, a_ge = -P.a_gap_extend_score;
   const int b_go = -P.b_gap_open_score, b_ge = -P.b_gap_extend_score;
   std::vector<int> H(glen + 1, 0), B(glen + 1, -b_go);
@@ -515,7 +528,7 @@ static inline int sw_vector_cs(const Params& P, int mismatch, const uint32_t* ge
     const int q = EXTRACT(read, i);
     int hdiag = 0, hleft = 0, a = -a_go;
     for (int j = 0; j < glen; j++) {
-      const int gcode = (i == 0) ? lstocs((int)EXTRACT(genome_ls, goff + j), initbp) : (int)EXTRACT(genome_cs, goff + j);
+      const int gcode = (i == 0) ? lstocs((int)EXTRACT(genome_ls, goff + j), initbp, is_rna) : (int)EXTRACT(genome_cs, goff + j);
       a = std::max(a - a_ge, hleft - a_go - a_ge);
       const int b = std::max(B[j + 1] - b_ge, H[j + 1] - b_go - b_ge);
       int h = hdiag + (gcode == q ? P.match_score : mismatch);
@@ -733,7 +746,8 @@ typedef SwFullResults SwFullCsResults;
 static inline void sw_full_cs(const CsParams& C, const uint32_t* genome_ls, llint goff, int glen, const uint32_t* read, int rlen, int initbp,
                               int threshscore, SwFullCsResults* sfr, bool revcmpl, const Anchor* anchors, int anchors_cnt,
                               const int* crossover_score = nullptr,     // per-position crossover scores from the read's QVs (gmapper.c:532-544), or null
-                              int local_alignment = 0) {                // Gflag off (--local): states floored at 0 / the crossover score with a null back pointer, best cell of the whole band (:199-203,315,439-552)
+                              int local_alignment = 0,                  // Gflag off (--local): states floored at 0 / the crossover score with a null back pointer, best cell of the whole band (:199-203,315,439-552)
+                              bool is_rna = false) {                    // genome_is_rna: the four letter translations of the read hold U where DNA has T (:1191)
   const int lena = glen, lenb = rlen;
   struct Lay { int n, w, nw; int8_t bn, bw, bnw; };
   struct Cell { Lay from[4]; };
@@ -747,7 +761,7 @@ static inline void sw_full_cs(const CsParams& C, const uint32_t* genome_ls, llin
     for (int j = 0; j < lenb; j++) {
       const int base = EXTRACT(read, j);
       if (base == 15) { qr[k][j] = 15; letter = (k + initbp) % 4; }
-      else { qr[k][j] = (int8_t)cstols(letter, base); letter = qr[k][j]; }
+      else { qr[k][j] = (int8_t)cstols(letter, base, is_rna); letter = qr[k][j]; }
     }
   }
   int xo = C.xover;                                                      // global_xover_penalty; per row below (:312)
@@ -1122,7 +1136,7 @@ struct Mapper {
     std::vector<uint8_t> codes(re.read_len);
     for (int i = 0; i < re.read_len; i++) codes[i] = (uint8_t)char_to_code_ls((unsigned char)re.seq[i]);
     re.bits[0] = pack_codes(codes.data(), codes.size());
-    re.bits[1] = revcomp_ls(re.bits[0].data(), re.read_len);
+    re.bits[1] = revcomp_ls(re.bits[0].data(), re.read_len, codes_are_rna(codes.data(), codes.size()));   // re->is_rna (fasta.c:528-542), gmapper.c:487
     if (re.max_n_kmers < 0) re.max_n_kmers = 0;
     re.min_kmer_pos = 0; re.input_strand = 0;
     re.window_len = (uint16_t)GMO_ABS_OR_PCT(P.window_len, re.read_len);  // gmapper.c:530
@@ -1383,8 +1397,8 @@ struct Mapper {
       hv = hash_genome_window(genome, (uint32_t)goff, (uint32_t)wlen) % f1_window_cache_size;
       if (T.f1_tag[hv] == tag) { T.stats.vec_bypassed++; return (int)T.f1_score[hv]; }
     }
-    int score = gapless_call ? sw_gapless(P, genome, gapless_glen, read, rlen, gapless_g_idx, gapless_r_idx, genome_ls, initbp) :
-                genome_ls ? sw_vector_cs(P, P.match_score + P.crossover_score, genome, goff, wlen, read, rlen, genome_ls, initbp)   // gmapper.c:2935
+    int score = gapless_call ? sw_gapless(P, genome, gapless_glen, read, rlen, gapless_g_idx, gapless_r_idx, genome_ls, initbp, G->is_rna) :
+                genome_ls ? sw_vector_cs(P, P.match_score + P.crossover_score, genome, goff, wlen, read, rlen, genome_ls, initbp, G->is_rna)   // gmapper.c:2935; genome_is_rna: mapping.c:1318
                           : sw_vector(P, genome, goff, wlen, read, rlen);
     T.stats.vec_calls++; T.stats.vec_cells += (uint64_t)wlen * rlen;
     if (P.hash_filter_calls && tag != 0) { T.f1_tag[hv] = tag; T.f1_score[hv] = (uint32_t)score; }
@@ -1469,7 +1483,7 @@ struct Mapper {
       C.anchor_width = P.anchor_width; C.indel_taboo_len = P.indel_taboo_len;
       T.stats.full_calls++;
       sw_full_cs(C, gen, h.g_off, h.w_len, re.bits[h.st].data(), re.read_len, re.initbp[h.st], thresh, &h.sfr, h.gen_st && P.Tflag, &h.anchor, 1,
-                 re.crossover_score.empty() ? nullptr : re.crossover_score.data(), P.Gflag ? 0 : 1);
+                 re.crossover_score.empty() ? nullptr : re.crossover_score.data(), P.Gflag ? 0 : 1, G->is_rna);   // mapping.c:375-379
       h.score_full = h.sfr.score;
       h.pct_score_full = (1000 * 100 * h.score_full) / h.score_max;
       return;

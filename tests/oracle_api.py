@@ -341,3 +341,53 @@ def load_kat_cs(name="sw_kat_cs.txt.gz"):
                 recs.append((t[0].decode(), [int(x) for x in t[1:11]], words(t[11]), words(t[12]), [int(x) for x in t[13:23]],
                              b"" if t[23] == b"-" else t[23], b"" if t[24] == b"-" else t[24]))
     return recs
+
+
+# RNA fixtures (tools/make_golden.py rna_cases): tag -> (colour space?, genome file, read files, oracle options, pairing)
+RNA_CASES = {
+    "rna_ls": (False, "rna_genome.fa.gz", ["rna_reads_ls.fa.gz"], None, None),
+    "rna_ls_pairs": (False, "rna_genome.fa.gz", ["rna_pairs_1.fa.gz", "rna_pairs_2.fa.gz"], None, ("opp-in", 100, 500)),
+    "rna_ls_last_dna": (False, "rna_genome_last_dna.fa.gz", ["rna_reads_ls.fa.gz"], None, None),
+    "rna_cs": (True, "rna_genome.fa.gz", ["rna_reads_cs.fa.gz"], None, None),
+    "rna_cs_fq": (True, "rna_genome.fa.gz", ["rna_reads_cs.fq.gz"], None, None),
+    "rna_cs_last_dna": (True, "rna_genome_last_dna.fa.gz", ["rna_reads_cs.fa.gz"], None, None),
+    "rna_cs_last_rna": (True, "rna_genome_last_rna.fa.gz", ["rna_reads_cs.fa.gz"], None, None),
+    "rna_cs_ungapped": (True, "rna_genome.fa.gz", ["rna_reads_cs.fa.gz"], "local=1;ungapped=1", None),
+}
+_LS_CODE = {c: i for i, c in enumerate(b"ACGTUMRWSYKVHDBN")}
+
+
+def read_fastx(name, colour=False):
+    """names, n x L code matrix (colour space: primer letter code first, then colours, 15 for '.'), QUAL strings or None -- of a fixed-length FASTA/FASTQ fixture"""
+    with gzip.open(os.path.join(ROOT, "tests", "golden", name), "rb") as f:
+        lines = [l for l in f.read().split(b"\n") if l]
+    fq = lines[0][:1] == b"@"
+    step = 4 if fq else 2
+    names = [lines[i][1:] for i in range(0, len(lines), step)]
+    seqs = [lines[i + 1] for i in range(0, len(lines), step)]
+    quals = [lines[i + 3] for i in range(0, len(lines), step)] if fq else None
+    if colour:
+        codes = np.array([[_LS_CODE[s[0]]] + [c - 48 if 48 <= c <= 51 else 15 for c in s[1:]] for s in seqs], dtype=np.uint8)
+    else:
+        codes = np.array([[_LS_CODE[c] for c in s.upper()] for s in seqs], dtype=np.uint8)
+    return names, codes, quals
+
+
+def read_genome_fixture(name):
+    """contig names and code arrays of a FASTA genome fixture"""
+    with gzip.open(os.path.join(ROOT, "tests", "golden", name), "rb") as f:
+        text = f.read()
+    names, contigs = [], []
+    for block in text.split(b">")[1:]:
+        head, _, body = block.partition(b"\n")
+        names.append(head.strip())
+        contigs.append(np.array([_LS_CODE[c] for c in body.replace(b"\n", b"").upper()], dtype=np.uint8))
+    return names, contigs
+
+
+def load_rna_case(tag):
+    colour, gname, rfiles, opts, pairing = RNA_CASES[tag]
+    cn, contigs = read_genome_fixture(gname)
+    with gzip.open(os.path.join(ROOT, "tests", "golden", tag + ".sam.gz"), "rb") as f:
+        sam = f.read()
+    return dict(colour=colour, contig_names=cn, contigs=contigs, reads=[read_fastx(r, colour) for r in rfiles], files=rfiles, opts=opts, pairing=pairing, sam=sam)

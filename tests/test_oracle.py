@@ -372,3 +372,32 @@ def test_colour_space_local_and_ungapped_match_reference(tag):
     o = oa.Session(contigs, opts=opts); o.set(sam_unaligned=unal, hash_filter_calls=("ungapped" not in opts))
     got = oa.sam_header(contigs) + o.map_sam(reads, nthreads=4); o.close()
     assert got == want
+
+
+@pytest.mark.parametrize("tag", sorted(oa.RNA_CASES))
+def test_oracle_rna_sequences_match_reference(tag, oracle_lib):
+    """RNA contigs and RNA reads (uracil and no thymine, ref: fasta.c:528-542): a contig's own flag in its reverse complement and colour translation
+    (genome.c:1107-1118), the last contig's flag as genome_is_rna in sw_vector / sw_gapless / sw_full_cs (genome.c:1063-1064; mapping.c:375-388,1318-1327;
+    util.h:125-205), a letter-space read's own flag in its reverse complement (gmapper.c:487) -- against gmapper-ls / gmapper-cs on the rna_* fixtures"""
+    g = oa.load_rna_case(tag)
+    opts = ";".join(x for x in (("colour=1" if g["colour"] else None), g["opts"]) if x)
+    s = oa.Session(g["contigs"], g["contig_names"], opts=opts or None); s.set(True, True)
+    if g["pairing"]:
+        (n1, m1, _), (n2, m2, _) = g["reads"]
+        s.set_pairing(*g["pairing"])
+        body = s.map_pairs_sam(m1, m2, n1, n2, nthreads=4)
+    else:
+        names, codes, quals = g["reads"][0]
+        if quals is not None:
+            s.L.gmo_map_sam_q.restype = C.c_void_p
+            s.L.gmo_map_sam_q.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+            codes = np.ascontiguousarray(codes)
+            p = s.L.gmo_map_sam_q(s.h, codes.shape[0], codes.shape[1], codes.ctypes.data_as(C.POINTER(C.c_uint8)), b"\n".join(names), b"\n".join(quals), 33, 4)
+            body = C.string_at(p); s.L.gmo_free(p)
+        else:
+            codes = np.ascontiguousarray(codes)
+            p = s.L.gmo_map_sam(s.h, codes.shape[0], codes.shape[1], codes.ctypes.data_as(C.POINTER(C.c_uint8)), b"\n".join(names), 4, None)
+            body = C.string_at(p); s.L.gmo_free(p)
+    s.close()
+    got = oa.sam_header(g["contigs"], g["contig_names"]) + body
+    assert got == g["sam"], "oracle SAM differs from the reference's for %s" % tag

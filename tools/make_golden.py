@@ -877,6 +877,105 @@ def format_cases():
         print("%s@%s: %d mappings" % (base, tag, p.stdout.count(b"\n>")))
 
 
+RNA_CASES = {
+    # tag: (binary, genome fixture, read fixtures, options of the reference): RNA sequences -- uracil and no thymine (ref: fasta.c:528-542).  A contig's flag decides its
+    # reverse complement (A -> U) and its colour translation (U read as T; genome.c:1107-1118); the LAST contig's flag is genome_is_rna, which the SW calls get
+    # (genome.c:1063-1064; mapping.c:375-388,1318-1327); a letter-space read's own flag decides its reverse complement (gmapper.c:487).
+    "rna_ls": ("gmapper-ls", "rna_genome.fa.gz", ["rna_reads_ls.fa.gz"], []),
+    "rna_ls_pairs": ("gmapper-ls", "rna_genome.fa.gz", ["rna_pairs_1.fa.gz", "rna_pairs_2.fa.gz"], ["-p", "opp-in", "-I", "100,500"]),
+    "rna_ls_last_dna": ("gmapper-ls", "rna_genome_last_dna.fa.gz", ["rna_reads_ls.fa.gz"], []),
+    "rna_cs": ("gmapper-cs", "rna_genome.fa.gz", ["rna_reads_cs.fa.gz"], []),
+    "rna_cs_fq": ("gmapper-cs", "rna_genome.fa.gz", ["rna_reads_cs.fq.gz"], ["--qv-offset", "33"]),
+    "rna_cs_last_dna": ("gmapper-cs", "rna_genome_last_dna.fa.gz", ["rna_reads_cs.fa.gz"], []),
+    "rna_cs_last_rna": ("gmapper-cs", "rna_genome_last_rna.fa.gz", ["rna_reads_cs.fa.gz"], []),
+    "rna_cs_ungapped": ("gmapper-cs", "rna_genome.fa.gz", ["rna_reads_cs.fa.gz"], ["--local", "-U"]),
+}
+
+
+def rna_cases():
+    """RNA genomes and RNA reads through the reference.  Fixtures: three genome files (two RNA contigs; the same + a DNA contig last; the DNA contig first), letter-space
+    reads spelled in RNA, in DNA and in both, mate files, colour reads with and without QVs, and the reference's SAM for each combination of RNA_CASES."""
+    rng = np.random.Generator(np.random.PCG64(9090))
+    def contig(n, p_last):                                                          # codes 0..2 + `last` (3 = T, 4 = U), the last letter rare so that colour reads survive
+        return rng.choice(np.array([0, 1, 2, 9], dtype=np.uint8), size=n, p=[0.32, 0.30, 0.30, 0.08])
+    rna1 = contig(30000, 0); rna2 = contig(20000, 0); dna3 = contig(20000, 0)
+    rna1[rna1 == 9] = 4; rna2[rna2 == 9] = 4; dna3[dna3 == 9] = 3
+    rna2[5000:5040] = 15                                                            # a run of N
+    LET = b"ACGTUMRWSYKVHDBN"
+    def fa(names, seqs):
+        out = bytearray()
+        for nm, sq in zip(names, seqs):
+            out += b">" + nm + b"\n"; t = bytes(LET[c] for c in sq)
+            for k in range(0, len(t), 60): out += t[k:k + 60] + b"\n"
+        return bytes(out)
+    genomes = {"rna_genome.fa.gz": fa([b"rna1", b"rna2"], [rna1, rna2]),
+               "rna_genome_last_dna.fa.gz": fa([b"rna1", b"rna2", b"dna3"], [rna1, rna2, dna3]),
+               "rna_genome_last_rna.fa.gz": fa([b"dna3", b"rna1", b"rna2"], [dna3, rna1, rna2])}
+    contigs = [rna1, rna2, dna3]
+    def draw(L, nsub, indel):
+        c = contigs[int(rng.integers(0, 3))]
+        p = int(rng.integers(0, len(c) - L - 8)); s = c[p:p + L + 4].copy()
+        if indel == 1: s = np.delete(s, int(rng.integers(10, L - 10)))
+        elif indel == 2: s = np.insert(s, int(rng.integers(10, L - 10)), int(rng.integers(0, 3)))
+        s = s[:L].copy()
+        for _ in range(nsub): s[int(rng.integers(0, L))] = int(rng.integers(0, 3))
+        return s
+    def revcomp(s, rna):                                                            # a molecule's other strand, spelled like the first
+        cm = np.array([4 if rna else 3, 2, 1, 0, 0, 10, 9, 7, 8, 6, 5, 14, 13, 12, 11, 15], dtype=np.uint8)
+        return cm[s[::-1]]
+    # letter space: 360 reads of 60 letters
+    ls = bytearray()
+    for n in range(360):
+        s = draw(60, int(rng.integers(0, 4)), int(rng.integers(0, 6)) if n % 3 == 0 else 0)
+        rna = bool((s == 4).any())
+        if n % 2: s = revcomp(s, rna)
+        kind = n % 12
+        if kind == 5: s = np.where(s == 4, 3, s).astype(np.uint8)                  # an RNA molecule spelled with T
+        elif kind == 7:                                                            # both U and T: not RNA to the reference
+            s = s.copy(); idx = np.flatnonzero((s == 4) | (s == 3))
+            if len(idx) >= 2: s[idx[0]] = 3; s[idx[1]] = 4
+        elif kind == 9: s = s.copy(); s[int(rng.integers(0, 60))] = 15
+        ls += b">r%d\n" % n + bytes(LET[c] for c in s) + b"\n"
+    # mates: opp-in, inserts of 150-400, the molecule spelled in its contig's alphabet
+    m1 = bytearray(); m2 = bytearray()
+    for n in range(160):
+        c = contigs[int(rng.integers(0, 2))]; ins = int(rng.integers(150, 400)); p = int(rng.integers(0, len(c) - ins))
+        frag = c[p:p + ins].copy()
+        for _ in range(int(rng.integers(0, 4))): frag[int(rng.integers(0, ins))] = int(rng.integers(0, 3))
+        a = frag[:50]; b = revcomp(frag[-50:], True)
+        if n % 2: a, b = b, a
+        if n % 10 == 3: b = draw(50, 0, 0)                                          # a mate from somewhere else
+        m1 += b">p%d/1\n" % n + bytes(LET[x] for x in a) + b"\n"; m2 += b">p%d/2\n" % n + bytes(LET[x] for x in b) + b"\n"
+    # colour space: 400 reads of 40 colours (primer T), with QVs in the FASTQ twin
+    cm4 = np.array([[0, 1, 2, 3], [1, 0, 3, 2], [2, 3, 0, 1], [3, 2, 1, 0]])
+    cs = bytearray(); cq = bytearray()
+    for n in range(400):
+        s = draw(40, 0, int(rng.integers(0, 6)) if n % 4 == 0 else 0)
+        if n % 2: s = revcomp(s, False)
+        s = np.where(s == 4, 3, s); s = np.where(s > 3, 0, s)
+        cols = [int(cm4[3][s[0]])] + [int(cm4[s[k]][s[k + 1]]) for k in range(39)]
+        for _ in range(int(rng.integers(0, 3))): cols[int(rng.integers(0, 40))] = int(rng.integers(0, 4))
+        t = b"T" + bytes(48 + c for c in cols)
+        if n % 37 == 0: t = t[:20] + b"." + t[21:]
+        q = rng.integers(8, 38, 40)
+        cs += b">c%d\n" % n + t + b"\n"; cq += b"@c%d\n" % n + t + b"\n+\n" + bytes((q + 33).astype(np.uint8)) + b"\n"
+    reads = {"rna_reads_ls.fa.gz": bytes(ls), "rna_pairs_1.fa.gz": bytes(m1), "rna_pairs_2.fa.gz": bytes(m2), "rna_reads_cs.fa.gz": bytes(cs), "rna_reads_cs.fq.gz": bytes(cq)}
+    for nm, data in {**genomes, **reads}.items():
+        with gzip.open(os.path.join(OUT, nm), "wb", compresslevel=9) as f: f.write(data)
+    with tempfile.TemporaryDirectory() as d:
+        for nm, data in genomes.items(): open(os.path.join(d, nm[:-3]), "wb").write(data)
+        for nm, data in reads.items(): open(os.path.join(d, nm), "wb").write(gzip.compress(data))
+        for tag, (binary, g, rds, extra) in RNA_CASES.items():
+            files = [os.path.join(d, r) for r in rds]
+            if len(files) == 2: files = ["-1", files[0], "-2", files[1]]
+            p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", binary), "-N", "2", "--sam-unaligned", *extra, *files, os.path.join(d, g[:-3])], capture_output=True)
+            if p.returncode != 0: print(p.stderr.decode()[-1500:]); raise SystemExit(1)
+            sam = b"".join(l + b"\n" for l in p.stdout.split(b"\n") if l and not l.startswith(b"@PG"))
+            with gzip.open(os.path.join(OUT, tag + ".sam.gz"), "wb", compresslevel=9) as f: f.write(sam)
+            recs = [l for l in sam.split(b"\n") if l and not l.startswith(b"@")]
+            print(tag + ":", len(recs), "records,", sum(1 for l in recs if not int(l.split(b"\t")[1]) & 4), "mapped")
+
+
 if __name__ == "__main__":
     if "--pair-file-only" in sys.argv:
         os.makedirs(OUT, exist_ok=True); pair_file_cases()
@@ -886,6 +985,8 @@ if __name__ == "__main__":
         os.makedirs(OUT, exist_ok=True); format_cases()
     elif "--file-only" in sys.argv:
         os.makedirs(OUT, exist_ok=True); file_cases()
+    elif "--rna-only" in sys.argv:
+        os.makedirs(OUT, exist_ok=True); rna_cases()
     elif "--preprocess-only" in sys.argv:
         os.makedirs(OUT, exist_ok=True); preprocess_cases()
     else:
