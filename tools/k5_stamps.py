@@ -18,15 +18,19 @@ lib = gm.lib()
 out = (C.c_ulonglong * 16)()
 has = hasattr(lib, "gm_debug_k5_stamps")
 if has: lib.gm_debug_k5_stamps(out)
-t = time.time(); s.map_reads(reads); dt = time.time() - t
-print("kernel", lib.gm_last_lookup_kernel().decode(), "map %.3fs" % dt, {k: v for k, v in s.stats.items() if k.startswith("ms_") or k in ("survivors", "survivors_pruned", "list_entries")})
-if has:
-    lib.gm_debug_k5_stamps(out)
-    v = [int(x) for x in out]; tot = sum(v) or 1
-    # (profiles/r04h, r04i were printed by the sorted-exact-stage experiment of commit 60c0567: there stamp 10 = counting sort to bucket order, 3 = position order,
-    # 4 = decisions + output)
-    names = ["setup(+clear wait)", "pass A", "pass B", "region table", "rules+output", "bookkeeping+clear"]
-    tot = sum(v[:6]) or 1
-    for nm, x in zip(names, v): print("%-20s %6.2f %%  %8.0f ticks per read-strand" % (nm, 100.0 * x / tot, x / (2.0 * n)))
-    for nm, x in zip(["  set-up: to the first barrier", "  set-up: k-mers ahead", "  region table: main loop", "  rules: main loop (2a)"], v[8:12]): print("%-32s %8.0f ticks per read-strand (not in the phase above)" % (nm, x / (2.0 * n)))
-    print("candidates per read-strand %.1f, fallbacks %d of %d" % (v[6] / (2.0 * n), v[7], 2 * n))
+for nk in (os.environ.get("GM_STAMPS_NK_SWEEP", "").split(",") if os.environ.get("GM_STAMPS_NK_SWEEP") else [None]):
+  if nk is not None:
+    os.environ["GM_K5_NK"] = nk; print("---- GM_K5_NK=%s" % nk)
+    if has: lib.gm_debug_k5_stamps(out)
+  t = time.time(); s.map_reads(reads); dt = time.time() - t
+  print("kernel", lib.gm_last_lookup_kernel().decode(), "map %.3fs" % dt, {k: v for k, v in s.stats.items() if k.startswith("ms_") or k in ("survivors", "survivors_pruned", "list_entries")})
+  if has:
+      lib.gm_debug_k5_stamps(out)
+      v = [int(x) for x in out]; tot = sum(v) or 1
+      # (profiles/r04h, r04i were printed by the sorted-exact-stage experiment of commit 60c0567: there stamp 10 = counting sort to bucket order, 3 = position order,
+      # 4 = decisions + output)
+      names = ["setup(+clear wait)", "pass A", "pass B", "region table", "rules+output", "bookkeeping+clear"]
+      tot = sum(v[:6]) or 1
+      for nm, x in zip(names, v): print("%-20s %6.2f %%  %8.0f ticks per read-strand" % (nm, 100.0 * x / tot, x / (2.0 * n)))
+      for nm, x in zip(["  set-up: to the first barrier", "  set-up: k-mers ahead", "  region table: main loop", "  rules: main loop (2a)"], v[8:12]): print("%-32s %8.0f ticks per read-strand (not in the phase above)" % (nm, x / (2.0 * n)))
+      print("candidates per read-strand %.1f, fallbacks %d of %d" % (v[6] / (2.0 * n), v[7], 2 * n))
