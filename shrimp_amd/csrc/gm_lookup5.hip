@@ -96,19 +96,11 @@ __device__ __forceinline__ uint32_t k5_lane_times(int lane, uint32_t W) {
 // whatever comes next, so pass B and the exact stages run a.rounds times, each time over the candidates of one part of the genome: a.round_regs regions plus ONE region
 // either side (a region's count takes the strip marks of the region behind it, its members look at the region before it, the prune rules at both neighbours -- with the
 // halo all of that is complete for every region of the part itself), and only candidates of the part itself are emitted.
-#ifndef K5_WPE
-#define K5_WPE __attribute__((amdgpu_waves_per_eu(5, 5)))
-#endif
-#define K5_KERNEL_HEAD template <int LSWC, int NKT> __global__ void __launch_bounds__(1024) K5_WPE k_lookup_v5(GmIndexDev ix, K5Args a)
+#define K5_KERNEL_HEAD template <int LSWC> __global__ void __launch_bounds__(1024) k_lookup_v5(GmIndexDev ix, K5Args a)
 #define K5_KERNEL_MULTI false
-#define K5_KERNEL_NK NKT
 #include "gm_lookup5_kernel.inc"
 #undef K5_KERNEL_HEAD
 #undef K5_KERNEL_MULTI
-#undef K5_KERNEL_NK
-#ifndef K5_NK
-#define K5_NK 12          // chunks a wave keeps in registers between the passes (k_lookup_v5<15, K5_NK>: the production kernel)
-#endif
 // (the variant with rounds carries a few more live values; five waves per SIMD as the allocator's target = 96 registers, so that -- like k_lookup_v5<15> -- its four waves per
 // SIMD leave 128 registers to the other stream's kernels; what the allocator then keeps in scratch is stored and re-read per read-strand or per round, outside the streaming loops)
 #define K5_KERNEL_HEAD __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 5))) k_lookup_v5_rounds(GmIndexDev ix, K5Args a)
@@ -325,19 +317,14 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   if (hipMemsetAsync(fb_cnt_p, 0, 4, stream) != hipSuccess || hipMemsetAsync(pl_cnt_p, 0, 4, stream) != hipSuccess) return GM_E_NODEVICE;
   static GmLdsLimit lim_configured; size_t& configured = lim_configured.cur();
   if (lds > 48 * 1024 && lds > configured) {
-    if (hipFuncSetAttribute((const void*)k_lookup_v5<15, K5_NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-#ifdef GM_TUNING
-        hipFuncSetAttribute((const void*)k_lookup_v5<15, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_lookup_v5<15, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_lookup_v5<15, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-#endif
-        hipFuncSetAttribute((const void*)k_lookup_v5<14, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+    if (hipFuncSetAttribute((const void*)k_lookup_v5<15>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_lookup_v5<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_lookup_v5_rounds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_lookup_v5_half, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
 #ifdef GM_TUNING
         hipFuncSetAttribute((const void*)k_lookup_v5_half_plain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
 #endif
-        hipFuncSetAttribute((const void*)k_lookup_v5<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
+        hipFuncSetAttribute((const void*)k_lookup_v5<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
     configured = lds;
   }
   int grid = std::min(2 * n_reads, half ? 2 * K.cus : K.cus);
@@ -369,20 +356,9 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
 #endif
     hipLaunchKernelGGL(k_lookup_v5_half, dim3(grid), dim3(threads), lds, stream, ix, a);
   } else if (rounds > 1) hipLaunchKernelGGL(k_lookup_v5_rounds, dim3(grid), dim3(threads), lds, stream, ix, a);
-  else if (lsw == 15) {
-    int nk = K5_NK;
-    if (const char* e = gm_tune("GM_K5_NK")) nk = atoi(e);      // (tuning builds: 0 = every chunk streamed twice, the round-3 kernel; 8 / 16: other register budgets)
-#ifdef GM_TUNING
-    if (nk == 0) hipLaunchKernelGGL((k_lookup_v5<15, 0>), dim3(grid), dim3(threads), lds, stream, ix, a);
-    else if (nk == 8) hipLaunchKernelGGL((k_lookup_v5<15, 8>), dim3(grid), dim3(threads), lds, stream, ix, a);
-    else if (nk == 16) hipLaunchKernelGGL((k_lookup_v5<15, 16>), dim3(grid), dim3(threads), lds, stream, ix, a);
-    else
-#endif
-    hipLaunchKernelGGL((k_lookup_v5<15, K5_NK>), dim3(grid), dim3(threads), lds, stream, ix, a);
-    (void)nk;
-  }
-  else if (lsw == 14) hipLaunchKernelGGL((k_lookup_v5<14, 0>), dim3(grid), dim3(threads), lds, stream, ix, a);
-  else hipLaunchKernelGGL((k_lookup_v5<0, 0>), dim3(grid), dim3(threads), lds, stream, ix, a);
+  else if (lsw == 15) hipLaunchKernelGGL((k_lookup_v5<15>), dim3(grid), dim3(threads), lds, stream, ix, a);
+  else if (lsw == 14) hipLaunchKernelGGL((k_lookup_v5<14>), dim3(grid), dim3(threads), lds, stream, ix, a);
+  else hipLaunchKernelGGL((k_lookup_v5<0>), dim3(grid), dim3(threads), lds, stream, ix, a);
   if (hipGetLastError() != hipSuccess) return GM_E_NODEVICE;
   *fb_list = K.fb; *fb_cnt = fb_cnt_p; *fb_cap_out = fb_cap; if (pl_list) *pl_list = K.pl; if (pl_cnt) *pl_cnt = pl_cnt_p;
   return 1;

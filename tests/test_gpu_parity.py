@@ -230,9 +230,6 @@ KERNEL_VARIANTS = [
     {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_NO_PRUNE": "1"},   # v5 without the prune rules (all survivors to K2)
     {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_SCAP": "256", "GM_SCAP2": "64"},   # v5 survivors beyond K2's LDS tier: heavy tier
     {"GM_SLAB_BITS": "17", "GM_K1_V5": "1", "GM_K1_THREADS": "128"},               # v5 with two waves per workgroup
-    {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_NK": "0"},       # v5 with every list chunk streamed twice (no chunk kept in registers between the passes: the round-3 kernel)
-    {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_NK": "8"},       # ... eight chunks a wave kept
-    {"GM_SLAB_BITS": "17", "GM_K1_V5": "1", "GM_K1_THREADS": "128", "GM_K5_NK": "16"},   # ... sixteen kept, two waves a workgroup: kept and streamed chunks mixed in every wave
     {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_ROUNDS": "3"},   # v5 with pass B + exact stages per third of the genome (k_lookup_v5_rounds: what 2 x 150 bp reads on 3 Gbp take)
     {"GM_NO_BUCKETS": "1", "GM_K1_V5": "1", "GM_K5_ROUNDS": "2"},   # ... per half, one-slab index
     {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_ROUNDS": "4", "GM_NO_PRUNE": "1"},   # ... four parts, without the prune rules
