@@ -159,7 +159,7 @@ int gm_index_alloc_like(gm_index_t **out, int device, const void *meta, uint64_t
  * S1: vector Smith-Waterman filter (score only).  ref: common/sw-vector.c:388-515
  * Same parameter lists as the reference (penalties passed negative).  State is per calling
  * thread, as in the reference (threadprivate).  With use_colours the read's first colour is compared with lstocs(genome_ls[j], initbp)
- * (see the colour-space block below); is_rna is accepted for signature compatibility.
+ * (see the colour-space block below), with is_rna a U in the genome letters counting as T there (ref: sw-vector.c:129,289; util.h:182-205).
  * ------------------------------------------------------------------------------------------- */
 int sw_vector_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
                     int match, int mismatch, int use_colours, bool reset_stats);
@@ -223,11 +223,13 @@ void sw_full_ls_stats(uint64_t *invocs, uint64_t *cells, double *secs);   /* ref
  * global penalty everywhere) or rlen per-position penalties, what gmapper passes for every read with quality values (ref: mapping.c:375-379, gmapper.c:532-544, used per row
  * at sw-full-cs.c:312-322); the device keeps them in 8 bits (gmapper clamps them to [2 * global, -1]).  An argument combination that is not implemented (several anchors, a
  * score outside [-128, 127]) is refused LOUDLY -- the reason on stderr and in gm_last_error(), sfr->score = 0 -- never answered as if the window held no alignment.
- * is_rna (all three seams; the reference sets it for a genome with uracil and no thymine, genome.c:1063-1064): the U-as-T colour translation of lstocs / cstols
- * (util.h:157-205) is NOT implemented.  In letter space the argument changes nothing (sw-vector.c uses it in the colour-space row only); in colour space a call with is_rna
- * set is refused the same loud way, and gm_index_build refuses a contig that holds U and no T, so that an RNA genome is never mapped with DNA rules unnoticed.
- * The same goes for RNA READS in letter space (a read with U and no T has re->is_rna set, fasta.c:528-542, and its reverse complement then holds U for every A): the text and
- * file entries refuse such a read with an error; the packed-code entries cannot tell and map it with the DNA complement.
+ * is_rna (all three seams; gmapper passes genome_is_rna, the flag of the LAST contig it read: genome.c:1063-1064): lstocs reads a U as T, cstols takes a U as T and hands back U
+ * where it would hand back T (util.h:157-205) -- in sw_vector's and sw_gapless's first-colour comparison and in the four letter translations of sw_full_cs.  In letter space the
+ * argument changes nothing (sw-vector.c uses it in the colour-space row only).
+ * RNA in the batch entries (gm_map_reads* / gm_map_pairs*): a contig with uracil and no thymine is an RNA contig (fasta.c:528-542) -- its reverse complement holds U for A and its
+ * colour translation reads U as T (genome.c:1107-1118); the last contig's flag is what the SW stages get, as in the reference; a letter-space read with U and no T is
+ * reverse-complemented with U for A (gmapper.c:487).  The read's flag is taken from the letters the device gets, i.e. AFTER the file entries' trimming (the reference takes it
+ * from the file's sequence before trimming: the two differ only for a read that holds both U and T and loses every T to the trim).
  * ------------------------------------------------------------------------------------------- */
 int sw_full_cs_setup(int dblen, int qrlen, int a_gap_open, int a_gap_ext, int b_gap_open, int b_gap_ext,
                      int match, int mismatch, int global_xover_penalty, bool reset_stats, int anchor_width, int indel_taboo_len);

@@ -81,6 +81,12 @@ struct GmIndexDev {
                                       // swap -- strand label st stands for strand st ^ cs_flip of the read as sequenced, which is then the read's input strand
   int no_region_counts;               // set per call: the lookup keeps EVERY list entry -- unpaired -n 1, paired -n 2 (use_region_counts off, ref: gmapper.c:2610-2616,2652-2657)
   GmMpDev mp;                         // set per call (paired -n 3)
+  // RNA sequences (uracil and no thymine, ref: fasta.c:528-542).  A contig's own flag decides its reverse complement (A <-> U) and its colour translation (U read as T),
+  // ref: genome.c:1107-1118; the LAST contig's flag is genome_is_rna, which sw_vector / sw_gapless / sw_full_cs get (genome.c:1063-1064; mapping.c:375-388,1318-1327);
+  // a letter-space read's own flag decides its reverse complement (gmapper.c:487).  Null pointers: no contig / no read of this call is RNA.
+  const uint8_t* contig_rna;          // [n_contigs] or null
+  int genome_is_rna;
+  const uint8_t* read_rna;            // set per call: [reads of the sub-batch] or null (letter space only)
   uint64_t total_len;                 // sum of contig lengths (< 2^32)
   int n_contigs;
   const uint32_t* contig_off;         // [n_contigs+1] global offsets (ref: contig_offsets[])
@@ -138,10 +144,15 @@ struct GmFullRes {
   int32_t n_xover;               // colour space: crossovers on the sw_full_cs path (ref: sw-full-cs.c:929-932)
 };
 
+// complement_base as sixteen nibbles (ref: util.h:125-151): entry c = the complement of code c; in an RNA sequence the complement of A is U (code 4), not T
+__host__ __device__ __forceinline__ uint64_t gm_cmpl_tab(bool rna) { return 0xFBCDE56879A00123ull + (rna ? 1ull : 0ull); }
+
+#define GM_SEAM_RNA 0x100             // single-call seams (sw_vector / sw_gapless / sw_full_cs): is_rna rides in bit 8 of the primer-letter word handed to the kernel
+
 // 4-bit code i of strand st of a packed read.  Letter space: strand 1 is the reverse complement (ref: util.c:540-596).
 // Colour space: strand 1 holds the colours in reverse order, rc[i] = read[len - i] for i >= 1 (ref: util.c:600-617); rc[0]
 // involves the primer letter and is never used: k-mers start at colour 1 and the alignment kernels only see strand 0.
-__device__ __forceinline__ uint32_t gm_read_code(const uint32_t* __restrict__ rw, int read_len, int st, int colour, int i) {
+__device__ __forceinline__ uint32_t gm_read_code(const uint32_t* __restrict__ rw, int read_len, int st, int colour, int i, bool rna = false) {
   if (colour) {
     if (st && i == 0) return 15u;
     const int src = st ? (read_len - i) : i;
@@ -149,7 +160,7 @@ __device__ __forceinline__ uint32_t gm_read_code(const uint32_t* __restrict__ rw
   }
   const int src = st ? (read_len - 1 - i) : i;
   uint32_t c = (rw[src >> 3] >> ((src & 7) * 4)) & 0xf;
-  if (st) { const uint64_t cm = 0xFBCDE56879A00123ull; c = (uint32_t)(cm >> (c * 4)) & 0xf; }   // complement_base, ref: util.h:125-151
+  if (st) { const uint64_t cm = gm_cmpl_tab(rna); c = (uint32_t)(cm >> (c * 4)) & 0xf; }   // complement_base, ref: util.h:125-151
   return c;
 }
 

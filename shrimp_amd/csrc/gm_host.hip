@@ -101,6 +101,7 @@ static GmScoreDev make_score(const gm_params_t& P) {
 GmIndexDev GmIndexHost::dev_view() const {
   GmIndexDev d; memset(&d, 0, sizeof d);
   d.genome = d_genome; d.genome_cs = d_genome_cs; d.colour = params.colour_space ? 1 : 0; d.hflag = params.hash_seeds ? 1 : 0; d.total_len = total_len; d.n_contigs = n_contigs; d.contig_off = d_contig_off;
+  d.contig_rna = d_contig_rna; d.genome_is_rna = genome_is_rna; d.read_rna = nullptr;
   d.n_seeds = n_seeds; d.min_seed_span = min_seed_span; d.max_seed_span = max_seed_span;
   d.slab_bits = slab_bits; d.n_slabs = n_slabs; d.region_bits = params.region_bits; d.region_overlap = params.region_overlap;
   d.list_cutoff = list_cutoff;
@@ -187,17 +188,6 @@ extern "C" int gm_index_build(gm_index_t** out, int device, int n_contigs, const
                               int n_seeds, const char* const* seeds, const gm_params_t* params) {
   if (!out || n_contigs < 1 || !contigs || !contig_len) { gm_set_error("gm_index_build: bad arguments"); return GM_E_ARG; }
   if (gm_device_count() <= device) { gm_set_error("no HIP device %d (the seed index lives in HBM; there is no CPU path)", device); return GM_E_NODEVICE; }
-  // RNA contigs (uracil and no thymine, ref: fasta.c:528-542 -> genome_is_rna, genome.c:1063-1064) make the reference translate U as T in lstocs / cstols and complement A
-  // to U (util.h:125-205).  That is not built: such a genome is refused here, loudly, instead of being mapped with DNA rules.  (A contig that has a T ends the scan at once.)
-  for (int c = 0; c < n_contigs; c++) {
-    bool got_u = false, got_t = false;
-    const uint64_t nw = ((uint64_t)contig_len[c] + 7) / 8;
-    for (uint64_t w = 0; w < nw && !got_t; w++) {
-      const uint32_t x = contigs[c][w]; const int nn = (int)std::min<uint64_t>(8, (uint64_t)contig_len[c] - 8 * w);
-      for (int k = 0; k < nn; k++) { const uint32_t b = (x >> (4 * k)) & 0xf; got_t |= b == 3u; got_u |= b == 4u; }
-    }
-    if (got_u && !got_t) { gm_set_error("contig %d holds uracil and no thymine: RNA genomes (the reference's is_rna translation, ref: genome.c:1063-1064, util.h:125-205) are not implemented", c); return GM_E_ARG; }
-  }
   GM_HIP(hipSetDevice(device));
   gm_index* ix = new gm_index();
   ix->device = device;
@@ -220,7 +210,7 @@ extern "C" int gm_index_build(gm_index_t** out, int device, int n_contigs, const
 extern "C" void gm_index_free(gm_index_t* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
-  (void)hipFree(ix->d_genome); (void)hipFree(ix->d_genome_cs); (void)hipFree(ix->d_contig_off);
+  (void)hipFree(ix->d_genome); (void)hipFree(ix->d_genome_cs); (void)hipFree(ix->d_contig_off); (void)hipFree(ix->d_contig_rna);
   for (int i = 0; i < ix->n_seeds; i++) { (void)hipFree(ix->seeds[i].d_dir); (void)hipFree(ix->seeds[i].d_pos); (void)hipFree(ix->seeds[i].d_bkt);
                                            (void)hipFree(ix->seeds[i].d_sdir); (void)hipFree(ix->seeds[i].d_spos); }
   delete ix;
@@ -308,6 +298,7 @@ struct DevSet {
   int p2_grid = 0;                                           // pass-2 grid for this read length: the session's, capped so that the back-pointer scratch stays within 2 GB
   int8_t* d_xover = nullptr; bool xover_on = false;        // colour space with QVs: per-position crossover scores [B][read_len]
   uint8_t* d_qv = nullptr; uint8_t* d_post_bq = nullptr;   // ... and the QVs themselves (clamped to 0..250) for post_sw on the device, which leaves the base qualities in d_post_bq [rcap][read_len]
+  uint8_t* d_read_rna = nullptr;                             // letter space: 1 for a read with uracil and no thymine (re->is_rna, ref: fasta.c:528-542), set per sub-batch by k_read_rna_flags
   uint32_t* d_reads = nullptr; uint8_t* d_initbp = nullptr; uint64_t* d_surv = nullptr; uint32_t* d_surv_cnt = nullptr;   // d_initbp: colour space primer letters
   uint32_t* d_surv_seg = nullptr;                                          // [2B][S + 1] survivors after each slab (K1 emits slab by slab)
   uint64_t* d_surv2 = nullptr; uint32_t* d_surv_cnt2 = nullptr;            // survivors after the exact isolation prune (K1b) = input of K2
@@ -372,12 +363,12 @@ struct gm_session {
 };
 
 static void free_buffers(DevSet& D) {
-  void* ptrs[] = {D.d_xover, D.d_reads, D.d_initbp, D.d_surv, D.d_surv_cnt, D.d_surv_seg, D.d_surv2, D.d_surv_cnt2, D.d_hits, D.d_perm, D.d_hit_cnt, D.d_slots, D.d_heavy_list, D.d_heavy_cnt,
+  void* ptrs[] = {D.d_read_rna, D.d_xover, D.d_reads, D.d_initbp, D.d_surv, D.d_surv_cnt, D.d_surv_seg, D.d_surv2, D.d_surv_cnt2, D.d_hits, D.d_perm, D.d_hit_cnt, D.d_slots, D.d_heavy_list, D.d_heavy_cnt,
                   D.d_sel, D.d_sel_sidx, D.d_sel_cnt, D.d_sel_off, D.d_work, D.d_n_work, D.d_res, D.d_ops, D.d_back,
                   D.d_pmin, D.d_pmax, D.d_saved, D.d_saved_list, D.d_post, D.d_post_fw, D.d_post_info, D.d_qv, D.d_post_bq, D.d_mp_rows, D.d_mp_cnt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   D.d_post = nullptr; D.d_post_fw = nullptr; D.d_post_info = nullptr; D.d_qv = nullptr; D.d_post_bq = nullptr;
-  D.d_xover = nullptr; D.d_reads = nullptr; D.d_initbp = nullptr; D.d_surv = nullptr; D.d_surv_cnt = nullptr; D.d_surv_seg = nullptr; D.d_surv2 = nullptr; D.d_surv_cnt2 = nullptr; D.d_hits = nullptr; D.d_perm = nullptr; D.d_hit_cnt = nullptr; D.d_slots = nullptr;
+  D.d_read_rna = nullptr; D.d_xover = nullptr; D.d_reads = nullptr; D.d_initbp = nullptr; D.d_surv = nullptr; D.d_surv_cnt = nullptr; D.d_surv_seg = nullptr; D.d_surv2 = nullptr; D.d_surv_cnt2 = nullptr; D.d_hits = nullptr; D.d_perm = nullptr; D.d_hit_cnt = nullptr; D.d_slots = nullptr;
   D.d_heavy_list = nullptr; D.d_heavy_cnt = nullptr; D.d_sel = nullptr; D.d_sel_sidx = nullptr; D.d_sel_cnt = nullptr; D.d_sel_off = nullptr;
   D.d_work = nullptr; D.d_n_work = nullptr; D.d_res = nullptr; D.d_ops = nullptr; D.d_back = nullptr;
   D.d_pmin = nullptr; D.d_pmax = nullptr; D.d_saved = nullptr; D.d_saved_list = nullptr;
@@ -442,14 +433,6 @@ template <class F> static void gm_parallel_for(size_t n, size_t grain, F fn) {
   std::atomic<size_t> next(0);
   gm_run_on_threads(nt, [&]() { for (;;) { const size_t c = next.fetch_add(1); if (c >= pieces) break; fn(c * grain, std::min(n, (c + 1) * grain)); } });
 }
-// A letter-space read with uracil and no thymine is an RNA read to the reference (re->is_rna, ref: fasta.c:528-542): its reverse complement then holds U for every A
-// (util.h:125-151), which changes its k-mers and scores.  Not implemented, so the text / file entries refuse such a read instead of mapping it with DNA rules.
-static bool gm_is_rna_text(const char* seq, size_t len) {
-  if (!memchr(seq, 'U', len) && !memchr(seq, 'u', len)) return false;
-  return !memchr(seq, 'T', len) && !memchr(seq, 't', len);
-}
-// n lines of exactly `want` characters with '\n' between them (the last one may or may not end in '\n'): true when the text has that layout, checked on the host threads --
-// the line starts are then i * (want + 1) and nothing has to be searched
 static bool gm_fixed_lines(const char* text, size_t n, size_t want) {
   if (!n) return true;
   const size_t len = strlen(text), stride = want + 1;
@@ -484,6 +467,7 @@ static int alloc_buffers(gm_session* s, DevSet& D, int read_len, bool paired = f
   D.back_stride = (((size_t)read_len * W + 255) / 256) * 256;
   if (s->P.colour_space) { D.ops_stride *= 2; D.back_stride *= 12; }   // backtrace byte + letter codes per column; three words of back pointers per cell
   GM_HIP(hipMalloc(&D.d_reads, (size_t)B * read_words * 4 + 64));
+  if (!s->P.colour_space) GM_HIP(hipMalloc(&D.d_read_rna, (size_t)B + 64));
   if (s->P.colour_space) { GM_HIP(hipMalloc(&D.d_initbp, (size_t)B + 64)); GM_HIP(hipMalloc(&D.d_xover, (size_t)B * read_len + 64)); GM_HIP(hipMalloc(&D.d_qv, (size_t)B * read_len + 64)); }
   GM_HIP(hipMalloc(&D.d_surv, (size_t)rs * D.scap * 8));
   GM_HIP(hipMalloc(&D.d_surv_cnt, (size_t)rs * 4));
@@ -604,6 +588,7 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
   for (auto& d : s->d_pstats) GM_HIP_S(hipMalloc(&d, (size_t)GS_STRIPES * GS_STRIDE * 8));
   GM_HIP_S(hipHostMalloc((void**)&s->h_pin, (16 + 1024) * 4, hipHostMallocDefault));
   memset(s->h_pin, 0, (16 + 1024) * 4);
+  { const int rc = gm_index_derive_rna(const_cast<gm_index*>(ix), s->stream); if (rc) { gm_session_free(s); return rc; } }      // which contigs are RNA (once per index)
   // k_lookup_v5 streams large indexes with the help of per-list strip lists, derived once per index (not stored in the index files)
   if ((ix->n_slabs > 1 || gm_tune("GM_K1_V5")) && !gm_tune("GM_NO_V5") && ix->params.region_bits >= 9 && ix->params.region_bits <= 16) {
     const int rc = gm_index_derive_strips(const_cast<gm_index*>(ix), s->stream);
@@ -1058,7 +1043,7 @@ struct Finalizer {
           p = put_str(p, "\tCS:Z:", 6); p = put_csfasta(p); out.resize(p - out.data()); sam_tail(P, out, nullptr, nullptr, nullptr, nullptr); return 1;
         }
         if (seq_ptr) for (int i = 0; i < read_len; i++) *p++ = seq_from_text(seq_ptr[rd][i]);
-        else for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = (c < 4) ? "ACGT"[c] : 'N'; }
+        else for (int i = 0; i < read_len; i++) { int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; *p++ = "ACGTUMRWSYKVHDBN"[c]; }      // (the reference prints the file's own letters here: a U stays a U)
         if (qual_ptr) { *p++ = '\t'; p = put_str(p, qual_ptr[rd], (size_t)read_len); }      // ref: output.c:419-421 (verbatim)
         else p = put_str(p, "\t*", 2);
         out.resize(p - out.data()); sam_tail(P, out, nullptr, nullptr, nullptr, nullptr);
@@ -1185,6 +1170,9 @@ struct Finalizer {
 // Heavy tier of K2: the few read-strands whose survivors exceed the LDS tier (low-complexity reads,
 // repeats).  Sizes are known now, so every array is allocated exactly, the keys are re-emitted by K1
 // and sorted by one segmented radix sort; then K2 runs on global arrays.  Rare by construction.
+// the view a kernel that reads the reads of set D gets: with that set's RNA flags (letter space; null in colour space)
+static inline GmIndexDev gm_view_of(const GmIndexDev& dv, const DevSet& D) { GmIndexDev v = dv; v.read_rna = D.d_read_rna; return v; }
+
 static int run_heavy_tier(gm_session* s, DevSet& D, const GmIndexDev& dv, int n, int read_len, int read_words, int W, int n_heavy,
                           unsigned long long* d_stats = nullptr, const GmScoreDev* sc = nullptr) {
   if (!sc) sc = &s->sc;
@@ -1215,7 +1203,7 @@ static int run_heavy_tier(gm_session* s, DevSet& D, const GmIndexDev& dv, int n,
   GM_HIP(hipMemcpyAsync(d_e32, e32.data(), (size_t)n_heavy * 4, hipMemcpyHostToDevice, q));
   GM_HIP(hipMemcpyAsync(d_off, off.data(), (size_t)(n_heavy + 1) * 8, hipMemcpyHostToDevice, q));
   GM_HIP(hipMemsetAsync(d_ks, 0xff, tot * 8, q));
-  int rc = gm_launch_lookup_redo(dv, D.d_reads, n, read_len, read_words, n_heavy, d_list, d_off, d_kin, d_stats, q);
+  int rc = gm_launch_lookup_redo(gm_view_of(dv, D), D.d_reads, n, read_len, read_words, n_heavy, d_list, d_off, d_kin, d_stats, q);
   if (rc == GM_OK)
     rc = gm_launch_anchors_heavy(dv, *sc, n, read_len, W, n_heavy, d_list, d_off, d_segn, d_b32, d_e32, tot, d_kin, d_ks, d_aux, d_nxt, d_ord,
                                  D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, d_stats, q);
@@ -1244,7 +1232,7 @@ static int prune_e_max(const gm_session* s, int read_len, int W) {
 static int launch_lookup(gm_session* s, DevSet& D, const GmIndexDev& dv, int n, int read_len, int read_words, int W, unsigned long long* d_stats, int* fused) {
   GmFusePrune f; f.d_surv2 = D.d_surv2; f.d_surv_cnt2 = D.d_surv_cnt2; f.scap2 = D.scap2; f.window_len = W; f.e_max = D.scap2 > 0 ? prune_e_max(s, read_len, W) : -1; f.fused = fused;
   *fused = 0;
-  return gm_launch_lookup(dv, D.d_reads, n, read_len, read_words, D.d_surv, D.d_surv_cnt, D.scap, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, d_stats, s->stream, D.d_surv_seg, &f);
+  return gm_launch_lookup(gm_view_of(dv, D), D.d_reads, n, read_len, read_words, D.d_surv, D.d_surv_cnt, D.scap, D.d_heavy_list, D.d_heavy_cnt, 2 * D.eff_batch, d_stats, s->stream, D.d_surv_seg, &f);
 }
 
 // K1b + K2 on the survivors of K1
@@ -1267,7 +1255,11 @@ static int launch_prune_anchors(gm_session* s, DevSet& D, const GmIndexDev& dv, 
 // memory most of the time and leaves 96 VGPRs per SIMD and 26 KB of LDS free).  Each half uses the buffer set k of its sub-batch only.
 //
 // the index as the kernels see it, with the session's per-call switches: -n 1 keeps every list entry (use_region_counts off, ref: gmapper.c:2610-2616)
-static GmIndexDev session_view(const gm_session* s) { GmIndexDev dv = s->ix->dev_view(); dv.no_region_counts = s->P.match_mode == 1 ? 1 : 0; return dv; }
+static GmIndexDev session_view(const gm_session* s, const DevSet* D = nullptr) {
+  GmIndexDev dv = s->ix->dev_view(); dv.no_region_counts = s->P.match_mode == 1 ? 1 : 0;
+  if (D) dv.read_rna = D->d_read_rna;                        // (letter space: the flags k_read_rna_flags left for this sub-batch's reads)
+  return dv;
+}
 
 // Front, stream A: K1, K1b, K2; nothing here waits on the host (the heavy count lands in pinned memory, event pev[k][6] marks the end).
 static int pipeline_front(gm_session* s, int k, int n, int read_len) {
@@ -1279,6 +1271,7 @@ static int pipeline_front(gm_session* s, int k, int n, int read_len) {
   unsigned long long* d_stats = s->d_pstats[k];
   GM_HIP(hipMemsetAsync(d_stats, 0, (size_t)GS_STRIPES * GS_STRIDE * 8, q));
   GM_HIP(hipEventRecord(s->pev[k][0], q));
+  if (D.d_read_rna) { const int rc0 = gm_launch_read_rna_flags(D.d_reads, n, read_len, read_words, D.d_read_rna, q); if (rc0) return rc0; }      // which reads are RNA (ref: fasta.c:528-542)
   gm_lookup_set_start_flags(s->h_pin + 16, 1024, ++s->flag_epoch);
   int fused = 0;
   int rc = launch_lookup(s, D, dv, n, read_len, read_words, W, d_stats, &fused);
@@ -1324,7 +1317,7 @@ static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len,
       }
     }
     GM_HIP(hipEventRecord(s->pev[k][3], q));
-    rc = gm_launch_pass1(dv, s->sc, D.d_reads, n, read_len, read_words, W, overlap_abs, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, D.d_slots, d_stats, q,
+    rc = gm_launch_pass1(gm_view_of(dv, D), s->sc, D.d_reads, n, read_len, read_words, W, overlap_abs, D.d_hits, D.d_perm, D.d_hit_cnt, D.hcap, D.d_slots, d_stats, q,
                          nullptr, nullptr, D.d_initbp, true);
     if (rc) return rc;
     GM_HIP(hipEventRecord(s->pev[k][4], q));
@@ -1367,7 +1360,7 @@ static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len,
                                   GM_POST_THREADS, q);
       }
     } else
-    rc = gm_launch_pass2(dv, s->sc, D.d_reads, n, read_len, read_words, W, D.d_hits, D.d_perm, D.hcap, D.d_sel, D.d_sel_cnt, D.d_work, D.d_n_work,
+    rc = gm_launch_pass2(gm_view_of(dv, D), s->sc, D.d_reads, n, read_len, read_words, W, D.d_hits, D.d_perm, D.hcap, D.d_sel, D.d_sel_cnt, D.d_work, D.d_n_work,
                          D.d_res, D.d_ops, D.ops_stride, D.d_back, D.back_stride, D.p2_grid, d_stats, q);
     if (rc) return rc;
     GM_HIP(hipEventRecord(s->pev[k][7], q));
@@ -1731,7 +1724,6 @@ extern "C" int gm_map_reads_text(gm_session_t* s, int n_reads, int read_len, con
     gm_parallel_for((size_t)n_reads, 8192, [&](size_t b0, size_t e0) {
       for (size_t i = b0; i < e0 && bad_rc.load(std::memory_order_relaxed) == GM_OK; i++) {
         int b = 0; int rc = gm_sequence_to_bitfield(cs, seqs + i * ((size_t)line + 1), line, packed.data() + i * rwords, &b);
-        if (!rc && !cs && gm_is_rna_text(seqs + i * ((size_t)line + 1), (size_t)line)) { gm_set_error("read %zu holds uracil and no thymine: RNA reads (ref: fasta.c:528-542, util.h:125-151) are not implemented", i); rc = GM_E_ARG; }
         if (rc) { std::lock_guard<std::mutex> lk(em); if (bad_rc == GM_OK) { bad_rc = rc; emsg = gm_last_error(); } return; }
         if (cs) ibp[i] = (uint8_t)b;
       }
@@ -1743,7 +1735,6 @@ extern "C" int gm_map_reads_text(gm_session_t* s, int n_reads, int read_len, con
     const char* e = strchr(p, '\n'); if (!e) e = p + strlen(p);
     if ((int)(e - p) != line) { gm_set_error("read %d: %d characters, expected %d", i, (int)(e - p), line); return GM_E_ARG; }
     int b = 0; const int rc = gm_sequence_to_bitfield(cs, p, line, packed.data() + (size_t)i * rwords, &b); if (rc) return rc;
-    if (!cs && gm_is_rna_text(p, (size_t)line)) { gm_set_error("read %d holds uracil and no thymine: RNA reads (ref: fasta.c:528-542, util.h:125-151) are not implemented", i); return GM_E_ARG; }
     if (cs) ibp[i] = (uint8_t)b;
     p = *e ? e + 1 : e;
   }
@@ -1857,8 +1848,8 @@ extern "C" int gm_sw_vector_batch_bounded(int n, const uint32_t* genome, uint64_
 
 extern "C" int sw_vector(uint32_t* genome, int goff, int glen, uint32_t* read, int rlen, uint32_t* genome_ls, int initbp, bool is_rna) {
   if (!g_sv.init) abort();   // ref: sw-vector.c:462-463
-  // is_rna only matters to the colour-space first-colour row (lstocs(genome_ls[j], initbp, is_rna), ref: sw-vector.c:129,289): not implemented, refused loudly
-  if (is_rna && genome_ls) { gm_set_error("sw_vector: is_rna (U translated as T, ref: sw-vector.c:129) is not implemented"); fprintf(stderr, "gmapper_hip: sw_vector refused: is_rna is not implemented\n"); return GM_E_ARG; }
+  // is_rna only matters to the colour-space first-colour row (lstocs(genome_ls[j], initbp, is_rna), ref: sw-vector.c:129,289): it rides in bit 8 of the primer word
+  if (is_rna && genome_ls) initbp |= GM_SEAM_RNA;
   int64_t go = goff; int score = 0;
   const uint64_t gw = ((uint64_t)goff + glen + 7) / 8;
   if (g_sv.colours) {        // colour space: genome = colours, genome_ls = letters of the same contig (ref: sw-vector.c:476-479)
@@ -1919,7 +1910,7 @@ extern "C" int gm_sw_gapless_batch(int n, const uint32_t* genome, const uint32_t
 }
 extern "C" int sw_gapless(uint32_t* genome, int glen, uint32_t* read, int rlen, int g_idx, int r_idx, uint32_t* genome_ls, int init_bp, bool is_rna) {
   if (!g_sg.init) abort();   // ref: sw-gapless.c:66-67
-  if (is_rna && genome_ls) { gm_set_error("sw_gapless: is_rna (ref: sw-gapless.c:84) is not implemented"); fprintf(stderr, "gmapper_hip: sw_gapless refused: is_rna is not implemented\n"); return GM_E_ARG; }
+  if (is_rna && genome_ls) init_bp |= GM_SEAM_RNA;      // lstocs(letter, init_bp, is_rna), ref: sw-gapless.c:84
   int64_t wo = 0; int score = 0;
   int rc = gm_sw_gapless_batch(1, genome, genome_ls, ((uint64_t)glen + 7) / 8, &wo, &glen, read, (rlen + 7) / 8, &rlen, &g_idx, &r_idx, genome_ls ? &init_bp : nullptr, &score);
   return rc == GM_OK ? score : rc;
@@ -2033,8 +2024,6 @@ extern "C" void sw_full_cs(uint32_t* genome_ls, int goff, int glen, uint32_t* re
                            struct gm_sw_full_results* sfr, bool revcmpl, bool is_rna, struct gm_anchor* anchors, int anchors_cnt,
                            int local_alignment, int* crossover_score) {
   if (!g_sc.init) abort();   // ref: sw-full-cs.c:1155-1156
-  if (is_rna) { gm_set_error("sw_full_cs: is_rna (U translated as T, ref: sw-full-cs.c:1191, util.h:157-205) is not implemented"); fprintf(stderr, "gmapper_hip: sw_full_cs refused: is_rna is not implemented\n");
-                sfr->score = 0; sfr->dbalign = nullptr; sfr->qralign = nullptr; return; }
   SeamTimer tm(&g_sc.secs); g_sc.invocs++; g_sc.cells += 4ull * (uint64_t)std::max(glen, 0) * (uint64_t)std::max(rlen, 0);
   // A refusal must not read as "no alignment" (score 0 is what a window below the threshold returns): the reason goes to stderr as well as to gm_last_error().
   auto fail = [&](const char* why) { gm_set_error("sw_full_cs: %s", why); fprintf(stderr, "gmapper_hip: sw_full_cs refused: %s\n", why); sfr->score = 0; sfr->dbalign = nullptr; sfr->qralign = nullptr; };
@@ -2063,7 +2052,7 @@ extern "C" void sw_full_cs(uint32_t* genome_ls, int goff, int glen, uint32_t* re
          hipMemset(dr, 0, (size_t)rwords * 4) == hipSuccess && hipMemcpy(dr, read, (size_t)(rwords - 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
          (!dx || hipMemcpy(dx, xrow.data(), xrow.size(), hipMemcpyHostToDevice) == hipSuccess) &&
          hipMemset(dback, 0, back_bytes) == hipSuccess &&                                     // out-of-band cells: back == 0 (ref: init_cell)
-         gm_launch_sw_full_cs_single(g_sc.p, dg, goff, glen, dr, rlen, initbp, threshscore, anchors[0].x, anchors[0].y, anchors[0].length, anchors[0].width,
+         gm_launch_sw_full_cs_single(g_sc.p, dg, goff, glen, dr, rlen, initbp | (is_rna ? GM_SEAM_RNA : 0), threshscore, anchors[0].x, anchors[0].y, anchors[0].length, anchors[0].width,
                                      revcmpl ? 1 : 0, dback, dout, dops, ops_cap, 0, local_alignment ? 1 : 0, dx) == GM_OK &&
          hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, dout, 12 * 4, hipMemcpyDeviceToHost) == hipSuccess &&
          hipMemcpy(ops.data(), dops, ops_cap, hipMemcpyDeviceToHost) == hipSuccess;
@@ -2082,7 +2071,11 @@ extern "C" void sw_full_cs(uint32_t* genome_ls, int goff, int glen, uint32_t* re
     for (int j = 0; j < rlen; j++) {
       const int base = nib(read, j);
       if (base == 15) { qr[k][j] = 15; letter = (k + initbp) % 4; }
-      else { const int l2 = (letter % 2 == 0) ? ((4 + letter + base) % 4) : ((4 + letter - base) % 4); qr[k][j] = (uint8_t)((letter == 15 || base > 3) ? 15 : l2); letter = qr[k][j]; }
+      else {                                                   // cstols(letter, base, is_rna), ref: util.h:157-180
+        const int lt = (is_rna && letter == 4) ? 3 : letter;
+        int l2 = (lt % 2 == 0) ? ((4 + lt + base) % 4) : ((4 + lt - base) % 4); if (is_rna && l2 == 3) l2 = 4;
+        qr[k][j] = (uint8_t)((letter == 15 || base > 3) ? 15 : l2); letter = qr[k][j];
+      }
     }
   }
   std::string db, q;

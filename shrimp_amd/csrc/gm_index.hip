@@ -8,6 +8,7 @@
 #include <algorithm>
 #include "gm_common.h"
 #include "gm_internal.h"
+#include <mutex>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 
@@ -135,10 +136,57 @@ int gm_index_from_lists_device(GmIndexHost* ix, int sn, const uint32_t* lens, co
   return GM_OK;
 }
 
+// Which contigs are RNA: uracil and no thymine (ref: common/fasta.c:528-542).  flags[c] collects bit 0 = a U, bit 1 = a T among contig c's letters.
+__global__ void __launch_bounds__(256) k_contig_letters(const uint32_t* __restrict__ genome, uint64_t total_len, const uint32_t* __restrict__ contig_off, int n_contigs,
+                                                        uint32_t* __restrict__ flags, uint64_t n_words) {
+  uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; w < n_words; w += stride) {
+    const uint64_t p0 = w * 8;
+    if (p0 >= total_len) break;
+    const uint32_t x = genome[w];
+    int lo = 0, hi = n_contigs;
+    while (hi - lo > 1) { int m = (lo + hi) >> 1; if (contig_off[m] <= p0) lo = m; else hi = m; }
+    uint32_t f = 0;
+    for (int n = 0; n < 8; n++) {
+      const uint64_t p = p0 + n;
+      if (p >= total_len) break;
+      if (lo + 1 < n_contigs && p >= contig_off[lo + 1]) { if (f) atomicOr(&flags[lo], f); f = 0; while (lo + 1 < n_contigs && p >= contig_off[lo + 1]) lo++; }
+      const uint32_t b = (x >> (4 * n)) & 0xf;
+      f |= (b == 4u ? 1u : 0u) | (b == 3u ? 2u : 0u);
+    }
+    if (f) atomicOr(&flags[lo], f);
+  }
+}
+static std::mutex g_rna_mutex;
+int gm_index_derive_rna(GmIndexHost* ix, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_rna_mutex);
+  if (ix->rna_ready) return GM_OK;
+  uint32_t* d_f = nullptr;
+  GM_HIP(hipMalloc(&d_f, (size_t)ix->n_contigs * 4));
+  GM_HIP(hipMemsetAsync(d_f, 0, (size_t)ix->n_contigs * 4, stream));
+  hipLaunchKernelGGL(k_contig_letters, dim3(256 * 16), dim3(256), 0, stream, ix->d_genome, ix->total_len, ix->d_contig_off, ix->n_contigs, d_f, ix->genome_words);
+  GM_HIP(hipGetLastError());
+  std::vector<uint32_t> f(ix->n_contigs);
+  GM_HIP(hipMemcpyAsync(f.data(), d_f, (size_t)ix->n_contigs * 4, hipMemcpyDeviceToHost, stream));
+  GM_HIP(hipStreamSynchronize(stream));
+  (void)hipFree(d_f);
+  ix->contig_rna.assign(ix->n_contigs, 0);
+  bool any = false;
+  for (int c = 0; c < ix->n_contigs; c++) { ix->contig_rna[c] = (f[c] & 3u) == 1u ? 1 : 0; any |= ix->contig_rna[c] != 0; }
+  ix->genome_is_rna = ix->n_contigs ? ix->contig_rna[ix->n_contigs - 1] : 0;
+  if (any) {
+    GM_HIP(hipMalloc(&ix->d_contig_rna, (size_t)ix->n_contigs));
+    GM_HIP(hipMemcpy(ix->d_contig_rna, ix->contig_rna.data(), (size_t)ix->n_contigs, hipMemcpyHostToDevice));
+  }
+  ix->rna_ready = true;
+  return GM_OK;
+}
+
 // colour-space translation of the resident genome (ref: common/fasta.c:586-606, genome.c:1108-1136): colour p =
-// lstocs(letter p-1, letter p) with a 'T' before the first letter of every contig; anything but A/C/G/T gives 15.
+// lstocs(letter p-1, letter p) with a 'T' before the first letter of every contig; anything but A/C/G/T gives 15 -- in an RNA contig (contig_rna, or null) a U reads as T.
 __global__ void __launch_bounds__(256) k_colour_genome(const uint32_t* __restrict__ genome, uint64_t total_len, const uint32_t* __restrict__ contig_off,
-                                                       int n_contigs, uint32_t* __restrict__ genome_cs, uint64_t n_words) {
+                                                       int n_contigs, const uint8_t* __restrict__ contig_rna, uint32_t* __restrict__ genome_cs, uint64_t n_words) {
   uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (; w < n_words; w += stride) {
@@ -148,15 +196,17 @@ __global__ void __launch_bounds__(256) k_colour_genome(const uint32_t* __restric
       if (p >= total_len) break;
       int lo = 0, hi = n_contigs;
       while (hi - lo > 1) { int m = (lo + hi) >> 1; if (contig_off[m] <= p) lo = m; else hi = m; }
-      const uint32_t a = (p == contig_off[lo]) ? 3u : gm_nib(genome, p - 1), b = gm_nib(genome, p);
+      uint32_t a = (p == contig_off[lo]) ? 3u : gm_nib(genome, p - 1), b = gm_nib(genome, p);
+      if (contig_rna && contig_rna[lo]) { a = a == 4u ? 3u : a; b = b == 4u ? 3u : b; }
       out |= ((a > 3u || b > 3u) ? 15u : (a ^ b)) << (4 * n);
     }
     genome_cs[w] = out;
   }
 }
 int gm_index_colour_genome_device(GmIndexHost* ix, hipStream_t stream) {
+  { const int rc = gm_index_derive_rna(ix, stream); if (rc) return rc; }
   if (!ix->d_genome_cs) GM_HIP(hipMalloc(&ix->d_genome_cs, ix->genome_words * 4));
-  hipLaunchKernelGGL(k_colour_genome, dim3(256 * 16), dim3(256), 0, stream, ix->d_genome, ix->total_len, ix->d_contig_off, ix->n_contigs,
+  hipLaunchKernelGGL(k_colour_genome, dim3(256 * 16), dim3(256), 0, stream, ix->d_genome, ix->total_len, ix->d_contig_off, ix->n_contigs, ix->d_contig_rna,
                      ix->d_genome_cs, ix->genome_words);
   GM_HIP(hipGetLastError());
   GM_HIP(hipStreamSynchronize(stream));

@@ -20,6 +20,9 @@ struct GmIndexHost {
   uint32_t* d_genome = nullptr; uint64_t genome_words = 0;
   uint32_t* d_genome_cs = nullptr;      // colour space: colour translation of d_genome (same coordinates)
   uint32_t* d_contig_off = nullptr;
+  // RNA contigs (uracil and no thymine, ref: fasta.c:528-542), derived on the device from the resident genome (gm_index_derive_rna: after a build, a load or a
+  // broadcast alike): each contig's own flag, and the LAST contig's as genome_is_rna (genome.c:1063-1064)
+  bool rna_ready = false; std::vector<uint8_t> contig_rna; uint8_t* d_contig_rna = nullptr; int genome_is_rna = 0;
   int n_seeds = 0, min_seed_span = 64, max_seed_span = 0;
   GmSeedHost seeds[GM_MAX_SEEDS];
   int slab_bits = 29, n_slabs = 1;
@@ -73,6 +76,7 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
                      uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
                      unsigned long long* d_stats, hipStream_t stream, uint32_t* d_surv_seg = nullptr,   // d_surv_seg[rs][S + 1]: survivors after each slab
                      const GmFusePrune* fuse = nullptr);
+int gm_index_derive_rna(GmIndexHost* ix, hipStream_t stream);        // per-contig RNA flags (gm_index.hip); idempotent
 int gm_index_derive_strips(GmIndexHost* ix, hipStream_t stream);     // strip lists for k_lookup_v5 (gm_lookup5.hip); idempotent
 void gm_lookup5_set_start_flags(uint32_t* flags, int cap, uint32_t epoch);
 int gm_lookup5_start_flag_grid(void);
@@ -143,7 +147,8 @@ int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs
                        const int32_t* d_sel_sidx = nullptr);                                               // paired mode: sort index of every selected window
 
 // paired mode (gm_pair.hip): mate ranges per window, pair top-K, saved marks, mate reversal
-int gm_launch_revcomp_reads(uint32_t* d_reads, int n_reads, int read_len, int read_words, hipStream_t stream);
+int gm_launch_revcomp_reads(uint32_t* d_reads, int n_reads, int read_len, int read_words, hipStream_t stream, const uint8_t* d_read_rna = nullptr);
+int gm_launch_read_rna_flags(const uint32_t* d_reads, int n_reads, int read_len, int read_words, uint8_t* d_flags, hipStream_t stream);   // re->is_rna per packed letter-space read
 struct MpDelta { int amin[2], amax[2], bmin[2], bmax[2]; };   // region deltas of mate 1 / mate 2 per strand (ref: mapping.c:2422-2430)
 MpDelta gm_mp_region_deltas(int region_bits, const int* dmin1, const int* dmax1, const int* dmin2, const int* dmax2);
 int gm_launch_mp_filter(int n_pairs, int region_bits, int region_overlap, uint64_t* d_surv1, uint32_t* d_cnt1, int scap1, uint64_t* d_surv2, uint32_t* d_cnt2, int scap2,

@@ -90,7 +90,7 @@ k_lookup_body(const int item, GmIndexDev ix, const uint32_t* __restrict__ reads,
   // ---- 0. read codes of this strand (strand 1 = reverse complement, ref: util.c:540-596) ----
   const uint32_t* rw = reads + (size_t)rd * read_words;
   for (int i = tid; i < read_len; i += nthr) {
-    codes[i] = (uint8_t)gm_read_code(rw, read_len, st ^ ix.cs_flip, ix.colour, i);   // strand 1 = reverse complement (ref: util.c:540-617)
+    codes[i] = (uint8_t)gm_read_code(rw, read_len, st ^ ix.cs_flip, ix.colour, i, ix.read_rna && ix.read_rna[rd]);   // strand 1 = reverse complement (ref: util.c:540-617)
   }
   if (tid == 0) sh.n_surv = 0;
   if (MP == 1 && tid == 0) sh_mp_n = 0;
@@ -434,7 +434,7 @@ k_lookup_bkt(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int
   const uint32_t scap = (uint32_t)scap_all;
   const uint32_t* rw = reads + (size_t)rd * read_words;
   for (int i = tid; i < read_len; i += blockDim.x) {
-    codes[i] = (uint8_t)gm_read_code(rw, read_len, st ^ ix.cs_flip, ix.colour, i);
+    codes[i] = (uint8_t)gm_read_code(rw, read_len, st ^ ix.cs_flip, ix.colour, i, ix.read_rna && ix.read_rna[rd]);
   }
   { uint4* bm4 = (uint4*)bm; for (int w = tid; w < (bm_words >> 2); w += blockDim.x) bm4[w] = make_uint4(0, 0, 0, 0); }
   if (tid == 0) n_surv = 0;
@@ -562,7 +562,7 @@ k_lookup_v3(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
 
   const uint32_t* rw = reads + (size_t)rd * read_words;
   for (int i = tid; i < read_len; i += nthr) {
-    codes[i] = (uint8_t)gm_read_code(rw, read_len, st ^ ix.cs_flip, ix.colour, i);
+    codes[i] = (uint8_t)gm_read_code(rw, read_len, st ^ ix.cs_flip, ix.colour, i, ix.read_rna && ix.read_rna[rd]);
   }
   if (tid == 0) { n_surv = 0; n_lists = 0; any_long = 0; }
   __syncthreads();
@@ -839,7 +839,7 @@ k_lookup_v4(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int 
     const uint32_t scap = (uint32_t)scap_all;
     __syncthreads();                                         // the previous read-strand is done with the LDS
     const uint32_t* rw = reads + (size_t)rd * read_words;
-    for (int i = tid; i < read_len; i += nthr) codes[i] = (uint8_t)gm_read_code(rw, read_len, st ^ ix.cs_flip, ix.colour, i);
+    for (int i = tid; i < read_len; i += nthr) codes[i] = (uint8_t)gm_read_code(rw, read_len, st ^ ix.cs_flip, ix.colour, i, ix.read_rna && ix.read_rna[rd]);
     // pass C un-marks every word it touched, so after a read-strand that went through it the table is already clear
     if (!tab_clean) { uint4* t4 = (uint4*)tab; for (int w = tid; w < (tab_words >> 2); w += nthr) t4[w] = make_uint4(0, 0, 0, 0); }
     tab_clean = false;

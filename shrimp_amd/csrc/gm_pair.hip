@@ -8,11 +8,11 @@
 
 // In-place reverse complement of every packed read: the stored orientation of a read_reverse'd mate is
 // read[0] = revcomp(input) (ref: gmapper.c:174-185 swaps read[0]/read[1] and flips input_strand).
-__global__ void __launch_bounds__(256) k_revcomp_reads(uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words) {
+__global__ void __launch_bounds__(256) k_revcomp_reads(uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, const uint8_t* __restrict__ read_rna) {
   const int rd = blockIdx.x * blockDim.x + threadIdx.x;
   if (rd >= n_reads) return;
   uint32_t* rw = reads + (size_t)rd * read_words;
-  const uint64_t cm = 0xFBCDE56879A00123ull;   // complement_base as nibbles (ref: util.h:125-151)
+  const uint64_t cm = gm_cmpl_tab(read_rna && read_rna[rd]);   // complement_base as nibbles (ref: util.h:125-151); an RNA read's complement of A is U
   auto get = [&](int i) { return (rw[i >> 3] >> ((i & 7) * 4)) & 0xfu; };
   auto put = [&](int i, uint32_t c) { const int sh = (i & 7) * 4; rw[i >> 3] = (rw[i >> 3] & ~(0xfu << sh)) | (c << sh); };
   for (int i = 0, j = read_len - 1; i <= j; i++, j--) {
@@ -149,9 +149,31 @@ __global__ void __launch_bounds__(256) k_mark_saved(uint8_t* __restrict__ saved,
   if (i < n) saved[list[i]] = 1;
 }
 
-int gm_launch_revcomp_reads(uint32_t* d_reads, int n_reads, int read_len, int read_words, hipStream_t stream) {
+// re->is_rna of every packed letter-space read: uracil and no thymine among its letters (ref: common/fasta.c:528-542).  Taken from the reads as they were handed in --
+// before a read_reverse'd mate is turned (its complement of U is A).
+__global__ void __launch_bounds__(256) k_read_rna_flags(const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, uint8_t* __restrict__ flags) {
+  const int rd = blockIdx.x * blockDim.x + threadIdx.x;
+  if (rd >= n_reads) return;
+  const uint32_t* rw = reads + (size_t)rd * read_words;
+  bool u = false, t = false;
+  for (int w = 0; w < read_words; w++) {
+    const uint32_t x = rw[w]; const int nn = min(8, read_len - 8 * w);
+    uint32_t valid = nn >= 8 ? 0x88888888u : ((0x88888888u >> (4 * (8 - nn))));      // the top bit of every nibble that holds a letter
+    const uint32_t xu = x ^ 0x44444444u, xt = x ^ 0x33333333u;                          // a zero nibble = a U / a T
+    u |= (((xu - 0x11111111u) & ~xu) & valid) != 0u;
+    t |= (((xt - 0x11111111u) & ~xt) & valid) != 0u;
+  }
+  flags[rd] = (u && !t) ? 1 : 0;
+}
+int gm_launch_read_rna_flags(const uint32_t* d_reads, int n_reads, int read_len, int read_words, uint8_t* d_flags, hipStream_t stream) {
+  if (n_reads <= 0) return GM_OK;
+  hipLaunchKernelGGL(k_read_rna_flags, dim3((n_reads + 255) / 256), dim3(256), 0, stream, d_reads, n_reads, read_len, read_words, d_flags);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+int gm_launch_revcomp_reads(uint32_t* d_reads, int n_reads, int read_len, int read_words, hipStream_t stream, const uint8_t* d_read_rna) {
   if (n_reads == 0) return GM_OK;
-  hipLaunchKernelGGL(k_revcomp_reads, dim3((n_reads + 255) / 256), dim3(256), 0, stream, d_reads, n_reads, read_len, read_words);
+  hipLaunchKernelGGL(k_revcomp_reads, dim3((n_reads + 255) / 256), dim3(256), 0, stream, d_reads, n_reads, read_len, read_words, d_read_rna);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

@@ -65,7 +65,9 @@ k_post_sw_cs(GmCsPostDev K, const uint32_t* __restrict__ reads, const uint8_t* _
           const int cc = j < read_len ? colour(j) : 15; int col, which;
           if ((len == 0 && start_run == 15) || cc == 15) { col = 0; which = 1; } else { col = cc ^ (len == 0 ? start_run : 0); which = 0; }
           uint32_t word = (uint32_t)(let + 2) | ((uint32_t)col << 3) | ((uint32_t)which << 5);
-          const int bc = codes[t] & 15; word |= (uint32_t)(bc < 4 ? bc : 7) << 12;
+          int bc = codes[t] & 15;
+          if (bc == 15 && !ins) bc = d;                             // an unknown read letter is shown as the genome's (ref: sw-full-cs.c pretty_print), and THAT is what post_sw reads as the base call
+          word |= (uint32_t)(bc < 4 ? bc : 7) << 12;
           if (qvr && which == 0 && j < read_len) {                   // ref: sw-post.c:486-491 (the first column takes the smallest QV of the skipped colours and its own)
             const int q = len == 0 ? min(min_qv, (int)qvr[j]) : (int)qvr[j];
             word |= ((uint32_t)q << 16) | (1u << 24);

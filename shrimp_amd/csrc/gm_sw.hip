@@ -202,10 +202,10 @@ __device__ int sw_vector_wave(const uint8_t* db, int glen, const uint8_t* qr, in
 }
 
 // unpack `len` codes starting at global position g0 into dst (forward) or reverse-complemented
-__device__ void load_window(const uint32_t* __restrict__ genome, uint64_t g0, int len, bool rc, uint8_t* dst, int lane) {
+__device__ void load_window(const uint32_t* __restrict__ genome, uint64_t g0, int len, bool rc, uint8_t* dst, int lane, bool rna = false) {      // rna: the CONTIG's flag
   const uint64_t w0 = g0 >> 3; const int sh = (int)(g0 & 7);
   const int nwords = (sh + len + 7) >> 3;
-  const uint64_t cm = 0xFBCDE56879A00123ull;   // complement_base as nibbles (ref: util.h:125-151)
+  const uint64_t cm = gm_cmpl_tab(rna);   // complement_base as nibbles (ref: util.h:125-151)
   for (int k = lane; k < nwords; k += GM_WAVE) {
     const uint32_t w = genome[w0 + k];
 #pragma unroll
@@ -220,8 +220,8 @@ __device__ void load_window(const uint32_t* __restrict__ genome, uint64_t g0, in
   }
 }
 
-__device__ void load_read(const uint32_t* __restrict__ rw, int read_len, bool rc, uint8_t* dst, int lane) {
-  const uint64_t cm = 0xFBCDE56879A00123ull;
+__device__ void load_read(const uint32_t* __restrict__ rw, int read_len, bool rc, uint8_t* dst, int lane, bool rna = false) {      // rna: the READ's flag
+  const uint64_t cm = gm_cmpl_tab(rna);
   for (int i = lane; i < read_len; i += GM_WAVE) {
     const int src = rc ? (read_len - 1 - i) : i;
     uint32_t c = (rw[src >> 3] >> ((src & 7) * 4)) & 0xf;
@@ -285,12 +285,15 @@ __device__ uint32_t window_hash_slot(const uint8_t* db, int glen, int lane) {
 }
 
 // ---- colour space helpers -------------------------------------------------------------------------
-__device__ __forceinline__ int cs_lstocs(int a, int b) {           // ref: common/util.h:182-205 (is_rna = false)
+__device__ __forceinline__ int cs_lstocs(int a, int b, bool rna = false) {           // ref: common/util.h:182-205; with is_rna a U counts as T
+  if (rna) { a = a == 4 ? 3 : a; b = b == 4 ? 3 : b; }
   return (a > 3 || b > 3) ? 15 : (a ^ b);             // colourmat[a][b] == a ^ b
 }
-__device__ __forceinline__ int cs_cstols(int first_letter, int colour) {   // ref: common/util.h:157-180
+__device__ __forceinline__ int cs_cstols(int first_letter, int colour, bool rna = false) {   // ref: common/util.h:157-180; with is_rna a U goes in as T and a T comes out as U
   if (first_letter == 15 || colour < 0 || colour > 3) return 15;
-  return (first_letter % 2 == 0) ? ((4 + first_letter + colour) % 4) : ((4 + first_letter - colour) % 4);
+  if (rna && first_letter == 4) first_letter = 3;
+  const int ret = (first_letter % 2 == 0) ? ((4 + first_letter + colour) % 4) : ((4 + first_letter - colour) % 4);
+  return (rna && ret == 3) ? 4 : ret;
 }
 
 // The window a colour-space hit is scored on (ref: mapping.c:1297-1319): db = colours, db0[c] = lstocs(letter c, primer) for the
@@ -299,7 +302,8 @@ __device__ __forceinline__ int cs_cstols(int first_letter, int colour) {   // re
 // (complementing both letters keeps their colour), with 'T' + complement(last letter) at its very first position.
 __device__ void load_window_cs(const GmIndexDev& ix, int cn, uint32_t goff, int w_len, bool rc, int initbp, uint8_t* db, uint8_t* db0, int lane) {
   const uint64_t cbase = ix.contig_off[cn]; const uint64_t clen = (uint64_t)ix.contig_off[cn + 1] - cbase;
-  const uint64_t cm = 0xFBCDE56879A00123ull;   // complement_base as nibbles (ref: util.h:125-151)
+  const bool crna = ix.contig_rna && ix.contig_rna[cn], grna = ix.genome_is_rna != 0;      // the contig's own flag (its reverse complement and colours), the genome's (the SW call)
+  const uint64_t cm = gm_cmpl_tab(crna);   // complement_base as nibbles (ref: util.h:125-151)
   for (int c = lane; c < w_len; c += GM_WAVE) {
     uint32_t col, let;
     if (!rc) {
@@ -309,16 +313,16 @@ __device__ void load_window_cs(const GmIndexDev& ix, int cn, uint32_t goff, int 
       const uint64_t q = (uint64_t)goff + (uint64_t)w_len - (uint64_t)c;      // forward colour index; letter index q - 1
       const uint64_t pl = cbase + q - 1;
       let = (ix.genome[pl >> 3] >> ((pl & 7) * 4)) & 0xf; let = (uint32_t)(cm >> (let * 4)) & 0xf;
-      if (q == clen) col = (uint32_t)cs_lstocs(3, (int)let);
+      if (q == clen) col = (uint32_t)cs_lstocs(3, (int)let, crna);
       else {
         // the colour between the complements of forward letters q and q - 1.  For A / C / G / T that is the forward colour q; a 'U' in the contig complements to 'A'
         // (util.h:125-151), a regular letter, so its colours on the reverse-complement contig are real ones where the forward translation has 15 (fasta.c:586-606)
         const uint64_t pn = cbase + q;
         const uint32_t nxt = (uint32_t)(cm >> (((ix.genome[pn >> 3] >> ((pn & 7) * 4)) & 0xf) * 4)) & 0xf;
-        col = (uint32_t)cs_lstocs((int)nxt, (int)let);
+        col = (uint32_t)cs_lstocs((int)nxt, (int)let, crna);
       }
     }
-    db[c] = (uint8_t)col; db0[c] = (uint8_t)cs_lstocs((int)let, initbp);
+    db[c] = (uint8_t)col; db0[c] = (uint8_t)cs_lstocs((int)let, initbp, grna);
   }
 }
 
@@ -333,19 +337,20 @@ __device__ __forceinline__ int thr_of(double frac, int absval, int base) { retur
 // letters of the reverse-complement contig come from the forward arrays (see load_window_cs).  sc.mismatch is match + crossover here (gmapper.c:2935).
 __device__ int sw_gapless_cs_wave(const GmIndexDev& ix, int cn, bool rc, const uint8_t* qr, int rlen, long long g_idx, int r_idx, int initbp, const GmScoreDev& sc, int lane) {
   const uint64_t cbase = ix.contig_off[cn]; const long long clen = (long long)ix.contig_off[cn + 1] - (long long)cbase;
-  const uint64_t cm = 0xFBCDE56879A00123ull;   // complement_base as nibbles (ref: util.h:125-151)
+  const bool crna = ix.contig_rna && ix.contig_rna[cn], grna = ix.genome_is_rna != 0;
+  const uint64_t cm = gm_cmpl_tab(crna);   // complement_base as nibbles (ref: util.h:125-151)
   auto nib = [&](const uint32_t* a, uint64_t p) -> int { return (int)((a[p >> 3] >> ((p & 7) * 4)) & 0xf); };
   auto letter_at = [&](long long g) -> int { return rc ? (int)((cm >> (nib(ix.genome, cbase + (uint64_t)(clen - 1 - g)) * 4)) & 0xf) : nib(ix.genome, cbase + (uint64_t)g); };
   auto colour_at = [&](long long g) -> int {
     if (!rc) return nib(ix.genome_cs, cbase + (uint64_t)g);
-    if (g == 0) return cs_lstocs(3, letter_at(0));
-    return cs_lstocs(letter_at(g - 1), letter_at(g));          // from the complemented letters themselves (a 'U' complements to 'A': see load_window_cs)
+    if (g == 0) return cs_lstocs(3, letter_at(0), crna);
+    return cs_lstocs(letter_at(g - 1), letter_at(g), crna);          // from the complemented letters themselves (a 'U' complements to 'A': see load_window_cs)
   };
   long long g_left; int r_left;
   if (g_idx < r_idx) { g_left = 0; r_left = (int)(r_idx - g_idx); } else { g_left = g_idx - r_idx; r_left = 0; }
   int head = 0;
   if (r_left == 0) {                                   // forcefully match the first colour of the read (:84-94)
-    if (g_left < clen) head = (cs_lstocs(letter_at(g_left), initbp) == (int)qr[0]) ? sc.match : 0;
+    if (g_left < clen) head = (cs_lstocs(letter_at(g_left), initbp, grna) == (int)qr[0]) ? sc.match : 0;
     g_left++; r_left = 1;
   }
   const long long room = clen - g_left;
@@ -386,7 +391,7 @@ k_pass1(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
   uint8_t* db0 = db + ((max_w + 15) & ~15);           // colour space: first-colour row (max_w)
   int16_t* carry = (int16_t*)(db0 + (CS ? ((max_w + 15) & ~15) : 0));
   // colour space scores every window against the read as it was sequenced (strand 0): the hit is reversed instead (ref: mapping.c:1302-1303)
-  load_read(reads + (size_t)rd * read_words, read_len, CS ? false : (st != 0), qr, lane);
+  load_read(reads + (size_t)rd * read_words, read_len, CS ? false : (st != 0), qr, lane, !CS && ix.read_rna && ix.read_rna[rd]);
   const int ib = CS ? (int)initbp[rd] : 0;
   __syncthreads();
   GmHit* H = hits + (size_t)rs * hcap;
@@ -718,7 +723,7 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
     int st = id >> 16; const int hi = id & 0xFFFF;
     const GmHit h = hits[((size_t)rd * 2 + st) * hcap + hi];
     // the read in its input orientation == read[input_strand]; a read_reverse'd mate (ref: gmapper.c:174-185) is stored reverse-complemented
-    if (rd != cur_rd) { __syncthreads(); load_read(reads + (size_t)rd * read_words, read_len, input_strand != 0, qr, lane); cur_rd = rd; }
+    if (rd != cur_rd) { __syncthreads(); load_read(reads + (size_t)rd * read_words, read_len, input_strand != 0, qr, lane, ix.read_rna && ix.read_rna[rd]); cur_rd = rd; }
     const int cn = h.cn, w_len = h.w_len;
     const long long clen = (long long)ix.contig_off[cn + 1] - ix.contig_off[cn];
     long long g_off = h.g_off; long long ax = h.ax, ay = h.ay; int gen_st = 0;
@@ -732,7 +737,7 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
     // the window on the gen_st strand == the + strand window of the original hit, reverse-complemented
     const uint64_t g0 = (uint64_t)ix.contig_off[cn] + h.g_off;
     __syncthreads();
-    load_window(ix.genome, g0, w_len, gen_st != 0, db, lane);
+    load_window(ix.genome, g0, w_len, gen_st != 0, db, lane, ix.contig_rna && ix.contig_rna[cn]);
     __syncthreads();
     const int score_max = (read_len < w_len ? read_len : w_len) * sc.match;
     const int thresh = thr_of(sc.full_thr_frac, sc.full_abs, score_max);
@@ -969,13 +974,14 @@ k_pass2_g4(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int
       gen_st = 1; st = input_strand;
     }
     const uint64_t g0 = (uint64_t)ix.contig_off[cn] + h.g_off;
+    const int rna_bits = ((ix.contig_rna && has && ix.contig_rna[cn]) ? 2 : 0) | ((ix.read_rna && has && ix.read_rna[rd]) ? 4 : 0);
     __syncthreads();
     for (int gg = 0; gg < 4; gg++) {                             // the whole wave unpacks each group's read and window (wave-uniform arguments from the group's first lane)
       if (!__shfl((int)has, gg * 16)) continue;
-      const int rd_g = __shfl(rd, gg * 16), wl_g = __shfl(w_len, gg * 16), gs_g = __shfl(gen_st, gg * 16);
+      const int rd_g = __shfl(rd, gg * 16), wl_g = __shfl(w_len, gg * 16), gs_g = __builtin_amdgcn_readfirstlane(__shfl(gen_st | rna_bits, gg * 16));      // (bit 1: the contig is RNA, bit 2: the read is; wave-uniform)
       const uint64_t g0_g = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(g0 >> 32), gg * 16) << 32) | (uint32_t)__shfl((int)(uint32_t)g0, gg * 16);
-      load_read(reads + (size_t)rd_g * read_words, read_len, input_strand != 0, qr_all + gg * rl16, lane);
-      load_window(ix.genome, g0_g, wl_g, gs_g != 0, db_all + gg * mw16, lane);
+      load_read(reads + (size_t)rd_g * read_words, read_len, input_strand != 0, qr_all + gg * rl16, lane, (gs_g & 4) != 0);
+      load_window(ix.genome, g0_g, wl_g, (gs_g & 1) != 0, db_all + gg * mw16, lane, (gs_g & 2) != 0);
     }
     __syncthreads();
     const int score_max = (read_len < w_len ? read_len : w_len) * sc.match;
@@ -1304,7 +1310,7 @@ k_sw_vector_batch_cs(GmScoreDev sc, int n, const uint32_t* __restrict__ genome_c
     load_window(genome_cs, (uint64_t)goff[i], glen[i], false, db, lane);
     load_window(genome_ls, (uint64_t)goff[i], glen[i], false, db0, lane);
     __syncthreads();
-    for (int c = lane; c < glen[i]; c += GM_WAVE) db0[c] = (uint8_t)cs_lstocs(db0[c], initbp[i]);     // first-colour row, ref: sw-vector.c:131
+    for (int c = lane; c < glen[i]; c += GM_WAVE) db0[c] = (uint8_t)cs_lstocs(db0[c], initbp[i] & 0xff, (initbp[i] & GM_SEAM_RNA) != 0);     // first-colour row, ref: sw-vector.c:131 (is_rna rides in bit 8 of the primer word)
     __syncthreads();
     const int s = sw_vector_wave_t<true>(db, db0, glen[i], qr, rlen[i], sc, carry, lane);
     if (lane == 0) scores[i] = s;
@@ -1494,12 +1500,13 @@ k_sw_full_cs_single(GmCsDev P, const uint32_t* __restrict__ genome_ls, long long
   load_read(read, rlen, false, rc, lane);
   load_window(genome_ls, (uint64_t)goff, glen, false, db, lane);
   __syncthreads();
+  const bool is_rna = (initbp & GM_SEAM_RNA) != 0; initbp &= 0xff;      // (is_rna rides in bit 8 of the primer word)
   if (lane < 4) {                                     // ref :1182-1197
     int letter = (lane + initbp) % 4;
     for (int j = 0; j < rlen; j++) {
       const int base = rc[j];
       if (base == 15) { qr4[lane * qstride + j] = 15; letter = (lane + initbp) % 4; }
-      else { const int l2 = cs_cstols(letter, base); qr4[lane * qstride + j] = (uint8_t)l2; letter = l2; }
+      else { const int l2 = cs_cstols(letter, base, is_rna); qr4[lane * qstride + j] = (uint8_t)l2; letter = l2; }
     }
   }
   __syncthreads();
@@ -1605,7 +1612,7 @@ k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__
         for (int j = 0; j < read_len; j++) {
           const int base = rc[j];
           if (base == 15) { qr4[lane * qstride + j] = 15; letter = (lane + ib) % 4; }
-          else { const int l2 = cs_cstols(letter, base); qr4[lane * qstride + j] = (uint8_t)l2; letter = l2; }
+          else { const int l2 = cs_cstols(letter, base, ix.genome_is_rna != 0); qr4[lane * qstride + j] = (uint8_t)l2; letter = l2; }
         }
       }
       cur_rd = rd;
@@ -1619,7 +1626,7 @@ k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__
       ay = -ay + (read_len - 1) - (h.alen - 1) + (h.awidth - 1);
       gen_st = 1;
     }
-    load_window(ix.genome, (uint64_t)ix.contig_off[cn] + h.g_off, w_len, gen_st != 0, db, lane);
+    load_window(ix.genome, (uint64_t)ix.contig_off[cn] + h.g_off, w_len, gen_st != 0, db, lane, ix.contig_rna && ix.contig_rna[cn]);
     __syncthreads();
     const int score_max = (read_len < w_len ? read_len : w_len) * sc.match;
     const int thresh = thr_of(sc.full_thr_frac, sc.full_abs, score_max);
@@ -1946,13 +1953,14 @@ __device__ __forceinline__ void p2cs_g4_pass(const GmIndexDev& ix, const GmScore
     gen_st = 1;
   }
   const uint64_t g0 = (uint64_t)ix.contig_off[cn] + h.g_off;
+  const int rna_bits = (ix.contig_rna && has && ix.contig_rna[cn]) ? 2 : 0;
   __syncthreads();
   for (int gg = 0; gg < 4; gg++) {                       // the whole wave unpacks each group's colours and window
     if (!__shfl((int)has, gg * 16)) continue;
-    const int rd_g = __shfl(rd, gg * 16), wl_g = __shfl(w_len, gg * 16), gs_g = __shfl(gen_st, gg * 16);
+    const int rd_g = __shfl(rd, gg * 16), wl_g = __shfl(w_len, gg * 16), gs_g = __builtin_amdgcn_readfirstlane(__shfl(gen_st | rna_bits, gg * 16));      // (bit 1: the contig is RNA; wave-uniform)
     const uint64_t g0_g = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(g0 >> 32), gg * 16) << 32) | (uint32_t)__shfl((int)(uint32_t)g0, gg * 16);
     load_read(A.reads + (size_t)rd_g * A.read_words, read_len, false, A.rc_all + gg * qstride, lane);
-    load_window(ix.genome, g0_g, wl_g, gs_g != 0, A.db_all + gg * A.mw16, lane);
+    load_window(ix.genome, g0_g, wl_g, (gs_g & 1) != 0, A.db_all + gg * A.mw16, lane, (gs_g & 2) != 0);
   }
   __syncthreads();
   if (has && l < 4) {                                    // the four letter translations of the group's read, ref: sw-full-cs.c:1182-1197
@@ -1962,7 +1970,7 @@ __device__ __forceinline__ void p2cs_g4_pass(const GmIndexDev& ix, const GmScore
     for (int j = 0; j < read_len; j++) {
       const int base = rc[j];
       if (base == 15) { q4[l * qstride + j] = 15; letter = (l + ib) % 4; }
-      else { const int l2 = cs_cstols(letter, base); q4[l * qstride + j] = (uint8_t)l2; letter = l2; }
+      else { const int l2 = cs_cstols(letter, base, ix.genome_is_rna != 0); q4[l * qstride + j] = (uint8_t)l2; letter = l2; }
     }
   }
   const int score_max = (read_len < w_len ? read_len : w_len) * sc.match;
@@ -2156,7 +2164,7 @@ k_sw_gapless_batch(int n, int match, int mismatch, const uint32_t* __restrict__ 
       const long long gl0 = gi - ri;
       const uint32_t* gls = genome_ls + woff[i];
       const int letter = (int)((gls[gl0 >> 3] >> ((gl0 & 7) * 4)) & 0xf);
-      head = (cs_lstocs(letter, initbp[i]) == (int)qr[0]) ? match : 0;
+      head = (cs_lstocs(letter, initbp[i] & 0xff, (initbp[i] & GM_SEAM_RNA) != 0) == (int)qr[0]) ? match : 0;
       skip = 1;
     }
     // the rest of the diagonal: positions (g_left + skip + k, r_left + skip + k); a start value `head` >= 0 is a first cell of that score

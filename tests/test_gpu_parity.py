@@ -1592,3 +1592,40 @@ def test_colour_space_local_and_ungapped_match_reference_golden(gm, tag):
     got = oa.sam_header(contigs) + s.map_reads_cs(reads)
     s.close(); ix.close()
     assert got == want, _first_diff(got, want)
+
+
+@pytest.mark.parametrize("tag", sorted(oa.RNA_CASES))
+def test_rna_sequences_match_reference_golden(gm, tag):
+    """RNA contigs and RNA reads (uracil and no thymine, ref: fasta.c:528-542) on the GPU: a contig's own flag in its reverse complement (A <-> U) and its colour
+    translation (U read as T; genome.c:1107-1118), the LAST contig's flag as genome_is_rna in the first-colour row of pass 1, in sw_gapless and in sw_full_cs's letter
+    translations (genome.c:1063-1064; mapping.c:375-388,1318-1327), a letter-space read's own flag in its reverse complement (gmapper.c:487) -- byte-identical to
+    gmapper-ls / gmapper-cs on the rna_* fixtures: through the file entries (the files the reference read) and through the packed-code entries"""
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    g = oa.load_rna_case(tag)
+    p = gm.default_params_cs() if g["colour"] else gm.default_params()
+    p.sam_unaligned = 1
+    if g["opts"] == "local=1;ungapped=1":                     # --local -U with the companions the binary sets (ref: gmapper.c:2057-2062)
+        for k, v in dict(local_alignment=1, ungapped=1, anchor_width=0, a_gap_open_score=-255, b_gap_open_score=-255, hash_filter_calls=0).items(): setattr(p, k, v)
+    else: assert g["opts"] is None
+    ix = gm.Index(g["contigs"], names=g["contig_names"], params=p)
+    s = gm.Session(ix, params=p, max_batch_reads=256)         # (several sub-batches: the per-read flags of each)
+    head = oa.sam_header(g["contigs"], g["contig_names"])
+    paths = [os.path.join(G, f) for f in g["files"]]
+    if g["pairing"]:
+        mode, lo, hi = g["pairing"]
+        got = head + s.map_pairs_file(paths[0], paths[1], mode=mode, min_insert=lo, max_insert=hi)
+        assert got == g["sam"], _first_diff(got, g["sam"])
+        (n1, m1, _), (n2, m2, _) = g["reads"]
+        got = head + s.map_pairs(m1, m2, n1, n2, mode=mode, min_insert=lo, max_insert=hi)
+        assert got == g["sam"], _first_diff(got, g["sam"])
+    else:
+        got = head + s.map_reads_file(paths[0], qual_delta=33 if paths[0].endswith(".fq.gz") else None)
+        assert got == g["sam"], (_first_diff(got, g["sam"]), s.stats)
+        names, codes, quals = g["reads"][0]
+        if not g["colour"]:
+            got = head + s.map_reads(codes, names)
+            assert got == g["sam"], _first_diff(got, g["sam"])
+        elif quals is None:
+            got = head + s.map_reads_cs(codes, names)
+            assert got == g["sam"], _first_diff(got, g["sam"])
+    s.close(); ix.close()
