@@ -196,6 +196,23 @@ int gmo_sw_full_cs_mode(const uint32_t* genome_ls, int goff, int glen, const uin
   return 0;
 }
 
+// the same two functions with is_rna set (what gmapper passes for a genome whose last contig is RNA, ref: genome.c:1063-1064): U reads as T in lstocs, cstols hands back U for T
+int gmo_sw_vector_cs_rna(const uint32_t* genome_cs, int goff, int glen, const uint32_t* read, int rlen, const uint32_t* genome_ls, int initbp) {
+  Params P = default_params();
+  return sw_vector_cs(P, 10 + (-20), genome_cs, goff, glen, read, rlen, genome_ls, initbp, true);
+}
+int gmo_sw_full_cs_rna(const uint32_t* genome_ls, int goff, int glen, const uint32_t* read, int rlen, int initbp, int thresh,
+                       long long ax, long long ay, int alen, int awidth, int revcmpl, int local, int* out, char* dbalign, char* qralign, int cap) {
+  CsParams C; SwFullCsResults s;
+  Anchor a; a.x = ax; a.y = ay; a.length = alen; a.width = awidth; a.weight = 1;
+  sw_full_cs(C, genome_ls, goff, glen, read, rlen, initbp, thresh, &s, revcmpl != 0, &a, 1, nullptr, local, true);
+  int v[10] = {s.score, s.read_start, s.rmapped, s.genome_start, s.gmapped, s.matches, s.mismatches, s.insertions, s.deletions, s.crossovers};
+  memcpy(out, v, sizeof v);
+  if ((int)s.dbalign.size() + 1 > cap) return -1;
+  strcpy(dbalign, s.dbalign.c_str()); strcpy(qralign, s.qralign.c_str());
+  return 0;
+}
+
 // sw_full_cs with a per-position crossover_score[] (ref: sw-full-cs.c:312; gmapper.c:532-544 builds it from the read's QVs), either mode
 int gmo_sw_full_cs_xover(const uint32_t* genome_ls, int goff, int glen, const uint32_t* read, int rlen, int initbp, int thresh,
                          long long ax, long long ay, int alen, int awidth, int revcmpl, int local, const int* xover, int* out, char* dbalign, char* qralign, int cap) {

@@ -9,6 +9,9 @@
 //   X / Y ...  (second argument "xover"): sw_full_cs with a per-position crossover_score[] (what every csfastq read hands it, ref: mapping.c:375-379, gmapper.c:532-544),
 //     global (X) and local (Y) mode; the S record's fields with the rlen scores (comma separated, in [2 * global, -1] as gmapper.c:538-542 clamps them) behind the read words
 //     -> tests/golden/sw_kat_cs_xover.txt.gz
+//   C / S / L with second argument "rna": the genome holds U for every T (an RNA contig) and both functions get is_rna = true (what gmapper passes for a genome whose last
+//     contig is RNA, ref: genome.c:1063-1064, mapping.c:375-388,1318-1327) -- lstocs reads U as T, cstols hands back U for T (util.h:157-205); global and local mode
+//     -> tests/golden/sw_kat_cs_rna.txt.gz
 // Scores are the binary's colour-space defaults (ref: gmapper-defaults.h:52-58): match 10, mismatch -24, crossover -20,
 // gaps -33/-7 (reference) -33/-3 (query); the vector filter's mismatch is match + crossover (ref: gmapper.c:2935).
 #include <cstdio>
@@ -30,6 +33,7 @@ int main(int argc, char** argv) {
   int n = argc > 1 ? atoi(argv[1]) : 1500;
   const bool local = argc > 2 && !strcmp(argv[2], "local");     // "L" records: the same cases through sw_full_cs(.., local_alignment = true) (ref: sw-full-cs.c:199-203,315,439-552); no C / S records
   const bool xover = argc > 2 && !strcmp(argv[2], "xover");     // "X" / "Y" records only
+  const bool rna = argc > 2 && !strcmp(argv[2], "rna");         // C, S and L records on an RNA genome with is_rna = true
   std::mt19937_64 rng(20260202), xrng(20261005);
   sw_vector_setup(1400, 1000, -33, -7, -33, -3, 10, 10 + (-20), 1, true);
   sw_full_cs_setup(1400, 1000, -33, -7, -33, -3, 10, -24, -20, true, 8, 0);
@@ -42,7 +46,8 @@ int main(int argc, char** argv) {
     std::vector<int> g(goff + glen + 9);
     for (auto& b : g) b = rng() % 4;
     if (kind == 4) for (int k = 0; k < 3; k++) g[goff + rng() % glen] = 15;                 // N in the genome
-    if (kind == 6) for (auto& b : g) b = 0;                                                  // homopolymer: every tie rule fires
+    if (kind == 6) for (auto& b : g) b = rna ? 3 : 0;                                        // homopolymer: every tie rule fires
+    if (rna) for (auto& b : g) if (b == 3) b = BASE_U;                                       // an RNA contig: uracil, no thymine
     // letter-space read = mutated copy of a window diagonal
     int start = goff + (glen > rlen ? rng() % (glen - rlen + 1) : 0);
     std::vector<int> rl(rlen);
@@ -52,7 +57,7 @@ int main(int argc, char** argv) {
       double u = (rng() % 100000) / 100000.0;
       if (u < pind) { rl[i] = rng() % 4; continue; }
       if (u < 2 * pind) gi += 1 + rng() % 3;
-      int b = g[gi < (int)g.size() ? gi : (int)g.size() - 1] & 3; gi++;
+      int b = g[gi < (int)g.size() ? gi : (int)g.size() - 1]; if (b == BASE_U) b = 3; b &= 3; gi++;
       if ((rng() % 100000) / 100000.0 < psub) b = (b + 1 + rng() % 3) & 3;
       rl[i] = b;
     }
@@ -63,9 +68,9 @@ int main(int argc, char** argv) {
     for (int i = 0; i < rlen; i++) if ((rng() % 100000) / 100000.0 < pcol) rc[i] = (rc[i] + 1 + rng() % 3) & 3;
     if (kind == 7) for (int k = 0; k < 2; k++) rc[rng() % rlen] = 15;                        // '.' colours
     std::vector<uint32_t> gl((g.size() + 15) / 8 + 1, 0), gc((g.size() + 15) / 8 + 1, 0), rb(rlen / 8 + 1, 0);
-    for (size_t i = 0; i < g.size(); i++) { put(gl, (int)i, g[i]); put(gc, (int)i, lstocs(i ? g[i - 1] : BASE_T, g[i], false)); }   // ref: fasta.c:586-607
+    for (size_t i = 0; i < g.size(); i++) { put(gl, (int)i, g[i]); put(gc, (int)i, lstocs(i ? g[i - 1] : BASE_T, g[i], rna)); }   // ref: fasta.c:586-607
     for (int i = 0; i < rlen; i++) put(rb, i, rc[i]);
-    int sv = sw_vector(gc.data(), goff, glen, rb.data(), rlen, gl.data(), initbp, false);
+    int sv = sw_vector(gc.data(), goff, glen, rb.data(), rlen, gl.data(), initbp, rna);
     if (!local && !xover) { printf("C %d %d %d %d ", goff, glen, rlen, initbp); dump(gc); printf(" "); dump(gl); printf(" "); dump(rb); printf(" %d\n", sv); }
     struct anchor a; memset(&a, 0, sizeof a);
     a.x = (start - goff) + (int)(rng() % 7) - 3; a.y = 0; a.length = 10 + rng() % (rlen > 16 ? rlen - 10 : 6); a.width = 1 + rng() % 4; a.weight = 2;
@@ -89,10 +94,11 @@ int main(int argc, char** argv) {
       }
       continue;
     }
-    for (int rv = 0; rv < 2; rv++) {
+    for (int md = 0; md < (rna ? 2 : 1); md++) for (int rv = 0; rv < 2; rv++) {
+      const bool loc = rna ? md == 1 : local;
       struct sw_full_results sfr; memset(&sfr, 0, sizeof sfr);
-      sw_full_cs(gl.data(), goff, glen, rb.data(), rlen, initbp, thresh, &sfr, rv != 0, false, &a, 1, local ? 1 : 0, NULL);
-      printf("%s %d %d %d %d %lld %lld %d %d %d %d ", local ? "L" : "S", goff, glen, rlen, initbp, (long long)a.x, (long long)a.y, a.length, a.width, rv, thresh);
+      sw_full_cs(gl.data(), goff, glen, rb.data(), rlen, initbp, thresh, &sfr, rv != 0, rna, &a, 1, loc ? 1 : 0, NULL);
+      printf("%s %d %d %d %d %lld %lld %d %d %d %d ", loc ? "L" : "S", goff, glen, rlen, initbp, (long long)a.x, (long long)a.y, a.length, a.width, rv, thresh);
       dump(gl); printf(" "); dump(rb);
       printf(" %d %d %d %d %d %d %d %d %d %d %s %s\n", sfr.score, sfr.read_start, sfr.rmapped, sfr.genome_start, sfr.gmapped,
              sfr.matches, sfr.mismatches, sfr.insertions, sfr.deletions, sfr.crossovers,

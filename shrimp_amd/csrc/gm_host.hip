@@ -1987,7 +1987,7 @@ extern "C" int gm_sw_vector_batch_cs(int n, const uint32_t* genome_cs, const uin
   if (!g_sv.init) { gm_set_error("sw_vector called before sw_vector_setup"); return GM_E_NOTSETUP; }
   if (n <= 0) return GM_OK;
   int max_g = 0, max_r = 0;
-  for (int i = 0; i < n; i++) { max_g = std::max(max_g, glen[i]); max_r = std::max(max_r, rlen[i]); if (glen[i] < 1 || rlen[i] < 1 || initbp[i] < 0 || initbp[i] > 3) return GM_E_ARG; }
+  for (int i = 0; i < n; i++) { max_g = std::max(max_g, glen[i]); max_r = std::max(max_r, rlen[i]); if (glen[i] < 1 || rlen[i] < 1 || initbp[i] < 0 || (initbp[i] & ~GM_SEAM_RNA) > 3) return GM_E_ARG; }
   if (max_g > g_sv.dblen || max_r > g_sv.qrlen) { gm_set_error("window/read longer than sw_vector_setup sizes"); return GM_E_ARG; }
   uint32_t *dgc = nullptr, *dgl = nullptr, *dr = nullptr; long long* dgo = nullptr; int *dgn = nullptr, *drl = nullptr, *dib = nullptr, *ds = nullptr;
   GM_HIP(hipMalloc(&dgc, (genome_words + 8) * 4)); GM_HIP(hipMalloc(&dgl, (genome_words + 8) * 4)); GM_HIP(hipMalloc(&dr, (size_t)n * read_words * 4 + 32));

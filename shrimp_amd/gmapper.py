@@ -603,12 +603,12 @@ def sw_vector_batch_bounded(genome_words: np.ndarray, g_off, glen, reads_words: 
     return out, stopped
 
 
-def sw_vector(genome_words, goff, glen, read_words, rlen, genome_ls=None, initbp=-1) -> int:
+def sw_vector(genome_words, goff, glen, read_words, rlen, genome_ls=None, initbp=-1, is_rna=False) -> int:
     g = np.ascontiguousarray(genome_words, dtype=np.uint32); r = np.ascontiguousarray(read_words, dtype=np.uint32)
     gl = None
     if genome_ls is not None:
         gla = np.ascontiguousarray(genome_ls, dtype=np.uint32); gl = gla.ctypes.data_as(C.POINTER(C.c_uint32))
-    return lib().sw_vector(g.ctypes.data_as(C.POINTER(C.c_uint32)), goff, glen, r.ctypes.data_as(C.POINTER(C.c_uint32)), rlen, gl, initbp, False)
+    return lib().sw_vector(g.ctypes.data_as(C.POINTER(C.c_uint32)), goff, glen, r.ctypes.data_as(C.POINTER(C.c_uint32)), rlen, gl, initbp, bool(is_rna))
 
 
 def sw_gapless_setup(match, mismatch, reset_stats=True):
@@ -684,7 +684,7 @@ def sw_full_cs_setup(dblen, qrlen, a_gap_open, a_gap_ext, b_gap_open, b_gap_ext,
            "sw_full_cs_setup")
 
 
-def sw_full_cs(genome_ls, goff, glen, read_words, rlen, initbp, thresh, anchor, revcmpl=False, local=False, xover=None):
+def sw_full_cs(genome_ls, goff, glen, read_words, rlen, initbp, thresh, anchor, revcmpl=False, local=False, xover=None, is_rna=False):
     """anchor = (x, y, length, width); local: the reference's local_alignment argument; xover: the reference's crossover_score argument (one int per read position, what
     gmapper hands over for a read with quality values, ref: mapping.c:375-379) or None; returns (fields dict incl. crossovers, dbalign, qralign)."""
     L = lib()
@@ -693,7 +693,7 @@ def sw_full_cs(genome_ls, goff, glen, read_words, rlen, initbp, thresh, anchor, 
     s = SwFullResults()
     xs = None if xover is None else np.ascontiguousarray(xover, dtype=np.int32)
     L.sw_full_cs(g.ctypes.data_as(C.POINTER(C.c_uint32)), goff, glen, r.ctypes.data_as(C.POINTER(C.c_uint32)), rlen, initbp, thresh,
-                 C.byref(s), bool(revcmpl), False, C.byref(a), 1, 1 if local else 0, None if xs is None else xs.ctypes.data_as(C.POINTER(C.c_int)))
+                 C.byref(s), bool(revcmpl), bool(is_rna), C.byref(a), 1, 1 if local else 0, None if xs is None else xs.ctypes.data_as(C.POINTER(C.c_int)))
     db = C.string_at(s.dbalign).decode() if s.dbalign else ""
     qr = C.string_at(s.qralign).decode() if s.qralign else ""
     if s.dbalign: L.gm_free(s.dbalign)

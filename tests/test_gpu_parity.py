@@ -636,6 +636,22 @@ def test_colour_space_kernels_known_answers(gm):
             assert got == want and gdb.encode() == db and gqr.encode() == qr, (got, want, gdb, db, gqr, qr)
         nl += 1
     assert nl >= 800
+    # is_rna = true on RNA genomes (what gmapper passes when the last contig is RNA, ref: genome.c:1063-1064): U reads as T in the first-colour row, the letter translations hold U for T
+    nr = 0
+    for r in oa.load_kat_cs("sw_kat_cs_rna.txt.gz"):
+        if r[0] == "C":
+            _, goff, glen, rlen, initbp, gcs, gls, rd, score = r
+            assert gm.sw_vector(gcs, goff, glen, rd, rlen, genome_ls=gls, initbp=initbp, is_rna=True) == score, (goff, glen, rlen, initbp, score)
+        else:
+            kind, (goff, glen, rlen, initbp, ax, ay, alen, awidth, rv, thresh), gls, rd, want, db, qr = r
+            f, gdb, gqr = gm.sw_full_cs(gls, goff, glen, rd, rlen, initbp, thresh, (ax, ay, alen, awidth), revcmpl=bool(rv), local=kind == "L", is_rna=True)
+            if want[0] == 0:
+                assert f["score"] == 0, (f, want)
+            else:
+                got = [f[k] for k in ("score", "read_start", "rmapped", "genome_start", "gmapped", "matches", "mismatches", "insertions", "deletions", "crossovers")]
+                assert got == want and gdb.encode() == db and gqr.encode() == qr, (got, want, gdb, db, gqr, qr)
+        nr += 1
+    assert nr >= 1500
     # per-position crossover scores (crossover_score[]: what gmapper passes for every read with quality values, ref: mapping.c:375-379, sw-full-cs.c:312-322), global and local mode
     nx = ny = 0
     for r in oa.load_kat_cs("sw_kat_cs_xover.txt.gz"):

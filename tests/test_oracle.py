@@ -401,3 +401,27 @@ def test_oracle_rna_sequences_match_reference(tag, oracle_lib):
     s.close()
     got = oa.sam_header(g["contigs"], g["contig_names"]) + body
     assert got == g["sam"], "oracle SAM differs from the reference's for %s" % tag
+
+
+def test_oracle_colour_space_kernels_with_is_rna_match_reference_known_answers(oracle_lib):
+    """sw_vector (first-colour row) and sw_full_cs (global and local) with is_rna = true on RNA genomes -- lstocs reads U as T, cstols hands back U for T
+    (ref: util.h:157-205; sw-vector.c:129,289; sw-full-cs.c:1191) -- against the reference's own functions: 300 vector + 1200 full-SW known answers"""
+    import ctypes as C
+    L = oa.load(); u32p = C.POINTER(C.c_uint32)
+    nc = ns = 0
+    for r in oa.load_kat_cs("sw_kat_cs_rna.txt.gz"):
+        if r[0] == "C":
+            _, goff, glen, rlen, initbp, gcs, gls, rd, score = r
+            got = L.gmo_sw_vector_cs_rna(gcs.ctypes.data_as(u32p), goff, glen, rd.ctypes.data_as(u32p), rlen, gls.ctypes.data_as(u32p), initbp)
+            assert got == score, (goff, glen, rlen, initbp, got, score); nc += 1
+        else:
+            kind, (goff, glen, rlen, initbp, ax, ay, alen, awidth, rv, thresh), gls, rd, want, db, qr = r
+            out = (C.c_int * 10)(); dba = C.create_string_buffer(4096); qra = C.create_string_buffer(4096)
+            assert L.gmo_sw_full_cs_rna(gls.ctypes.data_as(u32p), goff, glen, rd.ctypes.data_as(u32p), rlen, initbp, thresh, C.c_longlong(ax), C.c_longlong(ay), alen, awidth, rv,
+                                        1 if kind == "L" else 0, out, dba, qra, 4096) == 0
+            if want[0] == 0:
+                assert out[0] == 0
+            else:
+                assert list(out) == want and dba.value == db and qra.value == qr, (list(out), want, dba.value, db, qra.value, qr)
+            ns += 1
+    assert nc >= 300 and ns >= 1200

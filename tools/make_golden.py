@@ -374,6 +374,10 @@ def cs_kat_cases():
     with gzip.open(os.path.join(OUT, "sw_kat_cs_xover.txt.gz"), "wb", compresslevel=9) as f:
         f.write(katx)
     print("sw_kat_cs_xover:", katx.count(b"\nX ") + 1, "sw_full_cs with per-position crossover scores,", katx.count(b"\nY "), "of them in local mode")
+    katr = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_kat_cs"), "300", "rna"], capture_output=True, check=True).stdout
+    with gzip.open(os.path.join(OUT, "sw_kat_cs_rna.txt.gz"), "wb", compresslevel=9) as f:
+        f.write(katr)
+    print("sw_kat_cs_rna:", katr.count(b"\nC ") + 1, "colour-space vector,", katr.count(b"\nS "), "+", katr.count(b"\nL "), "sw_full_cs (global + local), all on an RNA genome with is_rna = true")
 
 
 def post_kat_cases():
