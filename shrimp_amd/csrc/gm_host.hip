@@ -320,6 +320,8 @@ struct HostSlot {
   uint8_t* post_bq = nullptr; size_t post_bq_cap = 0; bool post_bq_on = false;   // base qualities of the device's post_sw (reads with QVs), read_len bytes per result
   GmPostRes* post = nullptr; size_t post_cap = 0; bool post_on = false;      // colour space: the device's post_sw results of this sub-batch (post_on: they are there)
   size_t res_cap = 0, ops_cap = 0, n_cap = 0, reads_cap = 0; uint32_t n_work = 0;
+  bool want_reads = false;                                   // set by the caller: copy the sub-batch's packed reads back as well (reads handed over in device memory)
+  unsigned long long* stats = nullptr; size_t stats_cap = 0;   // the sub-batch's stage counters as the device left them (pinned: their copy must not block the calling thread)
 };
 static int slot_reserve(void** p, size_t* cap, size_t bytes) {
   if (bytes <= *cap) return GM_OK;
@@ -331,7 +333,7 @@ static int slot_reserve(void** p, size_t* cap, size_t bytes) {
   return GM_OK;
 }
 static void slot_free(HostSlot& h) {
-  void* ptrs[] = {h.res, h.ops, h.sel_cnt, h.sel_off, h.reads, h.post, h.post_bq};
+  void* ptrs[] = {h.res, h.ops, h.sel_cnt, h.sel_off, h.reads, h.post, h.post_bq, h.stats};
   for (void* p : ptrs) if (p) (void)hipHostFree(p);
   h = HostSlot();
 }
@@ -1289,7 +1291,8 @@ static int pipeline_front(gm_session* s, int k, int n, int read_len) {
 
 // Back, stream B: heavy tier if any (stream A, rare), pass 1, selection, pass 2, results to the host slot.  Returns 1 when a capacity grew
 // (the buffers of set k were re-allocated: the caller re-submits the sub-batch from the front).
-static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len, gm_map_stats_t* st, float* lookup_ms, bool next_front_queued = false) {
+static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len, gm_map_stats_t* st, float* lookup_ms, bool next_front_queued = false,
+                         const std::function<int()>* after_pass2 = nullptr) {
   DevSet& D = s->set[k];
   const GmIndexDev dv = session_view(s);
   const int read_words = (read_len + 7) / 8;
@@ -1301,6 +1304,9 @@ static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len,
     GM_HIP(hipEventSynchronize(s->pev[k][6]));
     const uint32_t n_heavy = s->h_pin[k];
     int rc;
+    float ms[5];                                                     // (the front's times now: its events are recorded again when this set takes the sub-batch after next)
+    GM_HIP(hipEventElapsedTime(&ms[0], s->pev[k][0], s->pev[k][1]));
+    GM_HIP(hipEventElapsedTime(&ms[1], s->pev[k][1], s->pev[k][2]));
     if (n_heavy) {
       rc = run_heavy_tier(s, D, dv, n, read_len, read_words, W, (int)n_heavy, d_stats); if (rc) return rc;
       GM_HIP(hipEventRecord(s->pev[k][6], s->stream));
@@ -1374,6 +1380,15 @@ static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len,
     if (!H.post_on) H.post_bq_on = false;
     if (H.post_on) { size_t cap = H.post_cap; rc = slot_reserve((void**)&H.post, &cap, (size_t)n_work * sizeof(GmPostRes)); H.post_cap = cap; if (rc) return rc; }
     if (H.post_bq_on) { size_t cap = H.post_bq_cap; rc = slot_reserve((void**)&H.post_bq, &cap, (size_t)n_work * read_len + 64); H.post_bq_cap = cap; if (rc) return rc; }
+    // The stage counters first, then an event: from there on nothing of this set that the FRONT writes is read any more (the copies below take d_res / d_ops / d_sel_* /
+    // d_post only), so the front of the sub-batch after next may be queued onto this set before the host waits for the results (after_pass2, see map_impl).
+    { size_t cap = H.stats_cap; rc = slot_reserve((void**)&H.stats, &cap, hraw.size() * 8); H.stats_cap = cap; if (rc) return rc; }
+    GM_HIP(hipMemcpyAsync(H.stats, d_stats, hraw.size() * 8, hipMemcpyDeviceToHost, q));
+    if (H.want_reads) {                                              // reads handed over in device memory: the host's finalisation needs this sub-batch's letters too
+      size_t cap = H.reads_cap; rc = slot_reserve((void**)&H.reads, &cap, (size_t)n * read_words * 4); H.reads_cap = cap; if (rc) return rc;
+      GM_HIP(hipMemcpyAsync(H.reads, D.d_reads, (size_t)n * read_words * 4, hipMemcpyDeviceToHost, q));
+    }
+    GM_HIP(hipEventRecord(s->pev[k][9], q));
     if (n_work) {
       if (H.post_on) GM_HIP(hipMemcpyAsync(H.post, D.d_post, (size_t)n_work * sizeof(GmPostRes), hipMemcpyDeviceToHost, q));
       if (H.post_bq_on) GM_HIP(hipMemcpyAsync(H.post_bq, D.d_post_bq, (size_t)n_work * read_len, hipMemcpyDeviceToHost, q));
@@ -1382,12 +1397,10 @@ static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len,
     }
     GM_HIP(hipMemcpyAsync(H.sel_cnt, D.d_sel_cnt, (size_t)n * 4, hipMemcpyDeviceToHost, q));
     GM_HIP(hipMemcpyAsync(H.sel_off, D.d_sel_off, (size_t)n * 4, hipMemcpyDeviceToHost, q));
-    GM_HIP(hipMemcpyAsync(hraw.data(), d_stats, hraw.size() * 8, hipMemcpyDeviceToHost, q));
+    if (after_pass2) { rc = (*after_pass2)(); if (rc) return rc; }
     GM_HIP(hipStreamSynchronize(q));
+    memcpy(hraw.data(), H.stats, hraw.size() * 8);
     fold();
-    float ms[5];
-    GM_HIP(hipEventElapsedTime(&ms[0], s->pev[k][0], s->pev[k][1]));
-    GM_HIP(hipEventElapsedTime(&ms[1], s->pev[k][1], s->pev[k][2]));
     GM_HIP(hipEventElapsedTime(&ms[2], s->pev[k][3], s->pev[k][4]));
     GM_HIP(hipEventElapsedTime(&ms[3], s->pev[k][4], s->pev[k][5]));
     GM_HIP(hipEventElapsedTime(&ms[4], s->pev[k][5], s->pev[k][7]));
@@ -1597,24 +1610,45 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     }
     return n;
   };
-  int cur = 0; bool have_front = false;
-  for (int base = 0; base < n_reads;) {
-    DevSet& C = s->set[cur];
-    const int n = size_at(base, C.eff_batch);
+  // GM_TIMELINE=1: where the calling thread's time goes, per sub-batch (stderr)
+  const bool timeline = getenv("GM_TIMELINE") != nullptr;
+  auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tl0 = now_ms();
+  // Sub-batch i lives in set i & 1.  Its front is queued as early as the set allows: the first two at once, the front of i + 2 from inside the back of i -- behind pass 2
+  // and the copy of the counters, in front of the wait for the result copies (pipeline_back's after_pass2; the device orders it behind event pev[.][9]).  Short fronts
+  // (the bucket kernel on a small genome: 6 ms a sub-batch) then follow each other without the gap of a host round trip.
+  int q_base = 0, q_idx = 0;                                  // next sub-batch whose front is not queued yet: its first read, its number
+  int fr_n[2] = {0, 0};                                       // reads of the sub-batch whose front is queued on set k
+  auto queue_front = [&](bool behind_back) -> int {           // queues the front of sub-batch q_idx, if there is one
+    if (q_base >= n_reads) return GM_OK;
+    const int k = overlap ? (q_idx & 1) : 0;
+    const int n = size_at(q_base, s->set[k].eff_batch);
+    if (behind_back) { GM_HIP(hipStreamWaitEvent(s->stream, s->pev[k][9], 0)); GM_HIP(hipStreamWaitEvent(s->stream_c, s->pev[k][9], 0)); }
+    int rc = queue_inputs(k, q_base, n); if (!rc) rc = pipeline_front(s, k, n, read_len);
+    if (rc) return rc;
+    fr_n[k] = n; q_base += n; q_idx++;
+    return GM_OK;
+  };
+  const std::function<int()> ahead = [&]() -> int { return queue_front(true); };
+  int base = 0, idx = 0;
+  while (base < n_reads) {
+    const int cur = overlap ? (idx & 1) : 0;
     int rc = GM_OK; float lk = 0;
-    if (!have_front) { rc = queue_inputs(cur, base, n); if (!rc) rc = pipeline_front(s, cur, n, read_len); }
-    bool have_next = false;
-    if (!rc && overlap && base + n < n_reads) {
-      const int n2 = size_at(base + n, s->set[cur ^ 1].eff_batch);
-      rc = queue_inputs(cur ^ 1, base + n, n2); if (!rc) rc = pipeline_front(s, cur ^ 1, n2, read_len);
-      have_next = true;
-    }
+    const double tl_a = now_ms();
+    while (!rc && q_idx <= idx + (overlap ? 1 : 0) && q_base < n_reads) rc = queue_front(false);      // (the start of the call, and after a re-allocation)
+    const int n = fr_n[cur];
+    const bool have_next = q_idx > idx + 1;
     HostSlot& HS = s->slot[jobs.size() % 3];
-    if (!rc) rc = pipeline_back(s, cur, HS, n, read_len, stats, &lk, have_next);
-    if (rc == 1) {                                            // capacities of set `cur` grew: same for the other set, then again from the front
+    HS.want_reads = reads_host == nullptr;
+    const double tl_b = now_ms();
+    // (the front of i + 2 from inside this back only when the capacities are settled -- a re-allocation frees the set's buffers -- i.e. not for the first sub-batches)
+    const bool go_ahead = overlap && idx >= 2;
+    if (!rc) rc = pipeline_back(s, cur, HS, n, read_len, stats, &lk, have_next, go_ahead ? &ahead : nullptr);
+    const double tl_c = now_ms();
+    if (rc == 1) {                                            // capacities of set `cur` grew: same for the other set, then again from the front of this sub-batch
       GM_HIP(hipStreamSynchronize(s->stream));
       if (overlap) { rc = match_sets(cur); if (rc) { join_all(); return rc; } }
-      have_front = false;
+      q_base = base; q_idx = idx;
       continue;
     }
     if (rc) { (void)hipStreamSynchronize(s->stream); (void)hipStreamSynchronize(s->stream_b); join_all(); return rc; }
@@ -1622,24 +1656,21 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     std::unique_ptr<Job> J(new Job());
     J->base = base; J->n = n; J->idx = (int)jobs.size();
     J->hs = &HS;
-    if (reads_host) J->hreads = reads_host + (size_t)base * read_words;
-    else {
-      size_t cap = J->hs->reads_cap; rc = slot_reserve((void**)&J->hs->reads, &cap, (size_t)n * read_words * 4); J->hs->reads_cap = cap;
-      if (rc) { (void)hipStreamSynchronize(s->stream); join_all(); return rc; }
-      GM_HIP(hipMemcpyAsync(J->hs->reads, C.d_reads, (size_t)n * read_words * 4, hipMemcpyDeviceToHost, s->stream_b));
-      GM_HIP(hipStreamSynchronize(s->stream_b));
-      J->hreads = J->hs->reads;
-    }
+    J->hreads = reads_host ? reads_host + (size_t)base * read_words : HS.reads;
     // at most two host jobs outstanding
+    const double tl_d = now_ms();
     while (jobs.size() - joined >= 2) { jobs[joined]->th.join(); joined++; }
+    const double tl_e = now_ms();
     Job* jp = J.get();
     J->th = std::thread(run_job, jp);
     jobs.push_back(std::move(J));
-    base += n;
-    if (overlap) cur ^= 1;
-    have_front = have_next;
+    if (timeline) fprintf(stderr, "[timeline] t %8.2f  n %7d  fronts %6.2f  back %6.2f  join-wait %6.2f  spawn %5.2f  (K1 %.2f ms)\n",
+                          tl_a - tl0, n, tl_b - tl_a, tl_c - tl_b, tl_e - tl_d, now_ms() - tl_e, lk);
+    base += n; idx++;
   }
+  const double tl_f = now_ms();
   for (auto& j : jobs) if (j->th.joinable()) j->th.join();
+  if (timeline) { fprintf(stderr, "[timeline] t %8.2f  final join %6.2f; host jobs:", tl_f - tl0, now_ms() - tl_f); for (auto& j : jobs) fprintf(stderr, " %.1f", j->ms); fprintf(stderr, "\n"); }
   uint64_t matched = 0, records = 0;
   for (auto& j : jobs) {
     for (size_t c = 0; c < j->cm.size(); c++) { matched += j->cm[c]; records += j->cr[c]; }
