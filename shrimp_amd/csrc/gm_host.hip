@@ -339,6 +339,8 @@ static void slot_free(HostSlot& h) {
 }
 
 struct gm_session {
+  gm_session* twin = nullptr;                     // a second session on the same index with the same parameters, made by the file entry the first time a file has more than one
+                                                  // chunk: it maps every other chunk, so that a chunk's tail runs under the next chunk's lookups (freed with this one)
   const gm_index* ix = nullptr;
   gm_params_t P; GmScoreDev sc;
   double score_alpha = 0, score_beta = 0;
@@ -602,6 +604,7 @@ extern "C" int gm_session_create(gm_session_t** out, const gm_index_t* ix, const
 }
 extern "C" void gm_session_free(gm_session_t* s) {
   if (!s) return;
+  if (s->twin) { gm_session_free(s->twin); s->twin = nullptr; }
   (void)hipSetDevice(s->ix->device);
   free_buffers(s->set[0]); free_buffers(s->set[1]); free_buffers(s->set2[0]); free_buffers(s->set2[1]);
   for (auto& h : s->slot) slot_free(h);
@@ -1427,8 +1430,22 @@ static int run_device_pipeline(gm_session* s, DevSet& D, HostSlot& H, int n, int
 
 // The lookup kernels keep per-DEVICE scratch (fall-back lists, start flags, the rounds kernel's rows: gm_lookup.hip, gm_lookup5.hip), shared by every session on that
 // device: mapping calls of different sessions on one device take turns (a single call already fills the GPU).  Sessions on different devices run side by side.
-static std::mutex g_dev_call_mutex[16];
-static std::mutex& dev_call_mutex(const gm_session* s) { return g_dev_call_mutex[(unsigned)s->ix->device & 15u]; }
+// (round 4: that scratch exists twice per device -- gm_lookup_set_scratch_slot -- so TWO mapping calls may be in flight on a device, e.g. the two sessions the file entry
+// alternates its chunks between: the tail of one call, its last back half and host work, then runs under the other's lookups.  A third call waits for a free set.)
+struct GmDevTurn {
+  static std::mutex& m(int d) { static std::mutex a[16]; return a[d]; }
+  static std::condition_variable& cv(int d) { static std::condition_variable a[16]; return a[d]; }
+  static bool& busy(int d, int k) { static bool a[16][2] = {}; return a[d][k]; }
+  int dev, slot;
+  explicit GmDevTurn(const gm_session* s) : dev((int)((unsigned)s->ix->device & 15u)), slot(0) {
+    std::unique_lock<std::mutex> lk(m(dev));
+    cv(dev).wait(lk, [&] { return !busy(dev, 0) || !busy(dev, 1); });
+    slot = busy(dev, 0) ? 1 : 0; busy(dev, slot) = true;
+    gm_lookup_set_scratch_slot(slot);
+  }
+  ~GmDevTurn() { { std::lock_guard<std::mutex> lk(m(dev)); busy(dev, slot) = false; } cv(dev).notify_one(); }
+  GmDevTurn(const GmDevTurn&) = delete; GmDevTurn& operator=(const GmDevTurn&) = delete;
+};
 
 static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* reads_host, const void* reads_dev,
                     const char* names, int emit_sam, char** sam, size_t* sam_len, gm_map_stats_t* stats, const uint8_t* initbp_host = nullptr,
@@ -1437,7 +1454,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   if ((s->P.colour_space != 0) != (initbp_host != nullptr)) {
     gm_set_error(s->P.colour_space ? "colour-space session: use gm_map_reads_cs (colours + primer letters)" : "gm_map_reads_cs needs a colour-space session"); return GM_E_ARG; }
   if (read_len > s->P.longest_read_len || read_len >= 32768 / std::max(1, s->P.match_score)) { gm_set_error("read length %d out of range (ref: sw-vector.c:393-398)", read_len); return GM_E_RANGE; }
-  std::lock_guard<std::mutex> dev_turn(dev_call_mutex(s));
+  GmDevTurn dev_turn(s);
   GM_HIP(hipSetDevice(s->ix->device));
   DevSet& D = s->set[0];
   if (stats) memset(stats, 0, sizeof *stats);
@@ -1788,7 +1805,7 @@ extern "C" int gm_last_lookup_timing(gm_session_t* s, double* ms, uint64_t* alg_
 // stage dump for parity tests: hits selected by pass 1, in ext-heap array order (before pass 2 / reverse_hit)
 extern "C" int gm_debug_tophits(gm_session_t* s, int n_reads, int read_len, const uint32_t* reads_packed, long long* rows, long cap, long* n_rows) {
   if (!s) return GM_E_ARG;
-  std::lock_guard<std::mutex> dev_turn(dev_call_mutex(s));     // (the device's lookup scratch is shared by its sessions: one call at a time, like the mapping entries)
+  GmDevTurn dev_turn(s);     // (the device's lookup scratch is shared by its sessions: one call at a time, like the mapping entries)
   GM_HIP(hipSetDevice(s->ix->device));
   DevSet& D = s->set[0];
   if (D.cur_len != read_len || (D.caps_pair_mode != 0 && D.caps_pair_mode != 4)) { choose_caps(s, D, read_len); D.caps_pair_mode = 0; int rc = alloc_buffers(s, D, read_len); if (rc) return rc; }

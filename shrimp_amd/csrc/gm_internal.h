@@ -67,6 +67,7 @@ struct GmLdsLimit { size_t v[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
 
 // K1 seed lookup + region filter: one workgroup per read-strand; read-strands with more than scap
 // survivors are listed in d_heavy_list (count in d_surv_cnt) and re-run by gm_launch_lookup_redo
+void gm_lookup_set_scratch_slot(int slot);   // which of the device's two lookup-scratch sets the calling thread's launches use (0 / 1)
 void gm_lookup_set_start_flags(uint32_t* flags, int cap, uint32_t epoch);   // pinned words the persistent K1 grid raises when its workgroups are resident
 int gm_lookup_start_flag_grid(void);
 // Optional fusion of K1b into K1 (k_lookup_v5): when `fuse` is given and the chosen kernel can apply the prune rules itself, the kept

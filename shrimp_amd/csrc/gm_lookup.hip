@@ -1139,12 +1139,17 @@ static void k1_geometry(const GmIndexDev& ix, int read_len, int* max_n_kmers, in
 
 // v4 launch: returns false when the geometry does not fit (the caller falls back to the slab-sweep kernels)
 struct K4Scratch { uint64_t* scratch = nullptr; size_t words = 0; uint32_t* fb = nullptr; int cus = 0; };
-static K4Scratch g_k4[16];
+static K4Scratch g_k4[16][2];                                   // (two sets per device, see gm_lookup_set_scratch_slot)
+static thread_local int g_k4_slot = 0;
+void gm_lookup5_set_scratch_slot(int slot);
+// The lookup kernels' scratch (fall-back lists, the rounds kernel's rows, v4's candidate bins) exists twice per device: a mapping call runs all its launches with the set
+// its thread was given, so that two calls -- two sessions -- can be in flight on one device (gm_host.hip hands the sets out).
+void gm_lookup_set_scratch_slot(int slot) { g_k4_slot = slot & 1; gm_lookup5_set_scratch_slot(slot & 1); }
 static bool k4_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads, int read_len, int read_words, int max_n_kmers, int NL,
                       uint64_t* d_surv, uint32_t* d_surv_cnt, int scap, uint32_t* d_heavy_list, uint32_t* d_heavy_cnt, int heavy_cap,
                       unsigned long long* d_stats, hipStream_t stream, uint32_t* d_surv_seg, size_t lds_generic, int bm_words) {
   int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
-  K4Scratch& K = g_k4[dev];
+  K4Scratch& K = g_k4[dev][g_k4_slot];
   const int S = ix.n_slabs;
   {  // v4's fixed cost per read-strand (two 128 KB table clears, per-bin passes) pays off from ~30 k list entries per read-strand
      // (measured: 45 k at 100 bp / 3 Gbp 7 % faster than the slab sweep, 17 k at 50 colours 40 % slower)

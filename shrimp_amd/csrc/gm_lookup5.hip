@@ -212,7 +212,9 @@ int gm_index_derive_strips(GmIndexHost* ix, hipStream_t stream) {
 // launch: returns 1 when v5 ran (0: geometry does not fit, the caller takes another kernel; < 0: error)
 // ---------------------------------------------------------------------------------------------
 struct K5Scratch { uint32_t* fb = nullptr; uint32_t* pl = nullptr; int fb_cap = 0; int cus = 0; uint2* spill = nullptr; size_t spill_n = 0; };   // fb: read-strands for the lane-per-list kernel + K1b; pl: for K1b only
-static K5Scratch g_k5[16];
+static K5Scratch g_k5[16][2];                                   // per device, two sets: two mapping calls may be in flight on a device, each with the set its thread was given
+static thread_local int g_k5_slot = 0;
+void gm_lookup5_set_scratch_slot(int slot) { g_k5_slot = slot & 1; }
 // (launch state of the calling thread, like gm_lookup.hip's: set, used and read back by one host thread per launch)
 static thread_local uint32_t* g_k5_flags = nullptr; static thread_local uint32_t g_k5_epoch = 0; static thread_local int g_k5_flag_cap = 0, g_k5_flag_grid = 0;
 void gm_lookup5_set_start_flags(uint32_t* flags, int cap, uint32_t epoch) { g_k5_flags = flags; g_k5_flag_cap = cap; g_k5_epoch = epoch; g_k5_flag_grid = 0; }
@@ -228,7 +230,7 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
                       uint64_t* d_raw, int raw_cap, uint32_t* d_surv_seg, uint32_t** pl_list, uint32_t** pl_cnt) {
   int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
   if (!ix.seed[0].sdir || ix.region_bits < 9 || ix.region_bits > 16 || NL <= 0) return 0;
-  K5Scratch& K = g_k5[dev];
+  K5Scratch& K = g_k5[dev][g_k5_slot];
   const bool forced = gm_tune("GM_K1_V5") != nullptr;
   double entries = 0;                                          // expected list entries per read-strand
   for (int sn = 0; sn < ix.n_seeds; sn++) {
