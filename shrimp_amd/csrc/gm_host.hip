@@ -530,7 +530,9 @@ static void choose_caps(gm_session* s, DevSet& D, int read_len, int pair_mode = 
   D.hcap = 64;
   // K1b (exact isolation prune) shrinks K2's input; its LDS tier is sized for what typically remains
   // K1b's bounds assume the window-generation threshold: not in -U mode
-  D.scap2 = (s->P.match_mode == 2 && !s->P.ungapped && !gm_tune("GM_NO_PRUNE")) ? std::max(std::min(D.scap, 256), D.scap / 8) : 0;
+  // (a read that maps keeps one survivor per list at its true place -- 251 at 100 bases -- before any chance survivor: a tier of 256 sent 2 % of the read-strands of the
+  // 100 Mbp workload through the heavy tier, whose host round trips then cost a quarter of the step; the tier holds one and a half times the lists)
+  D.scap2 = (s->P.match_mode == 2 && !s->P.ungapped && !gm_tune("GM_NO_PRUNE")) ? std::max(std::min(D.scap, std::max(256, pow2ceil((long long)(1.5 * lists)))), D.scap / 8) : 0;
   if (pair_mode == 2 || pair_mode == 3) { D.scap = std::min(D.scap, 4096); D.scap2 = 0; }
   if (const char* e = gm_tune("GM_SCAP")) D.scap = std::min(16384, std::max(64, pow2ceil(atoi(e))));
   if (const char* e = gm_tune("GM_SCAP2")) { if (D.scap2) D.scap2 = std::min(D.scap, std::max(64, pow2ceil(atoi(e)))); }
@@ -1681,8 +1683,8 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
     Job* jp = J.get();
     J->th = std::thread(run_job, jp);
     jobs.push_back(std::move(J));
-    if (timeline) fprintf(stderr, "[timeline] t %8.2f  n %7d  fronts %6.2f  back %6.2f  join-wait %6.2f  spawn %5.2f  (K1 %.2f ms)\n",
-                          tl_a - tl0, n, tl_b - tl_a, tl_c - tl_b, tl_e - tl_d, now_ms() - tl_e, lk);
+    if (timeline) fprintf(stderr, "[timeline] t %8.2f  n %7d  fronts %6.2f  back %6.2f  join-wait %6.2f  spawn %5.2f  (K1 %.2f ms, %u read-strands through the heavy tier)\n",
+                          tl_a - tl0, n, tl_b - tl_a, tl_c - tl_b, tl_e - tl_d, now_ms() - tl_e, lk, s->h_pin[cur]);
     base += n; idx++;
   }
   const double tl_f = now_ms();
