@@ -338,7 +338,15 @@ static void slot_free(HostSlot& h) {
   h = HostSlot();
 }
 
+// A grow-only pinned host buffer that stands in for a std::vector as the target of a device-to-host copy (a copy into pageable memory is staged and blocks the caller)
+template <class T> struct GmPinVec {
+  T* p = nullptr; size_t cap = 0, n = 0;
+  int resize(size_t k) { n = k; void* q = p; const int rc = slot_reserve(&q, &cap, k * sizeof(T)); p = (T*)q; return rc; }
+  T* data() { return p; } const T* data() const { return p; } T& operator[](size_t i) { return p[i]; } const T& operator[](size_t i) const { return p[i]; } size_t size() const { return n; }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; n = 0; }
+};
 struct gm_session {
+  GmPinVec<GmFullRes> pin_res[4]; GmPinVec<uint8_t> pin_ops[4];   // paired path: results of the pairs' pass 2 (0, 1: the mates) and of the half-paired rescue (2, 3)
   gm_session* twin = nullptr;                     // a second session on the same index with the same parameters, made by the file entry the first time a file has more than one
                                                   // chunk: it maps every other chunk, so that a chunk's tail runs under the next chunk's lookups (freed with this one)
   const gm_index* ix = nullptr;
@@ -608,6 +616,8 @@ extern "C" void gm_session_free(gm_session_t* s) {
   if (!s) return;
   if (s->twin) { gm_session_free(s->twin); s->twin = nullptr; }
   (void)hipSetDevice(s->ix->device);
+  for (auto& v : s->pin_res) v.release();
+  for (auto& v : s->pin_ops) v.release();
   free_buffers(s->set[0]); free_buffers(s->set[1]); free_buffers(s->set2[0]); free_buffers(s->set2[1]);
   for (auto& h : s->slot) slot_free(h);
   if (s->d_qtab) (void)hipFree(s->d_qtab);
