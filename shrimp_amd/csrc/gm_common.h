@@ -147,6 +147,11 @@ struct GmFullRes {
 // complement_base as sixteen nibbles (ref: util.h:125-151): entry c = the complement of code c; in an RNA sequence the complement of A is U (code 4), not T
 __host__ __device__ __forceinline__ uint64_t gm_cmpl_tab(bool rna) { return 0xFBCDE56879A00123ull + (rna ? 1ull : 0ull); }
 
+#ifdef GM_NO_READ_RNA
+#define GM_READ_RNA(ix, rd) false
+#else
+#define GM_READ_RNA(ix, rd) ((ix).read_rna && (ix).read_rna[rd])      // the read's own RNA flag (letter space), see GmIndexDev
+#endif
 #define GM_SEAM_RNA 0x100             // single-call seams (sw_vector / sw_gapless / sw_full_cs): is_rna rides in bit 8 of the primer-letter word handed to the kernel
 
 // 4-bit code i of strand st of a packed read.  Letter space: strand 1 is the reverse complement (ref: util.c:540-596).
