@@ -16,8 +16,10 @@
  * parameter lists (for drop-in linking) and are thin wrappers over a batch of one.
  *
  * Errors: integer return codes (0 = ok, <0 = GM_E_*); nothing throws across the ABI.
- * Threading: one host thread per gm_session; a session owns its HIP streams on one device.  Mapping calls of different sessions on the SAME device take turns
- * (the lookup kernels keep per-device scratch); sessions on different devices run side by side.
+ * Threading: one host thread per gm_session; a session owns its HIP streams on one device.  TWO mapping calls (of two sessions) may be in flight on the SAME device --
+ * the lookup kernels' per-device scratch exists twice -- a third waits for one of them to return; sessions on different devices run side by side.  The unpaired file entry
+ * uses this itself: a file of more than one chunk is mapped by the session and a twin of it (same index and parameters, made on first use, freed with the session) on two
+ * threads, so that one chunk's tail runs under the next chunk's lookups (GM_FILE_ONE_SESSION=1 in the environment keeps it to the one session).
  */
 #ifndef GMAPPER_HIP_H
 #define GMAPPER_HIP_H
