@@ -196,6 +196,14 @@ int gmo_sw_full_cs_mode(const uint32_t* genome_ls, int goff, int glen, const uin
   return 0;
 }
 
+// sw_gapless with the scores sw_gapless_setup got (colour space: `mismatch` is what f1_setup hands over, match + crossover)
+int gmo_sw_gapless(const uint32_t* genome, int glen, const uint32_t* read, int rlen, int g_idx, int r_idx, const uint32_t* genome_ls, int init_bp, int is_rna, int match, int mismatch) {
+  Params P = default_params();
+  P.match_score = match;
+  if (genome_ls) P.crossover_score = mismatch - match; else P.mismatch_score = mismatch;
+  return sw_gapless(P, genome, glen, read, rlen, g_idx, r_idx, genome_ls, init_bp, is_rna != 0);
+}
+
 // the same two functions with is_rna set (what gmapper passes for a genome whose last contig is RNA, ref: genome.c:1063-1064): U reads as T in lstocs, cstols hands back U for T
 int gmo_sw_vector_cs_rna(const uint32_t* genome_cs, int goff, int glen, const uint32_t* read, int rlen, const uint32_t* genome_ls, int initbp) {
   Params P = default_params();

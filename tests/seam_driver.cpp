@@ -64,11 +64,13 @@ static std::vector<uint32_t> words(const std::string& t) {
 }
 static const char* str(const char* s) { return (s && s[0]) ? s : "-"; }
 
+static bool g_is_rna = false;
 int main() {
   std::string line;
   while (std::getline(std::cin, line)) {
     std::istringstream in(line); std::string op; in >> op;
-    if (op == "setup_v") { int col, mm; in >> col >> mm; if (sw_vector_setup(1400, 1000, -33, -7, -33, -3, 10, mm, col, true)) return 3; }
+    if (op == "rna") { int v; in >> v; g_is_rna = v != 0; }      // the is_rna argument of the calls that follow (sw_vector / sw_gapless / sw_full_cs)
+    else if (op == "setup_v") { int col, mm; in >> col >> mm; if (sw_vector_setup(1400, 1000, -33, -7, -33, -3, 10, mm, col, true)) return 3; }
     else if (op == "setup_f_ls") { if (sw_full_ls_setup(1400, 1000, -33, -7, -33, -3, 10, -15, true, 8)) return 3; }
     else if (op == "setup_f_cs") { if (sw_full_cs_setup(1400, 1000, -33, -7, -33, -3, 10, -24, -20, true, 8, 0)) return 3; }
     else if (op == "setup_g") { int m, mm; in >> m >> mm; if (sw_gapless_setup(m, mm, true)) return 3; }
@@ -83,11 +85,11 @@ int main() {
     } else if (op == "C") {
       int goff, glen, rlen, ib; std::string gc, gl, r; in >> goff >> glen >> rlen >> ib >> gc >> gl >> r;
       auto gcw = words(gc), glw = words(gl), rw = words(r);
-      printf("C %d\n", sw_vector(gcw.data(), goff, glen, rw.data(), rlen, glw.data(), ib, false));
+      printf("C %d\n", sw_vector(gcw.data(), goff, glen, rw.data(), rlen, glw.data(), ib, g_is_rna));
     } else if (op == "G") {
       int glen, rlen, gi, ri, ib; std::string g, r, gl; in >> glen >> rlen >> gi >> ri >> ib >> g >> r >> gl;
       auto gw = words(g), rw = words(r); std::vector<uint32_t> glw; if (gl != "-") glw = words(gl);
-      printf("G %d\n", sw_gapless(gw.data(), glen, rw.data(), rlen, gi, ri, gl != "-" ? glw.data() : nullptr, ib, false));
+      printf("G %d\n", sw_gapless(gw.data(), glen, rw.data(), rlen, gi, ri, gl != "-" ? glw.data() : nullptr, ib, g_is_rna));
     } else if (op == "F") {
       int goff, glen, rlen, rv; struct anchor a; memset(&a, 0, sizeof a); std::string g, r;
       in >> goff >> glen >> rlen >> a.x >> a.y >> a.length >> a.width >> rv >> g >> r; a.weight = 2;
@@ -106,7 +108,7 @@ int main() {
       if (op == "X" || op == "Y") { in >> xs; const char* p = xs.c_str(); while (*p) { char* e; xv.push_back((int)strtol(p, &e, 10)); p = e; if (*p == ',') p++; } }
       auto glw = words(gl), rw = words(r);
       struct sw_full_results f; memset(&f, 0, sizeof f);
-      sw_full_cs(glw.data(), goff, glen, rw.data(), rlen, ib, thresh, &f, rv != 0, false, &a, 1, (op == "L" || op == "Y") ? 1 : 0, xv.empty() ? nullptr : xv.data());
+      sw_full_cs(glw.data(), goff, glen, rw.data(), rlen, ib, thresh, &f, rv != 0, g_is_rna, &a, 1, (op == "L" || op == "Y") ? 1 : 0, xv.empty() ? nullptr : xv.data());
       if (op != "P") {
         printf("%s %d %d %d %d %d %d %d %d %d %d %s %s\n", op.c_str(), f.score, f.read_start, f.rmapped, f.genome_start, f.gmapped, f.matches, f.mismatches, f.insertions, f.deletions,
                f.crossovers, str(f.dbalign), str(f.qralign));

@@ -1023,6 +1023,16 @@ def test_mangled_seams_on_every_known_answer(gm, tmp_path):
         w, db, qr = r[4], r[5], r[6]
         req.append(r[0] + " " + s_args(r[:7]) + " " + ",".join(str(int(x)) for x in r[7]))
         want.append(r[0] + " " + " ".join(str(x) for x in w) + " %s %s" % ((db or b"-").decode(), (qr or b"-").decode()) if w[0] != 0 else None)
+    req.append("rna 1")                                             # is_rna = true on RNA genomes (sw_kat_cs_rna: the reference's own answers, global and local)
+    for r in oa.load_kat_cs("sw_kat_cs_rna.txt.gz"):
+        if r[0] == "C":
+            _, goff, glen, rlen, initbp, gcs, gls, rd, score = r
+            req.append("C %d %d %d %d %s %s %s" % (goff, glen, rlen, initbp, _hexw(gcs), _hexw(gls), _hexw(rd))); want.append("C %d" % score)
+        else:
+            w, db, qr = r[4], r[5], r[6]
+            req.append(r[0] + " " + s_args(r))
+            want.append(r[0] + " " + " ".join(str(x) for x in w) + " %s %s" % ((db or b"-").decode(), (qr or b"-").decode()) if w[0] != 0 else None)
+    req.append("rna 0")
     with gzip.open(os.path.join(oa.ROOT, "tests", "golden", "sw_kat_post.txt.gz"), "rt") as f: post = [l.split() for l in f if l.strip()]
     K = [t for t in post if t[0] == "K"][0][1:]
     nP = 0
@@ -1038,8 +1048,12 @@ def test_mangled_seams_on_every_known_answer(gm, tmp_path):
         for t in gl:
             if (t[5] != "-1") != bool(half): continue
             req.append(" ".join(t[:-1])); want.append("G " + t[-1]); nG += 1
+    with gzip.open(os.path.join(oa.ROOT, "tests", "golden", "sw_kat_gapless_rna.txt.gz"), "rt") as f: glr = [l.split() for l in f if l.startswith("G ")]
+    req.append("rna 1")                                             # sw_gapless with is_rna = true on RNA genomes (the forced first colour, ref: sw-gapless.c:84)
+    for t in glr: req.append(" ".join(t[:-1])); want.append("G " + t[-1]); nG += 1
+    req.append("rna 0")
     req.append("stats")
-    assert nV >= 1500 and nF >= 2990 and len(srecs) >= 1400 and nP >= 1800 and nG >= 2400
+    assert nV >= 1500 and nF >= 2990 and len(srecs) >= 1400 and nP >= 1800 and nG >= 3000
     p = subprocess.run([exe], input=("\n".join(req) + "\n").encode(), capture_output=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-2000:]
     got = p.stdout.decode().split("\n")
@@ -1053,7 +1067,8 @@ def test_mangled_seams_on_every_known_answer(gm, tmp_path):
     st = [int(x) for x in got[len(want)].split()[1:]]
     # the *_stats entries (ref: gmapper.c:734-745 reads them): every set-up above resets its counters, so each shows the calls since its last set-up
     nq = sum(1 for t in post if t[0] == "P" and t[2] == "1")
-    assert st == [700, nG // 2, nF, len(srecs) + len(lrecs) + len(xrecs) + nP, nq], st
+    nrc = sum(1 for r in oa.load_kat_cs("sw_kat_cs_rna.txt.gz") if r[0] == "C"); nrs = sum(1 for r in oa.load_kat_cs("sw_kat_cs_rna.txt.gz") if r[0] != "C")
+    assert st == [700 + nrc, (nG - len(glr)) // 2 + len(glr), nF, len(srecs) + len(lrecs) + len(xrecs) + nrs + nP, nq], st
 
 
 def test_full_size_genome_vs_oracle(gm, oracle_lib):

@@ -425,3 +425,23 @@ def test_oracle_colour_space_kernels_with_is_rna_match_reference_known_answers(o
                 assert list(out) == want and dba.value == db and qra.value == qr, (list(out), want, dba.value, db, qra.value, qr)
             ns += 1
     assert nc >= 300 and ns >= 1200
+
+
+def test_oracle_sw_gapless_matches_reference_known_answers(oracle_lib):
+    """S1's ungapped filter: the restated sw_gapless (ref: sw-gapless.c:57-117) against the reference's own function -- 2 400 letter- and colour-space answers, and 600
+    colour-space answers on RNA genomes with is_rna = true (the forced first colour through lstocs with U read as T, :84)"""
+    import ctypes as C, gzip
+    L = oa.load(); u32p = C.POINTER(C.c_uint32)
+    words = lambda s: np.array([int(x, 16) for x in s.split(",")], dtype=np.uint32)
+    n = {}
+    for name, rna in (("sw_kat_gapless.txt.gz", 0), ("sw_kat_gapless_rna.txt.gz", 1)):
+        with gzip.open(os.path.join(oa.ROOT, "tests", "golden", name), "rt") as f:
+            for line in f:
+                t = line.split()
+                if t[0] != "G": continue
+                glen, rlen, g_idx, r_idx, init_bp = (int(x) for x in t[1:6])
+                g = words(t[6]); r = words(t[7]); gl = None if t[8] == "-" else words(t[8])
+                got = L.gmo_sw_gapless(g.ctypes.data_as(u32p), glen, r.ctypes.data_as(u32p), rlen, g_idx, r_idx, None if gl is None else gl.ctypes.data_as(u32p), init_bp, rna,
+                                       10, -15 if gl is None else -24)
+                assert got == int(t[9]), (name, t[1:6], got, t[9]); n[name] = n.get(name, 0) + 1
+    assert n["sw_kat_gapless.txt.gz"] >= 2400 and n["sw_kat_gapless_rna.txt.gz"] >= 600

@@ -391,6 +391,10 @@ def post_kat_cases():
     with gzip.open(os.path.join(OUT, "sw_kat_gapless.txt.gz"), "wb", compresslevel=9) as f:
         f.write(kat)
     print("sw_kat_gapless:", kat.count(b"\nG ") + 1, "sw_gapless answers")
+    katr = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_kat_gapless"), "600", "rna"], capture_output=True, check=True).stdout
+    with gzip.open(os.path.join(OUT, "sw_kat_gapless_rna.txt.gz"), "wb", compresslevel=9) as f:
+        f.write(katr)
+    print("sw_kat_gapless_rna:", katr.count(b"\nG ") + 1, "colour-space sw_gapless answers on RNA genomes with is_rna = true")
 
 
 def run_cs_case(name, contigs, reads, extra=()):
