@@ -330,8 +330,8 @@ def test_one_session_through_every_mode_in_turn(gm):
 
 
 def test_two_sessions_on_one_device_from_two_threads(gm):
-    """two sessions of one index mapping at the same time from two host threads (ctypes drops the GIL during the calls): the lookup kernels' per-device scratch is
-    shared, so the library makes such calls take turns -- both outputs equal the golden, repeatedly"""
+    """two sessions mapping at the same time from two host threads (ctypes drops the GIL during the calls): the lookup kernels' per-device scratch exists twice and
+    the library hands a set to each call in flight -- both outputs equal the golden, repeatedly"""
     import threading
     contigs, reads, sam = oa.load_golden("cfg2s_100bp_2Mbp")
     g = oa.load_golden_pairs("cfg5s_2x150_1Mbp")
@@ -347,6 +347,33 @@ def test_two_sessions_on_one_device_from_two_threads(gm):
     s1.close(); s2.close(); ix.close(); ixp.close()
     assert len(out["a"]) == 4 and all(o == sam for o in out["a"])
     assert len(out["b"]) == 4 and all(o == g["sam"] for o in out["b"])
+
+
+def test_three_threads_share_the_two_scratch_sets_of_a_device(gm):
+    """three sessions mapping at once through k_lookup_v5 with tables so small that read-strands fall back (the fall-back lists are the per-device scratch): two calls are
+    in flight, the third waits for a set -- every output equals the golden, repeatedly"""
+    import threading
+    contigs, reads, sam = oa.load_golden("cfg2s_100bp_2Mbp")
+    env = {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_LSW": "11", "GM_K5_CANDLIMIT": "40"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ix = gm.Index(contigs)
+        ss = [gm.Session(ix, max_batch_reads=1024) for _ in range(3)]
+        outs = [[] for _ in ss]
+        def run(i):
+            for _ in range(3): outs[i].append(oa.sam_header(contigs) + ss[i].map_reads(reads))
+        th = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+        for x in th: x.start()
+        for x in th: x.join()
+        kern = gm.lib().gm_last_lookup_kernel().decode()
+        for s in ss: s.close()
+        ix.close()
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    for o in outs: assert len(o) == 3 and all(x == sam for x in o)
 
 
 def test_n1_on_noisy_reads_matches_reference_golden(gm):
