@@ -346,7 +346,8 @@ template <class T> struct GmPinVec {
   void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; n = 0; }
 };
 struct gm_session {
-  GmPinVec<GmFullRes> pin_res[4]; GmPinVec<uint8_t> pin_ops[4];   // paired path: results of the pairs' pass 2 (0, 1: the mates) and of the half-paired rescue (2, 3)
+  GmPinVec<GmFullRes> pin_res[8]; GmPinVec<uint8_t> pin_ops[8];   // paired path: results of the pairs' pass 2 (0, 1: the mates) and of the half-paired rescue (2, 3); 4-7: the same for
+                                                                  // odd sub-batches (the output stage of a sub-batch reads them on its own thread while the next one's copies arrive)
   gm_session* twin = nullptr;                     // a second session on the same index with the same parameters, made by the file entry the first time a file has more than one
                                                   // chunk: it maps every other chunk, so that a chunk's tail runs under the next chunk's lookups (freed with this one)
   const gm_index* ix = nullptr;
