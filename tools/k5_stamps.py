@@ -34,3 +34,4 @@ for nk in (os.environ.get("GM_STAMPS_NK_SWEEP", "").split(",") if os.environ.get
       for nm, x in zip(names, v): print("%-20s %6.2f %%  %8.0f ticks per read-strand" % (nm, 100.0 * x / tot, x / (2.0 * n)))
       for nm, x in zip(["  set-up: to the first barrier", "  set-up: k-mers ahead", "  region table: main loop", "  rules: main loop (2a)"], v[8:12]): print("%-32s %8.0f ticks per read-strand (not in the phase above)" % (nm, x / (2.0 * n)))
       print("candidates per read-strand %.1f, fallbacks %d of %d" % (v[6] / (2.0 * n), v[7], 2 * n))
+      if v[12]: print("pass A, first of two runs (K5_ABL_A_TWICE: lists from HBM; the line 'pass A' above is then the second run, lists from the caches) %8.0f ticks per read-strand" % (v[12] / (2.0 * n)))
