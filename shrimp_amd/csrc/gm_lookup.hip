@@ -522,6 +522,145 @@ k_lookup_bkt(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// Bucket mode, persistent form (round 4): the same lookup as k_lookup_bkt with the workgroups resident -- each strides through read-strands -- and the probes issued ONE
+// READ-STRAND AHEAD: a thread keeps its k-mer slot (seed, offset: span, mask and bucket base in registers), works out the map index of the NEXT read-strand from a second
+// code buffer and has its 64-byte bucket on the way while the marks and tests of the current one run out of the registers loaded an iteration earlier.  (One workgroup per
+// read-strand paid the whole chain -- codes, barrier, map index, bucket, marks, barrier, tests -- per launch slot: ~25 us each at eight workgroups a CU.)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512)
+k_lookup_bkt_p(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words, int max_n_kmers,
+               int NL, int bm_words, uint64_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt, int scap_all,
+               uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, int heavy_cap,
+               unsigned long long* __restrict__ stats, uint32_t* __restrict__ surv_seg) {
+  extern __shared__ __align__(16) uint32_t smem[];
+  __shared__ uint32_t n_surv;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int cwords = (((read_len + 3) / 4) + 3) & ~3;                 // words of one code buffer
+  uint8_t* const codes0 = (uint8_t*)smem; uint8_t* const codes1 = (uint8_t*)(smem + cwords);
+  uint32_t* const bm = smem + 2 * cwords;
+  const int rb = ix.region_bits;
+  const uint32_t rmask = (1u << rb) - 1u, ovl = (uint32_t)ix.region_overlap;
+  const uint32_t scap = (uint32_t)scap_all;
+  const int n_rs = 2 * n_reads;
+  // this thread's k-mer slot, the same for every read-strand
+  const int sn = tid / max_n_kmers, i = tid - sn * max_n_kmers;
+  int span = 0; uint64_t mask = 0; const uint32_t* bkt = nullptr; const uint32_t* dirp = nullptr; const uint32_t* posp = nullptr;
+  bool slot = false;
+  if (tid < NL && sn < ix.n_seeds) {
+    span = ix.seed[sn].span; mask = ix.seed[sn].mask; bkt = ix.seed[sn].bkt; dirp = ix.seed[sn].dir; posp = ix.seed[sn].pos;
+    slot = i >= ix.colour && i + span <= read_len;
+  }
+  const uint32_t y = (uint32_t)i;
+  auto fill_codes = [&](const int rs, uint8_t* cb) {
+    if (rs >= n_rs) return;
+    const int rd = rs >> 1, st = rs & 1;
+    const uint32_t* rw = reads + (size_t)rd * read_words;
+    const bool rna = ix.read_rna && ix.read_rna[rd];
+    for (int k = tid; k < read_len; k += blockDim.x) cb[k] = (uint8_t)gm_read_code(rw, read_len, st ^ ix.cs_flip, ix.colour, k, rna);
+  };
+  struct Probe { uint4 q0, q1, q2, q3; uint32_t mapidx; };
+  auto fetch = [&](const int rs, const uint8_t* cb, Probe& P) {      // the bucket of this thread's k-mer of read-strand rs: loads issued, used an iteration later
+    P.q0 = make_uint4(0, 0, 0, 0); P.q1 = P.q0; P.q2 = P.q0; P.q3 = P.q0; P.mapidx = 0;
+    if (slot && rs < n_rs) {
+      P.mapidx = gm_mapidx(ix, mask, span, cb + i);
+      const uint4* bk = (const uint4*)(bkt + (size_t)P.mapidx * 16);
+      P.q0 = bk[0]; P.q1 = bk[1]; P.q2 = bk[2]; P.q3 = bk[3];
+    }
+  };
+  unsigned long long lk = 0, en = 0;
+  { uint4* bm4 = (uint4*)bm; for (int w = tid; w < (bm_words >> 2); w += blockDim.x) bm4[w] = make_uint4(0, 0, 0, 0); }
+  if (tid == 0) n_surv = 0;
+  fill_codes((int)blockIdx.x, codes0);
+  __syncthreads();
+  Probe cur; fetch((int)blockIdx.x, codes0, cur);
+  int it = 0;
+  for (int rs = blockIdx.x; rs < n_rs; rs += gridDim.x, it++) {
+    uint8_t* const cb_next = (it & 1) ? codes0 : codes1;
+    const int rs_next = rs + (int)gridDim.x;
+    fill_codes(rs_next, cb_next);
+    __syncthreads();                                     // the next read-strand's codes are in; the bitmap is clear, n_surv is 0
+    Probe nxt; fetch(rs_next, cb_next, nxt);
+    // ---- the current read-strand, from the registers loaded an iteration ago ----
+    uint64_t* out = surv + (size_t)rs * scap_all;
+    uint32_t len = 0, lb = 0; bool longl = false;
+    if (slot) {
+      lk++;
+      len = cur.q0.x;
+      if (len > ix.list_cutoff) len = 0;                 // ref: mapping.c:497 (skipped, not deleted)
+      if (len > 15u) { longl = true; lb = dirp[cur.mapidx]; }
+      en += len;
+    }
+    const uint32_t p[15] = {cur.q0.y, cur.q0.z, cur.q0.w, cur.q1.x, cur.q1.y, cur.q1.z, cur.q1.w, cur.q2.x, cur.q2.y, cur.q2.z, cur.q2.w, cur.q3.x, cur.q3.y, cur.q3.z, cur.q3.w};
+    const uint32_t nreg = longl ? 0u : len;
+#pragma unroll
+    for (int u = 0; u < 15; u++)
+      if ((uint32_t)u < nreg) {
+        const uint32_t reg = p[u] >> rb;
+        k1_mark(bm, reg + 1u);
+        if (((p[u] & rmask) < ovl) && reg > 0) k1_mark(bm, reg);
+      }
+    unsigned long long lm = __ballot(longl);
+    while (lm) {                                         // long lists of this wave, one at a time, 64 entries per step
+      const int l = __builtin_ctzll(lm); lm &= lm - 1;
+      const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)lb, l), n = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
+      const uint32_t* pl = ix.seed[__builtin_amdgcn_readlane(sn, l)].pos;
+      for (uint32_t q = lane; q < n; q += 64) {
+        const uint32_t pv = pl[b + q]; const uint32_t reg = pv >> rb;
+        k1_mark(bm, reg + 1u);
+        if (((pv & rmask) < ovl) && reg > 0) k1_mark(bm, reg);
+      }
+    }
+    __syncthreads();
+    uint32_t alive = 0;
+#pragma unroll
+    for (int u = 0; u < 15; u++)
+      if ((uint32_t)u < nreg) {
+        const uint32_t reg = p[u] >> rb;
+        const bool strip = ((p[u] & rmask) < ovl) && reg > 0;
+        if (k1_has2(bm, reg + 1u) || (strip && k1_has2(bm, reg))) alive |= 1u << u;
+      }
+    if (alive) {
+      uint32_t sl = atomicAdd(&n_surv, (uint32_t)__popc(alive));
+#pragma unroll
+      for (int u = 0; u < 15; u++)
+        if (alive & (1u << u)) { if (sl < scap) out[sl] = ((uint64_t)p[u] << 32) | ((uint64_t)y << 16) | (uint32_t)sn; sl++; }
+    }
+    lm = __ballot(longl);
+    while (lm) {
+      const int l = __builtin_ctzll(lm); lm &= lm - 1;
+      const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)lb, l), n = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
+      const int lsn = __builtin_amdgcn_readlane(sn, l); const uint32_t ly = (uint32_t)__builtin_amdgcn_readlane((int)y, l);
+      const uint32_t* pl = ix.seed[lsn].pos;
+      for (uint32_t q = lane; q < n; q += 64) {
+        const uint32_t pv = pl[b + q]; const uint32_t reg = pv >> rb;
+        const bool strip = ((pv & rmask) < ovl) && reg > 0;
+        if (k1_has2(bm, reg + 1u) || (strip && k1_has2(bm, reg))) {
+          const uint32_t sl = atomicAdd(&n_surv, 1u);
+          if (sl < scap) out[sl] = ((uint64_t)pv << 32) | ((uint64_t)ly << 16) | (uint32_t)lsn;
+        }
+      }
+    }
+    __syncthreads();                                     // every test has read the bitmap, every survivor is counted
+    if (tid == 0) {
+      const uint32_t ns = n_surv;
+      surv_cnt[rs] = ns;
+      if (surv_seg) surv_seg[(size_t)rs * 2 + 1] = ns;    // one slab
+      GS_ADD(stats, GS_SURVIVORS, ns);
+      if (ns > scap) {
+        const uint32_t hs = atomicAdd(heavy_cnt, 1u);
+        if (hs < (uint32_t)heavy_cap) heavy_list[hs] = (uint32_t)rs; else GS_ADD(stats, GS_OVERFLOW_SURV, 1ull);
+      }
+      n_surv = 0;
+    }
+    { uint4* bm4 = (uint4*)bm; for (int w = tid; w < (bm_words >> 2); w += blockDim.x) bm4[w] = make_uint4(0, 0, 0, 0); }      // (visible behind the barrier at the next top)
+    cur = nxt;
+  }
+  (void)posp;
+  for (int d = GM_WAVE / 2; d > 0; d >>= 1) { lk += __shfl_down(lk, d); en += __shfl_down(en, d); }
+  if (lane == 0) { GS_ADD(stats, GS_LOOKUPS, lk); GS_ADD(stats, GS_ENTRIES, en); }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K1 v3 (large genomes: several slabs, list slices of tens of entries).  Same slab sweep and the same
 // exact region counters as k_lookup; what differs is the lane mapping and the amount of code per entry.
 // rocprofv3 on the 3 Gbp workload showed the lane-per-list kernel neither HBM- nor L2-bound but
@@ -1315,7 +1454,17 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
   if (bkt) {
     g_k1_name = "k_lookup_bkt";
     const size_t lds_b = (size_t)((((read_len + 3) / 4) + 3) & ~3) * 4 + (size_t)bm_words * 4;
-    hipLaunchKernelGGL(k_lookup_bkt, dim3(n_reads * 2), dim3((NL + 63) & ~63), lds_b, stream, ix, d_reads, n_reads, read_len, read_words,
+    // the persistent form (probes one read-strand ahead) unless GM_BKT_V1 asks for one workgroup per read-strand; its grid: what fits a CU by waves and LDS, times the CUs
+    const int threads_b = (NL + 63) & ~63;
+    const size_t lds_p = lds_b + (size_t)((((read_len + 3) / 4) + 3) & ~3) * 4;
+    int dev_b = 0, cus_b = 256; (void)hipGetDevice(&dev_b); if (hipDeviceGetAttribute(&cus_b, hipDeviceAttributeMultiprocessorCount, dev_b) != hipSuccess || cus_b < 1) cus_b = 256;
+    int per_cu = 0;                                              // resident workgroups per CU (registers, waves, LDS): the persistent grid is exactly that
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_lookup_bkt_p, threads_b, lds_p) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (gm_tune("GM_BKT_V1") || threads_b > 512 || lds_p > 64 * 1024)
+    hipLaunchKernelGGL(k_lookup_bkt, dim3(n_reads * 2), dim3(threads_b), lds_b, stream, ix, d_reads, n_reads, read_len, read_words,
+                       max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, d_surv_seg);
+    else
+    hipLaunchKernelGGL(k_lookup_bkt_p, dim3(std::min(n_reads * 2, cus_b * per_cu)), dim3(threads_b), lds_p, stream, ix, d_reads, n_reads, read_len, read_words,
                        max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, d_surv_seg);
   } else if (!all && ix.n_slabs > 1 && NL < 65536 && !gm_tune("GM_K1_V2") && !gm_tune("GM_K1_V3") && k4_launch(ix, d_reads, n_reads, read_len, read_words, max_n_kmers, NL, d_surv, d_surv_cnt, scap,
                                                                                                    d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, stream, d_surv_seg, lds, bm_words)) {
