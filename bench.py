@@ -55,7 +55,24 @@ def host_threads_for(local_world: int) -> int:
     """host threads per rank for the finalisation (selection, MAPQ, SAM text): this rank's share of the cores the job may run on"""
     try: n_cores = len(os.sched_getaffinity(0))
     except Exception: n_cores = os.cpu_count() or 1
-    return max(1, min(32, n_cores // max(1, local_world)))
+    return max(1, min(32, n_cores // max(1, local_world)))      # (not cut to the CPU quota: the finalisation comes in bursts, see gm_usable_cores in gm_host.hip)
+
+
+def usable_cores() -> int:
+    """the cores this job may really use: the affinity mask, cut to the container's CPU quota where there is one (cgroup v2 cpu.max, v1 cfs quota) -- a one-GPU box of
+    the pool shows 256 processors and grants 16"""
+    try: n = len(os.sched_getaffinity(0))
+    except Exception: n = os.cpu_count() or 1
+    quota = period = -1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max": quota, period = int(q), int(p)
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except Exception: pass
+    if quota > 0 and period > 0: n = min(n, max(1, -(-quota // period)))
+    return n
 
 
 def launch_ranks(n: int, argv, capture: bool = False, timeout=None):
@@ -315,13 +332,13 @@ def main():
             # the CPU restatement (oracle, "port") on this box's host cores over a bounded sample of the same workload -- on as many threads as the GPU run's
             # host side used (this process's CPU affinity share), so that the two numbers sit on the same cores
             from tests import oracle_api as oa
-            ncores = int(os.environ.get("GM_CPU_THREADS", host_threads))
+            ncores = int(os.environ.get("GM_CPU_THREADS", min(host_threads, usable_cores())))      # the CPU leg runs flat out: its threads = the cores the container grants
             oa.load().gmo_set_threads(ncores)
             t0 = time.time(); o = oa.Session(contigs, opts="colour=1" if kind == "cs" else None); t_oidx = time.time() - t0
             cdt, sam = oracle_sample(oa, o, kind, sample, ncores)
             if kind == "cs": o.close()
             else: o_ls = o                                   # the letter-space oracle index also serves the cfg5 entry below
-            out["cpu_baseline"] = {"value": n_sample / cdt, "unit": unit, "cores": ncores, "gpu_run_host_threads": host_threads, "kind": "port",
+            out["cpu_baseline"] = {"value": n_sample / cdt, "unit": unit, "cores": ncores, "gpu_run_host_threads": host_threads, "cpu_quota_cores": usable_cores(), "kind": "port",
                                    "sample": "%d %s of the same workload (same genome, same error model), oracle/gm_oracle.hpp with OpenMP over reads; "
                                              "index build %.1fs not included" % (n_sample, "pairs" if kind == "pairs" else "reads", t_oidx)}
             # the reference binary itself does not travel; its speed relative to the port was measured in the build container
