@@ -664,9 +664,12 @@ struct FHit {            // one pass-2 candidate on the host (read_hit + sw_full
   std::string db, qr, qual; int cs_match = 0, cs_mismatch = 0, cs_xover = 0;   // colour space: dbalign / qralign and the counts post_sw leaves (ref: sw-post.c:531-565)
 };
 
-static inline char* put_uint(char* p, unsigned long long v) {
+static inline char* put_uint(char* p, unsigned long long v) {      // two digits per division (a 64-bit division is ~25 cycles; a record prints half a dozen numbers)
+  static const char D2[201] = "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+  if (v < 10) { *p++ = (char)('0' + v); return p; }
   char tmp[24]; int n = 0;
-  do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+  if (v <= 0xFFFFFFFFull) { uint32_t w = (uint32_t)v; while (w >= 100) { const uint32_t r = w % 100; w /= 100; tmp[n++] = D2[2 * r + 1]; tmp[n++] = D2[2 * r]; } if (w >= 10) { tmp[n++] = D2[2 * w + 1]; tmp[n++] = D2[2 * w]; } else tmp[n++] = (char)('0' + w); }
+  else { while (v >= 100) { const unsigned r = (unsigned)(v % 100); v /= 100; tmp[n++] = D2[2 * r + 1]; tmp[n++] = D2[2 * r]; } if (v >= 10) { tmp[n++] = D2[2 * v + 1]; tmp[n++] = D2[2 * v]; } else tmp[n++] = (char)('0' + v); }
   while (n) *p++ = tmp[--n];
   return p;
 }
@@ -690,9 +693,22 @@ static int cmp_gen_end(const FHit* a, const FHit* b) {     // ref: mapping.c:149
   if (a->r->gen_st != b->r->gen_st) return a->r->gen_st - b->r->gen_st;
   return (-a->r->genome_start - a->r->rmapped + a->r->n_del - a->r->n_ins) - (-b->r->genome_start - b->r->rmapped + b->r->n_del - b->r->n_ins);
 }
+// A stable sort of the handful of mappings a read has: insertion sort below 24 elements (the same order as any stable sort; std::stable_sort asks the allocator for a merge
+// buffer at every call -- three calls a read were a third of the finalisation's cycles), the library's merge sort above.
+template <class It, class Less> static inline void gm_small_stable_sort(It b, It e, Less less) {
+  const auto n = e - b;
+  if (n < 2) return;
+  if (n > 24) { std::stable_sort(b, e, less); return; }
+  for (It i = b + 1; i != e; ++i) {
+    auto x = *i; It j = i;
+    while (j != b && less(x, *(j - 1))) { *j = *(j - 1); --j; }
+    *j = x;
+  }
+}
 template <class Cmp>
 static void dedup_pass(std::vector<FHit*>& v, Cmp cmp) {     // ref: mapping.c:1552-1600 (glibc qsort == stable merge sort here)
-  std::stable_sort(v.begin(), v.end(), [&](const FHit* a, const FHit* b) { return cmp(a, b) < 0; });
+  if (v.size() < 2) return;
+  gm_small_stable_sort(v.begin(), v.end(), [&](const FHit* a, const FHit* b) { return cmp(a, b) < 0; });
   size_t i = 0, k = 0, n = v.size();
   while (i < n) {
     int mx = v[i]->pass2_key; size_t mi = i, j = i + 1;
@@ -866,6 +882,31 @@ static void cs_alignment_strings(const uint8_t* bt, const uint8_t* codes, int n,
   }
 }
 
+// -DGM_HOST_PROFILE (diagnostic builds): where the finalisation's cycles go -- rdtsc sums per stage over all worker threads, printed by gm_host_profile_dump()
+#ifdef GM_HOST_PROFILE
+#include <x86intrin.h>
+struct GmHpSlots { unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
+static std::mutex g_hp_m; static std::vector<GmHpSlots*> g_hp_all;
+static GmHpSlots& gm_hp_mine() {      // per thread (the pool's threads live as long as the process): no shared counter is touched per read
+  static thread_local GmHpSlots* mine = nullptr;
+  if (!mine) { mine = new GmHpSlots(); std::lock_guard<std::mutex> lk(g_hp_m); g_hp_all.push_back(mine); }
+  return *mine;
+}
+struct GmHp { unsigned long long t; GmHpSlots& S; GmHp() : t(__rdtsc()), S(gm_hp_mine()) {} void lap(int k) { const unsigned long long n = __rdtsc(); S.v[k] += n - t; t = n; } };
+extern "C" void gm_host_profile_dump(void) {
+  static const char* nm[8] = {"post_sw / FHit build", "dedup + sort", "mapping qualities", "record text", "unaligned record", "reads (count)", "", ""};
+  unsigned long long g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  { std::lock_guard<std::mutex> lk(g_hp_m); for (GmHpSlots* s : g_hp_all) for (int k = 0; k < 8; k++) { g[k] += s->v[k]; s->v[k] = 0; } }
+  unsigned long long tot = 0; for (int k = 0; k < 5; k++) tot += g[k];
+  for (int k = 0; k < 6; k++) { fprintf(stderr, "[host profile] %-22s %14llu%s %5.1f %%\n", nm[k], g[k], k < 5 ? " cycles" : "       ", k < 5 ? 100.0 * g[k] / (tot ? tot : 1) : 0.0); }
+  if (g[5]) fprintf(stderr, "[host profile] %.0f cycles per read\n", (double)tot / (double)g[5]);
+}
+#define GM_HP_DECL GmHp hp_
+#define GM_HP(k) hp_.lap(k)
+#else
+#define GM_HP_DECL do { } while (0)
+#define GM_HP(k) do { } while (0)
+#endif
 struct Finalizer {
   const gm_session* s; int read_len, read_words; const uint32_t* reads;   // host copy of the packed reads of this sub-batch
   const char* const* name_ptr; const int* name_len; long name_base;
@@ -1042,6 +1083,7 @@ struct Finalizer {
   // read_pass2's selection over the n pass-2 results of one read (ref: mapping.c:1628-1750): p2 = final hits in output order
   void select_hits(const GmFullRes* res, const uint8_t* ops, int n, std::vector<FHit>& fh, std::vector<FHit*>& p2) const {
     const gm_params_t& P = s->P;
+    GM_HP_DECL;
     fh.clear(); p2.clear();
     fh.resize(n);
     for (int i = 0; i < n; i++) {
@@ -1049,22 +1091,28 @@ struct Finalizer {
       const double thr = P.sw_full_threshold < 0 ? -P.sw_full_threshold : h.r->score_max * (P.sw_full_threshold / 100.0);
       if (h.score_full >= thr) p2.push_back(&h);                                   // ref: mapping.c:1661 (double compare)
     }
+    GM_HP(0);
     dedup_pass(p2, cmp_gen_start);
     dedup_pass(p2, cmp_gen_end);
-    std::stable_sort(p2.begin(), p2.end(), [](const FHit* a, const FHit* b) { return (b->pass2_key - a->pass2_key) < 0; });   // ref :1479-1482,1678
+    gm_small_stable_sort(p2.begin(), p2.end(), [](const FHit* a, const FHit* b) { return (b->pass2_key - a->pass2_key) < 0; });   // ref :1479-1482,1678
     if ((int)p2.size() > P.num_outputs) p2.resize(P.num_outputs);
     if (P.strata && !p2.empty()) { size_t i = 1; while (i < p2.size() && p2[0]->score_full == p2[i]->score_full) i++; p2.resize(i); }   // ref :1706-1712
     if (P.max_alignments != 0 && (int)p2.size() > P.max_alignments) p2.clear();                                                        // ref :1713-1722
+    GM_HP(1);
   }
 
   // emits the SAM records of read `rd` (local index) into out; returns number of records
   int finalize_read(int rd, const GmFullRes* res, const uint8_t* ops, int ops_stride, int n, std::string& out, std::vector<FHit>& fh, std::vector<FHit*>& p2) const {
     const gm_params_t& P = s->P; const gm_index* ix = s->ix;
     select_hits(res, ops, n, fh, p2);
+    GM_HP_DECL;
+#ifdef GM_HOST_PROFILE
+    hp_.S.v[5]++;
+#endif
     const uint32_t* rw = reads + (size_t)rd * read_words;
     char nbuf[32]; const char* nm; size_t nl;
     if (name_ptr) { nm = name_ptr[rd]; nl = (size_t)name_len[rd]; }
-    else { nl = (size_t)snprintf(nbuf, sizeof nbuf, "r%ld", name_base + rd); nm = nbuf; }
+    else { nbuf[0] = 'r'; nl = (size_t)(put_int(nbuf + 1, (long long)(name_base + rd)) - nbuf); nm = nbuf; }
     // room reserved per record (std::string::resize zero-fills it: a letter-space record writes SEQ + QUAL + fixed fields, a colour-space one also CQ / CS / XX)
     const size_t need = 64 + nl + (P.colour_space ? 8 : 3) * (size_t)read_len + 320;
     // colour space: the read as csfasta text, primer letter + colours ('.' for a skipped cycle), for the CS:Z tag (ref: output.c:451,730)
@@ -1084,6 +1132,7 @@ struct Finalizer {
         if (qual_ptr) { *p++ = '\t'; p = put_str(p, qual_ptr[rd], (size_t)read_len); }      // ref: output.c:419-421 (verbatim)
         else p = put_str(p, "\t*", 2);
         out.resize(p - out.data()); sam_tail(P, out, nullptr, nullptr, nullptr, nullptr);
+        GM_HP(4);
         return 1;
       }
       return 0;
@@ -1108,6 +1157,7 @@ struct Finalizer {
         FHit* best = p2[mx]; p2.assign(1, best);
       }
     }
+    GM_HP(2);
     if (P.output_format) {                                                         // --shrimp-format / --pretty, ref: gmapper/output.c:270-296
       std::string db, qr;
       for (auto* h : p2) {
@@ -1118,7 +1168,13 @@ struct Finalizer {
     }
     for (auto* h : p2) {
       const GmFullRes& r = *h->r;
-      size_t o = out.size(); out.resize(o + need + 12 * (size_t)r.n_ops + ix->names[r.cn].size()); char* p = &out[o];
+      // The record is assembled in a buffer on the stack and appended (its bound -- every CIGAR operation a run of its own -- is ~2 KB for a 250-byte record, and
+      // std::string::resize zero-fills what it adds); a record beyond the buffer grows the string in place as before.
+      const size_t bound = need + 12 * (size_t)r.n_ops + ix->names[r.cn].size();
+      char stage[4096]; const bool staged = bound <= sizeof stage;
+      if (!staged) { const size_t o = out.size(); out.resize(o + bound); }
+      char* p = staged ? stage : &out[out.size() - bound];
+      auto commit = [&](char* e) { if (staged) out.append(stage, (size_t)(e - stage)); else out.resize((size_t)(e - out.data())); };
       const bool rev = r.gen_st == 1;
       const int read_start = r.read_start + 1, read_end = read_start + r.rmapped - 1;
       const int glen = (int)(ix->contig_off[r.cn + 1] - ix->contig_off[r.cn]);
@@ -1174,15 +1230,21 @@ struct Finalizer {
         p = put_str(p, "\tCS:Z:", 6); p = put_csfasta(p);
         p = put_str(p, "\tCM:i:", 6); p = put_int(p, h->cs_xover);
         p = put_str(p, "\tXX:Z:", 6); p = put_str(p, h->qr.data(), h->qr.size());
-        out.resize(p - out.data()); sam_tail(P, out, nullptr, h, &h->db, &h->qr);
+        commit(p); sam_tail(P, out, nullptr, h, &h->db, &h->qr);
         continue;
       }
       // SEQ: read bases in input orientation (aligned part from qralign == the read's own letters), revcomp on '-'
       // (text input: the clipped ends -- local mode only -- keep the file's letters, ref: output.c:326-351,482-533; on the reverse strand the reference's
       // reverse() knows no 'X' / 'U' and exits there, those print as N here)
       auto seq_at = [&](int i) -> char { const int c = (rw[i >> 3] >> ((i & 7) * 4)) & 0xf; return (seq_ptr && (i < read_start - 1 || i >= read_end)) ? seq_from_text(seq_ptr[rd][i]) : CODE2SEQ[c]; };
+      if (!seq_ptr || (read_start == 1 && read_end == read_len)) {                // every base from its code: eight to a word, the reverse strand through the complement's letters
+        static const char RC2SEQ[17] = "TGCANNNNNNNNNNNN";                         // rc_char(CODE2SEQ[c])
+        if (!rev) { for (int i = 0; i < read_len; i += 8) { uint32_t x = rw[i >> 3]; const int m = std::min(8, read_len - i); for (int k = 0; k < m; k++) { *p++ = CODE2SEQ[x & 15u]; x >>= 4; } } }
+        else { for (int i = read_len - 1; i >= 0;) { const uint32_t x = rw[i >> 3]; for (int k = i & 7; k >= 0; k--, i--) *p++ = RC2SEQ[(x >> (4 * k)) & 15u]; } }
+      } else {
       if (!rev) for (int i = 0; i < read_len; i++) *p++ = seq_at(i);
       else for (int i = read_len - 1; i >= 0; i--) { const char c = seq_at(i); *p++ = c == '.' ? '.' : rc_char(c); }
+      }
       if (qual_ptr) {                                                              // ref: output.c:539-570
         *p++ = '\t';
         const char* q = qual_ptr[rd]; const int dq = 33 - qual_delta;
@@ -1196,10 +1258,11 @@ struct Finalizer {
         p = put_str(p, "\tZ1:i:", 6); p = put_int(p, double_to_neglog(h->z1));
       }
       p = put_str(p, "\tNM:i:", 6); p = put_int(p, r.n_mismatch + r.n_del + r.n_ins);
-      out.resize(p - out.data());
+      commit(p);
       if (P.extra_sam_fields) { std::string db, qr; ls_alignment_strings(r, h->ops, std::min(r.n_ops, ops_stride), rw, db, qr); sam_tail(P, out, nullptr, h, &db, &qr); }
       else sam_tail(P, out, nullptr, nullptr, nullptr, nullptr);
     }
+    GM_HP(3);
     return (int)p2.size();
   }
 };
