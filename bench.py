@@ -206,8 +206,8 @@ def product_sample(sess, kind, sample):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("GM_BENCH_WORKLOAD", "cfg3"), choices=sorted(WORKLOADS))
     ap.add_argument("--reads-per-step", type=int, default=0, help="units (reads, or pairs for cfg5) per rank per step; 0 = the workload's default")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the genome (debugging only; makes the result invalid)")
