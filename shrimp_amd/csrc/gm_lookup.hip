@@ -1458,6 +1458,9 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
     const int threads_b = (NL + 63) & ~63;
     const size_t lds_p = lds_b + (size_t)((((read_len + 3) / 4) + 3) & ~3) * 4;
     int dev_b = 0, cus_b = 256; (void)hipGetDevice(&dev_b); if (hipDeviceGetAttribute(&cus_b, hipDeviceAttributeMultiprocessorCount, dev_b) != hipSuccess || cus_b < 1) cus_b = 256;
+    { static GmLdsLimit lim_b, lim_p; size_t &cb = lim_b.cur(), &cp = lim_p.cur();      // (a small region size on a bucket-sized genome: the bitmap can pass 48 KB)
+      if (lds_b > 48 * 1024 && lds_b > cb) { GM_HIP(hipFuncSetAttribute((const void*)k_lookup_bkt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b)); cb = lds_b; }
+      if (lds_p > 48 * 1024 && lds_p <= 64 * 1024 && lds_p > cp) { GM_HIP(hipFuncSetAttribute((const void*)k_lookup_bkt_p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p)); cp = lds_p; } }
     int per_cu = 0;                                              // resident workgroups per CU (registers, waves, LDS): the persistent grid is exactly that
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_lookup_bkt_p, threads_b, lds_p) != hipSuccess || per_cu < 1) per_cu = 4;
     if (gm_tune("GM_BKT_V1") || threads_b > 512 || lds_p > 64 * 1024)
