@@ -562,7 +562,18 @@ k_lookup_bkt_p(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, i
   auto fetch = [&](const int rs, const uint8_t* cb, Probe& P) {      // the bucket of this thread's k-mer of read-strand rs: loads issued, used an iteration later
     P.q0 = make_uint4(0, 0, 0, 0); P.q1 = P.q0; P.q2 = P.q0; P.q3 = P.q0; P.mapidx = 0;
     if (slot && rs < n_rs) {
-      P.mapidx = gm_mapidx(ix, mask, span, cb + i);
+      if (!ix.hflag) {
+        // KMER_TO_MAPIDX (ref: gmapper.h:349-368) without a branch per base: eight code bytes per LDS round trip, the mask bit selects (as k_lookup_v5's set-up)
+        uint32_t m = 0;
+        for (int t0 = 0; t0 < ix.max_seed_span; t0 += 8) {
+          uint32_t c[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) { const int x = i + span - 1 - t0 - u; c[u] = cb[min(max(x, 0), read_len - 1)]; }
+#pragma unroll
+          for (int u = 0; u < 8; u++) m = ((mask >> (t0 + u)) & 1ull) ? ((m << 2) | (c[u] & 3u)) : m;
+        }
+        P.mapidx = m;
+      } else P.mapidx = gm_mapidx(ix, mask, span, cb + i);
       const uint4* bk = (const uint4*)(bkt + (size_t)P.mapidx * 16);
       P.q0 = bk[0]; P.q1 = bk[1]; P.q2 = bk[2]; P.q3 = bk[3];
     }
@@ -592,13 +603,19 @@ k_lookup_bkt_p(GmIndexDev ix, const uint32_t* __restrict__ reads, int n_reads, i
     }
     const uint32_t p[15] = {cur.q0.y, cur.q0.z, cur.q0.w, cur.q1.x, cur.q1.y, cur.q1.z, cur.q1.w, cur.q2.x, cur.q2.y, cur.q2.z, cur.q2.w, cur.q3.x, cur.q3.y, cur.q3.z, cur.q3.w};
     const uint32_t nreg = longl ? 0u : len;
+    // the marks of the bucket's entries, five at a time: the first marks of five entries go out together, then the second marks of those that found theirs set (a mark
+    // is two dependent LDS atomics; one entry after the other made a chain of up to thirty round trips); the few strip marks (2.4 % of the entries) afterwards
+#pragma unroll
+    for (int u0 = 0; u0 < 15; u0 += 5) {
+      uint32_t old[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) { old[k] = 0; if ((uint32_t)(u0 + k) < nreg) { const uint32_t rl = (p[u0 + k] >> rb) + 1u; old[k] = atomicOr(&bm[rl >> 4], 1u << ((rl & 15u) * 2u)); } }
+#pragma unroll
+      for (int k = 0; k < 5; k++) if ((uint32_t)(u0 + k) < nreg) { const uint32_t rl = (p[u0 + k] >> rb) + 1u, sh = (rl & 15u) * 2u; if (old[k] & (1u << sh)) atomicOr(&bm[rl >> 4], 2u << sh); }
+    }
 #pragma unroll
     for (int u = 0; u < 15; u++)
-      if ((uint32_t)u < nreg) {
-        const uint32_t reg = p[u] >> rb;
-        k1_mark(bm, reg + 1u);
-        if (((p[u] & rmask) < ovl) && reg > 0) k1_mark(bm, reg);
-      }
+      if ((uint32_t)u < nreg && ((p[u] & rmask) < ovl) && (p[u] >> rb) > 0) k1_mark(bm, p[u] >> rb);
     unsigned long long lm = __ballot(longl);
     while (lm) {                                         // long lists of this wave, one at a time, 64 entries per step
       const int l = __builtin_ctzll(lm); lm &= lm - 1;
