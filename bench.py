@@ -29,7 +29,7 @@ WORKLOADS = {
     "cfg3": ("ls", "cfg3", 3, 100, 3, 1_000_000, METRIC, "reads/s", "100bp LS reads vs 24-contig 3.0Gbp uniform genome (BASELINE configs[2]), default 3 seeds w12"),
     "cfg2": ("ls", "cfg2", 2, 100, 2, 1_000_000, METRIC.replace("3Gbp", "100Mbp"), "reads/s", "1M x 100bp LS reads vs 4x25Mbp uniform genome (BASELINE configs[1]), default 3 seeds w12"),
     "cfg1": ("ls", "cfg1", 12345, 36, 12345, 100_000, METRIC.replace("100bp", "36bp").replace("3Gbp", "1Mbp"), "reads/s", "36bp LS reads vs 1Mbp (BASELINE configs[0])"),
-    "cfg4": ("cs", "cfg3", 3, 50, 4, 500_000, "reads/sec mapped (whole node), 50-colour CS reads vs 3Gbp ref", "reads/s",
+    "cfg4": ("cs", "cfg3", 3, 50, 4, 1_000_000, "reads/sec mapped (whole node), 50-colour CS reads vs 3Gbp ref", "reads/s",
              "50-colour SOLiD reads (1 indel, 4% colour errors) vs 24-contig 3.0Gbp genome (BASELINE configs[3]), sw_full_cs + post_sw, default CS seeds"),
     "cfg5": ("pairs", "cfg3", 3, 150, 5, 131_072, "pairs/sec mapped (whole node), 2x150bp LS pairs vs 3Gbp ref", "pairs/s",
              "2x150bp opp-in pairs, -I 100,600, vs 24-contig 3.0Gbp genome (BASELINE configs[4]), half-paired rescue on"),
