@@ -304,7 +304,7 @@ struct DevSet {
   uint64_t* d_surv2 = nullptr; uint32_t* d_surv_cnt2 = nullptr;            // survivors after the exact isolation prune (K1b) = input of K2
   GmHit* d_hits = nullptr; uint16_t* d_perm = nullptr; uint32_t* d_hit_cnt = nullptr; unsigned long long* d_slots = nullptr;
   uint32_t* d_heavy_list = nullptr; uint32_t* d_heavy_cnt = nullptr;   // read-strands beyond the LDS tier of K2
-  int32_t* d_sel = nullptr; int32_t* d_sel_sidx = nullptr; uint32_t* d_sel_cnt = nullptr; uint32_t* d_sel_off = nullptr; uint32_t* d_work = nullptr; uint32_t* d_n_work = nullptr;
+  int32_t* d_sel = nullptr; int32_t* d_sel_sidx = nullptr; uint32_t* d_sel_cnt = nullptr; uint32_t* d_sel_off = nullptr; uint32_t* d_work = nullptr; uint32_t* d_n_work = nullptr; uint32_t* d_p2_order = nullptr; uint32_t* d_p2_cls = nullptr;   // (colour space: pass 2's work items by kind, see k_p2cs_classify)
   GmFullRes* d_res = nullptr; uint8_t* d_ops = nullptr; uint8_t* d_back = nullptr; size_t back_stride = 0;
   GmPostRes* d_post = nullptr; double* d_post_fw = nullptr; uint32_t* d_post_info = nullptr;   // colour space: post_sw on the device (gm_post.hip), its per-thread scratch
   // paired mode only: mate range of every window (by sorted position) and the "saved" mark (by hit slot)
@@ -377,13 +377,13 @@ struct gm_session {
 
 static void free_buffers(DevSet& D) {
   void* ptrs[] = {D.d_read_rna, D.d_xover, D.d_reads, D.d_initbp, D.d_surv, D.d_surv_cnt, D.d_surv_seg, D.d_surv2, D.d_surv_cnt2, D.d_hits, D.d_perm, D.d_hit_cnt, D.d_slots, D.d_heavy_list, D.d_heavy_cnt,
-                  D.d_sel, D.d_sel_sidx, D.d_sel_cnt, D.d_sel_off, D.d_work, D.d_n_work, D.d_res, D.d_ops, D.d_back,
+                  D.d_sel, D.d_sel_sidx, D.d_sel_cnt, D.d_sel_off, D.d_work, D.d_n_work, D.d_p2_order, D.d_p2_cls, D.d_res, D.d_ops, D.d_back,
                   D.d_pmin, D.d_pmax, D.d_saved, D.d_saved_list, D.d_post, D.d_post_fw, D.d_post_info, D.d_qv, D.d_post_bq, D.d_mp_rows, D.d_mp_cnt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   D.d_post = nullptr; D.d_post_fw = nullptr; D.d_post_info = nullptr; D.d_qv = nullptr; D.d_post_bq = nullptr;
   D.d_read_rna = nullptr; D.d_xover = nullptr; D.d_reads = nullptr; D.d_initbp = nullptr; D.d_surv = nullptr; D.d_surv_cnt = nullptr; D.d_surv_seg = nullptr; D.d_surv2 = nullptr; D.d_surv_cnt2 = nullptr; D.d_hits = nullptr; D.d_perm = nullptr; D.d_hit_cnt = nullptr; D.d_slots = nullptr;
   D.d_heavy_list = nullptr; D.d_heavy_cnt = nullptr; D.d_sel = nullptr; D.d_sel_sidx = nullptr; D.d_sel_cnt = nullptr; D.d_sel_off = nullptr;
-  D.d_work = nullptr; D.d_n_work = nullptr; D.d_res = nullptr; D.d_ops = nullptr; D.d_back = nullptr;
+  D.d_work = nullptr; D.d_n_work = nullptr; D.d_p2_order = nullptr; D.d_p2_cls = nullptr; D.d_res = nullptr; D.d_ops = nullptr; D.d_back = nullptr;
   D.d_pmin = nullptr; D.d_pmax = nullptr; D.d_saved = nullptr; D.d_saved_list = nullptr;
   D.d_mp_rows = nullptr; D.d_mp_cnt = nullptr; D.mp_rows_for = 0;
   D.cur_len = -1;
@@ -519,6 +519,7 @@ static int alloc_buffers(gm_session* s, DevSet& D, int read_len, bool paired = f
   const size_t rcap = (size_t)B * D.rcap_per_read;
   GM_HIP(hipMalloc(&D.d_work, (size_t)B * GM_SEL_MAX * 4));
   GM_HIP(hipMalloc(&D.d_n_work, 4));
+  if (s->P.colour_space) { GM_HIP(hipMalloc(&D.d_p2_order, (size_t)B * GM_SEL_MAX * 4)); GM_HIP(hipMalloc(&D.d_p2_cls, 16)); }
   GM_HIP(hipMalloc(&D.d_res, rcap * sizeof(GmFullRes)));
   GM_HIP(hipMalloc(&D.d_ops, rcap * D.ops_stride));
   if (s->P.colour_space && !getenv("GM_POST_SW_HOST")) {     // post_sw on the device (gm_post.hip): one record per result, forward values + column descriptors per thread
@@ -1450,7 +1451,7 @@ static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len,
       const int cs9[9] = {s->P.match_score, s->P.mismatch_score, s->P.crossover_score, -s->P.a_gap_open_score, -s->P.a_gap_extend_score,
                           -s->P.b_gap_open_score, -s->P.b_gap_extend_score, s->P.anchor_width, s->P.indel_taboo_len};   // sw_full_cs_setup's arguments (ref: gmapper.c:2944-2947)
       rc = gm_launch_pass2_cs(dv, s->sc, cs9, D.d_reads, D.d_initbp, n, read_len, read_words, W, D.d_hits, D.hcap, D.d_sel, D.d_work, D.d_n_work,
-                              D.d_res, D.d_ops, D.ops_stride, (uint32_t*)D.d_back, D.back_stride / 4, D.p2_grid, d_stats, q, D.xover_on ? D.d_xover : nullptr);
+                              D.d_res, D.d_ops, D.ops_stride, (uint32_t*)D.d_back, D.back_stride / 4, D.p2_grid, d_stats, q, D.xover_on ? D.d_xover : nullptr, nullptr, D.d_p2_order, D.d_p2_cls);
       // post_sw of every result on the device (with the reads' quality values where they have them: per-colour error rates from the host's table, base qualities back), unless
       // the alignment is local (no mapping qualities at all, ref: gmapper.c:2325-2328)
       H.post_on = rc == GM_OK && D.d_post && gm_mqv_on(s->P) && (!D.xover_on || s->d_qtab);

@@ -145,7 +145,8 @@ int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs
                        int read_len, int read_words, int window_len, const GmHit* d_hits, int hcap, const int32_t* d_sel, const uint32_t* d_work,
                        const uint32_t* d_n_work, GmFullRes* d_res, uint8_t* d_ops, int ops_stride, uint32_t* d_back, size_t back_words, int grid,
                        unsigned long long* d_stats, hipStream_t stream, const int8_t* d_xover = nullptr,   // d_xover[n_reads][read_len]: per-position crossover scores (reads with QVs)
-                       const int32_t* d_sel_sidx = nullptr);                                               // paired mode: sort index of every selected window
+                       const int32_t* d_sel_sidx = nullptr,                                                // paired mode: sort index of every selected window
+                       uint32_t* d_order = nullptr, uint32_t* d_cls_cnt = nullptr);                        // the work items listed by kind (as many words as d_work), four counter words
 
 // paired mode (gm_pair.hip): mate ranges per window, pair top-K, saved marks, mate reversal
 int gm_launch_revcomp_reads(uint32_t* d_reads, int n_reads, int read_len, int read_words, hipStream_t stream, const uint8_t* d_read_rna = nullptr);

@@ -1483,9 +1483,9 @@ __device__ CsBest full_sw_cs_wave(const uint8_t* db, int glen, const uint8_t* qr
 // out[0..11] = score read_start rmapped genome_start gmapped matches mismatches insertions deletions crossovers n_ops 0;
 // ops[] = the reference's backtrace bytes in alignment order (type 1 insertion, 2-5 deletion in layer A-D, 6-9 match/mismatch in layer A-D; | 0x80 crossover)
 // (local mode lives in the four-window routine further down: the single call runs it with one group of 16 lanes)
-template <bool REV, bool TABOO, bool LOCAL>
+template <int G, typename CT, bool REV, bool TABOO, bool LOCAL>
 __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4, int qstride, int rlen, const GmCsDev& P, bool act,
-                                int rx, int ry, int rl, int rw, uint32_t* back, int* carry, int lane, const int8_t* xrow);
+                                int rx, int ry, int rl, int rw, uint32_t* back, CT* carry, int lane, const int8_t* xrow);
 __global__ void __launch_bounds__(GM_WAVE)
 k_sw_full_cs_single(GmCsDev P, const uint32_t* __restrict__ genome_ls, long long goff, int glen, const uint32_t* __restrict__ read, int rlen, int initbp,
                     int thresh, long long ax, long long ay, int alen, int awidth, int revcmpl, uint32_t* __restrict__ back, int* __restrict__ out,
@@ -1521,10 +1521,10 @@ k_sw_full_cs_single(GmCsDev P, const uint32_t* __restrict__ genome_ls, long long
   CsBest fo;
   if (local) {                                        // ref: sw-full-cs.c:199-203,315,439-552
     const bool act = lane < 16;
-    if (revcmpl) fo = P.taboo > 0 ? full_sw_cs_g4<true, true, true>(db, glen, qr4, qstride, rlen, P, act, (int)rx, (int)ry, rl, rw, back, carry, lane, xrow)
-                                  : full_sw_cs_g4<true, false, true>(db, glen, qr4, qstride, rlen, P, act, (int)rx, (int)ry, rl, rw, back, carry, lane, xrow);
-    else fo = P.taboo > 0 ? full_sw_cs_g4<false, true, true>(db, glen, qr4, qstride, rlen, P, act, (int)rx, (int)ry, rl, rw, back, carry, lane, xrow)
-                          : full_sw_cs_g4<false, false, true>(db, glen, qr4, qstride, rlen, P, act, (int)rx, (int)ry, rl, rw, back, carry, lane, xrow);
+    if (revcmpl) fo = P.taboo > 0 ? full_sw_cs_g4<16, int, true, true, true>(db, glen, qr4, qstride, rlen, P, act, (int)rx, (int)ry, rl, rw, back, carry, lane, xrow)
+                                  : full_sw_cs_g4<16, int, true, false, true>(db, glen, qr4, qstride, rlen, P, act, (int)rx, (int)ry, rl, rw, back, carry, lane, xrow);
+    else fo = P.taboo > 0 ? full_sw_cs_g4<16, int, false, true, true>(db, glen, qr4, qstride, rlen, P, act, (int)rx, (int)ry, rl, rw, back, carry, lane, xrow)
+                          : full_sw_cs_g4<16, int, false, false, true>(db, glen, qr4, qstride, rlen, P, act, (int)rx, (int)ry, rl, rw, back, carry, lane, xrow);
   } else fo = full_sw_cs_wave<true>(db, glen, qr4, qstride, rlen, P, revcmpl != 0, rx, ry, rl, rw, back, carry, lane, xrow);
   __syncthreads();
   __threadfence();
@@ -1700,20 +1700,36 @@ k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__
 // LOCAL (Gflag off, ref: sw-full-cs.c:199-203,315,439-552): a cell outside the band holds (0, -b_open, -a_open) -- plus the crossover score in layers 1-3 -- like the
 // virtual row above the matrix; a state at or below 0 (layer 0) / the crossover score (layers 1-3) takes that value with a null back pointer; the result is the
 // first cell in row-major order with the largest score.  (With per-position crossover scores an out-of-band cell carries the score of its own row, as the reference's init_cell leaves it: sw-full-cs.c:312-322.)
-template <bool REV, bool TABOO, bool LOCAL>
+#ifdef P2CS_STAMPS
+__device__ unsigned long long p2cs_stamps[8];
+#endif
+// Groups of G lanes (G = 16: four windows a wave, G = 8: eight).  row_shr:1 moves inside rows of 16 lanes, so with G = 8 the first lane of a row's second group is put right afterwards.
+template <int G> __device__ __forceinline__ int gn_shr1(int v, int first, int l) {
+  const int r = __builtin_amdgcn_update_dpp(first, v, 0x111, 0xf, 0xf, false);
+  return (G == 16) ? r : (l == 0 ? first : r);
+}
+// The carry rows (last row of a stripe, per column and state) as int, or as int16_t where the launch has checked that no score of a real path lies further than 16000 from 0: a
+// value of the "minus infinity" family (FS_NEG plus a few penalties) is stored as -32768 and goes on from there -- -32768 plus anything a path can collect stays below every
+// score of a real path, so such a state never wins against a real one, a state on the traced path never has one as its source, and the alignment is the same
+// (gm_launch_pass2_cs decides; ref for the values: sw-full-cs.c:201-215,312-322).
+__device__ __forceinline__ int cs_carry_ld(int v) { return v; }
+__device__ __forceinline__ int cs_carry_ld(int16_t v) { return (int)v; }
+__device__ __forceinline__ void cs_carry_st(int& d, int v) { d = v; }
+__device__ __forceinline__ void cs_carry_st(int16_t& d, int v) { d = (int16_t)max(v, -32768); }
+template <int G, typename CT, bool REV, bool TABOO, bool LOCAL>
 __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4, int qstride, int rlen, const GmCsDev& P, bool act,
-                                int rx, int ry, int rl, int rw, uint32_t* back, int* carry, int lane, const int8_t* xrow) {
+                                int rx, int ry, int rl, int rw, uint32_t* back, CT* carry, int lane, const int8_t* xrow) {
   constexpr bool revcmpl = REV;
   // a cell outside the band: what the reference's init_cell leaves there -- in local mode with the crossover score of the cell's ROW (per-position scores from quality values, ref: sw-full-cs.c:312-322)
   auto OBx = [&](const int x, const int xv) -> int { const int k = x / 3, st = x % 3; return LOCAL ? (st == 0 ? 0 : (st == 1 ? -P.b_go : -P.a_go)) + (k ? xv : 0) : FS_NEG; };
   CsBest best; best.score = 0; best.i = best.j = best.k = 0; best.e_nw = best.e_n = best.e_w = 0;
-  const int l = lane & 15;
+  const int l = lane & (G - 1);
   const int xg = P.xover;
   int xo = xg;
-  const int n_stripes = (rlen + 15) >> 4;
+  const int n_stripes = (rlen + G - 1) / G;
   int cw_lo = 1, cw_hi = 0;
   for (int s = 0; s < n_stripes; s++) {
-    const int r = s * 16 + l;
+    const int r = s * G + l;
     const bool row_ok = act && r < rlen;
     if (xrow) xo = row_ok ? (int)xrow[r] : xg;           // ref: sw-full-cs.c:312
     const int xo_up = (xrow && act && r >= 1 && r - 1 < rlen) ? (int)xrow[r - 1] : xg;      // the row above's
@@ -1726,10 +1742,15 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
     const bool notaboo = TABOO ? r < rlen - P.taboo : true;
     int t_lo = INT_MAX, t_hi = -1;
     if (row_ok && x_max >= x_min) { t_lo = x_min + l; t_hi = x_max + l; }
-    for (int dd = 8; dd > 0; dd >>= 1) { t_lo = min(t_lo, __shfl_xor(t_lo, dd)); t_hi = max(t_hi, __shfl_xor(t_hi, dd)); }
+    for (int dd = G / 2; dd > 0; dd >>= 1) { t_lo = min(t_lo, __shfl_xor(t_lo, dd)); t_hi = max(t_hi, __shfl_xor(t_hi, dd)); }
     int nst = t_hi >= 0 ? t_hi - t_lo + 1 : 0, nmax = nst;
-    for (int dd = 32; dd >= 16; dd >>= 1) nmax = max(nmax, __shfl_xor(nmax, dd));
+    for (int dd = 32; dd >= G; dd >>= 1) nmax = max(nmax, __shfl_xor(nmax, dd));
     nmax = __builtin_amdgcn_readfirstlane(nmax);
+#ifdef P2CS_STAMPS
+    if (lane == 0) atomicAdd(&p2cs_stamps[4], (unsigned long long)nmax);
+    if (l == 0) atomicAdd(&p2cs_stamps[5], (unsigned long long)nst);
+    if (row_ok && x_max >= x_min) atomicAdd(&p2cs_stamps[6], (unsigned long long)(x_max - x_min + 1));
+#endif
     int d[12], cur[12], inv[12];        // (cur: this lane's cell of the step before = the west neighbour of the next one)
 #pragma unroll
     for (int x = 0; x < 12; x++) { d[x] = OBx(x, xo_up); cur[x] = OB(x); }
@@ -1743,11 +1764,11 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
       } else if (t_hi >= 0) {
         if (t_lo >= 1 && t_lo - 1 >= cw_lo && t_lo - 1 <= cw_hi) {
 #pragma unroll
-          for (int x = 0; x < 12; x++) d[x] = carry[x * glen + t_lo - 1];
+          for (int x = 0; x < 12; x++) d[x] = cs_carry_ld(carry[x * glen + t_lo - 1]);
         }
         if (t_lo >= cw_lo && t_lo <= cw_hi) {
 #pragma unroll
-          for (int x = 0; x < 12; x++) inv[x] = carry[x * glen + t_lo];
+          for (int x = 0; x < 12; x++) inv[x] = cs_carry_ld(carry[x * glen + t_lo]);
         }
       }
     }
@@ -1760,13 +1781,13 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
       const int t = t_lo + i;
       const int c = t - l;
 #pragma unroll
-      for (int x = 0; x < 12; x++) u[x] = g4_shr1(cur[x], inv[x]);   // cell (r-1, c)
+      for (int x = 0; x < 12; x++) u[x] = gn_shr1<G>(cur[x], inv[x], l);   // cell (r-1, c)
       if (s > 0) {                                   // next step's carry values for the group's first lane
 #pragma unroll
         for (int x = 0; x < 12; x++) inv[x] = OBx(x, xo_up);
         if (l == 0 && i + 1 < nst && t + 1 >= cw_lo && t + 1 <= cw_hi) {
 #pragma unroll
-          for (int x = 0; x < 12; x++) inv[x] = carry[x * glen + t + 1];
+          for (int x = 0; x < 12; x++) inv[x] = cs_carry_ld(carry[x * glen + t + 1]);
         }
       }
       const bool inband = on && row_ok && c >= x_min && c <= x_max;
@@ -1881,9 +1902,9 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
       }
 #pragma unroll
       for (int x = 0; x < 12; x++) nv[x] = inband ? nv[x] : OB(x);
-      if (more && l == 15 && on && c >= 0 && c < glen) {
+      if (more && l == G - 1 && on && c >= 0 && c < glen) {
 #pragma unroll
-        for (int x = 0; x < 12; x++) carry[x * glen + c] = nv[x];
+        for (int x = 0; x < 12; x++) cs_carry_st(carry[x * glen + c], nv[x]);
       }
     };
     {
@@ -1893,16 +1914,16 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
       if (i < nmax) step(i, d, cur, d2, cur2);
     }
     cw_lo = 1; cw_hi = 0;
-    if (more && t_hi >= 0) { cw_lo = max(0, t_lo - 15); cw_hi = min(glen - 1, t_hi - 15); }
+    if (more && t_hi >= 0) { cw_lo = max(0, t_lo - (G - 1)); cw_hi = min(glen - 1, t_hi - (G - 1)); }
     if (more) __syncthreads();
   }
-  int src = (lane & 48) | ((rlen - 1) & 15);
+  int src = (lane & (64 - G)) | ((rlen - 1) & (G - 1));
   if (LOCAL) {                                         // the lane whose row comes first among those with the largest score
     int bs = best.score;
-    for (int dd = 8; dd > 0; dd >>= 1) bs = max(bs, __shfl_xor(bs, dd));
+    for (int dd = G / 2; dd > 0; dd >>= 1) bs = max(bs, __shfl_xor(bs, dd));
     int row = (best.score == bs) ? best.i : INT_MAX;
-    for (int dd = 8; dd > 0; dd >>= 1) row = min(row, __shfl_xor(row, dd));
-    src = (lane & 48) | ((bs > 0) ? (row & 15) : 0);
+    for (int dd = G / 2; dd > 0; dd >>= 1) row = min(row, __shfl_xor(row, dd));
+    src = (lane & (64 - G)) | ((bs > 0) ? (row & (G - 1)) : 0);
   }
   best.score = __shfl(best.score, src); best.i = __shfl(best.i, src); best.j = __shfl(best.j, src); best.k = __shfl(best.k, src);
   best.e_nw = __shfl(best.e_nw, src); best.e_n = __shfl(best.e_n, src); best.e_w = __shfl(best.e_w, src);
@@ -1912,7 +1933,6 @@ __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4,
 // Diagnostic build (-DP2CS_STAMPS, tools/p2cs_stamps.py): lane 0 of every wave adds the cycles of a pass's phases to p2cs_stamps[] (0: set-up -- unpack read and window,
 // translations; 1: the cells; 2: traceback; 3: passes).  No stamp executes in the normal build.
 #ifdef P2CS_STAMPS
-__device__ unsigned long long p2cs_stamps[8];
 #define P2CS_STAMP(i) do { if (lane == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&p2cs_stamps[i], t_ - t_prev); t_prev = t_; } } while (0)
 extern "C" int gm_debug_p2cs_stamps(unsigned long long* out) {
   unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1926,17 +1946,18 @@ extern "C" int gm_debug_p2cs_stamps(unsigned long long* out) {
 struct P2CsG4 {
   const uint32_t* reads; const uint8_t* initbp; int read_len, read_words; const GmHit* hits; int hcap; const int32_t* sel; const int32_t* sel_sidx;
   const uint32_t* work; GmFullRes* res; uint8_t* ops; int ops_stride, max_w; const int8_t* xover;
-  uint8_t* rc_all; uint8_t* qr4_all; uint8_t* db_all; int* carry_all; int qstride, mw16;
+  uint8_t* rc_all; uint8_t* qr4_all; uint8_t* db_all; void* carry_all; int qstride, mw16;
 };
-template <bool REV, bool TABOO, bool LOCAL>
+template <int G, typename CT, bool REV, bool TABOO, bool LOCAL>
 __device__ __forceinline__ void p2cs_g4_pass(const GmIndexDev& ix, const GmScoreDev& sc, const GmCsDev& P, const P2CsG4& A, const uint32_t wi, const bool has, uint32_t* back,
                                              const int lane, unsigned long long& fcalls, unsigned long long& fcells) {
-  const int g = lane >> 4, l = lane & 15;
+  constexpr int NG = 64 / G;
+  const int g = lane / G, l = lane & (G - 1);
 #ifdef P2CS_STAMPS
   unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
   const int read_len = A.read_len, qstride = A.qstride, half = A.ops_stride >> 1;
-  const uint8_t* qr4 = A.qr4_all + g * 4 * qstride; const uint8_t* db = A.db_all + g * A.mw16; int* carry = A.carry_all + g * 12 * A.max_w;
+  const uint8_t* qr4 = A.qr4_all + g * 4 * qstride; const uint8_t* db = A.db_all + g * A.mw16; CT* carry = (CT*)A.carry_all + g * 12 * A.max_w;
   const uint32_t wk = has ? A.work[wi] : 0u;
   const int rd = (int)(wk >> 6), k = (int)(wk & 63);
   const int id = has ? A.sel[(size_t)rd * SEL_MAX + k] : 0;
@@ -1955,10 +1976,10 @@ __device__ __forceinline__ void p2cs_g4_pass(const GmIndexDev& ix, const GmScore
   const uint64_t g0 = (uint64_t)ix.contig_off[cn] + h.g_off;
   const int rna_bits = (ix.contig_rna && has && ix.contig_rna[cn]) ? 2 : 0;
   __syncthreads();
-  for (int gg = 0; gg < 4; gg++) {                       // the whole wave unpacks each group's colours and window
-    if (!__shfl((int)has, gg * 16)) continue;
-    const int rd_g = __shfl(rd, gg * 16), wl_g = __shfl(w_len, gg * 16), gs_g = __builtin_amdgcn_readfirstlane(__shfl(gen_st | rna_bits, gg * 16));      // (bit 1: the contig is RNA; wave-uniform)
-    const uint64_t g0_g = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(g0 >> 32), gg * 16) << 32) | (uint32_t)__shfl((int)(uint32_t)g0, gg * 16);
+  for (int gg = 0; gg < NG; gg++) {                      // the whole wave unpacks each group's colours and window
+    if (!__shfl((int)has, gg * G)) continue;
+    const int rd_g = __shfl(rd, gg * G), wl_g = __shfl(w_len, gg * G), gs_g = __builtin_amdgcn_readfirstlane(__shfl(gen_st | rna_bits, gg * G));      // (bit 1: the contig is RNA; wave-uniform)
+    const uint64_t g0_g = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(g0 >> 32), gg * G) << 32) | (uint32_t)__shfl((int)(uint32_t)g0, gg * G);
     load_read(A.reads + (size_t)rd_g * A.read_words, read_len, false, A.rc_all + gg * qstride, lane);
     load_window(ix.genome, g0_g, wl_g, (gs_g & 1) != 0, A.db_all + gg * A.mw16, lane, (gs_g & 2) != 0);
   }
@@ -1999,7 +2020,7 @@ __device__ __forceinline__ void p2cs_g4_pass(const GmIndexDev& ix, const GmScore
   const int g_off_i = (int)g_off;
   __syncthreads();
   P2CS_STAMP(0);
-  const CsBest fo = full_sw_cs_g4<REV, TABOO, LOCAL>(db, w_len, qr4, qstride, read_len, P, has, rx, ry, rl, rw, back, carry, lane, A.xover ? A.xover + (size_t)rd * read_len : nullptr);
+  const CsBest fo = full_sw_cs_g4<G, CT, REV, TABOO, LOCAL>(db, w_len, qr4, qstride, read_len, P, has, rx, ry, rl, rw, back, carry, lane, A.xover ? A.xover + (size_t)rd * read_len : nullptr);
   __syncthreads();
   __threadfence();
   P2CS_STAMP(1);
@@ -2049,57 +2070,80 @@ __device__ __forceinline__ void p2cs_g4_pass(const GmIndexDev& ix, const GmScore
 #endif
 }
 
-template <bool TABOO, bool LOCAL>
+// The work items of a colour-space pass 2 listed by kind: forward-strand windows from the front of order[], reverse-strand ones (they take the mirrored tie rules, when
+// sc.tiebreak_rev) from its back; cnt[0] / cnt[1] count them, cnt[2] is the unit counter k_pass2_cs_g4 draws from (all three zeroed by the launch).  The order inside a
+// kind is whatever the atomics give: every result is stored under its work index, so the output does not depend on it.
+__global__ void __launch_bounds__(256) k_p2cs_classify(const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work_p, const int32_t* __restrict__ sel,
+                                                       int cs_flip, int tiebreak_rev, uint32_t* __restrict__ order, uint32_t* __restrict__ cnt) {
+  const uint32_t n_work = *n_work_p;
+  const int lane = threadIdx.x & 63;
+  for (uint32_t base = (blockIdx.x * 256u + threadIdx.x) & ~63u; base < n_work; base += gridDim.x * 256u) {
+    const uint32_t wi = base + (uint32_t)lane;
+    bool fw = false, rv = false;
+    if (wi < n_work) {
+      const uint32_t wk = work[wi];
+      const int id = sel[(size_t)(wk >> 6) * SEL_MAX + (wk & 63)];
+      rv = ((id >> 16) != cs_flip) && tiebreak_rev; fw = !rv;
+    }
+    const unsigned long long m_fw = __ballot(fw), m_rv = __ballot(rv);
+    uint32_t b_fw = 0, b_rv = 0;
+    if (lane == 0) { if (m_fw) b_fw = atomicAdd(&cnt[0], (uint32_t)__popcll(m_fw)); if (m_rv) b_rv = atomicAdd(&cnt[1], (uint32_t)__popcll(m_rv)); }
+    b_fw = (uint32_t)__shfl((int)b_fw, 0); b_rv = (uint32_t)__shfl((int)b_rv, 0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (fw) order[b_fw + (uint32_t)__popcll(m_fw & below)] = wi;
+    if (rv) order[n_work - 1u - (b_rv + (uint32_t)__popcll(m_rv & below))] = wi;
+  }
+}
+
+template <int G, typename CT, bool TABOO, bool LOCAL>
 __global__ void __launch_bounds__(GM_WAVE, 2)
 k_pass2_cs_g4(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__ reads, const uint8_t* __restrict__ initbp, int n_reads, int read_len,
               int read_words, const GmHit* __restrict__ hits, int hcap, const int32_t* __restrict__ sel,
               const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work_p, GmFullRes* __restrict__ res, uint8_t* __restrict__ ops, int ops_stride,
               uint32_t* __restrict__ back_pool, size_t back_words, int max_w, unsigned long long* __restrict__ stats,
-              const int8_t* __restrict__ xover, const int32_t* __restrict__ sel_sidx) {
+              const int8_t* __restrict__ xover, const int32_t* __restrict__ sel_sidx, const uint32_t* __restrict__ order, uint32_t* __restrict__ cls_cnt) {
   extern __shared__ __align__(16) uint8_t sm[];
-  const int lane = threadIdx.x, g = lane >> 4;
+  constexpr int NG = 64 / G;
+  const int lane = threadIdx.x, g = lane / G;
   P2CsG4 A;
   A.reads = reads; A.initbp = initbp; A.read_len = read_len; A.read_words = read_words; A.hits = hits; A.hcap = hcap; A.sel = sel; A.sel_sidx = sel_sidx;
   A.work = work; A.res = res; A.ops = ops; A.ops_stride = ops_stride; A.max_w = max_w; A.xover = xover;
   A.qstride = (read_len + 15) & ~15; A.mw16 = (max_w + 15) & ~15;
-  A.rc_all = sm; A.qr4_all = sm + 4 * A.qstride; A.db_all = A.qr4_all + 16 * A.qstride; A.carry_all = (int*)(A.db_all + 4 * A.mw16);
-  uint32_t* back = back_pool + ((size_t)blockIdx.x * 4 + g) * back_words;
+  A.rc_all = sm; A.qr4_all = sm + NG * A.qstride; A.db_all = A.qr4_all + 4 * NG * A.qstride; A.carry_all = (void*)(A.db_all + NG * A.mw16);
+  uint32_t* back = back_pool + ((size_t)blockIdx.x * NG + g) * back_words;
   const uint32_t n_work = *n_work_p;
   unsigned long long fcalls = 0, fcells = 0;
-  // A wave takes 32 consecutive work items at a time, first the forward-strand windows among them four by four, then the reverse-strand ones: a pass holds
-  // windows of one kind (the strand decides the tie rules of all 36 state updates of a cell, ref: sw-full-cs.c:356-541; as a per-lane value both
-  // variants of every update would run).
-  for (uint32_t chunk = blockIdx.x * 32u; chunk < n_work; chunk += gridDim.x * 32u) {
-    bool mine = false, rev = false;
-    if (lane < 32 && chunk + (uint32_t)lane < n_work) {
-      const uint32_t wk = work[chunk + lane];
-      const int id = sel[(size_t)(wk >> 6) * SEL_MAX + (wk & 63)];
-      mine = true; rev = ((id >> 16) != ix.cs_flip) && sc.tiebreak_rev;
-    }
-    const uint32_t m_fw = (uint32_t)__ballot(mine && !rev), m_rv = (uint32_t)__ballot(mine && rev);
-    for (int cls = 0; cls < 2; cls++) {
-      uint32_t m = cls ? m_rv : m_fw;
-      while (m) {
-        uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0; int np = 0;
-        if (m) { p0 = (uint32_t)__builtin_ctz(m); m &= m - 1u; np++; }
-        if (m) { p1 = (uint32_t)__builtin_ctz(m); m &= m - 1u; np++; }
-        if (m) { p2 = (uint32_t)__builtin_ctz(m); m &= m - 1u; np++; }
-        if (m) { p3 = (uint32_t)__builtin_ctz(m); m &= m - 1u; np++; }
-        const bool has = g < np;
-        const uint32_t wi = chunk + (g == 0 ? p0 : (g == 1 ? p1 : (g == 2 ? p2 : p3)));
-        if (cls) p2cs_g4_pass<true, TABOO, LOCAL>(ix, sc, P, A, wi, has, back, lane, fcalls, fcells);
-        else p2cs_g4_pass<false, TABOO, LOCAL>(ix, sc, P, A, wi, has, back, lane, fcalls, fcells);
-      }
+  // A pass holds windows of one kind (the strand decides the tie rules of all 36 state updates of a cell, ref: sw-full-cs.c:356-541; as a per-lane value both variants of every
+  // update would run).  k_p2cs_classify has listed the work items by kind -- forward ones from the front of order[], reverse ones from its back -- so a pass is one unit of NG
+  // list entries of one kind, full except for the last of each kind, and the waves draw units from a counter until none is left (round 4: chunks of 32 consecutive items split by
+  // kind filled 82 % of eight window slots, and 4 486 such chunks over 2 048 resident waves left a third of the waves idle in the last round).
+  const uint32_t n_fw = cls_cnt[0], n_rv = cls_cnt[1];
+  const uint32_t u_fw = (n_fw + NG - 1) / NG, u_all = u_fw + (n_rv + NG - 1) / NG;
+  for (;;) {
+    uint32_t u = 0;
+    if (lane == 0) u = atomicAdd(&cls_cnt[2], 1u);
+    u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+    if (u >= u_all) break;
+    if (u < u_fw) {
+      const uint32_t idx = u * NG + (uint32_t)g;
+      const bool has = idx < n_fw;
+      const uint32_t wi = has ? order[idx] : 0u;
+      p2cs_g4_pass<G, CT, false, TABOO, LOCAL>(ix, sc, P, A, wi, has, back, lane, fcalls, fcells);
+    } else {
+      const uint32_t idx = (u - u_fw) * NG + (uint32_t)g;
+      const bool has = idx < n_rv;
+      const uint32_t wi = has ? order[n_work - 1u - idx] : 0u;
+      p2cs_g4_pass<G, CT, true, TABOO, LOCAL>(ix, sc, P, A, wi, has, back, lane, fcalls, fcells);
     }
   }
-  for (int d = 32; d >= 16; d >>= 1) { fcalls += __shfl_xor(fcalls, d); fcells += __shfl_xor(fcells, d); }
+  for (int d = 32; d >= G; d >>= 1) { fcalls += __shfl_xor(fcalls, d); fcells += __shfl_xor(fcells, d); }
   if (lane == 0) { GS_ADD(stats, GS_FULL_CALLS, fcalls); GS_ADD(stats, GS_FULL_CELLS, fcells); }
 }
 
 int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs_params9, const uint32_t* d_reads, const uint8_t* d_initbp, int n_reads,
                        int read_len, int read_words, int window_len, const GmHit* d_hits, int hcap, const int32_t* d_sel, const uint32_t* d_work,
                        const uint32_t* d_n_work, GmFullRes* d_res, uint8_t* d_ops, int ops_stride, uint32_t* d_back, size_t back_words, int grid,
-                       unsigned long long* d_stats, hipStream_t stream, const int8_t* d_xover, const int32_t* d_sel_sidx) {
+                       unsigned long long* d_stats, hipStream_t stream, const int8_t* d_xover, const int32_t* d_sel_sidx, uint32_t* d_order, uint32_t* d_cls_cnt) {
   if (n_reads == 0) return GM_OK;
   GmCsDev P; P.match = cs_params9[0]; P.mismatch = cs_params9[1]; P.xover = cs_params9[2]; P.a_go = cs_params9[3]; P.a_ge = cs_params9[4];
   P.b_go = cs_params9[5]; P.b_ge = cs_params9[6]; P.anchor_width = cs_params9[7]; P.taboo = cs_params9[8];
@@ -2109,22 +2153,40 @@ int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs
   if (lds > 48 * 1024 && lds > configured) {
     GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = lds; }
-  // four windows per wave (k_pass2_cs_g4) unless GM_P2_G4=0 asks for the one-window kernel; a wave owns four consecutive back-pointer scratches.
-  // Local alignment (sc.local, ref: sw-full-cs.c:199-203,439-552) exists in the four-window kernel only.
-  const bool want_g4 = !(gm_tune("GM_P2_G4") && atoi(gm_tune("GM_P2_G4")) == 0) && grid >= 4;
+  // Four or eight windows per wave (k_pass2_cs_g4) unless GM_P2_G4=0 asks for the one-window kernel; a wave owns that many consecutive back-pointer scratches.
+  // Eight (groups of 8 lanes: a stripe of 8 rows takes band width + 14 steps, against band width + 30 for 16 rows -- the chain north, west, north, ... through a band is two steps a
+  // row whatever the lane count, so ~band width / 2 lanes a window is what the recurrence can feed) where the carry rows fit int16_t, see cs_carry_ld; GM_P2_G=16 keeps four.
+  // Local alignment (sc.local, ref: sw-full-cs.c:199-203,439-552) exists in these kernels only.
+  const bool want_g4 = !(gm_tune("GM_P2_G4") && atoi(gm_tune("GM_P2_G4")) == 0) && grid >= 8;
   if (want_g4 || sc.local) {
-    const size_t q16 = (size_t)((read_len + 15) & ~15), lds4 = 20 * q16 + 4 * (size_t)((window_len + 15) & ~15) + 4 * (size_t)window_len * 48 + 64;
-    if (lds4 <= 160 * 1024 && grid >= 4) {
+    const size_t q16 = (size_t)((read_len + 15) & ~15), w16 = (size_t)((window_len + 15) & ~15);
+    int big = std::max(std::max(std::abs(P.match), std::abs(P.mismatch)), std::max(std::abs(P.a_ge), std::abs(P.b_ge)));
+    big = std::max(big, std::max(std::abs(P.xover), d_xover ? 127 : 1));
+    const long long reach = (long long)(read_len + window_len) * big + std::abs(P.a_go) + std::abs(P.b_go);      // no score on a path through the matrix lies further from 0
+    const size_t lds8 = 8 * 5 * q16 + 8 * w16 + 8 * (size_t)window_len * 12 * sizeof(int16_t) + 64;
+    const size_t lds4 = 4 * 5 * q16 + 4 * w16 + 4 * (size_t)window_len * 12 * sizeof(int) + 64;
+    const bool g8 = reach < 16000 && lds8 <= 64 * 1024 && !(gm_tune("GM_P2_G") && atoi(gm_tune("GM_P2_G")) == 16);
+    const size_t ldsn = g8 ? lds8 : lds4;
+    if (ldsn <= 160 * 1024 && grid >= 8) {
       static GmLdsLimit lim4; size_t& conf4 = lim4.cur();
-      if (lds4 > 48 * 1024 && lds4 > conf4) {
-        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
-        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
-        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
-        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4)); conf4 = lds4; }
-#define GM_P2CS_G4(TB, LOC) hipLaunchKernelGGL((k_pass2_cs_g4<TB, LOC>), dim3(grid / 4), dim3(GM_WAVE), lds4, stream, ix, sc, P, d_reads, d_initbp, n_reads, read_len, read_words, d_hits, hcap, d_sel, \
-                           d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_words, window_len, d_stats, d_xover, d_sel_sidx)
-      if (P.taboo > 0) { if (sc.local) GM_P2CS_G4(true, true); else GM_P2CS_G4(true, false); }
-      else { if (sc.local) GM_P2CS_G4(false, true); else GM_P2CS_G4(false, false); }
+      if (ldsn > 48 * 1024 && ldsn > conf4) {
+        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<16, int, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
+        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<16, int, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
+        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<16, int, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
+        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<16, int, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
+        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<8, int16_t, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
+        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<8, int16_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
+        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<8, int16_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
+        GM_HIP(hipFuncSetAttribute((const void*)k_pass2_cs_g4<8, int16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn)); conf4 = ldsn; }
+#define GM_P2CS_G4(GG, CT, TB, LOC) hipLaunchKernelGGL((k_pass2_cs_g4<GG, CT, TB, LOC>), dim3(grid / (64 / GG)), dim3(GM_WAVE), ldsn, stream, ix, sc, P, d_reads, d_initbp, n_reads, read_len, read_words, d_hits, hcap, d_sel, \
+                           d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_words, window_len, d_stats, d_xover, d_sel_sidx, d_order, d_cls_cnt)
+#define GM_P2CS_GN(TB, LOC) do { if (g8) GM_P2CS_G4(8, int16_t, TB, LOC); else GM_P2CS_G4(16, int, TB, LOC); } while (0)
+      if (!d_order || !d_cls_cnt) { gm_set_error("colour-space pass 2: no work-order buffer"); return GM_E_ARG; }
+      GM_HIP(hipMemsetAsync(d_cls_cnt, 0, 16, stream));
+      hipLaunchKernelGGL(k_p2cs_classify, dim3(512), dim3(256), 0, stream, d_work, d_n_work, d_sel, ix.cs_flip, sc.tiebreak_rev ? 1 : 0, d_order, d_cls_cnt);
+      if (P.taboo > 0) { if (sc.local) GM_P2CS_GN(true, true); else GM_P2CS_GN(true, false); }
+      else { if (sc.local) GM_P2CS_GN(false, true); else GM_P2CS_GN(false, false); }
+#undef GM_P2CS_GN
 #undef GM_P2CS_G4
       GM_HIP(hipGetLastError());
       return GM_OK;

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from shrimp_amd import gmapper as gm, synth
 n = 262144
 gname, gseed, _, L, rseed = synth.CONFIGS["cfg3"]
+L = int(os.environ.get("GM_STAMPS_READ_LEN", L))            # 150: the reads of the paired workload, mapped unpaired here
 contigs = synth.make_genome(synth.contig_lengths(gname, 1.0), gseed)
 reads, _ = synth.make_reads(contigs, n, L, rseed)
 ix = gm.Index(contigs); s = gm.Session(ix, max_batch_reads=131072)

@@ -16,5 +16,6 @@ s.map_reads_cs(reads)
 print({k: v for k, v in s.stats.items() if k.startswith("ms_") or k == "full_calls"})
 lib.gm_debug_p2cs_stamps(out)
 v = [int(x) for x in out]; np_ = v[3] or 1
-for nm, x in zip(["set-up (unpack, translations)", "cells", "traceback"], v): print("%-32s %10.0f ticks per four-window pass" % (nm, x / np_))
+for nm, x in zip(["set-up (unpack, translations)", "cells", "traceback"], v): print("%-32s %10.0f ticks per pass" % (nm, x / np_))
+print("steps per pass %.1f, a group's own steps %.1f per window slot, band cells per pass %.0f, ticks per step %.0f" % (v[4] / np_, v[5] / np_, v[6] / np_, v[1] / max(v[4], 1)))
 print("passes", v[3])
