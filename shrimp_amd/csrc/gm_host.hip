@@ -1550,7 +1550,9 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   if ((s->P.colour_space != 0) != (initbp_host != nullptr)) {
     gm_set_error(s->P.colour_space ? "colour-space session: use gm_map_reads_cs (colours + primer letters)" : "gm_map_reads_cs needs a colour-space session"); return GM_E_ARG; }
   if (read_len > s->P.longest_read_len || read_len >= 32768 / std::max(1, s->P.match_score)) { gm_set_error("read length %d out of range (ref: sw-vector.c:393-398)", read_len); return GM_E_RANGE; }
+  const double tl_in = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
   GmDevTurn dev_turn(s);
+  const double tl_turn = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
   GM_HIP(hipSetDevice(s->ix->device));
   DevSet& D = s->set[0];
   if (stats) memset(stats, 0, sizeof *stats);
@@ -1644,8 +1646,10 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
         // first guess: this job's bytes per read for all reads, then geometric growth (large blocks move by remapping)
         size_t want = std::max(ob.len + sz + 1, ob.cap + ob.cap / 2);
         if (!ob.cap) want = std::max(want, (size_t)((double)sz / std::max(1, n) * 1.02 * n_reads) + 4096);
-        size_t ccap = 0; char* np = ob.p ? nullptr : outcache_take(want, &ccap);   // the buffer of the last call, if it was given back and is large enough
-        if (np) want = ccap; else np = (char*)realloc(ob.p, want);
+        // the buffer of the last call, if it was given back and is about large enough: the first guess is an estimate (+- 1 % from one call to the next), a parked buffer just
+        // below it would be thrown away for a fresh one (300 MB of page faults, ~25 ms a call on the calling thread's path), and a buffer that turns out short grows below anyway
+        size_t ccap = 0; char* np = ob.p ? nullptr : outcache_take(std::max(ob.len + sz + 1, want - want / 8), &ccap);
+        if (np) want = ccap; else { if (!ob.p) want += want / 16; np = (char*)realloc(ob.p, want); }
         if (!np) ob.failed = true; else { ob.p = np; ob.cap = want; }
       }
       if (!ob.failed) {
@@ -1727,6 +1731,7 @@ static int map_impl(gm_session* s, int n_reads, int read_len, const uint32_t* re
   const bool timeline = getenv("GM_TIMELINE") != nullptr;
   auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double tl0 = now_ms();
+  if (timeline) fprintf(stderr, "[timeline] before the first sub-batch: %.2f ms waiting for the device's turn, %.2f ms set-up\n", tl_turn - tl_in, tl0 - tl_turn);
   // Sub-batch i lives in set i & 1.  Its front is queued as early as the set allows: the first two at once, the front of i + 2 from inside the back of i -- behind pass 2
   // and the copy of the counters, in front of the wait for the result copies (pipeline_back's after_pass2; the device orders it behind event pev[.][9]).  Short fronts
   // (the bucket kernel on a small genome: 6 ms a sub-batch) then follow each other without the gap of a host round trip.
