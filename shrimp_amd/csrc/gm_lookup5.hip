@@ -254,7 +254,7 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
   // Colour space with few list entries per read-strand (50-colour reads on 3 Gbp: 17 k): the half-size shape -- tables of 2^19 + 2^16 bits (72 KB) and 512 threads.  The kernel
   // itself is slower that way (89 against 70 ms per 500 k reads), but it leaves half of a CU's LDS and 320 of a SIMD's 512 registers free, and k_pass2_cs_g4 (256 registers,
   // 15 KB of LDS a wave), which cannot run beside the full shape at all, then runs beside it: the step 132 -> 125 ms.  (Letter space: k_pass2_g4 fits beside the full shape.)
-  bool small_shape = false; (void)small_shape;
+  bool small_shape = false;
   if (!forced && ix.colour && NL <= 512 && !gm_tune("GM_K5_LSW") && !gm_tune("GM_K1_THREADS") && !(gm_tune("GM_K5_SMALL") && atoi(gm_tune("GM_K5_SMALL")) == 0)) {
     const double lam = entries * (double)((1u << ix.region_bits) + ix.region_overlap) / std::max(1.0, (double)ix.total_len);
     const double memb = 2.0 * entries * std::min(1.0, lam), late = 0.5 * entries * std::min(1.0, entries / (double)(32ull << 14));
@@ -329,7 +329,10 @@ int gm_lookup5_launch(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads
         hipFuncSetAttribute((const void*)k_lookup_v5<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
     configured = lds;
   }
-  int grid = std::min(2 * n_reads, half ? 2 * K.cus : K.cus);
+  // (the half-size shapes: two workgroups a CU.  For the colour-space shape that leaves 16 KB of a CU's LDS, so the colour-space pass 2 runs beside it on the CUs the lookup
+  // has not filled yet or has left already rather than on all of them -- but the lookup itself takes 7.1 instead of 11.5 ms per launch (66 k reads on average), and since pass 2 takes eight
+  // windows a wave the step is shorter that way: 190 -> 179 ms per 1 M 50-colour reads, tools/k5_shape_cfg4.sh; with the four-window pass 2 of round 3 it made no difference)
+  int grid = std::min(2 * n_reads, (half || small_shape) ? 2 * K.cus : K.cus);
   if (const char* e = gm_tune("GM_K5_GRID")) grid = std::max(1, std::min(2 * n_reads, atoi(e)));
   K5Args a;
   a.reads = d_reads; a.n_reads = n_reads; a.read_len = read_len; a.read_words = read_words; a.max_n_kmers = max_n_kmers; a.NL = NL;
