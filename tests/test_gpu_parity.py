@@ -719,7 +719,9 @@ def test_colour_space_sam_matches_reference_golden(gm, name):
 @pytest.mark.parametrize("env", [{"GM_SLAB_BITS": "18"}, {"GM_SLAB_BITS": "18", "GM_K1_V4": "1"}, {"GM_NO_BUCKETS": "1"}, {"GM_SLAB_BITS": "18", "GM_K1_V2": "1"},
                                  {"GM_SCAP": "256", "GM_SCAP2": "64"}, {"GM_SLAB_BITS": "18", "GM_K1_V5": "1"}, {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_LSW": "12"},
                                  {"GM_POST_SW_HOST": "1"},       # post_sw by the host routine instead of k_post_sw_cs
-                                 {"GM_P1_EARLY": "0"}],          # pass 1 without the early stop
+                                 {"GM_P1_EARLY": "0"},           # pass 1 without the early stop
+                                 {"GM_P2_G": "16"},              # pass 2 with four windows a wave and int carry rows (the default here: eight, int16_t)
+                                 {"GM_P2_G4": "0"}],             # pass 2 with one window a wave
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_colour_space_kernel_variants(gm, env):
     """every lookup kernel skips the first colour and reads strand 1 the colour-space way"""
