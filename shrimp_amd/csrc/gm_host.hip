@@ -304,7 +304,7 @@ struct DevSet {
   uint64_t* d_surv2 = nullptr; uint32_t* d_surv_cnt2 = nullptr;            // survivors after the exact isolation prune (K1b) = input of K2
   GmHit* d_hits = nullptr; uint16_t* d_perm = nullptr; uint32_t* d_hit_cnt = nullptr; unsigned long long* d_slots = nullptr;
   uint32_t* d_heavy_list = nullptr; uint32_t* d_heavy_cnt = nullptr;   // read-strands beyond the LDS tier of K2
-  int32_t* d_sel = nullptr; int32_t* d_sel_sidx = nullptr; uint32_t* d_sel_cnt = nullptr; uint32_t* d_sel_off = nullptr; uint32_t* d_work = nullptr; uint32_t* d_n_work = nullptr; uint32_t* d_p2_order = nullptr; uint32_t* d_p2_cls = nullptr;   // (colour space: pass 2's work items by kind, see k_p2cs_classify)
+  int32_t* d_sel = nullptr; int32_t* d_sel_sidx = nullptr; uint32_t* d_sel_cnt = nullptr; uint32_t* d_sel_off = nullptr; uint32_t* d_work = nullptr; uint32_t* d_n_work = nullptr; uint32_t* d_p2_order = nullptr; uint32_t* d_p2_cls = nullptr;   // (pass 2's work items by kind, see k_p2cs_classify)
   GmFullRes* d_res = nullptr; uint8_t* d_ops = nullptr; uint8_t* d_back = nullptr; size_t back_stride = 0;
   GmPostRes* d_post = nullptr; double* d_post_fw = nullptr; uint32_t* d_post_info = nullptr;   // colour space: post_sw on the device (gm_post.hip), its per-thread scratch
   // paired mode only: mate range of every window (by sorted position) and the "saved" mark (by hit slot)
@@ -519,7 +519,7 @@ static int alloc_buffers(gm_session* s, DevSet& D, int read_len, bool paired = f
   const size_t rcap = (size_t)B * D.rcap_per_read;
   GM_HIP(hipMalloc(&D.d_work, (size_t)B * GM_SEL_MAX * 4));
   GM_HIP(hipMalloc(&D.d_n_work, 4));
-  if (s->P.colour_space) { GM_HIP(hipMalloc(&D.d_p2_order, (size_t)B * GM_SEL_MAX * 4)); GM_HIP(hipMalloc(&D.d_p2_cls, 16)); }
+  GM_HIP(hipMalloc(&D.d_p2_order, (size_t)B * GM_SEL_MAX * 4)); GM_HIP(hipMalloc(&D.d_p2_cls, 16));
   GM_HIP(hipMalloc(&D.d_res, rcap * sizeof(GmFullRes)));
   GM_HIP(hipMalloc(&D.d_ops, rcap * D.ops_stride));
   if (s->P.colour_space && !getenv("GM_POST_SW_HOST")) {     // post_sw on the device (gm_post.hip): one record per result, forward values + column descriptors per thread
@@ -1466,7 +1466,7 @@ static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len,
       }
     } else
     rc = gm_launch_pass2(gm_view_of(dv, D), s->sc, D.d_reads, n, read_len, read_words, W, D.d_hits, D.d_perm, D.hcap, D.d_sel, D.d_sel_cnt, D.d_work, D.d_n_work,
-                         D.d_res, D.d_ops, D.ops_stride, D.d_back, D.back_stride, D.p2_grid, d_stats, q);
+                         D.d_res, D.d_ops, D.ops_stride, D.d_back, D.back_stride, D.p2_grid, d_stats, q, nullptr, 0, 0, D.d_p2_order, D.d_p2_cls);
     if (rc) return rc;
     GM_HIP(hipEventRecord(s->pev[k][7], q));
     { size_t cap;

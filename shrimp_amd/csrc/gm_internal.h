@@ -129,7 +129,8 @@ int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
                     int window_len, GmHit* d_hits, const uint16_t* d_perm, int hcap, const int32_t* d_sel, const uint32_t* d_sel_cnt,
                     const uint32_t* d_work, const uint32_t* d_n_work, GmFullRes* d_res, uint8_t* d_ops, int ops_stride,
                     uint8_t* d_back, size_t back_stride, int grid, unsigned long long* d_stats, hipStream_t stream,
-                    const int32_t* d_sel_sidx = nullptr, int input_strand = 0, int write_back = 0);
+                    const int32_t* d_sel_sidx = nullptr, int input_strand = 0, int write_back = 0,
+                    uint32_t* d_order = nullptr, uint32_t* d_cls_cnt = nullptr);        // the work items listed by kind (as many words as d_work), four counter words; without them: the one-window kernel
 
 // colour-space pass 2 (sw_full_cs per selected window); ops_stride bytes per result: backtrace bytes, then (genome << 4 | read) codes
 // colour-space post_sw on the device (gm_post.hip): constants = CsPostConsts of gm_host.hip (logs taken on the host), one record per pass-2 result

@@ -832,36 +832,52 @@ k_pass2(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_
 // Everything that is wave-uniform in full_sw_wave and differs between windows -- band box, window length, strand flag, "this group has work" -- is a
 // per-lane value here that is uniform inside a group.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int g4_shr1(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x111, 0xf, 0xf, false); }   // row_shr:1; lane 0 of each 16-lane row keeps `first`
+// Groups of G lanes (G = 16: four windows a wave, G = 8: eight).  row_shr:1 moves inside rows of 16 lanes, so with G = 8 the first lane of a row's second group is put right afterwards.
+template <int G> __device__ __forceinline__ int gn_shr1(int v, int first, int l) {
+  const int r = __builtin_amdgcn_update_dpp(first, v, 0x111, 0xf, 0xf, false);
+  return (G == 16) ? r : (l == 0 ? first : r);
+}
+// The carry rows (last row of a stripe, per column and state) as int, or as int16_t where the launch has checked that no score of a real path lies further than 16000 from 0: a
+// value of the "minus infinity" family (FS_NEG plus a few penalties) is stored as -32768 and goes on from there -- -32768 plus anything a path can collect stays below every
+// score of a real path, so such a state never wins against a real one, a state on the traced path never has one as its source, and the alignment is the same
+// (gm_launch_pass2 / gm_launch_pass2_cs decide; ref for the values: sw-full-ls.c:66-80,194-196, sw-full-cs.c:201-215,312-322).
+__device__ __forceinline__ int cs_carry_ld(int v) { return v; }
+__device__ __forceinline__ int cs_carry_ld(int16_t v) { return (int)v; }
+__device__ __forceinline__ void cs_carry_st(int& d, int v) { d = v; }
+__device__ __forceinline__ void cs_carry_st(int16_t& d, int v) { d = (int16_t)max(v, -32768); }
 
-template <bool LOCAL>
-__device__ FullOut full_sw_g4(const uint8_t* db, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc, bool revcmpl, bool act,
-                              long long rx, long long ry, int rl, int rw, uint8_t* back, int* carry, int lane) {
+// Round 4: G lanes a window (8 where the carry rows fit int16_t: a stripe of 8 rows takes band width + 14 steps against band width + 30 for 16 rows -- the chain north, west,
+// north, ... through a band is two steps a row whatever the lane count), the strand kind REV a template constant (a pass holds windows of one kind, see k_pass2_g4), and the cell
+// worked out by every lane with the band deciding afterwards what is kept (no branch around it).
+template <int G, typename CT, bool LOCAL, bool REV>
+__device__ FullOut full_sw_g4(const uint8_t* db, int glen, const uint8_t* qr, int rlen, const GmScoreDev& sc, bool act,
+                              long long rx, long long ry, int rl, int rw, uint8_t* back, CT* carry, int lane) {
+  constexpr bool revcmpl = REV;
   const int a_go = sc.a_go, a_ge = sc.a_ge, b_go = sc.b_go, b_ge = sc.b_ge;
   const int o_nw = LOCAL ? 0 : FS_NEG, o_n = LOCAL ? -b_go : FS_NEG, o_w = LOCAL ? -a_go : FS_NEG;   // a cell outside the band
   FullOut out; out.score = 0; out.max_i = 0; out.max_j = 0; out.e_nw = out.e_n = out.e_w = 0;
-  const int l = lane & 15;
-  const int n_stripes = (rlen + 15) >> 4;
-  int* cNW = carry; int* cN = carry + glen; int* cW = carry + 2 * glen;   // this group's carry rows: last row of the previous stripe, per column
+  const int l = lane & (G - 1);
+  const int n_stripes = (rlen + G - 1) / G;
+  CT* cNW = carry; CT* cN = carry + glen; CT* cW = carry + 2 * glen;   // this group's carry rows: last row of the previous stripe, per column
   int cw_lo = 1, cw_hi = 0;
   for (int s = 0; s < n_stripes; s++) {
-    const int r = s * 16 + l;
+    const int r = s * G + l;
     const bool row_ok = act && r < rlen;
     const int q = row_ok ? qr[r] : 0x7F;
     int x_min = 0, x_max = -1;
     if (row_ok) band_range(rx, ry, rl, rw, glen, r, &x_min, &x_max);
     int t_lo = INT_MAX, t_hi = -1;
     if (row_ok && x_max >= x_min) { t_lo = x_min + l; t_hi = x_max + l; }
-    for (int dd = 8; dd > 0; dd >>= 1) { t_lo = min(t_lo, __shfl_xor(t_lo, dd)); t_hi = max(t_hi, __shfl_xor(t_hi, dd)); }     // over the group
+    for (int dd = G / 2; dd > 0; dd >>= 1) { t_lo = min(t_lo, __shfl_xor(t_lo, dd)); t_hi = max(t_hi, __shfl_xor(t_hi, dd)); }     // over the group
     int nst = t_hi >= 0 ? t_hi - t_lo + 1 : 0, nmax = nst;
-    for (int dd = 32; dd >= 16; dd >>= 1) nmax = max(nmax, __shfl_xor(nmax, dd));                                             // over the four groups
+    for (int dd = 32; dd >= G; dd >>= 1) nmax = max(nmax, __shfl_xor(nmax, dd));                                                // over the groups
     nmax = __builtin_amdgcn_readfirstlane(nmax);
     int pw_nw = o_nw, pw_w = o_w;
     int d_nw = o_nw, d_n = o_n, d_w = o_w;
     int cur_nw = o_nw, cur_n = o_n, cur_w = o_w;
     if (l == 0) {
       if (s == 0) { d_nw = 0; d_n = -b_go; d_w = -a_go; }
-      else if (t_hi >= 0 && t_lo >= 1 && t_lo - 1 >= cw_lo && t_lo - 1 <= cw_hi) { d_nw = cNW[t_lo - 1]; d_n = cN[t_lo - 1]; d_w = cW[t_lo - 1]; }
+      else if (t_hi >= 0 && t_lo >= 1 && t_lo - 1 >= cw_lo && t_lo - 1 <= cw_hi) { d_nw = cs_carry_ld(cNW[t_lo - 1]); d_n = cs_carry_ld(cN[t_lo - 1]); d_w = cs_carry_ld(cW[t_lo - 1]); }
     }
     const bool more = (s + 1 < n_stripes);
     const bool last_row_lane = row_ok && (r == rlen - 1);
@@ -871,12 +887,12 @@ __device__ FullOut full_sw_g4(const uint8_t* db, int glen, const uint8_t* qr, in
       const int c = t - l;
       int in_nw, in_n, in_w;
       if (s == 0) { in_nw = 0; in_n = -b_go; in_w = -a_go; }
-      else { in_nw = o_nw; in_n = o_n; in_w = o_w; if (l == 0 && on && t >= cw_lo && t <= cw_hi) { in_nw = cNW[t]; in_n = cN[t]; in_w = cW[t]; } }
-      const int u_nw = g4_shr1(cur_nw, in_nw), u_n = g4_shr1(cur_n, in_n), u_w = g4_shr1(cur_w, in_w);   // cell_n = (r-1, c)
+      else { in_nw = o_nw; in_n = o_n; in_w = o_w; if (l == 0 && on && t >= cw_lo && t <= cw_hi) { in_nw = cs_carry_ld(cNW[t]); in_n = cs_carry_ld(cN[t]); in_w = cs_carry_ld(cW[t]); } }
+      const int u_nw = gn_shr1<G>(cur_nw, in_nw, l), u_n = gn_shr1<G>(cur_n, in_n, l), u_w = gn_shr1<G>(cur_w, in_w, l);   // cell_n = (r-1, c)
       const bool inband = on && row_ok && c >= x_min && c <= x_max;
-      int n_nw = o_nw, n_n = o_n, n_w = o_w;
-      if (inband) {
-        const int ms = (db[c] == q) ? sc.match : sc.mismatch;
+      int n_nw, n_n, n_w;
+      {
+        const int ms = (db[min(max(c, 0), glen - 1)] == q) ? sc.match : sc.mismatch;
         int tmp, b0, b1, b2, nul = 0;
         if (!revcmpl) {                                            // ref: sw-full-ls.c:264-278
           tmp = d_nw + ms; b0 = 0;
@@ -907,57 +923,96 @@ __device__ FullOut full_sw_g4(const uint8_t* db, int glen, const uint8_t* qr, in
         }
         if (LOCAL && tmp <= 0) { tmp = 0; nul |= 0x40; }
         n_w = tmp;
-        back[(size_t)r * glen + c] = (uint8_t)(0x80 | nul | b0 | (b1 << 2) | (b2 << 3));
-        if (LOCAL || last_row_lane) {                              // :359-368 leftmost strict maximum: of the last read row, or (local) of this lane's rows
+        if (inband) back[(size_t)r * glen + c] = (uint8_t)(0x80 | nul | b0 | (b1 << 2) | (b2 << 3));
+        if (inband && (LOCAL || last_row_lane)) {                  // :359-368 leftmost strict maximum: of the last read row, or (local) of this lane's rows
           int m = max(n_n, n_nw); m = max(m, n_w);
           if (m > out.score) { out.score = m; out.max_i = r; out.max_j = c; out.e_nw = n_nw; out.e_n = n_n; out.e_w = n_w; }
         }
       }
-      if (more && l == 15 && on && c >= 0 && c < glen) { cNW[c] = n_nw; cN[c] = n_n; cW[c] = n_w; }
+      if (!inband) { n_nw = o_nw; n_n = o_n; n_w = o_w; }
+      if (more && l == G - 1 && on && c >= 0 && c < glen) { cs_carry_st(cNW[c], n_nw); cs_carry_st(cN[c], n_n); cs_carry_st(cW[c], n_w); }
       d_nw = u_nw; d_n = u_n; d_w = u_w;
       pw_nw = n_nw; pw_w = n_w;
       cur_nw = n_nw; cur_n = n_n; cur_w = n_w;
     }
     cw_lo = 1; cw_hi = 0;
-    if (more && t_hi >= 0) { cw_lo = max(0, t_lo - 15); cw_hi = min(glen - 1, t_hi - 15); }
+    if (more && t_hi >= 0) { cw_lo = max(0, t_lo - (G - 1)); cw_hi = min(glen - 1, t_hi - (G - 1)); }
     if (more) __syncthreads();
   }
   // the group's result: from the last row's lane, or (local) from the lane whose row comes first among those with the largest score
-  const int gb = lane & 48;
-  int src = (rlen - 1) & 15;
+  const int gb = lane & (64 - G);
+  int src = (rlen - 1) & (G - 1);
   if (LOCAL) {
     int best = out.score;
-    for (int d = 8; d > 0; d >>= 1) best = max(best, __shfl_xor(best, d));
+    for (int d = G / 2; d > 0; d >>= 1) best = max(best, __shfl_xor(best, d));
     int row = (out.score == best) ? out.max_i : INT_MAX;
-    for (int d = 8; d > 0; d >>= 1) row = min(row, __shfl_xor(row, d));
-    src = (best > 0) ? (row & 15) : 0;
+    for (int d = G / 2; d > 0; d >>= 1) row = min(row, __shfl_xor(row, d));
+    src = (best > 0) ? (row & (G - 1)) : 0;
   }
   out.score = __shfl(out.score, gb | src); out.max_i = __shfl(out.max_i, gb | src); out.max_j = __shfl(out.max_j, gb | src);
   out.e_nw = __shfl(out.e_nw, gb | src); out.e_n = __shfl(out.e_n, gb | src); out.e_w = __shfl(out.e_w, gb | src);
   return out;
 }
 
-template <bool LOCAL>
+// The work items of a pass 2 (letter or colour space) listed by kind: forward-strand windows from the front of order[], reverse-strand ones (they take the mirrored tie rules, when
+// sc.tiebreak_rev) from its back; cnt[0] / cnt[1] count them, cnt[2] is the unit counter k_pass2_g4 / k_pass2_cs_g4 draw from (all three zeroed by the launch).  The order inside a
+// kind is whatever the atomics give: every result is stored under its work index, so the output does not depend on it.
+__global__ void __launch_bounds__(256) k_p2cs_classify(const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work_p, const int32_t* __restrict__ sel,
+                                                       int cs_flip, int tiebreak_rev, uint32_t* __restrict__ order, uint32_t* __restrict__ cnt) {
+  const uint32_t n_work = *n_work_p;
+  const int lane = threadIdx.x & 63;
+  for (uint32_t base = (blockIdx.x * 256u + threadIdx.x) & ~63u; base < n_work; base += gridDim.x * 256u) {
+    const uint32_t wi = base + (uint32_t)lane;
+    bool fw = false, rv = false;
+    if (wi < n_work) {
+      const uint32_t wk = work[wi];
+      const int id = sel[(size_t)(wk >> 6) * SEL_MAX + (wk & 63)];
+      rv = ((id >> 16) != cs_flip) && tiebreak_rev; fw = !rv;
+    }
+    const unsigned long long m_fw = __ballot(fw), m_rv = __ballot(rv);
+    uint32_t b_fw = 0, b_rv = 0;
+    if (lane == 0) { if (m_fw) b_fw = atomicAdd(&cnt[0], (uint32_t)__popcll(m_fw)); if (m_rv) b_rv = atomicAdd(&cnt[1], (uint32_t)__popcll(m_rv)); }
+    b_fw = (uint32_t)__shfl((int)b_fw, 0); b_rv = (uint32_t)__shfl((int)b_rv, 0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (fw) order[b_fw + (uint32_t)__popcll(m_fw & below)] = wi;
+    if (rv) order[n_work - 1u - (b_rv + (uint32_t)__popcll(m_rv & below))] = wi;
+  }
+}
+
+template <int G, typename CT, bool LOCAL>
 __global__ void __launch_bounds__(GM_WAVE)
 k_pass2_g4(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int n_reads, int read_len, int read_words,
            GmHit* __restrict__ hits, const uint16_t* __restrict__ perm, int hcap,
            const int32_t* __restrict__ sel, const int32_t* __restrict__ sel_sidx, int input_strand, int write_back,
            const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work_p,
            GmFullRes* __restrict__ res, uint8_t* __restrict__ ops, int ops_stride,
-           uint8_t* __restrict__ back_pool, size_t back_stride, int max_w, unsigned long long* __restrict__ stats) {
+           uint8_t* __restrict__ back_pool, size_t back_stride, int max_w, unsigned long long* __restrict__ stats,
+           const uint32_t* __restrict__ order, uint32_t* __restrict__ cls_cnt) {
   extern __shared__ __align__(16) uint8_t sm[];
-  const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
+  constexpr int NG = 64 / G;
+  const int lane = threadIdx.x, g = lane / G, l = lane & (G - 1);
   const int rl16 = (read_len + 15) & ~15, mw16 = (max_w + 15) & ~15;
-  uint8_t* qr_all = sm;                                          // four reads, four windows, four sets of carry rows
-  uint8_t* db_all = sm + 4 * rl16;
-  int* carry_all = (int*)(db_all + 4 * mw16);
-  const uint8_t* qr = qr_all + g * rl16; const uint8_t* db = db_all + g * mw16; int* carry = carry_all + g * 3 * max_w;
-  uint8_t* back = back_pool + ((size_t)blockIdx.x * 4 + g) * back_stride;
+  uint8_t* qr_all = sm;                                          // NG reads, NG windows, NG sets of carry rows
+  uint8_t* db_all = sm + NG * rl16;
+  CT* carry_all = (CT*)(db_all + NG * mw16);
+  const uint8_t* qr = qr_all + g * rl16; const uint8_t* db = db_all + g * mw16; CT* carry = carry_all + g * 3 * max_w;
+  uint8_t* back = back_pool + ((size_t)blockIdx.x * NG + g) * back_stride;
   const uint32_t n_work = *n_work_p;
   unsigned long long vcalls = 0, vcells = 0, fcalls = 0;
-  for (uint32_t base = blockIdx.x * 4u; base < n_work; base += gridDim.x * 4u) {
-    const uint32_t wi = base + (uint32_t)g;
-    const bool has = wi < n_work;
+  // A pass holds windows of one strand kind (the kind decides the tie rules of a cell, ref: sw-full-ls.c:264-347; as a per-lane value both variants of every update ran, half the
+  // lanes masked): k_p2cs_classify has listed the work items by kind -- forward ones from the front of order[], reverse ones from its back -- a pass is one unit of NG list entries
+  // of one kind, and the waves draw units from a counter until none is left.
+  const uint32_t n_fw = cls_cnt[0], n_rv = cls_cnt[1];
+  const uint32_t u_fw = (n_fw + NG - 1) / NG, u_all = u_fw + (n_rv + NG - 1) / NG;
+  for (;;) {
+    uint32_t u = 0;
+    if (lane == 0) u = atomicAdd(&cls_cnt[2], 1u);
+    u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+    if (u >= u_all) break;
+    const bool rev_u = u >= u_fw;                                  // (wave-uniform)
+    const uint32_t idx = (rev_u ? u - u_fw : u) * NG + (uint32_t)g;
+    const bool has = idx < (rev_u ? n_rv : n_fw);
+    const uint32_t wi = has ? (rev_u ? order[n_work - 1u - idx] : order[idx]) : 0u;
     const uint32_t wk = has ? work[wi] : 0u;
     const int rd = (int)(wk >> 6), k = (int)(wk & 63);
     const int id = has ? sel[(size_t)rd * SEL_MAX + k] : 0;
@@ -976,10 +1031,10 @@ k_pass2_g4(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int
     const uint64_t g0 = (uint64_t)ix.contig_off[cn] + h.g_off;
     const int rna_bits = ((ix.contig_rna && has && ix.contig_rna[cn]) ? 2 : 0) | ((ix.read_rna && has && ix.read_rna[rd]) ? 4 : 0);
     __syncthreads();
-    for (int gg = 0; gg < 4; gg++) {                             // the whole wave unpacks each group's read and window (wave-uniform arguments from the group's first lane)
-      if (!__shfl((int)has, gg * 16)) continue;
-      const int rd_g = __shfl(rd, gg * 16), wl_g = __shfl(w_len, gg * 16), gs_g = __builtin_amdgcn_readfirstlane(__shfl(gen_st | rna_bits, gg * 16));      // (bit 1: the contig is RNA, bit 2: the read is; wave-uniform)
-      const uint64_t g0_g = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(g0 >> 32), gg * 16) << 32) | (uint32_t)__shfl((int)(uint32_t)g0, gg * 16);
+    for (int gg = 0; gg < NG; gg++) {                            // the whole wave unpacks each group's read and window (wave-uniform arguments from the group's first lane)
+      if (!__shfl((int)has, gg * G)) continue;
+      const int rd_g = __shfl(rd, gg * G), wl_g = __shfl(w_len, gg * G), gs_g = __builtin_amdgcn_readfirstlane(__shfl(gen_st | rna_bits, gg * G));      // (bit 1: the contig is RNA, bit 2: the read is; wave-uniform)
+      const uint64_t g0_g = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(g0 >> 32), gg * G) << 32) | (uint32_t)__shfl((int)(uint32_t)g0, gg * G);
       load_read(reads + (size_t)rd_g * read_words, read_len, input_strand != 0, qr_all + gg * rl16, lane, (gs_g & 4) != 0);
       load_window(ix.genome, g0_g, wl_g, (gs_g & 1) != 0, db_all + gg * mw16, lane, (gs_g & 2) != 0);
     }
@@ -989,10 +1044,10 @@ k_pass2_g4(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int
     // re-score only where pass 1 took the value from its cache (see k_pass2)
     int sv = h.score_vector;
     const bool need = has && !(h.flags & 1u);
-    for (int gg = 0; gg < 4; gg++) {
-      if (!__shfl((int)need, gg * 16)) continue;
+    for (int gg = 0; gg < NG; gg++) {
+      if (!__shfl((int)need, gg * G)) continue;
       __syncthreads();
-      const int v = sw_vector_wave(db_all + gg * mw16, __shfl(w_len, gg * 16), qr_all + gg * rl16, read_len, sc, (int16_t*)carry_all, lane);
+      const int v = sw_vector_wave(db_all + gg * mw16, __shfl(w_len, gg * G), qr_all + gg * rl16, read_len, sc, (int16_t*)carry_all, lane);
       __syncthreads();
       if (g == gg) { sv = v; if (l == 0) { vcalls++; vcells += (unsigned long long)w_len * read_len; } }
     }
@@ -1015,16 +1070,17 @@ k_pass2_g4(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int
       if ((se - nw) % 2 != 0) se++;
       rl = (int)((se - nw) / 2 + 1);
       rx -= sc.anchor_width / 2; ry += sc.anchor_width / 2; rw += sc.anchor_width; }
-    const bool rvc = (gen_st != 0) && sc.tiebreak_rev;
     __syncthreads();
-    FullOut fo = full_sw_g4<LOCAL>(db, w_len, qr, read_len, sc, rvc, act, rx, ry, rl, rw, back, carry, lane);
+    FullOut fo = rev_u ? full_sw_g4<G, CT, LOCAL, true>(db, w_len, qr, read_len, sc, act, rx, ry, rl, rw, back, carry, lane)
+                       : full_sw_g4<G, CT, LOCAL, false>(db, w_len, qr, read_len, sc, act, rx, ry, rl, rw, back, carry, lane);
     __syncthreads();
     if (LOCAL) {
       // the filter's best local alignment leaves the anchor band: once more over the band the threshold allows (ref: sw-full-ls.c:395-398)
       const bool again = act && fo.score != sv;
       if (__any(again)) {
         threshold_band(w_len, read_len, sc.match, thresh, &rx, &ry, &rl, &rw);
-        const FullOut f2 = full_sw_g4<LOCAL>(db, w_len, qr, read_len, sc, rvc, again, rx, ry, rl, rw, back, carry, lane);
+        const FullOut f2 = rev_u ? full_sw_g4<G, CT, LOCAL, true>(db, w_len, qr, read_len, sc, again, rx, ry, rl, rw, back, carry, lane)
+                                 : full_sw_g4<G, CT, LOCAL, false>(db, w_len, qr, read_len, sc, again, rx, ry, rl, rw, back, carry, lane);
         if (again) fo = f2;
         __syncthreads();
       }
@@ -1069,7 +1125,7 @@ k_pass2_g4(GmIndexDev ix, GmScoreDev sc, const uint32_t* __restrict__ reads, int
     }
     if (has && l == 0) res[wi] = R;
   }
-  for (int d = 32; d >= 16; d >>= 1) { fcalls += __shfl_xor(fcalls, d); vcalls += __shfl_xor(vcalls, d); vcells += __shfl_xor(vcells, d); }
+  for (int d = 32; d >= G; d >>= 1) { fcalls += __shfl_xor(fcalls, d); vcalls += __shfl_xor(vcalls, d); vcells += __shfl_xor(vcells, d); }
   if (lane == 0) { GS_ADD(stats, GS_FULL_CALLS, fcalls); GS_ADD(stats, GS_VEC_CALLS, vcalls); GS_ADD(stats, GS_VEC_CELLS, vcells); }
 }
 
@@ -1249,7 +1305,7 @@ int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
                     int window_len, GmHit* d_hits, const uint16_t* d_perm, int hcap, const int32_t* d_sel, const uint32_t* d_sel_cnt,
                     const uint32_t* d_work, const uint32_t* d_n_work, GmFullRes* d_res, uint8_t* d_ops, int ops_stride,
                     uint8_t* d_back, size_t back_stride, int grid, unsigned long long* d_stats, hipStream_t stream,
-                    const int32_t* d_sel_sidx, int input_strand, int write_back) {
+                    const int32_t* d_sel_sidx, int input_strand, int write_back, uint32_t* d_order, uint32_t* d_cls_cnt) {
   if (n_reads == 0) return GM_OK;
   const int p2_ablate = gm_tune("GM_P2_ABLATE") ? atoi(gm_tune("GM_P2_ABLATE")) : 0;
   size_t lds = ((read_len + 15) & ~15) + ((window_len + 15) & ~15) + (size_t)window_len * 12 + 64;
@@ -1258,15 +1314,41 @@ int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
     d_hits, d_perm, hcap, d_sel, d_sel_sidx, input_strand, write_back, d_sel_cnt, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats, p2_ablate)
   // Back pointers in LDS (14 KB per wave at 100 bp) cap the CU at ten waves; in a per-wave global scratch (L2-resident) the CU runs at full
   // occupancy: measured 109 -> 37 ms per 1 M reads on the 3 Gbp workload.  The LDS form stays for comparison (GM_P2_BACK_LDS=1).
-  // Four windows per wave (k_pass2_g4) unless GM_P2_G4=0 asks for the one-window kernel; its wave owns four consecutive back-pointer scratches
-  const bool g4 = !(gm_tune("GM_P2_G4") && atoi(gm_tune("GM_P2_G4")) == 0) && !gm_tune("GM_P2_BACK_LDS") && grid >= 4;
+  // Four windows per wave (k_pass2_g4) unless GM_P2_G4=0 asks for the one-window kernel; its wave owns that many consecutive back-pointer scratches.  Eight windows (groups of
+  // 8 lanes, int16_t carry rows, see cs_carry_ld) were built and measured for letter space too (tuning builds: GM_P2_G=8): 18.9 against 15.8 ms per 1 M 100-base reads -- the
+  // letter-space cell is ~30 instructions, so the thirteen stripes' set-up and the carry traffic of every step weigh more than the steps saved; colour space (360 instructions
+  // a cell) takes eight.
+  const bool g4 = !(gm_tune("GM_P2_G4") && atoi(gm_tune("GM_P2_G4")) == 0) && !gm_tune("GM_P2_BACK_LDS") && grid >= 8 && d_order && d_cls_cnt;
   if (g4) {
-    const size_t lds4 = 4 * (size_t)((read_len + 15) & ~15) + 4 * (size_t)((window_len + 15) & ~15) + 4 * (size_t)window_len * 12 + 64;
-    const int grid4 = grid / 4;
-    if (sc.local) hipLaunchKernelGGL((k_pass2_g4<true>), dim3(grid4), dim3(GM_WAVE), lds4, stream, ix, sc, d_reads, n_reads, read_len, read_words, d_hits, d_perm, hcap, d_sel, d_sel_sidx,
-                                     input_strand, write_back, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats);
-    else hipLaunchKernelGGL((k_pass2_g4<false>), dim3(grid4), dim3(GM_WAVE), lds4, stream, ix, sc, d_reads, n_reads, read_len, read_words, d_hits, d_perm, hcap, d_sel, d_sel_sidx,
-                            input_strand, write_back, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats);
+    const size_t r16 = (size_t)((read_len + 15) & ~15), w16 = (size_t)((window_len + 15) & ~15);
+    const int big = std::max(std::max(std::abs(sc.match), std::abs(sc.mismatch)), std::max(std::max(std::abs(sc.a_ge), std::abs(sc.b_ge)), 1));
+    const long long reach = (long long)(read_len + window_len) * big + std::abs(sc.a_go) + std::abs(sc.b_go);      // no score on a path through the matrix lies further from 0
+    const size_t lds8 = 8 * r16 + 8 * w16 + 8 * (size_t)window_len * 3 * sizeof(int16_t) + 64;
+    const size_t lds4 = 4 * r16 + 4 * w16 + 4 * (size_t)window_len * 3 * sizeof(int) + 64;
+#ifdef GM_TUNING
+    const bool g8 = reach < 16000 && lds8 <= 64 * 1024 && gm_tune("GM_P2_G") && atoi(gm_tune("GM_P2_G")) == 8;
+#else
+    const bool g8 = false; (void)reach; (void)lds8;
+#endif
+    const size_t ldsn = g8 ? lds8 : lds4;
+    static GmLdsLimit lim4; size_t& conf4 = lim4.cur();
+    if (ldsn > 48 * 1024 && ldsn > conf4) {
+      GM_HIP(hipFuncSetAttribute((const void*)k_pass2_g4<16, int, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
+      GM_HIP(hipFuncSetAttribute((const void*)k_pass2_g4<16, int, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
+#ifdef GM_TUNING
+      GM_HIP(hipFuncSetAttribute((const void*)k_pass2_g4<8, int16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
+      GM_HIP(hipFuncSetAttribute((const void*)k_pass2_g4<8, int16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
+#endif
+      conf4 = ldsn; }
+    GM_HIP(hipMemsetAsync(d_cls_cnt, 0, 16, stream));
+    hipLaunchKernelGGL(k_p2cs_classify, dim3(512), dim3(256), 0, stream, d_work, d_n_work, d_sel, input_strand, sc.tiebreak_rev ? 1 : 0, d_order, d_cls_cnt);
+#define GM_P2_G4L(GG, CT, LOC) hipLaunchKernelGGL((k_pass2_g4<GG, CT, LOC>), dim3(grid / (64 / GG)), dim3(GM_WAVE), ldsn, stream, ix, sc, d_reads, n_reads, read_len, read_words, d_hits, d_perm, hcap, d_sel, d_sel_sidx, \
+                                     input_strand, write_back, d_work, d_n_work, d_res, d_ops, ops_stride, d_back, back_stride, window_len, d_stats, d_order, d_cls_cnt)
+#ifdef GM_TUNING
+    if (g8) { if (sc.local) GM_P2_G4L(8, int16_t, true); else GM_P2_G4L(8, int16_t, false); } else
+#endif
+    { if (sc.local) GM_P2_G4L(16, int, true); else GM_P2_G4L(16, int, false); }
+#undef GM_P2_G4L
   } else
   if (back_bytes <= 40 * 1024 && gm_tune("GM_P2_BACK_LDS")) {
     lds += back_bytes + 16;
@@ -1703,19 +1785,6 @@ k_pass2_cs(GmIndexDev ix, GmScoreDev sc, GmCsDev P, const uint32_t* __restrict__
 #ifdef P2CS_STAMPS
 __device__ unsigned long long p2cs_stamps[8];
 #endif
-// Groups of G lanes (G = 16: four windows a wave, G = 8: eight).  row_shr:1 moves inside rows of 16 lanes, so with G = 8 the first lane of a row's second group is put right afterwards.
-template <int G> __device__ __forceinline__ int gn_shr1(int v, int first, int l) {
-  const int r = __builtin_amdgcn_update_dpp(first, v, 0x111, 0xf, 0xf, false);
-  return (G == 16) ? r : (l == 0 ? first : r);
-}
-// The carry rows (last row of a stripe, per column and state) as int, or as int16_t where the launch has checked that no score of a real path lies further than 16000 from 0: a
-// value of the "minus infinity" family (FS_NEG plus a few penalties) is stored as -32768 and goes on from there -- -32768 plus anything a path can collect stays below every
-// score of a real path, so such a state never wins against a real one, a state on the traced path never has one as its source, and the alignment is the same
-// (gm_launch_pass2_cs decides; ref for the values: sw-full-cs.c:201-215,312-322).
-__device__ __forceinline__ int cs_carry_ld(int v) { return v; }
-__device__ __forceinline__ int cs_carry_ld(int16_t v) { return (int)v; }
-__device__ __forceinline__ void cs_carry_st(int& d, int v) { d = v; }
-__device__ __forceinline__ void cs_carry_st(int16_t& d, int v) { d = (int16_t)max(v, -32768); }
 template <int G, typename CT, bool REV, bool TABOO, bool LOCAL>
 __device__ CsBest full_sw_cs_g4(const uint8_t* db, int glen, const uint8_t* qr4, int qstride, int rlen, const GmCsDev& P, bool act,
                                 int rx, int ry, int rl, int rw, uint32_t* back, CT* carry, int lane, const int8_t* xrow) {
@@ -2068,31 +2137,6 @@ __device__ __forceinline__ void p2cs_g4_pass(const GmIndexDev& ix, const GmScore
 #ifdef P2CS_STAMPS
   if (lane == 0) atomicAdd(&p2cs_stamps[3], 1ull);
 #endif
-}
-
-// The work items of a colour-space pass 2 listed by kind: forward-strand windows from the front of order[], reverse-strand ones (they take the mirrored tie rules, when
-// sc.tiebreak_rev) from its back; cnt[0] / cnt[1] count them, cnt[2] is the unit counter k_pass2_cs_g4 draws from (all three zeroed by the launch).  The order inside a
-// kind is whatever the atomics give: every result is stored under its work index, so the output does not depend on it.
-__global__ void __launch_bounds__(256) k_p2cs_classify(const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work_p, const int32_t* __restrict__ sel,
-                                                       int cs_flip, int tiebreak_rev, uint32_t* __restrict__ order, uint32_t* __restrict__ cnt) {
-  const uint32_t n_work = *n_work_p;
-  const int lane = threadIdx.x & 63;
-  for (uint32_t base = (blockIdx.x * 256u + threadIdx.x) & ~63u; base < n_work; base += gridDim.x * 256u) {
-    const uint32_t wi = base + (uint32_t)lane;
-    bool fw = false, rv = false;
-    if (wi < n_work) {
-      const uint32_t wk = work[wi];
-      const int id = sel[(size_t)(wk >> 6) * SEL_MAX + (wk & 63)];
-      rv = ((id >> 16) != cs_flip) && tiebreak_rev; fw = !rv;
-    }
-    const unsigned long long m_fw = __ballot(fw), m_rv = __ballot(rv);
-    uint32_t b_fw = 0, b_rv = 0;
-    if (lane == 0) { if (m_fw) b_fw = atomicAdd(&cnt[0], (uint32_t)__popcll(m_fw)); if (m_rv) b_rv = atomicAdd(&cnt[1], (uint32_t)__popcll(m_rv)); }
-    b_fw = (uint32_t)__shfl((int)b_fw, 0); b_rv = (uint32_t)__shfl((int)b_rv, 0);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (fw) order[b_fw + (uint32_t)__popcll(m_fw & below)] = wi;
-    if (rv) order[n_work - 1u - (b_rv + (uint32_t)__popcll(m_rv & below))] = wi;
-  }
 }
 
 template <int G, typename CT, bool TABOO, bool LOCAL>

@@ -240,6 +240,7 @@ KERNEL_VARIANTS = [
     {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_HALF": "2", "GM_K5_ROUNDS": "4"},   # ... the variant without the Bloom bits, four parts
     {"GM_SLAB_BITS": "18", "GM_K1_V5": "1", "GM_K5_HALF": "1", "GM_K5_ROUNDS": "2", "GM_K5_CANDLIMIT": "40"},   # ... most read-strands fall back
     {"GM_P1_EARLY": "0"},                                    # pass 1 without the early stop of windows that cannot reach the threshold
+    {"GM_P2_G": "8"},                                        # pass 2 with eight windows a wave and int16_t carry rows (the default in letter space: four, int)
 ]
 
 
