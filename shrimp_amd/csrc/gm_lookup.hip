@@ -1480,6 +1480,7 @@ int gm_launch_lookup(const GmIndexDev& ix, const uint32_t* d_reads, int n_reads,
       if (lds_p > 48 * 1024 && lds_p <= 64 * 1024 && lds_p > cp) { GM_HIP(hipFuncSetAttribute((const void*)k_lookup_bkt_p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p)); cp = lds_p; } }
     int per_cu = 0;                                              // resident workgroups per CU (registers, waves, LDS): the persistent grid is exactly that
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_lookup_bkt_p, threads_b, lds_p) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (const char* e = gm_tune("GM_BKT_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < per_cu) { if (getenv("GM_TIMELINE")) fprintf(stderr, "[bkt] %d workgroups a CU fit, %d taken (%d threads, %zu B of LDS)\n", per_cu, v, threads_b, lds_p); per_cu = v; } }
     if (gm_tune("GM_BKT_V1") || threads_b > 512 || lds_p > 64 * 1024)
     hipLaunchKernelGGL(k_lookup_bkt, dim3(n_reads * 2), dim3(threads_b), lds_b, stream, ix, d_reads, n_reads, read_len, read_words,
                        max_n_kmers, NL, bm_words, d_surv, d_surv_cnt, scap, d_heavy_list, d_heavy_cnt, heavy_cap, d_stats, d_surv_seg);
