@@ -295,6 +295,7 @@ extern "C" int gm_index_alloc_like(gm_index_t** out, int device, const void* met
 struct DevSet {
   // capacities (grown on overflow)
   int cur_len = -1, scap = 0, scap2 = 0, hcap = 0, rcap_per_read = 8, ops_stride = 0, eff_batch = 0;
+  int post_threads = 0;                                      // threads of k_post_sw_cs (each owns a column scratch)
   int p2_grid = 0;                                           // pass-2 grid for this read length: the session's, capped so that the back-pointer scratch stays within 2 GB
   int8_t* d_xover = nullptr; bool xover_on = false;        // colour space with QVs: per-position crossover scores [B][read_len]
   uint8_t* d_qv = nullptr; uint8_t* d_post_bq = nullptr;   // ... and the QVs themselves (clamped to 0..250) for post_sw on the device, which leaves the base qualities in d_post_bq [rcap][read_len]
@@ -524,8 +525,11 @@ static int alloc_buffers(gm_session* s, DevSet& D, int read_len, bool paired = f
   GM_HIP(hipMalloc(&D.d_ops, rcap * D.ops_stride));
   if (s->P.colour_space && !getenv("GM_POST_SW_HOST")) {     // post_sw on the device (gm_post.hip): one record per result, forward values + column descriptors per thread
     GM_HIP(hipMalloc(&D.d_post, rcap * sizeof(GmPostRes)));
-    GM_HIP(hipMalloc(&D.d_post_fw, (size_t)GM_POST_THREADS * (size_t)(read_len + 1) * 17 * 8));
-    GM_HIP(hipMalloc(&D.d_post_info, (size_t)GM_POST_THREADS * (size_t)(read_len + 1) * 4));
+    D.post_threads = GM_POST_THREADS;
+    while (D.post_threads > 16384 && (size_t)D.post_threads * (size_t)(read_len + 1) * 140 > ((size_t)2 << 30)) D.post_threads /= 2;      // (long reads: at most 2 GB of scratch a buffer set)
+    if (const char* e = gm_tune("GM_POST_THREADS")) D.post_threads = std::max(4096, std::min(1 << 20, atoi(e) & ~63));
+    GM_HIP(hipMalloc(&D.d_post_fw, (size_t)D.post_threads * (size_t)(read_len + 1) * 17 * 8));
+    GM_HIP(hipMalloc(&D.d_post_info, (size_t)D.post_threads * (size_t)(read_len + 1) * 4));
     GM_HIP(hipMalloc(&D.d_post_bq, rcap * (size_t)read_len + 64));
   }
   D.p2_grid = (int)std::max<size_t>(256, std::min<size_t>((size_t)s->p2_grid, ((size_t)2 << 30) / D.back_stride));
@@ -1462,7 +1466,7 @@ static int pipeline_back(gm_session* s, int k, HostSlot& H, int n, int read_len,
         K.pr_del_open = c.pr_del_open; K.pr_del_extend = c.pr_del_extend; K.pr_ins_open = c.pr_ins_open; K.pr_ins_extend = c.pr_ins_extend;
         K.qv = H.post_bq_on ? D.d_qv : nullptr; K.qtab = H.post_bq_on ? s->d_qtab : nullptr; K.bq = H.post_bq_on ? D.d_post_bq : nullptr;
         rc = gm_launch_post_sw_cs(K, D.d_reads, D.d_initbp, read_len, read_words, D.d_res, D.d_ops, D.ops_stride, D.d_n_work, (uint32_t)rcap, D.d_post, D.d_post_fw, D.d_post_info,
-                                  GM_POST_THREADS, q);
+                                  D.post_threads, q);
       }
     } else
     rc = gm_launch_pass2(gm_view_of(dv, D), s->sc, D.d_reads, n, read_len, read_words, W, D.d_hits, D.d_perm, D.hcap, D.d_sel, D.d_sel_cnt, D.d_work, D.d_n_work,

@@ -139,7 +139,7 @@ struct GmCsPostDev { double let_m, let_x, col_m[2], col_x[2], pr_del_open, pr_de
                      // computes them (ref: sw-post.c:486-491), bq[result][read position] receives the base qualities (PHRED + 33, ref: :568-586); all null without QVs
                      const uint8_t* qv; const double* qtab; uint8_t* bq; };
 struct GmPostRes { double posterior; int32_t cs_match, cs_mismatch, cs_xover, valid; };
-#define GM_POST_THREADS 32768
+#define GM_POST_THREADS 131072      // k_post_sw_cs: one thread per pass-2 result, a column scratch each (6.9 KB at 50 colours); 32 768 threads were half a wave per SIMD for a kernel that waits on its scratch: cfg4 5.62 -> 6.00 M reads/s (tools/post_threads_cfg4.sh)
 int gm_launch_post_sw_cs(const GmCsPostDev& K, const uint32_t* d_reads, const uint8_t* d_initbp, int read_len, int read_words, const GmFullRes* d_res, uint8_t* d_ops,
                          int ops_stride, const uint32_t* d_n_work, uint32_t res_cap, GmPostRes* d_post, double* d_fw, uint32_t* d_info, int threads, hipStream_t stream);
 int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs_params9, const uint32_t* d_reads, const uint8_t* d_initbp, int n_reads,
