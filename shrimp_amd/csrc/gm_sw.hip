@@ -1321,8 +1321,10 @@ int gm_launch_pass2(const GmIndexDev& ix, const GmScoreDev& sc, const uint32_t* 
   const bool g4 = !(gm_tune("GM_P2_G4") && atoi(gm_tune("GM_P2_G4")) == 0) && !gm_tune("GM_P2_BACK_LDS") && grid >= 8 && d_order && d_cls_cnt;
   if (g4) {
     const size_t r16 = (size_t)((read_len + 15) & ~15), w16 = (size_t)((window_len + 15) & ~15);
-    const int big = std::max(std::max(std::abs(sc.match), std::abs(sc.mismatch)), std::max(std::max(std::abs(sc.a_ge), std::abs(sc.b_ge)), 1));
-    const long long reach = (long long)(read_len + window_len) * big + std::abs(sc.a_go) + std::abs(sc.b_go);      // no score on a path through the matrix lies further from 0
+    // no score on a path through the matrix lies further from 0 than `reach`: a path has at most read_len + window_len moves, and a move changes the score by a match, a
+    // mismatch or a gap's opening + extension at most
+    const int big = std::max(std::max(std::abs(sc.match), std::abs(sc.mismatch)), std::max(std::max(std::abs(sc.a_go) + std::abs(sc.a_ge), std::abs(sc.b_go) + std::abs(sc.b_ge)), 1));
+    const long long reach = (long long)(read_len + window_len) * big;
     const size_t lds8 = 8 * r16 + 8 * w16 + 8 * (size_t)window_len * 3 * sizeof(int16_t) + 64;
     const size_t lds4 = 4 * r16 + 4 * w16 + 4 * (size_t)window_len * 3 * sizeof(int) + 64;
 #ifdef GM_TUNING
@@ -2204,9 +2206,11 @@ int gm_launch_pass2_cs(const GmIndexDev& ix, const GmScoreDev& sc, const int* cs
   const bool want_g4 = !(gm_tune("GM_P2_G4") && atoi(gm_tune("GM_P2_G4")) == 0) && grid >= 8;
   if (want_g4 || sc.local) {
     const size_t q16 = (size_t)((read_len + 15) & ~15), w16 = (size_t)((window_len + 15) & ~15);
-    int big = std::max(std::max(std::abs(P.match), std::abs(P.mismatch)), std::max(std::abs(P.a_ge), std::abs(P.b_ge)));
-    big = std::max(big, std::max(std::abs(P.xover), d_xover ? 127 : 1));
-    const long long reach = (long long)(read_len + window_len) * big + std::abs(P.a_go) + std::abs(P.b_go);      // no score on a path through the matrix lies further from 0
+    // no score on a path through the matrix lies further from 0 than `reach`: a path has at most read_len + window_len moves, and a move changes the score by a match or a
+    // mismatch plus a crossover (per-position crossover scores lie in [2 x crossover_score, -1], ref: gmapper.c:532-544; an int8 row), or by a gap's opening + extension, at most
+    const int xmax = d_xover ? std::min(127, 2 * std::abs(P.xover)) : std::abs(P.xover);
+    const int big = std::max(std::max(std::abs(P.match), std::abs(P.mismatch)) + xmax, std::max(std::max(std::abs(P.a_go) + std::abs(P.a_ge), std::abs(P.b_go) + std::abs(P.b_ge)), 1));
+    const long long reach = (long long)(read_len + window_len) * big;
     const size_t lds8 = 8 * 5 * q16 + 8 * w16 + 8 * (size_t)window_len * 12 * sizeof(int16_t) + 64;
     const size_t lds4 = 4 * 5 * q16 + 4 * w16 + 4 * (size_t)window_len * 12 * sizeof(int) + 64;
     const bool g8 = reach < 16000 && lds8 <= 64 * 1024 && !(gm_tune("GM_P2_G") && atoi(gm_tune("GM_P2_G")) == 16);
