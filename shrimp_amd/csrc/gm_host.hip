@@ -1073,9 +1073,22 @@ struct Finalizer {
         cs_post_sw(csk, reads + (size_t)r->read_idx * read_words, (int)initbp[r->read_idx], r->read_start, h,
                    qual_ptr ? qual_ptr[r->read_idx] : nullptr, qual_delta);
         }
+      }
+      int ps;
+      if (!P.colour_space) {
+        // letter space: posterior and score are functions of (score, mapped read length) alone -- a small per-thread table of the values libm gave for the pairs seen
+        // last (reads of one length that map with 0, 1, 2 mismatches share a handful of pairs) instead of a pow and a log per mapping; the same doubles, so the same bytes
+        struct Memo { int score, rmapped; double a, b, post; int ps; };
+        static thread_local Memo memo[256];                        // (zero-initialised: a == 0 matches no session)
+        Memo& m = memo[((unsigned)r->score * 31u + (unsigned)r->rmapped) & 255u];
+        if (m.score != r->score || m.rmapped != r->rmapped || m.a != a || m.b != b) {
+          m.score = r->score; m.rmapped = r->rmapped; m.a = a; m.b = b;
+          m.post = pow(2.0, ((double)r->score - (double)r->rmapped * (2.0 * a + b)) / a);
+          m.ps = (int)rint(a * log(m.post) / log(2.0) + (double)r->rmapped * (2.0 * a + b));
+        }
+        h.posterior = m.post; ps = m.ps;
       } else
-      h.posterior = pow(2.0, ((double)r->score - (double)r->rmapped * (2.0 * a + b)) / a);
-      int ps = (int)rint(a * log(h.posterior) / log(2.0) + (double)r->rmapped * (2.0 * a + b));
+      ps = (int)rint(a * log(h.posterior) / log(2.0) + (double)r->rmapped * (2.0 * a + b));
       if (ps < 0) ps = 0;
       h.score_full = ps; h.pct_score_full = (1000 * 100 * ps) / r->score_max;
     }
